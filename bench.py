@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""Headline benchmark: waveform-windows/s of the volpick picking path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1: run directly)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the whole hot path over one batch of 256
+windows cut from a device-resident synthetic 3-component stream: window gather +
+annotate_batch_pre, model forward, blinding + overlap stacking, trigger/peak scan of the
+phase traces.  Workload = BASELINE.json configs[1]: PhaseNet volpick, batch 256, 3x3001, fp32
+(--model eqtransformer runs configs[2]).  Inputs are resident in HBM before the timed region.
+Multi-GPU: every rank owns whole station streams (weak scaling, no data-path collective); the
+weights are broadcast once from rank 0 over RCCL before the timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PEAK_FP32_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="phasenet", choices=["phasenet", "eqtransformer"])
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    import volpick_amd as va
+    from volpick_amd import _lib
+    from volpick_amd.distributed import broadcast_weights
+    from volpick_amd.synthetic import synthetic_stream_array
+
+    lib = _lib.load()
+    cls = va.PhaseNet if args.model == "phasenet" else va.EQTransformer
+    model = cls.from_pretrained("volpick")
+    model._max_batch = args.batch
+    t_bcast = 0.0
+    if world > 1:
+        if rank != 0:
+            model._weights = np.zeros_like(model._weights)  # only rank 0's copy is real
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        broadcast_weights(model, src=0)
+        torch.cuda.synchronize()
+        t_bcast = time.perf_counter() - t0
+    else:
+        model.cuda(dev)
+    h = model._handle
+
+    # ---- workload: one stream per rank that cuts into exactly `batch` windows -------------
+    T = model.in_samples
+    if args.model == "phasenet":
+        overlap, blinding = 1500, (0, 0)  # class defaults of the reference API
+    else:
+        overlap, blinding = 5500, (500, 500)  # README.md:57-58
+    n_samples = T + (T - overlap) * (args.batch - 1)
+    data, _, _ = synthetic_stream_array(n_samples, seed=1002 + rank)
+    x = torch.from_numpy(data).to(dev)
+    out = torch.empty((3, n_samples), dtype=torch.float32, device=dev)
+    thr = {lab: model._threshold({}, lab) for lab in model.labels if lab not in ("N", "Detection")}
+    thr_det = model._threshold({}, "detection")
+    cap = 4096
+    on, off, peak = (C.c_int64 * cap)(), (C.c_int64 * cap)(), (C.c_int64 * cap)()
+    val = (C.c_float * cap)()
+    found = C.c_int()
+    fv, lv, nw = C.c_int64(), C.c_int64(), C.c_int64()
+
+    def step():
+        _lib.check(lib.vp_annotate(h, C.c_void_p(x.data_ptr()), _lib.VP_MEM_DEVICE, n_samples, overlap, blinding[0],
+                                   blinding[1], _lib.VP_STACK_AVG, args.batch, C.c_void_p(out.data_ptr()),
+                                   _lib.VP_MEM_DEVICE, C.byref(fv), C.byref(lv), C.byref(nw)), "vp_annotate")
+        n_picks = 0
+        for i, lab in enumerate(model.labels):
+            if lab == "N":
+                continue
+            if lab == "Detection":
+                t_on = thr_det
+                t_off = t_on / 2
+            else:
+                t_on = t_off = thr[lab]
+            row = out[i, fv.value : lv.value + 1]
+            _lib.check(lib.vp_pick(h, C.c_void_p(row.data_ptr()), _lib.VP_MEM_DEVICE, row.numel(), t_on, t_off, on,
+                                   off, peak, val, cap, C.byref(found)), "vp_pick")
+            n_picks += found.value
+        return n_picks
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        n_picks = step()
+    assert nw.value == args.batch, (nw.value, args.batch)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_picks = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    windows = args.batch * args.steps * world
+    value = windows / dt
+
+    # ---- per-kernel HIP-event timing on the handle's stream -> roofline of the dominant kernel
+    n_steps = lib.vp_step_count(h)
+    ms = (C.c_float * n_steps)()
+    _lib.check(lib.vp_profile_steps(h, args.batch, 20, ms, n_steps), "vp_profile_steps")
+    kernels = []
+    for i in range(n_steps):
+        name, fl = C.c_char_p(), C.c_double()
+        lib.vp_step_info(h, i, C.byref(name), C.byref(fl))
+        kernels.append({"name": name.value.decode(), "ms": float(ms[i]), "flop_per_window": fl.value})
+    fwd_ms = sum(k["ms"] for k in kernels)
+    dom = max(kernels, key=lambda k: k["ms"])
+    dom_tflops = dom["flop_per_window"] * args.batch / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+    flop_w = lib.vp_flops_per_window(h)
+    stage = (C.c_float * 4)()
+    total_ms = C.c_float()
+    lib.vp_last_timing(h, C.byref(total_ms), stage)
+
+    result = {
+        "metric": "waveform-windows/sec",
+        "value": value,
+        "unit": "windows/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{model.name} volpick, batch={args.batch}, 3x{T} windows, fp32, overlap={overlap}, "
+                        f"blinding={list(blinding)}, stacking=avg, full path A2-A8 per step",
+            "batch": args.batch,
+            "in_samples": T,
+            "parallelism": f"stream-sharded x{world}, weights broadcast once (RCCL)",
+        },
+        "roofline": {
+            "bound": "mfma",
+            "kernel": f"conv_mfma_kernel<{dom['name']}>",
+            "achieved": dom_tflops,
+            "peak": PEAK_FP32_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": dom_tflops / PEAK_FP32_TFLOPS,
+            "traffic": None,
+            "kernel_ms": dom["ms"],
+        },
+        "forward": {
+            "flop_per_window": flop_w,
+            "sum_kernel_ms": fwd_ms,
+            "tflops_kernels": flop_w * args.batch / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0,
+            "fp32_frac_end_to_end": value / world * flop_w / (PEAK_FP32_TFLOPS * 1e12),
+            "hbm_frac_compulsory": value / world * (2 * 3 * T * 4) / (PEAK_HBM_GBS * 1e9),
+            "stage_ms_last_step": {"forward": stage[1], "stack": stage[2], "pick_last": stage[3]},
+            "picks_per_step": n_picks,
+            "kernels": kernels,
+        },
+        "weight_broadcast_s": t_bcast,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.model, data, overlap, blinding, args.batch, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(model_name, data, overlap, blinding, batch, budget_s):
+    """The CPU oracle (torch-CPU restatement of the reference path, kind "port") timed on this
+    host's cores over a bounded prefix of the same stream."""
+    import torch
+
+    from oracle import pipeline as OP
+    from oracle.models import load_pretrained
+
+    net = load_pretrained(model_name)
+    cores = torch.get_num_threads()
+    T = net.in_samples
+    step = T - overlap
+    done, t_used = 0, 0.0
+    chunk = 64
+    # warm-up (thread pools, oneDNN primitives)
+    OP.classify_array(net, data[:, : T + step * 7], overlap=overlap, blinding=blinding, batch_size=batch)
+    while t_used < budget_s and done < batch * 8:
+        n = T + step * (chunk - 1)
+        seg = data[:, :n]
+        t0 = time.perf_counter()
+        OP.classify_array(net, seg, overlap=overlap, blinding=blinding, batch_size=batch)
+        t_used += time.perf_counter() - t0
+        done += chunk
+    return {
+        "value": done / t_used,
+        "unit": "windows/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{done} windows ({done // chunk} x {chunk}-window prefix of the bench stream) through "
+                  f"oracle.pipeline.classify_array, torch {torch.__version__} CPU, {cores} threads",
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+/*
+ * volpick_hip.h — C ABI of libvolpick_hip.so, the MI355X (gfx950) implementation of
+ * volpick's sliding-window phase-picking inference path.
+ *
+ * The reference reaches this path through a Python object API, not an FFI
+ * (SURVEY.md §8b): seisbench.models.{PhaseNet,EQTransformer} instances created with
+ * from_pretrained("volpick") and driven by classify()/annotate()/__call__
+ * (/root/reference README.md:46-66, Final_models/demo.ipynb:300-301,359-360,397-398,
+ * volpick/model/eval_taks0.py:58-89).  Each entry point below names the reference
+ * interface it replaces.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions: every function returns 0 on success or a negative vp_status;
+ * vp_last_error() returns a thread-local message.  Handles are opaque; one handle is
+ * bound to one HIP device and one HIP stream and is used from one thread at a time.
+ * "dev" pointers are HIP device pointers on the handle's device, "host" pointers are
+ * ordinary host memory.  All floats are IEEE fp32.
+ */
+#ifndef VOLPICK_HIP_H
+#define VOLPICK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vp_handle vp_handle;
+
+typedef enum {
+  VP_OK = 0,
+  VP_ERR_INVALID = -1,   /* bad argument */
+  VP_ERR_HIP = -2,       /* a HIP runtime call failed */
+  VP_ERR_NOMEM = -3,     /* workspace too small / allocation failed */
+  VP_ERR_UNSUPPORTED = -4
+} vp_status;
+
+enum { VP_MODEL_PHASENET = 0, VP_MODEL_EQTRANSFORMER = 1 };
+enum { VP_NORM_PEAK = 0, VP_NORM_STD = 1 };
+enum { VP_STACK_AVG = 0, VP_STACK_MAX = 1 };
+enum { VP_MEM_HOST = 0, VP_MEM_DEVICE = 1 };
+
+/* Constants the reference does not pin; defaults are the
+ * published SeisBench values, filled in by vp_default_config(). */
+typedef struct {
+  int32_t norm;               /* VP_NORM_*  — model_args.norm, Final_models/ ** /volpick.json.v1:6 */
+  int32_t norm_amp_per_comp;  /* EQT only: 1 = per-channel amplitude, 0 = one amplitude over all channels */
+  int32_t max_batch;          /* windows the workspace is sized for per forward pass */
+  float bn_eps;               /* BatchNorm eps, folded into the conv weights at load time */
+  float attention_eps;        /* EQT additive attention denominator eps */
+  float layernorm_eps;        /* EQT LayerNormalization eps */
+  float norm_eps;             /* x / (amp + norm_eps) */
+  int32_t taper_samples;      /* EQT half-cosine taper length (0 for PhaseNet) */
+  int32_t reserved[8];
+} vp_config;
+
+/* Fills cfg with the defaults for model_kind. */
+int vp_default_config(int model_kind, vp_config* cfg);
+
+/* Number of fp32 values vp_create expects in `weights` for model_kind, and the canonical
+ * tensor order: the state-dict order of Final_models/ ** / *.pt.v1 without the
+ * num_batches_tracked entries.  vp_param_name/vp_param_size
+ * enumerate it (index 0..vp_param_count-1). */
+size_t vp_weight_count(int model_kind);
+int vp_param_count(int model_kind);
+const char* vp_param_name(int model_kind, int index);
+size_t vp_param_size(int model_kind, int index);
+
+/* Replaces sbm.<Model>.from_pretrained(name) + model.cuda()  (README.md:46-47,
+ * demo.ipynb:224-227): builds the device plan (BN folding, MFMA fragment packing),
+ * uploads it and allocates the workspace.  weights_mem says where `weights` lives
+ * (VP_MEM_DEVICE after vp_bcast-style distribution). */
+int vp_create(int device_id, int model_kind, const float* weights, size_t n_floats, int weights_mem,
+              const vp_config* cfg, vp_handle** out);
+int vp_destroy(vp_handle* h);
+
+/* Geometry of the model behind the handle. */
+int vp_in_samples(const vp_handle* h);   /* 3001 (PhaseNet) / 6000 (EQTransformer) */
+int vp_n_outputs(const vp_handle* h);    /* 3: PhaseNet (P,S,N in `phases` order) / EQT (Detection,P,S) */
+
+/* Replaces model(x) under torch.no_grad()/model.eval() on a (B,3,T) float32 tensor
+ * (volpick/model/eval_taks0.py:58-61,69,86).  x: B*3*T, y: B*n_out*T, both in the memory
+ * space x_mem/y_mem.  preprocess != 0 additionally applies annotate_batch_pre
+ * (demean + amplitude normalisation [+ taper]) to each window first.
+ * B may exceed max_batch; it is processed in chunks. */
+int vp_forward(vp_handle* h, const float* x, int x_mem, int B, int preprocess, float* y, int y_mem);
+
+/* Replaces WaveformModel.annotate on one station block (call
+ * stack §3.1): windows of in_samples at stride in_samples-overlap plus one tail window,
+ * annotate_batch_pre, forward, NaN blinding, overlap stacking (avg / max).
+ * stream: 3*N samples, rows in component_order.  out: n_out*N, NaN where no un-blinded
+ * window covers a sample.  first_valid/last_valid (may be NULL): the NaN-trimmed range
+ * [first_valid, last_valid] of output row 0; first_valid = -1 if nothing is valid.
+ * Returns the number of windows in *n_windows (may be NULL).  N < in_samples yields an
+ * all-NaN output and 0 windows (the reference only warns). */
+int vp_annotate(vp_handle* h, const float* stream, int stream_mem, int64_t N, int overlap, int blind_l,
+                int blind_r, int stacking, int batch, float* out, int out_mem, int64_t* first_valid,
+                int64_t* last_valid, int64_t* n_windows);
+
+/* Replaces obspy trigger_onset + per-trigger max/argmax as used by
+ * picks_from_annotations / detections_from_annotations and by the reference's own
+ * get_picks_from_prob (volpick/model/eval_taks0.py:46-56).  trace: n samples (may hold
+ * NaN).  A trigger opens at the first sample > thr_on and closes at the last sample of
+ * the run of samples > thr_off.  Writes up to cap triggers; *n_found is the total. */
+int vp_pick(vp_handle* h, const float* trace, int trace_mem, int64_t n, float thr_on, float thr_off,
+            int64_t* on, int64_t* off, int64_t* peak, float* value, int cap, int* n_found);
+
+/* Host-only variant of vp_pick for traces already in host memory (no handle, no GPU). */
+int vp_pick_host(const float* trace, int64_t n, float thr_on, float thr_off, int64_t* on, int64_t* off,
+                 int64_t* peak, float* value, int cap, int* n_found);
+
+/* Window start rule of the reference.  Writes up to cap starts,
+ * returns the count (0 if N < in_samples), negative on bad arguments. */
+int64_t vp_window_starts(int64_t N, int in_samples, int overlap, int64_t* starts, int64_t cap);
+
+/* Timing of the last vp_forward / vp_annotate on this handle, measured with HIP events on
+ * the handle's stream: total milliseconds and the per-stage split
+ * (0 preprocess, 1 model forward, 2 blinding+stacking, 3 pick scan). */
+int vp_last_timing(const vp_handle* h, float* total_ms, float stage_ms[4]);
+
+/* The handle's HIP stream (hipStream_t) for callers that want to order their own work. */
+void* vp_stream(const vp_handle* h);
+int vp_synchronize(vp_handle* h);
+
+/* Introspection for bench.py: the forward pass is a fixed list of kernel launches
+ * ("steps").  vp_step_info gives a step's name and its ALGORITHMIC flop count per window
+ * (2*MAC of the layer it implements, not the padded MFMA work); vp_flops_per_window is
+ * their sum.  vp_profile_steps runs each launch `iters` times on B windows and reports its
+ * mean duration in ms, measured with HIP events on the handle's stream. */
+int vp_step_count(const vp_handle* h);
+int vp_step_info(const vp_handle* h, int index, const char** name, double* flops_per_window);
+double vp_flops_per_window(const vp_handle* h);
+int vp_profile_steps(vp_handle* h, int B, int iters, float* step_ms, int cap);
+
+/* Host-only (no GPU): plans the model and returns conv layer `conv_index`'s geometry
+ * (13 ints: cin1,cin2,cout,P,taps,sn,in_off,out_off,waves_m,waves_n,nw,relu,epi), packed
+ * MFMA A-fragments and folded bias.  Returns the fragment float count, or -(1000 + number
+ * of conv layers) when conv_index is out of range.  Used by the CPU tests of BN folding and
+ * fragment packing. */
+int vp_debug_plan_conv(int model_kind, const float* weights, size_t n_floats, const vp_config* cfg,
+                       int conv_index, int* geom13, float* afrag, size_t afrag_cap, float* bias, size_t bias_cap,
+                       const char** name, int* cols, int* l_out);
+
+/* Debug: number of intermediate activation tensors of the last forward pass and a copy of
+ * one of them as a dense (B, C, L) host array (used by the layer-by-layer parity tests). */
+int vp_debug_tensor_count(const vp_handle* h);
+int vp_debug_tensor_info(const vp_handle* h, int index, const char** name, int* channels, int* length);
+int vp_debug_tensor_read(vp_handle* h, int index, int B, float* host_out);
+
+const char* vp_last_error(void);
+const char* vp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOLPICK_HIP_H */

@@ -1,0 +1,139 @@
+"""GPU parity tests for the PhaseNet path: HIP (through the C ABI) vs the CPU oracle.
+Tolerance: 1e-4 absolute on probabilities (BASELINE.json north_star), fp32."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipeline as OP
+from oracle.models import load_pretrained
+from tests.gpu_util import debug_tensors
+from volpick_amd import PhaseNet
+from volpick_amd.synthetic import synthetic_stream_array, synthetic_windows
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return load_pretrained("phasenet")
+
+
+@pytest.fixture(scope="module")
+def model():
+    return PhaseNet.from_pretrained("volpick").cuda()
+
+
+def _oracle_acts(net, x):
+    acts = {}
+    hs = [m.register_forward_hook(lambda mod, i, o, n=n: acts.__setitem__(n, o.detach())) for n, m in
+          net.named_modules() if n]
+    with torch.no_grad():
+        y = net(x)
+    for h in hs:
+        h.remove()
+    return y, acts
+
+
+def test_layers_match_oracle(model, oracle):
+    x = synthetic_windows(3, 3001, seed=5)
+    xn = OP.batch_pre(oracle, torch.from_numpy(x))
+    y = model(xn).cpu().numpy()
+    yo, acts = _oracle_acts(oracle, xn)
+    t = debug_tensors(model, 3)
+    relu = lambda a: torch.relu(a).numpy()
+    exp = {"input": xn.numpy(), "inc": relu(acts["in_bn"])}
+    for i in range(5):
+        exp[f"down{i}.same"] = relu(acts[f"down_branch.{i}.1"])
+        if i < 4:
+            exp[f"down{i}.down"] = relu(acts[f"down_branch.{i}.3"])
+    for j in range(4):
+        full = relu(acts[f"up_branch.{j}.1"])[:, :, 1:-2]
+        L = exp[f"down{3 - j}.same"].shape[2]
+        off = (full.shape[2] - L) // 2
+        exp[f"up{j}.convT"] = full[:, :, off:off + L]
+        if j < 3:
+            exp[f"up{j}.same"] = relu(acts[f"up_branch.{j}.3"])
+    report = []
+    for name, want in exp.items():
+        got = t[name]
+        err = float(np.abs(got - want).max())
+        report.append((name, err, float(np.abs(want).max())))
+    print("\n".join(f"{n:14s} max|diff| {e:.3e}  (max|ref| {m:.3e})" for n, e, m in report))
+    for n, e, m in report:
+        assert e <= 2e-4 * max(1.0, m), (n, e)
+    assert np.abs(y - yo.numpy()).max() < TOL
+
+
+@pytest.mark.parametrize("B", [1, 5, 256, 300])
+def test_forward_parity(model, oracle, B):
+    x = synthetic_windows(B, 3001, seed=100 + B)
+    xn = OP.batch_pre(oracle, torch.from_numpy(x))
+    with torch.no_grad():
+        want = oracle(xn).numpy()
+    got_host = model(xn).numpy()  # host tensor in -> host tensor out
+    got_dev = model(xn.cuda()).cpu().numpy()
+    assert np.abs(got_host - want).max() < TOL
+    assert np.array_equal(got_host, got_dev)
+    assert np.abs(got_host.sum(1) - 1).max() < 1e-5  # softmax over channels
+
+
+def test_preprocess_matches_annotate_batch_pre(model, oracle):
+    x = synthetic_windows(7, 3001, seed=9)
+    x[2] += 1234.5  # DC offset
+    want = OP.batch_pre(oracle, torch.from_numpy(x)).numpy()
+    model._forward_raw(x, preprocess=True)
+    got = debug_tensors(model, 7)["input"]
+    assert np.abs(got - want).max() < 2e-5
+
+
+@pytest.mark.parametrize("overlap,blinding,stacking", [(1500, (0, 0), "avg"), (2500, (500, 500), "avg"),
+                                                       (2000, (250, 100), "max"), (0, (0, 0), "avg")])
+def test_annotate_parity(model, oracle, overlap, blinding, stacking):
+    data, _, _ = synthetic_stream_array(60_000, seed=1001, n_events=6)
+    want = OP.annotate_array(oracle, data, overlap=overlap, blinding=blinding, stacking=stacking)
+    args = model._argdict(dict(overlap=overlap, blinding=blinding, stacking=stacking))
+    out, fv, lv, nw = model._annotate_block(data, args)
+    out = out.cpu().numpy()
+    assert nw == len(OP.window_starts(60_000, 3001, overlap))
+    for i, (label, off, tr) in enumerate(want):
+        assert off == fv and len(tr) == lv - fv + 1
+        got = out[i, fv:lv + 1]
+        assert np.array_equal(np.isnan(got), np.isnan(tr))
+        assert np.nanmax(np.abs(got - tr)) < TOL
+    assert np.isnan(out[:, :fv]).all() and np.isnan(out[:, lv + 1:]).all()
+
+
+def test_classify_picks_match_oracle(model, oracle):
+    from volpick_amd import Stream, Trace, UTCDateTime
+
+    data, p_on, s_on = synthetic_stream_array(60_000, seed=1001, n_events=6)
+    t0 = UTCDateTime("2020-01-01T00:00:00")
+    st = Stream([Trace(data[i], dict(network="XX", station="SYN", location="", channel=f"HH{c}", starttime=t0,
+                                     sampling_rate=100.0)) for i, c in enumerate("ZNE")])
+    res = model.classify(st, batch_size=256)
+    want = OP.classify_array(oracle, data)
+    assert len(res.picks) == len(want["picks"]) >= 10
+    for p, (ph, on, off, pk, v) in zip(res.picks, want["picks"]):
+        assert p.phase == ph and p.trace_id == "XX.SYN."
+        assert abs((p.peak_time - t0) * 100 - pk) <= 1
+        assert abs((p.start_time - t0) * 100 - on) <= 1 and abs((p.end_time - t0) * 100 - off) <= 1
+        assert abs(p.peak_value - v) < TOL
+    ann = model.annotate(st)
+    assert [tr.stats.channel for tr in ann] == ["PhaseNet_P", "PhaseNet_S", "PhaseNet_N"]
+
+
+def test_short_and_edge_inputs(model):
+    from volpick_amd import Stream, Trace
+
+    short = np.zeros((3, 2000), np.float32)
+    st = Stream([Trace(short[i], dict(station="A", channel=f"HH{c}", sampling_rate=100.0)) for i, c in enumerate("ZNE")])
+    with pytest.warns(UserWarning):
+        assert len(model.annotate(st)) == 0
+    assert len(model.classify(Stream()).picks) == 0
+    exact, _, _ = synthetic_stream_array(3001, seed=3, n_events=1)  # exactly one window, no tail
+    args = model._argdict({})
+    out, fv, lv, nw = model._annotate_block(exact, args)
+    assert (nw, fv, lv) == (1, 0, 3000)
+    with pytest.raises(ValueError):
+        model.annotate(st, overlap=3001)

@@ -1,0 +1,114 @@
+"""ctypes binding of libvolpick_hip.so (include/volpick_hip.h).
+
+The library is the product: there is no Python/torch fallback for any stage of
+the path.  If it is missing, :func:`load` raises with the build command.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("VOLPICK_HIP_LIB", _HERE / "libvolpick_hip.so"))
+
+VP_MODEL_PHASENET, VP_MODEL_EQTRANSFORMER = 0, 1
+VP_NORM_PEAK, VP_NORM_STD = 0, 1
+VP_STACK_AVG, VP_STACK_MAX = 0, 1
+VP_MEM_HOST, VP_MEM_DEVICE = 0, 1
+
+
+class VpConfig(C.Structure):
+    _fields_ = [
+        ("norm", C.c_int32),
+        ("norm_amp_per_comp", C.c_int32),
+        ("max_batch", C.c_int32),
+        ("bn_eps", C.c_float),
+        ("attention_eps", C.c_float),
+        ("layernorm_eps", C.c_float),
+        ("norm_eps", C.c_float),
+        ("taper_samples", C.c_int32),
+        ("reserved", C.c_int32 * 8),
+    ]
+
+
+class VolpickHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol include/volpick_hip.h declares: (restype, argtypes)
+_FP = C.POINTER(C.c_float)
+_I64P = C.POINTER(C.c_int64)
+_H = C.c_void_p
+SIGNATURES = {
+    "vp_default_config": (C.c_int, [C.c_int, C.POINTER(VpConfig)]),
+    "vp_weight_count": (C.c_size_t, [C.c_int]),
+    "vp_param_count": (C.c_int, [C.c_int]),
+    "vp_param_name": (C.c_char_p, [C.c_int, C.c_int]),
+    "vp_param_size": (C.c_size_t, [C.c_int, C.c_int]),
+    "vp_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(VpConfig), C.POINTER(_H)]),
+    "vp_destroy": (C.c_int, [_H]),
+    "vp_in_samples": (C.c_int, [_H]),
+    "vp_n_outputs": (C.c_int, [_H]),
+    "vp_forward": (C.c_int, [_H, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "vp_annotate": (
+        C.c_int,
+        [_H, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+         _I64P, _I64P, _I64P],
+    ),
+    "vp_pick": (
+        C.c_int,
+        [_H, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, _I64P, _I64P, _I64P, _FP, C.c_int,
+         C.POINTER(C.c_int)],
+    ),
+    "vp_pick_host": (
+        C.c_int,
+        [C.c_void_p, C.c_int64, C.c_float, C.c_float, _I64P, _I64P, _I64P, _FP, C.c_int, C.POINTER(C.c_int)],
+    ),
+    "vp_window_starts": (C.c_int64, [C.c_int64, C.c_int, C.c_int, _I64P, C.c_int64]),
+    "vp_last_timing": (C.c_int, [_H, _FP, _FP]),
+    "vp_stream": (C.c_void_p, [_H]),
+    "vp_synchronize": (C.c_int, [_H]),
+    "vp_step_count": (C.c_int, [_H]),
+    "vp_step_info": (C.c_int, [_H, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double)]),
+    "vp_flops_per_window": (C.c_double, [_H]),
+    "vp_profile_steps": (C.c_int, [_H, C.c_int, C.c_int, _FP, C.c_int]),
+    "vp_debug_tensor_count": (C.c_int, [_H]),
+    "vp_debug_tensor_info": (C.c_int, [_H, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vp_debug_tensor_read": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
+    "vp_debug_plan_conv": (
+        C.c_int,
+        [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(VpConfig), C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_size_t,
+         C.c_void_p, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    ),
+    "vp_last_error": (C.c_char_p, []),
+    "vp_version": (C.c_char_p, []),
+}
+
+
+def load():
+    """Load libvolpick_hip.so once; fail loudly if the HIP extension is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise VolpickHipError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            f"Build it with `make -C {_HERE / 'csrc'}` or `python -c 'import __graft_entry__ as g; g.build()'`."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "volpick_hip"):
+    if rc < 0:
+        msg = load().vp_last_error().decode(errors="replace")
+        raise VolpickHipError(f"{what} failed ({rc}): {msg}")
+    return rc

@@ -1,0 +1,503 @@
+// C ABI of libvolpick_hip.so (include/volpick_hip.h).
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "net.h"
+#include "prepost.h"
+
+namespace vp {
+const char* last_error();
+}
+
+struct vp_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  vp::Net net;
+  hipEvent_t ev[5] = {};
+  float total_ms = 0.f;
+  float stage_ms[4] = {0.f, 0.f, 0.f, 0.f};
+  // growable device scratch
+  float* d_in = nullptr;    // staged host input (stream or windows)
+  size_t d_in_cap = 0;
+  float* d_pred = nullptr;  // [n_windows][n_out][T] predictions of one annotate call
+  size_t d_pred_cap = 0;
+  float* d_out = nullptr;   // stacked output when the caller's buffer is on the host
+  size_t d_out_cap = 0;
+  void* d_pick = nullptr;   // pick scratch: count + on/off/peak/value
+  size_t d_pick_cap = 0;
+};
+
+namespace {
+
+int grow(float** p, size_t* cap, size_t need) {
+  if (need <= *cap) return VP_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  VP_HIP(hipMalloc(p, need * sizeof(float)));
+  *cap = need;
+  return VP_OK;
+}
+
+int64_t count_windows(int64_t N, int T, int overlap, int64_t* n_regular, int* has_tail) {
+  if (N < T) {
+    *n_regular = 0;
+    *has_tail = 0;
+    return 0;
+  }
+  const int64_t step = T - overlap;
+  *n_regular = (N - T) / step + 1;
+  *has_tail = ((*n_regular - 1) * step + T < N) ? 1 : 0;
+  return *n_regular + *has_tail;
+}
+
+vp::PreArgs pre_args(const vp_handle* h, const float* src, int dense, long N, long step, long first, int preprocess) {
+  const vp::Net& net = h->net;
+  const vp::Tensor& in = net.tensors[net.input];
+  vp::PreArgs a{};
+  a.src = src;
+  a.N = N;
+  a.dense = dense;
+  a.T = net.in_samples;
+  a.step = step;
+  a.first_window = first;
+  a.preprocess = preprocess;
+  a.norm = net.cfg.norm;
+  a.per_comp = (net.model_kind == VP_MODEL_PHASENET) ? 1 : net.cfg.norm_amp_per_comp;
+  a.taper = net.cfg.taper_samples;
+  a.norm_eps = net.cfg.norm_eps;
+  a.dst = in.p;
+  a.lsd = in.ls;
+  a.wsd = (long)in.win_stride();
+  return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vp_last_error(void) { return vp::last_error(); }
+const char* vp_version(void) { return "volpick_hip 0.1 (gfx950)"; }
+
+int vp_default_config(int model_kind, vp_config* cfg) {
+  VP_REQUIRE(cfg != nullptr, "cfg is null");
+  VP_REQUIRE(model_kind == VP_MODEL_PHASENET || model_kind == VP_MODEL_EQTRANSFORMER, "unknown model kind %d",
+             model_kind);
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->norm = VP_NORM_PEAK;
+  cfg->norm_amp_per_comp = 0;
+  cfg->max_batch = 256;
+  cfg->bn_eps = 1e-3f;
+  cfg->attention_eps = 1e-5f;
+  cfg->layernorm_eps = 1e-14f;
+  cfg->norm_eps = 1e-10f;
+  cfg->taper_samples = (model_kind == VP_MODEL_EQTRANSFORMER) ? 6 : 0;
+  return VP_OK;
+}
+
+size_t vp_weight_count(int model_kind) {
+  const vp::ParamDesc* t;
+  const int n = vp::param_table(model_kind, &t);
+  size_t s = 0;
+  for (int i = 0; i < n; ++i) s += t[i].size;
+  return s;
+}
+int vp_param_count(int model_kind) {
+  const vp::ParamDesc* t;
+  return vp::param_table(model_kind, &t);
+}
+const char* vp_param_name(int model_kind, int index) {
+  const vp::ParamDesc* t;
+  const int n = vp::param_table(model_kind, &t);
+  return (index >= 0 && index < n) ? t[index].name : nullptr;
+}
+size_t vp_param_size(int model_kind, int index) {
+  const vp::ParamDesc* t;
+  const int n = vp::param_table(model_kind, &t);
+  return (index >= 0 && index < n) ? t[index].size : 0;
+}
+
+int vp_create(int device_id, int model_kind, const float* weights, size_t n_floats, int weights_mem,
+              const vp_config* cfg, vp_handle** out) {
+  VP_REQUIRE(out != nullptr && weights != nullptr, "null argument");
+  VP_REQUIRE(model_kind == VP_MODEL_PHASENET || model_kind == VP_MODEL_EQTRANSFORMER, "unknown model kind %d",
+             model_kind);
+  VP_REQUIRE(n_floats == vp_weight_count(model_kind), "expected %zu weight floats, got %zu",
+             vp_weight_count(model_kind), n_floats);
+  vp_config c;
+  if (cfg) {
+    c = *cfg;
+  } else {
+    vp_default_config(model_kind, &c);
+  }
+  VP_REQUIRE(c.max_batch > 0 && c.max_batch <= 65535, "max_batch %d out of range", c.max_batch);
+  VP_HIP(hipSetDevice(device_id));
+
+  std::vector<float> host;
+  if (weights_mem == VP_MEM_DEVICE) {  // e.g. the buffer an RCCL broadcast delivered
+    host.resize(n_floats);
+    VP_HIP(hipMemcpy(host.data(), weights, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    weights = host.data();
+  }
+  vp::ParamView pv;
+  VP_REQUIRE(vp::build_param_view(model_kind, weights, n_floats, &pv), "weight blob does not match the table");
+
+  auto* h = new vp_handle();
+  h->device = device_id;
+  h->net.model_kind = model_kind;
+  h->net.cfg = c;
+  h->net.max_batch = c.max_batch;
+  int rc = (model_kind == VP_MODEL_PHASENET) ? vp::plan_phasenet(h->net, pv) : vp::plan_eqt(h->net, pv);
+  if (rc == VP_OK) rc = h->net.finalize_layout();
+  if (rc == VP_OK) rc = h->net.upload();
+  if (rc != VP_OK) {
+    h->net.release();
+    delete h;
+    return rc;
+  }
+  VP_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  for (auto& e : h->ev) VP_HIP(hipEventCreate(&e));
+  *out = h;
+  return VP_OK;
+}
+
+int vp_destroy(vp_handle* h) {
+  if (!h) return VP_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  for (auto& e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->d_in) (void)hipFree(h->d_in);
+  if (h->d_pred) (void)hipFree(h->d_pred);
+  if (h->d_out) (void)hipFree(h->d_out);
+  if (h->d_pick) (void)hipFree(h->d_pick);
+  h->net.release();
+  delete h;
+  return VP_OK;
+}
+
+int vp_in_samples(const vp_handle* h) { return h ? h->net.in_samples : VP_ERR_INVALID; }
+int vp_n_outputs(const vp_handle* h) { return h ? h->net.n_out : VP_ERR_INVALID; }
+void* vp_stream(const vp_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int vp_synchronize(vp_handle* h) {
+  VP_REQUIRE(h != nullptr, "null handle");
+  VP_HIP(hipStreamSynchronize(h->stream));
+  return VP_OK;
+}
+
+int vp_forward(vp_handle* h, const float* x, int x_mem, int B, int preprocess, float* y, int y_mem) {
+  VP_REQUIRE(h && x && y, "null argument");
+  VP_REQUIRE(B > 0, "B must be positive");
+  VP_HIP(hipSetDevice(h->device));
+  vp::Net& net = h->net;
+  const int T = net.in_samples;
+  const size_t in_w = (size_t)3 * T, out_w = (size_t)net.n_out * T;
+  float* y_saved = net.y;
+  VP_HIP(hipEventRecord(h->ev[0], h->stream));
+  for (int b0 = 0; b0 < B; b0 += net.max_batch) {
+    const int nb = std::min(net.max_batch, B - b0);
+    const float* src = x + (size_t)b0 * in_w;
+    if (x_mem == VP_MEM_HOST) {
+      int rc = grow(&h->d_in, &h->d_in_cap, (size_t)net.max_batch * in_w);
+      if (rc != VP_OK) return rc;
+      VP_HIP(hipMemcpyAsync(h->d_in, src, nb * in_w * sizeof(float), hipMemcpyHostToDevice, h->stream));
+      src = h->d_in;
+    }
+    vp::launch_gather_normalize(pre_args(h, src, 1, 0, 0, 0, preprocess), nb, h->stream);
+    if (y_mem == VP_MEM_DEVICE) net.y = y + (size_t)b0 * out_w;  // last layer writes straight into y
+    int rc = net.run(nb, h->stream);
+    net.y = y_saved;
+    if (rc != VP_OK) return rc;
+    if (y_mem == VP_MEM_HOST) {
+      VP_HIP(hipMemcpyAsync(y + (size_t)b0 * out_w, net.y, nb * out_w * sizeof(float), hipMemcpyDeviceToHost,
+                            h->stream));
+      if (b0 + nb < B) VP_HIP(hipStreamSynchronize(h->stream));  // net.y is reused by the next chunk
+    }
+  }
+  VP_HIP(hipEventRecord(h->ev[1], h->stream));
+  VP_HIP(hipStreamSynchronize(h->stream));
+  VP_HIP(hipEventElapsedTime(&h->total_ms, h->ev[0], h->ev[1]));
+  h->stage_ms[0] = h->stage_ms[2] = h->stage_ms[3] = 0.f;
+  h->stage_ms[1] = h->total_ms;
+  return VP_OK;
+}
+
+int64_t vp_window_starts(int64_t N, int in_samples, int overlap, int64_t* starts, int64_t cap) {
+  if (in_samples <= 0 || overlap < 0 || overlap >= in_samples) {
+    vp::set_error("overlap %d must be in [0, in_samples=%d)", overlap, in_samples);
+    return VP_ERR_INVALID;
+  }
+  int64_t n_reg;
+  int tail;
+  const int64_t n = count_windows(N, in_samples, overlap, &n_reg, &tail);
+  const int64_t step = in_samples - overlap;
+  for (int64_t i = 0; i < n && i < cap; ++i) starts[i] = (i < n_reg) ? i * step : N - in_samples;
+  return n;
+}
+
+int vp_annotate(vp_handle* h, const float* stream, int stream_mem, int64_t N, int overlap, int blind_l,
+                int blind_r, int stacking, int batch, float* out, int out_mem, int64_t* first_valid,
+                int64_t* last_valid, int64_t* n_windows) {
+  VP_REQUIRE(h && stream && out, "null argument");
+  vp::Net& net = h->net;
+  const int T = net.in_samples;
+  VP_REQUIRE(N > 0, "N must be positive");
+  VP_REQUIRE(overlap >= 0 && overlap < T, "overlap %d must be in [0, %d)", overlap, T);
+  VP_REQUIRE(blind_l >= 0 && blind_r >= 0 && blind_l + blind_r < T, "blinding (%d, %d) leaves no samples", blind_l,
+             blind_r);
+  VP_REQUIRE(stacking == VP_STACK_AVG || stacking == VP_STACK_MAX, "unknown stacking %d", stacking);
+  if (batch <= 0 || batch > net.max_batch) batch = net.max_batch;
+  VP_HIP(hipSetDevice(h->device));
+
+  int64_t n_reg;
+  int tail;
+  const int64_t nwin = count_windows(N, T, overlap, &n_reg, &tail);
+  if (n_windows) *n_windows = nwin;
+  const long step = T - overlap;
+
+  // valid (un-blinded) output range: union of [s_i + blind_l, s_i + T - blind_r)
+  int64_t fv = -1, lv = -1;
+  if (nwin > 0) {
+    fv = blind_l;
+    lv = (tail ? N - T : (n_reg - 1) * step) + T - blind_r - 1;
+  }
+  if (first_valid) *first_valid = fv;
+  if (last_valid) *last_valid = lv;
+
+  float* d_out = out;
+  if (out_mem == VP_MEM_HOST) {
+    int rc = grow(&h->d_out, &h->d_out_cap, (size_t)net.n_out * N);
+    if (rc != VP_OK) return rc;
+    d_out = h->d_out;
+  }
+  VP_HIP(hipEventRecord(h->ev[0], h->stream));
+  const float* d_stream = stream;
+  if (stream_mem == VP_MEM_HOST) {
+    int rc = grow(&h->d_in, &h->d_in_cap, std::max((size_t)3 * N, (size_t)net.max_batch * 3 * T));
+    if (rc != VP_OK) return rc;
+    VP_HIP(hipMemcpyAsync(h->d_in, stream, (size_t)3 * N * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    d_stream = h->d_in;
+  }
+  if (nwin > 0) {
+    const size_t out_w = (size_t)net.n_out * T;
+    int rc = grow(&h->d_pred, &h->d_pred_cap, (size_t)nwin * out_w);
+    if (rc != VP_OK) return rc;
+    float* y_saved = net.y;
+    for (int64_t w0 = 0; w0 < nwin; w0 += batch) {
+      const int nb = (int)std::min<int64_t>(batch, nwin - w0);
+      vp::launch_gather_normalize(pre_args(h, d_stream, 0, N, step, w0, 1), nb, h->stream);
+      net.y = h->d_pred + (size_t)w0 * out_w;
+      rc = net.run(nb, h->stream);
+      net.y = y_saved;
+      if (rc != VP_OK) return rc;
+    }
+    VP_HIP(hipEventRecord(h->ev[1], h->stream));
+  } else {
+    VP_HIP(hipEventRecord(h->ev[1], h->stream));
+  }
+  vp::StackArgs sa{};
+  sa.pred = h->d_pred;
+  sa.out = d_out;
+  sa.N = N;
+  sa.T = T;
+  sa.n_out = net.n_out;
+  sa.step = step;
+  sa.n_regular = n_reg;
+  sa.has_tail = tail;
+  sa.blind_l = blind_l;
+  sa.blind_r = blind_r;
+  sa.mode = stacking;
+  vp::launch_stack(sa, h->stream);  // with zero windows this writes all-NaN rows
+  VP_HIP(hipEventRecord(h->ev[2], h->stream));
+  if (out_mem == VP_MEM_HOST) {
+    VP_HIP(hipMemcpyAsync(out, d_out, (size_t)net.n_out * N * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  }
+  VP_HIP(hipStreamSynchronize(h->stream));
+  float fwd = 0.f, stk = 0.f;
+  VP_HIP(hipEventElapsedTime(&fwd, h->ev[0], h->ev[1]));
+  VP_HIP(hipEventElapsedTime(&stk, h->ev[1], h->ev[2]));
+  h->stage_ms[0] = 0.f;
+  h->stage_ms[1] = fwd;  // gather/normalise + forward of every batch
+  h->stage_ms[2] = stk;
+  h->stage_ms[3] = 0.f;
+  h->total_ms = fwd + stk;
+  return VP_OK;
+}
+
+int vp_pick_host(const float* trace, int64_t n, float thr_on, float thr_off, int64_t* on, int64_t* off,
+                 int64_t* peak, float* value, int cap, int* n_found) {
+  VP_REQUIRE(trace && n_found, "null argument");
+  VP_REQUIRE(cap == 0 || (on && off && peak && value), "null output arrays");
+  return vp::pick_host(trace, n, thr_on, thr_off, on, off, peak, value, cap, n_found);
+}
+
+int vp_pick(vp_handle* h, const float* trace, int trace_mem, int64_t n, float thr_on, float thr_off, int64_t* on,
+            int64_t* off, int64_t* peak, float* value, int cap, int* n_found) {
+  VP_REQUIRE(h && trace && n_found, "null argument");
+  VP_REQUIRE(cap >= 0 && (cap == 0 || (on && off && peak && value)), "null output arrays");
+  if (trace_mem == VP_MEM_HOST || thr_off > thr_on) {
+    // host-resident traces are scanned where they are; thr_off > thr_on uses the general rule
+    std::vector<float> tmp;
+    if (trace_mem == VP_MEM_DEVICE) {
+      tmp.resize(n);
+      VP_HIP(hipSetDevice(h->device));
+      VP_HIP(hipMemcpy(tmp.data(), trace, n * sizeof(float), hipMemcpyDeviceToHost));
+      trace = tmp.data();
+    }
+    return vp::pick_host(trace, n, thr_on, thr_off, on, off, peak, value, cap, n_found);
+  }
+  VP_HIP(hipSetDevice(h->device));
+  const size_t dcap = (size_t)std::max(cap, 1);
+  const size_t bytes = 64 + dcap * (3 * sizeof(int64_t) + sizeof(float));
+  if (bytes > h->d_pick_cap) {
+    if (h->d_pick) (void)hipFree(h->d_pick);
+    h->d_pick = nullptr;
+    h->d_pick_cap = 0;
+    VP_HIP(hipMalloc(&h->d_pick, bytes));
+    h->d_pick_cap = bytes;
+  }
+  char* base = (char*)h->d_pick;
+  vp::PickArgs a{};
+  a.trace = trace;
+  a.n = n;
+  a.thr_on = thr_on;
+  a.thr_off = thr_off;
+  a.count = (int*)base;
+  a.on = (int64_t*)(base + 64);
+  a.off = a.on + dcap;
+  a.peak = a.off + dcap;
+  a.value = (float*)(a.peak + dcap);
+  a.cap = cap;
+  VP_HIP(hipEventRecord(h->ev[3], h->stream));
+  VP_HIP(hipMemsetAsync(a.count, 0, sizeof(int), h->stream));
+  vp::launch_pick(a, h->stream);
+  VP_HIP(hipEventRecord(h->ev[4], h->stream));
+  int found = 0;
+  VP_HIP(hipMemcpyAsync(&found, a.count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  VP_HIP(hipStreamSynchronize(h->stream));
+  VP_HIP(hipEventElapsedTime(&h->stage_ms[3], h->ev[3], h->ev[4]));
+  *n_found = found;
+  const int m = std::min(found, cap);
+  if (m > 0) {
+    std::vector<int64_t> t_on(m), t_off(m), t_pk(m);
+    std::vector<float> t_v(m);
+    VP_HIP(hipMemcpy(t_on.data(), a.on, m * sizeof(int64_t), hipMemcpyDeviceToHost));
+    VP_HIP(hipMemcpy(t_off.data(), a.off, m * sizeof(int64_t), hipMemcpyDeviceToHost));
+    VP_HIP(hipMemcpy(t_pk.data(), a.peak, m * sizeof(int64_t), hipMemcpyDeviceToHost));
+    VP_HIP(hipMemcpy(t_v.data(), a.value, m * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<int> order(m);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int i, int j) { return t_on[i] < t_on[j]; });
+    for (int i = 0; i < m; ++i) {
+      on[i] = t_on[order[i]];
+      off[i] = t_off[order[i]];
+      peak[i] = t_pk[order[i]];
+      value[i] = t_v[order[i]];
+    }
+  }
+  return VP_OK;
+}
+
+int vp_last_timing(const vp_handle* h, float* total_ms, float stage_ms[4]) {
+  VP_REQUIRE(h != nullptr, "null handle");
+  if (total_ms) *total_ms = h->total_ms;
+  if (stage_ms)
+    for (int i = 0; i < 4; ++i) stage_ms[i] = h->stage_ms[i];
+  return VP_OK;
+}
+
+// ---- introspection used by bench.py (per-kernel HIP-event timing) and the parity tests ----
+int vp_step_count(const vp_handle* h) { return h ? (int)h->net.steps.size() : VP_ERR_INVALID; }
+
+int vp_step_info(const vp_handle* h, int index, const char** name, double* flops_per_window) {
+  VP_REQUIRE(h && index >= 0 && index < (int)h->net.steps.size(), "bad step index");
+  if (name) *name = h->net.steps[index].name.c_str();
+  if (flops_per_window) *flops_per_window = h->net.steps[index].flops_per_window;
+  return VP_OK;
+}
+
+double vp_flops_per_window(const vp_handle* h) { return h ? h->net.flops_per_window : 0.0; }
+
+// Runs every launch of the forward pass `iters` times on B windows (whatever the input
+// tensor currently holds) and reports the mean duration of each launch in milliseconds,
+// measured with HIP events on the handle's stream.
+int vp_profile_steps(vp_handle* h, int B, int iters, float* step_ms, int cap) {
+  VP_REQUIRE(h && step_ms && iters > 0, "bad argument");
+  vp::Net& net = h->net;
+  VP_REQUIRE(B > 0 && B <= net.max_batch, "B outside (0, max_batch]");
+  VP_HIP(hipSetDevice(h->device));
+  const int n = (int)net.steps.size();
+  for (int s = 0; s < n && s < cap; ++s) {
+    int rc = net.steps[s].run(net, B, h->stream);  // warm
+    if (rc != 0) return rc;
+    VP_HIP(hipEventRecord(h->ev[0], h->stream));
+    for (int i = 0; i < iters; ++i) net.steps[s].run(net, B, h->stream);
+    VP_HIP(hipEventRecord(h->ev[1], h->stream));
+    VP_HIP(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    VP_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+    step_ms[s] = ms / iters;
+  }
+  return VP_OK;
+}
+
+int vp_debug_tensor_count(const vp_handle* h) { return h ? (int)h->net.tensors.size() : VP_ERR_INVALID; }
+
+int vp_debug_tensor_info(const vp_handle* h, int index, const char** name, int* channels, int* length) {
+  VP_REQUIRE(h && index >= 0 && index < (int)h->net.tensors.size(), "bad tensor index");
+  const vp::Tensor& t = h->net.tensors[index];
+  if (name) *name = t.name.c_str();
+  if (channels) *channels = t.C;
+  if (length) *length = t.L;
+  return VP_OK;
+}
+
+int vp_debug_tensor_read(vp_handle* h, int index, int B, float* host_out) {
+  VP_REQUIRE(h && host_out && index >= 0 && index < (int)h->net.tensors.size(), "bad argument");
+  const vp::Tensor& t = h->net.tensors[index];
+  VP_REQUIRE(B > 0 && B <= h->net.max_batch * h->net.tensor_sets[index], "bad B");
+  VP_HIP(hipSetDevice(h->device));
+  VP_HIP(hipStreamSynchronize(h->stream));
+  // strided copy: (B*C rows) x L floats out of rows of stride ls, skipping the halo
+  VP_HIP(hipMemcpy2D(host_out, (size_t)t.L * sizeof(float), t.p + vp::HALO, (size_t)t.ls * sizeof(float),
+                     (size_t)t.L * sizeof(float), (size_t)B * t.C, hipMemcpyDeviceToHost));
+  return VP_OK;
+}
+
+// Host-only: packed constants of one conv layer of a freshly planned model (no GPU
+// needed); lets the CPU test-suite check BN folding and MFMA fragment packing.
+int vp_debug_plan_conv(int model_kind, const float* weights, size_t n_floats, const vp_config* cfg,
+                       int conv_index, int* geom13, float* afrag, size_t afrag_cap, float* bias, size_t bias_cap,
+                       const char** name, int* cols, int* l_out) {
+  static thread_local std::string name_store;
+  vp::ParamView pv;
+  VP_REQUIRE(vp::build_param_view(model_kind, weights, n_floats, &pv), "weight blob does not match the table");
+  vp::Net net;
+  net.model_kind = model_kind;
+  if (cfg) {
+    net.cfg = *cfg;
+  } else {
+    vp_default_config(model_kind, &net.cfg);
+  }
+  net.max_batch = 1;
+  int rc = (model_kind == VP_MODEL_PHASENET) ? vp::plan_phasenet(net, pv) : vp::plan_eqt(net, pv);
+  if (rc != VP_OK) return rc;
+  if (conv_index < 0 || conv_index >= (int)net.convs.size()) return -1000 - (int)net.convs.size();
+  const vp::ConvLayer& L = *net.convs[conv_index];
+  const vp::ConvGeom& g = L.g;
+  const int gv[13] = {g.cin1, g.cin2, g.cout, g.P, g.taps, g.sn, g.in_off, g.out_off, g.waves_m, g.waves_n, g.nw,
+                      g.relu, g.epi};
+  if (geom13) memcpy(geom13, gv, sizeof(gv));
+  if (afrag) memcpy(afrag, L.afrag.h.data(), std::min(afrag_cap, L.afrag.h.size()) * sizeof(float));
+  if (bias) memcpy(bias, L.bias.h.data(), std::min(bias_cap, L.bias.h.size()) * sizeof(float));
+  name_store = L.name;
+  if (name) *name = name_store.c_str();
+  if (cols) *cols = L.cols;
+  if (l_out) *l_out = L.l_out;
+  return (int)L.afrag.h.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,295 @@
+// 1-D convolution family as an implicit GEMM on the gfx950 fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains, 64 FLOP/clk/SIMD = the fp32 peak).
+//
+// One kernel template covers every conv-shaped layer of PhaseNet and EQTransformer
+//  through a "polyphase" formulation:
+//
+//   out[co][P*n + p + OUT_OFF] = act( bias[co] +
+//        sum_{tap<TAPS} sum_{ci} A[(co,p)][(tap,ci)] * in[ci][SN*n + tap + IN_OFF] )
+//
+//   plain conv, stride s, left pad padL : P=1, SN=s, TAPS=K, IN_OFF=-padL
+//   conv with few output channels       : P=2 output phases per GEMM row block so that
+//                                         M = COUT*P fills the 16-row MFMA tile
+//                                         (TAPS = K + s*(P-1), SN = s*P)
+//   ConvTranspose1d(k=7, s=4) + crop    : P=4, TAPS=2, SN=1, IN_OFF=-1, OUT_OFF=-(crop)
+//
+// GEMM view per workgroup: M = COUT*P rows, N = TN output columns (time) of one window,
+// K = TAPS * CIN.  A (the folded weights) is pre-packed on the host in MFMA lane order
+// and streamed from L2; B is read straight out of an LDS image of the input tile — the
+// im2col matrix is never materialised: for K-step (tap, 4 channels) lane l reads
+// lds[(cb*4 + (l>>4))*S + (col(l&15))*SN + tap], i.e. a per-lane base + immediate offset.
+// The input image is fetched with unguarded, 16-byte coalesced loads because every
+// activation row carries zeroed halos (vp_common.h).
+#pragma once
+#include "vp_common.h"
+
+namespace vp {
+
+enum ConvEpi {
+  EPI_STORE = 0,     // dst[co][t] = v
+  EPI_POOL2 = 1,     // dst[co][j] = max(v[2j], v[2j+1])         (EQT encoder: ReLU + MaxPool1d(2))
+  EPI_UP2 = 2,       // dst[co][2t] = dst[co][2t+1] = v[t]       (EQT decoder: producer-side Upsample(2))
+  EPI_RES = 3,       // o = v + res[co][t]; dst = o; dst2 = relu(s2[co]*o + b2[co])   (EQT ResCNN)
+  EPI_SOFTMAX3 = 4,  // y[c][t] = softmax_c( w[c][:] . v[:][t] + b[c] )             (PhaseNet out)
+  EPI_POOL2_DUAL = 5 // POOL2, plus dst2 = relu(s2*pooled + b2)   (EQT encoder tail feeding ResCNN)
+};
+
+struct ConvArgs {
+  const float* src1;  // [win][CIN1][ls1]
+  const float* src2;  // [win][CIN2][ls2] (concat partner) or null
+  int ls1, ls2;
+  long ws1, ws2;      // window strides in floats
+  float* dst;         // [win][COUT or 3][lsd]
+  int lsd;
+  long wsd;
+  int dst_halo;       // HALO for internal tensors, 0 for the dense final output
+  float* dst2;
+  int lsd2;
+  long wsd2;
+  const float* afrag; // [set][MT][CB][TAPS][64]
+  const float* bias;  // [set][COUT]
+  long afrag_set_stride, bias_set_stride;
+  int win_per_set;    // windows sharing one weight set (three EQT decoders run as one launch)
+  int n_windows;
+  int l_out;          // valid length of the (pre-pool / pre-upsample) conv output
+  int l_dst;          // valid length of dst rows (after pool / upsample)
+  const float* e0;    // EPI_RES: residual tensor (same geometry as dst); EPI_SOFTMAX3: w[3][8]
+  const float* e1;    // EPI_RES/DUAL: s2[COUT];                          EPI_SOFTMAX3: b[3]
+  const float* e2;    // EPI_RES/DUAL: b2[COUT]
+  long e_set_stride;  // per-set stride of e1/e2
+};
+
+struct ConvGeom {  // runtime mirror of the template parameters (planning / packing / tests)
+  int cin1, cin2, cout, P, taps, sn, in_off, out_off, waves_m, waves_n, nw, relu, epi;
+  int cin() const { return cin1 + cin2; }
+  int cinp() const { return round_up(cin1 + cin2, 4); }
+  int M() const { return cout * P; }
+  int tn() const { return waves_n * nw * 16; }
+  int shift() const { return in_off - floor4(in_off); }
+  int w_in() const { return sn * (tn() - 1) + taps + shift(); }
+  int w4() const { return (w_in() + 3) / 4; }
+  // max physical index (+1) of a source row read when `cols` output columns are produced
+  int src_need(int cols) const {
+    int tiles = (cols + tn() - 1) / tn();
+    return HALO + sn * (tiles - 1) * tn() + floor4(in_off) + 4 * w4();
+  }
+  size_t afrag_floats() const { return (size_t)M() * cinp() * taps; }
+};
+
+template <int CIN1_, int CIN2_, int COUT_, int P_, int TAPS_, int SN_, int IN_OFF_, int OUT_OFF_, int WAVES_M_,
+          int WAVES_N_, int NW_, int RELU_, int EPI_>
+struct ConvCfg {
+  static constexpr int CIN1 = CIN1_, CIN2 = CIN2_, CIN = CIN1_ + CIN2_, CINP = (CIN + 3) / 4 * 4, CB = CINP / 4;
+  static constexpr int COUT = COUT_, P = P_, TAPS = TAPS_, SN = SN_, IN_OFF = IN_OFF_, OUT_OFF = OUT_OFF_;
+  static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, NW = NW_, RELU = RELU_, EPI = EPI_;
+  static constexpr int M = COUT * P, MT = M / 16, MW = MT / WAVES_M;
+  static constexpr int NT = WAVES_N * NW, TN = NT * 16;
+  static constexpr int IN_OFF_F4 = (IN_OFF >= 0) ? (IN_OFF / 4) * 4 : -(((-IN_OFF) + 3) / 4) * 4;
+  static constexpr int SHIFT = IN_OFF - IN_OFF_F4;
+  static constexpr int W_IN = SN * (TN - 1) + TAPS + SHIFT;
+  static constexpr int W4 = (W_IN + 3) / 4;
+  // LDS row stride: >= 4*W4, == 16 (mod 32) so the two 16-lane channel rows a ds_read_b32
+  // half-wave touches fall on disjoint banks (unit-stride case).
+  static constexpr int S = ((4 * W4 + 15) / 32) * 32 + 16;
+  static constexpr int OW = P * TN;  // staged output columns per tile
+  static constexpr int OS = OW + 4;
+  static constexpr int LDS_IN = CINP * S, LDS_OUT = COUT * OS;
+  static constexpr int LDS_FLOATS = LDS_IN > LDS_OUT ? LDS_IN : LDS_OUT;
+  static_assert(WAVES_M * WAVES_N == 4, "256-thread workgroups");
+  static_assert(M % (16 * WAVES_M) == 0, "M must tile into 16-row MFMA tiles per wave");
+  static_assert(S >= 4 * W4 && S % 32 == 16, "LDS stride");
+  static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+  static ConvGeom geom() {
+    return ConvGeom{CIN1, CIN2, COUT, P, TAPS, SN, IN_OFF, OUT_OFF, WAVES_M, WAVES_N, NW, RELU, EPI};
+  }
+};
+
+template <class C>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+  extern __shared__ float4 lds_raw[];
+  float* lds = reinterpret_cast<float*>(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int win = blockIdx.y;
+  const int col0 = blockIdx.x * C::TN;
+  const int set = win / a.win_per_set;
+
+  // ---- stage the input tile: CINP rows x 4*W4 floats, aligned 16-byte loads --------------
+  {
+    const int a0 = HALO + C::SN * col0 + C::IN_OFF_F4;  // multiple of 4 by construction
+    const float* s1 = a.src1 + (long)win * a.ws1 + a0;
+    const float* s2 = (C::CIN2 > 0) ? a.src2 + (long)win * a.ws2 + a0 : nullptr;
+    for (int idx = tid; idx < C::CINP * C::W4; idx += 256) {
+      const int c = idx / C::W4, q = idx - c * C::W4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < C::CIN1) {
+        v = *reinterpret_cast<const float4*>(s1 + (long)c * a.ls1 + 4 * q);
+      } else if (c < C::CIN) {
+        v = *reinterpret_cast<const float4*>(s2 + (long)(c - C::CIN1) * a.ls2 + 4 * q);
+      }
+      *reinterpret_cast<float4*>(lds + c * C::S + 4 * q) = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- MFMA main loop ---------------------------------------------------------------
+  const int wm = wave % C::WAVES_M, wn = wave / C::WAVES_M;
+  const int g = lane >> 4, n = lane & 15;
+  f32x4 acc[C::MW][C::NW];
+#pragma unroll
+  for (int i = 0; i < C::MW; ++i)
+#pragma unroll
+    for (int j = 0; j < C::NW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* ap = a.afrag + (long)set * a.afrag_set_stride + (long)(wm * C::MW) * C::CB * C::TAPS * 64 + lane;
+  const float* bp = lds + g * C::S + (wn * C::NW * 16 + n) * C::SN + C::SHIFT;
+  for (int cb = 0; cb < C::CB; ++cb) {
+#pragma unroll
+    for (int tap = 0; tap < C::TAPS; ++tap) {
+      float av[C::MW], bv[C::NW];
+#pragma unroll
+      for (int i = 0; i < C::MW; ++i) av[i] = ap[((long)i * C::CB + cb) * C::TAPS * 64 + tap * 64];
+#pragma unroll
+      for (int j = 0; j < C::NW; ++j) bv[j] = bp[cb * 4 * C::S + j * 16 * C::SN + tap];
+#pragma unroll
+      for (int i = 0; i < C::MW; ++i)
+#pragma unroll
+        for (int j = 0; j < C::NW; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();  // all B reads done; the LDS image is reused as the output staging tile
+
+  // ---- epilogue 1: bias (+ReLU), D fragments -> LDS [COUT][OS] ----------------------
+  {
+    const float* bias = a.bias + (long)set * a.bias_set_stride;
+#pragma unroll
+    for (int i = 0; i < C::MW; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = (wm * C::MW + i) * 16 + 4 * g + r;
+        const int co = m / C::P, p = m - co * C::P;
+        const float b = bias[co];
+#pragma unroll
+        for (int j = 0; j < C::NW; ++j) {
+          float v = acc[i][j][r] + b;
+          if (C::RELU) v = fmaxf(v, 0.f);
+          lds[co * C::OS + C::P * ((wn * C::NW + j) * 16 + n) + p] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue 2: coalesced stores of the staged tile -----------------------------
+  const int t0 = C::P * col0 + C::OUT_OFF;  // global output index of staged column 0
+  if constexpr (C::EPI == EPI_STORE) {
+    float* d = a.dst + (long)win * a.wsd + a.dst_halo;
+    if constexpr (C::OUT_OFF % 4 == 0) {
+      for (int idx = tid; idx < C::COUT * (C::OW / 4); idx += 256) {
+        const int co = idx / (C::OW / 4), q = idx - co * (C::OW / 4);
+        const int t = t0 + 4 * q;
+        if (t < a.l_out) {
+          float4 v = *reinterpret_cast<const float4*>(lds + co * C::OS + 4 * q);
+          if (t + 1 >= a.l_out) v.y = 0.f;  // keep the right margin zero
+          if (t + 2 >= a.l_out) v.z = 0.f;
+          if (t + 3 >= a.l_out) v.w = 0.f;
+          *reinterpret_cast<float4*>(d + (long)co * a.lsd + t) = v;
+        }
+      }
+    } else {
+      for (int idx = tid; idx < C::COUT * C::OW; idx += 256) {
+        const int co = idx / C::OW, q = idx - co * C::OW;
+        const int t = t0 + q;
+        if (t >= 0 && t < a.l_out) d[(long)co * a.lsd + t] = lds[co * C::OS + q];
+      }
+    }
+  } else if constexpr (C::EPI == EPI_POOL2 || C::EPI == EPI_POOL2_DUAL) {
+    // MaxPool1d(2) over the ReLU output; an odd tail is pooled with the -1e10 pad, i.e. alone.
+    float* d = a.dst + (long)win * a.wsd + a.dst_halo;
+    float* d2 = (C::EPI == EPI_POOL2_DUAL) ? a.dst2 + (long)win * a.wsd2 + HALO : nullptr;
+    for (int idx = tid; idx < C::COUT * (C::OW / 2); idx += 256) {
+      const int co = idx / (C::OW / 2), q = idx - co * (C::OW / 2);
+      const int t = t0 + 2 * q;
+      if (t < a.l_out) {
+        float v = lds[co * C::OS + 2 * q];
+        if (t + 1 < a.l_out) v = fmaxf(v, lds[co * C::OS + 2 * q + 1]);
+        d[(long)co * a.lsd + (t >> 1)] = v;
+        if constexpr (C::EPI == EPI_POOL2_DUAL) {
+          const float s = a.e1[co], b = a.e2[co];
+          d2[(long)co * a.lsd2 + (t >> 1)] = fmaxf(fmaf(s, v, b), 0.f);
+        }
+      }
+    }
+  } else if constexpr (C::EPI == EPI_UP2) {
+    float* d = a.dst + (long)win * a.wsd + a.dst_halo;
+    for (int idx = tid; idx < C::COUT * C::OW; idx += 256) {
+      const int co = idx / C::OW, q = idx - co * C::OW;
+      const int t = t0 + q;
+      if (t < a.l_out) {
+        const float v = lds[co * C::OS + q];
+        float* row = d + (long)co * a.lsd;
+        row[2 * t] = v;
+        if (2 * t + 1 < a.l_dst) row[2 * t + 1] = v;
+      }
+    }
+  } else if constexpr (C::EPI == EPI_RES) {
+    float* d = a.dst + (long)win * a.wsd + a.dst_halo;
+    const float* res = a.e0 + (long)win * a.wsd + a.dst_halo;
+    float* d2 = a.dst2 ? a.dst2 + (long)win * a.wsd2 + HALO : nullptr;
+    const float* s2 = a.e1 + (long)set * a.e_set_stride;
+    const float* b2 = a.e2 + (long)set * a.e_set_stride;
+    for (int idx = tid; idx < C::COUT * C::OW; idx += 256) {
+      const int co = idx / C::OW, q = idx - co * C::OW;
+      const int t = t0 + q;
+      if (t < a.l_out) {
+        const float o = lds[co * C::OS + q] + res[(long)co * a.lsd + t];
+        d[(long)co * a.lsd + t] = o;
+        if (d2) d2[(long)co * a.lsd2 + t] = fmaxf(fmaf(s2[co], o, b2[co]), 0.f);
+      }
+    }
+  } else if constexpr (C::EPI == EPI_SOFTMAX3) {
+    static_assert(C::EPI != EPI_SOFTMAX3 || C::COUT == 8, "PhaseNet head: 8 -> 3");
+    float* d = a.dst + (long)win * a.wsd + a.dst_halo;
+    float w[3][8], bb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      bb[c] = a.e1[c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) w[c][k] = a.e0[c * 8 + k];
+    }
+    for (int q = tid; q < C::OW; q += 256) {
+      const int t = t0 + q;
+      if (t < a.l_out) {
+        float z[3] = {bb[0], bb[1], bb[2]};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float v = lds[k * C::OS + q];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) z[c] = fmaf(w[c][k], v, z[c]);
+        }
+        const float mx = fmaxf(z[0], fmaxf(z[1], z[2]));
+        const float e0 = __expf(z[0] - mx), e1 = __expf(z[1] - mx), e2 = __expf(z[2] - mx);
+        const float inv = 1.f / (e0 + e1 + e2);
+        d[t] = e0 * inv;
+        d[(long)a.lsd + t] = e1 * inv;
+        d[2l * a.lsd + t] = e2 * inv;
+      }
+    }
+  }
+}
+
+template <class C>
+int launch_conv(const ConvArgs& a, int cols, hipStream_t stream) {
+  dim3 grid((cols + C::TN - 1) / C::TN, a.n_windows, 1);
+  hipLaunchKernelGGL(conv_mfma_kernel<C>, grid, dim3(256), C::LDS_FLOATS * sizeof(float), stream, a);
+  return 0;
+}
+
+// ---- host-side A-matrix builders + MFMA-order packing (conv_pack.cpp) ------------------
+// Amat is row-major [M][TAPS*CINP], column index = tap*CINP + ci.
+std::vector<float> amat_conv(const float* W, int cout, int cin, int K, int stride, int P, int cinp,
+                             const float* row_scale);
+std::vector<float> amat_convT_k7s4(const float* Wt, int cin, int cout, int cinp, const float* row_scale);
+std::vector<float> pack_afrag(const std::vector<float>& amat, int M, int cinp, int taps);
+
+}  // namespace vp

@@ -1,0 +1,102 @@
+// Device plan of one picker model: activation tensors, packed weights and the ordered list
+// of kernel launches of one forward pass.  Built host-only (plan_*), then uploaded.
+#pragma once
+#include <functional>
+#include <memory>
+
+#include "conv_mfma.h"
+
+namespace vp {
+
+struct Net;
+
+struct HostBlob {  // host staging of a device constant array
+  std::vector<float> h;
+  float* d = nullptr;
+};
+
+struct ConvLayer {
+  std::string name;
+  ConvGeom g;
+  int src1 = -1, src2 = -1, dst = -1, dst2 = -1, res = -1;  // tensor ids; dst == kDenseOut -> net.y
+  int cols = 0, l_out = 0, l_dst = 0;
+  int n_sets = 1;  // weight sets (EQT decoders x3); windows = n_sets * B
+  HostBlob afrag, bias, e0, e1, e2;
+  int (*launch)(const ConvArgs&, int, hipStream_t) = nullptr;
+  const void* kernel = nullptr;
+  size_t lds_bytes = 0;
+  double flops_per_window = 0;  // algorithmic 2*MAC of the layer (not the padded MFMA work)
+};
+
+struct Step {
+  std::string name;
+  std::function<int(Net&, int /*B*/, hipStream_t)> run;
+  double flops_per_window = 0;
+};
+
+constexpr int kDenseOut = -2;
+
+struct Net {
+  int model_kind = 0;
+  vp_config cfg{};
+  int in_samples = 0, n_out = 3;
+  int max_batch = 0;
+  std::vector<Tensor> tensors;
+  std::vector<int> tensor_sets;  // capacity multiplier per tensor (3 for batched EQT decoders)
+  std::vector<std::unique_ptr<ConvLayer>> convs;
+  std::vector<HostBlob*> blobs;  // every constant array to upload (owned by layers / extra)
+  std::vector<std::unique_ptr<HostBlob>> extra;
+  std::vector<Step> steps;
+  int input = -1;          // tensor id of the normalised haloed input windows
+  float* y = nullptr;      // dense output [max_batch][n_out][in_samples]
+  float* arena = nullptr;  // one device allocation for tensors + constants
+  size_t arena_floats = 0;
+  double flops_per_window = 0;
+
+  int add_tensor(const std::string& name, int C, int L, int sets = 1);
+  HostBlob* add_blob(std::vector<float> v);
+  void need(int tensor, int phys_end) {
+    if (tensor >= 0 && tensors[tensor].need < phys_end) tensors[tensor].need = phys_end;
+  }
+
+  template <class Cfg>
+  ConvLayer* add_conv(const std::string& name, int src1, int src2, int dst, int cols, int l_out,
+                      std::vector<float> afrag, std::vector<float> bias, int n_sets = 1) {
+    auto L = std::make_unique<ConvLayer>();
+    L->name = name;
+    L->g = Cfg::geom();
+    L->src1 = src1;
+    L->src2 = src2;
+    L->dst = dst;
+    L->cols = cols;
+    L->l_out = l_out;
+    L->l_dst = l_out;
+    L->n_sets = n_sets;
+    L->afrag.h = std::move(afrag);
+    L->bias.h = std::move(bias);
+    L->launch = &launch_conv<Cfg>;
+    L->kernel = reinterpret_cast<const void*>(&conv_mfma_kernel<Cfg>);
+    L->lds_bytes = Cfg::LDS_FLOATS * sizeof(float);
+    need(src1, L->g.src_need(cols));
+    need(src2, L->g.src_need(cols));
+    ConvLayer* raw = L.get();
+    convs.push_back(std::move(L));
+    add_conv_step(raw);
+    return raw;
+  }
+  void add_conv_step(ConvLayer* L);
+  int finalize_layout();  // host-only: row strides, arena offsets
+  int upload();           // hipMalloc + copy constants + zero activations
+  int run(int B, hipStream_t stream);
+  void release();
+};
+
+int plan_phasenet(Net& net, const ParamView& pv);
+int plan_eqt(Net& net, const ParamView& pv);
+
+// BatchNorm (eval) folded into the preceding conv: scale = gamma / sqrt(var + eps),
+// shift = beta - mean * scale (+ conv bias * scale).
+void bn_fold(const ParamView& pv, const std::string& bn, int C, float eps, const float* conv_bias,
+             std::vector<float>* scale, std::vector<float>* shift);
+
+}  // namespace vp

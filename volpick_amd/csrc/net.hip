@@ -1,0 +1,215 @@
+// Plan bookkeeping shared by both models: tensor layout, constant upload, launch loop.
+#include "net.h"
+
+#include <cmath>
+
+namespace vp {
+
+#include "param_tables.inc"
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+int param_table(int model_kind, const ParamDesc** table) {
+  if (model_kind == VP_MODEL_PHASENET) {
+    *table = kPhaseNetParams;
+    return kPhaseNetParamsCount;
+  }
+  if (model_kind == VP_MODEL_EQTRANSFORMER) {
+    *table = kEqtParams;
+    return kEqtParamsCount;
+  }
+  *table = nullptr;
+  return 0;
+}
+
+bool build_param_view(int model_kind, const float* blob, size_t n_floats, ParamView* out) {
+  const ParamDesc* t;
+  const int n = param_table(model_kind, &t);
+  size_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    if (off + t[i].size > n_floats) return false;
+    out->by_name[t[i].name] = {blob + off, &t[i]};
+    off += t[i].size;
+  }
+  return off == n_floats;
+}
+
+const float* ParamView::get(const std::string& name, const ParamDesc** d) const {
+  auto it = by_name.find(name);
+  if (it == by_name.end()) {
+    set_error("missing parameter %s", name.c_str());
+    return nullptr;
+  }
+  if (d) *d = it->second.second;
+  return it->second.first;
+}
+
+void bn_fold(const ParamView& pv, const std::string& bn, int C, float eps, const float* conv_bias,
+             std::vector<float>* scale, std::vector<float>* shift) {
+  const float* w = pv.get(bn + ".weight");
+  const float* b = pv.get(bn + ".bias");
+  const float* m = pv.get(bn + ".running_mean");
+  const float* v = pv.get(bn + ".running_var");
+  scale->resize(C);
+  shift->resize(C);
+  for (int c = 0; c < C; ++c) {
+    const float s = w[c] / std::sqrt(v[c] + eps);
+    (*scale)[c] = s;
+    (*shift)[c] = b[c] + ((conv_bias ? conv_bias[c] : 0.f) - m[c]) * s;
+  }
+}
+
+int Net::add_tensor(const std::string& name, int C, int L, int sets) {
+  Tensor t;
+  t.name = name;
+  t.C = C;
+  t.L = L;
+  t.need = HALO + round_up(L, 4);
+  tensors.push_back(t);
+  tensor_sets.push_back(sets);
+  return (int)tensors.size() - 1;
+}
+
+HostBlob* Net::add_blob(std::vector<float> v) {
+  extra.push_back(std::make_unique<HostBlob>());
+  extra.back()->h = std::move(v);
+  return extra.back().get();
+}
+
+void Net::add_conv_step(ConvLayer* L) {
+  Step s;
+  s.name = L->name;
+  s.run = [L](Net& net, int B, hipStream_t stream) -> int {
+    ConvArgs a{};
+    const Tensor& s1 = net.tensors[L->src1];
+    a.src1 = s1.p;
+    a.ls1 = s1.ls;
+    a.ws1 = (long)s1.win_stride();
+    if (L->src2 >= 0) {
+      const Tensor& s2 = net.tensors[L->src2];
+      a.src2 = s2.p;
+      a.ls2 = s2.ls;
+      a.ws2 = (long)s2.win_stride();
+    }
+    if (L->dst == kDenseOut) {
+      a.dst = net.y;
+      a.lsd = net.in_samples;
+      a.wsd = (long)net.n_out * net.in_samples;
+      a.dst_halo = 0;
+    } else {
+      const Tensor& d = net.tensors[L->dst];
+      a.dst = d.p;
+      a.lsd = d.ls;
+      a.wsd = (long)d.win_stride();
+      a.dst_halo = HALO;
+    }
+    if (L->dst2 >= 0) {
+      const Tensor& d2 = net.tensors[L->dst2];
+      a.dst2 = d2.p;
+      a.lsd2 = d2.ls;
+      a.wsd2 = (long)d2.win_stride();
+    }
+    a.afrag = L->afrag.d;
+    a.bias = L->bias.d;
+    a.afrag_set_stride = (long)(L->afrag.h.size() / L->n_sets);
+    a.bias_set_stride = (long)(L->bias.h.size() / L->n_sets);
+    a.win_per_set = B;
+    a.n_windows = B * L->n_sets;
+    a.l_out = L->l_out;
+    a.l_dst = L->l_dst;
+    a.e0 = (L->res >= 0) ? net.tensors[L->res].p : L->e0.d;
+    a.e1 = L->e1.d;
+    a.e2 = L->e2.d;
+    a.e_set_stride = L->e1.h.empty() ? 0 : (long)(L->e1.h.size() / L->n_sets);
+    return L->launch(a, L->cols, stream);
+  };
+  s.flops_per_window = L->flops_per_window;
+  steps.push_back(std::move(s));
+}
+
+int Net::finalize_layout() {
+  size_t off = 0;
+  for (size_t i = 0; i < tensors.size(); ++i) {
+    Tensor& t = tensors[i];
+    t.ls = round_up(t.need, 4);
+    // offsets are turned into pointers by upload(); stash the offset in `need`'s place
+    off += (size_t)t.C * t.ls * max_batch * tensor_sets[i];
+    off = (off + 63) / 64 * 64;
+  }
+  (void)off;
+  return VP_OK;
+}
+
+int Net::upload() {
+  // collect every constant blob
+  blobs.clear();
+  for (auto& c : convs) {
+    for (HostBlob* b : {&c->afrag, &c->bias, &c->e0, &c->e1, &c->e2})
+      if (!b->h.empty()) blobs.push_back(b);
+  }
+  for (auto& e : extra)
+    if (!e->h.empty()) blobs.push_back(e.get());
+
+  size_t total = 0;
+  std::vector<size_t> toff(tensors.size()), boff(blobs.size());
+  for (size_t i = 0; i < tensors.size(); ++i) {
+    toff[i] = total;
+    total += (size_t)tensors[i].C * tensors[i].ls * max_batch * tensor_sets[i];
+    total = (total + 63) / 64 * 64;
+  }
+  const size_t y_off = total;
+  total += (size_t)max_batch * n_out * in_samples;
+  total = (total + 63) / 64 * 64;
+  for (size_t i = 0; i < blobs.size(); ++i) {
+    boff[i] = total;
+    total += blobs[i]->h.size();
+    total = (total + 63) / 64 * 64;
+  }
+  arena_floats = total;
+  VP_HIP(hipMalloc(&arena, total * sizeof(float)));
+  VP_HIP(hipMemset(arena, 0, total * sizeof(float)));  // zero halos / margins, once
+  for (size_t i = 0; i < tensors.size(); ++i) tensors[i].p = arena + toff[i];
+  y = arena + y_off;
+  for (size_t i = 0; i < blobs.size(); ++i) {
+    blobs[i]->d = arena + boff[i];
+    VP_HIP(hipMemcpy(blobs[i]->d, blobs[i]->h.data(), blobs[i]->h.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  for (auto& c : convs) {
+    if (c->lds_bytes > 48 * 1024) {
+      VP_HIP(hipFuncSetAttribute(c->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
+    }
+  }
+  return VP_OK;
+}
+
+int Net::run(int B, hipStream_t stream) {
+  if (B <= 0 || B > max_batch) {
+    set_error("batch %d outside (0, %d]", B, max_batch);
+    return VP_ERR_INVALID;
+  }
+  for (auto& s : steps) {
+    int rc = s.run(*this, B, stream);
+    if (rc != 0) return rc;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("kernel launch failed: %s", hipGetErrorString(e));
+    return VP_ERR_HIP;
+  }
+  return VP_OK;
+}
+
+void Net::release() {
+  if (arena) (void)hipFree(arena);
+  arena = nullptr;
+}
+
+}  // namespace vp

@@ -1,0 +1,51 @@
+// Argument blocks of the HBM-bound pre/post kernels (prepost.hip).
+#pragma once
+#include "vp_common.h"
+
+namespace vp {
+
+struct PreArgs {
+  const float* src;  // stream rows (3, N) or dense windows (B, 3, T)
+  long N;            // stream length (row stride) when !dense
+  int dense;         // 1: src is (B,3,T)
+  int T;             // in_samples
+  long step;         // in_samples - overlap
+  long first_window; // index of window 0 of this batch within the stream
+  int preprocess;    // 0: copy only (model(x) semantics)
+  int norm;          // VP_NORM_*
+  int per_comp;
+  int taper;
+  float norm_eps;
+  float* dst;        // haloed input tensor
+  int lsd;
+  long wsd;
+};
+int launch_gather_normalize(const PreArgs& a, int n_windows, hipStream_t stream);
+
+struct StackArgs {
+  const float* pred;  // [n_windows][n_out][T]
+  float* out;         // [n_out][N]
+  long N;
+  int T, n_out;
+  long step;
+  long n_regular;     // windows at i*step
+  int has_tail;       // one more window at N - T
+  int blind_l, blind_r;
+  int mode;           // VP_STACK_*
+};
+int launch_stack(const StackArgs& a, hipStream_t stream);
+
+struct PickArgs {
+  const float* trace;
+  long n;
+  float thr_on, thr_off;
+  int64_t *on, *off, *peak;
+  float* value;
+  int cap;
+  int* count;
+};
+int launch_pick(const PickArgs& a, hipStream_t stream);
+int pick_host(const float* x, int64_t n, float thr_on, float thr_off, int64_t* on, int64_t* off, int64_t* peak,
+              float* value, int cap, int* n_found);
+
+}  // namespace vp

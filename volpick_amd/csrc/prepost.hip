@@ -1,0 +1,249 @@
+// HBM-bound stages around the model forward pass:
+//   window gather + annotate_batch_pre, NaN blinding + overlap stacking, trigger/peak scan.
+#include "prepost.h"
+
+#include <cmath>
+
+namespace vp {
+
+// ---------------------------------------------------------------------------------------
+// A2 + A3: one workgroup per window.  Gathers window w of the (3, N) stream (or of a dense
+// (B,3,T) batch), subtracts the per-channel mean, divides by the peak / std amplitude
+// (per channel or over all three channels) + eps, applies the 6-sample half-cosine taper
+// (EQT) and writes the haloed model input row.  Three coalesced passes over <= 72 KB that
+// stay in L2; wavefront shuffle + LDS reductions.
+// ---------------------------------------------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__global__ __launch_bounds__(256) void gather_normalize_kernel(const PreArgs a) {
+  __shared__ float red[3][4];
+  __shared__ float stat[3][2];
+  const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = a.T;
+  long start = a.dense ? 0 : (long)(a.first_window + w) * a.step;
+  if (!a.dense && start > a.N - T) start = a.N - T;  // tail window flush with the end
+  const float* src = a.src + (a.dense ? (long)w * 3 * T : start);
+  const long cs = a.dense ? T : a.N;
+  float* dst = a.dst + (long)w * a.wsd + HALO;
+
+  if (!a.preprocess) {
+    for (int c = 0; c < 3; ++c)
+      for (int t = tid; t < T; t += 256) dst[(long)c * a.lsd + t] = src[c * cs + t];
+    return;
+  }
+  // pass 1: mean per channel
+  float s[3] = {0.f, 0.f, 0.f};
+  for (int c = 0; c < 3; ++c)
+    for (int t = tid; t < T; t += 256) s[c] += src[c * cs + t];
+  for (int c = 0; c < 3; ++c) {
+    const float v = wave_sum(s[c]);
+    if (lane == 0) red[c][wave] = v;
+  }
+  __syncthreads();
+  if (tid < 3) stat[tid][0] = (red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3]) / (float)T;
+  __syncthreads();
+  const float mean[3] = {stat[0][0], stat[1][0], stat[2][0]};
+  // pass 2: amplitude of the demeaned window
+  float m[3] = {0.f, 0.f, 0.f};
+  for (int c = 0; c < 3; ++c)
+    for (int t = tid; t < T; t += 256) {
+      const float d = src[c * cs + t] - mean[c];
+      if (a.norm == VP_NORM_PEAK) {
+        m[c] = fmaxf(m[c], fabsf(d));
+        if (d != d) m[c] = d;  // propagate NaN like torch.max
+      } else {
+        m[c] += d * d;
+      }
+    }
+  __syncthreads();
+  for (int c = 0; c < 3; ++c) {
+    const float v = (a.norm == VP_NORM_PEAK) ? wave_max(m[c]) : wave_sum(m[c]);
+    if (lane == 0) red[c][wave] = v;
+  }
+  __syncthreads();
+  if (tid < 3) {
+    const float* r = red[tid];
+    stat[tid][1] = (a.norm == VP_NORM_PEAK) ? fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])) : r[0] + r[1] + r[2] + r[3];
+  }
+  __syncthreads();
+  float amp[3];
+  if (a.per_comp) {
+    for (int c = 0; c < 3; ++c)
+      amp[c] = (a.norm == VP_NORM_PEAK) ? stat[c][1] : sqrtf(stat[c][1] / (float)(T - 1));
+  } else {
+    const float g = (a.norm == VP_NORM_PEAK) ? fmaxf(stat[0][1], fmaxf(stat[1][1], stat[2][1]))
+                                             : sqrtf((stat[0][1] + stat[1][1] + stat[2][1]) / (float)(3 * T - 1));
+    amp[0] = amp[1] = amp[2] = g;
+  }
+  // pass 3: scale (+ taper) and write
+  for (int c = 0; c < 3; ++c) {
+    const float den = amp[c] + a.norm_eps;
+    for (int t = tid; t < T; t += 256) {
+      float v = (src[c * cs + t] - mean[c]) / den;
+      if (a.taper > 0) {
+        const int e = (t < a.taper) ? t : ((T - 1 - t < a.taper) ? T - 1 - t : -1);
+        if (e >= 0) {  // 0.5 * (1 + cos(linspace(pi, 2 pi, taper)[e]))
+          const float ang = 3.14159265358979323846f * (1.f + (float)e / (float)(a.taper - 1));
+          v *= 0.5f * (1.f + cosf(ang));
+        }
+      }
+      dst[(long)c * a.lsd + t] = v;
+    }
+  }
+}
+
+int launch_gather_normalize(const PreArgs& a, int n_windows, hipStream_t stream) {
+  hipLaunchKernelGGL(gather_normalize_kernel, dim3(n_windows), dim3(256), 0, stream, a);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// A6 + A7: blinding + overlap stacking as a gather.  Output sample t of channel c averages
+// (or maxes) pred[i][c][t - s_i] over every window i whose un-blinded range
+// [s_i + blind_l, s_i + T - blind_r) contains t; none -> NaN.  The reference scatters into
+// a (L, n_out, coverage) NaN buffer and takes nanmean / nanmax; the gather form reads each
+// prediction once, writes each output once, and needs no coverage-deep buffer.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stack_kernel(const StackArgs a) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  if (t >= a.N) return;
+  const int T = a.T;
+  const long last_start = a.N - T;
+  // regular windows i*step, i in [lo, hi]
+  long hi = (t - a.blind_l >= 0) ? (t - a.blind_l) / a.step : -1;
+  long lo_num = t - T + a.blind_r;  // need i*step > lo_num
+  long lo = (lo_num < 0) ? 0 : lo_num / a.step + 1;
+  if (hi > a.n_regular - 1) hi = a.n_regular - 1;
+  float acc = (a.mode == VP_STACK_AVG) ? 0.f : -INFINITY;
+  int cnt = 0;
+  bool nan_seen = false;
+  for (long i = lo; i <= hi; ++i) {
+    const float v = a.pred[((long)i * a.n_out + c) * T + (t - i * a.step)];
+    if (v != v) continue;  // nanmean / nanmax skip NaN predictions
+    acc = (a.mode == VP_STACK_AVG) ? acc + v : fmaxf(acc, v);
+    ++cnt;
+  }
+  if (a.has_tail) {
+    const long j = t - last_start;
+    if (j >= a.blind_l && j < T - a.blind_r) {
+      const float v = a.pred[((long)a.n_regular * a.n_out + c) * T + j];
+      if (v == v) {
+        acc = (a.mode == VP_STACK_AVG) ? acc + v : fmaxf(acc, v);
+        ++cnt;
+      }
+    }
+  }
+  (void)nan_seen;
+  float r = NAN;
+  if (cnt > 0) r = (a.mode == VP_STACK_AVG) ? acc / (float)cnt : acc;
+  a.out[(long)c * a.N + t] = r;
+}
+
+int launch_stack(const StackArgs& a, hipStream_t stream) {
+  dim3 grid((unsigned)((a.N + 255) / 256), a.n_out, 1);
+  hipLaunchKernelGGL(stack_kernel, grid, dim3(256), 0, stream, a);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// A8: trigger_onset + peak.  For thr_off <= thr_on every maximal run of samples > thr_off
+// that holds a sample > thr_on yields one trigger: on = first sample > thr_on in the run,
+// off = last sample of the run, peak = first argmax over [on, off].  One thread per sample
+// finds run ends; the thread at a run end walks its run backwards (runs are short, ends
+// are rare).  Triggers are appended with one atomic each and sorted on the host.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pick_kernel(const PickArgs a) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.n) return;
+  const float v = a.trace[t];
+  if (!(v > a.thr_off)) return;
+  if (t + 1 < a.n && a.trace[t + 1] > a.thr_off) return;  // not a run end
+  long on = -1;
+  long s = t;
+  while (s >= 0 && a.trace[s] > a.thr_off) {
+    if (a.trace[s] > a.thr_on) on = s;
+    --s;
+  }
+  if (on < 0) return;
+  float best = a.trace[on];
+  long arg = on;
+  for (long k = on + 1; k <= t; ++k) {
+    const float x = a.trace[k];
+    if (x > best) {
+      best = x;
+      arg = k;
+    }
+  }
+  const int slot = atomicAdd(a.count, 1);
+  if (slot < a.cap) {
+    a.on[slot] = on;
+    a.off[slot] = t;
+    a.peak[slot] = arg;
+    a.value[slot] = best;
+  }
+}
+
+int launch_pick(const PickArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(pick_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, stream, a);
+  return 0;
+}
+
+// Host mirror of ObsPy's trigger_onset for host-resident traces (general thresholds).
+int pick_host(const float* x, int64_t n, float thr_on, float thr_off, int64_t* on, int64_t* off, int64_t* peak,
+              float* value, int cap, int* n_found) {
+  int found = 0;
+  int64_t i = 0;
+  // State machine equivalent to the deque pairing in obspy.signal.trigger.trigger_onset:
+  // a trigger opens at the first sample > thr_on and closes at the last sample of the run
+  // of consecutive samples > thr_off that contains (or follows) it.
+  while (i < n) {
+    if (!(x[i] > thr_on)) {
+      ++i;
+      continue;
+    }
+    const int64_t s0 = i;
+    int64_t s1;
+    if (x[i] > thr_off) {
+      int64_t k = i;
+      while (k + 1 < n && x[k + 1] > thr_off) ++k;
+      s1 = k;
+    } else {
+      // thr_off > thr_on corner: the next run end of (x > thr_off) after s0, or the last one
+      int64_t k = i + 1;
+      while (k < n && !(x[k] > thr_off)) ++k;
+      if (k >= n) break;
+      while (k + 1 < n && x[k + 1] > thr_off) ++k;
+      s1 = k;
+    }
+    float best = x[s0];
+    int64_t arg = s0;
+    for (int64_t k = s0 + 1; k <= s1; ++k) {
+      if (x[k] > best) {  // NaN compares false, like np.argmax on the > comparisons used upstream
+        best = x[k];
+        arg = k;
+      }
+    }
+    if (found < cap) {
+      on[found] = s0;
+      off[found] = s1;
+      peak[found] = arg;
+      value[found] = best;
+    }
+    ++found;
+    i = s1 + 1;
+  }
+  *n_found = found;
+  return VP_OK;
+}
+
+}  // namespace vp

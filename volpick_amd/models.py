@@ -1,0 +1,473 @@
+"""Picker API of the volpick path on MI355X: ``PhaseNet`` / ``EQTransformer`` with the
+``seisbench.models`` surface volpick users call.
+
+Reference usage this mirrors (names, argument meaning, error behaviour):
+  README.md:46-66            from_pretrained("volpick"); classify(stream, batch_size=256, overlap=5500,
+                             blinding=(500,500), stacking="avg", parallelism=None, P_threshold=..,
+                             S_threshold=.., copy=True).picks
+  Final_models/demo.ipynb    list_pretrained() (:60,92), .weights_docstring (:121), .device/.cuda()
+                             (:224-227), annotate(stream, overlap=, blinding=) -> traces
+                             "<Model>_<label>" (:300-327), classify(...).picks (:397-413)
+  volpick/model/eval_taks0.py:58-89   model.eval(); model(x) on (B,3,T) float32 tensors;
+                             model.name / model.labels / model.device
+  model_training/test.ipynb:231-240   .labels .norm .component_order .default_args
+
+Every numerical stage runs in libvolpick_hip.so (HIP, gfx950) through ctypes; torch is only
+used for device buffers and tensors handed back to the caller.  There is no CPU path: using a
+model without a GPU / without the built library raises ``VolpickHipError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import warnings
+from pathlib import Path
+
+import numpy as np
+
+from . import _lib
+from ._lib import VolpickHipError
+from .picks import ClassifyOutput, Detection, DetectionList, Pick, PickList
+from .stream import Stream, Trace, UTCDateTime
+
+WEIGHTS_DIR = Path(__file__).resolve().parent / "weights"
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+class WaveformModel:
+    """Common host logic: weight registry, device handle, stream handling, annotate/classify."""
+
+    name = "WaveformModel"
+    _kind = -1
+    _weights_subdir = ""
+    in_samples = 0
+    sampling_rate = 100.0
+    # class-level annotate defaults (SeisBench ``_annotate_args``), overridden by the JSON's default_args
+    _annotate_args = {
+        "batch_size": 256,
+        "overlap": 0,
+        "stacking": "avg",
+        "blinding": (0, 0),
+        "*_threshold": 0.3,
+    }
+    _known_args = {"batch_size", "overlap", "stacking", "blinding", "parallelism", "copy", "strict",
+                   "flexible_horizontal_components", "stride"}
+
+    def __init__(self, component_order="ZNE", norm="peak", **kwargs):
+        self.component_order = component_order
+        self.norm = norm
+        self.default_args = {}
+        self.weights_docstring = None
+        self._weights_metadata = None
+        self._weights_version = None
+        self._weights = None  # flat fp32 blob in the library's canonical order
+        self._handle = None
+        self._device_index = None
+        self._max_batch = 256
+        self._training = False
+        if norm not in ("peak", "std"):
+            raise ValueError("norm must be 'peak' or 'std'")
+
+    # ------------------------------------------------------------------ weights
+    @classmethod
+    def list_pretrained(cls, details=False, remote=False):
+        d = WEIGHTS_DIR / cls._weights_subdir
+        names = sorted(p.stem for p in d.glob("*.json"))
+        if details:
+            return {n: json.loads((d / f"{n}.json").read_text()).get("docstring", "") for n in names}
+        return names
+
+    @classmethod
+    def from_pretrained(cls, name, version_str="latest", update=False, force=False, wait_for_file=False):
+        d = WEIGHTS_DIR / cls._weights_subdir
+        meta_path, npz_path = d / f"{name}.json", d / f"{name}.npz"
+        if not meta_path.exists() or not npz_path.exists():
+            raise ValueError(f"No pretrained {cls.__name__} weights '{name}'. Available: {cls.list_pretrained()}")
+        meta = json.loads(meta_path.read_text())
+        with np.load(npz_path) as z:
+            tensors = {k: z[k] for k in z.files}
+        return cls._from_state(meta, tensors)
+
+    @classmethod
+    def load(cls, path, version_str=None):
+        """Load SeisBench-format ``<path>.json[.vN]`` + ``<path>.pt[.vN]`` (torch state dict)."""
+        path = str(path)
+        suffix = f".v{version_str}" if version_str else ""
+        meta = json.loads(Path(path + ".json" + suffix).read_text())
+        sd = _torch().load(path + ".pt" + suffix, map_location="cpu", weights_only=True)
+        return cls._from_state(meta, {k: v.numpy() for k, v in sd.items()})
+
+    @classmethod
+    def _from_state(cls, meta, tensors):
+        model = cls(**meta.get("model_args", {}))
+        model.load_state_dict(tensors)
+        model.default_args = dict(meta.get("default_args", {}))
+        model.weights_docstring = meta.get("docstring")
+        model._weights_version = meta.get("version")
+        model._weights_metadata = meta
+        return model
+
+    def load_state_dict(self, tensors, strict=True):
+        lib = _lib.load()
+        parts = []
+        expected = set()
+        for i in range(lib.vp_param_count(self._kind)):
+            key = lib.vp_param_name(self._kind, i).decode()
+            expected.add(key)
+            if key not in tensors:
+                raise KeyError(f"missing key in state dict: {key}")
+            a = np.asarray(getattr(tensors[key], "numpy", lambda: tensors[key])(), dtype=np.float32).ravel()
+            if a.size != lib.vp_param_size(self._kind, i):
+                raise ValueError(f"size mismatch for {key}: {a.size} vs {lib.vp_param_size(self._kind, i)}")
+            parts.append(a)
+        extra = [k for k in tensors if k not in expected and not k.endswith("num_batches_tracked")]
+        if strict and extra:
+            raise KeyError(f"unexpected keys in state dict: {extra[:5]}")
+        self._weights = np.ascontiguousarray(np.concatenate(parts))
+        self._release()
+
+    # ------------------------------------------------------------------ device
+    @property
+    def device(self):
+        torch = _torch()
+        return torch.device("cpu") if self._device_index is None else torch.device("cuda", self._device_index)
+
+    def cuda(self, device=None):
+        torch = _torch()
+        idx = torch.cuda.current_device() if device is None else torch.device(device if not isinstance(device, int) else f"cuda:{device}").index
+        if idx is None:
+            idx = torch.cuda.current_device()
+        if idx != self._device_index:
+            self._release()
+            self._device_index = idx
+        self._ensure_handle()
+        return self
+
+    def to(self, device):
+        dev = _torch().device(device)
+        if dev.type == "cpu":
+            return self.cpu()
+        return self.cuda(dev)
+
+    def cpu(self):
+        self._release()
+        self._device_index = None
+        return self
+
+    def eval(self):
+        self._training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("this package implements the inference path only")
+        return self.eval()
+
+    def _config(self):
+        lib = _lib.load()
+        cfg = _lib.VpConfig()
+        _lib.check(lib.vp_default_config(self._kind, C.byref(cfg)))
+        cfg.norm = _lib.VP_NORM_PEAK if self.norm == "peak" else _lib.VP_NORM_STD
+        cfg.max_batch = int(self._max_batch)
+        return cfg
+
+    def _ensure_handle(self, weights_device_ptr=None):
+        if self._handle is not None:
+            return self._handle
+        torch = _torch()
+        lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise VolpickHipError("no HIP device visible: the volpick path runs on MI355X only (no CPU fallback)")
+        if self._weights is None:
+            raise VolpickHipError("model has no weights; use from_pretrained() or load_state_dict()")
+        if self._device_index is None:
+            self._device_index = int(os.environ.get("LOCAL_RANK", torch.cuda.current_device())) % torch.cuda.device_count()
+        cfg = self._config()
+        h = C.c_void_p()
+        if weights_device_ptr is not None:
+            ptr, mem = C.c_void_p(weights_device_ptr), _lib.VP_MEM_DEVICE
+        else:
+            ptr, mem = self._weights.ctypes.data_as(C.c_void_p), _lib.VP_MEM_HOST
+        _lib.check(lib.vp_create(self._device_index, self._kind, ptr, self._weights.size, mem, C.byref(cfg),
+                                 C.byref(h)), "vp_create")
+        self._handle = h
+        return h
+
+    def _release(self):
+        if getattr(self, "_handle", None) is not None:
+            try:
+                _lib.load().vp_destroy(self._handle)
+            finally:
+                self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ model(x)
+    def _forward_raw(self, x, preprocess=False):
+        """(B,3,T) float32 torch tensor / ndarray -> (B,n_out,T) tensor on the input's device."""
+        torch = _torch()
+        lib = _lib.load()
+        h = self._ensure_handle()
+        as_numpy = isinstance(x, np.ndarray)
+        if as_numpy:
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        if x.ndim != 3 or x.shape[1] != 3 or x.shape[2] != self.in_samples:
+            raise ValueError(f"expected input of shape (B, 3, {self.in_samples}), got {tuple(x.shape)}")
+        x = x.contiguous().float()
+        B = x.shape[0]
+        on_dev = x.is_cuda
+        if on_dev and x.device.index != self._device_index:
+            raise ValueError(f"input on {x.device} but model on {self.device}")
+        y = torch.empty((B, 3, self.in_samples), dtype=torch.float32, device=x.device)
+        if B == 0:
+            return y
+        if on_dev:
+            torch.cuda.current_stream(x.device).synchronize()
+        mem = _lib.VP_MEM_DEVICE if on_dev else _lib.VP_MEM_HOST
+        _lib.check(lib.vp_forward(h, C.c_void_p(x.data_ptr()), mem, B, int(preprocess), C.c_void_p(y.data_ptr()), mem),
+                   "vp_forward")
+        return y.numpy() if as_numpy else y
+
+    def __call__(self, x, logits=False):
+        if logits:
+            raise NotImplementedError("logits=True is not part of the inference path")
+        return self._format_output(self._forward_raw(x))
+
+    forward = __call__
+
+    def _format_output(self, y):
+        return y
+
+    # ------------------------------------------------------------------ annotate / classify
+    def _argdict(self, kwargs):
+        for k in kwargs:
+            if k not in self._known_args and not k.endswith("_threshold"):
+                warnings.warn(f"Unknown argument '{k}' will be ignored.")
+        args = dict(kwargs)
+        for k in ("overlap", "blinding", "stacking", "batch_size"):
+            if k not in args:
+                args[k] = self.default_args.get(k, self._annotate_args[k])
+        if isinstance(args["overlap"], float) and 0 <= args["overlap"] < 1:  # fraction of the window
+            args["overlap"] = int(self.in_samples * args["overlap"])
+        args["overlap"] = int(args["overlap"])
+        if not 0 <= args["overlap"] < self.in_samples:
+            raise ValueError(f"overlap must be in [0, {self.in_samples}), got {args['overlap']}")
+        b = tuple(int(v) for v in args["blinding"])
+        if len(b) != 2 or min(b) < 0 or b[0] + b[1] >= self.in_samples:
+            raise ValueError(f"invalid blinding {args['blinding']}")
+        args["blinding"] = b
+        if args["stacking"] not in ("avg", "max"):
+            raise ValueError(f"Stacking method {args['stacking']} unknown. Known methods are 'avg' and 'max'.")
+        return args
+
+    def _threshold(self, args, label):
+        key = f"{label}_threshold"
+        if key in args:
+            return float(args[key])
+        if key in self.default_args:
+            return float(self.default_args[key])
+        return float(self._annotate_args.get(key, self._annotate_args["*_threshold"]))
+
+    def _annotate_block(self, data, args):
+        """(3,N) float32 ndarray -> (device tensor (n_out,N) with NaN, first_valid, last_valid, n_windows)."""
+        torch = _torch()
+        lib = _lib.load()
+        h = self._ensure_handle()
+        dev = torch.device("cuda", self._device_index)
+        n = data.shape[1]
+        x = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(dev)
+        out = torch.empty((3, n), dtype=torch.float32, device=dev)
+        torch.cuda.current_stream(dev).synchronize()
+        fv, lv, nw = C.c_int64(), C.c_int64(), C.c_int64()
+        stacking = _lib.VP_STACK_AVG if args["stacking"] == "avg" else _lib.VP_STACK_MAX
+        batch = max(1, min(int(args["batch_size"]), self._max_batch))
+        _lib.check(lib.vp_annotate(h, C.c_void_p(x.data_ptr()), _lib.VP_MEM_DEVICE, n, args["overlap"],
+                                   args["blinding"][0], args["blinding"][1], stacking, batch,
+                                   C.c_void_p(out.data_ptr()), _lib.VP_MEM_DEVICE, C.byref(fv), C.byref(lv),
+                                   C.byref(nw)), "vp_annotate")
+        return out, fv.value, lv.value, nw.value
+
+    def _pick_device(self, trace_dev, thr_on, thr_off, cap=4096):
+        lib = _lib.load()
+        n = trace_dev.numel()
+        while True:
+            on = (C.c_int64 * cap)()
+            off = (C.c_int64 * cap)()
+            peak = (C.c_int64 * cap)()
+            val = (C.c_float * cap)()
+            found = C.c_int()
+            _lib.check(lib.vp_pick(self._handle, C.c_void_p(trace_dev.data_ptr()), _lib.VP_MEM_DEVICE, n, thr_on,
+                                   thr_off, on, off, peak, val, cap, C.byref(found)), "vp_pick")
+            if found.value <= cap:
+                m = found.value
+                return [(on[i], off[i], peak[i], val[i]) for i in range(m)]
+            cap = found.value
+
+    def annotate(self, stream, copy=True, **kwargs):
+        """Sliding-window probability traces, one per label, named ``<Model>_<label>``."""
+        args = self._argdict(kwargs)
+        out = Stream()
+        for grp in _group_stream(stream, self.component_order, self.sampling_rate, copy, self.in_samples):
+            dev_out, fv, lv, nw = self._annotate_block(grp["data"], args)
+            if nw == 0 or fv < 0:
+                continue
+            host = dev_out[:, fv : lv + 1].cpu().numpy()
+            for i, label in enumerate(self.labels):
+                out.append(_make_trace(host[i], grp, fv, self.sampling_rate, f"{self.__class__.__name__}_{label}"))
+        return _maybe_obspy(out, stream)
+
+    def classify(self, stream, copy=True, **kwargs):
+        """``annotate`` + trigger/peak extraction -> ``ClassifyOutput`` with ``.picks`` (and ``.detections``)."""
+        args = self._argdict(kwargs)
+        picks, detections = PickList(), DetectionList()
+        for grp in _group_stream(stream, self.component_order, self.sampling_rate, copy, self.in_samples):
+            dev_out, fv, lv, nw = self._annotate_block(grp["data"], args)
+            if nw == 0 or fv < 0:
+                continue
+            t0 = grp["starttime"] + fv / self.sampling_rate
+            tid = grp["trace_id"]
+            for i, label in enumerate(self.labels):
+                if label == "N":
+                    continue
+                trace = dev_out[i, fv : lv + 1]
+                if label == "Detection":
+                    thr = self._threshold(args, "detection")
+                    for on, off, pk, v in self._pick_device(trace, thr, thr / 2):
+                        detections.append(Detection(tid, t0 + on / self.sampling_rate, t0 + off / self.sampling_rate, v))
+                else:
+                    thr = self._threshold(args, label)
+                    for on, off, pk, v in self._pick_device(trace, thr, thr):
+                        picks.append(Pick(tid, t0 + on / self.sampling_rate, t0 + off / self.sampling_rate,
+                                          t0 + pk / self.sampling_rate, v, label))
+        return ClassifyOutput(self.name, picks=PickList(sorted(picks)), detections=DetectionList(sorted(detections)))
+
+
+class PhaseNet(WaveformModel):
+    name = "PhaseNet"
+    _kind = _lib.VP_MODEL_PHASENET
+    _weights_subdir = "phasenet"
+    in_samples = 3001
+    _annotate_args = dict(WaveformModel._annotate_args, overlap=1500, blinding=(0, 0))
+    _annotate_args["*_threshold"] = 0.3
+
+    def __init__(self, in_channels=3, classes=3, phases="NPS", sampling_rate=100, norm="std", **kwargs):
+        if in_channels != 3 or classes != 3 or len(phases) != 3:
+            raise ValueError("only the released 3-component, 3-class PhaseNet topology is implemented")
+        if sampling_rate != 100:
+            raise ValueError("only 100 Hz models are implemented")
+        super().__init__(norm=norm, **kwargs)
+        self.labels = phases
+        self.in_channels, self.classes = in_channels, classes
+
+
+class EQTransformer(WaveformModel):
+    name = "EQTransformer"
+    _kind = _lib.VP_MODEL_EQTRANSFORMER
+    _weights_subdir = "eqtransformer"
+    in_samples = 6000
+    _annotate_args = dict(WaveformModel._annotate_args, overlap=1800, blinding=(500, 500))
+    _annotate_args["*_threshold"] = 0.1
+    _annotate_args["detection_threshold"] = 0.3
+
+    def __init__(self, in_channels=3, in_samples=6000, classes=2, phases="PS", sampling_rate=100, norm="std",
+                 norm_amp_per_comp=False, **kwargs):
+        if in_channels != 3 or in_samples != 6000 or classes != 2 or len(phases) != 2:
+            raise ValueError("only the released 3-component, 6000-sample, P/S EQTransformer topology is implemented")
+        if kwargs.pop("original_compatible", False):
+            raise ValueError("original_compatible variants are not part of the volpick path")
+        kwargs.pop("lstm_blocks", None), kwargs.pop("drop_rate", None)
+        super().__init__(norm=norm, **kwargs)
+        self.phases = phases
+        self.labels = ["Detection"] + list(phases)
+        self.norm_amp_per_comp = bool(norm_amp_per_comp)
+
+    def _config(self):
+        cfg = super()._config()
+        cfg.norm_amp_per_comp = int(self.norm_amp_per_comp)
+        return cfg
+
+    def _format_output(self, y):
+        return tuple(y[:, i] for i in range(3))  # (detection, P, S), each (B, T)
+
+
+# --------------------------------------------------------------------------- stream handling
+def _group_stream(stream, component_order, sampling_rate, copy, in_samples):
+    """Yield one dict per contiguous block of one instrument: data (3,N) float32 in
+    ``component_order`` (missing components / gaps inside a block zero-filled), start time and
+    ids.  In-repo twin of the array assembly: volpick/data/convert.py:26-70."""
+    traces = list(stream)
+    if copy:
+        traces = [t.copy() for t in traces]
+    if len(traces) == 0:
+        return
+    groups = {}
+    for tr in traces:
+        s = tr.stats
+        if abs(float(s.sampling_rate) - sampling_rate) > 1e-6:
+            raise ValueError(
+                f"trace {tr.id} has sampling rate {s.sampling_rate} Hz; this path expects {sampling_rate} Hz "
+                "(resample the stream first)")
+        groups.setdefault((s.network, s.station, s.location, s.channel[:-1]), []).append(tr)
+    comp_alias = {"1": "N", "2": "E", "3": "Z"}  # flexible horizontal components
+    for (net, sta, loc, cha), trs in sorted(groups.items()):
+        t_start = min(UTCDateTime(t.stats.starttime) for t in trs)
+        ends = [UTCDateTime(t.stats.starttime) + (len(t.data) - 1) / sampling_rate for t in trs]
+        n = int(round((max(ends) - t_start) * sampling_rate)) + 1
+        data = np.zeros((len(component_order), n), dtype=np.float32)
+        covered = np.zeros(n, dtype=bool)
+        for tr in sorted(trs, key=lambda t: len(t.data)):
+            comp = tr.stats.channel[-1] if tr.stats.channel else ""
+            comp = comp if comp in component_order else comp_alias.get(comp, comp)
+            s0 = int(round((UTCDateTime(tr.stats.starttime) - t_start) * sampling_rate))
+            l = min(len(tr.data), n - s0)
+            covered[s0 : s0 + l] = True
+            if comp in component_order:
+                d = np.asarray(tr.data[:l], dtype=np.float32)
+                data[component_order.index(comp), s0 : s0 + l] = np.nan_to_num(d) if np.ma.isMaskedArray(tr.data) else d
+        # contiguous covered runs become independent blocks (gaps are not bridged)
+        edges = np.flatnonzero(np.diff(np.concatenate([[0], covered.view(np.int8), [0]])))
+        for b0, b1 in zip(edges[::2], edges[1::2]):
+            if b1 - b0 < in_samples:
+                warnings.warn("Parts of the input stream consist of fragments shorter than the number of input "
+                              "samples. Output might be empty.")
+                continue
+            yield {
+                "data": data[:, b0:b1],
+                "starttime": t_start + b0 / sampling_rate,
+                "trace_id": f"{net}.{sta}.{loc}",
+                "network": net, "station": sta, "location": loc,
+            }
+
+
+def _make_trace(data, grp, first_valid, sampling_rate, channel):
+    return Trace(data, {
+        "network": grp["network"], "station": grp["station"], "location": grp["location"], "channel": channel,
+        "starttime": grp["starttime"] + first_valid / sampling_rate, "sampling_rate": sampling_rate,
+    })
+
+
+def _maybe_obspy(out, like):
+    """Return an obspy.Stream when the caller passed one (and obspy is importable)."""
+    if type(like).__module__.startswith("obspy"):
+        try:
+            import obspy
+        except ImportError:
+            return out
+        st = obspy.Stream()
+        for tr in out:
+            hdr = dict(tr.stats)
+            hdr["starttime"] = obspy.UTCDateTime(tr.stats.starttime.timestamp)
+            hdr.pop("npts", None)
+            st.append(obspy.Trace(tr.data, hdr))
+        return st
+    return out
