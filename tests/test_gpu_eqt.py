@@ -1,0 +1,158 @@
+"""GPU parity tests for the EQTransformer path: HIP (through the C ABI) vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import pipeline as OP
+from oracle.models import load_pretrained
+from tests.gpu_util import debug_tensors
+from volpick_amd import EQTransformer
+from volpick_amd.synthetic import synthetic_stream_array, synthetic_windows
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return load_pretrained("eqtransformer")
+
+
+@pytest.fixture(scope="module")
+def model():
+    return EQTransformer.from_pretrained("volpick").cuda()
+
+
+def _oracle_stages(net, x):
+    """Every intermediate the device plan materialises, keyed by its tensor name."""
+    out = {}
+    up2 = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
+    with torch.no_grad():
+        h = x
+        for s, (conv, pad) in enumerate(zip(net.encoder.convs, net.encoder.paddings)):
+            y = torch.relu(conv(h))
+            if pad:
+                y = F.pad(y, (0, pad), "constant", -1e10)
+            h = F.max_pool1d(y, 2)
+            out[f"encoder.{s}"] = h
+        h = net.res_cnn_stack(h)
+        out["res.out"] = h
+        for s, blk in enumerate(net.bi_lstm_stack.members):
+            h = blk(h)
+            out[f"bilstm.{s}"] = h
+        h = net.transformer_d0(h)
+        out["transformer_d0"] = h
+        h = net.transformer_d(h)
+        out["transformer_d"] = h
+        dec_in = [h]
+        for lstm, att in zip(net.pick_lstms, net.pick_attentions):
+            px = lstm(h.permute(2, 0, 1))[0].permute(1, 2, 0)
+            px, _ = att(px)
+            dec_in.append(px)
+        out["decoder.in.up"] = torch.cat([up2(t) for t in dec_in], 0)
+        decs = [net.decoder_d, net.pick_decoders[0], net.pick_decoders[1]]
+        hs = list(dec_in)
+        for s in range(7):
+            ys = []
+            for d, dec in enumerate(decs):
+                u = up2(hs[d])
+                if s in dec.crops:
+                    u = u[:, :, :-1]
+                ys.append(torch.relu(dec.convs[s](u)))
+            hs = ys
+            if s < 6:
+                nxt = [up2(y)[:, :, :-1] if (s + 1) in decs[0].crops else up2(y) for y in ys]
+                out[f"decoder.{s}.up"] = torch.cat(nxt, 0)
+            else:
+                out["decoder.6"] = torch.cat(ys, 0)
+        final = net(x)
+    return {k: v.numpy() for k, v in out.items()}, [f.numpy() for f in final]
+
+
+def test_layers_match_oracle(model, oracle):
+    B = 3
+    x = synthetic_windows(B, 6000, seed=21)
+    xn = OP.batch_pre(oracle, torch.from_numpy(x))
+    det, p, s = model(xn)
+    want, final = _oracle_stages(oracle, xn)
+    t = debug_tensors(model, 3 * B)
+    report = []
+    for name, w in want.items():
+        got = t[name][: w.shape[0]]
+        report.append((name, float(np.abs(got - w).max()), float(np.abs(w).max())))
+    print("\n" + "\n".join(f"{n:16s} max|diff| {e:.3e}  (max|ref| {m:.3e})" for n, e, m in report))
+    for n, e, m in report:
+        assert e <= 3e-4 * max(1.0, m), (n, e)
+    for got, w in zip((det, p, s), final):
+        assert np.abs(got.cpu().numpy() - w).max() < TOL
+
+
+@pytest.mark.parametrize("B", [1, 4, 256, 270])
+def test_forward_parity(model, oracle, B):
+    x = synthetic_windows(B, 6000, seed=200 + B)
+    xn = OP.batch_pre(oracle, torch.from_numpy(x))
+    with torch.no_grad():
+        want = oracle(xn)
+    got = model(xn.cuda())
+    assert isinstance(got, tuple) and len(got) == 3
+    for g, w in zip(got, want):
+        g = g.cpu().numpy()
+        assert g.shape == (B, 6000)
+        assert np.abs(g - w.numpy()).max() < TOL
+        assert (g > 0).all() and (g < 1).all()
+
+
+@pytest.mark.parametrize("per_comp", [False, True])
+def test_preprocess_matches_annotate_batch_pre(oracle, per_comp):
+    m = EQTransformer.from_pretrained("volpick")
+    m.norm_amp_per_comp = per_comp
+    m.cuda()
+    oracle.norm_amp_per_comp = per_comp
+    try:
+        x = synthetic_windows(5, 6000, seed=9)
+        x[1] -= 77.0
+        want = OP.batch_pre(oracle, torch.from_numpy(x)).numpy()
+        m._forward_raw(x, preprocess=True)
+        got = debug_tensors(m, 5)["input"]
+        assert np.abs(got - want).max() < 2e-5
+    finally:
+        oracle.norm_amp_per_comp = False
+
+
+@pytest.mark.parametrize("overlap,blinding,stacking", [(5500, (500, 500), "avg"), (1800, (500, 500), "avg"),
+                                                       (3000, (1000, 1000), "max")])
+def test_annotate_parity(model, oracle, overlap, blinding, stacking):
+    data, _, _ = synthetic_stream_array(36_000, seed=1003, n_events=4)
+    want = OP.annotate_array(oracle, data, overlap=overlap, blinding=blinding, stacking=stacking)
+    args = model._argdict(dict(overlap=overlap, blinding=blinding, stacking=stacking))
+    out, fv, lv, nw = model._annotate_block(data, args)
+    out = out.cpu().numpy()
+    assert nw == len(OP.window_starts(36_000, 6000, overlap))
+    for i, (label, off, tr) in enumerate(want):
+        assert off == fv and len(tr) == lv - fv + 1, (label, off, fv, len(tr), lv)
+        got = out[i, fv:lv + 1]
+        assert np.array_equal(np.isnan(got), np.isnan(tr))
+        assert np.nanmax(np.abs(got - tr)) < TOL
+
+
+def test_classify_matches_oracle_and_demo_shape(model, oracle):
+    """Single-component input (as Final_models/demo.ipynb:242,397-398) must work: missing
+    components are zero-filled; picks/detections match the oracle."""
+    from volpick_amd import Stream, Trace, UTCDateTime
+
+    data, _, _ = synthetic_stream_array(6890, seed=77, n_events=1)
+    t0 = UTCDateTime("2005-05-31T21:04:52.110000Z")
+    st = Stream([Trace(data[0], dict(network="NC", station="MMT", location="", channel="EHZ", starttime=t0,
+                                     sampling_rate=100.0))])
+    res = model.classify(st, overlap=1000, blinding=[500, 500], P_threshold=0.15, S_threshold=0.15)
+    zdata = np.zeros_like(data)
+    zdata[0] = data[0]
+    want = OP.classify_array(oracle, zdata, thresholds={"P": 0.15, "S": 0.15}, overlap=1000, blinding=(500, 500))
+    assert len(res.picks) == len(want["picks"])
+    for p, (ph, on, off, pk, v) in zip(res.picks, want["picks"]):
+        assert p.phase == ph and p.trace_id == "NC.MMT."
+        assert abs((p.peak_time - t0) * 100 - pk) <= 1
+        assert abs(p.peak_value - v) < TOL
+    assert len(res.detections) == len(want["detections"])
+    assert str(res.picks).startswith(f"PickList with {len(res.picks)} entries:")

@@ -92,3 +92,60 @@ def test_weight_table_matches_npz(lib):
         for i, k in enumerate(names):
             assert lib.vp_param_name(kind, i).decode() == k
             assert lib.vp_param_size(kind, i) == z[k].size
+
+
+def test_eqt_conv_layers_match_oracle(lib):
+    import torch.nn.functional as F
+
+    net = load_pretrained("eqtransformer")
+    z = np.load(WEIGHTS_DIR / "eqtransformer" / "volpick.npz")
+    w = flat_weights(_lib.VP_MODEL_EQTRANSFORMER, z)
+    assert w.size == lib.vp_weight_count(_lib.VP_MODEL_EQTRANSFORMER) == 378823
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.standard_normal((1, 3, 6000)).astype(np.float32))
+    layers = {}
+    i = 0
+    while True:
+        L = plan_conv(_lib.VP_MODEL_EQTRANSFORMER, w, i)
+        if L is None:
+            break
+        layers[L["name"]] = L
+        i += 1
+    assert len(layers) == 7 + 14 + 7
+
+    def check(name, src, want, **kw):
+        got = emulate_conv(layers[name], src, **kw)
+        assert got.shape == want.shape, (name, got.shape, want.shape)
+        err = np.abs(got - want).max()
+        assert err < 2e-4 * max(1.0, np.abs(want).max()), (name, err)
+
+    with torch.no_grad():
+        # encoder: conv + relu (pre-pool) per stage
+        h = x
+        for s, (conv, pad) in enumerate(zip(net.encoder.convs, net.encoder.paddings)):
+            y = torch.relu(conv(h))
+            check(f"encoder.{s}", h[0].numpy(), y[0].numpy())
+            if pad:
+                y = F.pad(y, (0, pad), "constant", -1e10)
+            h = F.max_pool1d(y, 2)
+        # ResCNN
+        for s, blk in enumerate(net.res_cnn_stack.members):
+            a = torch.relu(blk.norm1(h))
+            pad = (0, 1) if blk.right_pad else (0, 0)
+            m = torch.relu(blk.norm2(blk.conv1(F.pad(a, pad))))
+            check(f"res{s}.conv1", a[0].numpy(), m[0].numpy())
+            c2 = blk.conv2(F.pad(m, pad))
+            check(f"res{s}.conv2", m[0].numpy(), c2[0].numpy())
+            h = h + c2
+        bott = net.bottleneck(x)
+        # decoders: three weight sets per stage; feed the detection decoder's activations to all
+        decs = [net.decoder_d, net.pick_decoders[0], net.pick_decoders[1]]
+        for d, dec in enumerate(decs):
+            h = bott
+            for s, conv in enumerate(dec.convs):
+                u = F.interpolate(h, scale_factor=2, mode="nearest")
+                if s in dec.crops:
+                    u = u[:, :, :-1]
+                y = torch.relu(conv(u))
+                check(f"decoder.{s}", u[0].numpy(), y[0].numpy(), set_index=d, sets=3)
+                h = y

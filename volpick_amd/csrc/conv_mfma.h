@@ -57,6 +57,8 @@ struct ConvArgs {
   const float* e1;    // EPI_RES/DUAL: s2[COUT];                          EPI_SOFTMAX3: b[3]
   const float* e2;    // EPI_RES/DUAL: b2[COUT]
   long e_set_stride;  // per-set stride of e1/e2
+  int ls_res;         // EPI_RES: geometry of the residual tensor
+  long ws_res;
 };
 
 struct ConvGeom {  // runtime mirror of the template parameters (planning / packing / tests)
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     }
   } else if constexpr (C::EPI == EPI_RES) {
     float* d = a.dst + (long)win * a.wsd + a.dst_halo;
-    const float* res = a.e0 + (long)win * a.wsd + a.dst_halo;
+    const float* res = a.e0 + (long)win * a.ws_res + HALO;
     float* d2 = a.dst2 ? a.dst2 + (long)win * a.wsd2 + HALO : nullptr;
     const float* s2 = a.e1 + (long)set * a.e_set_stride;
     const float* b2 = a.e2 + (long)set * a.e_set_stride;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       const int co = idx / C::OW, q = idx - co * C::OW;
       const int t = t0 + q;
       if (t < a.l_out) {
-        const float o = lds[co * C::OS + q] + res[(long)co * a.lsd + t];
+        const float o = lds[co * C::OS + q] + res[(long)co * a.ls_res + t];
         d[(long)co * a.lsd + t] = o;
         if (d2) d2[(long)co * a.lsd2 + t] = fmaxf(fmaf(s2[co], o, b2[co]), 0.f);
       }

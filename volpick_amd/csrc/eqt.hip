@@ -1,8 +1,374 @@
+// EQTransformer (SeisBench topology, volpick weights): launch plan.
+// Reference contract: model(x) on (B,3,6000) -> (detection, P, S), each (B,6000)
+// (volpick/model/eval_taks0.py:68-72, volpick/model/models.py:543; SURVEY.md §8a row A5,
+// Appendix A.4/B.2).
+//
+//   encoder   7 x [Conv1d + ReLU + MaxPool1d(2)]            conv_mfma_kernel, pooled epilogue
+//   ResCNN    7 x [BN-ReLU-Conv, BN-ReLU-Conv, + skip]      conv_mfma_kernel (BN folded / dual epilogue)
+//   BiLSTM    3 x [LSTM(bi) + Conv1d(32,16,1) + BN]         bilstm_kernel
+//   transf.   2 x [additive attention + LN + FF + LN]       transformer_kernel
+//   picks     2 x [LSTM + banded attention]                  pick_branch_kernel
+//   decoders  3 x 7 x [Upsample(2) + Conv1d + ReLU]          conv_mfma_kernel, three weight sets per launch,
+//                                                            the producer writes its rows x2-upsampled
+//   heads     3 x [Conv1d(8,1,11) + sigmoid]                 head_kernel
+#include "eqt_kernels.h"
 #include "net.h"
+
 namespace vp {
-int plan_eqt(Net& net, const ParamView& pv) {
-  (void)net; (void)pv;
-  set_error("EQTransformer plan not built yet");
-  return VP_ERR_UNSUPPORTED;
+
+namespace {
+
+//                      CIN1 CIN2 COUT P TAPS SN IN_OFF OUT_OFF WM WN NW RELU EPI
+using EQ_e0 = ConvCfg<3, 0, 8, 2, 12, 2, -5, 0, 1, 4, 8, 1, EPI_POOL2>;
+using EQ_e1 = ConvCfg<8, 0, 16, 1, 9, 1, -4, 0, 1, 4, 8, 1, EPI_POOL2>;
+using EQ_e2 = ConvCfg<16, 0, 16, 1, 7, 1, -3, 0, 1, 4, 6, 1, EPI_POOL2>;
+using EQ_e3 = ConvCfg<16, 0, 32, 1, 7, 1, -3, 0, 2, 2, 6, 1, EPI_POOL2>;
+using EQ_e4 = ConvCfg<32, 0, 32, 1, 5, 1, -2, 0, 2, 2, 6, 1, EPI_POOL2>;
+using EQ_e5 = ConvCfg<32, 0, 64, 1, 5, 1, -2, 0, 4, 1, 6, 1, EPI_POOL2>;
+using EQ_e6 = ConvCfg<64, 0, 64, 1, 3, 1, -1, 0, 4, 1, 6, 1, EPI_POOL2_DUAL>;
+using EQ_r1k3 = ConvCfg<64, 0, 64, 1, 3, 1, -1, 0, 4, 1, 3, 1, EPI_STORE>;
+using EQ_r1k2 = ConvCfg<64, 0, 64, 1, 2, 1, 0, 0, 4, 1, 3, 1, EPI_STORE>;
+using EQ_r2k3 = ConvCfg<64, 0, 64, 1, 3, 1, -1, 0, 4, 1, 3, 0, EPI_RES>;
+using EQ_r2k2 = ConvCfg<64, 0, 64, 1, 2, 1, 0, 0, 4, 1, 3, 0, EPI_RES>;
+using EQ_d0 = ConvCfg<16, 0, 64, 1, 3, 1, -1, 0, 4, 1, 6, 1, EPI_UP2>;
+using EQ_d1 = ConvCfg<64, 0, 64, 1, 5, 1, -2, 0, 4, 1, 6, 1, EPI_UP2>;
+using EQ_d2 = ConvCfg<64, 0, 32, 1, 5, 1, -2, 0, 2, 2, 6, 1, EPI_UP2>;
+using EQ_d3 = ConvCfg<32, 0, 32, 1, 7, 1, -3, 0, 2, 2, 6, 1, EPI_UP2>;
+using EQ_d4 = ConvCfg<32, 0, 16, 1, 7, 1, -3, 0, 1, 4, 6, 1, EPI_UP2>;
+using EQ_d5 = ConvCfg<16, 0, 16, 1, 9, 1, -4, 0, 1, 4, 8, 1, EPI_UP2>;
+using EQ_d6 = ConvCfg<16, 0, 8, 2, 12, 2, -5, 0, 1, 4, 8, 1, EPI_STORE>;
+
+std::vector<float> vec(const float* p, size_t n) { return std::vector<float>(p, p + n); }
+
+std::vector<float> pack_plain(const ParamView& pv, const std::string& conv, int cout, int cin, int K, const ConvGeom& g,
+                              const float* row_scale = nullptr) {
+  return pack_afrag(amat_conv(pv.get(conv + ".weight"), cout, cin, K, 1, g.P, g.cinp(), row_scale), g.M(), g.cinp(),
+                    g.taps);
 }
+
+template <class Cfg>
+ConvLayer* add_plain(Net& net, const ParamView& pv, const std::string& name, const std::string& conv, int cout,
+                     int cin, int K, int src, int dst, int cols, int l_out) {
+  ConvLayer* L = net.add_conv<Cfg>(name, src, -1, dst, cols, l_out, pack_plain(pv, conv, cout, cin, K, Cfg::geom()),
+                                   vec(pv.get(conv + ".bias"), cout));
+  L->flops_per_window = 2.0 * cout * cin * K * l_out;
+  net.steps.back().flops_per_window = L->flops_per_window;
+  return L;
+}
+
+LstmWeights lstm_weights(Net& net, const ParamView& pv, const std::string& prefix, const std::string& suffix, int cin) {
+  const float* bi = pv.get(prefix + "bias_ih_l0" + suffix);
+  const float* bh = pv.get(prefix + "bias_hh_l0" + suffix);
+  std::vector<float> b(64);
+  for (int i = 0; i < 64; ++i) b[i] = bi[i] + bh[i];
+  LstmWeights w{};
+  // device pointers are patched after upload(); stash the blobs
+  HostBlob* wih = net.add_blob(vec(pv.get(prefix + "weight_ih_l0" + suffix), (size_t)64 * cin));
+  HostBlob* whh = net.add_blob(vec(pv.get(prefix + "weight_hh_l0" + suffix), (size_t)64 * 16));
+  HostBlob* bb = net.add_blob(b);
+  w.w_ih = reinterpret_cast<const float*>(wih);
+  w.w_hh = reinterpret_cast<const float*>(whh);
+  w.b = reinterpret_cast<const float*>(bb);
+  return w;
+}
+// The structs above temporarily hold HostBlob* in their float* fields; resolve at run time.
+inline const float* dptr(const float* stash) { return reinterpret_cast<const HostBlob*>(stash)->d; }
+LstmWeights resolve(const LstmWeights& w) { return LstmWeights{dptr(w.w_ih), dptr(w.w_hh), dptr(w.b)}; }
+
+AttnWeights attn_weights(Net& net, const ParamView& pv, const std::string& prefix) {
+  AttnWeights w{};
+  w.Wt = reinterpret_cast<const float*>(net.add_blob(vec(pv.get(prefix + "Wt"), 16 * 32)));
+  w.Wx = reinterpret_cast<const float*>(net.add_blob(vec(pv.get(prefix + "Wx"), 16 * 32)));
+  w.bh = reinterpret_cast<const float*>(net.add_blob(vec(pv.get(prefix + "bh"), 32)));
+  w.Wa = reinterpret_cast<const float*>(net.add_blob(vec(pv.get(prefix + "Wa"), 32)));
+  return w;
+}
+AttnWeights resolve(const AttnWeights& w) { return AttnWeights{dptr(w.Wt), dptr(w.Wx), dptr(w.bh), dptr(w.Wa)}; }
+
+}  // namespace
+
+int plan_eqt(Net& net, const ParamView& pv) {
+  const float eps = net.cfg.bn_eps;
+  const int T = 6000;
+  net.in_samples = T;
+  net.n_out = 3;
+  const int filt[7] = {8, 16, 16, 32, 32, 64, 64};
+  const int rker[7] = {3, 3, 3, 3, 2, 3, 2};
+  int len[8];
+  len[0] = T;
+  for (int i = 0; i < 7; ++i) len[i + 1] = (len[i] + 1) / 2;  // 3000 1500 750 375 188 94 47
+
+  // ---- encoder -----------------------------------------------------------------------
+  const int x = net.add_tensor("input", 3, T);
+  net.input = x;
+  int enc[7];
+  for (int i = 0; i < 7; ++i) enc[i] = net.add_tensor("encoder." + std::to_string(i), filt[i], len[i + 1]);
+  const int act0 = net.add_tensor("res.act", 64, EQT_T);  // relu(bn1(x)) feeding each block's conv1
+  ConvLayer* L;
+  add_plain<EQ_e0>(net, pv, "encoder.0", "encoder.convs.0", 8, 3, 11, x, enc[0], 3000, 6000);
+  add_plain<EQ_e1>(net, pv, "encoder.1", "encoder.convs.1", 16, 8, 9, enc[0], enc[1], 3000, 3000);
+  add_plain<EQ_e2>(net, pv, "encoder.2", "encoder.convs.2", 16, 16, 7, enc[1], enc[2], 1500, 1500);
+  add_plain<EQ_e3>(net, pv, "encoder.3", "encoder.convs.3", 32, 16, 7, enc[2], enc[3], 750, 750);
+  add_plain<EQ_e4>(net, pv, "encoder.4", "encoder.convs.4", 32, 32, 5, enc[3], enc[4], 375, 375);
+  add_plain<EQ_e5>(net, pv, "encoder.5", "encoder.convs.5", 64, 32, 5, enc[4], enc[5], 188, 188);
+  L = add_plain<EQ_e6>(net, pv, "encoder.6", "encoder.convs.6", 64, 64, 3, enc[5], enc[6], 94, 94);
+  {
+    std::vector<float> s, b;
+    bn_fold(pv, "res_cnn_stack.members.0.norm1", 64, eps, nullptr, &s, &b);
+    L->dst2 = act0;
+    L->e1.h = s;
+    L->e2.h = b;
+  }
+
+  // ---- ResCNN stack ---------------------------------------------------------------------
+  const int mid = net.add_tensor("res.mid", 64, EQT_T);
+  const int ping[2] = {net.add_tensor("res.xa", 64, EQT_T), net.add_tensor("res.xb", 64, EQT_T)};
+  int x_cur = enc[6];  // residual stream; block i reads x_cur and writes ping[i & 1]
+  for (int i = 0; i < 7; ++i) {
+    const std::string p = "res_cnn_stack.members." + std::to_string(i);
+    const int K = rker[i];
+    // conv1: relu(bn1 x) -> conv -> bn2 -> relu       [bn2 folded into conv1's weights]
+    std::vector<float> s2, b2;
+    bn_fold(pv, p + ".norm2", 64, eps, pv.get(p + ".conv1.bias"), &s2, &b2);
+    if (K == 3) {
+      L = net.add_conv<EQ_r1k3>("res" + std::to_string(i) + ".conv1", act0, -1, mid, EQT_T, EQT_T,
+                                pack_plain(pv, p + ".conv1", 64, 64, 3, EQ_r1k3::geom(), s2.data()), b2);
+    } else {
+      L = net.add_conv<EQ_r1k2>("res" + std::to_string(i) + ".conv1", act0, -1, mid, EQT_T, EQT_T,
+                                pack_plain(pv, p + ".conv1", 64, 64, 2, EQ_r1k2::geom(), s2.data()), b2);
+    }
+    L->flops_per_window = 2.0 * 64 * 64 * K * EQT_T;
+    net.steps.back().flops_per_window = L->flops_per_window;
+    // conv2 + skip; second output = relu(bn1 of the NEXT block), the input of its conv1
+    const int x_next = ping[i & 1];
+    if (K == 3) {
+      L = net.add_conv<EQ_r2k3>("res" + std::to_string(i) + ".conv2", mid, -1, x_next, EQT_T, EQT_T,
+                                pack_plain(pv, p + ".conv2", 64, 64, 3, EQ_r2k3::geom()),
+                                vec(pv.get(p + ".conv2.bias"), 64));
+    } else {
+      L = net.add_conv<EQ_r2k2>("res" + std::to_string(i) + ".conv2", mid, -1, x_next, EQT_T, EQT_T,
+                                pack_plain(pv, p + ".conv2", 64, 64, 2, EQ_r2k2::geom()),
+                                vec(pv.get(p + ".conv2.bias"), 64));
+    }
+    L->res = x_cur;
+    std::vector<float> s1(64, 0.f), b1(64, 0.f);
+    if (i < 6) {
+      bn_fold(pv, "res_cnn_stack.members." + std::to_string(i + 1) + ".norm1", 64, eps, nullptr, &s1, &b1);
+      L->dst2 = act0;
+    }
+    L->e1.h = s1;
+    L->e2.h = b1;
+    L->flops_per_window = 2.0 * 64 * 64 * K * EQT_T;
+    net.steps.back().flops_per_window = L->flops_per_window;
+    x_cur = x_next;
+  }
+  const int res_out = x_cur;
+
+  // ---- BiLSTM stack ---------------------------------------------------------------------
+  int lstm_in = res_out;
+  for (int i = 0; i < 3; ++i) {
+    const std::string p = "bi_lstm_stack.members." + std::to_string(i);
+    const int cin = (i == 0) ? 64 : 16;
+    const int out = net.add_tensor("bilstm." + std::to_string(i), 16, EQT_T);
+    LstmWeights fw = lstm_weights(net, pv, p + ".lstm.", "", cin);
+    LstmWeights bw = lstm_weights(net, pv, p + ".lstm.", "_reverse", cin);
+    std::vector<float> s, b;
+    bn_fold(pv, p + ".norm", 16, eps, pv.get(p + ".conv.bias"), &s, &b);
+    std::vector<float> wc = vec(pv.get(p + ".conv.weight"), 16 * 32);
+    for (int co = 0; co < 16; ++co)
+      for (int c = 0; c < 32; ++c) wc[co * 32 + c] *= s[co];
+    HostBlob* wcb = net.add_blob(wc);
+    HostBlob* bcb = net.add_blob(b);
+    Step st;
+    st.name = "bilstm." + std::to_string(i);
+    st.flops_per_window = 2.0 * 2 * EQT_T * (64.0 * cin + 64.0 * 16) + 2.0 * 16 * 32 * EQT_T;
+    const int src_t = lstm_in;
+    st.run = [=](Net& n, int B, hipStream_t s_) -> int {
+      BiLstmArgs a{};
+      const Tensor& s0 = n.tensors[src_t];
+      const Tensor& d0 = n.tensors[out];
+      a.src = s0.p;
+      a.ls_src = s0.ls;
+      a.ws_src = (long)s0.win_stride();
+      a.dst = d0.p;
+      a.ls_dst = d0.ls;
+      a.ws_dst = (long)d0.win_stride();
+      a.fwd = resolve(fw);
+      a.bwd = resolve(bw);
+      a.wc = wcb->d;
+      a.bc = bcb->d;
+      return launch_bilstm(a, cin, B, s_);
+    };
+    net.steps.push_back(std::move(st));
+    lstm_in = out;
+  }
+
+  // ---- transformers -----------------------------------------------------------------------
+  const int dec_in = net.add_tensor("decoder.in.up", 16, 2 * EQT_T, 3);  // x2-upsampled inputs of the 3 decoders
+  int tr_in = lstm_in;
+  const char* tr_names[2] = {"transformer_d0", "transformer_d"};
+  for (int i = 0; i < 2; ++i) {
+    const std::string p = tr_names[i];
+    const int out = net.add_tensor(p, 16, EQT_T);
+    AttnWeights aw = attn_weights(net, pv, p + ".attention.");
+    HostBlob* g1 = net.add_blob(vec(pv.get(p + ".norm1.gamma"), 16));
+    HostBlob* b1 = net.add_blob(vec(pv.get(p + ".norm1.beta"), 16));
+    HostBlob* g2 = net.add_blob(vec(pv.get(p + ".norm2.gamma"), 16));
+    HostBlob* b2 = net.add_blob(vec(pv.get(p + ".norm2.beta"), 16));
+    HostBlob* w1 = net.add_blob(vec(pv.get(p + ".ff.lin1.weight"), 128 * 16));
+    HostBlob* bb1 = net.add_blob(vec(pv.get(p + ".ff.lin1.bias"), 128));
+    HostBlob* w2 = net.add_blob(vec(pv.get(p + ".ff.lin2.weight"), 16 * 128));
+    HostBlob* bb2 = net.add_blob(vec(pv.get(p + ".ff.lin2.bias"), 16));
+    Step st;
+    st.name = p;
+    st.flops_per_window = 2.0 * (2 * EQT_T * 16 * 32 + EQT_T * EQT_T * 32 * 2 + EQT_T * EQT_T * 16 + 2 * EQT_T * 16 * 128);
+    const int src_t = tr_in;
+    const bool last = (i == 1);
+    const float attn_eps = net.cfg.attention_eps, ln_eps = net.cfg.layernorm_eps;
+    st.run = [=](Net& n, int B, hipStream_t s_) -> int {
+      TransformerArgs a{};
+      const Tensor& s0 = n.tensors[src_t];
+      const Tensor& d0 = n.tensors[out];
+      a.src = s0.p;
+      a.ls_src = s0.ls;
+      a.ws_src = (long)s0.win_stride();
+      a.dst = d0.p;
+      a.ls_dst = d0.ls;
+      a.ws_dst = (long)d0.win_stride();
+      if (last) {
+        const Tensor& u = n.tensors[dec_in];
+        a.up = u.p;
+        a.ls_up = u.ls;
+        a.ws_up = (long)u.win_stride();
+      }
+      a.att = resolve(aw);
+      a.g1 = g1->d;
+      a.b1 = b1->d;
+      a.g2 = g2->d;
+      a.b2 = b2->d;
+      a.w1 = w1->d;
+      a.bb1 = bb1->d;
+      a.w2 = w2->d;
+      a.bb2 = bb2->d;
+      a.attn_eps = attn_eps;
+      a.ln_eps = ln_eps;
+      return launch_transformer(a, B, s_);
+    };
+    net.steps.push_back(std::move(st));
+    tr_in = out;
+  }
+
+  // ---- P / S branches: LSTM + banded attention ------------------------------------------------
+  {
+    LstmWeights lw[2];
+    AttnWeights aw[2];
+    for (int br = 0; br < 2; ++br) {
+      lw[br] = lstm_weights(net, pv, "pick_lstms." + std::to_string(br) + ".", "", 16);
+      aw[br] = attn_weights(net, pv, "pick_attentions." + std::to_string(br) + ".");
+    }
+    Step st;
+    st.name = "pick_branches";
+    st.flops_per_window = 2.0 * (2.0 * EQT_T * (64 * 16 + 64 * 16) + 2.0 * (2 * EQT_T * 16 * 32 + EQT_T * EQT_T * 32 * 2 + EQT_T * EQT_T * 16));
+    const int src_t = tr_in;
+    const float attn_eps = net.cfg.attention_eps;
+    st.run = [=](Net& n, int B, hipStream_t s_) -> int {
+      PickBranchArgs a{};
+      const Tensor& s0 = n.tensors[src_t];
+      const Tensor& u = n.tensors[dec_in];
+      a.src = s0.p;
+      a.ls_src = s0.ls;
+      a.ws_src = (long)s0.win_stride();
+      a.up = u.p;
+      a.ls_up = u.ls;
+      a.ws_up = (long)u.win_stride();
+      a.B = B;
+      for (int br = 0; br < 2; ++br) {
+        a.lstm[br] = resolve(lw[br]);
+        a.att[br] = resolve(aw[br]);
+      }
+      a.attn_eps = attn_eps;
+      a.width = 3;
+      return launch_pick_branch(a, s_);
+    };
+    net.steps.push_back(std::move(st));
+  }
+
+  // ---- three decoders, one launch per stage ----------------------------------------------------
+  const int dlen[7] = {94, 188, 375, 750, 1500, 3000, 6000};  // conv length of stage i (= its upsampled input)
+  const int dco[7] = {64, 64, 32, 32, 16, 16, 8};
+  const int dci[7] = {16, 64, 64, 32, 32, 16, 16};
+  const int dk[7] = {3, 5, 5, 7, 7, 9, 11};
+  const char* dec_prefix[3] = {"decoder_d", "pick_decoders.0", "pick_decoders.1"};
+  int dsrc = dec_in;
+  for (int i = 0; i < 7; ++i) {
+    const int up_len = (i < 6) ? dlen[i + 1] : T;
+    const int dst = net.add_tensor("decoder." + std::to_string(i) + (i < 6 ? ".up" : ""), dco[i], up_len, 3);
+    auto pack3 = [&](const ConvGeom& g, std::vector<float>* af, std::vector<float>* bs) {
+      for (int d = 0; d < 3; ++d) {
+        const std::string c = std::string(dec_prefix[d]) + ".convs." + std::to_string(i);
+        std::vector<float> a = pack_plain(pv, c, dco[i], dci[i], dk[i], g);
+        af->insert(af->end(), a.begin(), a.end());
+        const float* b = pv.get(c + ".bias");
+        bs->insert(bs->end(), b, b + dco[i]);
+      }
+    };
+    std::vector<float> af, bs;
+    const std::string nm = "decoder." + std::to_string(i);
+    const int cols = (i == 6) ? dlen[i] / 2 : dlen[i];
+#define EQ_DEC(CFG)                                                  \
+  pack3(CFG::geom(), &af, &bs);                                      \
+  L = net.add_conv<CFG>(nm, dsrc, -1, dst, cols, dlen[i], af, bs, 3);
+    switch (i) {
+      case 0: EQ_DEC(EQ_d0) break;
+      case 1: EQ_DEC(EQ_d1) break;
+      case 2: EQ_DEC(EQ_d2) break;
+      case 3: EQ_DEC(EQ_d3) break;
+      case 4: EQ_DEC(EQ_d4) break;
+      case 5: EQ_DEC(EQ_d5) break;
+      default: EQ_DEC(EQ_d6) break;
+    }
+#undef EQ_DEC
+    L->l_dst = up_len;
+    L->flops_per_window = 3 * 2.0 * dco[i] * dci[i] * dk[i] * dlen[i];
+    net.steps.back().flops_per_window = L->flops_per_window;
+    dsrc = dst;
+  }
+
+  // ---- heads --------------------------------------------------------------------------------
+  {
+    std::vector<float> w, b;
+    const char* head[3] = {"conv_d", "pick_convs.0", "pick_convs.1"};
+    for (int d = 0; d < 3; ++d) {
+      const float* hw = pv.get(std::string(head[d]) + ".weight");
+      w.insert(w.end(), hw, hw + 88);
+      b.push_back(pv.get(std::string(head[d]) + ".bias")[0]);
+    }
+    HostBlob* wb = net.add_blob(w);
+    HostBlob* bb = net.add_blob(b);
+    net.need(dsrc, HALO + T + 8);
+    Step st;
+    st.name = "heads";
+    st.flops_per_window = 3 * 2.0 * 8 * 11 * T;
+    const int src_t = dsrc;
+    st.run = [=](Net& n, int B, hipStream_t s_) -> int {
+      HeadArgs a{};
+      const Tensor& s0 = n.tensors[src_t];
+      a.src = s0.p;
+      a.ls_src = s0.ls;
+      a.ws_src = (long)s0.win_stride();
+      a.y = n.y;
+      a.w = wb->d;
+      a.b = bb->d;
+      a.B = B;
+      a.T = n.in_samples;
+      return launch_head(a, s_);
+    };
+    net.steps.push_back(std::move(st));
+  }
+
+  net.flops_per_window = 0;
+  for (auto& s : net.steps) net.flops_per_window += s.flops_per_window;
+  return VP_OK;
+}
+
 }  // namespace vp

@@ -1,0 +1,90 @@
+// EQTransformer bottleneck kernels (sequence length 47, 16 channels): BiLSTM blocks,
+// additive-attention transformer blocks, the P/S pick branches (LSTM + banded attention)
+// and the 8->1 sigmoid heads.  SURVEY.md §8a row A5, Appendix A.4/B.2.
+//
+// These stages are latency-bound (47 sequential LSTM steps; 47x47x32 tanh per attention)
+// and hold <2 % of the model's FLOPs, so they are plain VALU code: one workgroup per
+// window, activations in LDS, wavefront shuffles / readlanes for the recurrent state and
+// the softmax-style row reductions.
+#pragma once
+#include "vp_common.h"
+
+namespace vp {
+
+constexpr int EQT_T = 47;  // bottleneck sequence length (6000 / 2^7)
+constexpr int EQT_H = 16;  // hidden size / channels
+
+struct LstmWeights {  // one direction, torch layout, gate order i,f,g,o
+  const float* w_ih;  // [64][CIN]
+  const float* w_hh;  // [64][16]
+  const float* b;     // [64] = b_ih + b_hh
+};
+
+struct BiLstmArgs {
+  const float* src;  // [B][CIN][ls]
+  int ls_src;
+  long ws_src;
+  float* dst;        // [B][16][ls]
+  int ls_dst;
+  long ws_dst;
+  LstmWeights fwd, bwd;
+  const float* wc;   // folded conv1x1+BN: [16][32]
+  const float* bc;   // [16]
+};
+
+struct AttnWeights {
+  const float* Wt;  // [16][32]
+  const float* Wx;  // [16][32]
+  const float* bh;  // [32]
+  const float* Wa;  // [32]
+};
+
+struct TransformerArgs {
+  const float* src;  // [B][16][ls]
+  int ls_src;
+  long ws_src;
+  float* dst;        // [B][16][ls]
+  int ls_dst;
+  long ws_dst;
+  float* up;         // optional: decoder input, x2-upsampled rows [B][16][ls_up] (set 0)
+  int ls_up;
+  long ws_up;
+  AttnWeights att;
+  const float *g1, *b1, *g2, *b2;  // LayerNormalization gamma/beta [16]
+  const float* w1;   // [128][16]
+  const float* bb1;  // [128]
+  const float* w2;   // [16][128]
+  const float* bb2;  // [16]
+  float attn_eps, ln_eps;
+};
+
+struct PickBranchArgs {
+  const float* src;  // transformer output [B][16][ls]
+  int ls_src;
+  long ws_src;
+  float* up;         // decoder input sets 1..2: [3B][16][ls_up], x2-upsampled
+  int ls_up;
+  long ws_up;
+  int B;
+  LstmWeights lstm[2];
+  AttnWeights att[2];
+  float attn_eps;
+  int width;         // band width (3)
+};
+
+struct HeadArgs {
+  const float* src;  // [3B][8][ls]
+  int ls_src;
+  long ws_src;
+  float* y;          // dense [B][3][T]
+  const float* w;    // [3 sets][8][11]
+  const float* b;    // [3]
+  int B, T;
+};
+
+int launch_bilstm(const BiLstmArgs& a, int cin, int B, hipStream_t s);
+int launch_transformer(const TransformerArgs& a, int B, hipStream_t s);
+int launch_pick_branch(const PickBranchArgs& a, hipStream_t s);
+int launch_head(const HeadArgs& a, hipStream_t s);
+
+}  // namespace vp

@@ -1,0 +1,328 @@
+// EQTransformer bottleneck kernels; see eqt_kernels.h.
+#include "eqt_kernels.h"
+
+namespace vp {
+
+namespace {
+
+constexpr int T = EQT_T;
+
+__device__ inline float wave_sum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ inline float lane_bcast(float v, int lane) {  // lane is a compile-time constant
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ inline float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+// tanh via one exp; abs error ~1e-7, saturates correctly at +-inf
+__device__ inline float tanh_fast(float z) {
+  const float t = __expf(2.f * z);
+  return 1.f - 2.f * __frcp_rn(t + 1.f);
+}
+
+// One LSTM direction on ONE wavefront.  Lane j owns gate row j (torch order i,f,g,o x 16
+// units): its W_ih / W_hh rows sit in registers.  h_{t-1} is broadcast with v_readlane, the
+// four gates of a unit are gathered with three ds_bpermute shuffles, c/h are kept
+// redundantly in all four 16-lane groups.  xs: LDS [T][CIN]; gx: LDS [T][64] per-lane
+// scratch for the input projection; hout: LDS rows [16][hs].
+template <int CIN>
+__device__ void lstm_direction(const float* xs, float* gx, const LstmWeights w, const bool reverse, float* hout,
+                               const int hs) {
+  const int lane = threadIdx.x & 63;
+  {
+    float wih[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) wih[c] = w.w_ih[lane * CIN + c];
+    const float b = w.b[lane];
+    for (int t = 0; t < T; ++t) {
+      float a0 = b, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+      for (int c = 0; c < CIN; c += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(xs + t * CIN + c);  // same address in every lane
+        a0 = fmaf(wih[c], x.x, a0);
+        a1 = fmaf(wih[c + 1], x.y, a1);
+        a2 = fmaf(wih[c + 2], x.z, a2);
+        a3 = fmaf(wih[c + 3], x.w, a3);
+      }
+      gx[t * 64 + lane] = (a0 + a1) + (a2 + a3);
+    }
+  }
+  float whh[EQT_H];
+#pragma unroll
+  for (int u = 0; u < EQT_H; ++u) whh[u] = w.w_hh[lane * EQT_H + u];
+  const int u = lane & 15;
+  const bool is_g = (lane >> 4) == 2;
+  float h = 0.f, c = 0.f;
+  for (int s = 0; s < T; ++s) {
+    const int t = reverse ? T - 1 - s : s;
+    float g0 = gx[t * 64 + lane], g1 = 0.f, g2 = 0.f, g3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < EQT_H; k += 4) {
+      g0 = fmaf(whh[k], lane_bcast(h, k), g0);
+      g1 = fmaf(whh[k + 1], lane_bcast(h, k + 1), g1);
+      g2 = fmaf(whh[k + 2], lane_bcast(h, k + 2), g2);
+      g3 = fmaf(whh[k + 3], lane_bcast(h, k + 3), g3);
+    }
+    const float g = (g0 + g1) + (g2 + g3);
+    const float act = is_g ? tanhf(g) : sigmoid_f(g);
+    const float ig = __shfl(act, u, 64), fg = __shfl(act, u + 16, 64);
+    const float gg = __shfl(act, u + 32, 64), og = __shfl(act, u + 48, 64);
+    c = fmaf(fg, c, ig * gg);
+    h = og * tanhf(c);
+    if (lane < EQT_H) hout[lane * hs + t] = h;
+  }
+}
+
+// Additive self-attention on one window held in LDS (SeisBench SeqSelfAttention):
+//   e[i][j] = Wa . tanh(x_i Wt + x_j Wx + bh)   (+ ba, which cancels in e - max_j e)
+//   a = exp(e - rowmax) [band mask] / (sum + eps),  v = a x.
+// The row max is taken over the FULL row before the band mask, as upstream does.
+constexpr int KP = 33;  // padded row of q/k: consecutive rows hit consecutive LDS banks
+__device__ void attention_core(const float (*xs)[EQT_H], float (*q)[KP], float (*k)[KP], float (*e)[48],
+                               float (*v)[EQT_H], const AttnWeights w, const float eps, const int width) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int idx = tid; idx < T * 32; idx += nt) {
+    const int t = idx >> 5, u = idx & 31;
+    float aq = 0.f, ak = w.bh[u];
+#pragma unroll
+    for (int c = 0; c < EQT_H; ++c) {
+      aq = fmaf(xs[t][c], w.Wt[c * 32 + u], aq);
+      ak = fmaf(xs[t][c], w.Wx[c * 32 + u], ak);
+    }
+    q[t][u] = aq;
+    k[t][u] = ak;
+  }
+  __syncthreads();
+  {
+    float wa[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) wa[u] = w.Wa[u];
+    for (int idx = tid; idx < T * T; idx += nt) {
+      const int i = idx / T, j = idx - i * T;
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int u = 0; u < 32; u += 2) {
+        s0 = fmaf(wa[u], tanh_fast(q[i][u] + k[j][u]), s0);
+        s1 = fmaf(wa[u + 1], tanh_fast(q[i][u + 1] + k[j][u + 1]), s1);
+      }
+      e[i][j] = s0 + s1;
+    }
+  }
+  __syncthreads();
+  {
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    for (int i = wave; i < T; i += nw) {
+      const float x = (lane < T) ? e[i][lane] : -INFINITY;
+      const float m = wave_max64(x);
+      float ex = (lane < T) ? expf(x - m) : 0.f;
+      if (width > 0) {
+        const int lower = lane - width / 2;  // mask[i][j] = lower_j <= i < lower_j + width
+        if (!(lower <= i && i < lower + width)) ex = 0.f;
+      }
+      const float sum = wave_sum64(ex);
+      if (lane < T) e[i][lane] = ex / (sum + eps);
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < T * EQT_H; idx += nt) {
+    const int i = idx >> 4, c = idx & 15;
+    float acc = 0.f;
+    for (int j = 0; j < T; ++j) acc = fmaf(e[i][j], xs[j][c], acc);
+    v[i][c] = acc;
+  }
+  __syncthreads();
+}
+
+__device__ inline void load_window_transposed(const float* src, int ls, float (*xs)[EQT_H]) {
+  for (int idx = threadIdx.x; idx < EQT_H * T; idx += blockDim.x) {
+    const int c = idx / T, t = idx - c * T;
+    xs[t][c] = src[(long)c * ls + HALO + t];
+  }
+}
+
+// LayerNormalization over the channel axis of one time step (eps under the sqrt).
+__device__ inline void layer_norm16(const float* z, const float* gamma, const float* beta, float eps, float* out) {
+  float mean = 0.f;
+#pragma unroll
+  for (int c = 0; c < EQT_H; ++c) mean += z[c];
+  mean *= (1.f / EQT_H);
+  float var = 0.f;
+#pragma unroll
+  for (int c = 0; c < EQT_H; ++c) var = fmaf(z[c] - mean, z[c] - mean, var);
+  var = var * (1.f / EQT_H) + eps;
+  const float sd = sqrtf(var);
+#pragma unroll
+  for (int c = 0; c < EQT_H; ++c) out[c] = (z[c] - mean) / sd * gamma[c] + beta[c];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(128) void bilstm_kernel(const BiLstmArgs a) {
+  __shared__ __attribute__((aligned(16))) float xs[T * CIN];
+  __shared__ float gx[2][T * 64];
+  __shared__ float hc[32][48];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const float* src = a.src + (long)b * a.ws_src;
+  for (int idx = tid; idx < CIN * T; idx += 128) {
+    const int c = idx / T, t = idx - c * T;
+    xs[t * CIN + c] = src[(long)c * a.ls_src + HALO + t];
+  }
+  __syncthreads();
+  const int wave = tid >> 6;
+  lstm_direction<CIN>(xs, gx[wave], wave == 0 ? a.fwd : a.bwd, wave == 1, &hc[wave * 16][0], 48);
+  __syncthreads();
+  float* dst = a.dst + (long)b * a.ws_dst;
+  for (int idx = tid; idx < EQT_H * T; idx += 128) {  // Conv1d(32,16,1) + BatchNorm, folded
+    const int co = idx / T, t = idx - co * T;
+    float acc = a.bc[co];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc = fmaf(a.wc[co * 32 + c], hc[c][t], acc);
+    dst[(long)co * a.ls_dst + HALO + t] = acc;
+  }
+}
+
+int launch_bilstm(const BiLstmArgs& a, int cin, int B, hipStream_t s) {
+  if (cin == 64) {
+    hipLaunchKernelGGL(bilstm_kernel<64>, dim3(B), dim3(128), 0, s, a);
+  } else if (cin == 16) {
+    hipLaunchKernelGGL(bilstm_kernel<16>, dim3(B), dim3(128), 0, s, a);
+  } else {
+    set_error("bilstm: unsupported input size %d", cin);
+    return VP_ERR_UNSUPPORTED;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void transformer_kernel(const TransformerArgs a) {
+  __shared__ float xs[T][EQT_H];
+  __shared__ float q[T][KP], k[T][KP];
+  __shared__ float e[T][48];
+  __shared__ float v[T][EQT_H];
+  __shared__ float y1[T][EQT_H];
+  __shared__ float h1[T][128];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  load_window_transposed(a.src + (long)b * a.ws_src, a.ls_src, xs);
+  __syncthreads();
+  attention_core(xs, q, k, e, v, a.att, a.attn_eps, 0);
+  if (tid < T) {  // y1 = LN1(x + attention(x))
+    float z[EQT_H];
+#pragma unroll
+    for (int c = 0; c < EQT_H; ++c) z[c] = xs[tid][c] + v[tid][c];
+    layer_norm16(z, a.g1, a.b1, a.ln_eps, y1[tid]);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < T * 128; idx += 512) {  // FF: Linear(16,128) + ReLU
+    const int t = idx >> 7, m = idx & 127;
+    float acc = a.bb1[m];
+#pragma unroll
+    for (int c = 0; c < EQT_H; ++c) acc = fmaf(a.w1[m * 16 + c], y1[t][c], acc);
+    h1[t][m] = fmaxf(acc, 0.f);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < T * EQT_H; idx += 512) {  // Linear(128,16) + residual
+    const int t = idx >> 4, c = idx & 15;
+    float a0 = a.bb2[c], a1 = 0.f;
+#pragma unroll 8
+    for (int m = 0; m < 128; m += 2) {
+      a0 = fmaf(a.w2[c * 128 + m], h1[t][m], a0);
+      a1 = fmaf(a.w2[c * 128 + m + 1], h1[t][m + 1], a1);
+    }
+    v[t][c] = y1[t][c] + (a0 + a1);
+  }
+  __syncthreads();
+  if (tid < T) layer_norm16(v[tid], a.g2, a.b2, a.ln_eps, xs[tid]);
+  __syncthreads();
+  float* dst = a.dst + (long)b * a.ws_dst;
+  float* up = a.up ? a.up + (long)b * a.ws_up : nullptr;
+  for (int idx = tid; idx < EQT_H * T; idx += 512) {
+    const int c = idx / T, t = idx - c * T;
+    const float val = xs[t][c];
+    dst[(long)c * a.ls_dst + HALO + t] = val;
+    if (up) {
+      up[(long)c * a.ls_up + HALO + 2 * t] = val;
+      up[(long)c * a.ls_up + HALO + 2 * t + 1] = val;
+    }
+  }
+}
+
+int launch_transformer(const TransformerArgs& a, int B, hipStream_t s) {
+  hipLaunchKernelGGL(transformer_kernel, dim3(B), dim3(512), 0, s, a);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// P / S branch: LSTM(16,16) -> banded additive attention -> x2-upsampled decoder input.
+__global__ __launch_bounds__(256) void pick_branch_kernel(const PickBranchArgs a) {
+  __shared__ __attribute__((aligned(16))) float xs[T][EQT_H];
+  __shared__ float gx[T * 64];
+  __shared__ float hl[EQT_H][48];
+  __shared__ float x2[T][EQT_H];
+  __shared__ float q[T][KP], k[T][KP];
+  __shared__ float e[T][48];
+  __shared__ float v[T][EQT_H];
+  const int tid = threadIdx.x, b = blockIdx.x, br = blockIdx.y;
+  load_window_transposed(a.src + (long)b * a.ws_src, a.ls_src, xs);
+  __syncthreads();
+  if (tid < 64) lstm_direction<EQT_H>(&xs[0][0], gx, a.lstm[br], false, &hl[0][0], 48);
+  __syncthreads();
+  for (int idx = tid; idx < T * EQT_H; idx += 256) {
+    const int t = idx >> 4, c = idx & 15;
+    x2[t][c] = hl[c][t];
+  }
+  __syncthreads();
+  attention_core(x2, q, k, e, v, a.att[br], a.attn_eps, a.width);
+  float* up = a.up + (long)((1 + br) * a.B + b) * a.ws_up;
+  for (int idx = tid; idx < EQT_H * T; idx += 256) {
+    const int c = idx / T, t = idx - c * T;
+    const float val = v[t][c];
+    up[(long)c * a.ls_up + HALO + 2 * t] = val;
+    up[(long)c * a.ls_up + HALO + 2 * t + 1] = val;
+  }
+}
+
+int launch_pick_branch(const PickBranchArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(pick_branch_kernel, dim3(a.B, 2), dim3(256), 0, s, a);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Conv1d(8,1,11,pad 5) + sigmoid heads of the three decoders -> dense (B,3,T) output.
+__global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int win = blockIdx.y;  // set-major: win = d * B + b
+  const int d = win / a.B, b = win - d * a.B;
+  if (t >= a.T) return;
+  const float* src = a.src + (long)win * a.ws_src + HALO + t - 5;
+  const float* w = a.w + d * 88;
+  float a0 = a.b[d], a1 = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < 8; ++ci) {
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float x = src[(long)ci * a.ls_src + k];
+      if (k & 1) {
+        a1 = fmaf(w[ci * 11 + k], x, a1);
+      } else {
+        a0 = fmaf(w[ci * 11 + k], x, a0);
+      }
+    }
+  }
+  a.y[((long)b * 3 + d) * a.T + t] = sigmoid_f(a0 + a1);
+}
+
+int launch_head(const HeadArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(head_kernel, dim3((a.T + 255) / 256, 3 * a.B), dim3(256), 0, s, a);
+  return 0;
+}
+
+}  // namespace vp

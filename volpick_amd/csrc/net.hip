@@ -126,6 +126,10 @@ void Net::add_conv_step(ConvLayer* L) {
     a.l_out = L->l_out;
     a.l_dst = L->l_dst;
     a.e0 = (L->res >= 0) ? net.tensors[L->res].p : L->e0.d;
+    if (L->res >= 0) {
+      a.ls_res = net.tensors[L->res].ls;
+      a.ws_res = (long)net.tensors[L->res].win_stride();
+    }
     a.e1 = L->e1.d;
     a.e2 = L->e2.d;
     a.e_set_stride = L->e1.h.empty() ? 0 : (long)(L->e1.h.size() / L->n_sets);
