@@ -37,7 +37,7 @@ def _oracle_stages(net, x):
             h = F.max_pool1d(y, 2)
             out[f"encoder.{s}"] = h
         h = net.res_cnn_stack(h)
-        out["res.out"] = h
+        out["res.xa"] = h  # block 6 writes the ping buffer "res.xa"
         for s, blk in enumerate(net.bi_lstm_stack.members):
             h = blk(h)
             out[f"bilstm.{s}"] = h

@@ -1,0 +1,149 @@
+"""CPU: host-side logic of the product package and the C ABI surface (no GPU compute)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import volpick_amd as va
+from oracle import pipeline as OP
+from volpick_amd import _lib
+from volpick_amd.models import _group_stream
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    hdr = (ROOT / "include" / "volpick_hip.h").read_text()
+    declared = set(re.findall(r"\b(vp_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in volpick_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_lib.SIGNATURES) <= declared
+    assert b"gfx950" in lib.vp_version()
+
+
+def test_default_config_and_error_paths(lib):
+    cfg = _lib.VpConfig()
+    assert lib.vp_default_config(_lib.VP_MODEL_EQTRANSFORMER, C.byref(cfg)) == 0
+    assert (cfg.taper_samples, cfg.max_batch, cfg.norm) == (6, 256, _lib.VP_NORM_PEAK)
+    assert abs(cfg.bn_eps - 1e-3) < 1e-9 and abs(cfg.attention_eps - 1e-5) < 1e-12
+    assert lib.vp_default_config(7, C.byref(cfg)) < 0 and b"unknown model" in lib.vp_last_error()
+    h = C.c_void_p()
+    w = np.zeros(10, np.float32)
+    rc = lib.vp_create(0, _lib.VP_MODEL_PHASENET, w.ctypes.data_as(C.c_void_p), 10, 0, None, C.byref(h))
+    assert rc < 0 and b"expected 269675" in lib.vp_last_error()
+    assert lib.vp_weight_count(_lib.VP_MODEL_EQTRANSFORMER) == 378823
+
+
+@pytest.mark.parametrize("N,T,ov", [(6890, 6000, 1000), (60_000, 3001, 1500), (3001, 3001, 0), (3000, 3001, 0),
+                                    (8_640_000, 6000, 5500), (10_000, 3001, 3000)])
+def test_window_starts_matches_oracle(lib, N, T, ov):
+    want = OP.window_starts(N, T, ov)
+    buf = (C.c_int64 * (len(want) + 4))()
+    n = lib.vp_window_starts(N, T, ov, buf, len(buf))
+    assert n == len(want) and list(buf[:n]) == want.tolist()
+    assert lib.vp_window_starts(N, T, T, buf, len(buf)) < 0
+
+
+def _pick_host(lib, x, on_thr, off_thr, cap=64):
+    on, off, pk = (C.c_int64 * cap)(), (C.c_int64 * cap)(), (C.c_int64 * cap)()
+    val = (C.c_float * cap)()
+    n = C.c_int()
+    x = np.ascontiguousarray(x, np.float32)
+    assert lib.vp_pick_host(x.ctypes.data_as(C.c_void_p), len(x), on_thr, off_thr, on, off, pk, val, cap, C.byref(n)) == 0
+    return [(on[i], off[i], pk[i], val[i]) for i in range(min(n.value, cap))], n.value
+
+
+def test_pick_host_matches_trigger_onset(lib):
+    z = np.load(ROOT / "tests" / "golden" / "trigger_cases.npz")
+    got, n = _pick_host(lib, z["x"], .3, .3)
+    assert [(a, b) for a, b, _, _ in got] == [(2, 3), (7, 8), (11, 14)] and [g[2] for g in got] == [3, 8, 11]
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        n_s = int(rng.integers(1, 400))
+        x = np.clip(np.cumsum(rng.standard_normal(n_s)) * 0.15 + 0.3, 0, 1).astype(np.float32)
+        if trial % 3 == 0:
+            x[rng.integers(0, n_s, size=max(1, n_s // 20))] = np.nan
+        thr = float(rng.uniform(0.1, 0.8))
+        for off_thr in (thr, thr / 2):
+            want = OP.picks_from_trace(x, thr, off_thr)
+            got, n = _pick_host(lib, x, thr, off_thr, cap=512)
+            assert n == len(want)
+            for g, w in zip(got, want):
+                assert g[:3] == w[:3] and g[3] == pytest.approx(w[3])
+    got, n = _pick_host(lib, np.ones(10), .5, .5, cap=0)  # count only
+    assert n == 1 and got == []
+
+
+def test_stream_types_and_grouping():
+    t0 = va.UTCDateTime("2005-05-31T21:04:52.110000Z")
+    assert str(t0) == "2005-05-31T21:04:52.110000Z" and str(t0 + 18.86) == "2005-05-31T21:05:10.970000Z"
+    assert (t0 + 1.5) - t0 == 1.5 and va.UTCDateTime(t0.timestamp) == t0 and t0 < t0 + 0.01
+    mk = lambda ch, start, n, sta="AAA": va.Trace(np.arange(n, dtype=np.float32) + 1,
+                                                   dict(network="XX", station=sta, channel=ch, starttime=start,
+                                                        sampling_rate=100.0))
+    st = va.Stream([mk("HHZ", t0, 4000), mk("HHN", t0 + 1.0, 3500), mk("HHE", t0, 4000, sta="BBB")])
+    assert st[0].id == "XX.AAA..HHZ" and st[0].stats.endtime == t0 + 39.99
+    assert len(st.select(channel="HH?")) == 3 and len(st.select(station="BBB")) == 1 and len(st.copy()) == 3
+    groups = list(_group_stream(st, "ZNE", 100.0, True, 3001))
+    assert [g["trace_id"] for g in groups] == ["XX.AAA.", "XX.BBB."]
+    a = groups[0]["data"]
+    assert a.shape == (3, 4000) and a.dtype == np.float32
+    assert a[0, 0] == 1 and a[1, 99] == 0 and a[1, 100] == 1 and (a[2] == 0).all()  # N starts 1 s late, E missing
+    assert (groups[1]["data"][2] == np.arange(4000) + 1).all() and (groups[1]["data"][:2] == 0).all()
+    # a gap splits the station into independent blocks; short fragments are dropped with a warning
+    st2 = va.Stream([mk("HHZ", t0, 3200), mk("HHZ", t0 + 60, 1000)])
+    with pytest.warns(UserWarning):
+        blocks = list(_group_stream(st2, "ZNE", 100.0, True, 3001))
+    assert len(blocks) == 1 and blocks[0]["data"].shape == (3, 3200)
+    with pytest.raises(ValueError):
+        list(_group_stream(va.Stream([va.Trace(np.zeros(10), dict(channel="HHZ", sampling_rate=50.0))]), "ZNE", 100.0,
+                           True, 3001))
+    merged = va.Stream([mk("HHZ", t0, 100), mk("HHZ", t0 + 1.0, 100)]).merge(-1)
+    assert len(merged) == 1 and len(merged[0].data) == 200
+
+
+def test_picker_api_surface_without_gpu():
+    assert va.PhaseNet.list_pretrained() == ["volpick", "volpick_95train"] == va.EQTransformer.list_pretrained()
+    pn = va.PhaseNet.from_pretrained("volpick")
+    assert (pn.name, pn.labels, pn.norm, pn.component_order, pn.in_samples) == ("PhaseNet", "PSN", "peak", "ZNE", 3001)
+    assert pn.default_args == {"P_threshold": 0.39, "S_threshold": 0.34} and "Zhong" in pn.weights_docstring
+    assert str(pn.device) == "cpu" and pn.eval() is pn
+    eq = va.EQTransformer.from_pretrained("volpick_95train")
+    assert eq.labels == ["Detection", "P", "S"] and eq.default_args["detection_threshold"] == 0.3
+    assert eq._threshold({}, "P") == 0.26 and eq._threshold({"P_threshold": 0.5}, "P") == 0.5
+    assert eq._threshold({}, "detection") == 0.3
+    args = eq._argdict({"overlap": 5500, "blinding": [500, 500], "parallelism": None, "P_threshold": 0.2})
+    assert args["overlap"] == 5500 and args["blinding"] == (500, 500) and args["stacking"] == "avg"
+    assert pn._argdict({})["overlap"] == 1500 and pn._argdict({})["blinding"] == (0, 0)
+    with pytest.raises(ValueError):
+        eq._argdict({"stacking": "median"})
+    with pytest.raises(ValueError):
+        eq._argdict({"overlap": 6000})
+    with pytest.warns(UserWarning):
+        eq._argdict({"not_an_arg": 1})
+    with pytest.raises(ValueError):
+        va.PhaseNet.from_pretrained("original")
+    with pytest.raises(KeyError):
+        va.PhaseNet().load_state_dict({"inc.weight": np.zeros((8, 3, 7))})
+    p = va.Pick("NC.MMT.", va.UTCDateTime(0), va.UTCDateTime(1), va.UTCDateTime("2005-05-31T21:05:10.97"), 0.5, "P")
+    assert str(va.PickList([p])) == "PickList with 1 entries:\n\nNC.MMT.\t2005-05-31T21:05:10.970000Z\tP"
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    pn = va.PhaseNet.from_pretrained("volpick")
+    with pytest.raises(va.VolpickHipError, match="no CPU fallback"):
+        pn(np.zeros((1, 3, 3001), np.float32))
+
+
+def test_product_never_imports_oracle():
+    for f in (ROOT / "volpick_amd").rglob("*.py"):
+        src = f.read_text()
+        assert "import oracle" not in src and "from oracle" not in src, f
