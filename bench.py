@@ -89,32 +89,21 @@ def main():
     data, _, _ = synthetic_stream_array(n_samples, seed=1002 + rank)
     x = torch.from_numpy(data).to(dev)
     out = torch.empty((3, n_samples), dtype=torch.float32, device=dev)
-    thr = {lab: model._threshold({}, lab) for lab in model.labels if lab not in ("N", "Detection")}
-    thr_det = model._threshold({}, "detection")
-    cap = 4096
+    specs = model._trigger_specs({})
+    c_specs = (_lib.VpTriggerSpec * len(specs))(*[_lib.VpTriggerSpec(r, t_on, t_off) for r, _, t_on, t_off in specs])
+    cap = 8192
     on, off, peak = (C.c_int64 * cap)(), (C.c_int64 * cap)(), (C.c_int64 * cap)()
-    val = (C.c_float * cap)()
+    val, spec_of = (C.c_float * cap)(), (C.c_int32 * cap)()
     found = C.c_int()
     fv, lv, nw = C.c_int64(), C.c_int64(), C.c_int64()
 
     def step():
-        _lib.check(lib.vp_annotate(h, C.c_void_p(x.data_ptr()), _lib.VP_MEM_DEVICE, n_samples, overlap, blinding[0],
-                                   blinding[1], _lib.VP_STACK_AVG, args.batch, C.c_void_p(out.data_ptr()),
-                                   _lib.VP_MEM_DEVICE, C.byref(fv), C.byref(lv), C.byref(nw)), "vp_annotate")
-        n_picks = 0
-        for i, lab in enumerate(model.labels):
-            if lab == "N":
-                continue
-            if lab == "Detection":
-                t_on = thr_det
-                t_off = t_on / 2
-            else:
-                t_on = t_off = thr[lab]
-            row = out[i, fv.value : lv.value + 1]
-            _lib.check(lib.vp_pick(h, C.c_void_p(row.data_ptr()), _lib.VP_MEM_DEVICE, row.numel(), t_on, t_off, on,
-                                   off, peak, val, cap, C.byref(found)), "vp_pick")
-            n_picks += found.value
-        return n_picks
+        # one library call = gather+normalise, forward, blinding+stacking, trigger scan; one host sync
+        _lib.check(lib.vp_classify(h, C.c_void_p(x.data_ptr()), _lib.VP_MEM_DEVICE, n_samples, overlap, blinding[0],
+                                   blinding[1], _lib.VP_STACK_AVG, args.batch, c_specs, len(specs),
+                                   C.c_void_p(out.data_ptr()), _lib.VP_MEM_DEVICE, C.byref(fv), C.byref(lv),
+                                   C.byref(nw), on, off, peak, val, spec_of, cap, C.byref(found)), "vp_classify")
+        return found.value
 
     def sync_all():
         torch.cuda.synchronize()
@@ -191,7 +180,7 @@ def main():
             "tflops_kernels": flop_w * args.batch / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0,
             "fp32_frac_end_to_end": value / world * flop_w / (PEAK_FP32_TFLOPS * 1e12),
             "hbm_frac_compulsory": value / world * (2 * 3 * T * 4) / (PEAK_HBM_GBS * 1e9),
-            "stage_ms_last_step": {"forward": stage[1], "stack": stage[2], "pick_last": stage[3]},
+            "stage_ms_last_step": {"forward": stage[1], "stack": stage[2], "trigger_scan": stage[3]},
             "picks_per_step": n_picks,
             "kernels": kernels,
         },

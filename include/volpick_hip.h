@@ -105,6 +105,23 @@ int vp_annotate(vp_handle* h, const float* stream, int stream_mem, int64_t N, in
 int vp_pick(vp_handle* h, const float* trace, int trace_mem, int64_t n, float thr_on, float thr_off,
             int64_t* on, int64_t* off, int64_t* peak, float* value, int cap, int* n_found);
 
+/* Replaces model.classify(stream, ...) on one station block (README.md:54-66): vp_annotate
+ * followed by the trigger/peak scan of the output rows named in `specs`, with a single
+ * host synchronisation and a single device->host copy of the triggers.  `out` may be NULL
+ * (annotations not wanted), a device buffer or a host buffer of n_out*N floats.  Triggers
+ * are indices into the N-sample output rows (not the NaN-trimmed traces), grouped by spec in
+ * spec order and sorted by onset inside each group; spec_of[i] (may be NULL) is the spec
+ * index of trigger i.  Requires thr_off <= thr_on. */
+typedef struct {
+  int32_t row;     /* output row: PhaseNet 0..2 in `phases` order; EQT 0 Detection, 1 P, 2 S */
+  float thr_on;    /* trigger opens at the first sample > thr_on */
+  float thr_off;   /* ... and closes at the last sample of the run of samples > thr_off */
+} vp_trigger_spec;
+int vp_classify(vp_handle* h, const float* stream, int stream_mem, int64_t N, int overlap, int blind_l,
+                int blind_r, int stacking, int batch, const vp_trigger_spec* specs, int n_specs, float* out,
+                int out_mem, int64_t* first_valid, int64_t* last_valid, int64_t* n_windows, int64_t* on,
+                int64_t* off, int64_t* peak, float* value, int32_t* spec_of, int cap, int* n_found);
+
 /* Host-only variant of vp_pick for traces already in host memory (no handle, no GPU). */
 int vp_pick_host(const float* trace, int64_t n, float thr_on, float thr_off, int64_t* on, int64_t* off,
                  int64_t* peak, float* value, int cap, int* n_found);

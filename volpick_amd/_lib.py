@@ -32,6 +32,10 @@ class VpConfig(C.Structure):
     ]
 
 
+class VpTriggerSpec(C.Structure):
+    _fields_ = [("row", C.c_int32), ("thr_on", C.c_float), ("thr_off", C.c_float)]
+
+
 class VolpickHipError(RuntimeError):
     pass
 
@@ -61,6 +65,12 @@ SIGNATURES = {
     "vp_pick": (
         C.c_int,
         [_H, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float, _I64P, _I64P, _I64P, _FP, C.c_int,
+         C.POINTER(C.c_int)],
+    ),
+    "vp_classify": (
+        C.c_int,
+        [_H, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(VpTriggerSpec),
+         C.c_int, C.c_void_p, C.c_int, _I64P, _I64P, _I64P, _I64P, _I64P, _I64P, _FP, C.POINTER(C.c_int32), C.c_int,
          C.POINTER(C.c_int)],
     ),
     "vp_pick_host": (

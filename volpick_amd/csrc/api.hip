@@ -24,8 +24,11 @@ struct vp_handle {
   size_t d_pred_cap = 0;
   float* d_out = nullptr;   // stacked output when the caller's buffer is on the host
   size_t d_out_cap = 0;
-  void* d_pick = nullptr;   // pick scratch: count + on/off/peak/value
-  size_t d_pick_cap = 0;
+  char* d_pick = nullptr;   // trigger results: counters + per-spec on/off/peak/value arrays
+  char* h_pick = nullptr;   // pinned host mirror, filled by ONE async copy per call
+  size_t pick_bytes = 0;
+  int64_t* d_ends = nullptr;  // run-end scratch of the trigger scan
+  size_t ends_cap = 0;
 };
 
 namespace {
@@ -173,6 +176,8 @@ int vp_destroy(vp_handle* h) {
   if (h->d_pred) (void)hipFree(h->d_pred);
   if (h->d_out) (void)hipFree(h->d_out);
   if (h->d_pick) (void)hipFree(h->d_pick);
+  if (h->h_pick) (void)hipHostFree(h->h_pick);
+  if (h->d_ends) (void)hipFree(h->d_ends);
   h->net.release();
   delete h;
   return VP_OK;
@@ -238,10 +243,11 @@ int64_t vp_window_starts(int64_t N, int in_samples, int overlap, int64_t* starts
   return n;
 }
 
-int vp_annotate(vp_handle* h, const float* stream, int stream_mem, int64_t N, int overlap, int blind_l,
-                int blind_r, int stacking, int batch, float* out, int out_mem, int64_t* first_valid,
-                int64_t* last_valid, int64_t* n_windows) {
-  VP_REQUIRE(h && stream && out, "null argument");
+// Shared body of vp_annotate / vp_classify: everything up to the stacked (n_out, N) rows in
+// device memory.  No host synchronisation.
+static int annotate_device(vp_handle* h, const float* stream, int stream_mem, int64_t N, int overlap, int blind_l,
+                           int blind_r, int stacking, int batch, float* d_out, int64_t* first_valid,
+                           int64_t* last_valid, int64_t* n_windows) {
   vp::Net& net = h->net;
   const int T = net.in_samples;
   VP_REQUIRE(N > 0, "N must be positive");
@@ -250,14 +256,12 @@ int vp_annotate(vp_handle* h, const float* stream, int stream_mem, int64_t N, in
              blind_r);
   VP_REQUIRE(stacking == VP_STACK_AVG || stacking == VP_STACK_MAX, "unknown stacking %d", stacking);
   if (batch <= 0 || batch > net.max_batch) batch = net.max_batch;
-  VP_HIP(hipSetDevice(h->device));
 
   int64_t n_reg;
   int tail;
   const int64_t nwin = count_windows(N, T, overlap, &n_reg, &tail);
   if (n_windows) *n_windows = nwin;
   const long step = T - overlap;
-
   // valid (un-blinded) output range: union of [s_i + blind_l, s_i + T - blind_r)
   int64_t fv = -1, lv = -1;
   if (nwin > 0) {
@@ -267,12 +271,6 @@ int vp_annotate(vp_handle* h, const float* stream, int stream_mem, int64_t N, in
   if (first_valid) *first_valid = fv;
   if (last_valid) *last_valid = lv;
 
-  float* d_out = out;
-  if (out_mem == VP_MEM_HOST) {
-    int rc = grow(&h->d_out, &h->d_out_cap, (size_t)net.n_out * N);
-    if (rc != VP_OK) return rc;
-    d_out = h->d_out;
-  }
   VP_HIP(hipEventRecord(h->ev[0], h->stream));
   const float* d_stream = stream;
   if (stream_mem == VP_MEM_HOST) {
@@ -294,10 +292,8 @@ int vp_annotate(vp_handle* h, const float* stream, int stream_mem, int64_t N, in
       net.y = y_saved;
       if (rc != VP_OK) return rc;
     }
-    VP_HIP(hipEventRecord(h->ev[1], h->stream));
-  } else {
-    VP_HIP(hipEventRecord(h->ev[1], h->stream));
   }
+  VP_HIP(hipEventRecord(h->ev[1], h->stream));
   vp::StackArgs sa{};
   sa.pred = h->d_pred;
   sa.out = d_out;
@@ -312,18 +308,175 @@ int vp_annotate(vp_handle* h, const float* stream, int stream_mem, int64_t N, in
   sa.mode = stacking;
   vp::launch_stack(sa, h->stream);  // with zero windows this writes all-NaN rows
   VP_HIP(hipEventRecord(h->ev[2], h->stream));
-  if (out_mem == VP_MEM_HOST) {
-    VP_HIP(hipMemcpyAsync(out, d_out, (size_t)net.n_out * N * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  }
-  VP_HIP(hipStreamSynchronize(h->stream));
-  float fwd = 0.f, stk = 0.f;
-  VP_HIP(hipEventElapsedTime(&fwd, h->ev[0], h->ev[1]));
-  VP_HIP(hipEventElapsedTime(&stk, h->ev[1], h->ev[2]));
+  return VP_OK;
+}
+
+static void read_stage_timing(vp_handle* h, bool with_scan) {
+  float fwd = 0.f, stk = 0.f, scan = 0.f;
+  (void)hipEventElapsedTime(&fwd, h->ev[0], h->ev[1]);
+  (void)hipEventElapsedTime(&stk, h->ev[1], h->ev[2]);
+  if (with_scan) (void)hipEventElapsedTime(&scan, h->ev[3], h->ev[4]);
   h->stage_ms[0] = 0.f;
   h->stage_ms[1] = fwd;  // gather/normalise + forward of every batch
   h->stage_ms[2] = stk;
-  h->stage_ms[3] = 0.f;
-  h->total_ms = fwd + stk;
+  h->stage_ms[3] = scan;
+  h->total_ms = fwd + stk + scan;
+}
+
+int vp_annotate(vp_handle* h, const float* stream, int stream_mem, int64_t N, int overlap, int blind_l,
+                int blind_r, int stacking, int batch, float* out, int out_mem, int64_t* first_valid,
+                int64_t* last_valid, int64_t* n_windows) {
+  VP_REQUIRE(h && stream && out, "null argument");
+  VP_HIP(hipSetDevice(h->device));
+  float* d_out = out;
+  if (out_mem == VP_MEM_HOST) {
+    int rc = grow(&h->d_out, &h->d_out_cap, (size_t)h->net.n_out * std::max<int64_t>(N, 1));
+    if (rc != VP_OK) return rc;
+    d_out = h->d_out;
+  }
+  int rc = annotate_device(h, stream, stream_mem, N, overlap, blind_l, blind_r, stacking, batch, d_out, first_valid,
+                           last_valid, n_windows);
+  if (rc != VP_OK) return rc;
+  if (out_mem == VP_MEM_HOST) {
+    VP_HIP(hipMemcpyAsync(out, d_out, (size_t)h->net.n_out * N * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  }
+  VP_HIP(hipStreamSynchronize(h->stream));
+  read_stage_timing(h, false);
+  return VP_OK;
+}
+
+// ---- trigger scan of one or more device rows; ONE device->host copy, one synchronisation ----
+struct ScanLayout {
+  size_t header, per_spec, total;
+  int cap;
+};
+static ScanLayout scan_layout(int n_specs, int cap) {
+  ScanLayout L;
+  L.cap = std::max(cap, 1);
+  L.header = ((size_t)n_specs * 2 * sizeof(int) + 255) / 256 * 256;
+  L.per_spec = (size_t)L.cap * (3 * sizeof(int64_t) + sizeof(float));
+  L.per_spec = (L.per_spec + 255) / 256 * 256;
+  L.total = L.header + L.per_spec * n_specs;
+  return L;
+}
+
+static int scan_rows(vp_handle* h, const float* const* rows, const int64_t* lens, const float* thr_on,
+                     const float* thr_off, int n_specs, int cap, int64_t* on, int64_t* off, int64_t* peak,
+                     float* value, int32_t* spec_of, int* n_found) {
+  const ScanLayout L = scan_layout(n_specs, cap);
+  if (L.total > h->pick_bytes) {
+    if (h->d_pick) (void)hipFree(h->d_pick);
+    if (h->h_pick) (void)hipHostFree(h->h_pick);
+    h->d_pick = h->h_pick = nullptr;
+    h->pick_bytes = 0;
+    VP_HIP(hipMalloc((void**)&h->d_pick, L.total));
+    VP_HIP(hipHostMalloc((void**)&h->h_pick, L.total, hipHostMallocDefault));
+    h->pick_bytes = L.total;
+  }
+  int64_t max_len = 0;
+  for (int i = 0; i < n_specs; ++i) max_len = std::max(max_len, lens[i]);
+  const size_t ends_need = (size_t)max_len / 2 + 2;
+  if (ends_need > h->ends_cap) {
+    if (h->d_ends) (void)hipFree(h->d_ends);
+    h->d_ends = nullptr;
+    h->ends_cap = 0;
+    VP_HIP(hipMalloc((void**)&h->d_ends, ends_need * sizeof(int64_t)));
+    h->ends_cap = ends_need;
+  }
+  VP_HIP(hipEventRecord(h->ev[3], h->stream));
+  VP_HIP(hipMemsetAsync(h->d_pick, 0, L.header, h->stream));
+  for (int i = 0; i < n_specs; ++i) {
+    if (lens[i] <= 0) continue;
+    char* base = h->d_pick + L.header + L.per_spec * i;
+    vp::PickArgs a{};
+    a.trace = rows[i];
+    a.n = lens[i];
+    a.thr_on = thr_on[i];
+    a.thr_off = thr_off[i];
+    a.count = (int*)h->d_pick + 2 * i;
+    a.n_ends = (int*)h->d_pick + 2 * i + 1;
+    a.on = (int64_t*)base;
+    a.off = a.on + L.cap;
+    a.peak = a.off + L.cap;
+    a.value = (float*)(a.peak + L.cap);
+    a.cap = cap;
+    a.ends = h->d_ends;
+    a.ends_cap = (int)std::min<size_t>(h->ends_cap, 0x7fffffff);
+    vp::launch_pick(a, h->stream);
+  }
+  VP_HIP(hipEventRecord(h->ev[4], h->stream));
+  VP_HIP(hipMemcpyAsync(h->h_pick, h->d_pick, L.total, hipMemcpyDeviceToHost, h->stream));
+  VP_HIP(hipStreamSynchronize(h->stream));
+  int total = 0, written = 0;
+  for (int i = 0; i < n_specs; ++i) {
+    const int found = ((const int*)h->h_pick)[2 * i];
+    total += found;
+    const int m = std::min(found, cap);
+    const char* base = h->h_pick + L.header + L.per_spec * i;
+    const int64_t* t_on = (const int64_t*)base;
+    const int64_t* t_off = t_on + L.cap;
+    const int64_t* t_pk = t_off + L.cap;
+    const float* t_v = (const float*)(t_pk + L.cap);
+    std::vector<int> order(m);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return t_on[x] < t_on[y]; });
+    for (int k = 0; k < m && written < cap; ++k, ++written) {
+      on[written] = t_on[order[k]];
+      off[written] = t_off[order[k]];
+      peak[written] = t_pk[order[k]];
+      value[written] = t_v[order[k]];
+      if (spec_of) spec_of[written] = i;
+    }
+  }
+  *n_found = total;
+  return VP_OK;
+}
+
+int vp_classify(vp_handle* h, const float* stream, int stream_mem, int64_t N, int overlap, int blind_l,
+                int blind_r, int stacking, int batch, const vp_trigger_spec* specs, int n_specs, float* out,
+                int out_mem, int64_t* first_valid, int64_t* last_valid, int64_t* n_windows, int64_t* on,
+                int64_t* off, int64_t* peak, float* value, int32_t* spec_of, int cap, int* n_found) {
+  VP_REQUIRE(h && stream && n_found, "null argument");
+  VP_REQUIRE(n_specs >= 0 && n_specs <= 16 && (n_specs == 0 || specs), "bad trigger specs");
+  VP_REQUIRE(cap >= 0 && (cap == 0 || (on && off && peak && value)), "null output arrays");
+  VP_HIP(hipSetDevice(h->device));
+  const int n_out = h->net.n_out;
+  for (int i = 0; i < n_specs; ++i) {
+    VP_REQUIRE(specs[i].row >= 0 && specs[i].row < n_out, "spec %d: row %d out of range", i, specs[i].row);
+    VP_REQUIRE(specs[i].thr_off <= specs[i].thr_on, "spec %d: thr_off must not exceed thr_on", i);
+  }
+  float* d_out = (out && out_mem == VP_MEM_DEVICE) ? out : nullptr;
+  if (!d_out) {
+    int rc = grow(&h->d_out, &h->d_out_cap, (size_t)n_out * std::max<int64_t>(N, 1));
+    if (rc != VP_OK) return rc;
+    d_out = h->d_out;
+  }
+  int64_t fv = -1, lv = -1;
+  int rc = annotate_device(h, stream, stream_mem, N, overlap, blind_l, blind_r, stacking, batch, d_out, &fv, &lv,
+                           n_windows);
+  if (rc != VP_OK) return rc;
+  if (first_valid) *first_valid = fv;
+  if (last_valid) *last_valid = lv;
+  if (out && out_mem == VP_MEM_HOST) {
+    VP_HIP(hipMemcpyAsync(out, d_out, (size_t)n_out * N * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  }
+  const float* rows[16];
+  int64_t lens[16];
+  float t_on[16], t_off[16];
+  for (int i = 0; i < n_specs; ++i) {
+    rows[i] = d_out + (size_t)specs[i].row * N;  // NaN outside [fv, lv] never triggers
+    lens[i] = N;
+    t_on[i] = specs[i].thr_on;
+    t_off[i] = specs[i].thr_off;
+  }
+  *n_found = 0;
+  if (n_specs > 0) {
+    rc = scan_rows(h, rows, lens, t_on, t_off, n_specs, cap, on, off, peak, value, spec_of, n_found);
+    if (rc != VP_OK) return rc;
+  } else {
+    VP_HIP(hipStreamSynchronize(h->stream));
+  }
+  read_stage_timing(h, n_specs > 0);
   return VP_OK;
 }
 
@@ -350,55 +503,11 @@ int vp_pick(vp_handle* h, const float* trace, int trace_mem, int64_t n, float th
     return vp::pick_host(trace, n, thr_on, thr_off, on, off, peak, value, cap, n_found);
   }
   VP_HIP(hipSetDevice(h->device));
-  const size_t dcap = (size_t)std::max(cap, 1);
-  const size_t bytes = 64 + dcap * (3 * sizeof(int64_t) + sizeof(float));
-  if (bytes > h->d_pick_cap) {
-    if (h->d_pick) (void)hipFree(h->d_pick);
-    h->d_pick = nullptr;
-    h->d_pick_cap = 0;
-    VP_HIP(hipMalloc(&h->d_pick, bytes));
-    h->d_pick_cap = bytes;
-  }
-  char* base = (char*)h->d_pick;
-  vp::PickArgs a{};
-  a.trace = trace;
-  a.n = n;
-  a.thr_on = thr_on;
-  a.thr_off = thr_off;
-  a.count = (int*)base;
-  a.on = (int64_t*)(base + 64);
-  a.off = a.on + dcap;
-  a.peak = a.off + dcap;
-  a.value = (float*)(a.peak + dcap);
-  a.cap = cap;
-  VP_HIP(hipEventRecord(h->ev[3], h->stream));
-  VP_HIP(hipMemsetAsync(a.count, 0, sizeof(int), h->stream));
-  vp::launch_pick(a, h->stream);
-  VP_HIP(hipEventRecord(h->ev[4], h->stream));
-  int found = 0;
-  VP_HIP(hipMemcpyAsync(&found, a.count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  VP_HIP(hipStreamSynchronize(h->stream));
-  VP_HIP(hipEventElapsedTime(&h->stage_ms[3], h->ev[3], h->ev[4]));
-  *n_found = found;
-  const int m = std::min(found, cap);
-  if (m > 0) {
-    std::vector<int64_t> t_on(m), t_off(m), t_pk(m);
-    std::vector<float> t_v(m);
-    VP_HIP(hipMemcpy(t_on.data(), a.on, m * sizeof(int64_t), hipMemcpyDeviceToHost));
-    VP_HIP(hipMemcpy(t_off.data(), a.off, m * sizeof(int64_t), hipMemcpyDeviceToHost));
-    VP_HIP(hipMemcpy(t_pk.data(), a.peak, m * sizeof(int64_t), hipMemcpyDeviceToHost));
-    VP_HIP(hipMemcpy(t_v.data(), a.value, m * sizeof(float), hipMemcpyDeviceToHost));
-    std::vector<int> order(m);
-    std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(), [&](int i, int j) { return t_on[i] < t_on[j]; });
-    for (int i = 0; i < m; ++i) {
-      on[i] = t_on[order[i]];
-      off[i] = t_off[order[i]];
-      peak[i] = t_pk[order[i]];
-      value[i] = t_v[order[i]];
-    }
-  }
-  return VP_OK;
+  const float* rows[1] = {trace};
+  const int64_t lens[1] = {n};
+  int rc = scan_rows(h, rows, lens, &thr_on, &thr_off, 1, cap, on, off, peak, value, nullptr, n_found);
+  if (rc == VP_OK) (void)hipEventElapsedTime(&h->stage_ms[3], h->ev[3], h->ev[4]);
+  return rc;
 }
 
 int vp_last_timing(const vp_handle* h, float* total_ms, float stage_ms[4]) {

@@ -43,6 +43,9 @@ struct PickArgs {
   float* value;
   int cap;
   int* count;
+  int64_t* ends;   // scratch: run-end indices
+  int ends_cap;
+  int* n_ends;
 };
 int launch_pick(const PickArgs& a, hipStream_t stream);
 int pick_host(const float* x, int64_t n, float thr_on, float thr_off, int64_t* on, int64_t* off, int64_t* peak,

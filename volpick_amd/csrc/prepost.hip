@@ -24,8 +24,9 @@ __device__ inline float wave_max(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void gather_normalize_kernel(const PreArgs a) {
-  __shared__ float red[3][4];
+__global__ __launch_bounds__(1024) void gather_normalize_kernel(const PreArgs a) {
+  constexpr int NTH = 1024, NWV = NTH / 64;
+  __shared__ float red[3][NWV];
   __shared__ float stat[3][2];
   const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = a.T;
@@ -37,25 +38,29 @@ __global__ __launch_bounds__(256) void gather_normalize_kernel(const PreArgs a) 
 
   if (!a.preprocess) {
     for (int c = 0; c < 3; ++c)
-      for (int t = tid; t < T; t += 256) dst[(long)c * a.lsd + t] = src[c * cs + t];
+      for (int t = tid; t < T; t += NTH) dst[(long)c * a.lsd + t] = src[c * cs + t];
     return;
   }
   // pass 1: mean per channel
   float s[3] = {0.f, 0.f, 0.f};
   for (int c = 0; c < 3; ++c)
-    for (int t = tid; t < T; t += 256) s[c] += src[c * cs + t];
+    for (int t = tid; t < T; t += NTH) s[c] += src[c * cs + t];
   for (int c = 0; c < 3; ++c) {
     const float v = wave_sum(s[c]);
     if (lane == 0) red[c][wave] = v;
   }
   __syncthreads();
-  if (tid < 3) stat[tid][0] = (red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3]) / (float)T;
+  if (tid < 3) {
+    float acc = 0.f;
+    for (int i = 0; i < NWV; ++i) acc += red[tid][i];
+    stat[tid][0] = acc / (float)T;
+  }
   __syncthreads();
   const float mean[3] = {stat[0][0], stat[1][0], stat[2][0]};
   // pass 2: amplitude of the demeaned window
   float m[3] = {0.f, 0.f, 0.f};
   for (int c = 0; c < 3; ++c)
-    for (int t = tid; t < T; t += 256) {
+    for (int t = tid; t < T; t += NTH) {
       const float d = src[c * cs + t] - mean[c];
       if (a.norm == VP_NORM_PEAK) {
         m[c] = fmaxf(m[c], fabsf(d));
@@ -72,7 +77,9 @@ __global__ __launch_bounds__(256) void gather_normalize_kernel(const PreArgs a) 
   __syncthreads();
   if (tid < 3) {
     const float* r = red[tid];
-    stat[tid][1] = (a.norm == VP_NORM_PEAK) ? fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])) : r[0] + r[1] + r[2] + r[3];
+    float acc = r[0];
+    for (int i = 1; i < NWV; ++i) acc = (a.norm == VP_NORM_PEAK) ? fmaxf(acc, r[i]) : acc + r[i];
+    stat[tid][1] = acc;
   }
   __syncthreads();
   float amp[3];
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(256) void gather_normalize_kernel(const PreArgs a) 
   // pass 3: scale (+ taper) and write
   for (int c = 0; c < 3; ++c) {
     const float den = amp[c] + a.norm_eps;
-    for (int t = tid; t < T; t += 256) {
+    for (int t = tid; t < T; t += NTH) {
       float v = (src[c * cs + t] - mean[c]) / den;
       if (a.taper > 0) {
         const int e = (t < a.taper) ? t : ((T - 1 - t < a.taper) ? T - 1 - t : -1);
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(256) void gather_normalize_kernel(const PreArgs a) 
 }
 
 int launch_gather_normalize(const PreArgs& a, int n_windows, hipStream_t stream) {
-  hipLaunchKernelGGL(gather_normalize_kernel, dim3(n_windows), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(gather_normalize_kernel, dim3(n_windows), dim3(1024), 0, stream, a);
   return 0;
 }
 
@@ -158,43 +165,75 @@ int launch_stack(const StackArgs& a, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------
 // A8: trigger_onset + peak.  For thr_off <= thr_on every maximal run of samples > thr_off
 // that holds a sample > thr_on yields one trigger: on = first sample > thr_on in the run,
-// off = last sample of the run, peak = first argmax over [on, off].  One thread per sample
-// finds run ends; the thread at a run end walks its run backwards (runs are short, ends
-// are rare).  Triggers are appended with one atomic each and sorted on the host.
+// off = last sample of the run, peak = first argmax over [on, off].
+//   pass 1 (one thread per sample): append the index of every run END to a list;
+//   pass 2 (one wavefront per run end): walk the run backwards 64 coalesced samples at a
+//          time (ballot finds the run start and the earliest sample > thr_on), then a
+//          strided max/argmax over [on, off] with a wave reduction.
+// Triggers are appended with one atomic each and sorted on the host.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pick_kernel(const PickArgs a) {
+__global__ __launch_bounds__(256) void run_end_kernel(const PickArgs a) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   if (t >= a.n) return;
-  const float v = a.trace[t];
-  if (!(v > a.thr_off)) return;
+  if (!(a.trace[t] > a.thr_off)) return;
   if (t + 1 < a.n && a.trace[t + 1] > a.thr_off) return;  // not a run end
-  long on = -1;
-  long s = t;
-  while (s >= 0 && a.trace[s] > a.thr_off) {
-    if (a.trace[s] > a.thr_on) on = s;
-    --s;
-  }
-  if (on < 0) return;
-  float best = a.trace[on];
-  long arg = on;
-  for (long k = on + 1; k <= t; ++k) {
-    const float x = a.trace[k];
-    if (x > best) {
-      best = x;
-      arg = k;
+  const int slot = atomicAdd(a.n_ends, 1);
+  if (slot < a.ends_cap) a.ends[slot] = t;
+}
+
+__global__ __launch_bounds__(256) void run_scan_kernel(const PickArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * 256) >> 6;
+  int n_ends = *a.n_ends;
+  if (n_ends > a.ends_cap) n_ends = a.ends_cap;
+  for (int r = wave; r < n_ends; r += n_waves) {
+    const long off = a.ends[r];
+    long on = -1;
+    for (long pos = off; pos >= 0; pos -= 64) {
+      const long idx = pos - lane;
+      const float v = (idx >= 0) ? a.trace[idx] : -INFINITY;
+      const bool above = (idx >= 0) && (v > a.thr_off);
+      const unsigned long long broken = __ballot(!above);
+      const int k = broken ? __ffsll((long long)broken) - 1 : 64;  // lanes [0, k) lie inside the run
+      const unsigned long long hit = __ballot(lane < k && v > a.thr_on);
+      if (hit) on = pos - (63 - __clzll((long long)hit));
+      if (k < 64) break;
     }
-  }
-  const int slot = atomicAdd(a.count, 1);
-  if (slot < a.cap) {
-    a.on[slot] = on;
-    a.off[slot] = t;
-    a.peak[slot] = arg;
-    a.value[slot] = best;
+    if (on < 0) continue;
+    float best = -INFINITY;
+    long arg = off;
+    for (long i = on + lane; i <= off; i += 64) {
+      const float v = a.trace[i];
+      if (v > best) {
+        best = v;
+        arg = i;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const long oa = __shfl_xor(arg, o, 64);
+      if (ob > best || (ob == best && oa < arg)) {
+        best = ob;
+        arg = oa;
+      }
+    }
+    if (lane == 0) {
+      const int slot = atomicAdd(a.count, 1);
+      if (slot < a.cap) {
+        a.on[slot] = on;
+        a.off[slot] = off;
+        a.peak[slot] = arg;
+        a.value[slot] = best;
+      }
+    }
   }
 }
 
 int launch_pick(const PickArgs& a, hipStream_t stream) {
-  hipLaunchKernelGGL(pick_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(run_end_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(run_scan_kernel, dim3(256), dim3(256), 0, stream, a);
   return 0;
 }
 

@@ -297,20 +297,43 @@ class WaveformModel:
                                    C.byref(nw)), "vp_annotate")
         return out, fv.value, lv.value, nw.value
 
-    def _pick_device(self, trace_dev, thr_on, thr_off, cap=4096):
+    def _trigger_specs(self, args):
+        """[(row, label, thr_on, thr_off)]: picks use thr/thr, detections thr/(thr/2); 'N' is skipped."""
+        specs = []
+        for i, label in enumerate(self.labels):
+            if label == "N":
+                continue
+            if label == "Detection":
+                thr = self._threshold(args, "detection")
+                specs.append((i, label, thr, thr / 2))
+            else:
+                thr = self._threshold(args, label)
+                specs.append((i, label, thr, thr))
+        return specs
+
+    def _classify_block(self, data, args, specs, cap=8192):
+        """(3,N) float32 ndarray -> ([(spec_index, on, off, peak, value)], n_windows); indices into the block."""
+        torch = _torch()
         lib = _lib.load()
-        n = trace_dev.numel()
+        h = self._ensure_handle()
+        dev = torch.device("cuda", self._device_index)
+        n = data.shape[1]
+        x = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(dev)
+        torch.cuda.current_stream(dev).synchronize()
+        c_specs = (_lib.VpTriggerSpec * len(specs))(*[_lib.VpTriggerSpec(r, on, off) for r, _, on, off in specs])
+        stacking = _lib.VP_STACK_AVG if args["stacking"] == "avg" else _lib.VP_STACK_MAX
+        batch = max(1, min(int(args["batch_size"]), self._max_batch))
+        fv, lv, nw = C.c_int64(), C.c_int64(), C.c_int64()
         while True:
-            on = (C.c_int64 * cap)()
-            off = (C.c_int64 * cap)()
-            peak = (C.c_int64 * cap)()
-            val = (C.c_float * cap)()
-            found = C.c_int()
-            _lib.check(lib.vp_pick(self._handle, C.c_void_p(trace_dev.data_ptr()), _lib.VP_MEM_DEVICE, n, thr_on,
-                                   thr_off, on, off, peak, val, cap, C.byref(found)), "vp_pick")
+            on, off, peak = (C.c_int64 * cap)(), (C.c_int64 * cap)(), (C.c_int64 * cap)()
+            val, spec_of, found = (C.c_float * cap)(), (C.c_int32 * cap)(), C.c_int()
+            _lib.check(lib.vp_classify(h, C.c_void_p(x.data_ptr()), _lib.VP_MEM_DEVICE, n, args["overlap"],
+                                       args["blinding"][0], args["blinding"][1], stacking, batch, c_specs, len(specs),
+                                       None, _lib.VP_MEM_DEVICE, C.byref(fv), C.byref(lv), C.byref(nw), on, off, peak,
+                                       val, spec_of, cap, C.byref(found)), "vp_classify")
             if found.value <= cap:
                 m = found.value
-                return [(on[i], off[i], peak[i], val[i]) for i in range(m)]
+                return [(spec_of[i], on[i], off[i], peak[i], val[i]) for i in range(m)], nw.value
             cap = found.value
 
     def annotate(self, stream, copy=True, **kwargs):
@@ -329,26 +352,18 @@ class WaveformModel:
     def classify(self, stream, copy=True, **kwargs):
         """``annotate`` + trigger/peak extraction -> ``ClassifyOutput`` with ``.picks`` (and ``.detections``)."""
         args = self._argdict(kwargs)
+        specs = self._trigger_specs(args)
         picks, detections = PickList(), DetectionList()
-        for grp in _group_stream(stream, self.component_order, self.sampling_rate, copy, self.in_samples):
-            dev_out, fv, lv, nw = self._annotate_block(grp["data"], args)
-            if nw == 0 or fv < 0:
-                continue
-            t0 = grp["starttime"] + fv / self.sampling_rate
-            tid = grp["trace_id"]
-            for i, label in enumerate(self.labels):
-                if label == "N":
-                    continue
-                trace = dev_out[i, fv : lv + 1]
+        sr = self.sampling_rate
+        for grp in _group_stream(stream, self.component_order, sr, copy, self.in_samples):
+            triggers, nw = self._classify_block(grp["data"], args, specs)
+            t0, tid = grp["starttime"], grp["trace_id"]
+            for si, on, off, pk, v in triggers:
+                label = specs[si][1]
                 if label == "Detection":
-                    thr = self._threshold(args, "detection")
-                    for on, off, pk, v in self._pick_device(trace, thr, thr / 2):
-                        detections.append(Detection(tid, t0 + on / self.sampling_rate, t0 + off / self.sampling_rate, v))
+                    detections.append(Detection(tid, t0 + on / sr, t0 + off / sr, v))
                 else:
-                    thr = self._threshold(args, label)
-                    for on, off, pk, v in self._pick_device(trace, thr, thr):
-                        picks.append(Pick(tid, t0 + on / self.sampling_rate, t0 + off / self.sampling_rate,
-                                          t0 + pk / self.sampling_rate, v, label))
+                    picks.append(Pick(tid, t0 + on / sr, t0 + off / sr, t0 + pk / sr, v, label))
         return ClassifyOutput(self.name, picks=PickList(sorted(picks)), detections=DetectionList(sorted(detections)))
 
 
