@@ -51,7 +51,8 @@ typedef struct {
   float layernorm_eps;        /* EQT LayerNormalization eps */
   float norm_eps;             /* x / (amp + norm_eps) */
   int32_t taper_samples;      /* EQT half-cosine taper length (0 for PhaseNet) */
-  int32_t reserved[8];
+  int32_t reserved[8];        /* [0]: 1 = PhaseNet layer-by-layer plan instead of the fused kernels (debug / A-B);
+                                 [1]: 1 = fused kernels also dump their LDS intermediates to the debug tensors */
 } vp_config;
 
 /* Fills cfg with the defaults for model_kind. */

@@ -35,7 +35,11 @@ def _oracle_acts(net, x):
     return y, acts
 
 
-def test_layers_match_oracle(model, oracle):
+@pytest.mark.parametrize("flags", [(0, 1), (1, 0)], ids=["fused+dumps", "layerwise"])
+def test_layers_match_oracle(oracle, flags):
+    model = PhaseNet.from_pretrained("volpick")
+    model._plan_flags = flags
+    model.cuda()
     x = synthetic_windows(3, 3001, seed=5)
     xn = OP.batch_pre(oracle, torch.from_numpy(x))
     y = model(xn).cpu().numpy()
@@ -63,6 +67,17 @@ def test_layers_match_oracle(model, oracle):
     for n, e, m in report:
         assert e <= 2e-4 * max(1.0, m), (n, e)
     assert np.abs(y - yo.numpy()).max() < TOL
+
+
+def test_fused_equals_layerwise_bitwise(oracle):
+    """Same packed weights, same k-order of every MFMA chain: the two plans must agree exactly."""
+    x = synthetic_windows(9, 3001, seed=77)
+    xn = OP.batch_pre(oracle, torch.from_numpy(x))
+    fused = PhaseNet.from_pretrained("volpick").cuda()
+    layer = PhaseNet.from_pretrained("volpick")
+    layer._plan_flags = (1, 0)
+    layer.cuda()
+    assert np.array_equal(fused(xn).numpy(), layer(xn).numpy())
 
 
 @pytest.mark.parametrize("B", [1, 5, 256, 300])

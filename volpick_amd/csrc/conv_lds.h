@@ -1,0 +1,108 @@
+// LDS-to-LDS form of the polyphase MFMA convolution (conv_mfma.h): the building block of the
+// fused PhaseNet kernels, where whole layer chains run inside one workgroup and activations
+// never leave the CU.
+//
+// An "image" is a [C][S] float array in LDS; logical sample t of a row sits at column BASE + t.
+// Columns outside a layer's valid range hold zeros (they are the convolution padding) or
+// don't-care values that only feed masked output columns.
+//
+//   out[co][P*n + p + OUT_OFF] = act(bias[co] + sum_tap sum_ci A[(co,p)][(tap,ci)] * in[ci][SN*n + tap + IN_OFF])
+//
+// Work is split into items = (m-tile, block of NB n-tiles); wave w takes items w, w+nwaves, ...
+// Each item keeps NB accumulators (NB*4 VGPRs), loads one A fragment per K-step from L2/L1 and
+// NB B fragments from LDS (per-lane base + immediate offsets).
+#pragma once
+#include "vp_common.h"
+
+namespace vp {
+
+template <int CIN1_, int CIN2_, int COUT_, int P_, int TAPS_, int SN_, int IN_OFF_, int OUT_OFF_, int NB_, int RELU_>
+struct LdsLayer {
+  static constexpr int CIN1 = CIN1_, CIN2 = CIN2_, CIN = CIN1_ + CIN2_;
+  static constexpr int CB1 = (CIN1 + 3) / 4, CB2 = (CIN2 + 3) / 4, CB = CB1 + CB2, CINP = 4 * CB;
+  static constexpr int COUT = COUT_, P = P_, TAPS = TAPS_, SN = SN_, IN_OFF = IN_OFF_, OUT_OFF = OUT_OFF_;
+  static constexpr int NB = NB_, RELU = RELU_;
+  static constexpr int M = COUT * P, MT = M / 16;
+  static_assert(M % 16 == 0, "M must be a multiple of the 16-row MFMA tile");
+  static_assert(CIN2 == 0 || CIN1 % 4 == 0, "concat boundary must fall on a 4-channel block");
+};
+
+// in1/in2: LDS images (row strides S1/S2, logical 0 at column B1/B2).  afrag: packed A
+// fragments [MT][CB][TAPS][64] in global memory.  store(co, t, v) consumes every output
+// (t = P*col + p + OUT_OFF in the caller's local coordinates) and applies its own masks.
+template <class L, int S1, int B1, int S2, int B2, class Store>
+__device__ __forceinline__ void conv_lds(const float* in1, const float* in2, const float* __restrict__ afrag,
+                                         const float* __restrict__ bias, const int cols, Store store, const int wave,
+                                         const int nwaves, const int lane) {
+  const int NT = (cols + 15) >> 4;
+  const int NBLK = (NT + L::NB - 1) / L::NB;
+  const int items = L::MT * NBLK;
+  const int g = lane >> 4, n = lane & 15;
+  for (int item = wave; item < items; item += nwaves) {
+    const int mt = item % L::MT, nblk = item / L::MT;
+    const int colb = nblk * L::NB * 16;
+    f32x4 acc[L::NB];
+#pragma unroll
+    for (int j = 0; j < L::NB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* ap = afrag + (long)mt * L::CB * L::TAPS * 64 + lane;
+    {
+      const float* bp = in1 + g * S1 + B1 + (colb + n) * L::SN + L::IN_OFF;
+      for (int cb = 0; cb < L::CB1; ++cb) {
+#pragma unroll
+        for (int tap = 0; tap < L::TAPS; ++tap) {
+          const float av = ap[(cb * L::TAPS + tap) * 64];
+#pragma unroll
+          for (int j = 0; j < L::NB; ++j) {
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[cb * 4 * S1 + j * 16 * L::SN + tap], acc[j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if constexpr (L::CB2 > 0) {
+      const float* bp = in2 + g * S2 + B2 + (colb + n) * L::SN + L::IN_OFF;
+      const float* ap2 = ap + L::CB1 * L::TAPS * 64;
+      for (int cb = 0; cb < L::CB2; ++cb) {
+#pragma unroll
+        for (int tap = 0; tap < L::TAPS; ++tap) {
+          const float av = ap2[(cb * L::TAPS + tap) * 64];
+#pragma unroll
+          for (int j = 0; j < L::NB; ++j) {
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[cb * 4 * S2 + j * 16 * L::SN + tap], acc[j], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = mt * 16 + 4 * g + r;
+      const int co = m / L::P, p = m - co * L::P;
+      const float b = bias[co];
+#pragma unroll
+      for (int j = 0; j < L::NB; ++j) {
+        float v = acc[j][r] + b;
+        if (L::RELU) v = fmaxf(v, 0.f);
+        store(co, L::P * (colb + j * 16 + n) + p + L::OUT_OFF, v);
+      }
+    }
+  }
+}
+
+// Store functor: LDS image with a valid range [lo, hi) in the caller's local coordinates and a
+// "signal" range [sig_lo, sig_hi): positions inside the image but outside the signal are written
+// as zero (they are the next layer's zero padding, not activations of zero-padded input).
+template <int S, int B>
+struct ImageStore {
+  float* img;
+  int lo, hi;          // columns of the image this layer may write (local coords)
+  int sig_lo, sig_hi;  // local coords whose global position lies inside the signal [0, L)
+  __device__ __forceinline__ void operator()(int co, int t, float v) const {
+    if (t >= lo && t < hi) img[co * S + B + t] = (t >= sig_lo && t < sig_hi) ? v : 0.f;
+  }
+};
+
+template <int C, int S>
+__device__ __forceinline__ void zero_image(float* img, int tid, int nthreads) {
+  for (int i = tid; i < C * S / 4; i += nthreads) reinterpret_cast<float4*>(img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+}  // namespace vp

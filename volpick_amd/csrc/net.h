@@ -47,6 +47,7 @@ struct Net {
   std::vector<HostBlob*> blobs;  // every constant array to upload (owned by layers / extra)
   std::vector<std::unique_ptr<HostBlob>> extra;
   std::vector<Step> steps;
+  std::vector<std::pair<const void*, size_t>> extra_kernels;  // (kernel, dynamic LDS bytes) needing the LDS attribute
   int input = -1;          // tensor id of the normalised haloed input windows
   float* y = nullptr;      // dense output [max_batch][n_out][in_samples]
   float* arena = nullptr;  // one device allocation for tensors + constants
@@ -92,6 +93,7 @@ struct Net {
 };
 
 int plan_phasenet(Net& net, const ParamView& pv);
+int plan_phasenet_fused(Net& net, bool debug_dumps);  // swaps the 18 layer steps for 3 fused launches
 int plan_eqt(Net& net, const ParamView& pv);
 
 // BatchNorm (eval) folded into the preceding conv: scale = gamma / sqrt(var + eps),

@@ -191,6 +191,11 @@ int Net::upload() {
       VP_HIP(hipFuncSetAttribute(c->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes));
     }
   }
+  for (auto& k : extra_kernels) {
+    if (k.second > 48 * 1024) {
+      VP_HIP(hipFuncSetAttribute(k.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.second));
+    }
+  }
   return VP_OK;
 }
 

@@ -1,0 +1,473 @@
+// PhaseNet forward as THREE fused launches instead of 18 (same arithmetic, same packed weights):
+//
+//   pn_down0_kernel  inc -> down0.same -> down0.down, time-tiled over 512 level-0 samples; the two
+//                    8-channel intermediates live in LDS, only the skip tensor (down0.same) and the
+//                    751-sample down0.down rows go back to memory.
+//   pn_core_kernel   ONE workgroup per window: levels 1-4 down and up0..up2 (13 layers, 71 % of the
+//                    model's FLOPs) run back to back out of a 158 KB LDS arena; the only traffic is
+//                    the 24 KB input, the 48 KB output and the L2-resident weight stream.
+//   pn_up3_kernel    up3.convT -> concat(skip0) -> up3.same -> 1x1 conv + softmax, time-tiled.
+//
+// Every layer is conv_lds<> (conv_lds.h): LDS image -> MFMA -> LDS image.  Coordinates inside a
+// tiled kernel are local to the tile; ImageStore writes explicit zeros where the global position
+// falls outside the signal so that the next layer sees the reference's zero padding.
+#include "conv_lds.h"
+#include "net.h"
+
+namespace vp {
+
+namespace {
+
+constexpr int T0 = 3001, T1 = 751, T2 = 188, T3 = 47, T4 = 12;
+constexpr int IB = 4;  // column of logical sample 0 in every LDS image
+
+constexpr int img_stride(int L) { return ((4 + L + 20 - 16 + 31) / 32) * 32 + 16; }
+constexpr int S1_ = img_stride(T1), S2_ = img_stride(T2), S3_ = img_stride(T3), S4_ = img_stride(T4);
+static_assert(S1_ == 784 && S2_ == 240 && S3_ == 80 && S4_ == 48, "image strides");
+
+template <int C, int S>
+__device__ __forceinline__ void zero_halo(float* img, int L, int tid, int nth) {
+  const int RW = S - L;
+  for (int i = tid; i < C * RW; i += nth) {
+    const int c = i / RW, k = i - c * RW;
+    img[c * S + (k < IB ? k : L + k)] = 0.f;
+  }
+}
+
+struct GlobalRowStore {  // haloed activation tensor row store with a valid range
+  float* p;              // window base + HALO
+  int ls, L, t_add;      // global t = t_local + t_add
+  __device__ __forceinline__ void operator()(int co, int t, float v) const {
+    const int tg = t + t_add;
+    if (t >= 0 && tg >= 0 && tg < L) p[(long)co * ls + tg] = v;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Core: one workgroup (16 waves) per window.
+// ---------------------------------------------------------------------------------------------
+using C_d1same = LdsLayer<8, 0, 16, 1, 7, 1, -3, 0, 3, 1>;
+using C_d1down = LdsLayer<16, 0, 16, 1, 7, 4, -2, 0, 1, 1>;
+using C_d2same = LdsLayer<16, 0, 32, 1, 7, 1, -3, 0, 2, 1>;
+using C_d2down = LdsLayer<32, 0, 32, 1, 7, 4, -1, 0, 1, 1>;
+using C_d3same = LdsLayer<32, 0, 64, 1, 7, 1, -3, 0, 1, 1>;
+using C_d3down = LdsLayer<64, 0, 64, 1, 7, 4, -2, 0, 1, 1>;
+using C_d4same = LdsLayer<64, 0, 128, 1, 7, 1, -3, 0, 1, 1>;
+using C_u0T = LdsLayer<128, 0, 64, 4, 2, 1, -1, -1, 1, 1>;
+using C_u0same = LdsLayer<64, 64, 64, 1, 7, 1, -3, 0, 1, 1>;
+using C_u1T = LdsLayer<64, 0, 32, 4, 2, 1, -1, -1, 1, 1>;
+using C_u1same = LdsLayer<32, 32, 32, 1, 7, 1, -3, 0, 2, 1>;
+using C_u2T = LdsLayer<32, 0, 16, 4, 2, 1, -1, -1, 3, 1>;
+using C_u2same = LdsLayer<16, 16, 16, 1, 7, 1, -3, 0, 3, 1>;
+
+// LDS arena (floats); lifetimes in the header comment of pn_core_kernel
+constexpr int A_SKIP1 = 0;                       // 16 x 784
+constexpr int A_SKIP2 = A_SKIP1 + 16 * S1_;      // 32 x 240
+constexpr int A_Q = A_SKIP2 + 32 * S2_;          // scratch region Q
+constexpr int A_SKIP3 = A_Q;                     // 64 x 80
+constexpr int A_R = A_Q + 64 * S3_;
+constexpr int A_D0 = A_R;                        // 8 x 784
+constexpr int A_D1 = A_R;                        // 16 x 240
+constexpr int A_D2 = A_R;                        // 32 x 80
+constexpr int A_D3 = A_R;                        // 64 x 48
+constexpr int A_BOT = A_R + 64 * S4_;            // 128 x 48
+constexpr int A_U0T = A_BOT + 128 * S4_;         // 64 x 80
+constexpr int A_U0S = A_R;                       // 64 x 80
+constexpr int A_U1T = A_U0S + 64 * S3_;          // 32 x 240
+constexpr int A_U1S = A_Q;                       // 32 x 240
+constexpr int A_U2T = A_U1S + 32 * S2_;          // 16 x 784
+constexpr int CORE_LDS_FLOATS = A_U2T + 16 * S1_;
+static_assert(A_U0T + 64 * S3_ <= CORE_LDS_FLOATS && A_U1T + 32 * S2_ <= CORE_LDS_FLOATS, "arena overflow");
+static_assert(CORE_LDS_FLOATS * 4 <= 160 * 1024, "core arena must fit the 160 KiB LDS");
+
+struct CoreArgs {
+  const float* d0;  // [B][8][ls]   (down0.down)
+  int ls_d0;
+  long ws_d0;
+  float* u2s;       // [B][16][ls]  (up2.same)
+  int ls_u2s;
+  long ws_u2s;
+  const float* af[13];
+  const float* bs[13];
+  // optional debug dumps of every intermediate (null = off): order skip1,d1,skip2,d2,skip3,d3,bottom,u0T,u0s,u1T,u1s,u2T
+  float* dbg[12];
+  int dbg_ls[12];
+  long dbg_ws[12];
+};
+
+template <int C, int S>
+__device__ void dump_image(const float* img, int L, float* dst, int ls, long ws, int win, int tid, int nth) {
+  if (!dst) return;
+  float* d = dst + (long)win * ws + HALO;
+  for (int i = tid; i < C * L; i += nth) {
+    const int c = i / L, t = i - c * L;
+    d[(long)c * ls + t] = img[c * S + IB + t];
+  }
+}
+
+__global__ __launch_bounds__(1024) void pn_core_kernel(const CoreArgs a) {
+  extern __shared__ float4 lds_raw[];
+  float* lds = reinterpret_cast<float*>(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, win = blockIdx.x;
+  constexpr int NTH = 1024, NWV = 16;
+
+  // ---- load down0.down (8 x 751) -------------------------------------------------------
+  {
+    const float* src = a.d0 + (long)win * a.ws_d0 + HALO;
+    float* img = lds + A_D0;
+    for (int i = tid; i < 8 * T1; i += NTH) {
+      const int c = i / T1, t = i - c * T1;
+      img[c * S1_ + IB + t] = src[(long)c * a.ls_d0 + t];
+    }
+    zero_halo<8, S1_>(img, T1, tid, NTH);
+  }
+  __syncthreads();
+
+#define CORE_LAYER(IDX, LAYER, IN1, SI1, IN2, SI2, OUT, SO, CO, COLS, LOUT, DBG)                                   \
+  {                                                                                                                \
+    ImageStore<SO, IB> st{lds + (OUT), 0, (LOUT), 0, (LOUT)};                                                      \
+    zero_halo<CO, SO>(lds + (OUT), (LOUT), tid, NTH);                                                              \
+    conv_lds<LAYER, SI1, IB, SI2, IB>(lds + (IN1), lds + (IN2), a.af[IDX], a.bs[IDX], (COLS), st, wave, NWV, lane); \
+    __syncthreads();                                                                                               \
+    if (a.dbg[DBG]) dump_image<CO, SO>(lds + (OUT), (LOUT), a.dbg[DBG], a.dbg_ls[DBG], a.dbg_ws[DBG], win, tid, NTH); \
+  }
+  //          idx layer      in1      S    in2      S    out      S    C    cols     Lout dbg
+  CORE_LAYER(0, C_d1same, A_D0, S1_, A_D0, S1_, A_SKIP1, S1_, 16, T1, T1, 0)
+  CORE_LAYER(1, C_d1down, A_SKIP1, S1_, A_SKIP1, S1_, A_D1, S2_, 16, T2, T2, 1)
+  CORE_LAYER(2, C_d2same, A_D1, S2_, A_D1, S2_, A_SKIP2, S2_, 32, T2, T2, 2)
+  CORE_LAYER(3, C_d2down, A_SKIP2, S2_, A_SKIP2, S2_, A_D2, S3_, 32, T3, T3, 3)
+  CORE_LAYER(4, C_d3same, A_D2, S3_, A_D2, S3_, A_SKIP3, S3_, 64, T3, T3, 4)
+  CORE_LAYER(5, C_d3down, A_SKIP3, S3_, A_SKIP3, S3_, A_D3, S4_, 64, T4, T4, 5)
+  CORE_LAYER(6, C_d4same, A_D3, S4_, A_D3, S4_, A_BOT, S4_, 128, T4, T4, 6)
+  CORE_LAYER(7, C_u0T, A_BOT, S4_, A_BOT, S4_, A_U0T, S3_, 64, T4 + 1, T3, 7)
+  CORE_LAYER(8, C_u0same, A_SKIP3, S3_, A_U0T, S3_, A_U0S, S3_, 64, T3, T3, 8)
+  CORE_LAYER(9, C_u1T, A_U0S, S3_, A_U0S, S3_, A_U1T, S2_, 32, T3 + 1, T2, 9)
+  CORE_LAYER(10, C_u1same, A_SKIP2, S2_, A_U1T, S2_, A_U1S, S2_, 32, T2, T2, 10)
+  CORE_LAYER(11, C_u2T, A_U1S, S2_, A_U1S, S2_, A_U2T, S1_, 16, T2 + 1, T1, 11)
+#undef CORE_LAYER
+  {
+    GlobalRowStore st{a.u2s + (long)win * a.ws_u2s + HALO, a.ls_u2s, T1, 0};
+    conv_lds<C_u2same, S1_, IB, S1_, IB>(lds + A_SKIP1, lds + A_U2T, a.af[12], a.bs[12], T1, st, wave, NWV, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Level-0 down path, time-tiled: inc -> down0.same -> down0.down.
+// Local coordinate l <-> global level-0 sample (t0 - 12) + l, t0 = tile * TT.
+// ---------------------------------------------------------------------------------------------
+constexpr int TT = 512;                   // level-0 samples per tile
+constexpr int D0_S = 560;                 // image stride (== 16 mod 32), covers local [-4, 556)
+using D_inc = LdsLayer<3, 0, 8, 2, 8, 2, -3, 0, 5, 1>;
+using D_same = LdsLayer<8, 0, 8, 2, 8, 2, -3, 0, 5, 1>;
+using D_down = LdsLayer<8, 0, 8, 2, 11, 8, 9, 0, 1, 1>;  // reads skip0 local 8n + tap + 9 (= global 8(c0+n) + tap - 3)
+constexpr int D0_X = 0, D0_H = 4 * D0_S, D0_K = 12 * D0_S, D0_LDS_FLOATS = 20 * D0_S;
+
+struct Down0Args {
+  const float* x;   // [B][3][ls] normalised input
+  int ls_x;
+  long ws_x;
+  float* skip0;     // [B][8][ls]  (down0.same)
+  int ls_s;
+  long ws_s;
+  float* d0;        // [B][8][ls]  (down0.down)
+  int ls_d;
+  long ws_d;
+  float* h0_dbg;    // optional [B][8][ls] (inc)
+  int ls_h;
+  long ws_h;
+  const float *af_inc, *bs_inc, *af_same, *bs_same, *af_down, *bs_down;
+};
+
+__global__ __launch_bounds__(256) void pn_down0_kernel(const Down0Args a) {
+  extern __shared__ float4 lds_raw[];
+  float* lds = reinterpret_cast<float*>(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x, win = blockIdx.y;
+  const int t0 = tile * TT, o = t0 - 12;
+  constexpr int NTH = 256, NWV = 4;
+
+  // x image: local [-4, TT + 24) as float4s; physical index = HALO + o - 4 + 4q = t0 - 8 + 4q
+  {
+    const float* src = a.x + (long)win * a.ws_x;
+    constexpr int NQ = (TT + 28) / 4;  // 135 float4 per row
+    for (int i = tid; i < 3 * NQ; i += NTH) {
+      const int c = i / NQ, q = i - c * NQ;
+      const int p = t0 - 8 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p >= 0 && p + 3 < a.ls_x) v = *reinterpret_cast<const float4*>(src + (long)c * a.ls_x + p);
+      *reinterpret_cast<float4*>(lds + D0_X + c * D0_S + 4 * q) = v;
+    }
+    for (int i = tid; i < D0_S / 4; i += NTH)  // 4th (padding) channel must be true zeros
+      *reinterpret_cast<float4*>(lds + D0_X + 3 * D0_S + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  const int sig_lo = -o, sig_hi = T0 - o;
+  {
+    ImageStore<D0_S, IB> st{lds + D0_H, 0, TT + 16, sig_lo, sig_hi};
+    conv_lds<D_inc, D0_S, IB, D0_S, IB>(lds + D0_X, lds + D0_X, a.af_inc, a.bs_inc, (TT + 16) / 2, st, wave, NWV, lane);
+  }
+  __syncthreads();
+  if (a.h0_dbg) {
+    float* d = a.h0_dbg + (long)win * a.ws_h + HALO;
+    for (int i = tid; i < 8 * TT; i += NTH) {
+      const int c = i / TT, l = 12 + (i - c * TT);
+      if (o + l < T0) d[(long)c * a.ls_h + o + l] = lds[D0_H + c * D0_S + IB + l];
+    }
+  }
+  {
+    ImageStore<D0_S, IB> st{lds + D0_K, 0, TT + 16, sig_lo, sig_hi};
+    conv_lds<D_same, D0_S, IB, D0_S, IB>(lds + D0_H, lds + D0_H, a.af_same, a.bs_same, (TT + 16) / 2, st, wave, NWV, lane);
+  }
+  __syncthreads();
+  {  // skip tensor rows [t0, t0 + TT) -> memory, 16-byte coalesced (local 12 <-> column 16)
+    float* d = a.skip0 + (long)win * a.ws_s + HALO + t0;
+    for (int i = tid; i < 8 * (TT / 4); i += NTH) {
+      const int c = i / (TT / 4), q = i - c * (TT / 4);
+      const int t = t0 + 4 * q;
+      if (t < T0) {
+        float4 v = *reinterpret_cast<const float4*>(lds + D0_K + c * D0_S + IB + 12 + 4 * q);  // zeros beyond the signal
+        *reinterpret_cast<float4*>(d + (long)c * a.ls_s + 4 * q) = v;
+      }
+    }
+  }
+  {
+    GlobalRowStore st{a.d0 + (long)win * a.ws_d + HALO, a.ls_d, T1, tile * (TT / 4)};
+    conv_lds<D_down, D0_S, IB, D0_S, IB>(lds + D0_K, lds + D0_K, a.af_down, a.bs_down, TT / 8, st, wave, NWV, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Level-0 up path, time-tiled: up3.convT -> cat(skip0, .) -> up3.same -> 1x1 conv + softmax.
+// Level-1 local n <-> global (t0/4 - 4) + n; level-0 local l <-> global (t0 - 16) + l.
+// ---------------------------------------------------------------------------------------------
+constexpr int U_S1 = 176;                 // u2s image stride: local1 [-4, 172)
+constexpr int U_S0 = 592;                 // level-0 image stride: local0 [-4, 588)
+constexpr int U_SO = 516;                 // staged up3.same tile
+using U_T = LdsLayer<16, 0, 8, 4, 2, 1, -1, -2, 5, 1>;
+using U_same = LdsLayer<8, 8, 8, 2, 8, 2, 13, 0, 4, 1>;  // out local'' 2n+p <-> level-0 local 16 + 2n + p
+constexpr int U_U2S = 0, U_SKIP = 16 * U_S1, U_UT = U_SKIP + 8 * U_S0, U_OUT = U_UT + 8 * U_S0;
+constexpr int UP3_LDS_FLOATS = U_OUT + 8 * U_SO;
+
+struct Up3Args {
+  const float* u2s;    // [B][16][ls] (up2.same)
+  int ls_u;
+  long ws_u;
+  const float* skip0;  // [B][8][ls]
+  int ls_s;
+  long ws_s;
+  float* y;            // dense [B][3][T0]
+  float* ut_dbg;       // optional [B][8][ls] (up3.convT)
+  int ls_t;
+  long ws_t;
+  const float *af_t, *bs_t, *af_same, *bs_same;
+  const float* w_out;  // [3][8]
+  const float* b_out;  // [3]
+};
+
+__global__ __launch_bounds__(256) void pn_up3_kernel(const Up3Args a) {
+  extern __shared__ float4 lds_raw[];
+  float* lds = reinterpret_cast<float*>(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x, win = blockIdx.y;
+  const int t0 = tile * TT, o1 = t0 / 4 - 4, o0 = t0 - 16;
+  constexpr int NTH = 256, NWV = 4;
+
+  {  // up2.same rows: local1 [0, 144); physical = HALO + o1 + 4q
+    const float* src = a.u2s + (long)win * a.ws_u + HALO + o1;
+    for (int i = tid; i < 16 * 36; i += NTH) {
+      const int c = i / 36, q = i - c * 36;
+      *reinterpret_cast<float4*>(lds + U_U2S + c * U_S1 + IB + 4 * q) =
+          *reinterpret_cast<const float4*>(src + (long)c * a.ls_u + 4 * q);
+    }
+    if (tid < 16) *reinterpret_cast<float4*>(lds + U_U2S + tid * U_S1) = make_float4(0.f, 0.f, 0.f, 0.f);  // local1 -4..-1
+  }
+  {  // skip rows: local0 [12, 532); physical = HALO + o0 + 12 + 4q = t0 + 4 + 4q
+    const float* src = a.skip0 + (long)win * a.ws_s + HALO + o0 + 12;
+    for (int i = tid; i < 8 * 130; i += NTH) {
+      const int c = i / 130, q = i - c * 130;
+      *reinterpret_cast<float4*>(lds + U_SKIP + c * U_S0 + IB + 12 + 4 * q) =
+          *reinterpret_cast<const float4*>(src + (long)c * a.ls_s + 4 * q);
+    }
+  }
+  __syncthreads();
+  {
+    ImageStore<U_S0, IB> st{lds + U_UT, 0, U_S0 - IB, -o0, T0 - o0};
+    conv_lds<U_T, U_S1, IB, U_S1, IB>(lds + U_U2S, lds + U_U2S, a.af_t, a.bs_t, 144, st, wave, NWV, lane);
+  }
+  __syncthreads();
+  if (a.ut_dbg) {
+    float* d = a.ut_dbg + (long)win * a.ws_t + HALO;
+    for (int i = tid; i < 8 * TT; i += NTH) {
+      const int c = i / TT, l = 16 + (i - c * TT);
+      if (o0 + l < T0) d[(long)c * a.ls_t + o0 + l] = lds[U_UT + c * U_S0 + IB + l];
+    }
+  }
+  {
+    ImageStore<U_SO, 0> st{lds + U_OUT, 0, TT, 0, TT};
+    conv_lds<U_same, U_S0, IB, U_S0, IB>(lds + U_SKIP, lds + U_UT, a.af_same, a.bs_same, TT / 2, st, wave, NWV, lane);
+  }
+  __syncthreads();
+  {  // 1x1 conv (8 -> 3) + softmax over channels, dense output
+    float w[3][8], bb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      bb[c] = a.b_out[c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) w[c][k] = a.w_out[c * 8 + k];
+    }
+    float* y = a.y + (long)win * 3 * T0;
+    for (int l = tid; l < TT; l += NTH) {
+      const int t = t0 + l;
+      if (t < T0) {
+        float z[3] = {bb[0], bb[1], bb[2]};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float v = lds[U_OUT + k * U_SO + l];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) z[c] = fmaf(w[c][k], v, z[c]);
+        }
+        const float mx = fmaxf(z[0], fmaxf(z[1], z[2]));
+        const float e0 = __expf(z[0] - mx), e1 = __expf(z[1] - mx), e2 = __expf(z[2] - mx);
+        const float inv = 1.f / (e0 + e1 + e2);
+        y[t] = e0 * inv;
+        y[T0 + t] = e1 * inv;
+        y[2 * T0 + t] = e2 * inv;
+      }
+    }
+  }
+}
+
+int tensor_id(const Net& net, const std::string& name) {
+  for (size_t i = 0; i < net.tensors.size(); ++i)
+    if (net.tensors[i].name == name) return (int)i;
+  return -1;
+}
+
+}  // namespace
+
+// Replaces the 18 layer steps planned by plan_phasenet with the three fused launches.  The
+// packed weights of the layer plan are reused as they are (same P / taps / channel padding).
+int plan_phasenet_fused(Net& net, bool debug_dumps) {
+  if (net.convs.size() != 18) {
+    set_error("fused PhaseNet plan expects the 18-layer plan");
+    return VP_ERR_INVALID;
+  }
+  const int n_tiles = (T0 + TT - 1) / TT;  // 6
+  const int x = net.input, h0 = tensor_id(net, "inc"), skip0 = tensor_id(net, "down0.same");
+  const int d0 = tensor_id(net, "down0.down"), u2s = tensor_id(net, "up2.same"), u3t = tensor_id(net, "up3.convT");
+  // furthest reads of the tiled loaders
+  net.need(x, (n_tiles - 1) * TT - 8 + 4 * ((TT + 28) / 4));
+  net.need(skip0, HALO + (n_tiles - 1) * TT - 16 + 12 + 4 * 130);
+  net.need(u2s, HALO + (n_tiles - 1) * TT / 4 - 4 + 144);
+  std::vector<Step> steps;
+  auto flops = [&](int lo, int hi) {
+    double f = 0;
+    for (int i = lo; i <= hi; ++i) f += net.convs[i]->flops_per_window;
+    return f;
+  };
+  {
+    Step st;
+    st.name = "fused.down0 (inc+down0.same+down0.down)";
+    st.flops_per_window = flops(0, 2);
+    st.run = [=](Net& n, int B, hipStream_t s) -> int {
+      Down0Args a{};
+      const Tensor &tx = n.tensors[x], &ts = n.tensors[skip0], &td = n.tensors[d0], &th = n.tensors[h0];
+      a.x = tx.p;
+      a.ls_x = tx.ls;
+      a.ws_x = (long)tx.win_stride();
+      a.skip0 = ts.p;
+      a.ls_s = ts.ls;
+      a.ws_s = (long)ts.win_stride();
+      a.d0 = td.p;
+      a.ls_d = td.ls;
+      a.ws_d = (long)td.win_stride();
+      if (debug_dumps) {
+        a.h0_dbg = th.p;
+        a.ls_h = th.ls;
+        a.ws_h = (long)th.win_stride();
+      }
+      a.af_inc = n.convs[0]->afrag.d;
+      a.bs_inc = n.convs[0]->bias.d;
+      a.af_same = n.convs[1]->afrag.d;
+      a.bs_same = n.convs[1]->bias.d;
+      a.af_down = n.convs[2]->afrag.d;
+      a.bs_down = n.convs[2]->bias.d;
+      hipLaunchKernelGGL(pn_down0_kernel, dim3(n_tiles, B), dim3(256), D0_LDS_FLOATS * sizeof(float), s, a);
+      return 0;
+    };
+    steps.push_back(std::move(st));
+  }
+  {
+    Step st;
+    st.name = "fused.core (down1..down4, up0..up2)";
+    st.flops_per_window = flops(3, 15);
+    static const char* dbg_names[12] = {"down1.same", "down1.down", "down2.same", "down2.down", "down3.same", "down3.down",
+                                        "down4.same", "up0.convT",  "up0.same",   "up1.convT",  "up1.same",   "up2.convT"};
+    std::vector<int> dbg_ids(12);
+    for (int i = 0; i < 12; ++i) dbg_ids[i] = tensor_id(net, dbg_names[i]);
+    st.run = [=](Net& n, int B, hipStream_t s) -> int {
+      CoreArgs a{};
+      const Tensor &td = n.tensors[d0], &tu = n.tensors[u2s];
+      a.d0 = td.p;
+      a.ls_d0 = td.ls;
+      a.ws_d0 = (long)td.win_stride();
+      a.u2s = tu.p;
+      a.ls_u2s = tu.ls;
+      a.ws_u2s = (long)tu.win_stride();
+      for (int i = 0; i < 13; ++i) {
+        a.af[i] = n.convs[3 + i]->afrag.d;
+        a.bs[i] = n.convs[3 + i]->bias.d;
+      }
+      for (int i = 0; i < 12; ++i) {
+        if (debug_dumps && dbg_ids[i] >= 0) {
+          const Tensor& t = n.tensors[dbg_ids[i]];
+          a.dbg[i] = t.p;
+          a.dbg_ls[i] = t.ls;
+          a.dbg_ws[i] = (long)t.win_stride();
+        }
+      }
+      hipLaunchKernelGGL(pn_core_kernel, dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
+      return 0;
+    };
+    steps.push_back(std::move(st));
+  }
+  {
+    Step st;
+    st.name = "fused.up3 (up3.convT+up3.same+out+softmax)";
+    st.flops_per_window = flops(16, 17);
+    HostBlob* e0 = &net.convs[17]->e0;
+    HostBlob* e1 = &net.convs[17]->e1;
+    st.run = [=](Net& n, int B, hipStream_t s) -> int {
+      Up3Args a{};
+      const Tensor &tu = n.tensors[u2s], &ts = n.tensors[skip0], &tt = n.tensors[u3t];
+      a.u2s = tu.p;
+      a.ls_u = tu.ls;
+      a.ws_u = (long)tu.win_stride();
+      a.skip0 = ts.p;
+      a.ls_s = ts.ls;
+      a.ws_s = (long)ts.win_stride();
+      a.y = n.y;
+      if (debug_dumps) {
+        a.ut_dbg = tt.p;
+        a.ls_t = tt.ls;
+        a.ws_t = (long)tt.win_stride();
+      }
+      a.af_t = n.convs[16]->afrag.d;
+      a.bs_t = n.convs[16]->bias.d;
+      a.af_same = n.convs[17]->afrag.d;
+      a.bs_same = n.convs[17]->bias.d;
+      a.w_out = e0->d;
+      a.b_out = e1->d;
+      hipLaunchKernelGGL(pn_up3_kernel, dim3(n_tiles, B), dim3(256), UP3_LDS_FLOATS * sizeof(float), s, a);
+      return 0;
+    };
+    steps.push_back(std::move(st));
+  }
+  net.steps = std::move(steps);
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_core_kernel), CORE_LDS_FLOATS * sizeof(float)});
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_down0_kernel), D0_LDS_FLOATS * sizeof(float)});
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_up3_kernel), UP3_LDS_FLOATS * sizeof(float)});
+  return VP_OK;
+}
+
+}  // namespace vp

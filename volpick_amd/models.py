@@ -70,6 +70,7 @@ class WaveformModel:
         self._handle = None
         self._device_index = None
         self._max_batch = 256
+        self._plan_flags = (0, 0)  # vp_config.reserved[0:2]: (layer-by-layer plan, dump fused intermediates)
         self._training = False
         if norm not in ("peak", "std"):
             raise ValueError("norm must be 'peak' or 'std'")
@@ -175,6 +176,7 @@ class WaveformModel:
         _lib.check(lib.vp_default_config(self._kind, C.byref(cfg)))
         cfg.norm = _lib.VP_NORM_PEAK if self.norm == "peak" else _lib.VP_NORM_STD
         cfg.max_batch = int(self._max_batch)
+        cfg.reserved[0], cfg.reserved[1] = int(self._plan_flags[0]), int(self._plan_flags[1])
         return cfg
 
     def _ensure_handle(self, weights_device_ptr=None):
