@@ -97,13 +97,31 @@ def main():
     found = C.c_int()
     fv, lv, nw = C.c_int64(), C.c_int64(), C.c_int64()
 
-    def step():
-        # one library call = gather+normalise, forward, blinding+stacking, trigger scan; one host sync
-        _lib.check(lib.vp_classify(h, C.c_void_p(x.data_ptr()), _lib.VP_MEM_DEVICE, n_samples, overlap, blinding[0],
-                                   blinding[1], _lib.VP_STACK_AVG, args.batch, c_specs, len(specs),
-                                   C.c_void_p(out.data_ptr()), _lib.VP_MEM_DEVICE, C.byref(fv), C.byref(lv),
-                                   C.byref(nw), on, off, peak, val, spec_of, cap, C.byref(found)), "vp_classify")
+    DEPTH = 2  # submits kept in flight: the host enqueues step i+1 while the GPU runs step i
+
+    def submit(slot):
+        # one submit = gather+normalise, forward, blinding+stacking, trigger scan, one async D2H of the triggers
+        _lib.check(lib.vp_classify_submit(h, slot, C.c_void_p(x.data_ptr()), _lib.VP_MEM_DEVICE, n_samples, overlap,
+                                          blinding[0], blinding[1], _lib.VP_STACK_AVG, args.batch, c_specs,
+                                          len(specs), C.c_void_p(out.data_ptr()), _lib.VP_MEM_DEVICE, cap),
+                   "vp_classify_submit")
+
+    def collect(slot):
+        _lib.check(lib.vp_classify_collect(h, slot, C.byref(fv), C.byref(lv), C.byref(nw), on, off, peak, val, spec_of,
+                                           cap, C.byref(found)), "vp_classify_collect")
         return found.value
+
+    def run_steps(k):
+        """k steps, each one full pass of the path over one 256-window batch; every step is collected."""
+        inflight, n_picks = [], 0
+        for i in range(k):
+            if len(inflight) == DEPTH:
+                n_picks = collect(inflight.pop(0))
+            submit(i % DEPTH)
+            inflight.append(i % DEPTH)
+        while inflight:
+            n_picks = collect(inflight.pop(0))
+        return n_picks
 
     def sync_all():
         torch.cuda.synchronize()
@@ -111,13 +129,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        n_picks = step()
+    n_picks = run_steps(args.warmup)
     assert nw.value == args.batch, (nw.value, args.batch)
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        n_picks = step()
+    n_picks = run_steps(args.steps)
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -163,6 +179,7 @@ def main():
             "batch": args.batch,
             "in_samples": T,
             "parallelism": f"stream-sharded x{world}, weights broadcast once (RCCL)",
+            "inflight_steps": DEPTH,
         },
         "roofline": {
             "bound": "mfma",

@@ -123,6 +123,20 @@ int vp_classify(vp_handle* h, const float* stream, int stream_mem, int64_t N, in
                 int out_mem, int64_t* first_valid, int64_t* last_valid, int64_t* n_windows, int64_t* on,
                 int64_t* off, int64_t* peak, float* value, int32_t* spec_of, int cap, int* n_found);
 
+/* Asynchronous form of vp_classify for callers that keep the GPU fed (several station blocks
+ * or bench steps in flight): vp_classify_submit enqueues the whole path on the handle's stream
+ * and returns without synchronising; vp_classify_collect(slot) waits for that submit and returns
+ * its triggers.  Up to VP_MAX_INFLIGHT submits may be outstanding, each in its own slot; work is
+ * executed in submit order.  Buffers passed to submit (stream, out) must stay valid until the
+ * matching collect; a device `out` shared by several in-flight submits is overwritten in order. */
+#define VP_MAX_INFLIGHT 4
+int vp_classify_submit(vp_handle* h, int slot, const float* stream, int stream_mem, int64_t N, int overlap,
+                       int blind_l, int blind_r, int stacking, int batch, const vp_trigger_spec* specs, int n_specs,
+                       float* out, int out_mem, int cap);
+int vp_classify_collect(vp_handle* h, int slot, int64_t* first_valid, int64_t* last_valid, int64_t* n_windows,
+                        int64_t* on, int64_t* off, int64_t* peak, float* value, int32_t* spec_of, int cap,
+                        int* n_found);
+
 /* Host-only variant of vp_pick for traces already in host memory (no handle, no GPU). */
 int vp_pick_host(const float* trace, int64_t n, float thr_on, float thr_off, int64_t* on, int64_t* off,
                  int64_t* peak, float* value, int cap, int* n_found);

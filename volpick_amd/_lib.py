@@ -16,6 +16,7 @@ VP_MODEL_PHASENET, VP_MODEL_EQTRANSFORMER = 0, 1
 VP_NORM_PEAK, VP_NORM_STD = 0, 1
 VP_STACK_AVG, VP_STACK_MAX = 0, 1
 VP_MEM_HOST, VP_MEM_DEVICE = 0, 1
+VP_MAX_INFLIGHT = 4
 
 
 class VpConfig(C.Structure):
@@ -71,6 +72,16 @@ SIGNATURES = {
         C.c_int,
         [_H, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(VpTriggerSpec),
          C.c_int, C.c_void_p, C.c_int, _I64P, _I64P, _I64P, _I64P, _I64P, _I64P, _FP, C.POINTER(C.c_int32), C.c_int,
+         C.POINTER(C.c_int)],
+    ),
+    "vp_classify_submit": (
+        C.c_int,
+        [_H, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+         C.POINTER(VpTriggerSpec), C.c_int, C.c_void_p, C.c_int, C.c_int],
+    ),
+    "vp_classify_collect": (
+        C.c_int,
+        [_H, C.c_int, _I64P, _I64P, _I64P, _I64P, _I64P, _I64P, _FP, C.POINTER(C.c_int32), C.c_int,
          C.POINTER(C.c_int)],
     ),
     "vp_pick_host": (

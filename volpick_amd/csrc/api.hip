@@ -24,9 +24,15 @@ struct vp_handle {
   size_t d_pred_cap = 0;
   float* d_out = nullptr;   // stacked output when the caller's buffer is on the host
   size_t d_out_cap = 0;
-  char* d_pick = nullptr;   // trigger results: counters + per-spec on/off/peak/value arrays
-  char* h_pick = nullptr;   // pinned host mirror, filled by ONE async copy per call
-  size_t pick_bytes = 0;
+  struct Slot {             // one in-flight vp_classify_submit
+    char* d_pick = nullptr;  // trigger results: counters + per-spec on/off/peak/value arrays
+    char* h_pick = nullptr;  // pinned host mirror, filled by ONE async copy per submit
+    size_t pick_bytes = 0;
+    hipEvent_t done = nullptr;
+    bool busy = false;
+    int n_specs = 0, cap = 0;
+    int64_t fv = -1, lv = -1, nwin = 0;
+  } slot[VP_MAX_INFLIGHT];
   int64_t* d_ends = nullptr;  // run-end scratch of the trigger scan
   size_t ends_cap = 0;
 };
@@ -161,6 +167,7 @@ int vp_create(int device_id, int model_kind, const float* weights, size_t n_floa
   }
   VP_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   for (auto& e : h->ev) VP_HIP(hipEventCreate(&e));
+  for (auto& sl : h->slot) VP_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
   *out = h;
   return VP_OK;
 }
@@ -175,8 +182,11 @@ int vp_destroy(vp_handle* h) {
   if (h->d_in) (void)hipFree(h->d_in);
   if (h->d_pred) (void)hipFree(h->d_pred);
   if (h->d_out) (void)hipFree(h->d_out);
-  if (h->d_pick) (void)hipFree(h->d_pick);
-  if (h->h_pick) (void)hipHostFree(h->h_pick);
+  for (auto& sl : h->slot) {
+    if (sl.d_pick) (void)hipFree(sl.d_pick);
+    if (sl.h_pick) (void)hipHostFree(sl.h_pick);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+  }
   if (h->d_ends) (void)hipFree(h->d_ends);
   h->net.release();
   delete h;
@@ -360,23 +370,25 @@ static ScanLayout scan_layout(int n_specs, int cap) {
   return L;
 }
 
-static int scan_rows(vp_handle* h, const float* const* rows, const int64_t* lens, const float* thr_on,
-                     const float* thr_off, int n_specs, int cap, int64_t* on, int64_t* off, int64_t* peak,
-                     float* value, int32_t* spec_of, int* n_found) {
+// Enqueue the trigger scan of `n_specs` device rows into slot `sl` (no host synchronisation).
+static int scan_submit(vp_handle* h, vp_handle::Slot& sl, const float* const* rows, const int64_t* lens,
+                       const float* thr_on, const float* thr_off, int n_specs, int cap) {
   const ScanLayout L = scan_layout(n_specs, cap);
-  if (L.total > h->pick_bytes) {
-    if (h->d_pick) (void)hipFree(h->d_pick);
-    if (h->h_pick) (void)hipHostFree(h->h_pick);
-    h->d_pick = h->h_pick = nullptr;
-    h->pick_bytes = 0;
-    VP_HIP(hipMalloc((void**)&h->d_pick, L.total));
-    VP_HIP(hipHostMalloc((void**)&h->h_pick, L.total, hipHostMallocDefault));
-    h->pick_bytes = L.total;
+  if (L.total > sl.pick_bytes) {
+    if (sl.d_pick) (void)hipFree(sl.d_pick);
+    if (sl.h_pick) (void)hipHostFree(sl.h_pick);
+    sl.d_pick = sl.h_pick = nullptr;
+    sl.pick_bytes = 0;
+    VP_HIP(hipMalloc((void**)&sl.d_pick, L.total));
+    VP_HIP(hipHostMalloc((void**)&sl.h_pick, L.total, hipHostMallocDefault));
+    sl.pick_bytes = L.total;
   }
   int64_t max_len = 0;
   for (int i = 0; i < n_specs; ++i) max_len = std::max(max_len, lens[i]);
-  const size_t ends_need = (size_t)max_len / 2 + 2;
+  const size_t ends_per_row = (size_t)max_len / 2 + 2;
+  const size_t ends_need = ends_per_row * std::min(n_specs, vp::kMaxPickRows);
   if (ends_need > h->ends_cap) {
+    VP_HIP(hipStreamSynchronize(h->stream));  // earlier scans may still use the old scratch
     if (h->d_ends) (void)hipFree(h->d_ends);
     h->d_ends = nullptr;
     h->ends_cap = 0;
@@ -384,35 +396,45 @@ static int scan_rows(vp_handle* h, const float* const* rows, const int64_t* lens
     h->ends_cap = ends_need;
   }
   VP_HIP(hipEventRecord(h->ev[3], h->stream));
-  VP_HIP(hipMemsetAsync(h->d_pick, 0, L.header, h->stream));
-  for (int i = 0; i < n_specs; ++i) {
-    if (lens[i] <= 0) continue;
-    char* base = h->d_pick + L.header + L.per_spec * i;
-    vp::PickArgs a{};
-    a.trace = rows[i];
-    a.n = lens[i];
-    a.thr_on = thr_on[i];
-    a.thr_off = thr_off[i];
-    a.count = (int*)h->d_pick + 2 * i;
-    a.n_ends = (int*)h->d_pick + 2 * i + 1;
-    a.on = (int64_t*)base;
-    a.off = a.on + L.cap;
-    a.peak = a.off + L.cap;
-    a.value = (float*)(a.peak + L.cap);
-    a.cap = cap;
-    a.ends = h->d_ends;
-    a.ends_cap = (int)std::min<size_t>(h->ends_cap, 0x7fffffff);
-    vp::launch_pick(a, h->stream);
+  VP_HIP(hipMemsetAsync(sl.d_pick, 0, L.header, h->stream));
+  for (int i0 = 0; i0 < n_specs; i0 += vp::kMaxPickRows) {
+    vp::PickBatch batch{};
+    for (int i = i0; i < n_specs && i < i0 + vp::kMaxPickRows; ++i) {
+      char* base = sl.d_pick + L.header + L.per_spec * i;
+      vp::PickArgs& a = batch.a[batch.n++];
+      a.trace = rows[i];
+      a.n = lens[i] > 0 ? lens[i] : 0;
+      a.thr_on = thr_on[i];
+      a.thr_off = thr_off[i];
+      a.count = (int*)sl.d_pick + 2 * i;
+      a.n_ends = (int*)sl.d_pick + 2 * i + 1;
+      a.on = (int64_t*)base;
+      a.off = a.on + L.cap;
+      a.peak = a.off + L.cap;
+      a.value = (float*)(a.peak + L.cap);
+      a.cap = cap;
+      a.ends = h->d_ends + (size_t)(i - i0) * ends_per_row;  // rows of one launch scan concurrently
+      a.ends_cap = (int)std::min<size_t>(ends_per_row, 0x7fffffff);
+    }
+    vp::launch_pick(batch, h->stream);
   }
   VP_HIP(hipEventRecord(h->ev[4], h->stream));
-  VP_HIP(hipMemcpyAsync(h->h_pick, h->d_pick, L.total, hipMemcpyDeviceToHost, h->stream));
-  VP_HIP(hipStreamSynchronize(h->stream));
+  VP_HIP(hipMemcpyAsync(sl.h_pick, sl.d_pick, L.total, hipMemcpyDeviceToHost, h->stream));
+  sl.n_specs = n_specs;
+  sl.cap = cap;
+  return VP_OK;
+}
+
+// After the slot's `done` event: sort each spec's triggers by onset and hand them out.
+static int scan_collect(const vp_handle::Slot& sl, int64_t* on, int64_t* off, int64_t* peak, float* value,
+                        int32_t* spec_of, int cap, int* n_found) {
+  const ScanLayout L = scan_layout(sl.n_specs, sl.cap);
   int total = 0, written = 0;
-  for (int i = 0; i < n_specs; ++i) {
-    const int found = ((const int*)h->h_pick)[2 * i];
+  for (int i = 0; i < sl.n_specs; ++i) {
+    const int found = ((const int*)sl.h_pick)[2 * i];
     total += found;
-    const int m = std::min(found, cap);
-    const char* base = h->h_pick + L.header + L.per_spec * i;
+    const int m = std::min(found, sl.cap);
+    const char* base = sl.h_pick + L.header + L.per_spec * i;
     const int64_t* t_on = (const int64_t*)base;
     const int64_t* t_off = t_on + L.cap;
     const int64_t* t_pk = t_off + L.cap;
@@ -432,31 +454,32 @@ static int scan_rows(vp_handle* h, const float* const* rows, const int64_t* lens
   return VP_OK;
 }
 
-int vp_classify(vp_handle* h, const float* stream, int stream_mem, int64_t N, int overlap, int blind_l,
-                int blind_r, int stacking, int batch, const vp_trigger_spec* specs, int n_specs, float* out,
-                int out_mem, int64_t* first_valid, int64_t* last_valid, int64_t* n_windows, int64_t* on,
-                int64_t* off, int64_t* peak, float* value, int32_t* spec_of, int cap, int* n_found) {
-  VP_REQUIRE(h && stream && n_found, "null argument");
+int vp_classify_submit(vp_handle* h, int slot, const float* stream, int stream_mem, int64_t N, int overlap,
+                       int blind_l, int blind_r, int stacking, int batch, const vp_trigger_spec* specs, int n_specs,
+                       float* out, int out_mem, int cap) {
+  VP_REQUIRE(h && stream, "null argument");
+  VP_REQUIRE(slot >= 0 && slot < VP_MAX_INFLIGHT, "slot %d outside [0, %d)", slot, VP_MAX_INFLIGHT);
+  VP_REQUIRE(!h->slot[slot].busy, "slot %d has an uncollected submit", slot);
   VP_REQUIRE(n_specs >= 0 && n_specs <= 16 && (n_specs == 0 || specs), "bad trigger specs");
-  VP_REQUIRE(cap >= 0 && (cap == 0 || (on && off && peak && value)), "null output arrays");
+  VP_REQUIRE(cap >= 0, "negative cap");
   VP_HIP(hipSetDevice(h->device));
   const int n_out = h->net.n_out;
   for (int i = 0; i < n_specs; ++i) {
     VP_REQUIRE(specs[i].row >= 0 && specs[i].row < n_out, "spec %d: row %d out of range", i, specs[i].row);
     VP_REQUIRE(specs[i].thr_off <= specs[i].thr_on, "spec %d: thr_off must not exceed thr_on", i);
   }
+  vp_handle::Slot& sl = h->slot[slot];
   float* d_out = (out && out_mem == VP_MEM_DEVICE) ? out : nullptr;
   if (!d_out) {
-    int rc = grow(&h->d_out, &h->d_out_cap, (size_t)n_out * std::max<int64_t>(N, 1));
+    const size_t need = (size_t)n_out * std::max<int64_t>(N, 1);
+    if (need > h->d_out_cap) VP_HIP(hipStreamSynchronize(h->stream));  // in-flight work may still read the old buffer
+    int rc = grow(&h->d_out, &h->d_out_cap, need);
     if (rc != VP_OK) return rc;
     d_out = h->d_out;
   }
-  int64_t fv = -1, lv = -1;
-  int rc = annotate_device(h, stream, stream_mem, N, overlap, blind_l, blind_r, stacking, batch, d_out, &fv, &lv,
-                           n_windows);
+  int rc = annotate_device(h, stream, stream_mem, N, overlap, blind_l, blind_r, stacking, batch, d_out, &sl.fv, &sl.lv,
+                           &sl.nwin);
   if (rc != VP_OK) return rc;
-  if (first_valid) *first_valid = fv;
-  if (last_valid) *last_valid = lv;
   if (out && out_mem == VP_MEM_HOST) {
     VP_HIP(hipMemcpyAsync(out, d_out, (size_t)n_out * N * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   }
@@ -469,13 +492,54 @@ int vp_classify(vp_handle* h, const float* stream, int stream_mem, int64_t N, in
     t_on[i] = specs[i].thr_on;
     t_off[i] = specs[i].thr_off;
   }
-  *n_found = 0;
+  sl.n_specs = 0;
   if (n_specs > 0) {
-    rc = scan_rows(h, rows, lens, t_on, t_off, n_specs, cap, on, off, peak, value, spec_of, n_found);
+    rc = scan_submit(h, sl, rows, lens, t_on, t_off, n_specs, cap);
     if (rc != VP_OK) return rc;
-  } else {
-    VP_HIP(hipStreamSynchronize(h->stream));
   }
+  VP_HIP(hipEventRecord(sl.done, h->stream));
+  sl.busy = true;
+  return VP_OK;
+}
+
+int vp_classify_collect(vp_handle* h, int slot, int64_t* first_valid, int64_t* last_valid, int64_t* n_windows,
+                        int64_t* on, int64_t* off, int64_t* peak, float* value, int32_t* spec_of, int cap,
+                        int* n_found) {
+  VP_REQUIRE(h && n_found, "null argument");
+  VP_REQUIRE(slot >= 0 && slot < VP_MAX_INFLIGHT, "slot %d outside [0, %d)", slot, VP_MAX_INFLIGHT);
+  VP_REQUIRE(h->slot[slot].busy, "slot %d has nothing to collect", slot);
+  VP_REQUIRE(cap >= 0 && (cap == 0 || (on && off && peak && value)), "null output arrays");
+  vp_handle::Slot& sl = h->slot[slot];
+  VP_HIP(hipSetDevice(h->device));
+  VP_HIP(hipEventSynchronize(sl.done));
+  sl.busy = false;
+  if (first_valid) *first_valid = sl.fv;
+  if (last_valid) *last_valid = sl.lv;
+  if (n_windows) *n_windows = sl.nwin;
+  *n_found = 0;
+  if (sl.n_specs > 0) return scan_collect(sl, on, off, peak, value, spec_of, cap, n_found);
+  return VP_OK;
+}
+
+int vp_classify(vp_handle* h, const float* stream, int stream_mem, int64_t N, int overlap, int blind_l,
+                int blind_r, int stacking, int batch, const vp_trigger_spec* specs, int n_specs, float* out,
+                int out_mem, int64_t* first_valid, int64_t* last_valid, int64_t* n_windows, int64_t* on,
+                int64_t* off, int64_t* peak, float* value, int32_t* spec_of, int cap, int* n_found) {
+  VP_REQUIRE(h && stream && n_found, "null argument");
+  VP_REQUIRE(cap >= 0 && (cap == 0 || (on && off && peak && value)), "null output arrays");
+  int slot = -1;
+  for (int i = 0; i < VP_MAX_INFLIGHT; ++i)
+    if (!h->slot[i].busy) {
+      slot = i;
+      break;
+    }
+  VP_REQUIRE(slot >= 0, "all %d in-flight slots are busy", VP_MAX_INFLIGHT);
+  int rc = vp_classify_submit(h, slot, stream, stream_mem, N, overlap, blind_l, blind_r, stacking, batch, specs,
+                              n_specs, out, out_mem, cap);
+  if (rc != VP_OK) return rc;
+  rc = vp_classify_collect(h, slot, first_valid, last_valid, n_windows, on, off, peak, value, spec_of, cap, n_found);
+  if (rc != VP_OK) return rc;
+  VP_HIP(hipStreamSynchronize(h->stream));  // also covers a host-side `out` copy
   read_stage_timing(h, n_specs > 0);
   return VP_OK;
 }
@@ -505,9 +569,19 @@ int vp_pick(vp_handle* h, const float* trace, int trace_mem, int64_t n, float th
   VP_HIP(hipSetDevice(h->device));
   const float* rows[1] = {trace};
   const int64_t lens[1] = {n};
-  int rc = scan_rows(h, rows, lens, &thr_on, &thr_off, 1, cap, on, off, peak, value, nullptr, n_found);
-  if (rc == VP_OK) (void)hipEventElapsedTime(&h->stage_ms[3], h->ev[3], h->ev[4]);
-  return rc;
+  int slot = -1;
+  for (int i = 0; i < VP_MAX_INFLIGHT; ++i)
+    if (!h->slot[i].busy) {
+      slot = i;
+      break;
+    }
+  VP_REQUIRE(slot >= 0, "all %d in-flight slots are busy", VP_MAX_INFLIGHT);
+  vp_handle::Slot& sl = h->slot[slot];
+  int rc = scan_submit(h, sl, rows, lens, &thr_on, &thr_off, 1, cap);
+  if (rc != VP_OK) return rc;
+  VP_HIP(hipStreamSynchronize(h->stream));
+  (void)hipEventElapsedTime(&h->stage_ms[3], h->ev[3], h->ev[4]);
+  return scan_collect(sl, on, off, peak, value, nullptr, cap, n_found);
 }
 
 int vp_last_timing(const vp_handle* h, float* total_ms, float stage_ms[4]) {

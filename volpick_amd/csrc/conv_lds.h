@@ -45,31 +45,32 @@ __device__ __forceinline__ void conv_lds(const float* in1, const float* in2, con
 #pragma unroll
     for (int j = 0; j < L::NB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* ap = afrag + (long)mt * L::CB * L::TAPS * 64 + lane;
-    {
-      const float* bp = in1 + g * S1 + B1 + (colb + n) * L::SN + L::IN_OFF;
-      for (int cb = 0; cb < L::CB1; ++cb) {
+    const float* bp1 = in1 + g * S1 + B1 + (colb + n) * L::SN + L::IN_OFF;
+    const float* bp2 = in2 + g * S2 + B2 + (colb + n) * L::SN + L::IN_OFF;
+    // K loop over 4-channel blocks; the A fragments of block cb+1 are fetched (L2 -> VGPR) while
+    // block cb's TAPS*NB MFMAs issue, two named register sets, loop unrolled by two.
+    float a0[L::TAPS], a1[L::TAPS];
+    auto load_a = [&](float (&dst)[L::TAPS], int cb) {
 #pragma unroll
-        for (int tap = 0; tap < L::TAPS; ++tap) {
-          const float av = ap[(cb * L::TAPS + tap) * 64];
+      for (int tap = 0; tap < L::TAPS; ++tap) dst[tap] = ap[(cb * L::TAPS + tap) * 64];
+    };
+    auto mac = [&](const float (&av)[L::TAPS], int cb) {
+      const float* bp = (cb < L::CB1) ? bp1 + cb * 4 * S1 : bp2 + (cb - L::CB1) * 4 * S2;
 #pragma unroll
-          for (int j = 0; j < L::NB; ++j) {
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[cb * 4 * S1 + j * 16 * L::SN + tap], acc[j], 0, 0, 0);
-          }
+      for (int tap = 0; tap < L::TAPS; ++tap) {
+#pragma unroll
+        for (int j = 0; j < L::NB; ++j) {
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap], bp[j * 16 * L::SN + tap], acc[j], 0, 0, 0);
         }
       }
-    }
-    if constexpr (L::CB2 > 0) {
-      const float* bp = in2 + g * S2 + B2 + (colb + n) * L::SN + L::IN_OFF;
-      const float* ap2 = ap + L::CB1 * L::TAPS * 64;
-      for (int cb = 0; cb < L::CB2; ++cb) {
-#pragma unroll
-        for (int tap = 0; tap < L::TAPS; ++tap) {
-          const float av = ap2[(cb * L::TAPS + tap) * 64];
-#pragma unroll
-          for (int j = 0; j < L::NB; ++j) {
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[cb * 4 * S2 + j * 16 * L::SN + tap], acc[j], 0, 0, 0);
-          }
-        }
+    };
+    load_a(a0, 0);
+    for (int cb = 0; cb < L::CB; cb += 2) {
+      if (cb + 1 < L::CB) load_a(a1, cb + 1);
+      mac(a0, cb);
+      if (cb + 1 < L::CB) {
+        if (cb + 2 < L::CB) load_a(a0, cb + 2);
+        mac(a1, cb + 1);
       }
     }
 #pragma unroll

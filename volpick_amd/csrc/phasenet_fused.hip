@@ -47,16 +47,16 @@ struct GlobalRowStore {  // haloed activation tensor row store with a valid rang
 // Core: one workgroup (16 waves) per window.
 // ---------------------------------------------------------------------------------------------
 using C_d1same = LdsLayer<8, 0, 16, 1, 7, 1, -3, 0, 3, 1>;
-using C_d1down = LdsLayer<16, 0, 16, 1, 7, 4, -2, 0, 1, 1>;
-using C_d2same = LdsLayer<16, 0, 32, 1, 7, 1, -3, 0, 2, 1>;
+using C_d1down = LdsLayer<16, 0, 16, 1, 7, 4, -2, 0, 3, 1>;
+using C_d2same = LdsLayer<16, 0, 32, 1, 7, 1, -3, 0, 3, 1>;
 using C_d2down = LdsLayer<32, 0, 32, 1, 7, 4, -1, 0, 1, 1>;
-using C_d3same = LdsLayer<32, 0, 64, 1, 7, 1, -3, 0, 1, 1>;
+using C_d3same = LdsLayer<32, 0, 64, 1, 7, 1, -3, 0, 3, 1>;
 using C_d3down = LdsLayer<64, 0, 64, 1, 7, 4, -2, 0, 1, 1>;
 using C_d4same = LdsLayer<64, 0, 128, 1, 7, 1, -3, 0, 1, 1>;
 using C_u0T = LdsLayer<128, 0, 64, 4, 2, 1, -1, -1, 1, 1>;
-using C_u0same = LdsLayer<64, 64, 64, 1, 7, 1, -3, 0, 1, 1>;
-using C_u1T = LdsLayer<64, 0, 32, 4, 2, 1, -1, -1, 1, 1>;
-using C_u1same = LdsLayer<32, 32, 32, 1, 7, 1, -3, 0, 2, 1>;
+using C_u0same = LdsLayer<64, 64, 64, 1, 7, 1, -3, 0, 3, 1>;
+using C_u1T = LdsLayer<64, 0, 32, 4, 2, 1, -1, -1, 3, 1>;
+using C_u1same = LdsLayer<32, 32, 32, 1, 7, 1, -3, 0, 3, 1>;
 using C_u2T = LdsLayer<32, 0, 16, 4, 2, 1, -1, -1, 3, 1>;
 using C_u2same = LdsLayer<16, 16, 16, 1, 7, 1, -3, 0, 3, 1>;
 

@@ -47,7 +47,12 @@ struct PickArgs {
   int ends_cap;
   int* n_ends;
 };
-int launch_pick(const PickArgs& a, hipStream_t stream);
+constexpr int kMaxPickRows = 4;
+struct PickBatch {
+  PickArgs a[kMaxPickRows];
+  int n;
+};
+int launch_pick(const PickBatch& b, hipStream_t stream);
 int pick_host(const float* x, int64_t n, float thr_on, float thr_off, int64_t* on, int64_t* off, int64_t* peak,
               float* value, int cap, int* n_found);
 

@@ -172,7 +172,8 @@ int launch_stack(const StackArgs& a, hipStream_t stream) {
 //          strided max/argmax over [on, off] with a wave reduction.
 // Triggers are appended with one atomic each and sorted on the host.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void run_end_kernel(const PickArgs a) {
+__global__ __launch_bounds__(256) void run_end_kernel(const PickBatch batch) {
+  const PickArgs& a = batch.a[blockIdx.y];
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   if (t >= a.n) return;
   if (!(a.trace[t] > a.thr_off)) return;
@@ -181,7 +182,8 @@ __global__ __launch_bounds__(256) void run_end_kernel(const PickArgs a) {
   if (slot < a.ends_cap) a.ends[slot] = t;
 }
 
-__global__ __launch_bounds__(256) void run_scan_kernel(const PickArgs a) {
+__global__ __launch_bounds__(256) void run_scan_kernel(const PickBatch batch) {
+  const PickArgs& a = batch.a[blockIdx.y];
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
   const int n_waves = (gridDim.x * 256) >> 6;
@@ -231,9 +233,13 @@ __global__ __launch_bounds__(256) void run_scan_kernel(const PickArgs a) {
   }
 }
 
-int launch_pick(const PickArgs& a, hipStream_t stream) {
-  hipLaunchKernelGGL(run_end_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(run_scan_kernel, dim3(256), dim3(256), 0, stream, a);
+// All rows of one classify call in two launches (blockIdx.y = row); rows need separate scratch.
+int launch_pick(const PickBatch& b, hipStream_t stream) {
+  long n_max = 0;
+  for (int i = 0; i < b.n; ++i) n_max = (b.a[i].n > n_max) ? b.a[i].n : n_max;
+  if (b.n <= 0 || n_max <= 0) return 0;
+  hipLaunchKernelGGL(run_end_kernel, dim3((unsigned)((n_max + 255) / 256), b.n), dim3(256), 0, stream, b);
+  hipLaunchKernelGGL(run_scan_kernel, dim3(64, b.n), dim3(256), 0, stream, b);
   return 0;
 }
 
