@@ -52,7 +52,8 @@ typedef struct {
   float norm_eps;             /* x / (amp + norm_eps) */
   int32_t taper_samples;      /* EQT half-cosine taper length (0 for PhaseNet) */
   int32_t reserved[8];        /* [0]: 1 = PhaseNet layer-by-layer plan instead of the fused kernels (debug / A-B);
-                                 [1]: 1 = fused kernels also dump their LDS intermediates to the debug tensors */
+                                 [1]: bit0 = fused kernels also dump their LDS intermediates to the debug tensors,
+                                      bit1 = the fused core kernel records per-layer clock stamps */
 } vp_config;
 
 /* Fills cfg with the defaults for model_kind. */
@@ -178,6 +179,10 @@ int vp_debug_plan_conv(int model_kind, const float* weights, size_t n_floats, co
 int vp_debug_tensor_count(const vp_handle* h);
 int vp_debug_tensor_info(const vp_handle* h, int index, const char** name, int* channels, int* length);
 int vp_debug_tensor_read(vp_handle* h, int index, int B, float* host_out);
+
+/* Debug (handles created with reserved[1] & 2): B x 16 shader-clock stamps of the fused PhaseNet
+ * core kernel: kernel start, input loaded, then after each of its 13 layers. */
+int vp_debug_core_clock(vp_handle* h, int B, unsigned long long* out16);
 
 const char* vp_last_error(void);
 const char* vp_version(void);

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Per-layer cycle shares of the fused PhaseNet core kernel (debug plan, shader-clock stamps)."""
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch  # noqa: E402
+
+import volpick_amd as va  # noqa: E402
+from volpick_amd import _lib  # noqa: E402
+from volpick_amd.synthetic import synthetic_windows  # noqa: E402
+
+B = 256
+m = va.PhaseNet.from_pretrained("volpick")
+m._plan_flags = (0, 2)
+m.cuda()
+x = torch.from_numpy(synthetic_windows(B, 3001, seed=1)).cuda()
+for _ in range(3):
+    m._forward_raw(x, preprocess=True)
+# steady state: 200 back-to-back launches of every step, stamps of the last launch survive
+lib = _lib.load()
+n = lib.vp_step_count(m._handle)
+ms = (C.c_float * n)()
+_lib.check(lib.vp_profile_steps(m._handle, B, 200, ms, n))
+print("step ms:", [round(v * 1e3, 1) for v in ms])
+clk = np.zeros((B, 32), np.uint64)
+_lib.check(_lib.load().vp_debug_core_clock(m._handle, B, clk.ctypes.data_as(C.c_void_p)))
+d = np.diff(clk[:, :15].astype(np.int64), axis=1)
+names = ["load d0", "d1same", "d1down", "d2same", "d2down", "d3same", "d3down", "d4same", "u0T", "u0same", "u1T",
+         "u1same", "u2T", "u2same"]
+med = np.median(d, axis=0)
+tot = med.sum()
+for n, c in zip(names, med):
+    print(f"{n:10s} {c:10.0f} cycles  {100 * c / tot:5.1f} %")
+wall = (clk[:, 17] - clk[:, 16]).astype(np.float64) / 100e6
+cyc = (clk[:, 14] - clk[:, 0]).astype(np.float64)
+print("in-kernel wall us (median)", np.median(wall) * 1e6, " shader clock GHz (median)", np.median(cyc / wall) / 1e9)
+print("total", tot, "cycles; window span min/med/max", (clk[:, 14] - clk[:, 0]).min(), np.median(clk[:, 14] - clk[:, 0]),
+      (clk[:, 14] - clk[:, 0]).max())

@@ -380,7 +380,8 @@ static int scan_submit(vp_handle* h, vp_handle::Slot& sl, const float* const* ro
     sl.d_pick = sl.h_pick = nullptr;
     sl.pick_bytes = 0;
     VP_HIP(hipMalloc((void**)&sl.d_pick, L.total));
-    VP_HIP(hipHostMalloc((void**)&sl.h_pick, L.total, hipHostMallocDefault));
+    VP_HIP(hipMemset(sl.d_pick, 0, L.total));  // counters start at zero; publish_kernel re-arms them
+    VP_HIP(hipHostMalloc((void**)&sl.h_pick, L.total, hipHostMallocMapped));
     sl.pick_bytes = L.total;
   }
   int64_t max_len = 0;
@@ -396,7 +397,6 @@ static int scan_submit(vp_handle* h, vp_handle::Slot& sl, const float* const* ro
     h->ends_cap = ends_need;
   }
   VP_HIP(hipEventRecord(h->ev[3], h->stream));
-  VP_HIP(hipMemsetAsync(sl.d_pick, 0, L.header, h->stream));
   for (int i0 = 0; i0 < n_specs; i0 += vp::kMaxPickRows) {
     vp::PickBatch batch{};
     for (int i = i0; i < n_specs && i < i0 + vp::kMaxPickRows; ++i) {
@@ -418,8 +418,8 @@ static int scan_submit(vp_handle* h, vp_handle::Slot& sl, const float* const* ro
     }
     vp::launch_pick(batch, h->stream);
   }
+  vp::launch_publish(sl.d_pick, sl.h_pick, n_specs, cap, (long)L.header, (long)L.per_spec, h->stream);
   VP_HIP(hipEventRecord(h->ev[4], h->stream));
-  VP_HIP(hipMemcpyAsync(sl.h_pick, sl.d_pick, L.total, hipMemcpyDeviceToHost, h->stream));
   sl.n_specs = n_specs;
   sl.cap = cap;
   return VP_OK;
@@ -647,6 +647,15 @@ int vp_debug_tensor_read(vp_handle* h, int index, int B, float* host_out) {
   // strided copy: (B*C rows) x L floats out of rows of stride ls, skipping the halo
   VP_HIP(hipMemcpy2D(host_out, (size_t)t.L * sizeof(float), t.p + vp::HALO, (size_t)t.ls * sizeof(float),
                      (size_t)t.L * sizeof(float), (size_t)B * t.C, hipMemcpyDeviceToHost));
+  return VP_OK;
+}
+
+// Debug: per-window shader-clock stamps of the fused PhaseNet core kernel (plan flag reserved[1]).
+int vp_debug_core_clock(vp_handle* h, int B, unsigned long long* out32) {
+  VP_REQUIRE(h && out32 && h->net.debug_clock && h->net.debug_clock->d, "no clock stamps (create with reserved[1]=1)");
+  VP_HIP(hipSetDevice(h->device));
+  VP_HIP(hipStreamSynchronize(h->stream));
+  VP_HIP(hipMemcpy(out32, h->net.debug_clock->d, (size_t)B * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return VP_OK;
 }
 

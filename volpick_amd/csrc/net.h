@@ -53,6 +53,7 @@ struct Net {
   float* arena = nullptr;  // one device allocation for tensors + constants
   size_t arena_floats = 0;
   double flops_per_window = 0;
+  HostBlob* debug_clock = nullptr;  // fused PhaseNet core: per-layer shader-clock stamps (debug plan flag)
 
   int add_tensor(const std::string& name, int C, int L, int sets = 1);
   HostBlob* add_blob(std::vector<float> v);
@@ -93,7 +94,7 @@ struct Net {
 };
 
 int plan_phasenet(Net& net, const ParamView& pv);
-int plan_phasenet_fused(Net& net, bool debug_dumps);  // swaps the 18 layer steps for 3 fused launches
+int plan_phasenet_fused(Net& net, int debug_flags);  // bit0: dump LDS intermediates, bit1: clock stamps;  // swaps the 18 layer steps for 3 fused launches
 int plan_eqt(Net& net, const ParamView& pv);
 
 // BatchNorm (eval) folded into the preceding conv: scale = gamma / sqrt(var + eps),

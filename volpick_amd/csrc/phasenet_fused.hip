@@ -25,14 +25,23 @@ constexpr int img_stride(int L) { return ((4 + L + 20 - 16 + 31) / 32) * 32 + 16
 constexpr int S1_ = img_stride(T1), S2_ = img_stride(T2), S3_ = img_stride(T3), S4_ = img_stride(T4);
 static_assert(S1_ == 784 && S2_ == 240 && S3_ == 80 && S4_ == 48, "image strides");
 
-template <int C, int S>
-__device__ __forceinline__ void zero_halo(float* img, int L, int tid, int nth) {
-  const int RW = S - L;
+template <int C, int S, int L>
+__device__ __forceinline__ void zero_halo(float* img, int tid, int nth) {
+  constexpr int RW = S - L;
   for (int i = tid; i < C * RW; i += nth) {
     const int c = i / RW, k = i - c * RW;
     img[c * S + (k < IB ? k : L + k)] = 0.f;
   }
 }
+
+template <int S, int B>
+struct RangeStore {  // LDS image store, valid t in [0, L)
+  float* img;
+  int L;
+  __device__ __forceinline__ void operator()(int co, int t, float v) const {
+    if ((unsigned)t < (unsigned)L) img[co * S + B + t] = v;
+  }
+};
 
 struct GlobalRowStore {  // haloed activation tensor row store with a valid range
   float* p;              // window base + HALO
@@ -46,7 +55,7 @@ struct GlobalRowStore {  // haloed activation tensor row store with a valid rang
 // ---------------------------------------------------------------------------------------------
 // Core: one workgroup (16 waves) per window.
 // ---------------------------------------------------------------------------------------------
-using C_d1same = LdsLayer<8, 0, 16, 1, 7, 1, -3, 0, 3, 1>;
+using C_d1same = LdsLayer<8, 0, 16, 1, 7, 1, -3, 0, 6, 1>;
 using C_d1down = LdsLayer<16, 0, 16, 1, 7, 4, -2, 0, 3, 1>;
 using C_d2same = LdsLayer<16, 0, 32, 1, 7, 1, -3, 0, 3, 1>;
 using C_d2down = LdsLayer<32, 0, 32, 1, 7, 4, -1, 0, 1, 1>;
@@ -56,9 +65,9 @@ using C_d4same = LdsLayer<64, 0, 128, 1, 7, 1, -3, 0, 1, 1>;
 using C_u0T = LdsLayer<128, 0, 64, 4, 2, 1, -1, -1, 1, 1>;
 using C_u0same = LdsLayer<64, 64, 64, 1, 7, 1, -3, 0, 3, 1>;
 using C_u1T = LdsLayer<64, 0, 32, 4, 2, 1, -1, -1, 3, 1>;
-using C_u1same = LdsLayer<32, 32, 32, 1, 7, 1, -3, 0, 3, 1>;
+using C_u1same = LdsLayer<32, 32, 32, 1, 7, 1, -3, 0, 6, 1>;
 using C_u2T = LdsLayer<32, 0, 16, 4, 2, 1, -1, -1, 3, 1>;
-using C_u2same = LdsLayer<16, 16, 16, 1, 7, 1, -3, 0, 3, 1>;
+using C_u2same = LdsLayer<16, 16, 16, 1, 7, 1, -3, 0, 6, 1>;
 
 // LDS arena (floats); lifetimes in the header comment of pn_core_kernel
 constexpr int A_SKIP1 = 0;                       // 16 x 784
@@ -93,6 +102,7 @@ struct CoreArgs {
   float* dbg[12];
   int dbg_ls[12];
   long dbg_ws[12];
+  unsigned long long* clk;  // optional [B][32]: [0..14] shader-clock stamps (start, load, 13 layers), [16],[17] 100 MHz wall clock
 };
 
 template <int C, int S>
@@ -105,11 +115,18 @@ __device__ void dump_image(const float* img, int L, float* dst, int ls, long ws,
   }
 }
 
+template <bool PIPE>
 __global__ __launch_bounds__(1024) void pn_core_kernel(const CoreArgs a) {
   extern __shared__ float4 lds_raw[];
   float* lds = reinterpret_cast<float*>(lds_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, win = blockIdx.x;
   constexpr int NTH = 1024, NWV = 16;
+  int stamp = 0;
+  if (a.clk && tid == 0) a.clk[(long)win * 32 + 16] = wall_clock64();  // 100 MHz constant clock
+#define CORE_STAMP()                                                              \
+  if (a.clk && tid == 0) a.clk[(long)win * 32 + stamp] = __builtin_readcyclecounter(); \
+  ++stamp;
+  CORE_STAMP()
 
   // ---- load down0.down (8 x 751) -------------------------------------------------------
   {
@@ -119,16 +136,18 @@ __global__ __launch_bounds__(1024) void pn_core_kernel(const CoreArgs a) {
       const int c = i / T1, t = i - c * T1;
       img[c * S1_ + IB + t] = src[(long)c * a.ls_d0 + t];
     }
-    zero_halo<8, S1_>(img, T1, tid, NTH);
+    zero_halo<8, S1_, T1>(img, tid, NTH);
   }
   __syncthreads();
+  CORE_STAMP()
 
 #define CORE_LAYER(IDX, LAYER, IN1, SI1, IN2, SI2, OUT, SO, CO, COLS, LOUT, DBG)                                   \
   {                                                                                                                \
-    ImageStore<SO, IB> st{lds + (OUT), 0, (LOUT), 0, (LOUT)};                                                      \
-    zero_halo<CO, SO>(lds + (OUT), (LOUT), tid, NTH);                                                              \
-    conv_lds<LAYER, SI1, IB, SI2, IB>(lds + (IN1), lds + (IN2), a.af[IDX], a.bs[IDX], (COLS), st, wave, NWV, lane); \
+    RangeStore<SO, IB> st{lds + (OUT), (LOUT)};                                                                   \
+    zero_halo<CO, SO, LOUT>(lds + (OUT), tid, NTH);                                                              \
+    conv_lds<LAYER, SI1, IB, SI2, IB, PIPE>(lds + (IN1), lds + (IN2), a.af[IDX], a.bs[IDX], (COLS), st, wave, NWV, lane); \
     __syncthreads();                                                                                               \
+    CORE_STAMP()                                                                                                   \
     if (a.dbg[DBG]) dump_image<CO, SO>(lds + (OUT), (LOUT), a.dbg[DBG], a.dbg_ls[DBG], a.dbg_ws[DBG], win, tid, NTH); \
   }
   //          idx layer      in1      S    in2      S    out      S    C    cols     Lout dbg
@@ -147,8 +166,12 @@ __global__ __launch_bounds__(1024) void pn_core_kernel(const CoreArgs a) {
 #undef CORE_LAYER
   {
     GlobalRowStore st{a.u2s + (long)win * a.ws_u2s + HALO, a.ls_u2s, T1, 0};
-    conv_lds<C_u2same, S1_, IB, S1_, IB>(lds + A_SKIP1, lds + A_U2T, a.af[12], a.bs[12], T1, st, wave, NWV, lane);
+    conv_lds<C_u2same, S1_, IB, S1_, IB, PIPE>(lds + A_SKIP1, lds + A_U2T, a.af[12], a.bs[12], T1, st, wave, NWV, lane);
   }
+  __syncthreads();
+  CORE_STAMP()
+  if (a.clk && tid == 0) a.clk[(long)win * 32 + 17] = wall_clock64();
+#undef CORE_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -178,6 +201,7 @@ struct Down0Args {
   const float *af_inc, *bs_inc, *af_same, *bs_same, *af_down, *bs_down;
 };
 
+template <bool PIPE>
 __global__ __launch_bounds__(256) void pn_down0_kernel(const Down0Args a) {
   extern __shared__ float4 lds_raw[];
   float* lds = reinterpret_cast<float*>(lds_raw);
@@ -204,7 +228,7 @@ __global__ __launch_bounds__(256) void pn_down0_kernel(const Down0Args a) {
   const int sig_lo = -o, sig_hi = T0 - o;
   {
     ImageStore<D0_S, IB> st{lds + D0_H, 0, TT + 16, sig_lo, sig_hi};
-    conv_lds<D_inc, D0_S, IB, D0_S, IB>(lds + D0_X, lds + D0_X, a.af_inc, a.bs_inc, (TT + 16) / 2, st, wave, NWV, lane);
+    conv_lds<D_inc, D0_S, IB, D0_S, IB, PIPE>(lds + D0_X, lds + D0_X, a.af_inc, a.bs_inc, (TT + 16) / 2, st, wave, NWV, lane);
   }
   __syncthreads();
   if (a.h0_dbg) {
@@ -216,7 +240,7 @@ __global__ __launch_bounds__(256) void pn_down0_kernel(const Down0Args a) {
   }
   {
     ImageStore<D0_S, IB> st{lds + D0_K, 0, TT + 16, sig_lo, sig_hi};
-    conv_lds<D_same, D0_S, IB, D0_S, IB>(lds + D0_H, lds + D0_H, a.af_same, a.bs_same, (TT + 16) / 2, st, wave, NWV, lane);
+    conv_lds<D_same, D0_S, IB, D0_S, IB, PIPE>(lds + D0_H, lds + D0_H, a.af_same, a.bs_same, (TT + 16) / 2, st, wave, NWV, lane);
   }
   __syncthreads();
   {  // skip tensor rows [t0, t0 + TT) -> memory, 16-byte coalesced (local 12 <-> column 16)
@@ -232,7 +256,7 @@ __global__ __launch_bounds__(256) void pn_down0_kernel(const Down0Args a) {
   }
   {
     GlobalRowStore st{a.d0 + (long)win * a.ws_d + HALO, a.ls_d, T1, tile * (TT / 4)};
-    conv_lds<D_down, D0_S, IB, D0_S, IB>(lds + D0_K, lds + D0_K, a.af_down, a.bs_down, TT / 8, st, wave, NWV, lane);
+    conv_lds<D_down, D0_S, IB, D0_S, IB, PIPE>(lds + D0_K, lds + D0_K, a.af_down, a.bs_down, TT / 8, st, wave, NWV, lane);
   }
 }
 
@@ -264,6 +288,7 @@ struct Up3Args {
   const float* b_out;  // [3]
 };
 
+template <bool PIPE>
 __global__ __launch_bounds__(256) void pn_up3_kernel(const Up3Args a) {
   extern __shared__ float4 lds_raw[];
   float* lds = reinterpret_cast<float*>(lds_raw);
@@ -292,7 +317,7 @@ __global__ __launch_bounds__(256) void pn_up3_kernel(const Up3Args a) {
   __syncthreads();
   {
     ImageStore<U_S0, IB> st{lds + U_UT, 0, U_S0 - IB, -o0, T0 - o0};
-    conv_lds<U_T, U_S1, IB, U_S1, IB>(lds + U_U2S, lds + U_U2S, a.af_t, a.bs_t, 144, st, wave, NWV, lane);
+    conv_lds<U_T, U_S1, IB, U_S1, IB, PIPE>(lds + U_U2S, lds + U_U2S, a.af_t, a.bs_t, 144, st, wave, NWV, lane);
   }
   __syncthreads();
   if (a.ut_dbg) {
@@ -304,7 +329,7 @@ __global__ __launch_bounds__(256) void pn_up3_kernel(const Up3Args a) {
   }
   {
     ImageStore<U_SO, 0> st{lds + U_OUT, 0, TT, 0, TT};
-    conv_lds<U_same, U_S0, IB, U_S0, IB>(lds + U_SKIP, lds + U_UT, a.af_same, a.bs_same, TT / 2, st, wave, NWV, lane);
+    conv_lds<U_same, U_S0, IB, U_S0, IB, PIPE>(lds + U_SKIP, lds + U_UT, a.af_same, a.bs_same, TT / 2, st, wave, NWV, lane);
   }
   __syncthreads();
   {  // 1x1 conv (8 -> 3) + softmax over channels, dense output
@@ -347,7 +372,11 @@ int tensor_id(const Net& net, const std::string& name) {
 
 // Replaces the 18 layer steps planned by plan_phasenet with the three fused launches.  The
 // packed weights of the layer plan are reused as they are (same P / taps / channel padding).
-int plan_phasenet_fused(Net& net, bool debug_dumps) {
+int plan_phasenet_fused(Net& net, int debug_flags) {
+  const bool debug_dumps = (debug_flags & 1) != 0, debug_clock = (debug_flags & 2) != 0;
+  // reserved[2] = 1 selects the hand-pipelined K loop (sched_barrier) for A/B timing; the compiler's own
+  // schedule measured 0-5 % faster on every layer (tools/micro/micro_layers.hip), so it is the default.
+  const bool pipe = net.cfg.reserved[2] == 1;
   if (net.convs.size() != 18) {
     set_error("fused PhaseNet plan expects the 18-layer plan");
     return VP_ERR_INVALID;
@@ -392,7 +421,11 @@ int plan_phasenet_fused(Net& net, bool debug_dumps) {
       a.bs_same = n.convs[1]->bias.d;
       a.af_down = n.convs[2]->afrag.d;
       a.bs_down = n.convs[2]->bias.d;
-      hipLaunchKernelGGL(pn_down0_kernel, dim3(n_tiles, B), dim3(256), D0_LDS_FLOATS * sizeof(float), s, a);
+      if (pipe) {
+        hipLaunchKernelGGL(pn_down0_kernel<true>, dim3(n_tiles, B), dim3(256), D0_LDS_FLOATS * sizeof(float), s, a);
+      } else {
+        hipLaunchKernelGGL(pn_down0_kernel<false>, dim3(n_tiles, B), dim3(256), D0_LDS_FLOATS * sizeof(float), s, a);
+      }
       return 0;
     };
     steps.push_back(std::move(st));
@@ -405,6 +438,8 @@ int plan_phasenet_fused(Net& net, bool debug_dumps) {
                                         "down4.same", "up0.convT",  "up0.same",   "up1.convT",  "up1.same",   "up2.convT"};
     std::vector<int> dbg_ids(12);
     for (int i = 0; i < 12; ++i) dbg_ids[i] = tensor_id(net, dbg_names[i]);
+    HostBlob* clk = debug_clock ? net.add_blob(std::vector<float>((size_t)net.max_batch * 32 * 2, 0.f)) : nullptr;
+    net.debug_clock = clk;
     st.run = [=](Net& n, int B, hipStream_t s) -> int {
       CoreArgs a{};
       const Tensor &td = n.tensors[d0], &tu = n.tensors[u2s];
@@ -426,7 +461,12 @@ int plan_phasenet_fused(Net& net, bool debug_dumps) {
           a.dbg_ws[i] = (long)t.win_stride();
         }
       }
-      hipLaunchKernelGGL(pn_core_kernel, dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
+      a.clk = clk ? reinterpret_cast<unsigned long long*>(clk->d) : nullptr;
+      if (pipe) {
+        hipLaunchKernelGGL(pn_core_kernel<true>, dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
+      } else {
+        hipLaunchKernelGGL(pn_core_kernel<false>, dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
+      }
       return 0;
     };
     steps.push_back(std::move(st));
@@ -458,15 +498,22 @@ int plan_phasenet_fused(Net& net, bool debug_dumps) {
       a.bs_same = n.convs[17]->bias.d;
       a.w_out = e0->d;
       a.b_out = e1->d;
-      hipLaunchKernelGGL(pn_up3_kernel, dim3(n_tiles, B), dim3(256), UP3_LDS_FLOATS * sizeof(float), s, a);
+      if (pipe) {
+        hipLaunchKernelGGL(pn_up3_kernel<true>, dim3(n_tiles, B), dim3(256), UP3_LDS_FLOATS * sizeof(float), s, a);
+      } else {
+        hipLaunchKernelGGL(pn_up3_kernel<false>, dim3(n_tiles, B), dim3(256), UP3_LDS_FLOATS * sizeof(float), s, a);
+      }
       return 0;
     };
     steps.push_back(std::move(st));
   }
   net.steps = std::move(steps);
-  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_core_kernel), CORE_LDS_FLOATS * sizeof(float)});
-  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_down0_kernel), D0_LDS_FLOATS * sizeof(float)});
-  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_up3_kernel), UP3_LDS_FLOATS * sizeof(float)});
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_core_kernel<true>), CORE_LDS_FLOATS * sizeof(float)});
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_core_kernel<false>), CORE_LDS_FLOATS * sizeof(float)});
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_down0_kernel<true>), D0_LDS_FLOATS * sizeof(float)});
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_down0_kernel<false>), D0_LDS_FLOATS * sizeof(float)});
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_up3_kernel<true>), UP3_LDS_FLOATS * sizeof(float)});
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_up3_kernel<false>), UP3_LDS_FLOATS * sizeof(float)});
   return VP_OK;
 }
 

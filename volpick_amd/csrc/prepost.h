@@ -53,6 +53,7 @@ struct PickBatch {
   int n;
 };
 int launch_pick(const PickBatch& b, hipStream_t stream);
+int launch_publish(char* dev, char* host, int n_specs, int cap, long header, long per_spec, hipStream_t stream);
 int pick_host(const float* x, int64_t n, float thr_on, float thr_off, int64_t* on, int64_t* off, int64_t* peak,
               float* value, int cap, int* n_found);
 

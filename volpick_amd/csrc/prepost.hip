@@ -243,6 +243,41 @@ int launch_pick(const PickBatch& b, hipStream_t stream) {
   return 0;
 }
 
+// Result hand-off without the copy engine: one workgroup copies the counters and the found triggers
+// from the device result block into host-mapped pinned memory, then re-arms the counters for the next
+// scan.  (A hipMemcpyAsync here would park the stream behind an SDMA round trip before the next
+// batch's kernels may start.)
+__global__ __launch_bounds__(256) void publish_kernel(char* dev, char* host, int n_specs, int cap, long header,
+                                                      long per_spec) {
+  int* cnt = reinterpret_cast<int*>(dev);
+  int* hcnt = reinterpret_cast<int*>(host);
+  const int tid = threadIdx.x;
+  for (int i = 0; i < n_specs; ++i) {
+    const int found = cnt[2 * i];
+    const int m = found < cap ? found : cap;
+    const int64_t* s_on = reinterpret_cast<const int64_t*>(dev + header + per_spec * i);
+    int64_t* d_on = reinterpret_cast<int64_t*>(host + header + per_spec * i);
+    const long L = cap > 0 ? cap : 1;
+    for (int k = tid; k < m; k += 256) {
+      d_on[k] = s_on[k];
+      d_on[L + k] = s_on[L + k];
+      d_on[2 * L + k] = s_on[2 * L + k];
+      reinterpret_cast<float*>(d_on + 3 * L)[k] = reinterpret_cast<const float*>(s_on + 3 * L)[k];
+    }
+    if (tid == 0) {
+      hcnt[2 * i] = found;
+      hcnt[2 * i + 1] = cnt[2 * i + 1];
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * n_specs) cnt[tid] = 0;
+}
+
+int launch_publish(char* dev, char* host, int n_specs, int cap, long header, long per_spec, hipStream_t stream) {
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(256), 0, stream, dev, host, n_specs, cap, header, per_spec);
+  return 0;
+}
+
 // Host mirror of ObsPy's trigger_onset for host-resident traces (general thresholds).
 int pick_host(const float* x, int64_t n, float thr_on, float thr_off, int64_t* on, int64_t* off, int64_t* peak,
               float* value, int cap, int* n_found) {

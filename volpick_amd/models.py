@@ -176,7 +176,8 @@ class WaveformModel:
         _lib.check(lib.vp_default_config(self._kind, C.byref(cfg)))
         cfg.norm = _lib.VP_NORM_PEAK if self.norm == "peak" else _lib.VP_NORM_STD
         cfg.max_batch = int(self._max_batch)
-        cfg.reserved[0], cfg.reserved[1] = int(self._plan_flags[0]), int(self._plan_flags[1])
+        for i, v in enumerate(self._plan_flags):
+            cfg.reserved[i] = int(v)
         return cfg
 
     def _ensure_handle(self, weights_device_ptr=None):
