@@ -147,9 +147,12 @@ int vp_pick_host(const float* trace, int64_t n, float thr_on, float thr_off, int
 int64_t vp_window_starts(int64_t N, int in_samples, int overlap, int64_t* starts, int64_t cap);
 
 /* Timing of the last vp_forward / vp_annotate on this handle, measured with HIP events on
- * the handle's stream: total milliseconds and the per-stage split
+ * the handle's stream (only while vp_set_timing(h, 1) is in effect): total milliseconds and the per-stage split
  * (0 preprocess, 1 model forward, 2 blinding+stacking, 3 pick scan). */
 int vp_last_timing(const vp_handle* h, float* total_ms, float stage_ms[4]);
+/* Stage events are OFF by default (each hipEventRecord opens a ~5 us bubble on the stream);
+ * enable them for the calls whose vp_last_timing split is wanted. */
+int vp_set_timing(vp_handle* h, int enable);
 
 /* The handle's HIP stream (hipStream_t) for callers that want to order their own work. */
 void* vp_stream(const vp_handle* h);

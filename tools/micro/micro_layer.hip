@@ -22,6 +22,8 @@ struct RangeStoreT {
   __device__ __forceinline__ void operator()(int co, int t, float v) const {
     if ((unsigned)t < (unsigned)L) img[co * S + IB_ + t] = v;
   }
+  __device__ __forceinline__ bool all_valid(int t0, int t1) const { return t0 >= 0 && t1 < L; }
+  __device__ __forceinline__ void unchecked(int co, int t, float v) const { img[co * S + IB_ + t] = v; }
 };
 
 // VAR 0: conv_lds PIPE=true, 4: conv_lds PIPE=false, 1: no A loads, 2: no B reads, 3: neither

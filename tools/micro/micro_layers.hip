@@ -19,6 +19,8 @@ struct RStore {
   __device__ __forceinline__ void operator()(int co, int t, float v) const {
     if ((unsigned)t < (unsigned)L) img[co * S + B + t] = v;
   }
+  __device__ __forceinline__ bool all_valid(int t0, int t1) const { return t0 >= 0 && t1 < L; }
+  __device__ __forceinline__ void unchecked(int co, int t, float v) const { img[co * S + B + t] = v; }
 };
 
 template <class L, int SI, int SO, int COLS, int LOUT, bool PIPE, int NWV>

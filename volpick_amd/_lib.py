@@ -90,6 +90,7 @@ SIGNATURES = {
     ),
     "vp_window_starts": (C.c_int64, [C.c_int64, C.c_int, C.c_int, _I64P, C.c_int64]),
     "vp_last_timing": (C.c_int, [_H, _FP, _FP]),
+    "vp_set_timing": (C.c_int, [_H, C.c_int]),
     "vp_stream": (C.c_void_p, [_H]),
     "vp_synchronize": (C.c_int, [_H]),
     "vp_step_count": (C.c_int, [_H]),

@@ -16,6 +16,7 @@ struct vp_handle {
   vp::Net net;
   hipEvent_t ev[5] = {};
   float total_ms = 0.f;
+  bool timing = false;  // stage events cost ~5 us of stream bubble each: off unless vp_set_timing(h, 1)
   float stage_ms[4] = {0.f, 0.f, 0.f, 0.f};
   // growable device scratch
   float* d_in = nullptr;    // staged host input (stream or windows)
@@ -33,8 +34,6 @@ struct vp_handle {
     int n_specs = 0, cap = 0;
     int64_t fv = -1, lv = -1, nwin = 0;
   } slot[VP_MAX_INFLIGHT];
-  int64_t* d_ends = nullptr;  // run-end scratch of the trigger scan
-  size_t ends_cap = 0;
 };
 
 namespace {
@@ -187,7 +186,6 @@ int vp_destroy(vp_handle* h) {
     if (sl.h_pick) (void)hipHostFree(sl.h_pick);
     if (sl.done) (void)hipEventDestroy(sl.done);
   }
-  if (h->d_ends) (void)hipFree(h->d_ends);
   h->net.release();
   delete h;
   return VP_OK;
@@ -281,7 +279,7 @@ static int annotate_device(vp_handle* h, const float* stream, int stream_mem, in
   if (first_valid) *first_valid = fv;
   if (last_valid) *last_valid = lv;
 
-  VP_HIP(hipEventRecord(h->ev[0], h->stream));
+  if (h->timing) VP_HIP(hipEventRecord(h->ev[0], h->stream));
   const float* d_stream = stream;
   if (stream_mem == VP_MEM_HOST) {
     int rc = grow(&h->d_in, &h->d_in_cap, std::max((size_t)3 * N, (size_t)net.max_batch * 3 * T));
@@ -303,7 +301,7 @@ static int annotate_device(vp_handle* h, const float* stream, int stream_mem, in
       if (rc != VP_OK) return rc;
     }
   }
-  VP_HIP(hipEventRecord(h->ev[1], h->stream));
+  if (h->timing) VP_HIP(hipEventRecord(h->ev[1], h->stream));
   vp::StackArgs sa{};
   sa.pred = h->d_pred;
   sa.out = d_out;
@@ -317,11 +315,12 @@ static int annotate_device(vp_handle* h, const float* stream, int stream_mem, in
   sa.blind_r = blind_r;
   sa.mode = stacking;
   vp::launch_stack(sa, h->stream);  // with zero windows this writes all-NaN rows
-  VP_HIP(hipEventRecord(h->ev[2], h->stream));
+  if (h->timing) VP_HIP(hipEventRecord(h->ev[2], h->stream));
   return VP_OK;
 }
 
 static void read_stage_timing(vp_handle* h, bool with_scan) {
+  if (!h->timing) return;
   float fwd = 0.f, stk = 0.f, scan = 0.f;
   (void)hipEventElapsedTime(&fwd, h->ev[0], h->ev[1]);
   (void)hipEventElapsedTime(&stk, h->ev[1], h->ev[2]);
@@ -384,19 +383,7 @@ static int scan_submit(vp_handle* h, vp_handle::Slot& sl, const float* const* ro
     VP_HIP(hipHostMalloc((void**)&sl.h_pick, L.total, hipHostMallocMapped));
     sl.pick_bytes = L.total;
   }
-  int64_t max_len = 0;
-  for (int i = 0; i < n_specs; ++i) max_len = std::max(max_len, lens[i]);
-  const size_t ends_per_row = (size_t)max_len / 2 + 2;
-  const size_t ends_need = ends_per_row * std::min(n_specs, vp::kMaxPickRows);
-  if (ends_need > h->ends_cap) {
-    VP_HIP(hipStreamSynchronize(h->stream));  // earlier scans may still use the old scratch
-    if (h->d_ends) (void)hipFree(h->d_ends);
-    h->d_ends = nullptr;
-    h->ends_cap = 0;
-    VP_HIP(hipMalloc((void**)&h->d_ends, ends_need * sizeof(int64_t)));
-    h->ends_cap = ends_need;
-  }
-  VP_HIP(hipEventRecord(h->ev[3], h->stream));
+  if (h->timing) VP_HIP(hipEventRecord(h->ev[3], h->stream));
   for (int i0 = 0; i0 < n_specs; i0 += vp::kMaxPickRows) {
     vp::PickBatch batch{};
     for (int i = i0; i < n_specs && i < i0 + vp::kMaxPickRows; ++i) {
@@ -407,19 +394,16 @@ static int scan_submit(vp_handle* h, vp_handle::Slot& sl, const float* const* ro
       a.thr_on = thr_on[i];
       a.thr_off = thr_off[i];
       a.count = (int*)sl.d_pick + 2 * i;
-      a.n_ends = (int*)sl.d_pick + 2 * i + 1;
       a.on = (int64_t*)base;
       a.off = a.on + L.cap;
       a.peak = a.off + L.cap;
       a.value = (float*)(a.peak + L.cap);
       a.cap = cap;
-      a.ends = h->d_ends + (size_t)(i - i0) * ends_per_row;  // rows of one launch scan concurrently
-      a.ends_cap = (int)std::min<size_t>(ends_per_row, 0x7fffffff);
     }
     vp::launch_pick(batch, h->stream);
   }
   vp::launch_publish(sl.d_pick, sl.h_pick, n_specs, cap, (long)L.header, (long)L.per_spec, h->stream);
-  VP_HIP(hipEventRecord(h->ev[4], h->stream));
+  if (h->timing) VP_HIP(hipEventRecord(h->ev[4], h->stream));
   sl.n_specs = n_specs;
   sl.cap = cap;
   return VP_OK;
@@ -580,8 +564,14 @@ int vp_pick(vp_handle* h, const float* trace, int trace_mem, int64_t n, float th
   int rc = scan_submit(h, sl, rows, lens, &thr_on, &thr_off, 1, cap);
   if (rc != VP_OK) return rc;
   VP_HIP(hipStreamSynchronize(h->stream));
-  (void)hipEventElapsedTime(&h->stage_ms[3], h->ev[3], h->ev[4]);
+  if (h->timing) (void)hipEventElapsedTime(&h->stage_ms[3], h->ev[3], h->ev[4]);
   return scan_collect(sl, on, off, peak, value, nullptr, cap, n_found);
+}
+
+int vp_set_timing(vp_handle* h, int enable) {
+  VP_REQUIRE(h != nullptr, "null handle");
+  h->timing = enable != 0;
+  return VP_OK;
 }
 
 int vp_last_timing(const vp_handle* h, float* total_ms, float stage_ms[4]) {

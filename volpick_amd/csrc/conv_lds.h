@@ -47,7 +47,7 @@ __device__ __forceinline__ void conv_lds(const float* in1, const float* in2, con
     const float* ap = afrag + (long)mt * L::CB * L::TAPS * 64 + lane;
     float biasv[4];  // fetched now, consumed after the K loop (no exposed L2 round trip in the epilogue)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) biasv[r] = bias[(mt * 16 + 4 * g + r) / L::P];
+    for (int r = 0; r < 4; ++r) biasv[r] = bias[mt * (16 / L::P) + (4 * g) / L::P + r / L::P];
     const float* bp1 = in1 + g * S1 + B1 + (colb + n) * L::SN + L::IN_OFF;
     const float* bp2 = in2 + g * S2 + B2 + (colb + n) * L::SN + L::IN_OFF;
     // K loop over 4-channel blocks, software-pipelined by hand: the operands of block cb+1 (TAPS A
@@ -86,16 +86,28 @@ __device__ __forceinline__ void conv_lds(const float* in1, const float* in2, con
         if (PIPE) __builtin_amdgcn_sched_barrier(0);
       }
     }
+    // Epilogue.  Row m = 16*mt + 4*g + r of the D tile is (co, p) = (m / P, m % P); with P in
+    // {1,2,4} both split into a per-lane part and a compile-time part of r, so every store address
+    // is a per-lane base plus immediates.  If the whole block of columns is inside the store's
+    // unconditional range (wave-uniform test) the per-element range checks are skipped.
+    static_assert(L::P == 1 || L::P == 2 || L::P == 4, "P must divide the 4-row register group");
+    const int co_lane = mt * (16 / L::P) + (4 * g) / L::P;
+    const int t_first = L::P * colb + L::OUT_OFF, t_last = L::P * (colb + L::NB * 16) - 1 + L::OUT_OFF;
+    const bool fast = store.all_valid(t_first, t_last);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int m = mt * 16 + 4 * g + r;
-      const int co = m / L::P, p = m - co * L::P;
+      const int co = co_lane + r / L::P, p = r % L::P;
       const float b = biasv[r];
 #pragma unroll
       for (int j = 0; j < L::NB; ++j) {
         float v = acc[j][r] + b;
         if (L::RELU) v = fmaxf(v, 0.f);
-        store(co, L::P * (colb + j * 16 + n) + p + L::OUT_OFF, v);
+        const int t = L::P * (colb + j * 16 + n) + p + L::OUT_OFF;
+        if (fast) {
+          store.unchecked(co, t, v);
+        } else {
+          store(co, t, v);
+        }
       }
     }
   }
@@ -112,6 +124,10 @@ struct ImageStore {
   __device__ __forceinline__ void operator()(int co, int t, float v) const {
     if (t >= lo && t < hi) img[co * S + B + t] = (t >= sig_lo && t < sig_hi) ? v : 0.f;
   }
+  __device__ __forceinline__ bool all_valid(int t0, int t1) const {
+    return t0 >= lo && t1 < hi && t0 >= sig_lo && t1 < sig_hi;
+  }
+  __device__ __forceinline__ void unchecked(int co, int t, float v) const { img[co * S + B + t] = v; }
 };
 
 template <int C, int S>

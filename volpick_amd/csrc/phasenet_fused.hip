@@ -41,6 +41,8 @@ struct RangeStore {  // LDS image store, valid t in [0, L)
   __device__ __forceinline__ void operator()(int co, int t, float v) const {
     if ((unsigned)t < (unsigned)L) img[co * S + B + t] = v;
   }
+  __device__ __forceinline__ bool all_valid(int t0, int t1) const { return t0 >= 0 && t1 < L; }
+  __device__ __forceinline__ void unchecked(int co, int t, float v) const { img[co * S + B + t] = v; }
 };
 
 struct GlobalRowStore {  // haloed activation tensor row store with a valid range
@@ -50,6 +52,8 @@ struct GlobalRowStore {  // haloed activation tensor row store with a valid rang
     const int tg = t + t_add;
     if (t >= 0 && tg >= 0 && tg < L) p[(long)co * ls + tg] = v;
   }
+  __device__ __forceinline__ bool all_valid(int t0, int t1) const { return t0 >= 0 && t0 + t_add >= 0 && t1 + t_add < L; }
+  __device__ __forceinline__ void unchecked(int co, int t, float v) const { p[(long)co * ls + t + t_add] = v; }
 };
 
 // ---------------------------------------------------------------------------------------------

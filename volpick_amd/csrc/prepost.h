@@ -43,9 +43,6 @@ struct PickArgs {
   float* value;
   int cap;
   int* count;
-  int64_t* ends;   // scratch: run-end indices
-  int ends_cap;
-  int* n_ends;
 };
 constexpr int kMaxPickRows = 4;
 struct PickBatch {

@@ -166,31 +166,34 @@ int launch_stack(const StackArgs& a, hipStream_t stream) {
 // A8: trigger_onset + peak.  For thr_off <= thr_on every maximal run of samples > thr_off
 // that holds a sample > thr_on yields one trigger: on = first sample > thr_on in the run,
 // off = last sample of the run, peak = first argmax over [on, off].
-//   pass 1 (one thread per sample): append the index of every run END to a list;
-//   pass 2 (one wavefront per run end): walk the run backwards 64 coalesced samples at a
-//          time (ballot finds the run start and the earliest sample > thr_on), then a
-//          strided max/argmax over [on, off] with a wave reduction.
+// The owner of a run is the workgroup whose chunk holds its END; one wavefront walks the run
+// backwards 64 coalesced samples at a time (ballot finds the run start and the earliest sample
+// > thr_on), then takes a strided max/argmax over [on, off] with a wave reduction.
 // Triggers are appended with one atomic each and sorted on the host.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void run_end_kernel(const PickBatch batch) {
-  const PickArgs& a = batch.a[blockIdx.y];
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= a.n) return;
-  if (!(a.trace[t] > a.thr_off)) return;
-  if (t + 1 < a.n && a.trace[t + 1] > a.thr_off) return;  // not a run end
-  const int slot = atomicAdd(a.n_ends, 1);
-  if (slot < a.ends_cap) a.ends[slot] = t;
-}
+constexpr int SCAN_CHUNK = 2048;  // samples per workgroup
 
-__global__ __launch_bounds__(256) void run_scan_kernel(const PickBatch batch) {
+// One launch: every workgroup lists the run ENDS inside its 2048-sample chunk in LDS (phase 1,
+// one thread per 8 samples), then its four wavefronts walk those runs backwards through memory
+// (phase 2) -- a run may start in an earlier chunk, only its end decides who owns it.
+__global__ __launch_bounds__(256) void trigger_scan_kernel(const PickBatch batch) {
+  __shared__ int n_ends;
+  __shared__ int ends[SCAN_CHUNK / 2 + 1];
   const PickArgs& a = batch.a[blockIdx.y];
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-  const int n_waves = (gridDim.x * 256) >> 6;
-  int n_ends = *a.n_ends;
-  if (n_ends > a.ends_cap) n_ends = a.ends_cap;
-  for (int r = wave; r < n_ends; r += n_waves) {
-    const long off = a.ends[r];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long c0 = (long)blockIdx.x * SCAN_CHUNK;
+  if (c0 >= a.n) return;
+  if (tid == 0) n_ends = 0;
+  __syncthreads();
+  for (int i = tid; i < SCAN_CHUNK; i += 256) {
+    const long t = c0 + i;
+    if (t < a.n && a.trace[t] > a.thr_off && !(t + 1 < a.n && a.trace[t + 1] > a.thr_off))
+      ends[atomicAdd(&n_ends, 1)] = i;
+  }
+  __syncthreads();
+  const int ne = n_ends;
+  for (int r = wave; r < ne; r += 4) {
+    const long off = c0 + ends[r];
     long on = -1;
     for (long pos = off; pos >= 0; pos -= 64) {
       const long idx = pos - lane;
@@ -233,13 +236,13 @@ __global__ __launch_bounds__(256) void run_scan_kernel(const PickBatch batch) {
   }
 }
 
-// All rows of one classify call in two launches (blockIdx.y = row); rows need separate scratch.
+// All rows of one classify call in one launch (blockIdx.y = row).
 int launch_pick(const PickBatch& b, hipStream_t stream) {
   long n_max = 0;
   for (int i = 0; i < b.n; ++i) n_max = (b.a[i].n > n_max) ? b.a[i].n : n_max;
   if (b.n <= 0 || n_max <= 0) return 0;
-  hipLaunchKernelGGL(run_end_kernel, dim3((unsigned)((n_max + 255) / 256), b.n), dim3(256), 0, stream, b);
-  hipLaunchKernelGGL(run_scan_kernel, dim3(64, b.n), dim3(256), 0, stream, b);
+  hipLaunchKernelGGL(trigger_scan_kernel, dim3((unsigned)((n_max + SCAN_CHUNK - 1) / SCAN_CHUNK), b.n), dim3(256), 0,
+                     stream, b);
   return 0;
 }
 
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256) void publish_kernel(char* dev, char* host, int
     }
     if (tid == 0) {
       hcnt[2 * i] = found;
-      hcnt[2 * i + 1] = cnt[2 * i + 1];
+      hcnt[2 * i + 1] = 0;
     }
   }
   __syncthreads();
