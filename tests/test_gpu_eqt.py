@@ -50,7 +50,7 @@ def _oracle_stages(net, x):
             px = lstm(h.permute(2, 0, 1))[0].permute(1, 2, 0)
             px, _ = att(px)
             dec_in.append(px)
-        out["decoder.in.up"] = torch.cat([up2(t) for t in dec_in], 0)
+        out["decoder.in"] = torch.cat(dec_in, 0)
         decs = [net.decoder_d, net.pick_decoders[0], net.pick_decoders[1]]
         hs = list(dec_in)
         for s in range(7):
@@ -61,11 +61,8 @@ def _oracle_stages(net, x):
                     u = u[:, :, :-1]
                 ys.append(torch.relu(dec.convs[s](u)))
             hs = ys
-            if s < 6:
-                nxt = [up2(y)[:, :, :-1] if (s + 1) in decs[0].crops else up2(y) for y in ys]
-                out[f"decoder.{s}.up"] = torch.cat(nxt, 0)
-            else:
-                out["decoder.6"] = torch.cat(ys, 0)
+            # stage 1 stores its rows x2-upsampled and cropped (input of the plain-conv stage 2)
+            out[f"decoder.{s}"] = torch.cat([up2(y)[:, :, :-1] for y in ys], 0) if s == 1 else torch.cat(ys, 0)
         final = net(x)
     return {k: v.numpy() for k, v in out.items()}, [f.numpy() for f in final]
 

@@ -138,7 +138,8 @@ def test_eqt_conv_layers_match_oracle(lib):
             check(f"res{s}.conv2", m[0].numpy(), c2[0].numpy())
             h = h + c2
         bott = net.bottleneck(x)
-        # decoders: three weight sets per stage; feed the detection decoder's activations to all
+        # decoders: three weight sets per stage.  Every stage but #2 folds Upsample(2) into the conv
+        # (input = the NOT-upsampled rows); stage 2 reads stage 1's x2-upsampled, cropped rows.
         decs = [net.decoder_d, net.pick_decoders[0], net.pick_decoders[1]]
         for d, dec in enumerate(decs):
             h = bott
@@ -147,5 +148,6 @@ def test_eqt_conv_layers_match_oracle(lib):
                 if s in dec.crops:
                     u = u[:, :, :-1]
                 y = torch.relu(conv(u))
-                check(f"decoder.{s}", u[0].numpy(), y[0].numpy(), set_index=d, sets=3)
+                src = u if s == 2 else h
+                check(f"decoder.{s}", src[0].numpy(), y[0].numpy(), set_index=d, sets=3)
                 h = y

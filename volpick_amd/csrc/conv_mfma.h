@@ -292,6 +292,7 @@ int launch_conv(const ConvArgs& a, int cols, hipStream_t stream) {
 std::vector<float> amat_conv(const float* W, int cout, int cin, int K, int stride, int P, int cinp,
                              const float* row_scale);
 std::vector<float> amat_convT_k7s4(const float* Wt, int cin, int cout, int cinp, const float* row_scale);
+std::vector<float> amat_upconv(const float* W, int cout, int cin, int K, int cinp);
 std::vector<float> pack_afrag(const std::vector<float>& amat, int M, int cinp, int taps);
 
 }  // namespace vp

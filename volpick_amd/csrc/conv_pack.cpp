@@ -45,6 +45,24 @@ std::vector<float> amat_convT_k7s4(const float* Wt, int cin, int cout, int cinp,
   return A;
 }
 
+// Upsample(2, nearest) + Conv1d(K odd, pad K/2) folded into a 2-phase filter on the un-upsampled
+// input: u[i] = x[i >> 1], so y[2n+p] = sum_k W[k] u[2n+p+k-pad] = sum_d (sum_{k: floor((p+k-pad)/2)=d} W[k]) x[n+d].
+// Rows m = co*2 + p; tap' = d - dmin with dmin = floor(-pad/2); the kernel uses IN_OFF = dmin.
+std::vector<float> amat_upconv(const float* W, int cout, int cin, int K, int cinp) {
+  auto fdiv2 = [](int x) { return (x >= 0) ? x / 2 : -((-x + 1) / 2); };
+  const int pad = K / 2, dmin = fdiv2(-pad), dmax = fdiv2(K - pad), taps = dmax - dmin + 1;
+  std::vector<float> A((size_t)cout * 2 * taps * cinp, 0.f);
+  for (int co = 0; co < cout; ++co)
+    for (int p = 0; p < 2; ++p) {
+      float* row = &A[(size_t)(co * 2 + p) * taps * cinp];
+      for (int k = 0; k < K; ++k) {
+        const int tap = fdiv2(p + k - pad) - dmin;
+        for (int ci = 0; ci < cin; ++ci) row[tap * cinp + ci] += W[((size_t)co * cin + ci) * K + k];
+      }
+    }
+  return A;
+}
+
 // [M][taps*cinp] -> [MT][CB][taps][64]: lane l of K-step (cb, tap) holds
 // A[mt*16 + (l & 15)][tap*cinp + cb*4 + (l >> 4)].
 std::vector<float> pack_afrag(const std::vector<float>& amat, int M, int cinp, int taps) {

@@ -30,13 +30,21 @@ using EQ_r1k3 = ConvCfg<64, 0, 64, 1, 3, 1, -1, 0, 4, 1, 3, 1, EPI_STORE>;
 using EQ_r1k2 = ConvCfg<64, 0, 64, 1, 2, 1, 0, 0, 4, 1, 3, 1, EPI_STORE>;
 using EQ_r2k3 = ConvCfg<64, 0, 64, 1, 3, 1, -1, 0, 4, 1, 3, 0, EPI_RES>;
 using EQ_r2k2 = ConvCfg<64, 0, 64, 1, 2, 1, 0, 0, 4, 1, 3, 0, EPI_RES>;
-using EQ_d0 = ConvCfg<16, 0, 64, 1, 3, 1, -1, 0, 4, 1, 6, 1, EPI_UP2>;
-using EQ_d1 = ConvCfg<64, 0, 64, 1, 5, 1, -2, 0, 4, 1, 6, 1, EPI_UP2>;
-using EQ_d2 = ConvCfg<64, 0, 32, 1, 5, 1, -2, 0, 2, 2, 6, 1, EPI_UP2>;
-using EQ_d3 = ConvCfg<32, 0, 32, 1, 7, 1, -3, 0, 2, 2, 6, 1, EPI_UP2>;
-using EQ_d4 = ConvCfg<32, 0, 16, 1, 7, 1, -3, 0, 1, 4, 6, 1, EPI_UP2>;
-using EQ_d5 = ConvCfg<16, 0, 16, 1, 9, 1, -4, 0, 1, 4, 8, 1, EPI_UP2>;
-using EQ_d6 = ConvCfg<16, 0, 8, 2, 12, 2, -5, 0, 1, 4, 8, 1, EPI_STORE>;
+// Decoder stage = Upsample(2, nearest) + Conv1d(K, pad K/2) + ReLU.  The upsample is folded into the
+// conv as a 2-phase polyphase filter on the NOT-upsampled input (conv_pack.cpp amat_upconv):
+//   y[co][2n+p] = sum_ci sum_d Wp[co][ci][d] x[ci][n+d],  d in [floor(-pad/2), floor((K-pad)/2)]
+// K = 3/5/7/9/11 -> 3/3/5/5/7 taps for two outputs instead of 2K: 0.6-0.7x the MACs, half the reads,
+// and the x2 intermediate is never written.  Stage 2 (188 -> 375, odd) is the exception: the reference
+// crops the upsampled row by one sample, which a polyphase filter cannot express at the right edge, so
+// stage 1 writes its output x2-upsampled and cropped and stage 2 stays a plain conv.
+//                      CIN1 CIN2 COUT P TAPS SN IN_OFF OUT_OFF WM WN NW RELU EPI
+using EQ_d0 = ConvCfg<16, 0, 64, 2, 3, 1, -1, 0, 4, 1, 3, 1, EPI_STORE>;
+using EQ_d1 = ConvCfg<64, 0, 64, 2, 3, 1, -1, 0, 4, 1, 6, 1, EPI_UP2>;
+using EQ_d2 = ConvCfg<64, 0, 32, 1, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
+using EQ_d3 = ConvCfg<32, 0, 32, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
+using EQ_d4 = ConvCfg<32, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
+using EQ_d5 = ConvCfg<16, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
+using EQ_d6 = ConvCfg<16, 0, 8, 2, 7, 1, -3, 0, 1, 4, 8, 1, EPI_STORE>;
 
 std::vector<float> vec(const float* p, size_t n) { return std::vector<float>(p, p + n); }
 
@@ -204,7 +212,7 @@ int plan_eqt(Net& net, const ParamView& pv) {
   }
 
   // ---- transformers -----------------------------------------------------------------------
-  const int dec_in = net.add_tensor("decoder.in.up", 16, 2 * EQT_T, 3);  // x2-upsampled inputs of the 3 decoders
+  const int dec_in = net.add_tensor("decoder.in", 16, EQT_T, 3);  // inputs of the 3 decoders (set-major)
   int tr_in = lstm_in;
   const char* tr_names[2] = {"transformer_d0", "transformer_d"};
   for (int i = 0; i < 2; ++i) {
@@ -294,19 +302,24 @@ int plan_eqt(Net& net, const ParamView& pv) {
   }
 
   // ---- three decoders, one launch per stage ----------------------------------------------------
-  const int dlen[7] = {94, 188, 375, 750, 1500, 3000, 6000};  // conv length of stage i (= its upsampled input)
+  const int din[7] = {47, 94, 375, 375, 750, 1500, 3000};    // length of the stage's input rows
+  const int dout[7] = {94, 188, 375, 750, 1500, 3000, 6000};  // conv output length
   const int dco[7] = {64, 64, 32, 32, 16, 16, 8};
   const int dci[7] = {16, 64, 64, 32, 32, 16, 16};
   const int dk[7] = {3, 5, 5, 7, 7, 9, 11};
   const char* dec_prefix[3] = {"decoder_d", "pick_decoders.0", "pick_decoders.1"};
   int dsrc = dec_in;
   for (int i = 0; i < 7; ++i) {
-    const int up_len = (i < 6) ? dlen[i + 1] : T;
-    const int dst = net.add_tensor("decoder." + std::to_string(i) + (i < 6 ? ".up" : ""), dco[i], up_len, 3);
+    const bool polyphase = (i != 2);
+    const int dst_len = (i == 1) ? 375 : dout[i];  // stage 1 stores its rows x2-upsampled and cropped
+    const int dst = net.add_tensor("decoder." + std::to_string(i), dco[i], dst_len, 3);
     auto pack3 = [&](const ConvGeom& g, std::vector<float>* af, std::vector<float>* bs) {
       for (int d = 0; d < 3; ++d) {
         const std::string c = std::string(dec_prefix[d]) + ".convs." + std::to_string(i);
-        std::vector<float> a = pack_plain(pv, c, dco[i], dci[i], dk[i], g);
+        std::vector<float> a =
+            polyphase ? pack_afrag(amat_upconv(pv.get(c + ".weight"), dco[i], dci[i], dk[i], g.cinp()), g.M(), g.cinp(),
+                                   g.taps)
+                      : pack_plain(pv, c, dco[i], dci[i], dk[i], g);
         af->insert(af->end(), a.begin(), a.end());
         const float* b = pv.get(c + ".bias");
         bs->insert(bs->end(), b, b + dco[i]);
@@ -314,10 +327,10 @@ int plan_eqt(Net& net, const ParamView& pv) {
     };
     std::vector<float> af, bs;
     const std::string nm = "decoder." + std::to_string(i);
-    const int cols = (i == 6) ? dlen[i] / 2 : dlen[i];
+    const int cols = din[i];  // polyphase: one column per input sample; stage 2: one per output sample
 #define EQ_DEC(CFG)                                                  \
   pack3(CFG::geom(), &af, &bs);                                      \
-  L = net.add_conv<CFG>(nm, dsrc, -1, dst, cols, dlen[i], af, bs, 3);
+  L = net.add_conv<CFG>(nm, dsrc, -1, dst, cols, dout[i], af, bs, 3);
     switch (i) {
       case 0: EQ_DEC(EQ_d0) break;
       case 1: EQ_DEC(EQ_d1) break;
@@ -328,8 +341,8 @@ int plan_eqt(Net& net, const ParamView& pv) {
       default: EQ_DEC(EQ_d6) break;
     }
 #undef EQ_DEC
-    L->l_dst = up_len;
-    L->flops_per_window = 3 * 2.0 * dco[i] * dci[i] * dk[i] * dlen[i];
+    L->l_dst = dst_len;
+    L->flops_per_window = 3 * 2.0 * dco[i] * dci[i] * dk[i] * dout[i];  // algorithmic (reference) MACs
     net.steps.back().flops_per_window = L->flops_per_window;
     dsrc = dst;
   }

@@ -46,7 +46,7 @@ struct TransformerArgs {
   float* dst;        // [B][16][ls]
   int ls_dst;
   long ws_dst;
-  float* up;         // optional: decoder input, x2-upsampled rows [B][16][ls_up] (set 0)
+  float* up;         // optional: decoder input, decoder input rows [B][16][ls_up] (set 0)
   int ls_up;
   long ws_up;
   AttnWeights att;
@@ -62,7 +62,7 @@ struct PickBranchArgs {
   const float* src;  // transformer output [B][16][ls]
   int ls_src;
   long ws_src;
-  float* up;         // decoder input sets 1..2: [3B][16][ls_up], x2-upsampled
+  float* up;         // decoder input sets 1..2: [3B][16][ls_up]
   int ls_up;
   long ws_up;
   int B;

@@ -248,10 +248,7 @@ __global__ __launch_bounds__(512) void transformer_kernel(const TransformerArgs 
     const int c = idx / T, t = idx - c * T;
     const float val = xs[t][c];
     dst[(long)c * a.ls_dst + HALO + t] = val;
-    if (up) {
-      up[(long)c * a.ls_up + HALO + 2 * t] = val;
-      up[(long)c * a.ls_up + HALO + 2 * t + 1] = val;
-    }
+    if (up) up[(long)c * a.ls_up + HALO + t] = val;
   }
 }
 
@@ -285,8 +282,7 @@ __global__ __launch_bounds__(256) void pick_branch_kernel(const PickBranchArgs a
   for (int idx = tid; idx < EQT_H * T; idx += 256) {
     const int c = idx / T, t = idx - c * T;
     const float val = v[t][c];
-    up[(long)c * a.ls_up + HALO + 2 * t] = val;
-    up[(long)c * a.ls_up + HALO + 2 * t + 1] = val;
+    up[(long)c * a.ls_up + HALO + t] = val;
   }
 }
 
