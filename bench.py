@@ -97,28 +97,34 @@ def main():
     found = C.c_int()
     fv, lv, nw = C.c_int64(), C.c_int64(), C.c_int64()
 
-    DEPTH = 2  # submits kept in flight: the host enqueues step i+1 while the GPU runs step i
+    # Two device contexts (HIP stream + workspace each), two submits in flight per context: the host
+    # enqueues ahead of the GPU, and one context's latency-bound stages (LSTM/attention, small tail
+    # kernels) overlap the other's MFMA-bound ones.  Every step is still one full pass over one batch.
+    NCTX, DEPTH = 2, 2
+    ctxs = [model._context(k) for k in range(NCTX)]
+    outs = [out] + [torch.empty_like(out) for _ in range(NCTX - 1)]
 
-    def submit(slot):
-        # one submit = gather+normalise, forward, blinding+stacking, trigger scan, one async D2H of the triggers
-        _lib.check(lib.vp_classify_submit(h, slot, C.c_void_p(x.data_ptr()), _lib.VP_MEM_DEVICE, n_samples, overlap,
-                                          blinding[0], blinding[1], _lib.VP_STACK_AVG, args.batch, c_specs,
-                                          len(specs), C.c_void_p(out.data_ptr()), _lib.VP_MEM_DEVICE, cap),
+    def submit(i):
+        k, slot = i % NCTX, (i // NCTX) % DEPTH
+        _lib.check(lib.vp_classify_submit(ctxs[k], slot, C.c_void_p(x.data_ptr()), _lib.VP_MEM_DEVICE, n_samples,
+                                          overlap, blinding[0], blinding[1], _lib.VP_STACK_AVG, args.batch, c_specs,
+                                          len(specs), C.c_void_p(outs[k].data_ptr()), _lib.VP_MEM_DEVICE, cap),
                    "vp_classify_submit")
 
-    def collect(slot):
-        _lib.check(lib.vp_classify_collect(h, slot, C.byref(fv), C.byref(lv), C.byref(nw), on, off, peak, val, spec_of,
-                                           cap, C.byref(found)), "vp_classify_collect")
+    def collect(i):
+        k, slot = i % NCTX, (i // NCTX) % DEPTH
+        _lib.check(lib.vp_classify_collect(ctxs[k], slot, C.byref(fv), C.byref(lv), C.byref(nw), on, off, peak, val,
+                                           spec_of, cap, C.byref(found)), "vp_classify_collect")
         return found.value
 
     def run_steps(k):
         """k steps, each one full pass of the path over one 256-window batch; every step is collected."""
         inflight, n_picks = [], 0
         for i in range(k):
-            if len(inflight) == DEPTH:
+            if len(inflight) == NCTX * DEPTH:
                 n_picks = collect(inflight.pop(0))
-            submit(i % DEPTH)
-            inflight.append(i % DEPTH)
+            submit(i)
+            inflight.append(i)
         while inflight:
             n_picks = collect(inflight.pop(0))
         return n_picks
@@ -185,7 +191,8 @@ def main():
             "batch": args.batch,
             "in_samples": T,
             "parallelism": f"stream-sharded x{world}, weights broadcast once (RCCL)",
-            "inflight_steps": DEPTH,
+            "device_contexts": NCTX,
+            "inflight_steps_per_context": DEPTH,
         },
         "roofline": {
             "bound": "mfma",

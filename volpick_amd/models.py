@@ -68,6 +68,8 @@ class WaveformModel:
         self._weights_version = None
         self._weights = None  # flat fp32 blob in the library's canonical order
         self._handle = None
+        self._extra_handles = []
+        self.n_contexts = 2  # device contexts classify() pipelines station blocks over
         self._device_index = None
         self._max_batch = 256
         self._plan_flags = (0, 0)  # vp_config.reserved[0:2]: (layer-by-layer plan, dump fused intermediates)
@@ -202,7 +204,26 @@ class WaveformModel:
         self._handle = h
         return h
 
+    def _context(self, k):
+        """k-th device context of this model (own HIP stream + workspace).  Context 0 is ``_handle``;
+        further ones are created on first use.  ``classify`` round-robins station blocks over two
+        contexts so that one block's latency-bound stages overlap the other's MFMA-bound ones."""
+        self._ensure_handle()
+        if k == 0:
+            return self._handle
+        while len(self._extra_handles) < k:
+            lib = _lib.load()
+            cfg = self._config()
+            h = C.c_void_p()
+            _lib.check(lib.vp_create(self._device_index, self._kind, self._weights.ctypes.data_as(C.c_void_p),
+                                     self._weights.size, _lib.VP_MEM_HOST, C.byref(cfg), C.byref(h)), "vp_create")
+            self._extra_handles.append(h)
+        return self._extra_handles[k - 1]
+
     def _release(self):
+        for h in getattr(self, "_extra_handles", []):
+            _lib.load().vp_destroy(h)
+        self._extra_handles = []
         if getattr(self, "_handle", None) is not None:
             try:
                 _lib.load().vp_destroy(self._handle)
@@ -314,11 +335,11 @@ class WaveformModel:
                 specs.append((i, label, thr, thr))
         return specs
 
-    def _classify_block(self, data, args, specs, cap=8192):
-        """(3,N) float32 ndarray -> ([(spec_index, on, off, peak, value)], n_windows); indices into the block."""
+    def _submit_block(self, ctx, data, args, specs, cap):
+        """Enqueue one (3,N) block on device context ``ctx`` (no host synchronisation)."""
         torch = _torch()
         lib = _lib.load()
-        h = self._ensure_handle()
+        h = self._context(ctx)
         dev = torch.device("cuda", self._device_index)
         n = data.shape[1]
         x = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(dev)
@@ -326,18 +347,29 @@ class WaveformModel:
         c_specs = (_lib.VpTriggerSpec * len(specs))(*[_lib.VpTriggerSpec(r, on, off) for r, _, on, off in specs])
         stacking = _lib.VP_STACK_AVG if args["stacking"] == "avg" else _lib.VP_STACK_MAX
         batch = max(1, min(int(args["batch_size"]), self._max_batch))
+        _lib.check(lib.vp_classify_submit(h, 0, C.c_void_p(x.data_ptr()), _lib.VP_MEM_DEVICE, n, args["overlap"],
+                                          args["blinding"][0], args["blinding"][1], stacking, batch, c_specs,
+                                          len(specs), None, _lib.VP_MEM_DEVICE, cap), "vp_classify_submit")
+        return {"ctx": ctx, "x": x, "cap": cap, "data": data}  # x must outlive the submit
+
+    def _collect_block(self, job, args, specs):
+        """Wait for a submitted block -> ([(spec_index, on, off, peak, value)], n_windows)."""
+        lib = _lib.load()
+        h = self._context(job["ctx"])
+        cap = job["cap"]
+        on, off, peak = (C.c_int64 * cap)(), (C.c_int64 * cap)(), (C.c_int64 * cap)()
+        val, spec_of, found = (C.c_float * cap)(), (C.c_int32 * cap)(), C.c_int()
         fv, lv, nw = C.c_int64(), C.c_int64(), C.c_int64()
-        while True:
-            on, off, peak = (C.c_int64 * cap)(), (C.c_int64 * cap)(), (C.c_int64 * cap)()
-            val, spec_of, found = (C.c_float * cap)(), (C.c_int32 * cap)(), C.c_int()
-            _lib.check(lib.vp_classify(h, C.c_void_p(x.data_ptr()), _lib.VP_MEM_DEVICE, n, args["overlap"],
-                                       args["blinding"][0], args["blinding"][1], stacking, batch, c_specs, len(specs),
-                                       None, _lib.VP_MEM_DEVICE, C.byref(fv), C.byref(lv), C.byref(nw), on, off, peak,
-                                       val, spec_of, cap, C.byref(found)), "vp_classify")
-            if found.value <= cap:
-                m = found.value
-                return [(spec_of[i], on[i], off[i], peak[i], val[i]) for i in range(m)], nw.value
-            cap = found.value
+        _lib.check(lib.vp_classify_collect(h, 0, C.byref(fv), C.byref(lv), C.byref(nw), on, off, peak, val, spec_of,
+                                           cap, C.byref(found)), "vp_classify_collect")
+        if found.value > cap:  # rare: more triggers than the result block holds -> redo this block with room
+            job2 = self._submit_block(job["ctx"], job["data"], args, specs, found.value)
+            return self._collect_block(job2, args, specs)
+        return [(spec_of[i], on[i], off[i], peak[i], val[i]) for i in range(found.value)], nw.value
+
+    def _classify_block(self, data, args, specs, cap=8192):
+        """(3,N) float32 ndarray -> ([(spec_index, on, off, peak, value)], n_windows); indices into the block."""
+        return self._collect_block(self._submit_block(0, data, args, specs, cap), args, specs)
 
     def annotate(self, stream, copy=True, **kwargs):
         """Sliding-window probability traces, one per label, named ``<Model>_<label>``."""
@@ -358,8 +390,7 @@ class WaveformModel:
         specs = self._trigger_specs(args)
         picks, detections = PickList(), DetectionList()
         sr = self.sampling_rate
-        for grp in _group_stream(stream, self.component_order, sr, copy, self.in_samples):
-            triggers, nw = self._classify_block(grp["data"], args, specs)
+        def emit(grp, triggers):
             t0, tid = grp["starttime"], grp["trace_id"]
             for si, on, off, pk, v in triggers:
                 label = specs[si][1]
@@ -367,6 +398,17 @@ class WaveformModel:
                     detections.append(Detection(tid, t0 + on / sr, t0 + off / sr, v))
                 else:
                     picks.append(Pick(tid, t0 + on / sr, t0 + off / sr, t0 + pk / sr, v, label))
+
+        # station blocks are pipelined over the model's device contexts: block i+1 is enqueued (on
+        # the other context's stream) before block i is collected
+        pending = []
+        for i, grp in enumerate(_group_stream(stream, self.component_order, sr, copy, self.in_samples)):
+            if len(pending) == max(1, self.n_contexts):
+                g0, job = pending.pop(0)
+                emit(g0, self._collect_block(job, args, specs)[0])
+            pending.append((grp, self._submit_block(i % max(1, self.n_contexts), grp["data"], args, specs, 8192)))
+        for g0, job in pending:
+            emit(g0, self._collect_block(job, args, specs)[0])
         return ClassifyOutput(self.name, picks=PickList(sorted(picks)), detections=DetectionList(sorted(detections)))
 
 
