@@ -31,7 +31,9 @@ enum ConvEpi {
   EPI_UP2 = 2,       // dst[co][2t] = dst[co][2t+1] = v[t]       (EQT decoder: producer-side Upsample(2))
   EPI_RES = 3,       // o = v + res[co][t]; dst = o; dst2 = relu(s2[co]*o + b2[co])   (EQT ResCNN)
   EPI_SOFTMAX3 = 4,  // y[c][t] = softmax_c( w[c][:] . v[:][t] + b[c] )             (PhaseNet out)
-  EPI_POOL2_DUAL = 5 // POOL2, plus dst2 = relu(s2*pooled + b2)   (EQT encoder tail feeding ResCNN)
+  EPI_POOL2_DUAL = 5,// POOL2, plus dst2 = relu(s2*pooled + b2)   (EQT encoder tail feeding ResCNN)
+  EPI_HEAD = 6       // y[t] = sigmoid(b + sum_ci sum_k w[ci][k] v[ci][t+k-5])  (EQT decoder tail + Conv1d(8,1,11) head):
+                     // tiles overlap by 8 columns so the 5-sample halo of the head is recomputed, not re-read
 };
 
 struct ConvArgs {
@@ -112,7 +114,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   float* lds = reinterpret_cast<float*>(lds_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int win = blockIdx.y;
-  const int col0 = blockIdx.x * C::TN;
+  // EPI_HEAD tiles advance by TN-8 columns and start 4 columns early (halo of the fused head conv)
+  const int col0 = (C::EPI == EPI_HEAD) ? (int)blockIdx.x * (C::TN - 8) - 4 : (int)blockIdx.x * C::TN;
   const int set = win / a.win_per_set;
 
   // ---- stage the input tile: CINP rows x 4*W4 floats, aligned 16-byte loads --------------
@@ -175,6 +178,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         for (int j = 0; j < C::NW; ++j) {
           float v = acc[i][j][r] + b;
           if (C::RELU) v = fmaxf(v, 0.f);
+          if constexpr (C::EPI == EPI_HEAD) {  // outside the signal the head must see zero padding
+            const int tg = C::P * (col0 + (wn * C::NW + j) * 16 + n) + p;
+            if (tg < 0 || tg >= a.l_out) v = 0.f;
+          }
           lds[co * C::OS + C::P * ((wn * C::NW + j) * 16 + n) + p] = v;
         }
       }
@@ -249,6 +256,33 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         if (d2) d2[(long)co * a.lsd2 + t] = fmaxf(fmaf(s2[co], o, b2[co]), 0.f);
       }
     }
+  } else if constexpr (C::EPI == EPI_HEAD) {
+    static_assert(C::EPI != EPI_HEAD || (C::COUT == 8 && C::SN == 1 && C::P == 2), "EQT decoder tail");
+    const int b = win - set * a.win_per_set;
+    float* y = a.dst + ((long)b * 3 + set) * a.l_out;  // dense (B, 3, T): row = decoder index
+    const float* w = a.e0 + set * 88;
+    const float bias_h = a.e1[set];
+    const int t_first = C::P * ((int)blockIdx.x * (C::TN - 8));   // first output this tile owns
+    const int n_own = C::P * (C::TN - 8);
+    for (int q = tid; q < n_own; q += 256) {
+      const int t = t_first + q;
+      if (t < a.l_out) {
+        const float* s = lds + (t - C::P * col0) - 5;  // staged column of output t, minus the head's left pad
+        float a0 = bias_h, a1 = 0.f;
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+#pragma unroll
+          for (int k = 0; k < 11; ++k) {
+            if (k & 1) {
+              a1 = fmaf(w[ci * 11 + k], s[ci * C::OS + k], a1);
+            } else {
+              a0 = fmaf(w[ci * 11 + k], s[ci * C::OS + k], a0);
+            }
+          }
+        }
+        y[t] = 1.f / (1.f + expf(-(a0 + a1)));
+      }
+    }
   } else if constexpr (C::EPI == EPI_SOFTMAX3) {
     static_assert(C::EPI != EPI_SOFTMAX3 || C::COUT == 8, "PhaseNet head: 8 -> 3");
     float* d = a.dst + (long)win * a.wsd + a.dst_halo;
@@ -282,7 +316,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 
 template <class C>
 int launch_conv(const ConvArgs& a, int cols, hipStream_t stream) {
-  dim3 grid((cols + C::TN - 1) / C::TN, a.n_windows, 1);
+  constexpr int STEP = (C::EPI == EPI_HEAD) ? C::TN - 8 : C::TN;
+  dim3 grid((cols + STEP - 1) / STEP, a.n_windows, 1);
   hipLaunchKernelGGL(conv_mfma_kernel<C>, grid, dim3(256), C::LDS_FLOATS * sizeof(float), stream, a);
   return 0;
 }

@@ -44,7 +44,7 @@ using EQ_d2 = ConvCfg<64, 0, 32, 1, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
 using EQ_d3 = ConvCfg<32, 0, 32, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
 using EQ_d4 = ConvCfg<32, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
 using EQ_d5 = ConvCfg<16, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
-using EQ_d6 = ConvCfg<16, 0, 8, 2, 7, 1, -3, 0, 1, 4, 8, 1, EPI_STORE>;
+using EQ_d6 = ConvCfg<16, 0, 8, 2, 7, 1, -3, 0, 1, 4, 8, 1, EPI_HEAD>;  // + Conv1d(8,1,11) + sigmoid head
 
 std::vector<float> vec(const float* p, size_t n) { return std::vector<float>(p, p + n); }
 
@@ -312,7 +312,7 @@ int plan_eqt(Net& net, const ParamView& pv) {
   for (int i = 0; i < 7; ++i) {
     const bool polyphase = (i != 2);
     const int dst_len = (i == 1) ? 375 : dout[i];  // stage 1 stores its rows x2-upsampled and cropped
-    const int dst = net.add_tensor("decoder." + std::to_string(i), dco[i], dst_len, 3);
+    const int dst = (i == 6) ? kDenseOut : net.add_tensor("decoder." + std::to_string(i), dco[i], dst_len, 3);
     auto pack3 = [&](const ConvGeom& g, std::vector<float>* af, std::vector<float>* bs) {
       for (int d = 0; d < 3; ++d) {
         const std::string c = std::string(dec_prefix[d]) + ".convs." + std::to_string(i);
@@ -347,40 +347,23 @@ int plan_eqt(Net& net, const ParamView& pv) {
     dsrc = dst;
   }
 
-  // ---- heads --------------------------------------------------------------------------------
+  // ---- heads: Conv1d(8,1,11,pad 5) + sigmoid of the three decoders, fused into decoder.6's epilogue ----
   {
-    std::vector<float> w, b;
     const char* head[3] = {"conv_d", "pick_convs.0", "pick_convs.1"};
     for (int d = 0; d < 3; ++d) {
       const float* hw = pv.get(std::string(head[d]) + ".weight");
-      w.insert(w.end(), hw, hw + 88);
-      b.push_back(pv.get(std::string(head[d]) + ".bias")[0]);
+      L->e0.h.insert(L->e0.h.end(), hw, hw + 88);
+      L->e1.h.push_back(pv.get(std::string(head[d]) + ".bias")[0]);
     }
-    HostBlob* wb = net.add_blob(w);
-    HostBlob* bb = net.add_blob(b);
-    net.need(dsrc, HALO + T + 8);
-    Step st;
-    st.name = "heads";
-    st.flops_per_window = 3 * 2.0 * 8 * 11 * T;
-    const int src_t = dsrc;
-    st.run = [=](Net& n, int B, hipStream_t s_) -> int {
-      HeadArgs a{};
-      const Tensor& s0 = n.tensors[src_t];
-      a.src = s0.p;
-      a.ls_src = s0.ls;
-      a.ws_src = (long)s0.win_stride();
-      a.y = n.y;
-      a.w = wb->d;
-      a.b = bb->d;
-      a.B = B;
-      a.T = n.in_samples;
-      return launch_head(a, s_);
-    };
-    net.steps.push_back(std::move(st));
+    L->flops_per_window += 3 * 2.0 * 8 * 11 * T;
+    net.steps.back().flops_per_window = L->flops_per_window;
+    net.steps.back().name = "decoder.6+heads";
   }
 
   net.flops_per_window = 0;
   for (auto& s : net.steps) net.flops_per_window += s.flops_per_window;
+  // reserved[0] = 1 keeps the 14 ResCNN conv launches (layer-by-layer debug / A-B plan)
+  if (net.cfg.reserved[0] != 1) return plan_eqt_fuse_res(net);
   return VP_OK;
 }
 

@@ -1,0 +1,159 @@
+// EQTransformer ResCNN stack as ONE launch: seven residual blocks (14 convs 64->64, k 3/2, length 47)
+// run back to back inside one workgroup per window with the residual stream, the BN-ReLU'd conv
+// input and the mid activation in LDS (60 KB); only the packed weights stream in from L2.
+// Same arithmetic and the same packed A-fragments as the 14 conv_mfma_kernel launches it replaces
+// (plan flag reserved[0] = 1 keeps those for A/B timing and the layer-by-layer parity test).
+#include "conv_lds.h"
+#include "eqt_kernels.h"
+#include "net.h"
+
+namespace vp {
+
+namespace {
+
+constexpr int RT = EQT_T;   // 47
+constexpr int RS = 80;      // image stride (== 16 mod 32): logical 0 at column 4, 29 zero columns to the right
+constexpr int RB = 4;
+using R_k3 = LdsLayer<64, 0, 64, 1, 3, 1, -1, 0, 3, 1>;   // conv1: (BN folded) + ReLU
+using R_k2 = LdsLayer<64, 0, 64, 1, 2, 1, 0, 0, 3, 1>;
+using R_k3n = LdsLayer<64, 0, 64, 1, 3, 1, -1, 0, 3, 0>;  // conv2: no activation, residual epilogue
+using R_k2n = LdsLayer<64, 0, 64, 1, 2, 1, 0, 0, 3, 0>;
+
+struct ResArgs {
+  const float* x0;    // encoder output [B][64][ls]
+  const float* act0;  // relu(bn1_0(x0)) [B][64][ls]
+  int ls_x, ls_a;
+  long ws_x, ws_a;
+  float* out;         // [B][64][ls]
+  int ls_out;
+  long ws_out;
+  const float* af1[7];
+  const float* bs1[7];
+  const float* af2[7];
+  const float* bs2[7];
+  const float* s_next[7];  // BN scale/shift of the NEXT block's norm1 (block 6: unused)
+  const float* b_next[7];
+};
+
+struct MidStore {  // conv1 epilogue -> mid image
+  float* img;
+  __device__ __forceinline__ void operator()(int co, int t, float v) const {
+    if ((unsigned)t < (unsigned)RT) img[co * RS + RB + t] = v;
+  }
+  __device__ __forceinline__ bool all_valid(int t0, int t1) const { return t0 >= 0 && t1 < RT; }
+  __device__ __forceinline__ void unchecked(int co, int t, float v) const { img[co * RS + RB + t] = v; }
+};
+
+struct ResStore {  // conv2 epilogue: x += v (in place); act = relu(s*x + b) for the next block's conv1
+  float* x;
+  float* act;
+  const float* s;
+  const float* b;
+  bool last;
+  __device__ __forceinline__ void unchecked(int co, int t, float v) const {
+    const float o = v + x[co * RS + RB + t];
+    x[co * RS + RB + t] = o;
+    if (!last) act[co * RS + RB + t] = fmaxf(fmaf(s[co], o, b[co]), 0.f);
+  }
+  __device__ __forceinline__ void operator()(int co, int t, float v) const {
+    if ((unsigned)t < (unsigned)RT) unchecked(co, t, v);
+  }
+  __device__ __forceinline__ bool all_valid(int t0, int t1) const { return t0 >= 0 && t1 < RT; }
+};
+
+__global__ __launch_bounds__(256) void eqt_res_kernel(const ResArgs a) {
+  __shared__ __attribute__((aligned(16))) float X[64 * RS];
+  __shared__ __attribute__((aligned(16))) float ACT[64 * RS];
+  __shared__ __attribute__((aligned(16))) float MID[64 * RS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, win = blockIdx.x;
+  {
+    const float* x0 = a.x0 + (long)win * a.ws_x + HALO;
+    const float* a0 = a.act0 + (long)win * a.ws_a + HALO;
+    for (int i = tid; i < 64 * RS; i += 256) {
+      const int c = i / RS, col = i - c * RS, t = col - RB;
+      const bool in = (unsigned)t < (unsigned)RT;
+      X[i] = in ? x0[(long)c * a.ls_x + t] : 0.f;
+      ACT[i] = in ? a0[(long)c * a.ls_a + t] : 0.f;  // halo columns stay zero for the whole kernel
+      MID[i] = 0.f;
+    }
+  }
+  __syncthreads();
+  constexpr int kers[7] = {3, 3, 3, 3, 2, 3, 2};
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    MidStore ms{MID};
+    ResStore rs{X, ACT, a.s_next[i], a.b_next[i], i == 6};
+    if (kers[i] == 3) {
+      conv_lds<R_k3, RS, RB, RS, RB, false>(ACT, ACT, a.af1[i], a.bs1[i], RT, ms, wave, 4, lane);
+      __syncthreads();
+      conv_lds<R_k3n, RS, RB, RS, RB, false>(MID, MID, a.af2[i], a.bs2[i], RT, rs, wave, 4, lane);
+    } else {
+      conv_lds<R_k2, RS, RB, RS, RB, false>(ACT, ACT, a.af1[i], a.bs1[i], RT, ms, wave, 4, lane);
+      __syncthreads();
+      conv_lds<R_k2n, RS, RB, RS, RB, false>(MID, MID, a.af2[i], a.bs2[i], RT, rs, wave, 4, lane);
+    }
+    __syncthreads();
+  }
+  float* out = a.out + (long)win * a.ws_out + HALO;
+  for (int i = tid; i < 64 * RT; i += 256) {
+    const int c = i / RT, t = i - c * RT;
+    out[(long)c * a.ls_out + t] = X[c * RS + RB + t];
+  }
+}
+
+}  // namespace
+
+// Replaces the steps "res0.conv1" .. "res6.conv2" of the layer plan by one fused step.
+int plan_eqt_fuse_res(Net& net) {
+  int first = -1;
+  for (size_t i = 0; i < net.steps.size(); ++i)
+    if (net.steps[i].name == "res0.conv1") first = (int)i;
+  if (first < 0 || first + 14 > (int)net.steps.size() || net.steps[first + 13].name != "res6.conv2") {
+    set_error("fused ResCNN: layer plan not found");
+    return VP_ERR_INVALID;
+  }
+  std::vector<ConvLayer*> c1(7), c2(7);
+  for (auto& c : net.convs)
+    for (int i = 0; i < 7; ++i) {
+      if (c->name == "res" + std::to_string(i) + ".conv1") c1[i] = c.get();
+      if (c->name == "res" + std::to_string(i) + ".conv2") c2[i] = c.get();
+    }
+  for (int i = 0; i < 7; ++i)
+    if (!c1[i] || !c2[i]) {
+      set_error("fused ResCNN: conv layer %d missing", i);
+      return VP_ERR_INVALID;
+    }
+  const int x0 = c2[0]->res, act0 = c1[0]->src1, out = c2[6]->dst;
+  Step st;
+  st.name = "fused.rescnn (7 residual blocks)";
+  st.flops_per_window = 0;
+  for (int i = 0; i < 14; ++i) st.flops_per_window += net.steps[first + i].flops_per_window;
+  st.run = [=](Net& n, int B, hipStream_t s) -> int {
+    ResArgs a{};
+    const Tensor &tx = n.tensors[x0], &ta = n.tensors[act0], &to = n.tensors[out];
+    a.x0 = tx.p;
+    a.act0 = ta.p;
+    a.ls_x = tx.ls;
+    a.ws_x = (long)tx.win_stride();
+    a.ls_a = ta.ls;
+    a.ws_a = (long)ta.win_stride();
+    a.out = to.p;
+    a.ls_out = to.ls;
+    a.ws_out = (long)to.win_stride();
+    for (int i = 0; i < 7; ++i) {
+      a.af1[i] = c1[i]->afrag.d;
+      a.bs1[i] = c1[i]->bias.d;
+      a.af2[i] = c2[i]->afrag.d;
+      a.bs2[i] = c2[i]->bias.d;
+      a.s_next[i] = c2[i]->e1.d;
+      a.b_next[i] = c2[i]->e2.d;
+    }
+    hipLaunchKernelGGL(eqt_res_kernel, dim3(B), dim3(256), 0, s, a);
+    return 0;
+  };
+  net.steps.erase(net.steps.begin() + first, net.steps.begin() + first + 14);
+  net.steps.insert(net.steps.begin() + first, std::move(st));
+  return VP_OK;
+}
+
+}  // namespace vp

@@ -21,6 +21,8 @@ __device__ inline float lane_bcast(float v, int lane) {  // lane is a compile-ti
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 __device__ inline float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+// recurrent gates: v_exp_f32 + v_rcp_f32 (abs error ~1e-7); 47 dependent steps make this the critical path
+__device__ inline float sigmoid_fast(float x) { return __frcp_rn(1.f + __expf(-x)); }
 // tanh via one exp; abs error ~1e-7, saturates correctly at +-inf
 __device__ inline float tanh_fast(float z) {
   const float t = __expf(2.f * z);
@@ -71,11 +73,13 @@ __device__ void lstm_direction(const float* xs, float* gx, const LstmWeights w, 
       g3 = fmaf(whh[k + 3], lane_bcast(h, k + 3), g3);
     }
     const float g = (g0 + g1) + (g2 + g3);
-    const float act = is_g ? tanhf(g) : sigmoid_f(g);
+    // tanh(g) = 2*sigmoid(2g) - 1: one exp + one rcp for every gate lane, no divergence
+    const float sg = sigmoid_fast(is_g ? 2.f * g : g);
+    const float act = is_g ? 2.f * sg - 1.f : sg;
     const float ig = __shfl(act, u, 64), fg = __shfl(act, u + 16, 64);
     const float gg = __shfl(act, u + 32, 64), og = __shfl(act, u + 48, 64);
     c = fmaf(fg, c, ig * gg);
-    h = og * tanhf(c);
+    h = og * tanh_fast(c);
     if (lane < EQT_H) hout[lane * hs + t] = h;
   }
 }
@@ -203,7 +207,8 @@ int launch_bilstm(const BiLstmArgs& a, int cin, int B, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void transformer_kernel(const TransformerArgs a) {
+__global__ __launch_bounds__(1024) void transformer_kernel(const TransformerArgs a) {
+  constexpr int NTH = 1024;
   __shared__ float xs[T][EQT_H];
   __shared__ float q[T][KP], k[T][KP];
   __shared__ float e[T][48];
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(512) void transformer_kernel(const TransformerArgs 
     layer_norm16(z, a.g1, a.b1, a.ln_eps, y1[tid]);
   }
   __syncthreads();
-  for (int idx = tid; idx < T * 128; idx += 512) {  // FF: Linear(16,128) + ReLU
+  for (int idx = tid; idx < T * 128; idx += NTH) {  // FF: Linear(16,128) + ReLU
     const int t = idx >> 7, m = idx & 127;
     float acc = a.bb1[m];
 #pragma unroll
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(512) void transformer_kernel(const TransformerArgs 
     h1[t][m] = fmaxf(acc, 0.f);
   }
   __syncthreads();
-  for (int idx = tid; idx < T * EQT_H; idx += 512) {  // Linear(128,16) + residual
+  for (int idx = tid; idx < T * EQT_H; idx += NTH) {  // Linear(128,16) + residual
     const int t = idx >> 4, c = idx & 15;
     float a0 = a.bb2[c], a1 = 0.f;
 #pragma unroll 8
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(512) void transformer_kernel(const TransformerArgs 
   __syncthreads();
   float* dst = a.dst + (long)b * a.ws_dst;
   float* up = a.up ? a.up + (long)b * a.ws_up : nullptr;
-  for (int idx = tid; idx < EQT_H * T; idx += 512) {
+  for (int idx = tid; idx < EQT_H * T; idx += NTH) {
     const int c = idx / T, t = idx - c * T;
     const float val = xs[t][c];
     dst[(long)c * a.ls_dst + HALO + t] = val;
@@ -253,13 +258,14 @@ __global__ __launch_bounds__(512) void transformer_kernel(const TransformerArgs 
 }
 
 int launch_transformer(const TransformerArgs& a, int B, hipStream_t s) {
-  hipLaunchKernelGGL(transformer_kernel, dim3(B), dim3(512), 0, s, a);
+  hipLaunchKernelGGL(transformer_kernel, dim3(B), dim3(1024), 0, s, a);
   return 0;
 }
 
 // ---------------------------------------------------------------------------------------
 // P / S branch: LSTM(16,16) -> banded additive attention -> x2-upsampled decoder input.
-__global__ __launch_bounds__(256) void pick_branch_kernel(const PickBranchArgs a) {
+__global__ __launch_bounds__(1024) void pick_branch_kernel(const PickBranchArgs a) {
+  constexpr int NTH = 1024;
   __shared__ __attribute__((aligned(16))) float xs[T][EQT_H];
   __shared__ float gx[T * 64];
   __shared__ float hl[EQT_H][48];
@@ -272,14 +278,14 @@ __global__ __launch_bounds__(256) void pick_branch_kernel(const PickBranchArgs a
   __syncthreads();
   if (tid < 64) lstm_direction<EQT_H>(&xs[0][0], gx, a.lstm[br], false, &hl[0][0], 48);
   __syncthreads();
-  for (int idx = tid; idx < T * EQT_H; idx += 256) {
+  for (int idx = tid; idx < T * EQT_H; idx += NTH) {
     const int t = idx >> 4, c = idx & 15;
     x2[t][c] = hl[c][t];
   }
   __syncthreads();
   attention_core(x2, q, k, e, v, a.att[br], a.attn_eps, a.width);
   float* up = a.up + (long)((1 + br) * a.B + b) * a.ws_up;
-  for (int idx = tid; idx < EQT_H * T; idx += 256) {
+  for (int idx = tid; idx < EQT_H * T; idx += NTH) {
     const int c = idx / T, t = idx - c * T;
     const float val = v[t][c];
     up[(long)c * a.ls_up + HALO + t] = val;
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(256) void pick_branch_kernel(const PickBranchArgs a
 }
 
 int launch_pick_branch(const PickBranchArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(pick_branch_kernel, dim3(a.B, 2), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(pick_branch_kernel, dim3(a.B, 2), dim3(1024), 0, s, a);
   return 0;
 }
 
