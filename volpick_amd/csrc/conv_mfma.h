@@ -262,25 +262,37 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     float* y = a.dst + ((long)b * 3 + set) * a.l_out;  // dense (B, 3, T): row = decoder index
     const float* w = a.e0 + set * 88;
     const float bias_h = a.e1[set];
-    const int t_first = C::P * ((int)blockIdx.x * (C::TN - 8));   // first output this tile owns
-    const int n_own = C::P * (C::TN - 8);
-    for (int q = tid; q < n_own; q += 256) {
-      const int t = t_first + q;
-      if (t < a.l_out) {
-        const float* s = lds + (t - C::P * col0) - 5;  // staged column of output t, minus the head's left pad
-        float a0 = bias_h, a1 = 0.f;
+    // Thread i owns the 4 staged columns 4i+5 .. 4i+8 and reads the 16 staged values 4i .. 4i+15 of each
+    // channel with four aligned ds_read_b128 (8x fewer LDS instructions than one read per tap).  The tile
+    // owns staged columns [8, 8 + 2*(TN-8)), i.e. outputs [2*tile*(TN-8), +2*(TN-8)).
+    const int t_tile = C::P * col0;  // output index of staged column 0
+    constexpr int N_THR = (C::P * (C::TN - 8) + 8 - 5 + 3) / 4;
+    static_assert(N_THR <= 256 && 4 * (N_THR - 1) + 15 < C::OS, "head epilogue geometry");
+    if (tid < N_THR) {
+      float acc[4] = {bias_h, bias_h, bias_h, bias_h};
 #pragma unroll
-        for (int ci = 0; ci < 8; ++ci) {
+      for (int ci = 0; ci < 8; ++ci) {
+        float v[16];
 #pragma unroll
-          for (int k = 0; k < 11; ++k) {
-            if (k & 1) {
-              a1 = fmaf(w[ci * 11 + k], s[ci * C::OS + k], a1);
-            } else {
-              a0 = fmaf(w[ci * 11 + k], s[ci * C::OS + k], a0);
-            }
-          }
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float4 x4 = *reinterpret_cast<const float4*>(lds + ci * C::OS + 4 * tid + 4 * q4);
+          v[4 * q4] = x4.x;
+          v[4 * q4 + 1] = x4.y;
+          v[4 * q4 + 2] = x4.z;
+          v[4 * q4 + 3] = x4.w;
         }
-        y[t] = 1.f / (1.f + expf(-(a0 + a1)));
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+          const float wk = w[ci * 11 + k];
+#pragma unroll
+          for (int o = 0; o < 4; ++o) acc[o] = fmaf(wk, v[o + k], acc[o]);  // staged col (4i+5+o) + k - 5
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const int col = 4 * tid + 5 + o;
+        const int t = t_tile + col;
+        if (col >= 8 && col < 8 + C::P * (C::TN - 8) && t < a.l_out) y[t] = 1.f / (1.f + expf(-acc[o]));
       }
     }
   } else if constexpr (C::EPI == EPI_SOFTMAX3) {

@@ -358,12 +358,17 @@ int plan_eqt(Net& net, const ParamView& pv) {
     L->flops_per_window += 3 * 2.0 * 8 * 11 * T;
     net.steps.back().flops_per_window = L->flops_per_window;
     net.steps.back().name = "decoder.6+heads";
+    L->name = "decoder.6";
   }
 
   net.flops_per_window = 0;
   for (auto& s : net.steps) net.flops_per_window += s.flops_per_window;
   // reserved[0] = 1 keeps the 14 ResCNN conv launches (layer-by-layer debug / A-B plan)
-  if (net.cfg.reserved[0] != 1) return plan_eqt_fuse_res(net);
+  if (net.cfg.reserved[0] != 1) {
+    int rc = plan_eqt_fuse_res(net);
+    if (rc == VP_OK) rc = plan_eqt_fuse_dec_tail(net);
+    return rc;
+  }
   return VP_OK;
 }
 
