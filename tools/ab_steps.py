@@ -46,6 +46,6 @@ for v in variants:
     a = np.array(res[v]) * 1e3
     med = np.median(a, axis=0)
     print(f"variant {v}: total median {med.sum():8.1f} us   min-of-rounds {a.sum(1).min():8.1f} us")
-    if len(med) <= 6:
+    if len(med) <= 40:
         for n_, t in zip(names[v], med):
             print(f"     {n_:50s} {t:8.1f} us")

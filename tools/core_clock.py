@@ -38,5 +38,7 @@ for n, c in zip(names, med):
 wall = (clk[:, 17] - clk[:, 16]).astype(np.float64) / 100e6
 cyc = (clk[:, 14] - clk[:, 0]).astype(np.float64)
 print("in-kernel wall us (median)", np.median(wall) * 1e6, " shader clock GHz (median)", np.median(cyc / wall) / 1e9)
+u = np.diff(clk[:, 18:23].astype(np.int64), axis=1)
+print("up3 (tile 2) median cycles: load %d  u3T %d  u3same %d  softmax+store %d" % tuple(np.median(u, axis=0)))
 print("total", tot, "cycles; window span min/med/max", (clk[:, 14] - clk[:, 0]).min(), np.median(clk[:, 14] - clk[:, 0]),
       (clk[:, 14] - clk[:, 0]).max())

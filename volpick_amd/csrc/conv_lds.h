@@ -136,3 +136,71 @@ __device__ __forceinline__ void zero_image(float* img, int tid, int nthreads) {
 }
 
 }  // namespace vp
+
+namespace vp {
+
+// ---- register-resident A variant -----------------------------------------------------------------
+// For short-K layers run many times by one (persistent) workgroup the A fragments of the wave's
+// m-tile are loaded ONCE into registers; the K loop is fully unrolled and only touches LDS.
+template <class L>
+__device__ __forceinline__ void load_areg(const float* __restrict__ afrag, const int mt, const int lane,
+                                          float (&areg)[L::CB * L::TAPS]) {
+  const float* ap = afrag + (long)mt * L::CB * L::TAPS * 64 + lane;
+#pragma unroll
+  for (int k = 0; k < L::CB * L::TAPS; ++k) areg[k] = ap[k * 64];
+}
+template <class L>
+__device__ __forceinline__ void load_biasreg(const float* __restrict__ bias, const int mt, const int lane,
+                                             float (&biasv)[4]) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) biasv[r] = bias[mt * (16 / L::P) + (4 * g) / L::P + r / L::P];
+}
+
+// Blocks nblk = first_block, first_block + block_step, ... of m-tile `mt` (the caller maps waves to
+// (mt, block) pairs; all blocks of a wave share areg / biasv).
+template <class L, int S1, int B1, int S2, int B2, class Store>
+__device__ __forceinline__ void conv_lds_areg(const float* in1, const float* in2, const float (&areg)[L::CB * L::TAPS],
+                                              const float (&biasv)[4], const int mt, const int cols, Store store,
+                                              const int first_block, const int block_step, const int lane) {
+  const int NT = (cols + 15) >> 4;
+  const int NBLK = (NT + L::NB - 1) / L::NB;
+  const int g = lane >> 4, n = lane & 15;
+  for (int nblk = first_block; nblk < NBLK; nblk += block_step) {
+    const int colb = nblk * L::NB * 16;
+    f32x4 acc[L::NB];
+#pragma unroll
+    for (int j = 0; j < L::NB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* bp1 = in1 + g * S1 + B1 + (colb + n) * L::SN + L::IN_OFF;
+    const float* bp2 = in2 + g * S2 + B2 + (colb + n) * L::SN + L::IN_OFF;
+#pragma unroll
+    for (int cb = 0; cb < L::CB; ++cb) {
+      const float* bp = (cb < L::CB1) ? bp1 + cb * 4 * S1 : bp2 + (cb - L::CB1) * 4 * S2;
+#pragma unroll
+      for (int tap = 0; tap < L::TAPS; ++tap)
+#pragma unroll
+        for (int j = 0; j < L::NB; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[cb * L::TAPS + tap], bp[j * 16 * L::SN + tap], acc[j], 0, 0, 0);
+    }
+    const int co_lane = mt * (16 / L::P) + (4 * g) / L::P;
+    const int t_first = L::P * colb + L::OUT_OFF, t_last = L::P * (colb + L::NB * 16) - 1 + L::OUT_OFF;
+    const bool fast = store.all_valid(t_first, t_last);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co_lane + r / L::P, p = r % L::P;
+#pragma unroll
+      for (int j = 0; j < L::NB; ++j) {
+        float v = acc[j][r] + biasv[r];
+        if (L::RELU) v = fmaxf(v, 0.f);
+        const int t = L::P * (colb + j * 16 + n) + p + L::OUT_OFF;
+        if (fast) {
+          store.unchecked(co, t, v);
+        } else {
+          store(co, t, v);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace vp

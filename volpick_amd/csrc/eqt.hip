@@ -45,6 +45,11 @@ using EQ_d3 = ConvCfg<32, 0, 32, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
 using EQ_d4 = ConvCfg<32, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
 using EQ_d5 = ConvCfg<16, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
 using EQ_d6 = ConvCfg<16, 0, 8, 2, 7, 1, -3, 0, 1, 4, 8, 1, EPI_HEAD>;  // + Conv1d(8,1,11) + sigmoid head
+// A/B tile variants (plan flag reserved[3] = 1): half-width tiles, twice the workgroups per CU
+using EQ_d3b = ConvCfg<32, 0, 32, 2, 5, 1, -2, 0, 2, 2, 3, 1, EPI_STORE>;
+using EQ_d4b = ConvCfg<32, 0, 16, 2, 5, 1, -2, 0, 2, 2, 3, 1, EPI_STORE>;
+using EQ_d5b = ConvCfg<16, 0, 16, 2, 5, 1, -2, 0, 2, 2, 3, 1, EPI_STORE>;
+using EQ_d6b = ConvCfg<16, 0, 8, 2, 7, 1, -3, 0, 1, 4, 4, 1, EPI_HEAD>;
 
 std::vector<float> vec(const float* p, size_t n) { return std::vector<float>(p, p + n); }
 
@@ -309,6 +314,7 @@ int plan_eqt(Net& net, const ParamView& pv) {
   const int dk[7] = {3, 5, 5, 7, 7, 9, 11};
   const char* dec_prefix[3] = {"decoder_d", "pick_decoders.0", "pick_decoders.1"};
   int dsrc = dec_in;
+  const bool alt = net.cfg.reserved[3] == 1;
   for (int i = 0; i < 7; ++i) {
     const bool polyphase = (i != 2);
     const int dst_len = (i == 1) ? 375 : dout[i];  // stage 1 stores its rows x2-upsampled and cropped
@@ -335,10 +341,10 @@ int plan_eqt(Net& net, const ParamView& pv) {
       case 0: EQ_DEC(EQ_d0) break;
       case 1: EQ_DEC(EQ_d1) break;
       case 2: EQ_DEC(EQ_d2) break;
-      case 3: EQ_DEC(EQ_d3) break;
-      case 4: EQ_DEC(EQ_d4) break;
-      case 5: EQ_DEC(EQ_d5) break;
-      default: EQ_DEC(EQ_d6) break;
+      case 3: if (alt) { EQ_DEC(EQ_d3b) } else { EQ_DEC(EQ_d3) } break;
+      case 4: if (alt) { EQ_DEC(EQ_d4b) } else { EQ_DEC(EQ_d4) } break;
+      case 5: if (alt) { EQ_DEC(EQ_d5b) } else { EQ_DEC(EQ_d5) } break;
+      default: if (alt) { EQ_DEC(EQ_d6b) } else { EQ_DEC(EQ_d6) } break;
     }
 #undef EQ_DEC
     L->l_dst = dst_len;
@@ -366,7 +372,6 @@ int plan_eqt(Net& net, const ParamView& pv) {
   // reserved[0] = 1 keeps the 14 ResCNN conv launches (layer-by-layer debug / A-B plan)
   if (net.cfg.reserved[0] != 1) {
     int rc = plan_eqt_fuse_res(net);
-    if (rc == VP_OK) rc = plan_eqt_fuse_dec_tail(net);
     return rc;
   }
   return VP_OK;

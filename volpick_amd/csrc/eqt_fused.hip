@@ -102,94 +102,6 @@ __global__ __launch_bounds__(256) void eqt_res_kernel(const ResArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// Decoder tail as ONE launch per 512 output samples: decoder.5 (16->16, k9) -> decoder.6 (16->8, k11)
-// -> Conv1d(8,1,11) + sigmoid head, for the three decoders (weight set = window / B).  The 16x3000
-// rows between stages 5 and 6 (147 MB per 256-window batch, written and read back by the layer plan)
-// stay in LDS.  Local coordinates: y4 col c <-> global 128*tile - 8 + c; y5 col <-> global 256*tile - 16 + c;
-// staged stage-6 col s <-> output sample 512*tile - 16 + s.
-// ---------------------------------------------------------------------------------------------
-constexpr int DT_TT = 512;
-constexpr int DT_S4 = 176, DT_S5 = 304, DT_SO = 548;  // image strides (== 16 mod 32 for the conv inputs)
-using DT_d5 = LdsLayer<16, 0, 16, 2, 5, 1, -2, 0, 5, 1>;
-using DT_d6 = LdsLayer<16, 0, 8, 2, 7, 1, 5, 0, 5, 1>;   // column j reads y5 local j + 8 + d, d in [-3, 3]
-constexpr int DT_Y4 = 0, DT_Y5 = 16 * DT_S4, DT_ST = DT_Y5 + 16 * DT_S5, DT_LDS_FLOATS = DT_ST + 8 * DT_SO;
-
-struct DecTailArgs {
-  const float* y4;  // decoder.4 rows [3B][16][ls]
-  int ls4;
-  long ws4;
-  float* y;         // dense (B, 3, T)
-  const float* af5; // [3 sets]
-  const float* bs5;
-  const float* af6;
-  const float* bs6;
-  long af5_stride, af6_stride;
-  const float* wh;  // [3][8][11]
-  const float* bh;  // [3]
-  int B, T;
-};
-
-__global__ __launch_bounds__(256) void eqt_dec_tail_kernel(const DecTailArgs a) {
-  extern __shared__ float4 lds_raw[];
-  float* lds = reinterpret_cast<float*>(lds_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = blockIdx.x, win = blockIdx.y;
-  const int set = win / a.B, b = win - set * a.B;
-  const int o5 = 256 * tile - 16, t_st = DT_TT * tile - 16;  // global index of y5 col 0 / staged col 0
-  {  // y4 rows: cols [0, 152); physical = HALO + 128*tile - 8 + 4q
-    const float* src = a.y4 + (long)win * a.ws4 + 128 * tile;
-    for (int i = tid; i < 16 * 38; i += 256) {
-      const int c = i / 38, q = i - c * 38;
-      *reinterpret_cast<float4*>(lds + DT_Y4 + c * DT_S4 + RB + 4 * q) =
-          *reinterpret_cast<const float4*>(src + (long)c * a.ls4 + 4 * q);
-    }
-  }
-  __syncthreads();
-  {
-    ImageStore<DT_S5, RB> st{lds + DT_Y5, 0, 288, -o5, 3000 - o5};
-    conv_lds<DT_d5, DT_S4, RB, DT_S4, RB, false>(lds + DT_Y4, lds + DT_Y4, a.af5 + set * a.af5_stride, a.bs5 + set * 16,
-                                                   144, st, wave, 4, lane);
-  }
-  __syncthreads();
-  {
-    ImageStore<DT_SO, 0> st{lds + DT_ST, 0, 544, -t_st, a.T - t_st};
-    conv_lds<DT_d6, DT_S5, RB, DT_S5, RB, false>(lds + DT_Y5, lds + DT_Y5, a.af6 + set * a.af6_stride, a.bs6 + set * 8,
-                                                   272, st, wave, 4, lane);
-  }
-  __syncthreads();
-  // head: thread i reads staged cols 4i..4i+15 of each channel, owns cols 4i+5..4i+8 inside [16, 528)
-  if (tid < 132) {
-    const float* w = a.wh + set * 88;
-    const float bias_h = a.bh[set];
-    float acc[4] = {bias_h, bias_h, bias_h, bias_h};
-#pragma unroll
-    for (int ci = 0; ci < 8; ++ci) {
-      float v[16];
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const float4 x4 = *reinterpret_cast<const float4*>(lds + DT_ST + ci * DT_SO + 4 * tid + 4 * q4);
-        v[4 * q4] = x4.x;
-        v[4 * q4 + 1] = x4.y;
-        v[4 * q4 + 2] = x4.z;
-        v[4 * q4 + 3] = x4.w;
-      }
-#pragma unroll
-      for (int k = 0; k < 11; ++k) {
-        const float wk = w[ci * 11 + k];
-#pragma unroll
-        for (int o = 0; o < 4; ++o) acc[o] = fmaf(wk, v[o + k], acc[o]);
-      }
-    }
-    float* y = a.y + ((long)b * 3 + set) * a.T;
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      const int col = 4 * tid + 5 + o, t = t_st + col;
-      if (col >= 16 && col < 16 + DT_TT && t < a.T) y[t] = 1.f / (1.f + expf(-acc[o]));
-    }
-  }
-}
-
 }  // namespace
 
 // Replaces the steps "res0.conv1" .. "res6.conv2" of the layer plan by one fused step.
@@ -245,56 +157,4 @@ int plan_eqt_fuse_res(Net& net) {
   return VP_OK;
 }
 
-}  // namespace vp
-
-namespace vp {
-// Replaces "decoder.5" and "decoder.6+heads" by the fused decoder tail.
-int plan_eqt_fuse_dec_tail(Net& net) {
-  int first = -1;
-  for (size_t i = 0; i < net.steps.size(); ++i)
-    if (net.steps[i].name == "decoder.5") first = (int)i;
-  if (first < 0 || first + 2 != (int)net.steps.size() || net.steps[first + 1].name != "decoder.6+heads") {
-    set_error("fused decoder tail: layer plan not found");
-    return VP_ERR_INVALID;
-  }
-  ConvLayer *c5 = nullptr, *c6 = nullptr;
-  for (auto& c : net.convs) {
-    if (c->name == "decoder.5") c5 = c.get();
-    if (c->name == "decoder.6") c6 = c.get();
-  }
-  if (!c5 || !c6) {
-    set_error("fused decoder tail: conv layers missing");
-    return VP_ERR_INVALID;
-  }
-  const int y4 = c5->src1;
-  const int n_tiles = (net.in_samples + DT_TT - 1) / DT_TT;
-  net.need(y4, HALO + 128 * (n_tiles - 1) - 8 + 152);
-  Step st;
-  st.name = "fused.decoder_tail (decoder.5+6+heads)";
-  st.flops_per_window = net.steps[first].flops_per_window + net.steps[first + 1].flops_per_window;
-  st.run = [=](Net& n, int B, hipStream_t s) -> int {
-    DecTailArgs a{};
-    const Tensor& t4 = n.tensors[y4];
-    a.y4 = t4.p;
-    a.ls4 = t4.ls;
-    a.ws4 = (long)t4.win_stride();
-    a.y = n.y;
-    a.af5 = c5->afrag.d;
-    a.bs5 = c5->bias.d;
-    a.af6 = c6->afrag.d;
-    a.bs6 = c6->bias.d;
-    a.af5_stride = (long)(c5->afrag.h.size() / 3);
-    a.af6_stride = (long)(c6->afrag.h.size() / 3);
-    a.wh = c6->e0.d;
-    a.bh = c6->e1.d;
-    a.B = B;
-    a.T = n.in_samples;
-    hipLaunchKernelGGL(eqt_dec_tail_kernel, dim3(n_tiles, 3 * B), dim3(256), DT_LDS_FLOATS * sizeof(float), s, a);
-    return 0;
-  };
-  net.steps.erase(net.steps.begin() + first, net.steps.end());
-  net.steps.push_back(std::move(st));
-  net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_dec_tail_kernel), DT_LDS_FLOATS * sizeof(float)});
-  return VP_OK;
-}
 }  // namespace vp

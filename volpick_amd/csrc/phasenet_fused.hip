@@ -290,6 +290,7 @@ struct Up3Args {
   const float *af_t, *bs_t, *af_same, *bs_same;
   const float* w_out;  // [3][8]
   const float* b_out;  // [3]
+  unsigned long long* clk;  // optional debug stamps (tile 2 of each window): slots 18..23 of the core's [B][32] block
 };
 
 template <bool PIPE>
@@ -300,6 +301,11 @@ __global__ __launch_bounds__(256) void pn_up3_kernel(const Up3Args a) {
   const int tile = blockIdx.x, win = blockIdx.y;
   const int t0 = tile * TT, o1 = t0 / 4 - 4, o0 = t0 - 16;
   constexpr int NTH = 256, NWV = 4;
+  int stamp = 18;
+#define UP3_STAMP()                                                                                   \
+  if (a.clk && tid == 0 && tile == 2) a.clk[(long)win * 32 + stamp] = __builtin_readcyclecounter(); \
+  ++stamp;
+  UP3_STAMP()
 
   {  // up2.same rows: local1 [0, 144); physical = HALO + o1 + 4q
     const float* src = a.u2s + (long)win * a.ws_u + HALO + o1;
@@ -319,11 +325,13 @@ __global__ __launch_bounds__(256) void pn_up3_kernel(const Up3Args a) {
     }
   }
   __syncthreads();
+  UP3_STAMP()
   {
     ImageStore<U_S0, IB> st{lds + U_UT, 0, U_S0 - IB, -o0, T0 - o0};
     conv_lds<U_T, U_S1, IB, U_S1, IB, PIPE>(lds + U_U2S, lds + U_U2S, a.af_t, a.bs_t, 144, st, wave, NWV, lane);
   }
   __syncthreads();
+  UP3_STAMP()
   if (a.ut_dbg) {
     float* d = a.ut_dbg + (long)win * a.ws_t + HALO;
     for (int i = tid; i < 8 * TT; i += NTH) {
@@ -336,6 +344,7 @@ __global__ __launch_bounds__(256) void pn_up3_kernel(const Up3Args a) {
     conv_lds<U_same, U_S0, IB, U_S0, IB, PIPE>(lds + U_SKIP, lds + U_UT, a.af_same, a.bs_same, TT / 2, st, wave, NWV, lane);
   }
   __syncthreads();
+  UP3_STAMP()
   {  // 1x1 conv (8 -> 3) + softmax over channels, dense output
     float w[3][8], bb[3];
 #pragma unroll
@@ -364,6 +373,195 @@ __global__ __launch_bounds__(256) void pn_up3_kernel(const Up3Args a) {
       }
     }
   }
+  __syncthreads();
+  UP3_STAMP()
+#undef UP3_STAMP
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent forms of the two tiled kernels.  One workgroup walks TPS consecutive tiles of a window:
+// the A fragments of its waves' m-tiles are loaded ONCE into registers (the layers here have K of
+// only 8-32 steps, so an exposed L2 round trip per tile costs as much as the MFMAs), and the next
+// tile's input rows are fetched into registers while the current tile computes.
+// ---------------------------------------------------------------------------------------------
+constexpr int NSPLIT = 2;                       // workgroups per window
+constexpr int N_TILES = (T0 + TT - 1) / TT;     // 6
+constexpr int TPS = (N_TILES + NSPLIT - 1) / NSPLIT;
+
+__global__ __launch_bounds__(256) void pn_down0p_kernel(const Down0Args a) {
+  extern __shared__ float4 lds_raw[];
+  float* lds = reinterpret_cast<float*>(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int win = blockIdx.y;
+  const int tile_lo = blockIdx.x * TPS, tile_hi = (tile_lo + TPS < N_TILES) ? tile_lo + TPS : N_TILES;
+  constexpr int NTH = 256;
+  constexpr int NQ = (TT + 28) / 4;  // float4 per x row
+  float aI[D_inc::CB * D_inc::TAPS], aS[D_same::CB * D_same::TAPS], aD[D_down::CB * D_down::TAPS];
+  float bI[4], bS[4], bD[4];
+  load_areg<D_inc>(a.af_inc, 0, lane, aI);
+  load_areg<D_same>(a.af_same, 0, lane, aS);
+  load_areg<D_down>(a.af_down, 0, lane, aD);
+  load_biasreg<D_inc>(a.bs_inc, 0, lane, bI);
+  load_biasreg<D_same>(a.bs_same, 0, lane, bS);
+  load_biasreg<D_down>(a.bs_down, 0, lane, bD);
+  for (int i = tid; i < D0_S / 4; i += NTH)  // 4th (padding) input channel: true zeros, written once
+    *reinterpret_cast<float4*>(lds + D0_X + 3 * D0_S + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  const float* xsrc = a.x + (long)win * a.ws_x;
+  float4 px[2];  // 3 rows x NQ float4 = 405 <= 2 * 256
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + k * NTH;
+      px[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < 3 * NQ) {
+        const int c = i / NQ, q = i - c * NQ;
+        const int p = tile * TT - 8 + 4 * q;  // physical index of local -4 + 4q
+        if (p >= 0 && p + 3 < a.ls_x) px[k] = *reinterpret_cast<const float4*>(xsrc + (long)c * a.ls_x + p);
+      }
+    }
+  };
+  fetch(tile_lo);
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int t0 = tile * TT, o = t0 - 12;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + k * NTH;
+      if (i < 3 * NQ) {
+        const int c = i / NQ, q = i - c * NQ;
+        *reinterpret_cast<float4*>(lds + D0_X + c * D0_S + 4 * q) = px[k];
+      }
+    }
+    __syncthreads();
+    if (tile + 1 < tile_hi) fetch(tile + 1);
+    const int sig_lo = -o, sig_hi = T0 - o;
+    {
+      ImageStore<D0_S, IB> st{lds + D0_H, 0, TT + 16, sig_lo, sig_hi};
+      conv_lds_areg<D_inc, D0_S, IB, D0_S, IB>(lds + D0_X, lds + D0_X, aI, bI, 0, (TT + 16) / 2, st, wave, 4, lane);
+    }
+    __syncthreads();
+    {
+      ImageStore<D0_S, IB> st{lds + D0_K, 0, TT + 16, sig_lo, sig_hi};
+      conv_lds_areg<D_same, D0_S, IB, D0_S, IB>(lds + D0_H, lds + D0_H, aS, bS, 0, (TT + 16) / 2, st, wave, 4, lane);
+    }
+    __syncthreads();
+    {  // skip tensor rows [t0, t0 + TT) -> memory, 16-byte coalesced (local 12 <-> column 16)
+      float* d = a.skip0 + (long)win * a.ws_s + HALO + t0;
+      for (int i = tid; i < 8 * (TT / 4); i += NTH) {
+        const int c = i / (TT / 4), q = i - c * (TT / 4);
+        if (t0 + 4 * q < T0)
+          *reinterpret_cast<float4*>(d + (long)c * a.ls_s + 4 * q) =
+              *reinterpret_cast<const float4*>(lds + D0_K + c * D0_S + IB + 12 + 4 * q);  // zeros beyond the signal
+      }
+    }
+    {
+      GlobalRowStore st{a.d0 + (long)win * a.ws_d + HALO, a.ls_d, T1, tile * (TT / 4)};
+      conv_lds_areg<D_down, D0_S, IB, D0_S, IB>(lds + D0_K, lds + D0_K, aD, bD, 0, TT / 8, st, wave, 4, lane);
+    }
+    // no barrier needed here: the next iteration's first barrier orders these reads before any rewrite
+    // of the skip image (written after two more barriers); X is rewritten now, but its last reader (inc)
+    // finished two barriers ago.
+  }
+}
+
+__global__ __launch_bounds__(256) void pn_up3p_kernel(const Up3Args a) {
+  extern __shared__ float4 lds_raw[];
+  float* lds = reinterpret_cast<float*>(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int win = blockIdx.y;
+  const int tile_lo = blockIdx.x * TPS, tile_hi = (tile_lo + TPS < N_TILES) ? tile_lo + TPS : N_TILES;
+  constexpr int NTH = 256;
+  float aT[U_T::CB * U_T::TAPS], aS[U_same::CB * U_same::TAPS], bT[4], bS[4];
+  const int mtT = wave & 1;  // up3.convT: M = 32 -> two m-tiles; waves (0,2) take m-tile 0, (1,3) m-tile 1
+  load_areg<U_T>(a.af_t, mtT, lane, aT);
+  load_biasreg<U_T>(a.bs_t, mtT, lane, bT);
+  load_areg<U_same>(a.af_same, 0, lane, aS);
+  load_biasreg<U_same>(a.bs_same, 0, lane, bS);
+  float w[3][8], bb[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    bb[c] = a.b_out[c];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[c][k] = a.w_out[c * 8 + k];
+  }
+  if (tid < 16) *reinterpret_cast<float4*>(lds + U_U2S + tid * U_S1) = make_float4(0.f, 0.f, 0.f, 0.f);  // local1 -4..-1
+
+  const float* usrc = a.u2s + (long)win * a.ws_u + HALO;
+  const float* ssrc = a.skip0 + (long)win * a.ws_s + HALO;
+  float4 pu[3], ps[5];  // 16 x 36 = 576 and 8 x 130 = 1040 float4
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
+    const int o1 = tile * (TT / 4) - 4, o0 = tile * TT - 16;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int i = tid + k * NTH;
+      pu[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < 16 * 36) {
+        const int c = i / 36, q = i - c * 36;
+        pu[k] = *reinterpret_cast<const float4*>(usrc + o1 + (long)c * a.ls_u + 4 * q);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int i = tid + k * NTH;
+      ps[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < 8 * 130) {
+        const int c = i / 130, q = i - c * 130;
+        ps[k] = *reinterpret_cast<const float4*>(ssrc + o0 + 12 + (long)c * a.ls_s + 4 * q);
+      }
+    }
+  };
+  fetch(tile_lo);
+  for (int tile = tile_lo; tile < tile_hi; ++tile) {
+    const int t0 = tile * TT, o0 = t0 - 16;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int i = tid + k * NTH;
+      if (i < 16 * 36) {
+        const int c = i / 36, q = i - c * 36;
+        *reinterpret_cast<float4*>(lds + U_U2S + c * U_S1 + IB + 4 * q) = pu[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int i = tid + k * NTH;
+      if (i < 8 * 130) {
+        const int c = i / 130, q = i - c * 130;
+        *reinterpret_cast<float4*>(lds + U_SKIP + c * U_S0 + IB + 12 + 4 * q) = ps[k];
+      }
+    }
+    __syncthreads();
+    if (tile + 1 < tile_hi) fetch(tile + 1);
+    {
+      ImageStore<U_S0, IB> st{lds + U_UT, 0, U_S0 - IB, -o0, T0 - o0};
+      conv_lds_areg<U_T, U_S1, IB, U_S1, IB>(lds + U_U2S, lds + U_U2S, aT, bT, mtT, 144, st, wave >> 1, 2, lane);
+    }
+    __syncthreads();
+    {
+      ImageStore<U_SO, 0> st{lds + U_OUT, 0, TT, 0, TT};
+      conv_lds_areg<U_same, U_S0, IB, U_S0, IB>(lds + U_SKIP, lds + U_UT, aS, bS, 0, TT / 2, st, wave, 4, lane);
+    }
+    __syncthreads();
+    float* y = a.y + (long)win * 3 * T0;
+    for (int l = tid; l < TT; l += NTH) {  // 1x1 conv (8 -> 3) + softmax over channels
+      const int t = t0 + l;
+      if (t < T0) {
+        float z[3] = {bb[0], bb[1], bb[2]};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float v = lds[U_OUT + k * U_SO + l];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) z[c] = fmaf(w[c][k], v, z[c]);
+        }
+        const float mx = fmaxf(z[0], fmaxf(z[1], z[2]));
+        const float e0 = __expf(z[0] - mx), e1 = __expf(z[1] - mx), e2 = __expf(z[2] - mx);
+        const float inv = 1.f / (e0 + e1 + e2);
+        y[t] = e0 * inv;
+        y[T0 + t] = e1 * inv;
+        y[2 * T0 + t] = e2 * inv;
+      }
+    }
+    // the next iteration's first barrier orders this read of the staged tile before its rewrite
+  }
 }
 
 int tensor_id(const Net& net, const std::string& name) {
@@ -381,6 +579,7 @@ int plan_phasenet_fused(Net& net, int debug_flags) {
   // reserved[2] = 1 selects the hand-pipelined K loop (sched_barrier) for A/B timing; the compiler's own
   // schedule measured 0-5 % faster on every layer (tools/micro/micro_layers.hip), so it is the default.
   const bool pipe = net.cfg.reserved[2] == 1;
+  const bool persistent = net.cfg.reserved[3] != 1;  // reserved[3] = 1: one workgroup per tile (A/B timing)
   if (net.convs.size() != 18) {
     set_error("fused PhaseNet plan expects the 18-layer plan");
     return VP_ERR_INVALID;
@@ -425,7 +624,9 @@ int plan_phasenet_fused(Net& net, int debug_flags) {
       a.bs_same = n.convs[1]->bias.d;
       a.af_down = n.convs[2]->afrag.d;
       a.bs_down = n.convs[2]->bias.d;
-      if (pipe) {
+      if (persistent && !debug_dumps) {
+        hipLaunchKernelGGL(pn_down0p_kernel, dim3(NSPLIT, B), dim3(256), D0_LDS_FLOATS * sizeof(float), s, a);
+      } else if (pipe) {
         hipLaunchKernelGGL(pn_down0_kernel<true>, dim3(n_tiles, B), dim3(256), D0_LDS_FLOATS * sizeof(float), s, a);
       } else {
         hipLaunchKernelGGL(pn_down0_kernel<false>, dim3(n_tiles, B), dim3(256), D0_LDS_FLOATS * sizeof(float), s, a);
@@ -502,7 +703,10 @@ int plan_phasenet_fused(Net& net, int debug_flags) {
       a.bs_same = n.convs[17]->bias.d;
       a.w_out = e0->d;
       a.b_out = e1->d;
-      if (pipe) {
+      a.clk = n.debug_clock ? reinterpret_cast<unsigned long long*>(n.debug_clock->d) : nullptr;
+      if (persistent && !debug_dumps) {
+        hipLaunchKernelGGL(pn_up3p_kernel, dim3(NSPLIT, B), dim3(256), UP3_LDS_FLOATS * sizeof(float), s, a);
+      } else if (pipe) {
         hipLaunchKernelGGL(pn_up3_kernel<true>, dim3(n_tiles, B), dim3(256), UP3_LDS_FLOATS * sizeof(float), s, a);
       } else {
         hipLaunchKernelGGL(pn_up3_kernel<false>, dim3(n_tiles, B), dim3(256), UP3_LDS_FLOATS * sizeof(float), s, a);
@@ -518,6 +722,8 @@ int plan_phasenet_fused(Net& net, int debug_flags) {
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_down0_kernel<false>), D0_LDS_FLOATS * sizeof(float)});
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_up3_kernel<true>), UP3_LDS_FLOATS * sizeof(float)});
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_up3_kernel<false>), UP3_LDS_FLOATS * sizeof(float)});
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_down0p_kernel), D0_LDS_FLOATS * sizeof(float)});
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_up3p_kernel), UP3_LDS_FLOATS * sizeof(float)});
   return VP_OK;
 }
 
