@@ -384,16 +384,16 @@ __global__ __launch_bounds__(256) void pn_up3_kernel(const Up3Args a) {
 // only 8-32 steps, so an exposed L2 round trip per tile costs as much as the MFMAs), and the next
 // tile's input rows are fetched into registers while the current tile computes.
 // ---------------------------------------------------------------------------------------------
-constexpr int NSPLIT = 2;                       // workgroups per window
 constexpr int N_TILES = (T0 + TT - 1) / TT;     // 6
-constexpr int TPS = (N_TILES + NSPLIT - 1) / NSPLIT;
+constexpr int NSPLIT_D = 3, TPS_D = (N_TILES + NSPLIT_D - 1) / NSPLIT_D;  // down0: 45 KB LDS -> 3 workgroups / CU
+constexpr int NSPLIT_U = 2, TPS_U = (N_TILES + NSPLIT_U - 1) / NSPLIT_U;  // up3:   66 KB LDS -> 2 workgroups / CU
 
 __global__ __launch_bounds__(256) void pn_down0p_kernel(const Down0Args a) {
   extern __shared__ float4 lds_raw[];
   float* lds = reinterpret_cast<float*>(lds_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int win = blockIdx.y;
-  const int tile_lo = blockIdx.x * TPS, tile_hi = (tile_lo + TPS < N_TILES) ? tile_lo + TPS : N_TILES;
+  const int tile_lo = blockIdx.x * TPS_D, tile_hi = (tile_lo + TPS_D < N_TILES) ? tile_lo + TPS_D : N_TILES;
   constexpr int NTH = 256;
   constexpr int NQ = (TT + 28) / 4;  // float4 per x row
   float aI[D_inc::CB * D_inc::TAPS], aS[D_same::CB * D_same::TAPS], aD[D_down::CB * D_down::TAPS];
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void pn_up3p_kernel(const Up3Args a) {
   float* lds = reinterpret_cast<float*>(lds_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int win = blockIdx.y;
-  const int tile_lo = blockIdx.x * TPS, tile_hi = (tile_lo + TPS < N_TILES) ? tile_lo + TPS : N_TILES;
+  const int tile_lo = blockIdx.x * TPS_U, tile_hi = (tile_lo + TPS_U < N_TILES) ? tile_lo + TPS_U : N_TILES;
   constexpr int NTH = 256;
   float aT[U_T::CB * U_T::TAPS], aS[U_same::CB * U_same::TAPS], bT[4], bS[4];
   const int mtT = wave & 1;  // up3.convT: M = 32 -> two m-tiles; waves (0,2) take m-tile 0, (1,3) m-tile 1
@@ -579,7 +579,8 @@ int plan_phasenet_fused(Net& net, int debug_flags) {
   // reserved[2] = 1 selects the hand-pipelined K loop (sched_barrier) for A/B timing; the compiler's own
   // schedule measured 0-5 % faster on every layer (tools/micro/micro_layers.hip), so it is the default.
   const bool pipe = net.cfg.reserved[2] == 1;
-  const bool persistent = net.cfg.reserved[3] != 1;  // reserved[3] = 1: one workgroup per tile (A/B timing)
+  const bool persistent = net.cfg.reserved[3] != 1;  // reserved[3] = 1: one workgroup per tile for up3 too (A/B timing)
+  const bool down0_persistent = net.cfg.reserved[3] == 2;
   if (net.convs.size() != 18) {
     set_error("fused PhaseNet plan expects the 18-layer plan");
     return VP_ERR_INVALID;
@@ -624,8 +625,10 @@ int plan_phasenet_fused(Net& net, int debug_flags) {
       a.bs_same = n.convs[1]->bias.d;
       a.af_down = n.convs[2]->afrag.d;
       a.bs_down = n.convs[2]->bias.d;
-      if (persistent && !debug_dumps) {
-        hipLaunchKernelGGL(pn_down0p_kernel, dim3(NSPLIT, B), dim3(256), D0_LDS_FLOATS * sizeof(float), s, a);
+      // measured (tools/ab_steps.py, one process): the persistent form is 4-15 % SLOWER here (its 46
+      // A registers cost occupancy and one-tile workgroups already stagger well); reserved[3] = 2 selects it
+      if (down0_persistent && !debug_dumps) {
+        hipLaunchKernelGGL(pn_down0p_kernel, dim3(NSPLIT_D, B), dim3(256), D0_LDS_FLOATS * sizeof(float), s, a);
       } else if (pipe) {
         hipLaunchKernelGGL(pn_down0_kernel<true>, dim3(n_tiles, B), dim3(256), D0_LDS_FLOATS * sizeof(float), s, a);
       } else {
@@ -705,7 +708,7 @@ int plan_phasenet_fused(Net& net, int debug_flags) {
       a.b_out = e1->d;
       a.clk = n.debug_clock ? reinterpret_cast<unsigned long long*>(n.debug_clock->d) : nullptr;
       if (persistent && !debug_dumps) {
-        hipLaunchKernelGGL(pn_up3p_kernel, dim3(NSPLIT, B), dim3(256), UP3_LDS_FLOATS * sizeof(float), s, a);
+        hipLaunchKernelGGL(pn_up3p_kernel, dim3(NSPLIT_U, B), dim3(256), UP3_LDS_FLOATS * sizeof(float), s, a);
       } else if (pipe) {
         hipLaunchKernelGGL(pn_up3_kernel<true>, dim3(n_tiles, B), dim3(256), UP3_LDS_FLOATS * sizeof(float), s, a);
       } else {
