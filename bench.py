@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--contexts", type=int, default=2, help="device contexts (stream + workspace) steps alternate over")
     args = ap.parse_args()
 
     import torch
@@ -100,7 +101,7 @@ def main():
     # Two device contexts (HIP stream + workspace each), two submits in flight per context: the host
     # enqueues ahead of the GPU, and one context's latency-bound stages (LSTM/attention, small tail
     # kernels) overlap the other's MFMA-bound ones.  Every step is still one full pass over one batch.
-    NCTX, DEPTH = 2, 2
+    NCTX, DEPTH = max(1, args.contexts), 2
     ctxs = [model._context(k) for k in range(NCTX)]
     outs = [out] + [torch.empty_like(out) for _ in range(NCTX - 1)]
 
@@ -201,7 +202,7 @@ def main():
             "peak": PEAK_FP32_TFLOPS,
             "unit": "TFLOP/s",
             "frac": dom_tflops / PEAK_FP32_TFLOPS,
-            "traffic": None,
+            "traffic": traffic_bytes(args.model, dom["name"]),
             "kernel_ms": dom["ms"],
         },
         "forward": {
@@ -224,6 +225,19 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def traffic_bytes(model_name, step_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
+    MI355X_MICROARCH.md; separate --pmc runs of tools/run_forward.py on this build), else None."""
+    f = ROOT / "profiles" / "r01_traffic.json"
+    if not f.exists():
+        return None
+    try:
+        return json.loads(f.read_text()).get(model_name, {}).get(step_name)
+    except (ValueError, OSError):
+        return None
 
 
 def cpu_baseline(model_name, data, overlap, blinding, batch, budget_s):
