@@ -49,8 +49,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # under torch.distributed.run (RANK set) the RCCL path is exercised even for one rank
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", str(world))
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
@@ -67,7 +72,7 @@ def main():
     model = cls.from_pretrained("volpick")
     model._max_batch = args.batch
     t_bcast = 0.0
-    if world > 1:
+    if use_dist:
         if rank != 0:
             model._weights = np.zeros_like(model._weights)  # only rank 0's copy is real
         torch.cuda.synchronize()
@@ -132,7 +137,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -143,7 +148,7 @@ def main():
     n_picks = run_steps(args.steps)
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -222,7 +227,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args.model, data, overlap, blinding, args.batch, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
