@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--contexts", type=int, default=2, help="device contexts (stream + workspace) steps alternate over")
+    ap.add_argument("--contexts", type=int, default=3, help="device contexts (stream + workspace) steps alternate over")
     args = ap.parse_args()
 
     import torch
@@ -103,7 +103,8 @@ def main():
     found = C.c_int()
     fv, lv, nw = C.c_int64(), C.c_int64(), C.c_int64()
 
-    # Two device contexts (HIP stream + workspace each), two submits in flight per context: the host
+    # Three device contexts (HIP stream + workspace each; 3 measured best, 4+ share hardware queues), two
+    # submits in flight per context: the host
     # enqueues ahead of the GPU, and one context's latency-bound stages (LSTM/attention, small tail
     # kernels) overlap the other's MFMA-bound ones.  Every step is still one full pass over one batch.
     NCTX, DEPTH = max(1, args.contexts), 2

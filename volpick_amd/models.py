@@ -69,7 +69,7 @@ class WaveformModel:
         self._weights = None  # flat fp32 blob in the library's canonical order
         self._handle = None
         self._extra_handles = []
-        self.n_contexts = 2  # device contexts classify() pipelines station blocks over
+        self.n_contexts = 3  # device contexts classify() pipelines station blocks over (3 measured best: 4+ share HW queues)
         self._device_index = None
         self._max_batch = 256
         self._plan_flags = (0, 0)  # vp_config.reserved[0:2]: (layer-by-layer plan, dump fused intermediates)
