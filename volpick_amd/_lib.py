@@ -106,6 +106,7 @@ SIGNATURES = {
          C.c_void_p, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     ),
     "vp_debug_core_clock": (C.c_int, [_H, C.c_int, C.c_void_p]),
+    "vp_debug_conv_clock": (C.c_int, [_H, C.c_void_p, C.c_int]),
     "vp_last_error": (C.c_char_p, []),
     "vp_version": (C.c_char_p, []),
 }

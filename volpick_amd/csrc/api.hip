@@ -641,6 +641,18 @@ int vp_debug_tensor_read(vp_handle* h, int index, int B, float* host_out) {
 }
 
 // Debug: per-window shader-clock stamps of the fused PhaseNet core kernel (plan flag reserved[1]).
+// Debug: 8 stamps per conv launch (workgroup tile 1 / window 7): start, loaded, mfma done, staged, stored.
+int vp_debug_conv_clock(vp_handle* h, unsigned long long* out, int max_layers) {
+  VP_REQUIRE(h && out && h->net.debug_clock && h->net.debug_clock->d, "no clock stamps (create with reserved[1] & 2)");
+  VP_HIP(hipSetDevice(h->device));
+  VP_HIP(hipStreamSynchronize(h->stream));
+  const int n = std::min<int>(max_layers, 64);
+  const unsigned long long* src =
+      reinterpret_cast<const unsigned long long*>(h->net.debug_clock->d) + (size_t)h->net.max_batch * 32;
+  VP_HIP(hipMemcpy(out, src, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return (int)h->net.convs.size();
+}
+
 int vp_debug_core_clock(vp_handle* h, int B, unsigned long long* out32) {
   VP_REQUIRE(h && out32 && h->net.debug_clock && h->net.debug_clock->d, "no clock stamps (create with reserved[1]=1)");
   VP_HIP(hipSetDevice(h->device));

@@ -61,6 +61,7 @@ struct ConvArgs {
   long e_set_stride;  // per-set stride of e1/e2
   int ls_res;         // EPI_RES: geometry of the residual tensor
   long ws_res;
+  unsigned long long* clk;  // debug: 8 shader-clock stamps of workgroup (tile 1, window 7): start, loaded, mfma done, staged, stored
 };
 
 struct ConvGeom {  // runtime mirror of the template parameters (planning / packing / tests)
@@ -117,24 +118,48 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   // EPI_HEAD tiles advance by TN-8 columns and start 4 columns early (halo of the fused head conv)
   const int col0 = (C::EPI == EPI_HEAD) ? (int)blockIdx.x * (C::TN - 8) - 4 : (int)blockIdx.x * C::TN;
   const int set = win / a.win_per_set;
+  int stamp_i = 0;
+#define CONV_STAMP()                                                                                      \
+  if (a.clk && tid == 0 && blockIdx.x == 1 && win == 7) a.clk[stamp_i] = __builtin_readcyclecounter(); \
+  ++stamp_i;
+  CONV_STAMP()
 
   // ---- stage the input tile: CINP rows x 4*W4 floats, aligned 16-byte loads --------------
   {
     const int a0 = HALO + C::SN * col0 + C::IN_OFF_F4;  // multiple of 4 by construction
     const float* s1 = a.src1 + (long)win * a.ws1 + a0;
     const float* s2 = (C::CIN2 > 0) ? a.src2 + (long)win * a.ws2 + a0 : nullptr;
-    for (int idx = tid; idx < C::CINP * C::W4; idx += 256) {
-      const int c = idx / C::W4, q = idx - c * C::W4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < C::CIN1) {
-        v = *reinterpret_cast<const float4*>(s1 + (long)c * a.ls1 + 4 * q);
-      } else if (c < C::CIN) {
-        v = *reinterpret_cast<const float4*>(s2 + (long)(c - C::CIN1) * a.ls2 + 4 * q);
+    // All of a thread's loads are issued before its first LDS write (chunks of 8 x 16 B in flight):
+    // the rolled form serialised load -> wait -> ds_write and cost 5-17k cycles of pure latency per tile.
+    constexpr int TOT = C::CINP * C::W4, N_IT = (TOT + 255) / 256, CH = 8;
+#pragma unroll
+    for (int it0 = 0; it0 < N_IT; it0 += CH) {
+      float4 v[CH];
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int idx = tid + (it0 + k) * 256;
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (it0 + k < N_IT && idx < TOT) {
+          const int c = idx / C::W4, q = idx - c * C::W4;
+          if (c < C::CIN1) {
+            v[k] = *reinterpret_cast<const float4*>(s1 + (long)c * a.ls1 + 4 * q);
+          } else if (c < C::CIN) {
+            v[k] = *reinterpret_cast<const float4*>(s2 + (long)(c - C::CIN1) * a.ls2 + 4 * q);
+          }
+        }
       }
-      *reinterpret_cast<float4*>(lds + c * C::S + 4 * q) = v;
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int idx = tid + (it0 + k) * 256;
+        if (it0 + k < N_IT && idx < TOT) {
+          const int c = idx / C::W4, q = idx - c * C::W4;
+          *reinterpret_cast<float4*>(lds + c * C::S + 4 * q) = v[k];
+        }
+      }
     }
   }
   __syncthreads();
+  CONV_STAMP()
 
   // ---- MFMA main loop ---------------------------------------------------------------
   const int wm = wave % C::WAVES_M, wn = wave / C::WAVES_M;
@@ -163,6 +188,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     }
   }
   __syncthreads();  // all B reads done; the LDS image is reused as the output staging tile
+  CONV_STAMP()
 
   // ---- epilogue 1: bias (+ReLU), D fragments -> LDS [COUT][OS] ----------------------
   {
@@ -188,6 +214,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     }
   }
   __syncthreads();
+  CONV_STAMP()
 
   // ---- epilogue 2: coalesced stores of the staged tile -----------------------------
   const int t0 = C::P * col0 + C::OUT_OFF;  // global output index of staged column 0
@@ -324,6 +351,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       }
     }
   }
+  __syncthreads();
+  CONV_STAMP()
+#undef CONV_STAMP
 }
 
 template <class C>

@@ -369,6 +369,8 @@ int plan_eqt(Net& net, const ParamView& pv) {
 
   net.flops_per_window = 0;
   for (auto& s : net.steps) net.flops_per_window += s.flops_per_window;
+  if (net.cfg.reserved[1] & 2)  // debug clock stamps of every conv launch (tools/conv_clock.py)
+    net.debug_clock = net.add_blob(std::vector<float>(((size_t)net.max_batch * 32 + 64 * 8) * 2, 0.f));
   // reserved[0] = 1 keeps the 14 ResCNN conv launches (layer-by-layer debug / A-B plan)
   if (net.cfg.reserved[0] != 1) {
     int rc = plan_eqt_fuse_res(net);

@@ -133,6 +133,14 @@ void Net::add_conv_step(ConvLayer* L) {
     a.e1 = L->e1.d;
     a.e2 = L->e2.d;
     a.e_set_stride = L->e1.h.empty() ? 0 : (long)(L->e1.h.size() / L->n_sets);
+    if (net.debug_clock && net.debug_clock->d) {
+      int li = 0;
+      for (auto& c : net.convs) {
+        if (c.get() == L) break;
+        ++li;
+      }
+      a.clk = reinterpret_cast<unsigned long long*>(net.debug_clock->d) + (size_t)net.max_batch * 32 + (size_t)li * 8;
+    }
     return L->launch(a, L->cols, stream);
   };
   s.flops_per_window = L->flops_per_window;

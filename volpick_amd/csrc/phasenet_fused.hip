@@ -646,7 +646,7 @@ int plan_phasenet_fused(Net& net, int debug_flags) {
                                         "down4.same", "up0.convT",  "up0.same",   "up1.convT",  "up1.same",   "up2.convT"};
     std::vector<int> dbg_ids(12);
     for (int i = 0; i < 12; ++i) dbg_ids[i] = tensor_id(net, dbg_names[i]);
-    HostBlob* clk = debug_clock ? net.add_blob(std::vector<float>((size_t)net.max_batch * 32 * 2, 0.f)) : nullptr;
+    HostBlob* clk = debug_clock ? net.add_blob(std::vector<float>(((size_t)net.max_batch * 32 + 64 * 8) * 2, 0.f)) : nullptr;
     net.debug_clock = clk;
     st.run = [=](Net& n, int B, hipStream_t s) -> int {
       CoreArgs a{};
