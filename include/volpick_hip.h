@@ -138,6 +138,16 @@ int vp_classify_collect(vp_handle* h, int slot, int64_t* first_valid, int64_t* l
                         int64_t* on, int64_t* off, int64_t* peak, float* value, int32_t* spec_of, int cap,
                         int* n_found);
 
+/* Replaces the per-sample loop of the reference's own evaluation protocol
+ * (volpick/model/eval_taks0.py:46-56,96-142: get_picks_from_prob on window_borders slices).
+ * prob: (B, n_rows, T) model outputs; for window b the samples [lo[b], hi[b]) of channel `row`
+ * are scanned (lo/hi NULL = whole window).  Per window up to K triggers are returned, unordered:
+ * peak[b*K + i] = argmax index relative to lo[b], value[b*K + i] = the maximum; count[b] is the
+ * number found (may exceed K).  The reference calls this with thr_off = thr_on / 2. */
+int vp_pick_windows(vp_handle* h, const float* prob, int prob_mem, int B, int n_rows, int row, const int32_t* lo,
+                    const int32_t* hi, float thr_on, float thr_off, int K, int32_t* count, int32_t* peak,
+                    float* value);
+
 /* Host-only variant of vp_pick for traces already in host memory (no handle, no GPU). */
 int vp_pick_host(const float* trace, int64_t n, float thr_on, float thr_off, int64_t* on, int64_t* off,
                  int64_t* peak, float* value, int cap, int* n_found);

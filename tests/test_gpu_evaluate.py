@@ -1,0 +1,51 @@
+"""GPU: the reference's window-level evaluation protocol (eval_taks0.py:20-200) on the HIP path."""
+import numpy as np
+import pytest
+import torch
+
+import volpick_amd as va
+from oracle import pipeline as OP
+from oracle.models import load_pretrained
+from volpick_amd.evaluate import evaluate_windows
+from volpick_amd.synthetic import synthetic_windows
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,T", [("phasenet", 3001), ("eqtransformer", 6000)])
+def test_evaluate_windows_matches_reference_protocol(name, T):
+    cls = va.PhaseNet if name == "phasenet" else va.EQTransformer
+    model = cls.from_pretrained("volpick").cuda()
+    oracle = load_pretrained(name)
+    oracle.norm_amp_per_comp = True  # the evaluation generator normalises per component (eval_taks0.py:465-467)
+    n = 37
+    x = synthetic_windows(n, T, seed=5)
+    xn = x - x.mean(-1, keepdims=True)
+    xn = (xn / (np.abs(xn).max(-1, keepdims=True) + 1e-10)).astype(np.float32)
+    rng = np.random.default_rng(0)
+    borders = np.stack([rng.integers(0, 400, n), rng.integers(T - 600, T + 1, n)], 1)
+    borders[0] = (0, T)
+    thr = [0.39, 0.34] if name == "phasenet" else [0.22, 0.25]
+    got = evaluate_windows(model, xn, borders, threshold=thr, batch_size=16)
+    # expected: get_picks_from_prob (trigger_onset(prob, thr, thr / 2) + max / argmax) on the SAME probabilities
+    y = model._forward_raw(xn)
+    rows = (model.labels.index("P"), model.labels.index("S")) if name == "phasenet" else (1, 2)
+    for i in range(n):
+        s, e = borders[i]
+        for k, (row, t) in enumerate(zip(rows, thr)):
+            want = OP.picks_from_trace(y[i, row, s:e], t, t / 2)
+            assert got[2 * k][i].tolist() == [w[2] for w in want], (i, k)
+            assert np.allclose(got[2 * k + 1][i], [w[3] for w in want])
+    # and against the oracle's own probabilities: same picks within one sample wherever both see a trigger
+    with torch.no_grad():
+        yo = oracle(torch.from_numpy(xn))
+    yo = torch.stack(yo, 1).numpy() if isinstance(yo, tuple) else yo.numpy()
+    n_same = n_tot = 0
+    for i in range(n):
+        s, e = borders[i]
+        want = OP.picks_from_trace(yo[i, rows[0], s:e], thr[0], thr[0] / 2)
+        n_tot += 1
+        n_same += [w[2] for w in want] == got[0][i].tolist() or (
+            len(want) == len(got[0][i]) and all(abs(w[2] - g) <= 1 for w, g in zip(want, got[0][i])))
+    assert n_same >= n_tot - 1
+    assert len(got) == 4 and all(len(g) == n for g in got)

@@ -568,6 +568,57 @@ int vp_pick(vp_handle* h, const float* trace, int trace_mem, int64_t n, float th
   return scan_collect(sl, on, off, peak, value, nullptr, cap, n_found);
 }
 
+// Replaces the per-sample Python loop of the reference's evaluate() (eval_taks0.py:96-142).
+int vp_pick_windows(vp_handle* h, const float* prob, int prob_mem, int B, int n_rows, int row, const int32_t* lo,
+                    const int32_t* hi, float thr_on, float thr_off, int K, int32_t* count, int32_t* peak,
+                    float* value) {
+  VP_REQUIRE(h && prob && count && peak && value, "null argument");
+  VP_REQUIRE(B > 0 && K > 0 && n_rows > 0 && row >= 0 && row < n_rows, "bad shape arguments");
+  VP_REQUIRE(thr_off <= thr_on, "thr_off must not exceed thr_on");
+  VP_HIP(hipSetDevice(h->device));
+  const int T = h->net.in_samples;
+  const size_t n_prob = (size_t)B * n_rows * T;
+  // scratch layout (floats): [prob copy if host][lo B][hi B][count B][peak B*K][value B*K]
+  const size_t need = (prob_mem == VP_MEM_HOST ? n_prob : 0) + (size_t)B * 3 + (size_t)B * K * 2 + 64;
+  int rc = grow(&h->d_in, &h->d_in_cap, std::max(need, (size_t)h->net.max_batch * 3 * T));
+  if (rc != VP_OK) return rc;
+  float* p = h->d_in;
+  const float* d_prob = prob;
+  if (prob_mem == VP_MEM_HOST) {
+    VP_HIP(hipMemcpyAsync(p, prob, n_prob * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    d_prob = p;
+    p += n_prob;
+  }
+  int* d_lo = reinterpret_cast<int*>(p);
+  int* d_hi = d_lo + B;
+  int* d_count = d_hi + B;
+  int* d_peak = d_count + B;
+  float* d_value = reinterpret_cast<float*>(d_peak + (size_t)B * K);
+  if (lo) VP_HIP(hipMemcpyAsync(d_lo, lo, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (hi) VP_HIP(hipMemcpyAsync(d_hi, hi, B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  vp::WindowPickArgs a{};
+  a.prob = d_prob;
+  a.B = B;
+  a.n_rows = n_rows;
+  a.T = T;
+  a.row = row;
+  a.lo = lo ? d_lo : nullptr;
+  a.hi = hi ? d_hi : nullptr;
+  a.thr_on = thr_on;
+  a.thr_off = thr_off;
+  a.K = K;
+  a.count = d_count;
+  a.peak = d_peak;
+  a.value = d_value;
+  VP_HIP(hipMemsetAsync(d_count, 0, B * sizeof(int), h->stream));
+  vp::launch_window_pick(a, h->stream);
+  VP_HIP(hipMemcpyAsync(count, d_count, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  VP_HIP(hipMemcpyAsync(peak, d_peak, (size_t)B * K * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  VP_HIP(hipMemcpyAsync(value, d_value, (size_t)B * K * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  VP_HIP(hipStreamSynchronize(h->stream));
+  return VP_OK;
+}
+
 int vp_set_timing(vp_handle* h, int enable) {
   VP_REQUIRE(h != nullptr, "null handle");
   h->timing = enable != 0;

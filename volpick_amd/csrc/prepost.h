@@ -50,6 +50,18 @@ struct PickBatch {
   int n;
 };
 int launch_pick(const PickBatch& b, hipStream_t stream);
+struct WindowPickArgs {
+  const float* prob;  // [B][n_rows][T]
+  int B, n_rows, T, row;
+  const int* lo;      // per-window borders (may be null: whole window)
+  const int* hi;
+  float thr_on, thr_off;
+  int K;              // slots per window
+  int* count;         // [B] triggers found (may exceed K)
+  int* peak;          // [B][K] peak index relative to lo
+  float* value;       // [B][K]
+};
+int launch_window_pick(const WindowPickArgs& a, hipStream_t stream);
 int launch_publish(char* dev, char* host, int n_specs, int cap, long header, long per_spec, hipStream_t stream);
 int pick_host(const float* x, int64_t n, float thr_on, float thr_off, int64_t* on, int64_t* off, int64_t* peak,
               float* value, int cap, int* n_found);

@@ -330,3 +330,54 @@ int pick_host(const float* x, int64_t n, float thr_on, float thr_off, int64_t* o
 }
 
 }  // namespace vp
+
+namespace vp {
+
+// ---------------------------------------------------------------------------------------
+// Per-window trigger/peak extraction on pre-cut windows (the reference's own evaluation
+// protocol, volpick/model/eval_taks0.py:46-56,96-142): for window b, channel `row`, samples
+// [lo_b, hi_b): trigger_onset(prob, thr_on, thr_off) and per trigger max / first argmax.
+// One wavefront per window; lane l scans the l-th 1/64 of the range for run ENDS, walks each
+// run backwards (bounded by lo_b) and appends (peak index relative to lo_b, value) to the
+// window's slot list.  Lists are unordered; the host sorts the few entries per window.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void window_pick_kernel(const WindowPickArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  const float* x = a.prob + ((long)b * a.n_rows + a.row) * a.T;
+  int lo = a.lo ? a.lo[b] : 0, hi = a.hi ? a.hi[b] : a.T;
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > a.T ? a.T : hi;
+  const int len = hi - lo;
+  if (len <= 0) return;  // counts are zeroed by the caller (hipMemsetAsync) before the launch
+  const int seg = (len + 63) / 64;
+  const int s0 = lo + lane * seg, s1 = (s0 + seg < hi) ? s0 + seg : hi;
+  for (int t = s0; t < s1; ++t) {
+    if (!(x[t] > a.thr_off)) continue;
+    if (t + 1 < hi && x[t + 1] > a.thr_off) continue;  // not a run end
+    int on = -1;
+    for (int s = t; s >= lo && x[s] > a.thr_off; --s)
+      if (x[s] > a.thr_on) on = s;
+    if (on < 0) continue;
+    float best = x[on];
+    int arg = on;
+    for (int k = on + 1; k <= t; ++k)
+      if (x[k] > best) {
+        best = x[k];
+        arg = k;
+      }
+    const int slot = atomicAdd(&a.count[b], 1);
+    if (slot < a.K) {
+      a.peak[(long)b * a.K + slot] = arg - lo;
+      a.value[(long)b * a.K + slot] = best;
+    }
+  }
+}
+
+int launch_window_pick(const WindowPickArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(window_pick_kernel, dim3((a.B + 3) / 4), dim3(256), 0, stream, a);
+  return 0;
+}
+
+}  // namespace vp
