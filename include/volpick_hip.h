@@ -193,9 +193,13 @@ int vp_debug_tensor_count(const vp_handle* h);
 int vp_debug_tensor_info(const vp_handle* h, int index, const char** name, int* channels, int* length);
 int vp_debug_tensor_read(vp_handle* h, int index, int B, float* host_out);
 
-/* Debug (handles created with reserved[1] & 2): B x 16 shader-clock stamps of the fused PhaseNet
- * core kernel: kernel start, input loaded, then after each of its 13 layers. */
-int vp_debug_core_clock(vp_handle* h, int B, unsigned long long* out16);
+/* Debug (handles created with reserved[1] & 2): B x 32 words per window of the fused PhaseNet core
+ * kernel: [0..14] shader-clock stamps (kernel start, input loaded, after each of the 13 layers),
+ * [16],[17] the 100 MHz wall clock at kernel start / end, [18..22] phase stamps of pn_up3p_kernel. */
+int vp_debug_core_clock(vp_handle* h, int B, unsigned long long* out32);
+/* Same flag: 8 stamps per conv_mfma_kernel launch (in plan order of the conv layers) of one probe
+ * workgroup: start, input staged, MFMA loop done, output staged, stored.  Returns the layer count. */
+int vp_debug_conv_clock(vp_handle* h, unsigned long long* out, int max_layers);
 
 const char* vp_last_error(void);
 const char* vp_version(void);
