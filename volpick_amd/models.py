@@ -465,9 +465,7 @@ def _group_stream(stream, component_order, sampling_rate, copy, in_samples):
     """Yield one dict per contiguous block of one instrument: data (3,N) float32 in
     ``component_order`` (missing components / gaps inside a block zero-filled), start time and
     ids.  In-repo twin of the array assembly: volpick/data/convert.py:26-70."""
-    traces = list(stream)
-    if copy:
-        traces = [t.copy() for t in traces]
+    traces = list(stream)  # the input is never modified, so ``copy`` needs no deep copy here
     if len(traces) == 0:
         return
     groups = {}
@@ -481,28 +479,37 @@ def _group_stream(stream, component_order, sampling_rate, copy, in_samples):
     comp_alias = {"1": "N", "2": "E", "3": "Z"}  # flexible horizontal components
     for (net, sta, loc, cha), trs in sorted(groups.items()):
         t_start = min(UTCDateTime(t.stats.starttime) for t in trs)
-        ends = [UTCDateTime(t.stats.starttime) + (len(t.data) - 1) / sampling_rate for t in trs]
-        n = int(round((max(ends) - t_start) * sampling_rate)) + 1
-        data = np.zeros((len(component_order), n), dtype=np.float32)
-        covered = np.zeros(n, dtype=bool)
-        for tr in sorted(trs, key=lambda t: len(t.data)):
+        pieces = []  # (first sample, length, component index or -1, trace)
+        for tr in trs:
             comp = tr.stats.channel[-1] if tr.stats.channel else ""
             comp = comp if comp in component_order else comp_alias.get(comp, comp)
             s0 = int(round((UTCDateTime(tr.stats.starttime) - t_start) * sampling_rate))
-            l = min(len(tr.data), n - s0)
-            covered[s0 : s0 + l] = True
-            if comp in component_order:
-                d = np.asarray(tr.data[:l], dtype=np.float32)
-                data[component_order.index(comp), s0 : s0 + l] = np.nan_to_num(d) if np.ma.isMaskedArray(tr.data) else d
-        # contiguous covered runs become independent blocks (gaps are not bridged)
-        edges = np.flatnonzero(np.diff(np.concatenate([[0], covered.view(np.int8), [0]])))
-        for b0, b1 in zip(edges[::2], edges[1::2]):
+            pieces.append((s0, len(tr.data), component_order.index(comp) if comp in component_order else -1, tr))
+        # contiguous covered runs (union over all components) become independent blocks; gaps are not bridged
+        runs = []
+        for s0, l, _, _ in sorted(pieces, key=lambda p: p[0]):
+            if l <= 0:
+                continue
+            if runs and s0 <= runs[-1][1]:
+                runs[-1][1] = max(runs[-1][1], s0 + l)
+            else:
+                runs.append([s0, s0 + l])
+        for b0, b1 in runs:
             if b1 - b0 < in_samples:
                 warnings.warn("Parts of the input stream consist of fragments shorter than the number of input "
                               "samples. Output might be empty.")
                 continue
+            data = np.zeros((len(component_order), b1 - b0), dtype=np.float32)
+            for s0, l, c, tr in sorted(pieces, key=lambda p: p[1]):  # shorter first: longer traces win overlaps
+                lo, hi = max(s0, b0), min(s0 + l, b1)
+                if c < 0 or hi <= lo:
+                    continue
+                d = tr.data[lo - s0 : hi - s0]
+                if np.ma.isMaskedArray(d):
+                    d = d.filled(0)
+                data[c, lo - b0 : hi - b0] = d  # casts int / float64 counts to float32
             yield {
-                "data": data[:, b0:b1],
+                "data": data,
                 "starttime": t_start + b0 / sampling_rate,
                 "trace_id": f"{net}.{sta}.{loc}",
                 "network": net, "station": sta, "location": loc,
