@@ -497,6 +497,7 @@ int vp_classify_collect(vp_handle* h, int slot, int64_t* first_valid, int64_t* l
   VP_HIP(hipSetDevice(h->device));
   VP_HIP(hipEventSynchronize(sl.done));
   sl.busy = false;
+  read_stage_timing(h, sl.n_specs > 0);  // no-op unless vp_set_timing(h, 1); events of the latest submit
   if (first_valid) *first_valid = sl.fv;
   if (last_valid) *last_valid = sl.lv;
   if (n_windows) *n_windows = sl.nwin;
