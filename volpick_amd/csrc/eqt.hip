@@ -11,7 +11,6 @@
 //   decoders  3 x 7 x [Upsample(2) + Conv1d + ReLU]          conv_mfma_kernel, three weight sets per launch,
 //                                                            the producer writes its rows x2-upsampled
 //   heads     3 x [Conv1d(8,1,11) + sigmoid]                 head_kernel
-#include "conv_mfma_persist.h"
 #include "eqt_kernels.h"
 #include "net.h"
 
@@ -46,15 +45,13 @@ using EQ_d3 = ConvCfg<32, 0, 32, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
 using EQ_d4 = ConvCfg<32, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
 using EQ_d5 = ConvCfg<16, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
 using EQ_d6 = ConvCfg<16, 0, 8, 2, 7, 1, -3, 0, 1, 4, 8, 1, EPI_HEAD>;  // + Conv1d(8,1,11) + sigmoid head
+// A/B tile variants (plan flag reserved[3] = 1): half-width tiles, twice the workgroups per CU
+using EQ_d3b = ConvCfg<32, 0, 32, 2, 5, 1, -2, 0, 2, 2, 3, 1, EPI_STORE>;
+using EQ_d4b = ConvCfg<32, 0, 16, 2, 5, 1, -2, 0, 2, 2, 3, 1, EPI_STORE>;
+using EQ_d5b = ConvCfg<16, 0, 16, 2, 5, 1, -2, 0, 2, 2, 3, 1, EPI_STORE>;
+using EQ_d6b = ConvCfg<16, 0, 8, 2, 7, 1, -3, 0, 1, 4, 4, 1, EPI_HEAD>;
 
 std::vector<float> vec(const float* p, size_t n) { return std::vector<float>(p, p + n); }
-
-// Long low-channel layers run as persistent workgroups over TPW tiles (conv_mfma_persist.h).
-template <class Cfg, int TPW>
-void make_persistent(ConvLayer* L) {
-  L->launch = &launch_conv_persist<Cfg, TPW>;
-  L->kernel = reinterpret_cast<const void*>(&conv_mfma_persist_kernel<Cfg, TPW>);
-}
 
 std::vector<float> pack_plain(const ParamView& pv, const std::string& conv, int cout, int cin, int K, const ConvGeom& g,
                               const float* row_scale = nullptr) {
@@ -121,15 +118,10 @@ int plan_eqt(Net& net, const ParamView& pv) {
   for (int i = 0; i < 7; ++i) enc[i] = net.add_tensor("encoder." + std::to_string(i), filt[i], len[i + 1]);
   const int act0 = net.add_tensor("res.act", 64, EQT_T);  // relu(bn1(x)) feeding each block's conv1
   ConvLayer* L;
-  const bool persist = net.cfg.reserved[3] != 1;  // reserved[3] = 1: one workgroup per tile everywhere (A/B timing)
-  L = add_plain<EQ_e0>(net, pv, "encoder.0", "encoder.convs.0", 8, 3, 11, x, enc[0], 3000, 6000);
-  if (persist) make_persistent<EQ_e0, 3>(L);
-  L = add_plain<EQ_e1>(net, pv, "encoder.1", "encoder.convs.1", 16, 8, 9, enc[0], enc[1], 3000, 3000);
-  if (persist) make_persistent<EQ_e1, 3>(L);
-  L = add_plain<EQ_e2>(net, pv, "encoder.2", "encoder.convs.2", 16, 16, 7, enc[1], enc[2], 1500, 1500);
-  if (persist) make_persistent<EQ_e2, 2>(L);
-  L = add_plain<EQ_e3>(net, pv, "encoder.3", "encoder.convs.3", 32, 16, 7, enc[2], enc[3], 750, 750);
-  if (persist) make_persistent<EQ_e3, 2>(L);
+  add_plain<EQ_e0>(net, pv, "encoder.0", "encoder.convs.0", 8, 3, 11, x, enc[0], 3000, 6000);
+  add_plain<EQ_e1>(net, pv, "encoder.1", "encoder.convs.1", 16, 8, 9, enc[0], enc[1], 3000, 3000);
+  add_plain<EQ_e2>(net, pv, "encoder.2", "encoder.convs.2", 16, 16, 7, enc[1], enc[2], 1500, 1500);
+  add_plain<EQ_e3>(net, pv, "encoder.3", "encoder.convs.3", 32, 16, 7, enc[2], enc[3], 750, 750);
   add_plain<EQ_e4>(net, pv, "encoder.4", "encoder.convs.4", 32, 32, 5, enc[3], enc[4], 375, 375);
   add_plain<EQ_e5>(net, pv, "encoder.5", "encoder.convs.5", 64, 32, 5, enc[4], enc[5], 188, 188);
   L = add_plain<EQ_e6>(net, pv, "encoder.6", "encoder.convs.6", 64, 64, 3, enc[5], enc[6], 94, 94);
@@ -322,6 +314,7 @@ int plan_eqt(Net& net, const ParamView& pv) {
   const int dk[7] = {3, 5, 5, 7, 7, 9, 11};
   const char* dec_prefix[3] = {"decoder_d", "pick_decoders.0", "pick_decoders.1"};
   int dsrc = dec_in;
+  const bool alt = net.cfg.reserved[3] == 1;
   for (int i = 0; i < 7; ++i) {
     const bool polyphase = (i != 2);
     const int dst_len = (i == 1) ? 375 : dout[i];  // stage 1 stores its rows x2-upsampled and cropped
@@ -348,10 +341,10 @@ int plan_eqt(Net& net, const ParamView& pv) {
       case 0: EQ_DEC(EQ_d0) break;
       case 1: EQ_DEC(EQ_d1) break;
       case 2: EQ_DEC(EQ_d2) break;
-      case 3: EQ_DEC(EQ_d3) break;
-      case 4: EQ_DEC(EQ_d4) if (persist) make_persistent<EQ_d4, 2>(L); break;
-      case 5: EQ_DEC(EQ_d5) if (persist) make_persistent<EQ_d5, 4>(L); break;
-      default: EQ_DEC(EQ_d6) if (persist) make_persistent<EQ_d6, 3>(L); break;
+      case 3: if (alt) { EQ_DEC(EQ_d3b) } else { EQ_DEC(EQ_d3) } break;
+      case 4: if (alt) { EQ_DEC(EQ_d4b) } else { EQ_DEC(EQ_d4) } break;
+      case 5: if (alt) { EQ_DEC(EQ_d5b) } else { EQ_DEC(EQ_d5) } break;
+      default: if (alt) { EQ_DEC(EQ_d6b) } else { EQ_DEC(EQ_d6) } break;
     }
 #undef EQ_DEC
     L->l_dst = dst_len;
