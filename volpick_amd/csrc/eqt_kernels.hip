@@ -210,15 +210,27 @@ int launch_bilstm(const BiLstmArgs& a, int cin, int B, hipStream_t s) {
 __global__ __launch_bounds__(1024) void transformer_kernel(const TransformerArgs a) {
   constexpr int NTH = 1024;
   __shared__ float xs[T][EQT_H];
-  __shared__ float q[T][KP], k[T][KP];
-  __shared__ float e[T][48];
+  // q / k / e of the attention and, afterwards, the padded feed-forward weights share one pool
+  constexpr int POOL = 2 * T * KP + T * 48;
+  constexpr int W1S = 17, W2S = 129;  // row strides that spread the rows over the LDS banks
+  static_assert(128 * W1S + EQT_H * W2S <= POOL, "feed-forward weights must fit the attention scratch");
+  __shared__ float pool[POOL];
+  float(*q)[KP] = reinterpret_cast<float(*)[KP]>(pool);
+  float(*k)[KP] = reinterpret_cast<float(*)[KP]>(pool + T * KP);
+  float(*e)[48] = reinterpret_cast<float(*)[48]>(pool + 2 * T * KP);
+  float* w1s = pool;
+  float* w2s = pool + 128 * W1S;
   __shared__ float v[T][EQT_H];
   __shared__ float y1[T][EQT_H];
   __shared__ float h1[T][128];
   const int tid = threadIdx.x, b = blockIdx.x;
   load_window_transposed(a.src + (long)b * a.ws_src, a.ls_src, xs);
   __syncthreads();
-  attention_core(xs, q, k, e, v, a.att, a.attn_eps, 0);
+  attention_core(xs, q, k, e, v, a.att, a.attn_eps, 0);  // ends with a barrier: q / k / e are dead now
+  for (int i = tid; i < 128 * 16; i += NTH) {  // coalesced global reads, padded LDS rows
+    w1s[(i >> 4) * W1S + (i & 15)] = a.w1[i];
+    w2s[(i >> 7) * W2S + (i & 127)] = a.w2[i];
+  }
   if (tid < T) {  // y1 = LN1(x + attention(x))
     float z[EQT_H];
 #pragma unroll
@@ -230,7 +242,7 @@ __global__ __launch_bounds__(1024) void transformer_kernel(const TransformerArgs
     const int t = idx >> 7, m = idx & 127;
     float acc = a.bb1[m];
 #pragma unroll
-    for (int c = 0; c < EQT_H; ++c) acc = fmaf(a.w1[m * 16 + c], y1[t][c], acc);
+    for (int c = 0; c < EQT_H; ++c) acc = fmaf(w1s[m * W1S + c], y1[t][c], acc);
     h1[t][m] = fmaxf(acc, 0.f);
   }
   __syncthreads();
@@ -239,8 +251,8 @@ __global__ __launch_bounds__(1024) void transformer_kernel(const TransformerArgs
     float a0 = a.bb2[c], a1 = 0.f;
 #pragma unroll 8
     for (int m = 0; m < 128; m += 2) {
-      a0 = fmaf(a.w2[c * 128 + m], h1[t][m], a0);
-      a1 = fmaf(a.w2[c * 128 + m + 1], h1[t][m + 1], a1);
+      a0 = fmaf(w2s[c * W2S + m], h1[t][m], a0);
+      a1 = fmaf(w2s[c * W2S + m + 1], h1[t][m + 1], a1);
     }
     v[t][c] = y1[t][c] + (a0 + a1);
   }
