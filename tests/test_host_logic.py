@@ -147,3 +147,30 @@ def test_product_never_imports_oracle():
     for f in (ROOT / "volpick_amd").rglob("*.py"):
         src = f.read_text()
         assert "import oracle" not in src and "from oracle" not in src, f
+
+
+@pytest.mark.parametrize("cls,name", [(va.PhaseNet, "volpick"), (va.EQTransformer, "volpick_95train")])
+def test_save_round_trips_the_model_zoo_format(tmp_path, cls, name):
+    """``save`` writes the ``<name>.json.v1`` / ``<name>.pt.v1`` pair of
+    Final_models/ (model_training/tune.ipynb cell 7 ``export_model``); a strict torch load of the
+    .pt into the oracle module and ``load`` of the pair reproduce the source weights exactly."""
+    import json
+
+    import torch
+
+    from oracle import models as OM
+
+    m = cls.from_pretrained(name)
+    m.save(tmp_path / "zoo" / name, version_str="1")
+    meta = json.loads((tmp_path / "zoo" / f"{name}.json.v1").read_text())
+    assert set(meta) == {"docstring", "model_args", "seisbench_requirement", "version", "default_args"}
+    assert meta["model_args"]["norm"] == "peak" and meta["model_args"]["component_order"] == "ZNE"
+    assert meta["default_args"] == m.default_args and meta["version"] == "1"
+    sd = torch.load(tmp_path / "zoo" / f"{name}.pt.v1", map_location="cpu", weights_only=True)
+    net = {"phasenet": OM.PhaseNet, "eqtransformer": OM.EQTransformer}[m._weights_subdir](**meta["model_args"])
+    net.load_state_dict(sd, strict=True)  # every key torch expects, including num_batches_tracked
+    back = cls.load(tmp_path / "zoo" / name, version_str="1")
+    assert np.array_equal(back._weights, m._weights)
+    assert back.default_args == m.default_args and back.labels == m.labels
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), back.state_dict().items()):
+        assert k1 == k2 and v1.shape == v2.shape and v1.dtype == v2.dtype and np.array_equal(v1, v2)

@@ -40,6 +40,12 @@ def _torch():
     return torch
 
 
+def OrderedDictTensors(arrays, torch):
+    from collections import OrderedDict
+
+    return OrderedDict((k, torch.from_numpy(np.array(v, order="C"))) for k, v in arrays.items())
+
+
 class WaveformModel:
     """Common host logic: weight registry, device handle, stream handling, annotate/classify."""
 
@@ -133,7 +139,53 @@ class WaveformModel:
         if strict and extra:
             raise KeyError(f"unexpected keys in state dict: {extra[:5]}")
         self._weights = np.ascontiguousarray(np.concatenate(parts))
+        # key order / shapes / non-float buffers of the source dict, so state_dict() and save() round-trip it
+        self._state_layout = [(k, tuple(np.shape(tensors[k])), k in expected) for k in tensors if k not in extra]
+        self._state_buffers = {k: np.array(getattr(tensors[k], "numpy", lambda k=k: tensors[k])())
+                               for k, _, is_param in self._state_layout if not is_param}
         self._release()
+
+    def state_dict(self):
+        """``OrderedDict`` name -> numpy array in the source dict's key order (torch layout and names)."""
+        from collections import OrderedDict
+
+        if self._weights is None:
+            raise RuntimeError("no weights loaded")
+        lib = _lib.load()
+        offsets, off = {}, 0
+        for i in range(lib.vp_param_count(self._kind)):
+            n = lib.vp_param_size(self._kind, i)
+            offsets[lib.vp_param_name(self._kind, i).decode()] = (off, n)
+            off += n
+        out = OrderedDict()
+        for key, shape, is_param in self._state_layout:
+            if is_param:
+                o, n = offsets[key]
+                out[key] = self._weights[o:o + n].reshape(shape).copy()
+            else:
+                out[key] = self._state_buffers[key].copy()
+        return out
+
+    def get_model_args(self):
+        return {"component_order": self.component_order, "norm": self.norm}
+
+    def save(self, path, weights_docstring="", version_str=None):
+        """Write ``<path>.json[.vN]`` + ``<path>.pt[.vN]`` in the SeisBench model-zoo format
+        (the files ``model_training/tune.ipynb`` cell 7 ``export_model`` produces and
+        ``Final_models/*/*.{json,pt}.v1`` hold), so weights round-trip through ``load``."""
+        torch = _torch()
+        path = str(path)
+        suffix = f".v{version_str}" if version_str else ""
+        Path(path).parent.mkdir(parents=True, exist_ok=True)
+        meta = {
+            "docstring": weights_docstring or self.weights_docstring or "",
+            "model_args": self.get_model_args(),
+            "seisbench_requirement": (self._weights_metadata or {}).get("seisbench_requirement", "0.4.0"),
+            "version": str(version_str) if version_str else (self._weights_version or "1"),
+            "default_args": dict(self.default_args),
+        }
+        Path(path + ".json" + suffix).write_text(json.dumps(meta, indent=4))
+        torch.save(OrderedDictTensors(self.state_dict(), torch), path + ".pt" + suffix)
 
     # ------------------------------------------------------------------ device
     @property
@@ -429,6 +481,9 @@ class PhaseNet(WaveformModel):
         self.labels = phases
         self.in_channels, self.classes = in_channels, classes
 
+    def get_model_args(self):
+        return dict(super().get_model_args(), phases=self.labels)
+
 
 class EQTransformer(WaveformModel):
     name = "EQTransformer"
@@ -450,6 +505,12 @@ class EQTransformer(WaveformModel):
         self.phases = phases
         self.labels = ["Detection"] + list(phases)
         self.norm_amp_per_comp = bool(norm_amp_per_comp)
+
+    def get_model_args(self):
+        args = dict(super().get_model_args(), phases=self.phases)
+        if self.norm_amp_per_comp:
+            args["norm_amp_per_comp"] = True
+        return args
 
     def _config(self):
         cfg = super()._config()
