@@ -11,5 +11,6 @@ from .models import EQTransformer, PhaseNet, WaveformModel  # noqa: F401
 from .picks import ClassifyOutput, Detection, DetectionList, Pick, PickList  # noqa: F401
 from .stream import Stream, Trace, UTCDateTime  # noqa: F401
 from ._lib import VolpickHipError  # noqa: F401
+from .io import read  # noqa: F401
 
 __version__ = "0.1.0"

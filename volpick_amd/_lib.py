@@ -37,6 +37,27 @@ class VpTriggerSpec(C.Structure):
     _fields_ = [("row", C.c_int32), ("thr_on", C.c_float), ("thr_off", C.c_float)]
 
 
+class VpMseedRecord(C.Structure):
+    _fields_ = [
+        ("offset", C.c_int64),
+        ("start_us", C.c_int64),
+        ("sample_rate", C.c_double),
+        ("reclen", C.c_int32),
+        ("data_offset", C.c_int32),
+        ("nsamples", C.c_int32),
+        ("encoding", C.c_int32),
+        ("big_endian", C.c_int32),
+        ("quality", C.c_int32),
+        ("network", C.c_char * 4),
+        ("station", C.c_char * 8),
+        ("location", C.c_char * 4),
+        ("channel", C.c_char * 4),
+    ]
+
+
+VP_SAMPLES_INT32, VP_SAMPLES_FLOAT32 = 0, 1
+
+
 class VolpickHipError(RuntimeError):
     pass
 
@@ -112,6 +133,17 @@ SIGNATURES = {
     ),
     "vp_debug_core_clock": (C.c_int, [_H, C.c_int, C.c_void_p]),
     "vp_debug_conv_clock": (C.c_int, [_H, C.c_void_p, C.c_int]),
+    "vp_mseed_scan": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(VpMseedRecord), C.c_int64, _I64P]),
+    "vp_mseed_decode": (
+        C.c_int,
+        [C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(VpMseedRecord), _I64P, _I64P, C.c_int64, C.c_int,
+         C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int32)],
+    ),
+    "vp_mseed_decode_bench": (
+        C.c_int,
+        [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(VpMseedRecord), _I64P, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+         C.c_int, _FP],
+    ),
     "vp_last_error": (C.c_char_p, []),
     "vp_version": (C.c_char_p, []),
 }
@@ -127,6 +159,13 @@ def load():
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
             f"Build it with `make -C {_HERE / 'csrc'}` or `python -c 'import __graft_entry__ as g; g.build()'`."
         )
+    try:
+        # PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64; a process must run on ONE
+        # HIP runtime, and torch's device init fails ("No HIP GPUs are available") if the system copy was
+        # loaded first.  Importing torch before the dlopen makes its copy the one both sides resolve to.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
