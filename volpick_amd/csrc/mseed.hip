@@ -63,6 +63,8 @@ __global__ __launch_bounds__(64 * REC_PER_WG) void mseed_decode_kernel(const uin
     const int nwords = (rec.nbytes >> 6) << 4;  // whole 64-byte frames
     int produced = 0, carry = 0;
     unsigned x0 = 0, xn = 0;
+    const bool whole = rec.nwrite >= ns && rec.out_index >= 0 && rec.out_index + ns <= out_len;
+    OutT* dst = out + rec.out_index;
     for (int base = 0; base < nwords && produced < ns; base += 64) {
       const int g = base + lane;
       unsigned word = 0;
@@ -100,23 +102,33 @@ __global__ __launch_bounds__(64 * REC_PER_WG) void mseed_decode_kernel(const uin
       // running sums of the word's own differences (most significant field first), in registers
       int p[7];
       int run = 0;
+      int sh = bits * (cnt - 1);
 #pragma unroll
       for (int j = 0; j < 7; ++j) {
-        const int sh = bits * (cnt - 1 - j);
-        int d = j < cnt ? static_cast<int>(word << ((32 - bits - sh) & 31)) >> ((32 - bits) & 31) : 0;
+        int d = bits == 32 ? static_cast<int>(word) : __builtin_amdgcn_sbfe(static_cast<int>(word), sh, bits);  // v_bfe_i32
+        if (j >= cnt) d = 0;
         if (j == 0 && pos == 0 && cnt > 0) d = static_cast<int>(x0);  // x[0] = X0; the first difference is not used
         run += d;
         p[j] = run;
+        sh -= bits;
       }
       const int sincl = wave_incl_scan(run);
       const int before = carry + sincl - run;  // value of the sample preceding this word's first one
+      if (whole && produced + total <= ns) {  // every sample of the chunk lands inside `out`: no per-sample checks
 #pragma unroll
-      for (int j = 0; j < 7; ++j) {
-        const int k = pos + j;
-        if (j < cnt && k < ns) {
-          const int v = before + p[j];
-          store(k, v);
-          if (k == ns - 1 && status && v != static_cast<int>(xn)) status[r] = 1;
+        for (int j = 0; j < 7; ++j)
+          if (j < cnt) dst[pos + j] = static_cast<OutT>(before + p[j]);
+        if (produced + total == ns && status && pos + cnt == ns && cnt > 0 && before + run != static_cast<int>(xn))
+          status[r] = 1;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          const int k = pos + j;
+          if (j < cnt && k < ns) {
+            const int v = before + p[j];
+            store(k, v);
+            if (k == ns - 1 && status && v != static_cast<int>(xn)) status[r] = 1;
+          }
         }
       }
       carry += __shfl(sincl, 63, 64);
