@@ -239,6 +239,36 @@ int vp_mseed_decode_bench(int device_id, const uint8_t* buf_dev, size_t nbytes, 
                           const int64_t* out_index, int64_t n_recs, int out_kind, void* out_dev, int64_t out_len,
                           int iters, float* ms);
 
+/* ---------------------------------------------------------------------------------------------
+ * PhaseNet training step (BASELINE config 5): what one
+ * PhaseNetLit.training_step + Adam optimizer.step of the reference computes
+ * (/root/reference volpick/model/models.py:34-51 vector_cross_entropy, :160-164 training_step,
+ * :177-185 torch.optim.Adam).  fp32 throughout.
+ *
+ * vp_train_create uploads the flat weight blob (same order as vp_create; BatchNorm running
+ * statistics included) and sizes the workspace for max_batch windows.  vp_train_step runs
+ * forward in training mode (batch statistics; running statistics updated with momentum 0.1),
+ * the loss -(1/B) sum_b sum_c mean_t y log(p + 1e-5), backward, and -- if update != 0 -- one Adam
+ * step with learning rate lr (the caller owns the schedule, e.g. the reference's 500-step
+ * warm-up, models.py:168-175).  x, y: (B, 3, 3001) fp32, host or device (mem).  *loss (may be
+ * NULL; non-NULL synchronises) receives the batch loss.  vp_train_read copies out 0 = weights,
+ * 1 = gradients of the last step, 2/3 = Adam first/second moments. */
+typedef struct vp_trainer vp_trainer;
+int vp_train_create(int device_id, int model_kind, const float* weights, size_t n_floats, int max_batch,
+                    vp_trainer** out);
+int vp_train_destroy(vp_trainer* t);
+int vp_train_set_hyper(vp_trainer* t, float beta1, float beta2, float adam_eps, float bn_momentum, float loss_eps);
+int vp_train_step(vp_trainer* t, const float* x, const float* y, int mem, int B, float lr, int update, double* loss);
+int vp_train_synchronize(vp_trainer* t);
+int vp_train_read(vp_trainer* t, int which, float* out, size_t n_floats);
+int vp_train_write_weights(vp_trainer* t, const float* weights, size_t n_floats);
+int vp_train_predictions(vp_trainer* t, float* out, int B);
+/* Debug / parity tests: the z, a, gz, ga tensors of the last step as dense (B, C, L) arrays. */
+int vp_train_tensor_count(const vp_trainer* t);
+int vp_train_tensor_info(const vp_trainer* t, int index, const char** name, int* channels, int* length);
+int vp_train_tensor_read(vp_trainer* t, int index, int B, float* out);
+void* vp_train_stream(const vp_trainer* t);
+
 const char* vp_last_error(void);
 const char* vp_version(void);
 

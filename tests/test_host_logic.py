@@ -174,3 +174,28 @@ def test_save_round_trips_the_model_zoo_format(tmp_path, cls, name):
     assert back.default_args == m.default_args and back.labels == m.labels
     for (k1, v1), (k2, v2) in zip(m.state_dict().items(), back.state_dict().items()):
         assert k1 == k2 and v1.shape == v2.shape and v1.dtype == v2.dtype and np.array_equal(v1, v2)
+
+
+def test_training_host_pieces_without_gpu():
+    """vector_cross_entropy (volpick/model/models.py:34-51), the label shape PhaseNetLit asks for and the
+    500-step warm-up (models.py:168-175); the step itself needs the GPU and fails loudly without one."""
+    import torch
+
+    from volpick_amd.train import PhaseNetLit, PhaseNetTrainer, gaussian_labels, vector_cross_entropy
+
+    rng = np.random.default_rng(0)
+    logits = torch.from_numpy(rng.normal(size=(4, 3, 50)))
+    p = torch.softmax(logits, 1)
+    y = torch.from_numpy(rng.random((4, 3, 50)))
+    want = -(y * torch.log(p + 1e-5)).mean(-1).sum(-1).mean()
+    assert abs(vector_cross_entropy(p.numpy(), y.numpy()) - float(want)) < 1e-12
+    lab = gaussian_labels([100.0, 2000.0], [400.0, np.nan], n_samples=3001, sigma=20)
+    assert lab.shape == (2, 3, 3001) and lab.dtype == np.float32
+    assert lab[0, 0, 100] == 1.0 and lab[0, 1, 400] == 1.0 and lab[1, 1].max() == 0.0
+    assert abs(lab[0, 0, 120] - np.exp(-0.5)) < 1e-6 and np.allclose(lab.sum(1), 1.0, atol=1e-6)
+    lit = PhaseNetLit(lr=5e-4, model=va.PhaseNet.from_pretrained("volpick"))
+    lrs = [lit.learning_rate(k) for k in range(0, 600)]
+    assert lrs[0] == 5e-4 and lrs[1] == pytest.approx(5e-4 * 2 / 500) and lrs[499] == 5e-4 and lrs[599] == 5e-4
+    assert all(b >= a for a, b in zip(lrs[1:500], lrs[2:501]))
+    with pytest.raises(_lib.VolpickHipError):
+        PhaseNetTrainer(va.PhaseNet.from_pretrained("volpick"), max_batch=4)

@@ -144,6 +144,18 @@ SIGNATURES = {
         [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(VpMseedRecord), _I64P, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
          C.c_int, _FP],
     ),
+    "vp_train_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(_H)]),
+    "vp_train_destroy": (C.c_int, [_H]),
+    "vp_train_set_hyper": (C.c_int, [_H, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "vp_train_step": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(C.c_double)]),
+    "vp_train_synchronize": (C.c_int, [_H]),
+    "vp_train_read": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_size_t]),
+    "vp_train_write_weights": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
+    "vp_train_predictions": (C.c_int, [_H, C.c_void_p, C.c_int]),
+    "vp_train_tensor_count": (C.c_int, [_H]),
+    "vp_train_tensor_info": (C.c_int, [_H, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vp_train_tensor_read": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
+    "vp_train_stream": (C.c_void_p, [_H]),
     "vp_last_error": (C.c_char_p, []),
     "vp_version": (C.c_char_p, []),
 }

@@ -1,0 +1,436 @@
+// Kernels of the PhaseNet training step (BASELINE config 5) other than the
+// convolutions themselves (forward and input-gradient convs run on conv_mfma_kernel):
+// BatchNorm in training mode (batch statistics, forward and backward), the 1x1 head + softmax +
+// vector cross entropy (volpick/model/models.py:34-51) with its backward, the weight-gradient
+// GEMM on the fp32 matrix cores, weight packing, deterministic partial-sum reduction and Adam
+// (models.py:177-185 configure_optimizers).  All arithmetic is fp32; reductions finish in fp64.
+#pragma once
+#include "vp_common.h"
+
+namespace vp {
+
+// ------------------------------------------------------------------------------------------
+// rows of an activation / gradient tensor: element (b, c, t) at p[b * ws + c * ls + HALO + t]
+struct Rows {
+  float* p;
+  int ls;
+  long ws;
+};
+
+struct BnArgs {
+  Rows z;          // raw conv output, C channels, Lz samples
+  Rows a;          // relu(bn(z[crop + t])), t in [0, La)
+  Rows ga1, ga2;   // gradient wrt a (ga2.p may be null; the two are summed)
+  Rows gz;         // gradient wrt z, Lz samples
+  int C, B, Lz, La, crop;
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  float* stats;     // [4][C]: mean, rstd, S1 = sum(da'), S2 = sum(da' * xhat)
+  double* partial;  // [C][GB][2]
+  int GB;
+  float* g_gamma;   // gradient blob slots
+  float* g_beta;
+  float eps, momentum;
+};
+
+__device__ inline double block_sum_double(double v, double* sh) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+  return s;
+}
+
+// grid (C, GB), 256 threads: block (c, j) sums channel c over windows j, j + GB, ...
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const BnArgs a) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x, j = blockIdx.y;
+  float s = 0.f, q = 0.f;
+  for (int b = j; b < a.B; b += a.GB) {
+    const float* z = a.z.p + (long)b * a.z.ws + (long)c * a.z.ls + HALO;
+    for (int t = threadIdx.x; t < a.Lz; t += 256) {
+      const float v = z[t];
+      s += v;
+      q = fmaf(v, v, q);
+    }
+  }
+  const double S = block_sum_double((double)s, sh), Q = block_sum_double((double)q, sh);
+  if (threadIdx.x == 0) {
+    a.partial[((long)c * a.GB + j) * 2] = S;
+    a.partial[((long)c * a.GB + j) * 2 + 1] = Q;
+  }
+}
+
+// one block, thread c: batch mean / biased variance -> mean, rstd; running statistics as torch
+// (momentum 0.1, unbiased variance).
+__global__ void bn_stats_final_kernel(const BnArgs a) {
+  const int c = threadIdx.x;
+  if (c >= a.C) return;
+  double S = 0.0, Q = 0.0;
+  for (int j = 0; j < a.GB; ++j) {
+    S += a.partial[((long)c * a.GB + j) * 2];
+    Q += a.partial[((long)c * a.GB + j) * 2 + 1];
+  }
+  const double N = (double)a.B * a.Lz;
+  const double mean = S / N;
+  double var = Q / N - mean * mean;
+  if (var < 0.0) var = 0.0;
+  a.stats[c] = (float)mean;
+  a.stats[a.C + c] = (float)(1.0 / sqrt(var + (double)a.eps));
+  a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+  a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)(var * N / (N - 1.0));
+}
+
+// grid (ceil(La / 1024), C, B)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs a) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float mean = a.stats[c], rstd = a.stats[a.C + c];
+  const float sc = a.gamma[c] * rstd, sh = a.beta[c] - mean * sc;
+  const float* z = a.z.p + (long)b * a.z.ws + (long)c * a.z.ls + HALO + a.crop;
+  float* o = a.a.p + (long)b * a.a.ws + (long)c * a.a.ls + HALO;
+  const int t0 = blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int t = t0 + k * 256;
+    if (t < a.La) o[t] = fmaxf(fmaf(z[t], sc, sh), 0.f);
+  }
+}
+
+// grid (C, GB): S1 = sum da', S2 = sum da' * xhat with da' = ga * [a > 0]
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const BnArgs a) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x, j = blockIdx.y;
+  const float mean = a.stats[c], rstd = a.stats[a.C + c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = j; b < a.B; b += a.GB) {
+    const float* z = a.z.p + (long)b * a.z.ws + (long)c * a.z.ls + HALO + a.crop;
+    const float* act = a.a.p + (long)b * a.a.ws + (long)c * a.a.ls + HALO;
+    const float* g1 = a.ga1.p + (long)b * a.ga1.ws + (long)c * a.ga1.ls + HALO;
+    const float* g2 = a.ga2.p ? a.ga2.p + (long)b * a.ga2.ws + (long)c * a.ga2.ls + HALO : nullptr;
+    for (int t = threadIdx.x; t < a.La; t += 256) {
+      float g = g1[t];
+      if (g2) g += g2[t];
+      if (!(act[t] > 0.f)) g = 0.f;
+      s1 += g;
+      s2 = fmaf(g, (z[t] - mean) * rstd, s2);
+    }
+  }
+  const double S1 = block_sum_double((double)s1, sh), S2 = block_sum_double((double)s2, sh);
+  if (threadIdx.x == 0) {
+    a.partial[((long)c * a.GB + j) * 2] = S1;
+    a.partial[((long)c * a.GB + j) * 2 + 1] = S2;
+  }
+}
+
+__global__ void bn_bwd_final_kernel(const BnArgs a) {
+  const int c = threadIdx.x;
+  if (c >= a.C) return;
+  double S1 = 0.0, S2 = 0.0;
+  for (int j = 0; j < a.GB; ++j) {
+    S1 += a.partial[((long)c * a.GB + j) * 2];
+    S2 += a.partial[((long)c * a.GB + j) * 2 + 1];
+  }
+  a.stats[2 * a.C + c] = (float)S1;
+  a.stats[3 * a.C + c] = (float)S2;
+  a.g_beta[c] = (float)S1;
+  a.g_gamma[c] = (float)S2;
+}
+
+// grid (ceil(Lz / 1024), C, B): gz = gamma * rstd * (da' - S1/N - xhat * S2/N) over the FULL conv output
+// (positions cropped away before the next layer still receive gradient through the statistics).
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float mean = a.stats[c], rstd = a.stats[a.C + c];
+  const float invN = 1.f / ((float)a.B * (float)a.Lz);
+  const float m1 = a.stats[2 * a.C + c] * invN, m2 = a.stats[3 * a.C + c] * invN;
+  const float k = a.gamma[c] * rstd;
+  const float* z = a.z.p + (long)b * a.z.ws + (long)c * a.z.ls + HALO;
+  const float* act = a.a.p + (long)b * a.a.ws + (long)c * a.a.ls + HALO;
+  const float* g1 = a.ga1.p + (long)b * a.ga1.ws + (long)c * a.ga1.ls + HALO;
+  const float* g2 = a.ga2.p ? a.ga2.p + (long)b * a.ga2.ws + (long)c * a.ga2.ls + HALO : nullptr;
+  float* gz = a.gz.p + (long)b * a.gz.ws + (long)c * a.gz.ls + HALO;
+  const int j0 = blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int j = j0 + u * 256;
+    if (j < a.Lz) {
+      const int t = j - a.crop;
+      float g = 0.f;
+      if (t >= 0 && t < a.La && act[t] > 0.f) {
+        g = g1[t];
+        if (g2) g += g2[t];
+      }
+      const float xh = (z[j] - mean) * rstd;
+      gz[j] = k * (g - m1 - xh * m2);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Head: logits = W (3x8) a + b, p = softmax, loss = -(1/B) sum_b sum_c (1/T) sum_t y log(p + eps)
+// (vector_cross_entropy, models.py:34-51), and its backward down to ga (8 channels) plus
+// block partials of [loss, db(3), dW(24)].
+struct HeadArgs2 {
+  Rows a;       // 8 channels
+  Rows ga;      // 8 channels
+  const float* y;  // dense labels [B][3][T]
+  float* p;        // dense predictions [B][3][T] (may be null)
+  const float* w;  // [3][8]
+  const float* b;  // [3]
+  double* partial; // [blocks][28]
+  int B, T;
+  float eps;
+};
+
+__global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const HeadArgs2 h) {
+  __shared__ double sh[4];
+  const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
+  float w[3][8], bb[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    bb[c] = h.b[c];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[c][k] = h.w[c * 8 + k];
+  }
+  float vals[28];
+#pragma unroll
+  for (int i = 0; i < 28; ++i) vals[i] = 0.f;
+  if (t < h.T) {
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = h.a.p[(long)b * h.a.ws + (long)k * h.a.ls + HALO + t];
+    float z[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      z[c] = bb[c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) z[c] = fmaf(w[c][k], x[k], z[c]);
+    }
+    const float mx = fmaxf(z[0], fmaxf(z[1], z[2]));
+    float e[3] = {expf(z[0] - mx), expf(z[1] - mx), expf(z[2] - mx)};
+    const float inv = 1.f / (e[0] + e[1] + e[2]);
+    float p[3], g[3], gl[3];
+    const float scale = 1.f / ((float)h.B * (float)h.T);
+    float dot = 0.f, loss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      p[c] = e[c] * inv;
+      const float yv = h.y[((long)b * 3 + c) * h.T + t];
+      loss -= yv * logf(p[c] + h.eps);
+      g[c] = -yv / (p[c] + h.eps) * scale;
+      dot = fmaf(g[c], p[c], dot);
+      if (h.p) h.p[((long)b * 3 + c) * h.T + t] = p[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gl[c] = p[c] * (g[c] - dot);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      h.ga.p[(long)b * h.ga.ws + (long)k * h.ga.ls + HALO + t] = w[0][k] * gl[0] + w[1][k] * gl[1] + w[2][k] * gl[2];
+    vals[0] = loss * scale;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      vals[1 + c] = gl[c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) vals[4 + c * 8 + k] = gl[c] * x[k];
+    }
+  }
+  const long blk = (long)blockIdx.y * gridDim.x + blockIdx.x;
+#pragma unroll
+  for (int i = 0; i < 28; ++i) {
+    const double s = block_sum_double((double)vals[i], sh);
+    if (threadIdx.x == 0) h.partial[blk * 28 + i] = s;
+  }
+}
+
+// out[i] = sum_g partial[g * n + i]  (fixed order: run-to-run deterministic)
+__global__ __launch_bounds__(256) void sum_partials_f32_kernel(const float* __restrict__ partial, int G, int n,
+                                                               float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int g = 0; g < G; ++g) s += (double)partial[(long)g * n + i];
+  out[i] = (float)s;
+}
+__global__ __launch_bounds__(256) void sum_partials_f64_kernel(const double* __restrict__ partial, int G, int n,
+                                                               double* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int g = 0; g < G; ++g) s += partial[(long)g * n + i];
+  out[i] = s;
+}
+
+// head partial sums -> loss (double), gradient slots of out.bias / out.weight
+__global__ void head_final_kernel(const double* __restrict__ sums, double* loss, float* g_b, float* g_w) {
+  const int i = threadIdx.x;
+  if (i == 0) *loss = sums[0];
+  if (i >= 1 && i < 4) g_b[i - 1] = (float)sums[i];
+  if (i >= 4 && i < 28) g_w[i - 4] = (float)sums[i];
+}
+
+// per-channel sum over (B, L) of a tensor (the conv bias gradient of `inc`), one block per channel
+__global__ __launch_bounds__(256) void channel_sum_kernel(const Rows r, int B, int L, float* out) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float* p = r.p + (long)b * r.ws + (long)c * r.ls + HALO;
+    float acc = 0.f;
+    for (int t = threadIdx.x; t < L; t += 256) acc += p[t];
+    s += (double)acc;
+  }
+  s = block_sum_double(s, sh);
+  if (threadIdx.x == 0) out[c] = (float)s;
+}
+
+// packed MFMA A-fragments of every conv from the current weights: idx[i] = 1 + flat weight index, 0 = structural zero
+__global__ __launch_bounds__(256) void gather_pack_kernel(const int* __restrict__ idx, const float* __restrict__ w,
+                                                          float* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int k = idx[i];
+  out[i] = k > 0 ? w[k - 1] : 0.f;
+}
+
+// torch.optim.Adam (no weight decay, no amsgrad); `mask` = 1 for trainable entries, 0 for the BN running statistics
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ mask, int n, float lr, float b1, float b2,
+                                                   float eps, float bc1, float bc2_sqrt) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || mask[i] == 0.f) return;
+  const float gi = g[i];
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  w[i] -= (lr / bc1) * (mi / denom);
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient on the matrix cores:
+//   D[m][h][k] = sum_b sum_n lo[b][m][n] * hi[b][h][S * n + k + off]      m < LO, h < HI1 + HI2, k < K
+// conv:            lo = gz (cout rows),  hi = layer input (cin rows)       -> D = dW[cout][cin][K]
+// ConvTranspose1d: lo = layer input,     hi = gz over the full output      -> D = dWt[cin][cout][K]
+// GEMM view: M = LO rows, N = (k, h) columns (k-major), reduction over time in steps of 4
+// (v_mfma_f32_16x16x4_f32: lane l feeds A[l & 15][l >> 4] = lo[m][n0 + (l >> 4)] and
+// B[l >> 4][l & 15] = hi[h][S * (n0 + (l >> 4)) + k]).  A workgroup walks (window, time-chunk)
+// items grid-stride, staging lo / hi chunks in LDS, and keeps its D tiles in registers; it writes
+// one partial D per workgroup, summed afterwards in a fixed order (sum_partials_f32_kernel).
+struct WgradArgs {
+  Rows lo;
+  Rows hi1, hi2;
+  int lim_hi1, lim_hi2;  // floats readable after HALO in a hi row
+  int Ln;                // valid low-rate length
+  int off;               // hi sample offset of tap 0 (minus the left padding)
+  int B;
+  int chunks;            // time chunks per window
+  float* partial;        // [gridDim.x][LO * HI * K]
+};
+
+template <int LO_, int HI1_, int HI2_, int K_, int S_, int NWAVE_, int TT_>
+struct WgradCfg {
+  static constexpr int LO = LO_, HI1 = HI1_, HI2 = HI2_, HI = HI1_ + HI2_, K = K_, S = S_, NWAVE = NWAVE_, TT = TT_;
+  static constexpr int LOP = (LO + 15) / 16 * 16, MT = LOP / 16;
+  static constexpr int COLS = HI * K, NT = (COLS + 15) / 16, TILES = MT * NT, TPW = (TILES + NWAVE - 1) / NWAVE;
+  static constexpr int WH = S * TT + K - 1;           // staged hi samples per row
+  static constexpr int S_LO = TT + 2;                 // row strides chosen to spread rows over LDS banks
+  static constexpr int S_HI = (WH | 1) + 2;
+  static constexpr int LDS_FLOATS = LOP * S_LO + HI * S_HI;
+  static constexpr int OUT = LO * HI * K;
+  static_assert(TT % 4 == 0, "time chunk must be a multiple of the MFMA k (4)");
+  static_assert(LDS_FLOATS * 4 <= 64 * 1024, "static LDS budget");
+};
+
+template <class C>
+__global__ __launch_bounds__(64 * C::NWAVE) void wgrad_kernel(const WgradArgs a) {
+  __shared__ float lds[C::LDS_FLOATS];
+  float* lo_s = lds;
+  float* hi_s = lds + C::LOP * C::S_LO;
+  constexpr int NTH = 64 * C::NWAVE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l16 = lane & 15;
+  f32x4 acc[C::TPW];
+  int a_base[C::TPW], b_base[C::TPW];
+#pragma unroll
+  for (int i = 0; i < C::TPW; ++i) {
+    acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tile = wave + i * C::NWAVE;
+    const int mt = tile / C::NT, nt = tile - mt * C::NT;
+    int col = nt * 16 + l16;
+    if (col >= C::COLS) col = 0;  // padding columns compute garbage that is never stored
+    const int k = col / C::HI, h = col - k * C::HI;
+    a_base[i] = (mt * 16 + l16) * C::S_LO + g;
+    b_base[i] = h * C::S_HI + C::S * g + k;
+  }
+  for (int i = tid; i < (C::LOP - C::LO) * C::S_LO; i += NTH) lo_s[C::LO * C::S_LO + i] = 0.f;  // padding rows
+  const int items = a.B * a.chunks;
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int b = item / a.chunks, n_start = (item - b * a.chunks) * C::TT;
+    __syncthreads();  // previous item's MFMA reads are done
+    {
+      const float* lo = a.lo.p + (long)b * a.lo.ws + HALO + n_start;
+      for (int i = tid; i < C::LO * C::TT; i += NTH) {
+        const int m = i / C::TT, n = i - m * C::TT;
+        lo_s[m * C::S_LO + n] = (n_start + n < a.Ln) ? lo[(long)m * a.lo.ls + n] : 0.f;
+      }
+      const int s0 = C::S * n_start + a.off;  // hi sample index of staged column 0
+      for (int i = tid; i < C::HI * C::WH; i += NTH) {
+        const int h = i / C::WH, j = i - h * C::WH;
+        const int idx = s0 + j;
+        float v = 0.f;
+        if (idx >= -HALO) {
+          if (h < C::HI1) {
+            if (idx < a.lim_hi1) v = a.hi1.p[(long)b * a.hi1.ws + (long)h * a.hi1.ls + HALO + idx];
+          } else {
+            if (idx < a.lim_hi2) v = a.hi2.p[(long)b * a.hi2.ws + (long)(h - C::HI1) * a.hi2.ls + HALO + idx];
+          }
+        }
+        hi_s[h * C::S_HI + j] = v;
+      }
+    }
+    __syncthreads();
+    int n_len = a.Ln - n_start;
+    if (n_len > C::TT) n_len = C::TT;
+    for (int n0 = 0; n0 < n_len; n0 += 4) {
+#pragma unroll
+      for (int i = 0; i < C::TPW; ++i) {
+        if (wave + i * C::NWAVE < C::TILES) {
+          const float av = lo_s[a_base[i] + n0];
+          const float bv = hi_s[b_base[i] + C::S * n0];
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* out = a.partial + (long)blockIdx.x * C::OUT;
+#pragma unroll
+  for (int i = 0; i < C::TPW; ++i) {
+    const int tile = wave + i * C::NWAVE;
+    if (tile < C::TILES) {
+      const int mt = tile / C::NT, nt = tile - mt * C::NT;
+      const int col = nt * 16 + l16;
+      const int k = col / C::HI, h = col - k * C::HI;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mt * 16 + 4 * g + r;
+        if (m < C::LO && col < C::COLS) out[((long)m * C::HI + h) * C::K + k] = acc[i][r];
+      }
+    }
+  }
+}
+
+template <class C>
+int launch_wgrad(const WgradArgs& a, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(wgrad_kernel<C>, dim3(grid), dim3(64 * C::NWAVE), 0, s, a);
+  return 0;
+}
+
+}  // namespace vp

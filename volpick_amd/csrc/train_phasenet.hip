@@ -1,0 +1,760 @@
+// PhaseNet training step (BASELINE config 5): forward in training mode (batch
+// statistics), vector cross entropy, backward, Adam -- the arithmetic of one
+// PhaseNetLit.training_step + optimizer.step of the reference
+// (/root/reference volpick/model/models.py:34-51 loss, :160-164 shared_step/training_step,
+// :177-185 Adam; the SeisBench PhaseNet module it wraps is restated in oracle/models.py).
+//
+// Layout: every layer keeps z (raw conv output), a = relu(bn(z)) and the gradients gz, ga as haloed
+// [B][C][ls] rows.  Forward convs and input-gradient convs run on conv_mfma_kernel with fragments
+// re-packed from the live weights every step (gather_pack_kernel, index maps built once with the
+// inference packers); weight gradients on wgrad_kernel; everything else in train_kernels.h.
+// ConvTranspose outputs are kept at full length (4 L + 3): BatchNorm sees the samples the U-Net
+// crops away, and they receive gradient through the batch statistics.
+#include <memory>
+
+#include "conv_mfma.h"
+#include "train_kernels.h"
+
+namespace vp {
+namespace {
+
+constexpr int T0 = 3001, T1 = 751, T2 = 188, T3 = 47, T4 = 12;
+constexpr int NLAYER = 18;
+
+//                    CIN1 CIN2 COUT P TAPS SN IN_OFF OUT_OFF WM WN NW RELU EPI
+// forward (no activation: BatchNorm needs the raw output)
+using F_inc = ConvCfg<3, 0, 8, 2, 8, 2, -3, 0, 1, 4, 8, 0, EPI_STORE>;
+using F_d0s = ConvCfg<8, 0, 8, 2, 8, 2, -3, 0, 1, 4, 8, 0, EPI_STORE>;
+using F_d0d = ConvCfg<8, 0, 8, 2, 11, 8, -3, 0, 1, 4, 2, 0, EPI_STORE>;
+using F_d1s = ConvCfg<8, 0, 16, 1, 7, 1, -3, 0, 1, 4, 4, 0, EPI_STORE>;
+using F_d1d = ConvCfg<16, 0, 16, 1, 7, 4, -2, 0, 1, 4, 1, 0, EPI_STORE>;
+using F_d2s = ConvCfg<16, 0, 32, 1, 7, 1, -3, 0, 2, 2, 3, 0, EPI_STORE>;
+using F_d2d = ConvCfg<32, 0, 32, 1, 7, 4, -1, 0, 2, 2, 1, 0, EPI_STORE>;
+using F_d3s = ConvCfg<32, 0, 64, 1, 7, 1, -3, 0, 4, 1, 3, 0, EPI_STORE>;
+using F_d3d = ConvCfg<64, 0, 64, 1, 7, 4, -2, 0, 4, 1, 1, 0, EPI_STORE>;
+using F_d4s = ConvCfg<64, 0, 128, 1, 7, 1, -3, 0, 4, 1, 1, 0, EPI_STORE>;
+using F_u0T = ConvCfg<128, 0, 64, 4, 2, 1, -1, 0, 4, 1, 1, 0, EPI_STORE>;
+using F_u0s = ConvCfg<64, 64, 64, 1, 7, 1, -3, 0, 4, 1, 3, 0, EPI_STORE>;
+using F_u1T = ConvCfg<64, 0, 32, 4, 2, 1, -1, 0, 4, 1, 3, 0, EPI_STORE>;
+using F_u1s = ConvCfg<32, 32, 32, 1, 7, 1, -3, 0, 2, 2, 3, 0, EPI_STORE>;
+using F_u2T = ConvCfg<32, 0, 16, 4, 2, 1, -1, 0, 4, 1, 4, 0, EPI_STORE>;
+using F_u2s = ConvCfg<16, 16, 16, 1, 7, 1, -3, 0, 1, 4, 4, 0, EPI_STORE>;
+using F_u3T = ConvCfg<16, 0, 8, 4, 2, 1, -1, 0, 2, 2, 4, 0, EPI_STORE>;
+using F_u3s = ConvCfg<8, 8, 8, 2, 8, 2, -3, 0, 1, 4, 8, 0, EPI_STORE>;
+// input gradients: conv(k7, same) -> conv with the flipped, transposed kernel
+using G_d0s = ConvCfg<8, 0, 8, 2, 8, 2, -3, 0, 1, 4, 8, 0, EPI_STORE>;
+using G_d1s = ConvCfg<16, 0, 8, 2, 8, 2, -3, 0, 1, 4, 2, 0, EPI_STORE>;
+using G_d2s = ConvCfg<32, 0, 16, 1, 7, 1, -3, 0, 1, 4, 3, 0, EPI_STORE>;
+using G_d3s = ConvCfg<64, 0, 32, 1, 7, 1, -3, 0, 2, 2, 2, 0, EPI_STORE>;
+using G_d4s = ConvCfg<128, 0, 64, 1, 7, 1, -3, 0, 4, 1, 1, 0, EPI_STORE>;
+using G_u0s = ConvCfg<64, 0, 128, 1, 7, 1, -3, 0, 4, 1, 3, 0, EPI_STORE>;
+using G_u1s = ConvCfg<32, 0, 64, 1, 7, 1, -3, 0, 2, 2, 3, 0, EPI_STORE>;
+using G_u2s = ConvCfg<16, 0, 32, 1, 7, 1, -3, 0, 2, 2, 4, 0, EPI_STORE>;
+using G_u3s = ConvCfg<8, 0, 16, 1, 7, 1, -3, 0, 1, 4, 8, 0, EPI_STORE>;
+// conv(k7, s4, left pad p) -> ConvTranspose(k7, s4) of the same kernel, output shifted by -p
+using G_d0d = ConvCfg<8, 0, 8, 4, 2, 1, -1, -3, 2, 2, 4, 0, EPI_STORE>;
+using G_d1d = ConvCfg<16, 0, 16, 4, 2, 1, -1, -2, 4, 1, 4, 0, EPI_STORE>;
+using G_d2d = ConvCfg<32, 0, 32, 4, 2, 1, -1, -1, 4, 1, 3, 0, EPI_STORE>;
+using G_d3d = ConvCfg<64, 0, 64, 4, 2, 1, -1, -2, 4, 1, 1, 0, EPI_STORE>;
+// ConvTranspose(k7, s4) -> conv(k7, s4, no pad) of the same kernel over the full-length gradient
+using G_u0T = ConvCfg<64, 0, 128, 1, 7, 4, 0, 0, 4, 1, 1, 0, EPI_STORE>;
+using G_u1T = ConvCfg<32, 0, 64, 1, 7, 4, 0, 0, 4, 1, 3, 0, EPI_STORE>;
+using G_u2T = ConvCfg<16, 0, 32, 1, 7, 4, 0, 0, 2, 2, 3, 0, EPI_STORE>;
+using G_u3T = ConvCfg<8, 0, 16, 1, 7, 4, 0, 0, 1, 4, 4, 0, EPI_STORE>;
+//                     LO HI1 HI2 K S NWAVE TT
+using W_inc = WgradCfg<8, 3, 0, 7, 1, 4, 256>;
+using W_d0s = WgradCfg<8, 8, 0, 7, 1, 4, 256>;
+using W_d0d = WgradCfg<8, 8, 0, 7, 4, 4, 256>;
+using W_d1s = WgradCfg<16, 8, 0, 7, 1, 4, 256>;
+using W_d1d = WgradCfg<16, 16, 0, 7, 4, 4, 96>;
+using W_d2s = WgradCfg<32, 16, 0, 7, 1, 4, 192>;
+using W_d2d = WgradCfg<32, 32, 0, 7, 4, 4, 48>;
+using W_d3s = WgradCfg<64, 32, 0, 7, 1, 8, 48>;
+using W_d3d = WgradCfg<64, 64, 0, 7, 4, 16, 12>;
+using W_d4s = WgradCfg<128, 64, 0, 7, 1, 16, 12>;
+using W_u0T = WgradCfg<128, 64, 0, 7, 4, 16, 12>;
+using W_u0s = WgradCfg<64, 64, 64, 7, 1, 16, 48>;
+using W_u1T = WgradCfg<64, 32, 0, 7, 4, 8, 48>;
+using W_u1s = WgradCfg<32, 32, 32, 7, 1, 8, 96>;
+using W_u2T = WgradCfg<32, 16, 0, 7, 4, 4, 96>;
+using W_u2s = WgradCfg<16, 16, 16, 7, 1, 4, 256>;
+using W_u3T = WgradCfg<16, 8, 0, 7, 4, 4, 256>;
+using W_u3s = WgradCfg<8, 8, 8, 7, 1, 4, 256>;
+
+struct ConvOp {
+  bool used = false;
+  ConvGeom g{};
+  int (*launch)(const ConvArgs&, int, hipStream_t) = nullptr;
+  const void* kernel = nullptr;
+  size_t lds_bytes = 0;
+  int src1 = -1, src2 = -1, dst = -1;
+  int cols = 0, l_out = 0;
+  size_t frag_off = 0;
+  long bias_off = -1;  // offset of a real bias in the weight blob, -1 = zeros
+};
+
+struct WgradOp {
+  int (*launch)(const WgradArgs&, int, hipStream_t) = nullptr;
+  int lo = -1, hi1 = -1, hi2 = -1;
+  int Ln = 0, off = 0, TT = 0, out_n = 0;
+  long grad_off = 0;
+};
+
+struct BnOp {
+  int z = -1, a = -1, gz = -1;
+  int ga1 = -1, ga1_ch = 0, ga2 = -1, ga2_ch = 0;
+  int C = 0, Lz = 0, La = 0, crop = 0;
+  long gamma_off = 0, beta_off = 0, rm_off = 0, rv_off = 0;
+  size_t stats_off = 0;
+};
+
+struct Layer {
+  std::string name;
+  ConvOp fwd, dgrad;
+  BnOp bn;
+  WgradOp wg;
+};
+
+template <class Cfg>
+void set_conv(ConvOp* op, int src1, int src2, int dst, int cols, int l_out) {
+  op->used = true;
+  op->g = Cfg::geom();
+  op->launch = &launch_conv<Cfg>;
+  op->kernel = reinterpret_cast<const void*>(&conv_mfma_kernel<Cfg>);
+  op->lds_bytes = Cfg::LDS_FLOATS * sizeof(float);
+  op->src1 = src1;
+  op->src2 = src2;
+  op->dst = dst;
+  op->cols = cols;
+  op->l_out = l_out;
+}
+
+template <class Cfg>
+void set_wgrad(WgradOp* op, int lo, int hi1, int hi2, int Ln, int off) {
+  op->launch = &launch_wgrad<Cfg>;
+  op->lo = lo;
+  op->hi1 = hi1;
+  op->hi2 = hi2;
+  op->Ln = Ln;
+  op->off = off;
+  op->TT = Cfg::TT;
+  op->out_n = Cfg::OUT;
+}
+
+// dense (B, C, T) -> haloed rows
+__global__ __launch_bounds__(256) void load_rows_kernel(const float* __restrict__ x, Rows r, int C, int T) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < T) r.p[(long)b * r.ws + (long)c * r.ls + HALO + t] = x[((long)b * C + c) * T + t];
+}
+
+}  // namespace
+
+struct Trainer {
+  int device = 0, max_batch = 0;
+  hipStream_t stream = nullptr;
+  std::vector<Tensor> tensors;
+  std::vector<Layer> layers;
+  std::map<std::string, long> poff;  // parameter name -> offset in the flat blob
+  std::map<std::string, size_t> psize;
+  size_t n_params = 0;
+  // device memory
+  float* arena = nullptr;   // activation / gradient tensors
+  float* w = nullptr;       // weights (flat blob, canonical order)
+  float* grad = nullptr;
+  float* adam_m = nullptr;
+  float* adam_v = nullptr;
+  float* mask = nullptr;
+  int* frag_idx = nullptr;
+  float* frag = nullptr;
+  size_t frag_n = 0;
+  float* zeros = nullptr;   // 256 zero floats (bias of bias-free convs)
+  float* stats = nullptr;
+  double* bn_partial = nullptr;
+  float* wg_partial = nullptr;
+  size_t wg_partial_floats = 0;
+  double* head_partial = nullptr;
+  double* head_sums = nullptr;  // [28] + loss at [28]
+  float* x_dev = nullptr;       // staging for host inputs
+  float* y_dev = nullptr;
+  float* p_dev = nullptr;       // predictions of the last step
+  long step = 0;
+  float beta1 = 0.9f, beta2 = 0.999f, adam_eps = 1e-8f, bn_eps = 1e-3f, bn_momentum = 0.1f, loss_eps = 1e-5f;
+  int t_x = -1, t_ga_last = -1;
+  std::vector<int> frag_idx_host;
+
+  int add_tensor(const std::string& name, int C, int L) {
+    Tensor t;
+    t.name = name;
+    t.C = C;
+    t.L = L;
+    t.need = HALO + round_up(L, 4) + 4;
+    tensors.push_back(t);
+    return (int)tensors.size() - 1;
+  }
+  void need(int id, int phys) {
+    if (id >= 0 && tensors[id].need < phys) tensors[id].need = phys;
+  }
+  Rows rows(int id, int ch = 0) const {
+    const Tensor& t = tensors[id];
+    return Rows{t.p + (long)ch * t.ls, t.ls, (long)t.win_stride()};
+  }
+  ~Trainer() {
+    for (void* p : {(void*)arena, (void*)w, (void*)grad, (void*)adam_m, (void*)adam_v, (void*)mask, (void*)frag_idx,
+                    (void*)frag, (void*)zeros, (void*)stats, (void*)bn_partial, (void*)wg_partial, (void*)head_partial,
+                    (void*)head_sums, (void*)x_dev, (void*)y_dev, (void*)p_dev})
+      if (p) (void)hipFree(p);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+// index map of one conv's packed fragments: pack "weights" whose values are their own flat index + 1
+std::vector<int> to_index(const std::vector<float>& packed) {
+  std::vector<int> out(packed.size());
+  for (size_t i = 0; i < packed.size(); ++i) out[i] = (int)(packed[i] + 0.5f);
+  return out;
+}
+std::vector<float> index_weights(long off, size_t n) {
+  std::vector<float> w(n);
+  for (size_t i = 0; i < n; ++i) w[i] = (float)(off + (long)i + 1);  // exact below 2^24
+  return w;
+}
+// W[co][ci][K] -> W'[ci][co][K] with the taps reversed (input gradient of a stride-1 "same" conv)
+std::vector<float> flip_transpose(const std::vector<float>& w, int cout, int cin, int K) {
+  std::vector<float> o(w.size());
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int k = 0; k < K; ++k) o[((size_t)ci * cout + co) * K + (K - 1 - k)] = w[((size_t)co * cin + ci) * K + k];
+  return o;
+}
+
+void append_frag(Trainer& tr, ConvOp* op, const std::vector<float>& amat) {
+  const std::vector<int> idx = to_index(pack_afrag(amat, op->g.M(), op->g.cinp(), op->g.taps));
+  op->frag_off = tr.frag_idx_host.size();
+  tr.frag_idx_host.insert(tr.frag_idx_host.end(), idx.begin(), idx.end());
+}
+
+int build_plan(Trainer& tr) {
+  const ParamDesc* table;
+  const int np = param_table(VP_MODEL_PHASENET, &table);
+  long off = 0;
+  for (int i = 0; i < np; ++i) {
+    tr.poff[table[i].name] = off;
+    tr.psize[table[i].name] = table[i].size;
+    off += (long)table[i].size;
+  }
+  tr.n_params = (size_t)off;
+  const int len[5] = {T0, T1, T2, T3, T4};
+  const int ch[5] = {8, 16, 32, 64, 128};
+  const int padl[4] = {3, 2, 1, 2};
+  tr.layers.resize(NLAYER);
+  // layer order: 0 inc, 1+2i down{i}.same, 2+2i down{i}.down (i<4), 9 down4.same, 10+2j up{j}.convT, 11+2j up{j}.same
+  auto P = [&](const std::string& n) { return tr.poff.at(n); };
+  auto mk_bn = [&](Layer& L, const std::string& bn, int C, int Lz, int La, int crop) {
+    L.bn.C = C;
+    L.bn.Lz = Lz;
+    L.bn.La = La;
+    L.bn.crop = crop;
+    L.bn.gamma_off = P(bn + ".weight");
+    L.bn.beta_off = P(bn + ".bias");
+    L.bn.rm_off = P(bn + ".running_mean");
+    L.bn.rv_off = P(bn + ".running_var");
+    L.bn.z = tr.add_tensor(L.name + ".z", C, Lz);
+    L.bn.a = tr.add_tensor(L.name + ".a", C, La);
+    L.bn.gz = tr.add_tensor(L.name + ".gz", C, Lz);
+  };
+  tr.t_x = tr.add_tensor("x", 3, T0);
+  Layer* Ls = tr.layers.data();
+  Ls[0].name = "inc";
+  mk_bn(Ls[0], "in_bn", 8, T0, T0, 0);
+  for (int i = 0; i < 5; ++i) {
+    Layer& S = Ls[i < 4 ? 1 + 2 * i : 9];
+    S.name = "down" + std::to_string(i) + ".same";
+    mk_bn(S, "down_branch." + std::to_string(i) + ".1", ch[i], len[i], len[i], 0);
+    if (i < 4) {
+      Layer& D = Ls[2 + 2 * i];
+      D.name = "down" + std::to_string(i) + ".down";
+      mk_bn(D, "down_branch." + std::to_string(i) + ".3", ch[i], len[i + 1], len[i + 1], 0);
+    }
+  }
+  for (int j = 0; j < 4; ++j) {
+    const int lv = 3 - j;  // output level
+    Layer& U = Ls[10 + 2 * j];
+    U.name = "up" + std::to_string(j) + ".convT";
+    const int lfull = 4 * len[lv + 1] + 3;
+    const int crop = 1 + ((lfull - 3) - len[lv]) / 2;  // x[:, :, 1:-2] then the centre crop to the skip length
+    mk_bn(U, "up_branch." + std::to_string(j) + ".1", ch[lv], lfull, len[lv], crop);
+    Layer& S = Ls[11 + 2 * j];
+    S.name = "up" + std::to_string(j) + ".same";
+    mk_bn(S, "up_branch." + std::to_string(j) + ".3", ch[lv], len[lv], len[lv], 0);
+  }
+  // gradient-of-activation tensors
+  int ga[NLAYER];       // plain ga tensors (single producer)
+  int gcat[4], gskip[4];
+  for (int i = 0; i < NLAYER; ++i) ga[i] = -1;
+  for (int j = 0; j < 4; ++j) {
+    const int lv = 3 - j;
+    gcat[j] = tr.add_tensor("up" + std::to_string(j) + ".gcat", 2 * ch[lv], len[lv]);   // d(concat(skip, up)) of up{j}.same
+    gskip[lv] = tr.add_tensor("down" + std::to_string(lv) + ".gskip", ch[lv], len[lv]);  // from down{lv}.down
+  }
+  auto mk_ga = [&](int li) {
+    ga[li] = tr.add_tensor(Ls[li].name + ".ga", Ls[li].bn.C, Ls[li].bn.La);
+    Ls[li].bn.ga1 = ga[li];
+  };
+  mk_ga(0);                                    // inc        <- dgrad of down0.same
+  for (int i = 0; i < 4; ++i) mk_ga(2 + 2 * i);  // down{i}.down <- dgrad of down{i+1}.same
+  mk_ga(9);                                    // down4.same <- dgrad of up0.convT
+  for (int j = 0; j < 4; ++j) mk_ga(11 + 2 * j);  // up{j}.same <- dgrad of up{j+1}.convT, or the head for j = 3
+  tr.t_ga_last = ga[17];
+  for (int i = 0; i < 4; ++i) {  // skips: from the up path (first half of gcat) + from the strided conv below
+    BnOp& b = Ls[1 + 2 * i].bn;
+    b.ga1 = gcat[3 - i];
+    b.ga1_ch = 0;
+    b.ga2 = gskip[i];
+  }
+  for (int j = 0; j < 4; ++j) {  // convT outputs: second half of gcat
+    BnOp& b = Ls[10 + 2 * j].bn;
+    b.ga1 = gcat[j];
+    b.ga1_ch = ch[3 - j];
+  }
+
+  // ---- convolutions: forward, input gradient, weight gradient ------------------------------
+  auto W = [&](const std::string& n) { return index_weights(P(n), tr.psize.at(n)); };
+#define FWD_CONV(LI, CFG, WNAME, COUT, CIN, STRIDE, SRC1, SRC2, COLS)                                        \
+  set_conv<CFG>(&Ls[LI].fwd, SRC1, SRC2, Ls[LI].bn.z, COLS, Ls[LI].bn.Lz);                                    \
+  append_frag(tr, &Ls[LI].fwd, amat_conv(W(WNAME).data(), COUT, CIN, 7, STRIDE, CFG::P, CFG::CINP, nullptr));
+#define FWD_CONVT(LI, CFG, WNAME, CIN, COUT, SRC, LIN)                                                       \
+  set_conv<CFG>(&Ls[LI].fwd, SRC, -1, Ls[LI].bn.z, (LIN) + 1, Ls[LI].bn.Lz);                                  \
+  append_frag(tr, &Ls[LI].fwd, amat_convT_k7s4(W(WNAME).data(), CIN, COUT, CFG::CINP, nullptr));
+  // dgrad of a stride-1 conv W[COUT][CIN][7]: conv of gz (COUT channels) with the flipped transpose -> CIN channels
+#define BWD_SAME(LI, CFG, WNAME, COUT, CIN, DST, LDST)                                                       \
+  set_conv<CFG>(&Ls[LI].dgrad, Ls[LI].bn.gz, -1, DST, ((LDST) + CFG::P - 1) / CFG::P, LDST);                  \
+  append_frag(tr, &Ls[LI].dgrad,                                                                             \
+              amat_conv(flip_transpose(W(WNAME), COUT, CIN, 7).data(), CIN, COUT, 7, 1, CFG::P, CFG::CINP, nullptr));
+  // dgrad of a stride-4 conv W[C][C][7] with left pad PADL: transposed conv of gz, output index shifted by -PADL
+#define BWD_DOWN(LI, CFG, WNAME, C, DST, LDST, PADL)                                                         \
+  set_conv<CFG>(&Ls[LI].dgrad, Ls[LI].bn.gz, -1, DST, ((LDST)-1 + (PADL)) / 4 + 1, LDST);                     \
+  append_frag(tr, &Ls[LI].dgrad, amat_convT_k7s4(W(WNAME).data(), C, C, CFG::CINP, nullptr));
+  // dgrad of ConvTranspose Wt[CIN][COUT][7]: stride-4 conv of the full-length gz (COUT channels) -> CIN channels
+#define BWD_UPT(LI, CFG, WNAME, CIN, COUT, DST, LIN)                                                         \
+  set_conv<CFG>(&Ls[LI].dgrad, Ls[LI].bn.gz, -1, DST, LIN, LIN);                                              \
+  append_frag(tr, &Ls[LI].dgrad, amat_conv(W(WNAME).data(), CIN, COUT, 7, 4, 1, CFG::CINP, nullptr));
+
+  const int x = tr.t_x;
+  auto A = [&](int li) { return Ls[li].bn.a; };
+  FWD_CONV(0, F_inc, "inc.weight", 8, 3, 1, x, -1, (T0 + 1) / 2)
+  Ls[0].fwd.bias_off = P("inc.bias");
+  FWD_CONV(1, F_d0s, "down_branch.0.0.weight", 8, 8, 1, A(0), -1, (T0 + 1) / 2)
+  FWD_CONV(2, F_d0d, "down_branch.0.2.weight", 8, 8, 4, A(1), -1, (T1 + 1) / 2)
+  FWD_CONV(3, F_d1s, "down_branch.1.0.weight", 16, 8, 1, A(2), -1, T1)
+  FWD_CONV(4, F_d1d, "down_branch.1.2.weight", 16, 16, 4, A(3), -1, T2)
+  FWD_CONV(5, F_d2s, "down_branch.2.0.weight", 32, 16, 1, A(4), -1, T2)
+  FWD_CONV(6, F_d2d, "down_branch.2.2.weight", 32, 32, 4, A(5), -1, T3)
+  FWD_CONV(7, F_d3s, "down_branch.3.0.weight", 64, 32, 1, A(6), -1, T3)
+  FWD_CONV(8, F_d3d, "down_branch.3.2.weight", 64, 64, 4, A(7), -1, T4)
+  FWD_CONV(9, F_d4s, "down_branch.4.0.weight", 128, 64, 1, A(8), -1, T4)
+  FWD_CONVT(10, F_u0T, "up_branch.0.0.weight", 128, 64, A(9), T4)
+  FWD_CONV(11, F_u0s, "up_branch.0.2.weight", 64, 128, 1, A(7), A(10), T3)
+  FWD_CONVT(12, F_u1T, "up_branch.1.0.weight", 64, 32, A(11), T3)
+  FWD_CONV(13, F_u1s, "up_branch.1.2.weight", 32, 64, 1, A(5), A(12), T2)
+  FWD_CONVT(14, F_u2T, "up_branch.2.0.weight", 32, 16, A(13), T2)
+  FWD_CONV(15, F_u2s, "up_branch.2.2.weight", 16, 32, 1, A(3), A(14), T1)
+  FWD_CONVT(16, F_u3T, "up_branch.3.0.weight", 16, 8, A(15), T1)
+  FWD_CONV(17, F_u3s, "up_branch.3.2.weight", 8, 16, 1, A(1), A(16), (T0 + 1) / 2)
+
+  BWD_SAME(1, G_d0s, "down_branch.0.0.weight", 8, 8, ga[0], T0)
+  BWD_SAME(3, G_d1s, "down_branch.1.0.weight", 16, 8, ga[2], T1)
+  BWD_SAME(5, G_d2s, "down_branch.2.0.weight", 32, 16, ga[4], T2)
+  BWD_SAME(7, G_d3s, "down_branch.3.0.weight", 64, 32, ga[6], T3)
+  BWD_SAME(9, G_d4s, "down_branch.4.0.weight", 128, 64, ga[8], T4)
+  BWD_SAME(11, G_u0s, "up_branch.0.2.weight", 64, 128, gcat[0], T3)
+  BWD_SAME(13, G_u1s, "up_branch.1.2.weight", 32, 64, gcat[1], T2)
+  BWD_SAME(15, G_u2s, "up_branch.2.2.weight", 16, 32, gcat[2], T1)
+  BWD_SAME(17, G_u3s, "up_branch.3.2.weight", 8, 16, gcat[3], T0)
+  BWD_DOWN(2, G_d0d, "down_branch.0.2.weight", 8, gskip[0], T0, padl[0])
+  BWD_DOWN(4, G_d1d, "down_branch.1.2.weight", 16, gskip[1], T1, padl[1])
+  BWD_DOWN(6, G_d2d, "down_branch.2.2.weight", 32, gskip[2], T2, padl[2])
+  BWD_DOWN(8, G_d3d, "down_branch.3.2.weight", 64, gskip[3], T3, padl[3])
+  BWD_UPT(10, G_u0T, "up_branch.0.0.weight", 128, 64, ga[9], T4)
+  BWD_UPT(12, G_u1T, "up_branch.1.0.weight", 64, 32, ga[11], T3)
+  BWD_UPT(14, G_u2T, "up_branch.2.0.weight", 32, 16, ga[13], T2)
+  BWD_UPT(16, G_u3T, "up_branch.3.0.weight", 16, 8, ga[15], T1)
+#undef FWD_CONV
+#undef FWD_CONVT
+#undef BWD_SAME
+#undef BWD_DOWN
+#undef BWD_UPT
+
+  auto GZ = [&](int li) { return Ls[li].bn.gz; };
+#define WG(LI, CFG, WNAME, LO, HI1, HI2, LN, OFF)            \
+  set_wgrad<CFG>(&Ls[LI].wg, LO, HI1, HI2, LN, OFF);          \
+  Ls[LI].wg.grad_off = P(WNAME);
+  WG(0, W_inc, "inc.weight", GZ(0), x, -1, T0, -3)
+  WG(1, W_d0s, "down_branch.0.0.weight", GZ(1), A(0), -1, T0, -3)
+  WG(2, W_d0d, "down_branch.0.2.weight", GZ(2), A(1), -1, T1, -padl[0])
+  WG(3, W_d1s, "down_branch.1.0.weight", GZ(3), A(2), -1, T1, -3)
+  WG(4, W_d1d, "down_branch.1.2.weight", GZ(4), A(3), -1, T2, -padl[1])
+  WG(5, W_d2s, "down_branch.2.0.weight", GZ(5), A(4), -1, T2, -3)
+  WG(6, W_d2d, "down_branch.2.2.weight", GZ(6), A(5), -1, T3, -padl[2])
+  WG(7, W_d3s, "down_branch.3.0.weight", GZ(7), A(6), -1, T3, -3)
+  WG(8, W_d3d, "down_branch.3.2.weight", GZ(8), A(7), -1, T4, -padl[3])
+  WG(9, W_d4s, "down_branch.4.0.weight", GZ(9), A(8), -1, T4, -3)
+  WG(10, W_u0T, "up_branch.0.0.weight", A(9), GZ(10), -1, T4, 0)   // ConvTranspose: lo = layer input, hi = gz
+  WG(11, W_u0s, "up_branch.0.2.weight", GZ(11), A(7), A(10), T3, -3)
+  WG(12, W_u1T, "up_branch.1.0.weight", A(11), GZ(12), -1, T3, 0)
+  WG(13, W_u1s, "up_branch.1.2.weight", GZ(13), A(5), A(12), T2, -3)
+  WG(14, W_u2T, "up_branch.2.0.weight", A(13), GZ(14), -1, T2, 0)
+  WG(15, W_u2s, "up_branch.2.2.weight", GZ(15), A(3), A(14), T1, -3)
+  WG(16, W_u3T, "up_branch.3.0.weight", A(15), GZ(16), -1, T1, 0)
+  WG(17, W_u3s, "up_branch.3.2.weight", GZ(17), A(1), A(16), T0, -3)
+#undef WG
+
+  for (Layer& L : tr.layers)
+    for (ConvOp* op : {&L.fwd, &L.dgrad})
+      if (op->used) {
+        tr.need(op->src1, op->g.src_need(op->cols));
+        tr.need(op->src2, op->g.src_need(op->cols));
+      }
+  size_t so = 0;
+  for (Layer& L : tr.layers) {
+    L.bn.stats_off = so;
+    so += 4 * (size_t)L.bn.C;
+  }
+  return VP_OK;
+}
+
+#define TR_HIP(call)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);       \
+      return VP_ERR_HIP;                                                                          \
+    }                                                                                             \
+  } while (0)
+
+int upload(Trainer& tr, const float* weights) {
+  const int B = tr.max_batch;
+  size_t total = 0;
+  std::vector<size_t> toff(tr.tensors.size());
+  for (size_t i = 0; i < tr.tensors.size(); ++i) {
+    Tensor& t = tr.tensors[i];
+    t.ls = round_up(t.need, 4);
+    toff[i] = total;
+    total += (size_t)t.C * t.ls * B;
+    total = (total + 63) / 64 * 64;
+  }
+  TR_HIP(hipMalloc(&tr.arena, total * sizeof(float)));
+  TR_HIP(hipMemset(tr.arena, 0, total * sizeof(float)));
+  for (size_t i = 0; i < tr.tensors.size(); ++i) tr.tensors[i].p = tr.arena + toff[i];
+  const size_t np = tr.n_params;
+  for (float** p : {&tr.w, &tr.grad, &tr.adam_m, &tr.adam_v, &tr.mask}) {
+    TR_HIP(hipMalloc(p, np * sizeof(float)));
+    TR_HIP(hipMemset(*p, 0, np * sizeof(float)));
+  }
+  TR_HIP(hipMemcpy(tr.w, weights, np * sizeof(float), hipMemcpyHostToDevice));
+  std::vector<float> mask(np, 1.f);
+  for (auto& kv : tr.poff) {
+    const std::string& n = kv.first;
+    const bool running = n.size() > 12 && (n.rfind("running_mean") == n.size() - 12 || n.rfind("running_var") == n.size() - 11);
+    if (running)
+      for (size_t i = 0; i < tr.psize[n]; ++i) mask[kv.second + i] = 0.f;
+  }
+  TR_HIP(hipMemcpy(tr.mask, mask.data(), np * sizeof(float), hipMemcpyHostToDevice));
+  tr.frag_n = tr.frag_idx_host.size();
+  TR_HIP(hipMalloc(&tr.frag_idx, tr.frag_n * sizeof(int)));
+  TR_HIP(hipMemcpy(tr.frag_idx, tr.frag_idx_host.data(), tr.frag_n * sizeof(int), hipMemcpyHostToDevice));
+  TR_HIP(hipMalloc(&tr.frag, tr.frag_n * sizeof(float)));
+  TR_HIP(hipMalloc(&tr.zeros, 256 * sizeof(float)));
+  TR_HIP(hipMemset(tr.zeros, 0, 256 * sizeof(float)));
+  size_t ns = 0;
+  for (Layer& L : tr.layers) ns += 4 * (size_t)L.bn.C;
+  TR_HIP(hipMalloc(&tr.stats, ns * sizeof(float)));
+  TR_HIP(hipMemset(tr.stats, 0, ns * sizeof(float)));
+  TR_HIP(hipMalloc(&tr.bn_partial, (size_t)128 * 64 * 2 * sizeof(double)));
+  size_t wmax = 0;
+  for (Layer& L : tr.layers) {
+    const size_t g = L.wg.out_n > 30000 ? 128 : 512;
+    wmax = std::max(wmax, g * (size_t)L.wg.out_n);
+  }
+  tr.wg_partial_floats = wmax;
+  TR_HIP(hipMalloc(&tr.wg_partial, wmax * sizeof(float)));
+  const size_t hb = (size_t)((T0 + 255) / 256) * B;
+  TR_HIP(hipMalloc(&tr.head_partial, hb * 28 * sizeof(double)));
+  TR_HIP(hipMalloc(&tr.head_sums, 32 * sizeof(double)));
+  TR_HIP(hipMemset(tr.head_sums, 0, 32 * sizeof(double)));
+  const size_t dense = (size_t)B * 3 * T0;
+  TR_HIP(hipMalloc(&tr.x_dev, dense * sizeof(float)));
+  TR_HIP(hipMalloc(&tr.y_dev, dense * sizeof(float)));
+  TR_HIP(hipMalloc(&tr.p_dev, dense * sizeof(float)));
+  for (Layer& L : tr.layers)
+    for (ConvOp* op : {&L.fwd, &L.dgrad})
+      if (op->used && op->lds_bytes > 48 * 1024)
+        TR_HIP(hipFuncSetAttribute(op->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)op->lds_bytes));
+  TR_HIP(hipStreamCreate(&tr.stream));
+  return VP_OK;
+}
+
+void run_conv(Trainer& tr, const ConvOp& op, int B) {
+  ConvArgs a{};
+  const Tensor& s1 = tr.tensors[op.src1];
+  a.src1 = s1.p;
+  a.ls1 = s1.ls;
+  a.ws1 = (long)s1.win_stride();
+  if (op.src2 >= 0) {
+    const Tensor& s2 = tr.tensors[op.src2];
+    a.src2 = s2.p;
+    a.ls2 = s2.ls;
+    a.ws2 = (long)s2.win_stride();
+  }
+  const Tensor& d = tr.tensors[op.dst];
+  a.dst = d.p;
+  a.lsd = d.ls;
+  a.wsd = (long)d.win_stride();
+  a.dst_halo = HALO;
+  a.afrag = tr.frag + op.frag_off;
+  a.bias = op.bias_off >= 0 ? tr.w + op.bias_off : tr.zeros;
+  a.win_per_set = B;
+  a.n_windows = B;
+  a.l_out = op.l_out;
+  a.l_dst = op.l_out;
+  op.launch(a, op.cols, tr.stream);
+}
+
+BnArgs bn_args(Trainer& tr, const BnOp& b, int B) {
+  BnArgs a{};
+  a.z = tr.rows(b.z);
+  a.a = tr.rows(b.a);
+  a.gz = tr.rows(b.gz);
+  a.ga1 = tr.rows(b.ga1, b.ga1_ch);
+  a.ga2 = b.ga2 >= 0 ? tr.rows(b.ga2, b.ga2_ch) : Rows{nullptr, 0, 0};
+  a.C = b.C;
+  a.B = B;
+  a.Lz = b.Lz;
+  a.La = b.La;
+  a.crop = b.crop;
+  a.gamma = tr.w + b.gamma_off;
+  a.beta = tr.w + b.beta_off;
+  a.running_mean = tr.w + b.rm_off;
+  a.running_var = tr.w + b.rv_off;
+  a.stats = tr.stats + b.stats_off;
+  a.partial = tr.bn_partial;
+  a.GB = B < 64 ? B : 64;
+  a.g_gamma = tr.grad + b.gamma_off;
+  a.g_beta = tr.grad + b.beta_off;
+  a.eps = tr.bn_eps;
+  a.momentum = tr.bn_momentum;
+  return a;
+}
+
+int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B, bool update, float lr) {
+  hipStream_t s = tr.stream;
+  hipLaunchKernelGGL(gather_pack_kernel, dim3((unsigned)((tr.frag_n + 255) / 256)), dim3(256), 0, s, tr.frag_idx, tr.w,
+                     tr.frag, (long)tr.frag_n);
+  hipLaunchKernelGGL(load_rows_kernel, dim3((T0 + 255) / 256, 3, B), dim3(256), 0, s, x_dev, tr.rows(tr.t_x), 3, T0);
+  for (Layer& L : tr.layers) {
+    run_conv(tr, L.fwd, B);
+    const BnArgs a = bn_args(tr, L.bn, B);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(a.C, a.GB), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(1), dim3(128), 0, s, a);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((a.La + 1023) / 1024, a.C, B), dim3(256), 0, s, a);
+  }
+  {
+    HeadArgs2 h{};
+    h.a = tr.rows(tr.layers[17].bn.a);
+    h.ga = tr.rows(tr.t_ga_last);
+    h.y = y_dev;
+    h.p = tr.p_dev;
+    h.w = tr.w + tr.poff.at("out.weight");
+    h.b = tr.w + tr.poff.at("out.bias");
+    h.partial = tr.head_partial;
+    h.B = B;
+    h.T = T0;
+    h.eps = tr.loss_eps;
+    const int gx = (T0 + 255) / 256;
+    hipLaunchKernelGGL(head_fwd_bwd_kernel, dim3(gx, B), dim3(256), 0, s, h);
+    hipLaunchKernelGGL(sum_partials_f64_kernel, dim3(1), dim3(256), 0, s, tr.head_partial, gx * B, 28, tr.head_sums);
+    hipLaunchKernelGGL(head_final_kernel, dim3(1), dim3(32), 0, s, tr.head_sums, tr.head_sums + 28,
+                       tr.grad + tr.poff.at("out.bias"), tr.grad + tr.poff.at("out.weight"));
+  }
+  for (int li = NLAYER - 1; li >= 0; --li) {
+    Layer& L = tr.layers[li];
+    const BnArgs a = bn_args(tr, L.bn, B);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(a.C, a.GB), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(1), dim3(128), 0, s, a);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((a.Lz + 1023) / 1024, a.C, B), dim3(256), 0, s, a);
+    {
+      const WgradOp& w = L.wg;
+      WgradArgs g{};
+      g.lo = tr.rows(w.lo);
+      g.hi1 = tr.rows(w.hi1);
+      g.lim_hi1 = tr.tensors[w.hi1].ls - HALO;
+      if (w.hi2 >= 0) {
+        g.hi2 = tr.rows(w.hi2);
+        g.lim_hi2 = tr.tensors[w.hi2].ls - HALO;
+      }
+      g.Ln = w.Ln;
+      g.off = w.off;
+      g.B = B;
+      g.chunks = (w.Ln + w.TT - 1) / w.TT;
+      g.partial = tr.wg_partial;
+      const int items = B * g.chunks;
+      const int cap = w.out_n > 30000 ? 128 : 512;
+      const int grid = items < cap ? items : cap;
+      w.launch(g, grid, s);
+      hipLaunchKernelGGL(sum_partials_f32_kernel, dim3((w.out_n + 255) / 256), dim3(256), 0, s, tr.wg_partial, grid,
+                         w.out_n, tr.grad + w.grad_off);
+    }
+    if (li == 0)
+      hipLaunchKernelGGL(channel_sum_kernel, dim3(8), dim3(256), 0, s, tr.rows(L.bn.gz), B, T0,
+                         tr.grad + tr.poff.at("inc.bias"));
+    if (L.dgrad.used) run_conv(tr, L.dgrad, B);
+  }
+  if (update) {
+    tr.step += 1;
+    const float bc1 = 1.f - powf(tr.beta1, (float)tr.step);
+    const float bc2 = 1.f - powf(tr.beta2, (float)tr.step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((tr.n_params + 255) / 256)), dim3(256), 0, s, tr.w, tr.grad,
+                       tr.adam_m, tr.adam_v, tr.mask, (int)tr.n_params, lr, tr.beta1, tr.beta2, tr.adam_eps, bc1,
+                       sqrtf(bc2));
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("training step: kernel launch failed: %s", hipGetErrorString(e));
+    return VP_ERR_HIP;
+  }
+  return VP_OK;
+}
+
+}  // namespace
+}  // namespace vp
+
+using namespace vp;
+
+extern "C" {
+
+int vp_train_create(int device_id, int model_kind, const float* weights, size_t n_floats, int max_batch,
+                    vp_trainer** out) {
+  VP_REQUIRE(out && weights && max_batch > 0, "vp_train_create: bad argument");
+  if (model_kind != VP_MODEL_PHASENET) {
+    set_error("vp_train_create: only PhaseNet has a training step");
+    return VP_ERR_UNSUPPORTED;
+  }
+  auto tr = std::make_unique<Trainer>();
+  tr->device = device_id;
+  tr->max_batch = max_batch;
+  int rc = build_plan(*tr);
+  if (rc != VP_OK) return rc;
+  VP_REQUIRE(n_floats == tr->n_params, "vp_train_create: expected %zu weights, got %zu", tr->n_params, n_floats);
+  VP_HIP(hipSetDevice(device_id));
+  rc = upload(*tr, weights);
+  if (rc != VP_OK) return rc;
+  *out = reinterpret_cast<vp_trainer*>(tr.release());
+  return VP_OK;
+}
+
+int vp_train_destroy(vp_trainer* h) {
+  delete reinterpret_cast<Trainer*>(h);
+  return VP_OK;
+}
+
+int vp_train_set_hyper(vp_trainer* h, float beta1, float beta2, float adam_eps, float bn_momentum, float loss_eps) {
+  VP_REQUIRE(h, "vp_train_set_hyper: null handle");
+  Trainer& tr = *reinterpret_cast<Trainer*>(h);
+  tr.beta1 = beta1;
+  tr.beta2 = beta2;
+  tr.adam_eps = adam_eps;
+  tr.bn_momentum = bn_momentum;
+  tr.loss_eps = loss_eps;
+  return VP_OK;
+}
+
+int vp_train_step(vp_trainer* h, const float* x, const float* y, int mem, int B, float lr, int update, double* loss) {
+  VP_REQUIRE(h && x && y, "vp_train_step: null argument");
+  Trainer& tr = *reinterpret_cast<Trainer*>(h);
+  VP_REQUIRE(B >= 2 && B <= tr.max_batch, "vp_train_step: batch %d outside [2, %d]", B, tr.max_batch);
+  VP_HIP(hipSetDevice(tr.device));
+  const float *xd = x, *yd = y;
+  if (mem == VP_MEM_HOST) {
+    const size_t n = (size_t)B * 3 * T0 * sizeof(float);
+    VP_HIP(hipMemcpyAsync(tr.x_dev, x, n, hipMemcpyHostToDevice, tr.stream));
+    VP_HIP(hipMemcpyAsync(tr.y_dev, y, n, hipMemcpyHostToDevice, tr.stream));
+    xd = tr.x_dev;
+    yd = tr.y_dev;
+  }
+  const int rc = forward_backward(tr, xd, yd, B, update != 0, lr);
+  if (rc != VP_OK) return rc;
+  if (loss) {
+    VP_HIP(hipMemcpyAsync(loss, tr.head_sums + 28, sizeof(double), hipMemcpyDeviceToHost, tr.stream));
+    VP_HIP(hipStreamSynchronize(tr.stream));
+  }
+  return VP_OK;
+}
+
+int vp_train_synchronize(vp_trainer* h) {
+  VP_REQUIRE(h, "vp_train_synchronize: null handle");
+  VP_HIP(hipStreamSynchronize(reinterpret_cast<Trainer*>(h)->stream));
+  return VP_OK;
+}
+
+// which: 0 weights (incl. BN running statistics), 1 gradients of the last step, 2 Adam m, 3 Adam v
+int vp_train_read(vp_trainer* h, int which, float* out, size_t n_floats) {
+  VP_REQUIRE(h && out, "vp_train_read: null argument");
+  Trainer& tr = *reinterpret_cast<Trainer*>(h);
+  VP_REQUIRE(n_floats == tr.n_params && which >= 0 && which <= 3, "vp_train_read: bad size or selector");
+  const float* src = which == 0 ? tr.w : which == 1 ? tr.grad : which == 2 ? tr.adam_m : tr.adam_v;
+  VP_HIP(hipSetDevice(tr.device));
+  VP_HIP(hipStreamSynchronize(tr.stream));
+  VP_HIP(hipMemcpy(out, src, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+  return VP_OK;
+}
+
+int vp_train_write_weights(vp_trainer* h, const float* weights, size_t n_floats) {
+  VP_REQUIRE(h && weights, "vp_train_write_weights: null argument");
+  Trainer& tr = *reinterpret_cast<Trainer*>(h);
+  VP_REQUIRE(n_floats == tr.n_params, "vp_train_write_weights: bad size");
+  VP_HIP(hipSetDevice(tr.device));
+  VP_HIP(hipStreamSynchronize(tr.stream));
+  VP_HIP(hipMemcpy(tr.w, weights, n_floats * sizeof(float), hipMemcpyHostToDevice));
+  return VP_OK;
+}
+
+// predictions (B, 3, 3001) of the last step's forward pass
+int vp_train_predictions(vp_trainer* h, float* out, int B) {
+  VP_REQUIRE(h && out, "vp_train_predictions: null argument");
+  Trainer& tr = *reinterpret_cast<Trainer*>(h);
+  VP_REQUIRE(B > 0 && B <= tr.max_batch, "vp_train_predictions: bad batch");
+  VP_HIP(hipSetDevice(tr.device));
+  VP_HIP(hipStreamSynchronize(tr.stream));
+  VP_HIP(hipMemcpy(out, tr.p_dev, (size_t)B * 3 * T0 * sizeof(float), hipMemcpyDeviceToHost));
+  return VP_OK;
+}
+
+int vp_train_tensor_count(const vp_trainer* h) {
+  return h ? (int)reinterpret_cast<const Trainer*>(h)->tensors.size() : VP_ERR_INVALID;
+}
+int vp_train_tensor_info(const vp_trainer* h, int index, const char** name, int* channels, int* length) {
+  VP_REQUIRE(h, "vp_train_tensor_info: null handle");
+  const Trainer& tr = *reinterpret_cast<const Trainer*>(h);
+  VP_REQUIRE(index >= 0 && index < (int)tr.tensors.size(), "vp_train_tensor_info: bad index");
+  if (name) *name = tr.tensors[index].name.c_str();
+  if (channels) *channels = tr.tensors[index].C;
+  if (length) *length = tr.tensors[index].L;
+  return VP_OK;
+}
+// dense (B, C, L) copy of an activation / gradient tensor of the last step (parity tests)
+int vp_train_tensor_read(vp_trainer* h, int index, int B, float* out) {
+  VP_REQUIRE(h && out, "vp_train_tensor_read: null argument");
+  Trainer& tr = *reinterpret_cast<Trainer*>(h);
+  VP_REQUIRE(index >= 0 && index < (int)tr.tensors.size() && B > 0 && B <= tr.max_batch, "vp_train_tensor_read: bad argument");
+  const Tensor& t = tr.tensors[index];
+  VP_HIP(hipSetDevice(tr.device));
+  VP_HIP(hipStreamSynchronize(tr.stream));
+  VP_HIP(hipMemcpy2D(out, (size_t)t.L * sizeof(float), t.p + HALO, (size_t)t.ls * sizeof(float), (size_t)t.L * sizeof(float),
+                     (size_t)B * t.C, hipMemcpyDeviceToHost));
+  return VP_OK;
+}
+void* vp_train_stream(const vp_trainer* h) { return h ? reinterpret_cast<const Trainer*>(h)->stream : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,207 @@
+"""PhaseNet training step on the GPU (BASELINE config 5).
+
+Host-side mirror of the pieces of the reference's Lightning module that define the arithmetic of
+one optimisation step (/root/reference volpick/model/models.py):
+
+* ``vector_cross_entropy`` (:34-51),
+* ``PhaseNetLit.shared_step`` / ``training_step`` (:160-169): ``loss(model(batch["X"]), batch["y"])``,
+* ``configure_optimizers`` (:177-185): ``torch.optim.Adam(lr)``,
+* ``optimizer_step`` (:168-175): linear learning-rate warm-up over the first 500 steps.
+
+Data loading, augmentation, logging and checkpointing (Lightning / SeisBench generators) are not
+part of this package.  Forward (training-mode BatchNorm), loss, backward and Adam all run in
+``libvolpick_hip.so`` (``vp_train_*``); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .models import PhaseNet
+
+
+def vector_cross_entropy(y_pred, y_true, eps=1e-5):
+    """models.py:34-51 on numpy arrays (B, C, T): mean over samples, sum over classes, mean over batch."""
+    h = y_true * np.log(y_pred + eps)
+    h = h.mean(-1).sum(-1) if y_pred.ndim == 3 else h.sum(-1)
+    return -float(h.mean())
+
+
+def gaussian_labels(p_samples, s_samples, n_samples=3001, sigma=20.0):
+    """Soft labels in ``phases = "PSN"`` order: Gaussians of width sigma at the P and S picks,
+    noise = 1 - P - S (SeisBench ProbabilisticLabeller as PhaseNetLit configures it, models.py:254-260).
+    NaN / negative picks leave the phase row zero."""
+    B = len(p_samples)
+    t = np.arange(n_samples, dtype=np.float64)
+    y = np.zeros((B, 3, n_samples), dtype=np.float64)
+    for row, picks in ((0, p_samples), (1, s_samples)):
+        for b, s in enumerate(picks):
+            if s is not None and np.isfinite(s) and s >= 0:
+                y[b, row] = np.exp(-((t - float(s)) ** 2) / (2.0 * sigma ** 2))
+    y[:, 2] = np.clip(1.0 - y[:, 0] - y[:, 1], 0.0, 1.0)
+    return y.astype(np.float32)
+
+
+class PhaseNetTrainer:
+    """One device-resident PhaseNet with its gradients and Adam state."""
+
+    def __init__(self, model: PhaseNet, max_batch=512, device=0, betas=(0.9, 0.999), eps=1e-8, bn_momentum=0.1,
+                 loss_eps=1e-5):
+        if not isinstance(model, PhaseNet):
+            raise TypeError("the training step is implemented for PhaseNet")
+        if model._weights is None:
+            raise RuntimeError("model has no weights (use from_pretrained / load / load_state_dict)")
+        self._lib = _lib.load()
+        self.model = model
+        self.max_batch = int(max_batch)
+        self.in_samples = model.in_samples
+        self.n_params = int(model._weights.size)
+        self._h = C.c_void_p()
+        w = np.ascontiguousarray(model._weights, dtype=np.float32)
+        _lib.check(self._lib.vp_train_create(int(device), _lib.VP_MODEL_PHASENET, w.ctypes.data_as(C.c_void_p), w.size,
+                                             self.max_batch, C.byref(self._h)), "vp_train_create")
+        _lib.check(self._lib.vp_train_set_hyper(self._h, betas[0], betas[1], eps, bn_momentum, loss_eps))
+        self.global_step = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vp_train_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @staticmethod
+    def _arg(a):
+        """(pointer, mem) of a numpy array or a CUDA torch tensor, fp32 contiguous."""
+        if hasattr(a, "data_ptr"):
+            if a.dtype != _torch().float32 or not a.is_contiguous():
+                a = a.float().contiguous()
+            return a, C.c_void_p(a.data_ptr()), (_lib.VP_MEM_DEVICE if a.is_cuda else _lib.VP_MEM_HOST)
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        return a, a.ctypes.data_as(C.c_void_p), _lib.VP_MEM_HOST
+
+    def step(self, x, y, lr, update=True, want_loss=True):
+        """Forward + loss + backward (+ Adam when ``update``).  x, y: (B, 3, 3001)."""
+        if tuple(x.shape) != tuple(y.shape) or x.ndim != 3 or x.shape[1] != 3 or x.shape[2] != self.in_samples:
+            raise ValueError(f"expected x and y of shape (B, 3, {self.in_samples}), got {tuple(x.shape)} / {tuple(y.shape)}")
+        xk, xp, xm = self._arg(x)
+        yk, yp, ym = self._arg(y)
+        if xm != ym:
+            raise ValueError("x and y must both be host arrays or both be device tensors")
+        loss = C.c_double(float("nan"))
+        _lib.check(self._lib.vp_train_step(self._h, xp, yp, xm, int(x.shape[0]), float(lr), int(bool(update)),
+                                           C.byref(loss) if want_loss else None), "vp_train_step")
+        if update:
+            self.global_step += 1
+        return loss.value if want_loss else None
+
+    def synchronize(self):
+        _lib.check(self._lib.vp_train_synchronize(self._h))
+
+    def _read(self, which):
+        out = np.empty(self.n_params, dtype=np.float32)
+        _lib.check(self._lib.vp_train_read(self._h, which, out.ctypes.data_as(C.c_void_p), out.size), "vp_train_read")
+        return out
+
+    def _named(self, blob):
+        lib, out, off = self._lib, {}, 0
+        shapes = {k: s for k, s, is_param in self.model._state_layout if is_param}
+        for i in range(lib.vp_param_count(_lib.VP_MODEL_PHASENET)):
+            key = lib.vp_param_name(_lib.VP_MODEL_PHASENET, i).decode()
+            n = lib.vp_param_size(_lib.VP_MODEL_PHASENET, i)
+            out[key] = blob[off:off + n].reshape(shapes[key])
+            off += n
+        return out
+
+    def weights(self):
+        return self._named(self._read(0))
+
+    def gradients(self):
+        return self._named(self._read(1))
+
+    def adam_state(self):
+        return self._named(self._read(2)), self._named(self._read(3))
+
+    def predictions(self, B):
+        out = np.empty((B, 3, self.in_samples), dtype=np.float32)
+        _lib.check(self._lib.vp_train_predictions(self._h, out.ctypes.data_as(C.c_void_p), B))
+        return out
+
+    def tensors(self, B):
+        """Every z / a / gz / ga tensor of the last step as (B, C, L) arrays, by name (parity tests)."""
+        lib, out = self._lib, {}
+        for i in range(lib.vp_train_tensor_count(self._h)):
+            name, c, l = C.c_char_p(), C.c_int(), C.c_int()
+            _lib.check(lib.vp_train_tensor_info(self._h, i, C.byref(name), C.byref(c), C.byref(l)))
+            a = np.empty((B, c.value, l.value), dtype=np.float32)
+            _lib.check(lib.vp_train_tensor_read(self._h, i, B, a.ctypes.data_as(C.c_void_p)))
+            out[name.value.decode()] = a
+        return out
+
+    def export(self):
+        """Copy the trained weights (and BatchNorm running statistics) back into ``self.model``."""
+        sd = self.model.state_dict()
+        sd.update(self.weights())
+        for k in sd:
+            if k.endswith("num_batches_tracked"):
+                sd[k] = np.asarray(sd[k] + self.global_step - getattr(self, "_exported_at", 0))
+        self._exported_at = self.global_step
+        self.model.load_state_dict(sd)
+        return self.model
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+class PhaseNetLit:
+    """The arithmetic of the reference's ``PhaseNetLit`` (models.py:108-185): Adam at ``lr`` with the
+    500-step linear warm-up of ``optimizer_step``.  ``training_step(batch)`` takes
+    ``{"X": (B, 3, 3001), "y": (B, 3, 3001)}`` and performs forward, loss, backward AND the
+    optimiser step (Lightning's loop does the last two around the reference's ``training_step``)."""
+
+    WARMUP_STEPS = 500
+
+    def __init__(self, lr=1e-2, sigma=20, max_batch=512, model=None, device=0, **model_kwargs):
+        self.lr = float(lr)
+        self.sigma = sigma
+        self.model = model if model is not None else PhaseNet(**model_kwargs)
+        self._trainer = None
+        self._max_batch, self._device = max_batch, device
+
+    def _ensure(self):
+        if self._trainer is None:
+            self._trainer = PhaseNetTrainer(self.model, max_batch=self._max_batch, device=self._device)
+        return self._trainer
+
+    def learning_rate(self, step):
+        """lr used by optimiser step number ``step`` (0-based).  Step 0 runs at ``lr`` (the optimiser's
+        initial value); after every step < 500 the reference sets lr * min(1, (global_step + 1) / 500)
+        with global_step = steps completed."""
+        if step == 0 or step > self.WARMUP_STEPS:
+            return self.lr
+        return self.lr * min(1.0, (step + 1) / float(self.WARMUP_STEPS))
+
+    def training_step(self, batch, batch_idx=None):
+        tr = self._ensure()
+        return tr.step(batch["X"], batch["y"], self.learning_rate(tr.global_step), update=True)
+
+    def validation_step(self, batch, batch_idx=None):
+        """Loss in eval mode (running statistics), as Lightning's validation loop computes it: the
+        current weights go through the inference path (``vp_forward``)."""
+        model = self._ensure().export()
+        if model._device_index is None:
+            model.cuda(self._device)
+        p = model(batch["X"])
+        p = p.cpu().numpy() if hasattr(p, "cpu") else np.asarray(p)
+        y = batch["y"]
+        y = y.cpu().numpy() if hasattr(y, "cpu") else np.asarray(y)
+        return vector_cross_entropy(p.astype(np.float64), y.astype(np.float64))
+
+    @property
+    def trainer_state(self):
+        return self._ensure()
