@@ -1,0 +1,90 @@
+"""PhaseNet training-step throughput (BASELINE config 5): forward + loss + backward + Adam on
+VCSEIS-shaped synthetic batches resident in HBM, next to the same step through torch autograd on the
+host cores (the oracle module, `kind: "port"`).
+
+    python tools/bench_train.py [--batch 512] [--steps 30] [--warmup 5] [--no-cpu-baseline]
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch  # noqa: E402
+
+from volpick_amd import PhaseNet  # noqa: E402
+from volpick_amd.synthetic import synthetic_windows  # noqa: E402
+from volpick_amd.train import PhaseNetTrainer, gaussian_labels  # noqa: E402
+
+FLOP_FWD = 38.93e6  # algorithmic forward FLOP per 3x3001 window; backward = dgrad + wgrad = 2x
+
+
+def make_batch(B, seed=1005):
+    rng = np.random.default_rng(seed)
+    x = synthetic_windows(B, 3001, seed=seed)
+    x = x - x.mean(-1, keepdims=True)
+    x = x / (np.abs(x).max(-1, keepdims=True) + 1e-10)
+    p = rng.integers(300, 1500, B).astype(float)
+    s = p + rng.integers(200, 1200, B)
+    return x.astype(np.float32), gaussian_labels(p, s)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    a = ap.parse_args()
+    B = a.batch
+    x, y = make_batch(B)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    tr = PhaseNetTrainer(PhaseNet.from_pretrained("volpick"), max_batch=B)
+    for _ in range(a.warmup):
+        tr.step(xd, yd, 1e-4, want_loss=False)
+    tr.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.step(xd, yd, 1e-4, want_loss=False)
+    tr.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    loss = tr.step(xd, yd, 1e-4)
+    out = {
+        "metric": "PhaseNet training windows/sec (fwd+loss+bwd+Adam, fp32)", "value": B / dt, "unit": "windows/s",
+        "ms_per_step": dt * 1e3, "batch": B, "steps": a.steps, "warmup": a.warmup, "dtype": "f32", "data": "synthetic",
+        "loss_after": loss,
+        "roofline": {"bound": "mfma", "achieved": 3 * FLOP_FWD * B / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                     "frac": 3 * FLOP_FWD * B / dt / 157.3e12,
+                     "note": "whole step (about 130 launches), algorithmic 3 x forward FLOP"},
+    }
+    if not a.no_cpu_baseline:
+        from oracle.models import load_pretrained
+
+        net = load_pretrained("phasenet").train()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+        nb = min(B, 128)
+        xt, yt = torch.from_numpy(x[:nb]), torch.from_numpy(y[:nb])
+
+        def cpu_step():
+            opt.zero_grad()
+            pred = net(xt)
+            l = -(yt * torch.log(pred + 1e-5)).mean(-1).sum(-1).mean()
+            l.backward()
+            opt.step()
+
+        cpu_step()
+        t0 = time.perf_counter()
+        for _ in range(a.cpu_steps):
+            cpu_step()
+        ct = (time.perf_counter() - t0) / a.cpu_steps
+        out["cpu_baseline"] = {"value": nb / ct, "unit": "windows/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{a.cpu_steps} steps of batch {nb} through torch autograd + Adam on the oracle module"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -27,7 +27,7 @@ struct BnArgs {
   const float* beta;
   float* running_mean;
   float* running_var;
-  float* stats;     // [4][C]: mean, rstd, S1 = sum(da'), S2 = sum(da' * xhat)
+  float* stats;     // [4][C]: batch mean, rstd, S1 = sum(da'), S2 = sum(da' * xhat)
   double* partial;  // [C][GB][2]
   int GB;
   float* g_gamma;   // gradient blob slots
@@ -47,36 +47,30 @@ __device__ inline double block_sum_double(double v, double* sh) {
   return s;
 }
 
-// grid (C, GB), 256 threads: block (c, j) sums channel c over windows j, j + GB, ...
-__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const BnArgs a) {
-  __shared__ double sh[4];
-  const int c = blockIdx.x, j = blockIdx.y;
-  float s = 0.f, q = 0.f;
-  for (int b = j; b < a.B; b += a.GB) {
-    const float* z = a.z.p + (long)b * a.z.ws + (long)c * a.z.ls + HALO;
-    for (int t = threadIdx.x; t < a.Lz; t += 256) {
-      const float v = z[t];
-      s += v;
-      q = fmaf(v, v, q);
-    }
+// one wavefront per channel: totals of the GB partial pairs (fixed order), valid in lane 0
+__device__ inline void channel_totals(const BnArgs& a, int c, double* s0, double* s1) {
+  double x = 0.0, y = 0.0;
+  for (int j = threadIdx.x; j < a.GB; j += 64) {
+    x += a.partial[((long)c * a.GB + j) * 2];
+    y += a.partial[((long)c * a.GB + j) * 2 + 1];
   }
-  const double S = block_sum_double((double)s, sh), Q = block_sum_double((double)q, sh);
-  if (threadIdx.x == 0) {
-    a.partial[((long)c * a.GB + j) * 2] = S;
-    a.partial[((long)c * a.GB + j) * 2 + 1] = Q;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    x += __shfl_xor(x, o, 64);
+    y += __shfl_xor(y, o, 64);
   }
+  *s0 = x;
+  *s1 = y;
 }
 
-// one block, thread c: batch mean / biased variance -> mean, rstd; running statistics as torch
-// (momentum 0.1, unbiased variance).
-__global__ void bn_stats_final_kernel(const BnArgs a) {
-  const int c = threadIdx.x;
-  if (c >= a.C) return;
-  double S = 0.0, Q = 0.0;
-  for (int j = 0; j < a.GB; ++j) {
-    S += a.partial[((long)c * a.GB + j) * 2];
-    Q += a.partial[((long)c * a.GB + j) * 2 + 1];
-  }
+// grid (C), 64 threads: batch mean / biased variance -> mean, rstd; running statistics as torch
+// (momentum 0.1, unbiased variance).  (A last-block-finalises scheme with __threadfence + an arrival
+// counter was 4-5x SLOWER here: the device-scope fence costs tens of microseconds per launch.)
+__global__ __launch_bounds__(64) void bn_stats_final_kernel(const BnArgs a) {
+  const int c = blockIdx.x;
+  double S, Q;
+  channel_totals(a, c, &S, &Q);
+  if (threadIdx.x != 0) return;
   const double N = (double)a.B * a.Lz;
   const double mean = S / N;
   double var = Q / N - mean * mean;
@@ -85,6 +79,42 @@ __global__ void bn_stats_final_kernel(const BnArgs a) {
   a.stats[a.C + c] = (float)(1.0 / sqrt(var + (double)a.eps));
   a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
   a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)(var * N / (N - 1.0));
+}
+
+__global__ __launch_bounds__(64) void bn_bwd_final_kernel(const BnArgs a) {
+  const int c = blockIdx.x;
+  double S1, S2;
+  channel_totals(a, c, &S1, &S2);
+  if (threadIdx.x != 0) return;
+  a.stats[2 * a.C + c] = (float)S1;
+  a.stats[3 * a.C + c] = (float)S2;
+  a.g_beta[c] = (float)S1;
+  a.g_gamma[c] = (float)S2;
+}
+
+// grid (C, GB), 256 threads: block (c, j) sums channel c over windows j, j + GB, ...
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const BnArgs a) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x, j = blockIdx.y;
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = j; b < a.B; b += a.GB) {
+    const float* z = a.z.p + (long)b * a.z.ws + (long)c * a.z.ls + HALO;
+    for (int t0 = threadIdx.x; t0 < a.Lz; t0 += 1024) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // four independent loads in flight
+        const int t = t0 + u * 256;
+        const float v = t < a.Lz ? z[t] : 0.f;
+        s[u] += v;
+        q[u] = fmaf(v, v, q[u]);
+      }
+    }
+  }
+  const double S = block_sum_double((double)((s[0] + s[1]) + (s[2] + s[3])), sh);
+  const double Q = block_sum_double((double)((q[0] + q[1]) + (q[2] + q[3])), sh);
+  if (threadIdx.x == 0) {
+    a.partial[((long)c * a.GB + j) * 2] = S;
+    a.partial[((long)c * a.GB + j) * 2 + 1] = Q;
+  }
 }
 
 // grid (ceil(La / 1024), C, B)
@@ -107,39 +137,31 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const BnArgs a) {
   __shared__ double sh[4];
   const int c = blockIdx.x, j = blockIdx.y;
   const float mean = a.stats[c], rstd = a.stats[a.C + c];
-  float s1 = 0.f, s2 = 0.f;
+  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
   for (int b = j; b < a.B; b += a.GB) {
     const float* z = a.z.p + (long)b * a.z.ws + (long)c * a.z.ls + HALO + a.crop;
     const float* act = a.a.p + (long)b * a.a.ws + (long)c * a.a.ls + HALO;
     const float* g1 = a.ga1.p + (long)b * a.ga1.ws + (long)c * a.ga1.ls + HALO;
     const float* g2 = a.ga2.p ? a.ga2.p + (long)b * a.ga2.ws + (long)c * a.ga2.ls + HALO : nullptr;
-    for (int t = threadIdx.x; t < a.La; t += 256) {
-      float g = g1[t];
-      if (g2) g += g2[t];
-      if (!(act[t] > 0.f)) g = 0.f;
-      s1 += g;
-      s2 = fmaf(g, (z[t] - mean) * rstd, s2);
+    for (int t0 = threadIdx.x; t0 < a.La; t0 += 512) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = t0 + u * 256;
+        if (t < a.La) {
+          float g = g1[t];
+          if (g2) g += g2[t];
+          if (!(act[t] > 0.f)) g = 0.f;
+          s1[u] += g;
+          s2[u] = fmaf(g, (z[t] - mean) * rstd, s2[u]);
+        }
+      }
     }
   }
-  const double S1 = block_sum_double((double)s1, sh), S2 = block_sum_double((double)s2, sh);
+  const double S1 = block_sum_double((double)(s1[0] + s1[1]), sh), S2 = block_sum_double((double)(s2[0] + s2[1]), sh);
   if (threadIdx.x == 0) {
     a.partial[((long)c * a.GB + j) * 2] = S1;
     a.partial[((long)c * a.GB + j) * 2 + 1] = S2;
   }
-}
-
-__global__ void bn_bwd_final_kernel(const BnArgs a) {
-  const int c = threadIdx.x;
-  if (c >= a.C) return;
-  double S1 = 0.0, S2 = 0.0;
-  for (int j = 0; j < a.GB; ++j) {
-    S1 += a.partial[((long)c * a.GB + j) * 2];
-    S2 += a.partial[((long)c * a.GB + j) * 2 + 1];
-  }
-  a.stats[2 * a.C + c] = (float)S1;
-  a.stats[3 * a.C + c] = (float)S2;
-  a.g_beta[c] = (float)S1;
-  a.g_gamma[c] = (float)S2;
 }
 
 // grid (ceil(Lz / 1024), C, B): gz = gamma * rstd * (da' - S1/N - xhat * S2/N) over the FULL conv output
@@ -189,7 +211,6 @@ struct HeadArgs2 {
 };
 
 __global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const HeadArgs2 h) {
-  __shared__ double sh[4];
   const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
   float w[3][8], bb[3];
 #pragma unroll
@@ -240,30 +261,42 @@ __global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const HeadArgs2 h) {
       for (int k = 0; k < 8; ++k) vals[4 + c * 8 + k] = gl[c] * x[k];
     }
   }
-  const long blk = (long)blockIdx.y * gridDim.x + blockIdx.x;
+  // 28 block sums: wavefront butterflies, then the four wave results through LDS (one barrier)
+  __shared__ float shv[4][28];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < 28; ++i) {
-    const double s = block_sum_double((double)vals[i], sh);
-    if (threadIdx.x == 0) h.partial[blk * 28 + i] = s;
+    float v = vals[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) shv[wave][i] = v;
   }
+  __syncthreads();
+  const long blk = (long)blockIdx.y * gridDim.x + blockIdx.x;
+  if (threadIdx.x < 28)
+    h.partial[blk * 28 + threadIdx.x] = ((double)shv[0][threadIdx.x] + (double)shv[1][threadIdx.x]) +
+                                        ((double)shv[2][threadIdx.x] + (double)shv[3][threadIdx.x]);
 }
 
-// out[i] = sum_g partial[g * n + i]  (fixed order: run-to-run deterministic)
-__global__ __launch_bounds__(256) void sum_partials_f32_kernel(const float* __restrict__ partial, int G, int n,
-                                                               float* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+// out[r][i] = sum over rows g = r, r + R, ... of partial[g][i]  (fixed order: run-to-run deterministic).
+// grid (ceil(n / 32), R): a block owns 32 columns, its 8 row lanes stride over the rows, LDS folds the lanes.
+// R = 1 gives the final sum; a larger R is the first stage of a two-stage reduction over many rows.
+template <typename T, typename TOut>
+__global__ __launch_bounds__(256) void sum_rows_kernel(const T* __restrict__ partial, int G, int n, TOut* __restrict__ out) {
+  __shared__ double sh[8][33];
+  const int col = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+  const int R = gridDim.y, r = blockIdx.y;
   double s = 0.0;
-  for (int g = 0; g < G; ++g) s += (double)partial[(long)g * n + i];
-  out[i] = (float)s;
-}
-__global__ __launch_bounds__(256) void sum_partials_f64_kernel(const double* __restrict__ partial, int G, int n,
-                                                               double* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  double s = 0.0;
-  for (int g = 0; g < G; ++g) s += partial[(long)g * n + i];
-  out[i] = s;
+  if (col < n)
+    for (int g = r + rl * R; g < G; g += 8 * R) s += (double)partial[(long)g * n + col];
+  sh[rl][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (rl == 0 && col < n) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sh[k][threadIdx.x & 31];
+    out[(long)r * n + col] = (TOut)t;
+  }
 }
 
 // head partial sums -> loss (double), gradient slots of out.bias / out.weight
@@ -274,19 +307,17 @@ __global__ void head_final_kernel(const double* __restrict__ sums, double* loss,
   if (i >= 4 && i < 28) g_w[i - 4] = (float)sums[i];
 }
 
-// per-channel sum over (B, L) of a tensor (the conv bias gradient of `inc`), one block per channel
-__global__ __launch_bounds__(256) void channel_sum_kernel(const Rows r, int B, int L, float* out) {
+// per-channel sum over (B, L) of a tensor (the conv bias gradient of `inc`): grid (C, GB) partials, then sum_rows
+__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const Rows r, int B, int L, int GB, double* partial) {
   __shared__ double sh[4];
-  const int c = blockIdx.x;
-  double s = 0.0;
-  for (int b = 0; b < B; ++b) {
+  const int c = blockIdx.x, j = blockIdx.y;
+  float acc = 0.f;
+  for (int b = j; b < B; b += GB) {
     const float* p = r.p + (long)b * r.ws + (long)c * r.ls + HALO;
-    float acc = 0.f;
     for (int t = threadIdx.x; t < L; t += 256) acc += p[t];
-    s += (double)acc;
   }
-  s = block_sum_double(s, sh);
-  if (threadIdx.x == 0) out[c] = (float)s;
+  const double s = block_sum_double((double)acc, sh);
+  if (threadIdx.x == 0) partial[(long)j * gridDim.x + c] = s;  // [GB][C]
 }
 
 // packed MFMA A-fragments of every conv from the current weights: idx[i] = 1 + flat weight index, 0 = structural zero
@@ -345,6 +376,11 @@ struct WgradCfg {
   static constexpr int S_HI = (WH | 1) + 2;
   static constexpr int LDS_FLOATS = LOP * S_LO + HI * S_HI;
   static constexpr int OUT = LO * HI * K;
+  // few output tiles: every wave keeps ALL tiles and takes every NWAVE-th time step (split-K), folded through
+  // LDS at the end; many tiles: the tiles are dealt out to the waves and each wave walks the whole chunk
+  static constexpr bool SPLITK = TILES <= 14;
+  static constexpr int NACC = SPLITK ? TILES : TPW;
+  static_assert(!SPLITK || TILES * 256 <= LDS_FLOATS, "split-K fold reuses the staging LDS");
   static_assert(TT % 4 == 0, "time chunk must be a multiple of the MFMA k (4)");
   static_assert(LDS_FLOATS * 4 <= 64 * 1024, "static LDS budget");
 };
@@ -357,12 +393,12 @@ __global__ __launch_bounds__(64 * C::NWAVE) void wgrad_kernel(const WgradArgs a)
   constexpr int NTH = 64 * C::NWAVE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l16 = lane & 15;
-  f32x4 acc[C::TPW];
-  int a_base[C::TPW], b_base[C::TPW];
+  f32x4 acc[C::NACC];
+  int a_base[C::NACC], b_base[C::NACC];
 #pragma unroll
-  for (int i = 0; i < C::TPW; ++i) {
+  for (int i = 0; i < C::NACC; ++i) {
     acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int tile = wave + i * C::NWAVE;
+    const int tile = C::SPLITK ? i : wave + i * C::NWAVE;
     const int mt = tile / C::NT, nt = tile - mt * C::NT;
     int col = nt * 16 + l16;
     if (col >= C::COLS) col = 0;  // padding columns compute garbage that is never stored
@@ -377,43 +413,70 @@ __global__ __launch_bounds__(64 * C::NWAVE) void wgrad_kernel(const WgradArgs a)
     __syncthreads();  // previous item's MFMA reads are done
     {
       const float* lo = a.lo.p + (long)b * a.lo.ws + HALO + n_start;
-      for (int i = tid; i < C::LO * C::TT; i += NTH) {
-        const int m = i / C::TT, n = i - m * C::TT;
-        lo_s[m * C::S_LO + n] = (n_start + n < a.Ln) ? lo[(long)m * a.lo.ls + n] : 0.f;
+      for (int m = wave; m < C::LO; m += C::NWAVE) {  // one row per wave: no integer division per element
+        const float* row = lo + (long)m * a.lo.ls;
+        for (int n = lane; n < C::TT; n += 64) lo_s[m * C::S_LO + n] = (n_start + n < a.Ln) ? row[n] : 0.f;
       }
       const int s0 = C::S * n_start + a.off;  // hi sample index of staged column 0
-      for (int i = tid; i < C::HI * C::WH; i += NTH) {
-        const int h = i / C::WH, j = i - h * C::WH;
-        const int idx = s0 + j;
-        float v = 0.f;
-        if (idx >= -HALO) {
-          if (h < C::HI1) {
-            if (idx < a.lim_hi1) v = a.hi1.p[(long)b * a.hi1.ws + (long)h * a.hi1.ls + HALO + idx];
-          } else {
-            if (idx < a.lim_hi2) v = a.hi2.p[(long)b * a.hi2.ws + (long)(h - C::HI1) * a.hi2.ls + HALO + idx];
-          }
+      for (int h = wave; h < C::HI; h += C::NWAVE) {
+        const float* row = (h < C::HI1) ? a.hi1.p + (long)b * a.hi1.ws + (long)h * a.hi1.ls + HALO
+                                        : a.hi2.p + (long)b * a.hi2.ws + (long)(h - C::HI1) * a.hi2.ls + HALO;
+        const int lim = (h < C::HI1) ? a.lim_hi1 : a.lim_hi2;
+        for (int j = lane; j < C::WH; j += 64) {
+          const int idx = s0 + j;
+          hi_s[h * C::S_HI + j] = (idx >= -HALO && idx < lim) ? row[idx] : 0.f;
         }
-        hi_s[h * C::S_HI + j] = v;
       }
     }
     __syncthreads();
     int n_len = a.Ln - n_start;
     if (n_len > C::TT) n_len = C::TT;
-    for (int n0 = 0; n0 < n_len; n0 += 4) {
+    if constexpr (C::SPLITK) {
+      for (int n0 = 4 * wave; n0 < n_len; n0 += 4 * C::NWAVE) {
+        float av[C::MT];
 #pragma unroll
-      for (int i = 0; i < C::TPW; ++i) {
-        if (wave + i * C::NWAVE < C::TILES) {
-          const float av = lo_s[a_base[i] + n0];
+        for (int mt = 0; mt < C::MT; ++mt) av[mt] = lo_s[a_base[mt * C::NT] + n0];
+#pragma unroll
+        for (int i = 0; i < C::NACC; ++i) {
           const float bv = hi_s[b_base[i] + C::S * n0];
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i / C::NT], bv, acc[i], 0, 0, 0);
+        }
+      }
+    } else {
+      for (int n0 = 0; n0 < n_len; n0 += 4) {
+#pragma unroll
+        for (int i = 0; i < C::NACC; ++i) {
+          if (wave + i * C::NWAVE < C::TILES) {
+            const float av = lo_s[a_base[i] + n0];
+            const float bv = hi_s[b_base[i] + C::S * n0];
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i], 0, 0, 0);
+          }
         }
       }
     }
   }
+  if constexpr (C::SPLITK) {  // fold the waves' partial tiles into wave 0, one wave per round
+    for (int w = 1; w < C::NWAVE; ++w) {
+      __syncthreads();
+      if (wave == w) {
+#pragma unroll
+        for (int i = 0; i < C::NACC; ++i) *reinterpret_cast<f32x4*>(lds + (i * 64 + lane) * 4) = acc[i];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < C::NACC; ++i) {
+          const f32x4 o = *reinterpret_cast<const f32x4*>(lds + (i * 64 + lane) * 4);
+          acc[i] += o;
+        }
+      }
+    }
+    if (wave != 0) return;
+  }
   float* out = a.partial + (long)blockIdx.x * C::OUT;
 #pragma unroll
-  for (int i = 0; i < C::TPW; ++i) {
-    const int tile = wave + i * C::NWAVE;
+  for (int i = 0; i < C::NACC; ++i) {
+    const int tile = C::SPLITK ? i : wave + i * C::NWAVE;
     if (tile < C::TILES) {
       const int mt = tile / C::NT, nt = tile - mt * C::NT;
       const int col = nt * 16 + l16;

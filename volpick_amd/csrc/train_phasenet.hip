@@ -171,10 +171,12 @@ struct Trainer {
   float* zeros = nullptr;   // 256 zero floats (bias of bias-free convs)
   float* stats = nullptr;
   double* bn_partial = nullptr;
+  unsigned* bn_counter = nullptr;
   float* wg_partial = nullptr;
   size_t wg_partial_floats = 0;
   double* head_partial = nullptr;
   double* head_sums = nullptr;  // [28] + loss at [28]
+  double* head_stage = nullptr; // [64][28]
   float* x_dev = nullptr;       // staging for host inputs
   float* y_dev = nullptr;
   float* p_dev = nullptr;       // predictions of the last step
@@ -201,8 +203,8 @@ struct Trainer {
   }
   ~Trainer() {
     for (void* p : {(void*)arena, (void*)w, (void*)grad, (void*)adam_m, (void*)adam_v, (void*)mask, (void*)frag_idx,
-                    (void*)frag, (void*)zeros, (void*)stats, (void*)bn_partial, (void*)wg_partial, (void*)head_partial,
-                    (void*)head_sums, (void*)x_dev, (void*)y_dev, (void*)p_dev})
+                    (void*)frag, (void*)zeros, (void*)stats, (void*)bn_partial, (void*)bn_counter, (void*)wg_partial, (void*)head_partial,
+                    (void*)head_sums, (void*)head_stage, (void*)x_dev, (void*)y_dev, (void*)p_dev})
       if (p) (void)hipFree(p);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -472,7 +474,9 @@ int upload(Trainer& tr, const float* weights) {
   for (Layer& L : tr.layers) ns += 4 * (size_t)L.bn.C;
   TR_HIP(hipMalloc(&tr.stats, ns * sizeof(float)));
   TR_HIP(hipMemset(tr.stats, 0, ns * sizeof(float)));
-  TR_HIP(hipMalloc(&tr.bn_partial, (size_t)128 * 64 * 2 * sizeof(double)));
+  TR_HIP(hipMalloc(&tr.bn_partial, (size_t)128 * 256 * 2 * sizeof(double)));
+  TR_HIP(hipMalloc(&tr.bn_counter, 128 * sizeof(unsigned)));
+  TR_HIP(hipMemset(tr.bn_counter, 0, 128 * sizeof(unsigned)));
   size_t wmax = 0;
   for (Layer& L : tr.layers) {
     const size_t g = L.wg.out_n > 30000 ? 128 : 512;
@@ -484,6 +488,7 @@ int upload(Trainer& tr, const float* weights) {
   TR_HIP(hipMalloc(&tr.head_partial, hb * 28 * sizeof(double)));
   TR_HIP(hipMalloc(&tr.head_sums, 32 * sizeof(double)));
   TR_HIP(hipMemset(tr.head_sums, 0, 32 * sizeof(double)));
+  TR_HIP(hipMalloc(&tr.head_stage, 64 * 28 * sizeof(double)));
   const size_t dense = (size_t)B * 3 * T0;
   TR_HIP(hipMalloc(&tr.x_dev, dense * sizeof(float)));
   TR_HIP(hipMalloc(&tr.y_dev, dense * sizeof(float)));
@@ -540,7 +545,7 @@ BnArgs bn_args(Trainer& tr, const BnOp& b, int B) {
   a.running_var = tr.w + b.rv_off;
   a.stats = tr.stats + b.stats_off;
   a.partial = tr.bn_partial;
-  a.GB = B < 64 ? B : 64;
+  a.GB = b.Lz >= 1024 ? (B < 256 ? B : 256) : (B < 64 ? B : 64);  // more blocks for the long, few-channel layers
   a.g_gamma = tr.grad + b.gamma_off;
   a.g_beta = tr.grad + b.beta_off;
   a.eps = tr.bn_eps;
@@ -557,7 +562,7 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     run_conv(tr, L.fwd, B);
     const BnArgs a = bn_args(tr, L.bn, B);
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(a.C, a.GB), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(1), dim3(128), 0, s, a);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(a.C), dim3(64), 0, s, a);
     hipLaunchKernelGGL(bn_apply_kernel, dim3((a.La + 1023) / 1024, a.C, B), dim3(256), 0, s, a);
   }
   {
@@ -574,7 +579,11 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     h.eps = tr.loss_eps;
     const int gx = (T0 + 255) / 256;
     hipLaunchKernelGGL(head_fwd_bwd_kernel, dim3(gx, B), dim3(256), 0, s, h);
-    hipLaunchKernelGGL(sum_partials_f64_kernel, dim3(1), dim3(256), 0, s, tr.head_partial, gx * B, 28, tr.head_sums);
+    // two stages: 64 row groups, then the 64 group sums
+    hipLaunchKernelGGL((sum_rows_kernel<double, double>), dim3(1, 64), dim3(256), 0, s, tr.head_partial, gx * B, 28,
+                       tr.head_stage);
+    hipLaunchKernelGGL((sum_rows_kernel<double, double>), dim3(1, 1), dim3(256), 0, s, tr.head_stage, 64, 28,
+                       tr.head_sums);
     hipLaunchKernelGGL(head_final_kernel, dim3(1), dim3(32), 0, s, tr.head_sums, tr.head_sums + 28,
                        tr.grad + tr.poff.at("out.bias"), tr.grad + tr.poff.at("out.weight"));
   }
@@ -582,7 +591,7 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     Layer& L = tr.layers[li];
     const BnArgs a = bn_args(tr, L.bn, B);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(a.C, a.GB), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(1), dim3(128), 0, s, a);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(a.C), dim3(64), 0, s, a);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((a.Lz + 1023) / 1024, a.C, B), dim3(256), 0, s, a);
     {
       const WgradOp& w = L.wg;
@@ -603,12 +612,16 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
       const int cap = w.out_n > 30000 ? 128 : 512;
       const int grid = items < cap ? items : cap;
       w.launch(g, grid, s);
-      hipLaunchKernelGGL(sum_partials_f32_kernel, dim3((w.out_n + 255) / 256), dim3(256), 0, s, tr.wg_partial, grid,
-                         w.out_n, tr.grad + w.grad_off);
+      hipLaunchKernelGGL((sum_rows_kernel<float, float>), dim3((w.out_n + 31) / 32, 1), dim3(256), 0, s, tr.wg_partial,
+                         grid, w.out_n, tr.grad + w.grad_off);
     }
-    if (li == 0)
-      hipLaunchKernelGGL(channel_sum_kernel, dim3(8), dim3(256), 0, s, tr.rows(L.bn.gz), B, T0,
+    if (li == 0) {  // conv bias of `inc`: sum of gz per channel (zero up to rounding: BatchNorm removes the mean)
+      const int GB = B < 64 ? B : 64;
+      hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(8, GB), dim3(256), 0, s, tr.rows(L.bn.gz), B, T0, GB,
+                         tr.bn_partial);
+      hipLaunchKernelGGL((sum_rows_kernel<double, float>), dim3(1, 1), dim3(256), 0, s, tr.bn_partial, GB, 8,
                          tr.grad + tr.poff.at("inc.bias"));
+    }
     if (L.dgrad.used) run_conv(tr, L.dgrad, B);
   }
   if (update) {
