@@ -362,24 +362,28 @@ struct WgradArgs {
   int Ln;                // valid low-rate length
   int off;               // hi sample offset of tap 0 (minus the left padding)
   int B;
-  int chunks;            // time chunks per window
+  int chunks;            // time chunks per window (1 when an item holds several windows)
   float* partial;        // [gridDim.x][LO * HI * K]
 };
 
-template <int LO_, int HI1_, int HI2_, int K_, int S_, int NWAVE_, int TT_>
+// TT: low-rate samples per chunk; WB: windows per item (short layers batch several windows per LDS stage)
+template <int LO_, int HI1_, int HI2_, int K_, int S_, int NWAVE_, int TT_, int WB_ = 1>
 struct WgradCfg {
   static constexpr int LO = LO_, HI1 = HI1_, HI2 = HI2_, HI = HI1_ + HI2_, K = K_, S = S_, NWAVE = NWAVE_, TT = TT_;
+  static constexpr int WB = WB_;
   static constexpr int LOP = (LO + 15) / 16 * 16, MT = LOP / 16;
-  static constexpr int COLS = HI * K, NT = (COLS + 15) / 16, TILES = MT * NT, TPW = (TILES + NWAVE - 1) / NWAVE;
-  static constexpr int WH = S * TT + K - 1;           // staged hi samples per row
-  static constexpr int S_LO = TT + 2;                 // row strides chosen to spread rows over LDS banks
-  static constexpr int S_HI = (WH | 1) + 2;
+  static constexpr int COLS = HI * K, NT = (COLS + 15) / 16, TILES = MT * NT;
+  static constexpr int WH = S * TT + K - 1;           // staged hi samples per row and window
+  static constexpr int S_LO = WB * TT + 2;            // row strides chosen to spread rows over LDS banks
+  static constexpr int S_HI = ((WB * WH) | 1) + 2;
   static constexpr int LDS_FLOATS = LOP * S_LO + HI * S_HI;
   static constexpr int OUT = LO * HI * K;
   // few output tiles: every wave keeps ALL tiles and takes every NWAVE-th time step (split-K), folded through
-  // LDS at the end; many tiles: the tiles are dealt out to the waves and each wave walks the whole chunk
+  // LDS at the end; many tiles: a wave owns one 16-row block (A read once per step) and every NPG-th column tile
   static constexpr bool SPLITK = TILES <= 14;
-  static constexpr int NACC = SPLITK ? TILES : TPW;
+  static constexpr int NPG = SPLITK ? 1 : NWAVE / MT;       // waves sharing a row block
+  static constexpr int NACC = SPLITK ? TILES : NT / (NPG > 0 ? NPG : 1);
+  static_assert(SPLITK || (NWAVE % MT == 0 && NT % NPG == 0), "tile assignment: NWAVE = MT * NPG, NT = NPG * NACC");
   static_assert(!SPLITK || TILES * 256 <= LDS_FLOATS, "split-K fold reuses the staging LDS");
   static_assert(TT % 4 == 0, "time chunk must be a multiple of the MFMA k (4)");
   static_assert(LDS_FLOATS * 4 <= 64 * 1024, "static LDS budget");
@@ -393,62 +397,108 @@ __global__ __launch_bounds__(64 * C::NWAVE) void wgrad_kernel(const WgradArgs a)
   constexpr int NTH = 64 * C::NWAVE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l16 = lane & 15;
+  const int my_mt = C::SPLITK ? 0 : wave % C::MT, my_ng = C::SPLITK ? 0 : wave / C::MT;
+  auto tile_of = [&](const int i, int* mt, int* nt) __attribute__((always_inline)) {
+    if (C::SPLITK) {
+      *mt = i / C::NT;
+      *nt = i - *mt * C::NT;
+    } else {
+      *mt = my_mt;
+      *nt = my_ng + i * C::NPG;
+    }
+  };
   f32x4 acc[C::NACC];
-  int a_base[C::NACC], b_base[C::NACC];
+  int b_base[C::NACC];
 #pragma unroll
   for (int i = 0; i < C::NACC; ++i) {
     acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int tile = C::SPLITK ? i : wave + i * C::NWAVE;
-    const int mt = tile / C::NT, nt = tile - mt * C::NT;
+    int mt, nt;
+    tile_of(i, &mt, &nt);
     int col = nt * 16 + l16;
     if (col >= C::COLS) col = 0;  // padding columns compute garbage that is never stored
     const int k = col / C::HI, h = col - k * C::HI;
-    a_base[i] = (mt * 16 + l16) * C::S_LO + g;
     b_base[i] = h * C::S_HI + C::S * g + k;
   }
   for (int i = tid; i < (C::LOP - C::LO) * C::S_LO; i += NTH) lo_s[C::LO * C::S_LO + i] = 0.f;  // padding rows
-  const int items = a.B * a.chunks;
-  for (int item = blockIdx.x; item < items; item += gridDim.x) {
-    const int b = item / a.chunks, n_start = (item - b * a.chunks) * C::TT;
-    __syncthreads();  // previous item's MFMA reads are done
-    {
-      const float* lo = a.lo.p + (long)b * a.lo.ws + HALO + n_start;
-      for (int m = wave; m < C::LO; m += C::NWAVE) {  // one row per wave: no integer division per element
-        const float* row = lo + (long)m * a.lo.ls;
-        for (int n = lane; n < C::TT; n += 64) lo_s[m * C::S_LO + n] = (n_start + n < a.Ln) ? row[n] : 0.f;
-      }
-      const int s0 = C::S * n_start + a.off;  // hi sample index of staged column 0
-      for (int h = wave; h < C::HI; h += C::NWAVE) {
-        const float* row = (h < C::HI1) ? a.hi1.p + (long)b * a.hi1.ws + (long)h * a.hi1.ls + HALO
-                                        : a.hi2.p + (long)b * a.hi2.ws + (long)(h - C::HI1) * a.hi2.ls + HALO;
-        const int lim = (h < C::HI1) ? a.lim_hi1 : a.lim_hi2;
-        for (int j = lane; j < C::WH; j += 64) {
-          const int idx = s0 + j;
-          hi_s[h * C::S_HI + j] = (idx >= -HALO && idx < lim) ? row[idx] : 0.f;
+  // The next item's lo / hi chunks are fetched into registers while the MFMAs of the current one run
+  // (all loads of an item are issued back to back: a load -> LDS-store loop exposes the full HBM latency
+  // once per element and made this kernel 3-5x slower).
+  constexpr int N_LO = C::LO * C::WB * C::TT, N_HI = C::HI * C::WB * C::WH;
+  constexpr int NLO = (N_LO + NTH - 1) / NTH, NHI = (N_HI + NTH - 1) / NTH;
+  float pre_lo[NLO], pre_hi[NHI];
+  const int groups = (a.B + C::WB - 1) / C::WB;
+  const int items = groups * a.chunks;
+  auto fetch = [&](const int item) __attribute__((always_inline)) {
+    const int grp = item / a.chunks, n_start = (item - grp * a.chunks) * C::TT;
+    const int b0 = grp * C::WB;
+#pragma unroll
+    for (int k = 0; k < NLO; ++k) {
+      const int i = tid + k * NTH;
+      const int m = i / (C::WB * C::TT), r = i - m * (C::WB * C::TT);
+      const int w = r / C::TT, n = r - w * C::TT;
+      pre_lo[k] = (i < N_LO && b0 + w < a.B && n_start + n < a.Ln)
+                      ? a.lo.p[(long)(b0 + w) * a.lo.ws + (long)m * a.lo.ls + HALO + n_start + n]
+                      : 0.f;
+    }
+    const int s0 = C::S * n_start + a.off;  // hi sample index of staged column 0
+#pragma unroll
+    for (int k = 0; k < NHI; ++k) {
+      const int i = tid + k * NTH;
+      const int h = i / (C::WB * C::WH), r = i - h * (C::WB * C::WH);
+      const int w = r / C::WH, j = r - w * C::WH;
+      const int idx = s0 + j;
+      float v = 0.f;
+      if (i < N_HI && b0 + w < a.B && idx >= -HALO) {
+        if (h < C::HI1) {
+          if (idx < a.lim_hi1) v = a.hi1.p[(long)(b0 + w) * a.hi1.ws + (long)h * a.hi1.ls + HALO + idx];
+        } else {
+          if (idx < a.lim_hi2) v = a.hi2.p[(long)(b0 + w) * a.hi2.ws + (long)(h - C::HI1) * a.hi2.ls + HALO + idx];
         }
       }
+      pre_hi[k] = v;
+    }
+  };
+  if ((int)blockIdx.x < items) fetch(blockIdx.x);
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int grp = item / a.chunks, n_start = (item - grp * a.chunks) * C::TT;
+    __syncthreads();  // previous item's MFMA reads are done
+#pragma unroll
+    for (int k = 0; k < NLO; ++k) {
+      const int i = tid + k * NTH;
+      const int m = i / (C::WB * C::TT), r = i - m * (C::WB * C::TT);
+      if (i < N_LO) lo_s[m * C::S_LO + r] = pre_lo[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NHI; ++k) {
+      const int i = tid + k * NTH;
+      const int h = i / (C::WB * C::WH), r = i - h * (C::WB * C::WH);
+      if (i < N_HI) hi_s[h * C::S_HI + r] = pre_hi[k];
     }
     __syncthreads();
+    if (item + (int)gridDim.x < items) fetch(item + gridDim.x);
     int n_len = a.Ln - n_start;
     if (n_len > C::TT) n_len = C::TT;
-    if constexpr (C::SPLITK) {
-      for (int n0 = 4 * wave; n0 < n_len; n0 += 4 * C::NWAVE) {
-        float av[C::MT];
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) av[mt] = lo_s[a_base[mt * C::NT] + n0];
+    for (int w = 0; w < C::WB; ++w) {
+      const float* lo_w = lo_s + w * C::TT + g;
+      const float* hi_w = hi_s + w * C::WH;
+      if constexpr (C::SPLITK) {
+        for (int n0 = 4 * wave; n0 < n_len; n0 += 4 * C::NWAVE) {
+          float av[C::MT];
 #pragma unroll
-        for (int i = 0; i < C::NACC; ++i) {
-          const float bv = hi_s[b_base[i] + C::S * n0];
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i / C::NT], bv, acc[i], 0, 0, 0);
+          for (int mt = 0; mt < C::MT; ++mt) av[mt] = lo_w[(mt * 16 + l16) * C::S_LO + n0];
+#pragma unroll
+          for (int i = 0; i < C::NACC; ++i) {
+            const float bv = hi_w[b_base[i] + C::S * n0];
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i / C::NT], bv, acc[i], 0, 0, 0);
+          }
         }
-      }
-    } else {
-      for (int n0 = 0; n0 < n_len; n0 += 4) {
+      } else {
+        for (int n0 = 0; n0 < n_len; n0 += 4) {
+          const float av = lo_w[(my_mt * 16 + l16) * C::S_LO + n0];
 #pragma unroll
-        for (int i = 0; i < C::NACC; ++i) {
-          if (wave + i * C::NWAVE < C::TILES) {
-            const float av = lo_s[a_base[i] + n0];
-            const float bv = hi_s[b_base[i] + C::S * n0];
+          for (int i = 0; i < C::NACC; ++i) {
+            const float bv = hi_w[b_base[i] + C::S * n0];
             acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i], 0, 0, 0);
           }
         }
@@ -476,16 +526,14 @@ __global__ __launch_bounds__(64 * C::NWAVE) void wgrad_kernel(const WgradArgs a)
   float* out = a.partial + (long)blockIdx.x * C::OUT;
 #pragma unroll
   for (int i = 0; i < C::NACC; ++i) {
-    const int tile = C::SPLITK ? i : wave + i * C::NWAVE;
-    if (tile < C::TILES) {
-      const int mt = tile / C::NT, nt = tile - mt * C::NT;
-      const int col = nt * 16 + l16;
-      const int k = col / C::HI, h = col - k * C::HI;
+    int mt, nt;
+    tile_of(i, &mt, &nt);
+    const int col = nt * 16 + l16;
+    const int k = col / C::HI, h = col - k * C::HI;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = mt * 16 + 4 * g + r;
-        if (m < C::LO && col < C::COLS) out[((long)m * C::HI + h) * C::K + k] = acc[i][r];
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int m = mt * 16 + 4 * g + r;
+      if (m < C::LO && col < C::COLS) out[((long)m * C::HI + h) * C::K + k] = acc[i][r];
     }
   }
 }

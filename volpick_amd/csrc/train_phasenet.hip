@@ -61,7 +61,7 @@ using G_u0T = ConvCfg<64, 0, 128, 1, 7, 4, 0, 0, 4, 1, 1, 0, EPI_STORE>;
 using G_u1T = ConvCfg<32, 0, 64, 1, 7, 4, 0, 0, 4, 1, 3, 0, EPI_STORE>;
 using G_u2T = ConvCfg<16, 0, 32, 1, 7, 4, 0, 0, 2, 2, 3, 0, EPI_STORE>;
 using G_u3T = ConvCfg<8, 0, 16, 1, 7, 4, 0, 0, 1, 4, 4, 0, EPI_STORE>;
-//                     LO HI1 HI2 K S NWAVE TT
+//                     LO HI1 HI2 K S NWAVE TT [WB windows per item]
 using W_inc = WgradCfg<8, 3, 0, 7, 1, 4, 256>;
 using W_d0s = WgradCfg<8, 8, 0, 7, 1, 4, 256>;
 using W_d0d = WgradCfg<8, 8, 0, 7, 4, 4, 256>;
@@ -70,9 +70,9 @@ using W_d1d = WgradCfg<16, 16, 0, 7, 4, 4, 96>;
 using W_d2s = WgradCfg<32, 16, 0, 7, 1, 4, 192>;
 using W_d2d = WgradCfg<32, 32, 0, 7, 4, 4, 48>;
 using W_d3s = WgradCfg<64, 32, 0, 7, 1, 8, 48>;
-using W_d3d = WgradCfg<64, 64, 0, 7, 4, 16, 12>;
-using W_d4s = WgradCfg<128, 64, 0, 7, 1, 16, 12>;
-using W_u0T = WgradCfg<128, 64, 0, 7, 4, 16, 12>;
+using W_d3d = WgradCfg<64, 64, 0, 7, 4, 16, 12, 2>;
+using W_d4s = WgradCfg<128, 64, 0, 7, 1, 16, 12, 4>;
+using W_u0T = WgradCfg<128, 64, 0, 7, 4, 16, 12, 2>;
 using W_u0s = WgradCfg<64, 64, 64, 7, 1, 16, 48>;
 using W_u1T = WgradCfg<64, 32, 0, 7, 4, 8, 48>;
 using W_u1s = WgradCfg<32, 32, 32, 7, 1, 8, 96>;
@@ -96,7 +96,7 @@ struct ConvOp {
 struct WgradOp {
   int (*launch)(const WgradArgs&, int, hipStream_t) = nullptr;
   int lo = -1, hi1 = -1, hi2 = -1;
-  int Ln = 0, off = 0, TT = 0, out_n = 0;
+  int Ln = 0, off = 0, TT = 0, WB = 1, out_n = 0;
   long grad_off = 0;
 };
 
@@ -138,6 +138,7 @@ void set_wgrad(WgradOp* op, int lo, int hi1, int hi2, int Ln, int off) {
   op->Ln = Ln;
   op->off = off;
   op->TT = Cfg::TT;
+  op->WB = Cfg::WB;
   op->out_n = Cfg::OUT;
 }
 
@@ -479,7 +480,7 @@ int upload(Trainer& tr, const float* weights) {
   TR_HIP(hipMemset(tr.bn_counter, 0, 128 * sizeof(unsigned)));
   size_t wmax = 0;
   for (Layer& L : tr.layers) {
-    const size_t g = L.wg.out_n > 30000 ? 128 : 512;
+    const size_t g = L.wg.out_n > 30000 ? 256 : 512;
     wmax = std::max(wmax, g * (size_t)L.wg.out_n);
   }
   tr.wg_partial_floats = wmax;
@@ -608,8 +609,8 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
       g.B = B;
       g.chunks = (w.Ln + w.TT - 1) / w.TT;
       g.partial = tr.wg_partial;
-      const int items = B * g.chunks;
-      const int cap = w.out_n > 30000 ? 128 : 512;
+      const int items = ((B + w.WB - 1) / w.WB) * g.chunks;
+      const int cap = w.out_n > 30000 ? 256 : 512;
       const int grid = items < cap ? items : cap;
       w.launch(g, grid, s);
       hipLaunchKernelGGL((sum_rows_kernel<float, float>), dim3((w.out_n + 31) / 32, 1), dim3(256), 0, s, tr.wg_partial,
