@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--torch-gpu", action="store_true", help="also time stock PyTorch-ROCm on the same GPU")
     a = ap.parse_args()
     B = a.batch
     x, y = make_batch(B)
@@ -83,6 +84,31 @@ def main():
         ct = (time.perf_counter() - t0) / a.cpu_steps
         out["cpu_baseline"] = {"value": nb / ct, "unit": "windows/s", "cores": torch.get_num_threads(), "kind": "port",
                                "sample": f"{a.cpu_steps} steps of batch {nb} through torch autograd + Adam on the oracle module"}
+    if a.torch_gpu:
+        # the same module through stock PyTorch-ROCm (MIOpen / rocBLAS kernels) on this GPU: context only,
+        # not the reference's CPU path and not a target
+        from oracle.models import load_pretrained
+
+        gnet = load_pretrained("phasenet").cuda().train()
+        gopt = torch.optim.Adam(gnet.parameters(), lr=1e-4)
+
+        def gpu_step():
+            gopt.zero_grad(set_to_none=True)
+            pred = gnet(xd)
+            l = -(yd * torch.log(pred + 1e-5)).mean(-1).sum(-1).mean()
+            l.backward()
+            gopt.step()
+
+        for _ in range(3):
+            gpu_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            gpu_step()
+        torch.cuda.synchronize()
+        gt = (time.perf_counter() - t0) / 10
+        out["torch_rocm_same_gpu"] = {"value": B / gt, "unit": "windows/s", "ms_per_step": gt * 1e3,
+                                      "note": f"torch {torch.__version__} eager, fp32, batch {B}"}
     print(json.dumps(out))
 
 

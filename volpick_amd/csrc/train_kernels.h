@@ -299,6 +299,36 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const T* __restrict__ par
   }
 }
 
+// All weight-gradient partials of a step folded in ONE launch: job j sums `rows` rows of `n` floats into `out`.
+struct SumJob {
+  const float* partial;
+  float* out;
+  int rows, n, first_block;  // blocks [first_block, next job's first_block) own 32 columns each
+};
+constexpr int MAX_SUM_JOBS = 24;
+struct SumJobs {
+  SumJob job[MAX_SUM_JOBS];
+  int count;
+};
+__global__ __launch_bounds__(256) void sum_rows_multi_kernel(const SumJobs jobs) {
+  __shared__ double sh[8][33];
+  int j = 0;
+  while (j + 1 < jobs.count && (int)blockIdx.x >= jobs.job[j + 1].first_block) ++j;
+  const SumJob jb = jobs.job[j];
+  const int col = ((int)blockIdx.x - jb.first_block) * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+  double s = 0.0;
+  if (col < jb.n)
+    for (int g = rl; g < jb.rows; g += 8) s += (double)jb.partial[(long)g * jb.n + col];
+  sh[rl][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (rl == 0 && col < jb.n) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sh[k][threadIdx.x & 31];
+    jb.out[col] = (float)t;
+  }
+}
+
 // head partial sums -> loss (double), gradient slots of out.bias / out.weight
 __global__ void head_final_kernel(const double* __restrict__ sums, double* loss, float* g_b, float* g_w) {
   const int i = threadIdx.x;

@@ -98,6 +98,7 @@ struct WgradOp {
   int lo = -1, hi1 = -1, hi2 = -1;
   int Ln = 0, off = 0, TT = 0, WB = 1, out_n = 0;
   long grad_off = 0;
+  size_t partial_off = 0;  // slice of the shared partial buffer (all layers are folded by one launch at the end)
 };
 
 struct BnOp {
@@ -478,13 +479,13 @@ int upload(Trainer& tr, const float* weights) {
   TR_HIP(hipMalloc(&tr.bn_partial, (size_t)128 * 256 * 2 * sizeof(double)));
   TR_HIP(hipMalloc(&tr.bn_counter, 128 * sizeof(unsigned)));
   TR_HIP(hipMemset(tr.bn_counter, 0, 128 * sizeof(unsigned)));
-  size_t wmax = 0;
+  size_t wtot = 0;
   for (Layer& L : tr.layers) {
-    const size_t g = L.wg.out_n > 30000 ? 256 : 512;
-    wmax = std::max(wmax, g * (size_t)L.wg.out_n);
+    L.wg.partial_off = wtot;
+    wtot += (size_t)(L.wg.out_n > 30000 ? 256 : 512) * (size_t)L.wg.out_n;
   }
-  tr.wg_partial_floats = wmax;
-  TR_HIP(hipMalloc(&tr.wg_partial, wmax * sizeof(float)));
+  tr.wg_partial_floats = wtot;
+  TR_HIP(hipMalloc(&tr.wg_partial, wtot * sizeof(float)));
   const size_t hb = (size_t)((T0 + 255) / 256) * B;
   TR_HIP(hipMalloc(&tr.head_partial, hb * 28 * sizeof(double)));
   TR_HIP(hipMalloc(&tr.head_sums, 32 * sizeof(double)));
@@ -588,6 +589,9 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     hipLaunchKernelGGL(head_final_kernel, dim3(1), dim3(32), 0, s, tr.head_sums, tr.head_sums + 28,
                        tr.grad + tr.poff.at("out.bias"), tr.grad + tr.poff.at("out.weight"));
   }
+  SumJobs jobs{};
+  int sum_blocks = 0;
+  static_assert(NLAYER <= MAX_SUM_JOBS, "one sum job per layer");
   for (int li = NLAYER - 1; li >= 0; --li) {
     Layer& L = tr.layers[li];
     const BnArgs a = bn_args(tr, L.bn, B);
@@ -608,13 +612,18 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
       g.off = w.off;
       g.B = B;
       g.chunks = (w.Ln + w.TT - 1) / w.TT;
-      g.partial = tr.wg_partial;
+      g.partial = tr.wg_partial + w.partial_off;
       const int items = ((B + w.WB - 1) / w.WB) * g.chunks;
       const int cap = w.out_n > 30000 ? 256 : 512;
       const int grid = items < cap ? items : cap;
       w.launch(g, grid, s);
-      hipLaunchKernelGGL((sum_rows_kernel<float, float>), dim3((w.out_n + 31) / 32, 1), dim3(256), 0, s, tr.wg_partial,
-                         grid, w.out_n, tr.grad + w.grad_off);
+      SumJob& jb = jobs.job[jobs.count++];
+      jb.partial = g.partial;
+      jb.out = tr.grad + w.grad_off;
+      jb.rows = grid;
+      jb.n = w.out_n;
+      jb.first_block = sum_blocks;
+      sum_blocks += (w.out_n + 31) / 32;
     }
     if (li == 0) {  // conv bias of `inc`: sum of gz per channel (zero up to rounding: BatchNorm removes the mean)
       const int GB = B < 64 ? B : 64;
@@ -625,6 +634,7 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     }
     if (L.dgrad.used) run_conv(tr, L.dgrad, B);
   }
+  hipLaunchKernelGGL(sum_rows_multi_kernel, dim3(sum_blocks), dim3(256), 0, s, jobs);
   if (update) {
     tr.step += 1;
     const float bc1 = 1.f - powf(tr.beta1, (float)tr.step);
