@@ -252,12 +252,15 @@ int vp_mseed_decode_bench(int device_id, const uint8_t* buf_dev, size_t nbytes, 
  * step with learning rate lr (the caller owns the schedule, e.g. the reference's 500-step
  * warm-up, models.py:168-175).  x, y: (B, 3, 3001) fp32, host or device (mem).  *loss (may be
  * NULL; non-NULL synchronises) receives the batch loss.  vp_train_read copies out 0 = weights,
- * 1 = gradients of the last step, 2/3 = Adam first/second moments. */
+ * 1 = gradients of the last step, 2/3 = Adam first/second moments, 4 = EMA weights. */
 typedef struct vp_trainer vp_trainer;
 int vp_train_create(int device_id, int model_kind, const float* weights, size_t n_floats, int max_batch,
                     vp_trainer** out);
 int vp_train_destroy(vp_trainer* t);
 int vp_train_set_hyper(vp_trainer* t, float beta1, float beta2, float adam_eps, float bn_momentum, float loss_eps);
+/* Optional exponential moving average of the weights after every update (the reference's EMA callback,
+ * volpick/model/train.py:153-176: decay 0.999, every step); starts at the current weights. */
+int vp_train_set_ema(vp_trainer* t, float decay);
 int vp_train_step(vp_trainer* t, const float* x, const float* y, int mem, int B, float lr, int update, double* loss);
 int vp_train_synchronize(vp_trainer* t);
 int vp_train_read(vp_trainer* t, int which, float* out, size_t n_floats);

@@ -187,3 +187,27 @@ def test_read_then_classify_equals_classify_of_the_arrays():
     assert len(a) == len(b) > 0
     for p, q in zip(a, b):
         assert p.phase == q.phase and p.peak_time == q.peak_time and p.peak_value == q.peak_value
+    # device-resident traces: decoded, assembled and classified without visiting the host
+    buf = file_bytes(traces, encoding=11, reclen=4096)
+    dst = va.read(buf, device_resident=True)
+    assert all(tr._data is None and tr._dev.is_cuda for tr in dst) and [len(tr) for tr in dst] == [60_000] * 3
+    c = m.classify(dst).picks
+    assert all(tr._data is None for tr in dst)  # classify did not materialise host copies
+    assert len(c) == len(b)
+    for p, q in zip(c, b):
+        assert p.phase == q.phase and p.peak_time == q.peak_time and p.peak_value == q.peak_value
+    ann_d, ann_h = m.annotate(dst), m.annotate(ref)
+    for x, y in zip(ann_d, ann_h):
+        assert x.stats.channel == y.stats.channel and np.array_equal(x.data, y.data, equal_nan=True)
+    for tr, w in zip(dst, st):  # .data materialises the same samples on demand
+        assert np.array_equal(tr.data, w.data) and tr.stats.mseed == w.stats.mseed
+    # gaps between device-resident segments are zero-filled / split exactly like host traces
+    mk = lambda s, d, ch: dict(network="XX", station="GAP", location="", channel=ch, start_us=s, rate=100.0, data=d)
+    segs = []
+    for i, ch in enumerate(("HHZ", "HHN", "HHE")):
+        segs += [mk(T0, counts[i, :20_000], ch), mk(T0 + 250_000_000, counts[i, 25_000:], ch)]  # 50 s gap
+    gbuf = file_bytes(segs, encoding=11)
+    pg_d, pg_h = m.classify(va.read(gbuf, device_resident=True)).picks, m.classify(va.read(gbuf)).picks
+    assert len(pg_d) == len(pg_h) > 0
+    for p, q in zip(pg_d, pg_h):
+        assert p.phase == q.phase and p.peak_time == q.peak_time and p.peak_value == q.peak_value

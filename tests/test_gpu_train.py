@@ -169,6 +169,24 @@ def test_training_reduces_the_loss_and_lit_schedule():
     assert np.isfinite(val)
 
 
+def test_ema_tracks_the_weights():
+    tr = PhaseNetTrainer(PhaseNet.from_pretrained("volpick"), max_batch=8)
+    with pytest.raises(Exception, match="EMA is off"):
+        tr.ema_weights()
+    tr.enable_ema(0.9)
+    x, y = make_batch(8, 5)
+    want = {k: v.astype(np.float64) for k, v in tr.weights().items()}
+    for _ in range(3):
+        tr.step(x, y, 1e-3)
+        w = tr.weights()
+        for k in want:
+            want[k] = w[k] if "running_" in k else 0.9 * want[k] + 0.1 * w[k]
+    got = tr.ema_weights()
+    for k in want:
+        assert np.abs(got[k] - want[k]).max() < 1e-6, k
+    assert np.abs(got["inc.weight"] - w["inc.weight"]).max() > 1e-5  # it lags behind the live weights
+
+
 def test_argument_errors():
     tr = PhaseNetTrainer(PhaseNet.from_pretrained("volpick"), max_batch=4)
     x, y = make_batch(4, 3)

@@ -66,6 +66,12 @@ def main():
     st = va.read(buf)
     t_read = time.perf_counter() - t0
     assert sum(tr.stats.npts for tr in st) == total
+    va.read(buf[: len(buf) // 24], device_resident=True)
+    t0 = time.perf_counter()
+    std = va.read(buf, device_resident=True)
+    torch.cuda.synchronize()
+    t_read_dev = time.perf_counter() - t0
+    assert sum(tr.stats.npts for tr in std) == total
     # CPU baseline: the oracle's decoder on a bounded sample of records
     k = min(len(recs), 200)
     orecs = OM.scan_records(buf[: int(recs["offset"][k - 1] + recs["reclen"][k - 1])])
@@ -78,7 +84,7 @@ def main():
         "samples": total, "file_bytes": len(buf), "bytes_per_sample": len(buf) / total,
         "roofline": {"bound": "hbm", "achieved": algo_bytes / (ms.value * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": algo_bytes / (ms.value * 1e-3) / 8e12, "algorithmic_bytes": algo_bytes},
-        "read_wall_ms": t_read * 1e3, "scan_ms": t_scan * 1e3,
+        "read_wall_ms": t_read * 1e3, "read_device_resident_wall_ms": t_read_dev * 1e3, "scan_ms": t_scan * 1e3,
         "cpu_baseline": {"value": n_cpu / t_cpu, "unit": "samples/s", "cores": 1, "kind": "port",
                          "sample": f"{k} records through oracle/mseed.py (numpy/Python)"},
     }))

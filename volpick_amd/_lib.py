@@ -147,6 +147,7 @@ SIGNATURES = {
     "vp_train_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(_H)]),
     "vp_train_destroy": (C.c_int, [_H]),
     "vp_train_set_hyper": (C.c_int, [_H, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "vp_train_set_ema": (C.c_int, [_H, C.c_float]),
     "vp_train_step": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(C.c_double)]),
     "vp_train_synchronize": (C.c_int, [_H]),
     "vp_train_read": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_size_t]),

@@ -359,20 +359,31 @@ __global__ __launch_bounds__(256) void gather_pack_kernel(const int* __restrict_
   out[i] = k > 0 ? w[k - 1] : 0.f;
 }
 
-// torch.optim.Adam (no weight decay, no amsgrad); `mask` = 1 for trainable entries, 0 for the BN running statistics
+// torch.optim.Adam (no weight decay, no amsgrad); `mask` = 1 for trainable entries, 0 for the BN running statistics.
+// ema (may be null): exponential moving average of the weights after the step, ema = d * ema + (1 - d) * w
+// (the reference's optional EMA callback, volpick/model/train.py:153-176, decay 0.999, every step); the running
+// statistics are buffers, not parameters: their EMA slots simply track the current values.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
-                                                   const float* __restrict__ mask, int n, float lr, float b1, float b2,
-                                                   float eps, float bc1, float bc2_sqrt) {
+                                                   const float* __restrict__ mask, float* __restrict__ ema, int n, float lr,
+                                                   float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                   float ema_decay) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n || mask[i] == 0.f) return;
-  const float gi = g[i];
-  const float mi = b1 * m[i] + (1.f - b1) * gi;
-  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-  m[i] = mi;
-  v[i] = vi;
-  const float denom = sqrtf(vi) / bc2_sqrt + eps;
-  w[i] -= (lr / bc1) * (mi / denom);
+  if (i >= n) return;
+  float wi = w[i];
+  if (mask[i] != 0.f) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    wi -= (lr / bc1) * (mi / denom);
+    w[i] = wi;
+    if (ema) ema[i] = ema_decay * ema[i] + (1.f - ema_decay) * wi;
+  } else if (ema) {
+    ema[i] = wi;
+  }
 }
 
 // ------------------------------------------------------------------------------------------

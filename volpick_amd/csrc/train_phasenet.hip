@@ -167,6 +167,8 @@ struct Trainer {
   float* adam_m = nullptr;
   float* adam_v = nullptr;
   float* mask = nullptr;
+  float* ema = nullptr;     // EMA of the weights (allocated by vp_train_set_ema)
+  float ema_decay = 0.f;
   int* frag_idx = nullptr;
   float* frag = nullptr;
   size_t frag_n = 0;
@@ -204,7 +206,7 @@ struct Trainer {
     return Rows{t.p + (long)ch * t.ls, t.ls, (long)t.win_stride()};
   }
   ~Trainer() {
-    for (void* p : {(void*)arena, (void*)w, (void*)grad, (void*)adam_m, (void*)adam_v, (void*)mask, (void*)frag_idx,
+    for (void* p : {(void*)arena, (void*)w, (void*)grad, (void*)adam_m, (void*)adam_v, (void*)mask, (void*)ema, (void*)frag_idx,
                     (void*)frag, (void*)zeros, (void*)stats, (void*)bn_partial, (void*)bn_counter, (void*)wg_partial, (void*)head_partial,
                     (void*)head_sums, (void*)head_stage, (void*)x_dev, (void*)y_dev, (void*)p_dev})
       if (p) (void)hipFree(p);
@@ -640,8 +642,8 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     const float bc1 = 1.f - powf(tr.beta1, (float)tr.step);
     const float bc2 = 1.f - powf(tr.beta2, (float)tr.step);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((tr.n_params + 255) / 256)), dim3(256), 0, s, tr.w, tr.grad,
-                       tr.adam_m, tr.adam_v, tr.mask, (int)tr.n_params, lr, tr.beta1, tr.beta2, tr.adam_eps, bc1,
-                       sqrtf(bc2));
+                       tr.adam_m, tr.adam_v, tr.mask, tr.ema, (int)tr.n_params, lr, tr.beta1, tr.beta2, tr.adam_eps, bc1,
+                       sqrtf(bc2), tr.ema_decay);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -694,6 +696,17 @@ int vp_train_set_hyper(vp_trainer* h, float beta1, float beta2, float adam_eps, 
   return VP_OK;
 }
 
+int vp_train_set_ema(vp_trainer* h, float decay) {
+  VP_REQUIRE(h && decay >= 0.f && decay < 1.f, "vp_train_set_ema: bad argument");
+  Trainer& tr = *reinterpret_cast<Trainer*>(h);
+  VP_HIP(hipSetDevice(tr.device));
+  VP_HIP(hipStreamSynchronize(tr.stream));
+  if (!tr.ema) VP_HIP(hipMalloc(&tr.ema, tr.n_params * sizeof(float)));
+  VP_HIP(hipMemcpy(tr.ema, tr.w, tr.n_params * sizeof(float), hipMemcpyDeviceToDevice));  // starts at the current weights
+  tr.ema_decay = decay;
+  return VP_OK;
+}
+
 int vp_train_step(vp_trainer* h, const float* x, const float* y, int mem, int B, float lr, int update, double* loss) {
   VP_REQUIRE(h && x && y, "vp_train_step: null argument");
   Trainer& tr = *reinterpret_cast<Trainer*>(h);
@@ -722,12 +735,13 @@ int vp_train_synchronize(vp_trainer* h) {
   return VP_OK;
 }
 
-// which: 0 weights (incl. BN running statistics), 1 gradients of the last step, 2 Adam m, 3 Adam v
+// which: 0 weights (incl. BN running statistics), 1 gradients of the last step, 2 Adam m, 3 Adam v, 4 EMA weights
 int vp_train_read(vp_trainer* h, int which, float* out, size_t n_floats) {
   VP_REQUIRE(h && out, "vp_train_read: null argument");
   Trainer& tr = *reinterpret_cast<Trainer*>(h);
-  VP_REQUIRE(n_floats == tr.n_params && which >= 0 && which <= 3, "vp_train_read: bad size or selector");
-  const float* src = which == 0 ? tr.w : which == 1 ? tr.grad : which == 2 ? tr.adam_m : tr.adam_v;
+  VP_REQUIRE(n_floats == tr.n_params && which >= 0 && which <= 4, "vp_train_read: bad size or selector");
+  VP_REQUIRE(which != 4 || tr.ema, "vp_train_read: EMA is off (vp_train_set_ema)");
+  const float* src = which == 0 ? tr.w : which == 1 ? tr.grad : which == 2 ? tr.adam_m : which == 3 ? tr.adam_v : tr.ema;
   VP_HIP(hipSetDevice(tr.device));
   VP_HIP(hipStreamSynchronize(tr.stream));
   VP_HIP(hipMemcpy(out, src, n_floats * sizeof(float), hipMemcpyDeviceToHost));

@@ -82,11 +82,14 @@ def _segments(recs):
     return r, seg
 
 
-def read_mseed(source, device=0, dtype=None):
+def read_mseed(source, device=0, dtype=None, device_resident=False):
     """miniSEED -> Stream (one Trace per continuous segment, sorted by id and time).
 
     Integer encodings decode to int32 exactly; float32/float64 records to float32.  ``dtype``
     forces the sample type of every trace (``np.float32`` decodes integers straight to fp32).
+    ``device_resident=True`` leaves the decoded samples on the GPU: the traces are backed by CUDA
+    tensors, ``classify`` / ``annotate`` assemble and consume them there, and ``trace.data`` copies
+    to the host only when somebody reads it.
     """
     buf = _as_bytes(source)
     lib = _lib.load()
@@ -103,12 +106,21 @@ def read_mseed(source, device=0, dtype=None):
             continue
         ns = np.where(sel, r["nsamples"], 0).astype(np.int64)
         index = np.where(sel, np.cumsum(ns) - ns, -1).astype(np.int64)
-        out = np.empty(int(ns.sum()), dtype=np.int32 if kind == _lib.VP_SAMPLES_INT32 else np.float32)
+        n_out = int(ns.sum())
         status = np.zeros(len(r), np.int32)
+        if device_resident:
+            import torch
+
+            out = torch.empty(n_out, dtype=torch.int32 if kind == _lib.VP_SAMPLES_INT32 else torch.float32,
+                              device=torch.device("cuda", device))
+            out_ptr, out_mem = C.c_void_p(out.data_ptr()), _lib.VP_MEM_DEVICE
+        else:
+            out = np.empty(n_out, dtype=np.int32 if kind == _lib.VP_SAMPLES_INT32 else np.float32)
+            out_ptr, out_mem = out.ctypes.data_as(C.c_void_p), _lib.VP_MEM_HOST
         _lib.check(
             lib.vp_mseed_decode(device, buf, _lib.VP_MEM_HOST, len(buf), recs_c,
                                 index.ctypes.data_as(C.POINTER(C.c_int64)), None, len(r), kind,
-                                out.ctypes.data_as(C.c_void_p), _lib.VP_MEM_HOST, out.size, 0,
+                                out_ptr, out_mem, n_out, 0,
                                 status.ctypes.data_as(C.POINTER(C.c_int32))), "vp_mseed_decode")
         if (status == 2).any():
             bad = int(np.flatnonzero(status == 2)[0])
@@ -122,12 +134,16 @@ def read_mseed(source, device=0, dtype=None):
         out, index, status = buffers[kind]
         n = int(r["nsamples"][a:b].sum())
         data = out[index[a]:index[a] + n]
-        if dtype is not None and data.dtype != np.dtype(dtype):
-            data = data.astype(dtype)
-        tr = Trace(data, dict(network=r["network"][a].decode(), station=r["station"][a].decode(),
+        if device_resident:
+            tr_args = dict(device_data=data)
+        else:
+            if dtype is not None and data.dtype != np.dtype(dtype):
+                data = data.astype(dtype)
+            tr_args = dict(data=data)
+        tr = Trace(header=dict(network=r["network"][a].decode(), station=r["station"][a].decode(),
                               location=r["location"][a].decode(), channel=r["channel"][a].decode(),
                               starttime=UTCDateTime._from_us(int(r["start_us"][a])),
-                              sampling_rate=float(r["sample_rate"][a])))
+                              sampling_rate=float(r["sample_rate"][a])), **tr_args)
         tr.stats["mseed"] = dict(dataquality=chr(int(r["quality"][a])), number_of_records=int(b - a),
                                  encoding=int(r["encoding"][a]), byteorder=">" if r["big_endian"][a] else "<",
                                  record_length=int(r["reclen"][a]),
@@ -169,13 +185,13 @@ def read_sac(source):
     return Stream([tr])
 
 
-def read(source, format=None, device=0, dtype=None):
+def read(source, format=None, device=0, dtype=None, device_resident=False):
     """``obspy.read`` for the two formats the reference's data pipeline handles (miniSEED, SAC);
     the format is auto-detected from the header unless given."""
     buf = _as_bytes(source)
     fmt = (format or ("MSEED" if _looks_like_mseed(buf) else "SAC")).upper()
     if fmt == "MSEED":
-        return read_mseed(buf, device=device, dtype=dtype)
+        return read_mseed(buf, device=device, dtype=dtype, device_resident=device_resident)
     if fmt == "SAC":
         return read_sac(buf)
     raise ValueError(f"unsupported waveform format {fmt!r} (MSEED and SAC are implemented)")

@@ -361,7 +361,10 @@ class WaveformModel:
         h = self._ensure_handle()
         dev = torch.device("cuda", self._device_index)
         n = data.shape[1]
-        x = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(dev)
+        if torch.is_tensor(data):  # assembled on the device by _group_stream
+            x = data.to(dev, torch.float32).contiguous()
+        else:
+            x = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(dev)
         out = torch.empty((3, n), dtype=torch.float32, device=dev)
         torch.cuda.current_stream(dev).synchronize()
         fv, lv, nw = C.c_int64(), C.c_int64(), C.c_int64()
@@ -394,7 +397,10 @@ class WaveformModel:
         h = self._context(ctx)
         dev = torch.device("cuda", self._device_index)
         n = data.shape[1]
-        x = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(dev)
+        if torch.is_tensor(data):  # assembled on the device by _group_stream
+            x = data.to(dev, torch.float32).contiguous()
+        else:
+            x = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(dev)
         torch.cuda.current_stream(dev).synchronize()
         c_specs = (_lib.VpTriggerSpec * len(specs))(*[_lib.VpTriggerSpec(r, on, off) for r, _, on, off in specs])
         stacking = _lib.VP_STACK_AVG if args["stacking"] == "avg" else _lib.VP_STACK_MAX
@@ -545,7 +551,8 @@ def _group_stream(stream, component_order, sampling_rate, copy, in_samples):
             comp = tr.stats.channel[-1] if tr.stats.channel else ""
             comp = comp if comp in component_order else comp_alias.get(comp, comp)
             s0 = int(round((UTCDateTime(tr.stats.starttime) - t_start) * sampling_rate))
-            pieces.append((s0, len(tr.data), component_order.index(comp) if comp in component_order else -1, tr))
+            npts = int(tr.stats.npts) if getattr(tr, "_dev", None) is not None else len(tr.data)
+            pieces.append((s0, npts, component_order.index(comp) if comp in component_order else -1, tr))
         # contiguous covered runs (union over all components) become independent blocks; gaps are not bridged
         runs = []
         for s0, l, _, _ in sorted(pieces, key=lambda p: p[0]):
@@ -560,10 +567,19 @@ def _group_stream(stream, component_order, sampling_rate, copy, in_samples):
                 warnings.warn("Parts of the input stream consist of fragments shorter than the number of input "
                               "samples. Output might be empty.")
                 continue
-            data = np.zeros((len(component_order), b1 - b0), dtype=np.float32)
+            used = [p for p in pieces if p[2] >= 0 and min(p[0] + p[1], b1) > max(p[0], b0)]
+            on_device = bool(used) and all(getattr(p[3], "_dev", None) is not None for p in used)
+            if on_device:  # traces decoded on the GPU (read(..., device_resident=True)): assemble there, no host copy
+                torch = _torch()
+                data = torch.zeros((len(component_order), b1 - b0), dtype=torch.float32, device=used[0][3]._dev.device)
+            else:
+                data = np.zeros((len(component_order), b1 - b0), dtype=np.float32)
             for s0, l, c, tr in sorted(pieces, key=lambda p: p[1]):  # shorter first: longer traces win overlaps
                 lo, hi = max(s0, b0), min(s0 + l, b1)
                 if c < 0 or hi <= lo:
+                    continue
+                if on_device:
+                    data[c, lo - b0 : hi - b0] = tr._dev[lo - s0 : hi - s0]  # casts int counts to float32
                     continue
                 d = tr.data[lo - s0 : hi - s0]
                 if np.ma.isMaskedArray(d):

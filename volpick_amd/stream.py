@@ -145,10 +145,32 @@ class Stats(dict):
 
 
 class Trace:
-    def __init__(self, data=None, header=None):
-        self.data = np.asarray(data if data is not None else np.zeros(0, dtype=np.float32))
+    """``data`` is a numpy array.  A trace may instead be backed by a device array (``device_data``: a CUDA
+    torch tensor, as ``volpick_amd.read(..., device_resident=True)`` produces); ``data`` then materialises a
+    host copy on first access, and the picker consumes the device array directly."""
+
+    def __init__(self, data=None, header=None, device_data=None):
+        self._dev = device_data
+        if data is None and device_data is not None:
+            self._data = None
+            n = int(device_data.shape[0])
+        else:
+            self._data = np.asarray(data if data is not None else np.zeros(0, dtype=np.float32))
+            n = len(self._data)
         self.stats = Stats(header)
-        self.stats["npts"] = len(self.data)
+        self.stats["npts"] = n
+
+    @property
+    def data(self):
+        if self._data is None:
+            self._data = self._dev.cpu().numpy()
+        return self._data
+
+    @data.setter
+    def data(self, value):
+        self._data = np.asarray(value)
+        self._dev = None
+        self.stats["npts"] = len(self._data)
 
     @property
     def id(self):
@@ -165,11 +187,11 @@ class Trace:
         return Trace(self.data.copy(), self.stats.copy())
 
     def __len__(self):
-        return len(self.data)
+        return int(self.stats["npts"])
 
     def __str__(self):
         s = self.stats
-        return f"{self.id} | {s.starttime} - {s.endtime} | {s.sampling_rate:.1f} Hz, {len(self.data)} samples"
+        return f"{self.id} | {s.starttime} - {s.endtime} | {s.sampling_rate:.1f} Hz, {len(self)} samples"
 
     __repr__ = __str__
 

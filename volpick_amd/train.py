@@ -121,6 +121,13 @@ class PhaseNetTrainer:
     def gradients(self):
         return self._named(self._read(1))
 
+    def enable_ema(self, decay=0.999):
+        """Exponential moving average of the weights after every update (train.py:153-176 of the reference)."""
+        _lib.check(self._lib.vp_train_set_ema(self._h, float(decay)), "vp_train_set_ema")
+
+    def ema_weights(self):
+        return self._named(self._read(4))
+
     def adam_state(self):
         return self._named(self._read(2)), self._named(self._read(3))
 
