@@ -10,7 +10,7 @@
 //   picks     2 x [LSTM + banded attention]                  pick_branch_kernel
 //   decoders  3 x 7 x [Upsample(2) + Conv1d + ReLU]          conv_mfma_kernel, three weight sets per launch,
 //                                                            the producer writes its rows x2-upsampled
-//   heads     3 x [Conv1d(8,1,11) + sigmoid]                 head_kernel
+//   heads     3 x [Conv1d(8,1,11) + sigmoid]                 epilogue of decoder.6 (EPI_HEAD)
 #include "eqt_kernels.h"
 #include "net.h"
 

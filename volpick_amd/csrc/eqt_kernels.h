@@ -1,6 +1,6 @@
 // EQTransformer bottleneck kernels (sequence length 47, 16 channels): BiLSTM blocks,
-// additive-attention transformer blocks, the P/S pick branches (LSTM + banded attention)
-// and the 8->1 sigmoid heads.  SURVEY.md §8a row A5, Appendix A.4/B.2.
+// additive-attention transformer blocks and the P/S pick branches (LSTM + banded attention).
+// (The 8->1 sigmoid heads run in the epilogue of the last decoder conv, conv_mfma.h EPI_HEAD.)  SURVEY.md §8a row A5, Appendix A.4/B.2.
 //
 // These stages are latency-bound (47 sequential LSTM steps; 47x47x32 tanh per attention)
 // and hold <2 % of the model's FLOPs, so they are plain VALU code: one workgroup per
@@ -72,19 +72,8 @@ struct PickBranchArgs {
   int width;         // band width (3)
 };
 
-struct HeadArgs {
-  const float* src;  // [3B][8][ls]
-  int ls_src;
-  long ws_src;
-  float* y;          // dense [B][3][T]
-  const float* w;    // [3 sets][8][11]
-  const float* b;    // [3]
-  int B, T;
-};
-
 int launch_bilstm(const BiLstmArgs& a, int cin, int B, hipStream_t s);
 int launch_transformer(const TransformerArgs& a, int B, hipStream_t s);
 int launch_pick_branch(const PickBranchArgs& a, hipStream_t s);
-int launch_head(const HeadArgs& a, hipStream_t s);
 
 }  // namespace vp

@@ -309,34 +309,4 @@ int launch_pick_branch(const PickBranchArgs& a, hipStream_t s) {
   return 0;
 }
 
-// ---------------------------------------------------------------------------------------
-// Conv1d(8,1,11,pad 5) + sigmoid heads of the three decoders -> dense (B,3,T) output.
-__global__ __launch_bounds__(256) void head_kernel(const HeadArgs a) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  const int win = blockIdx.y;  // set-major: win = d * B + b
-  const int d = win / a.B, b = win - d * a.B;
-  if (t >= a.T) return;
-  const float* src = a.src + (long)win * a.ws_src + HALO + t - 5;
-  const float* w = a.w + d * 88;
-  float a0 = a.b[d], a1 = 0.f;
-#pragma unroll
-  for (int ci = 0; ci < 8; ++ci) {
-#pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float x = src[(long)ci * a.ls_src + k];
-      if (k & 1) {
-        a1 = fmaf(w[ci * 11 + k], x, a1);
-      } else {
-        a0 = fmaf(w[ci * 11 + k], x, a0);
-      }
-    }
-  }
-  a.y[((long)b * 3 + d) * a.T + t] = sigmoid_f(a0 + a1);
-}
-
-int launch_head(const HeadArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(head_kernel, dim3((a.T + 255) / 256, 3 * a.B), dim3(256), 0, s, a);
-  return 0;
-}
-
 }  // namespace vp

@@ -94,10 +94,9 @@ struct Net {
 };
 
 int plan_phasenet(Net& net, const ParamView& pv);
-int plan_phasenet_fused(Net& net, int debug_flags);  // bit0: dump LDS intermediates, bit1: clock stamps;  // swaps the 18 layer steps for 3 fused launches
+int plan_phasenet_fused(Net& net, int debug_flags);  // swaps the 18 layer steps for 3 fused launches; bit0: dump LDS intermediates, bit1: clock stamps
 int plan_eqt(Net& net, const ParamView& pv);
-int plan_eqt_fuse_res(Net& net);
-int plan_eqt_fuse_dec_tail(Net& net);  // decoder.5 + decoder.6 + heads as one tiled launch  // swaps the 14 ResCNN conv steps for one fused launch
+int plan_eqt_fuse_res(Net& net);  // swaps the 14 ResCNN conv steps for one fused launch
 
 // BatchNorm (eval) folded into the preceding conv: scale = gamma / sqrt(var + eps),
 // shift = beta - mean * scale (+ conv bias * scale).
