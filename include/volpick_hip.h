@@ -148,6 +148,20 @@ int vp_pick_windows(vp_handle* h, const float* prob, int prob_mem, int B, int n_
                     const int32_t* hi, float thr_on, float thr_off, int K, int32_t* count, int32_t* peak,
                     float* value);
 
+/* vp_classify over K stream blocks (stations / contiguous segments) in ONE call: the windows of all blocks
+ * share the forward batches -- SeisBench's batch_size spans every fragment of the stream it is given
+ * (/root/reference README.md:54-66) -- and stacking and the trigger scan are one launch each.
+ * `streams` (host or device) holds block k as 3 rows of lengths[k] samples at float offset offsets[k];
+ * `out` (may be NULL) receives the stacked rows in the same layout.  first_valid / last_valid / n_windows
+ * are arrays of K.  Triggers come back grouped by block, then spec, sorted by onset, with block_of /
+ * spec_of; every (block, spec) row has room for cap_per_row triggers on the device.  *n_found > cap (or a row
+ * with more than cap_per_row triggers) means: call again with more room. */
+int vp_classify_multi(vp_handle* h, const float* streams, int stream_mem, const int64_t* offsets,
+                      const int64_t* lengths, int K, int overlap, int blind_l, int blind_r, int stacking, int batch,
+                      const vp_trigger_spec* specs, int n_specs, float* out, int out_mem, int64_t* first_valid,
+                      int64_t* last_valid, int64_t* n_windows, int64_t* on, int64_t* off, int64_t* peak, float* value,
+                      int32_t* spec_of, int32_t* block_of, int cap_per_row, int cap, int* n_found);
+
 /* Host-only variant of vp_pick for traces already in host memory (no handle, no GPU). */
 int vp_pick_host(const float* trace, int64_t n, float thr_on, float thr_off, int64_t* on, int64_t* off,
                  int64_t* peak, float* value, int cap, int* n_found);

@@ -91,3 +91,113 @@ def test_stage_timing_is_opt_in():
     lib.vp_last_timing(model._handle, C.byref(total), stage)
     assert stage[1] > 0 and stage[2] > 0 and stage[3] > 0 and abs(total.value - sum(stage)) < 1e-3
     lib.vp_set_timing(model._handle, 0)
+
+
+def _many_stations(n_sta, seed0=300):
+    from volpick_amd import Stream, Trace, UTCDateTime
+    from volpick_amd.synthetic import synthetic_stream_array
+
+    t0 = UTCDateTime("2021-03-04T05:06:07")
+    trs, arrays = [], {}
+    for s in range(n_sta):
+        n = 30_000 + 4_321 * (s % 5)  # ragged lengths
+        data, _, _ = synthetic_stream_array(n, seed=seed0 + s, n_events=3)
+        arrays[f"S{s:02d}"] = data
+        for i, c in enumerate("ZNE"):
+            trs.append(Trace(data[i], dict(network="XX", station=f"S{s:02d}", location="", channel="HH" + c,
+                                           starttime=t0 + 7.0 * s, sampling_rate=100.0)))
+    return Stream(trs), arrays
+
+
+@pytest.mark.parametrize("cls", [va.PhaseNet, va.EQTransformer])
+def test_windows_of_many_stations_share_batches(cls):
+    """classify() of a multi-station stream through vp_classify_multi (windows of all blocks fill the forward
+    batches together) gives exactly the picks of the block-by-block path."""
+    import torch
+
+    from volpick_amd import Stream, Trace
+
+    host_st, _ = _many_stations(9)
+    # the same traces backed by device arrays (what read(..., device_resident=True) produces)
+    st = Stream([Trace(header=dict(tr.stats), device_data=torch.from_numpy(tr.data).cuda()) for tr in host_st])
+    m = cls.from_pretrained("volpick").cuda()
+    kw = dict(overlap=m.in_samples // 2, blinding=(250, 250), P_threshold=0.2, S_threshold=0.2)
+    a = m.classify(st, **kw)          # device blocks: vp_classify_multi
+    b = m.classify(host_st, **kw)     # host blocks: one vp_classify_submit per block
+    assert len(a.picks) == len(b.picks) > 0 and len(a.detections) == len(b.detections)
+    for p, q in zip(a.picks, b.picks):
+        assert (p.trace_id, p.phase, p.peak_time, p.start_time, p.end_time, p.peak_value) == (
+            q.trace_id, q.phase, q.peak_time, q.start_time, q.end_time, q.peak_value)
+    for p, q in zip(a.detections, b.detections):
+        assert (p.trace_id, p.start_time, p.end_time, p.peak_value) == (q.trace_id, q.start_time, q.end_time, q.peak_value)
+    # a tiny per-row capacity takes the retry path and ends in the same place
+    groups = list(__import__("volpick_amd.models", fromlist=["_group_stream"])._group_stream(
+        st, m.component_order, m.sampling_rate, True, m.in_samples))
+    args = m._argdict(kw)
+    specs = m._trigger_specs(args)
+    small = m._classify_blocks(groups, args, specs, cap_per_row=1)
+    big = m._classify_blocks(groups, args, specs, cap_per_row=512)
+    assert small == big and sum(len(t) for t in big) == len(a.picks) + len(a.detections)
+    # chunking by the window budget changes nothing either
+    m._max_windows_per_call = 40
+    c = m.classify(st, **kw)
+    m.batch_across_blocks = False
+    d = m.classify(st, **kw)
+    assert len(d.picks) == len(a.picks)
+    assert [(p.trace_id, p.phase, p.peak_time, p.peak_value) for p in c.picks] == [
+        (p.trace_id, p.phase, p.peak_time, p.peak_value) for p in a.picks]
+
+
+def test_classify_multi_rows_match_annotate_and_argument_errors():
+    """C ABI: the stacked rows of every block equal vp_annotate of that block alone (NaN pattern included)."""
+    import ctypes as C
+
+    from volpick_amd import _lib
+
+    lib = _lib.load()
+    m = va.PhaseNet.from_pretrained("volpick").cuda()
+    h = m._ensure_handle()
+    _, arrays = _many_stations(4, seed0=700)
+    blocks = [arrays[k] for k in sorted(arrays)]
+    blocks.append(blocks[0][:, :2000])  # shorter than one window: no windows, all-NaN rows
+    lens = np.array([b.shape[1] for b in blocks], np.int64)
+    offs = np.concatenate([[0], np.cumsum(3 * lens)[:-1]]).astype(np.int64)
+    flat = np.concatenate([b.reshape(-1) for b in blocks]).astype(np.float32)
+    out = np.empty_like(flat)
+    K = len(blocks)
+    fv, lv, nw = np.zeros(K, np.int64), np.zeros(K, np.int64), np.zeros(K, np.int64)
+    cap = 4096
+    on, off, pk = np.empty(cap, np.int64), np.empty(cap, np.int64), np.empty(cap, np.int64)
+    val, so, bo = np.empty(cap, np.float32), np.empty(cap, np.int32), np.empty(cap, np.int32)
+    found = C.c_int()
+    specs = (_lib.VpTriggerSpec * 2)(_lib.VpTriggerSpec(0, 0.3, 0.3), _lib.VpTriggerSpec(1, 0.3, 0.3))
+    I64 = C.POINTER(C.c_int64)
+
+    def call(k, overlap=1500, cap_row=256):
+        return lib.vp_classify_multi(
+            h, flat.ctypes.data_as(C.c_void_p), _lib.VP_MEM_HOST, offs.ctypes.data_as(I64), lens.ctypes.data_as(I64), k,
+            overlap, 100, 200, _lib.VP_STACK_AVG, 64, specs, 2, out.ctypes.data_as(C.c_void_p), _lib.VP_MEM_HOST,
+            fv.ctypes.data_as(I64), lv.ctypes.data_as(I64), nw.ctypes.data_as(I64), on.ctypes.data_as(I64),
+            off.ctypes.data_as(I64), pk.ctypes.data_as(I64), val.ctypes.data_as(C.POINTER(C.c_float)),
+            so.ctypes.data_as(C.POINTER(C.c_int32)), bo.ctypes.data_as(C.POINTER(C.c_int32)), cap_row, cap, C.byref(found))
+
+    assert call(K) == 0
+    assert nw[-1] == 0 and fv[-1] == -1 and np.isnan(out[offs[-1]:]).all()
+    n_trig = 0
+    for k, b in enumerate(blocks[:-1]):
+        n = b.shape[1]
+        want = np.empty((3, n), np.float32)
+        f1, l1, n1 = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(lib.vp_annotate(h, np.ascontiguousarray(b).ctypes.data_as(C.c_void_p), _lib.VP_MEM_HOST, n, 1500, 100,
+                                   200, _lib.VP_STACK_AVG, 64, want.ctypes.data_as(C.c_void_p), _lib.VP_MEM_HOST,
+                                   C.byref(f1), C.byref(l1), C.byref(n1)))
+        got = out[offs[k]:offs[k] + 3 * n].reshape(3, n)
+        assert (fv[k], lv[k], nw[k]) == (f1.value, l1.value, n1.value)
+        assert np.array_equal(got, want, equal_nan=True)
+        sel = bo[:found.value] == k
+        n_trig += int(sel.sum())
+        for i in np.flatnonzero(sel):  # every trigger sits on a peak of its row, inside the valid range
+            row = want[so[i]]
+            assert fv[k] <= on[i] <= pk[i] <= off[i] <= lv[k] and row[pk[i]] == val[i] == np.nanmax(row[on[i]:off[i] + 1])
+    assert n_trig == found.value > 0
+    assert call(0) == -1 and call(K, overlap=3001) == -1 and call(K, cap_row=0) == -1

@@ -110,6 +110,12 @@ SIGNATURES = {
         [_H, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int,
          C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "vp_classify_multi": (
+        C.c_int,
+        [_H, C.c_void_p, C.c_int, _I64P, _I64P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+         C.POINTER(VpTriggerSpec), C.c_int, C.c_void_p, C.c_int, _I64P, _I64P, _I64P, _I64P, _I64P, _I64P, _FP,
+         C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.POINTER(C.c_int)],
+    ),
     "vp_pick_host": (
         C.c_int,
         [C.c_void_p, C.c_int64, C.c_float, C.c_float, _I64P, _I64P, _I64P, _FP, C.c_int, C.POINTER(C.c_int)],

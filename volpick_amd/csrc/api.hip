@@ -25,6 +25,12 @@ struct vp_handle {
   size_t d_pred_cap = 0;
   float* d_out = nullptr;   // stacked output when the caller's buffer is on the host
   size_t d_out_cap = 0;
+  // vp_classify_multi: tables (window table, block table, scan rows) and the result block
+  char* d_tab = nullptr;
+  size_t d_tab_cap = 0;
+  char* m_pick_d = nullptr;
+  char* m_pick_h = nullptr;
+  size_t m_pick_bytes = 0;
   struct Slot {             // one in-flight vp_classify_submit
     char* d_pick = nullptr;  // trigger results: counters + per-spec on/off/peak/value arrays
     char* h_pick = nullptr;  // pinned host mirror, filled by ONE async copy per submit
@@ -181,6 +187,9 @@ int vp_destroy(vp_handle* h) {
   if (h->d_in) (void)hipFree(h->d_in);
   if (h->d_pred) (void)hipFree(h->d_pred);
   if (h->d_out) (void)hipFree(h->d_out);
+  if (h->d_tab) (void)hipFree(h->d_tab);
+  if (h->m_pick_d) (void)hipFree(h->m_pick_d);
+  if (h->m_pick_h) (void)hipHostFree(h->m_pick_h);
   for (auto& sl : h->slot) {
     if (sl.d_pick) (void)hipFree(sl.d_pick);
     if (sl.h_pick) (void)hipHostFree(sl.h_pick);
@@ -526,6 +535,194 @@ int vp_classify(vp_handle* h, const float* stream, int stream_mem, int64_t N, in
   if (rc != VP_OK) return rc;
   VP_HIP(hipStreamSynchronize(h->stream));  // also covers a host-side `out` copy
   read_stage_timing(h, n_specs > 0);
+  return VP_OK;
+}
+
+// K stream blocks in one call: the windows of ALL blocks fill the forward batches together, as the
+// reference's batch_size spans every fragment of the stream it is given (README.md:54-66); stacking and
+// the trigger scan of all blocks are one launch each.
+int vp_classify_multi(vp_handle* h, const float* streams, int stream_mem, const int64_t* offsets,
+                      const int64_t* lengths, int K, int overlap, int blind_l, int blind_r, int stacking, int batch,
+                      const vp_trigger_spec* specs, int n_specs, float* out, int out_mem, int64_t* first_valid,
+                      int64_t* last_valid, int64_t* n_windows, int64_t* on, int64_t* off, int64_t* peak, float* value,
+                      int32_t* spec_of, int32_t* block_of, int cap_per_row, int cap, int* n_found) {
+  VP_REQUIRE(h && streams && offsets && lengths && n_found, "null argument");
+  VP_REQUIRE(K > 0 && K <= 65535, "block count %d out of range", K);
+  VP_REQUIRE(n_specs >= 0 && n_specs <= 16 && (n_specs == 0 || specs), "bad trigger specs");
+  VP_REQUIRE(cap >= 0 && cap_per_row > 0 && (cap == 0 || (on && off && peak && value)), "bad result capacity");
+  vp::Net& net = h->net;
+  const int T = net.in_samples, n_out = net.n_out;
+  VP_REQUIRE(n_out == 3, "vp_classify_multi expects three output rows per block");
+  VP_REQUIRE(overlap >= 0 && overlap < T, "overlap %d must be in [0, %d)", overlap, T);
+  VP_REQUIRE(blind_l >= 0 && blind_r >= 0 && blind_l + blind_r < T, "blinding (%d, %d) leaves no samples", blind_l,
+             blind_r);
+  VP_REQUIRE(stacking == VP_STACK_AVG || stacking == VP_STACK_MAX, "unknown stacking %d", stacking);
+  for (int i = 0; i < n_specs; ++i) {
+    VP_REQUIRE(specs[i].row >= 0 && specs[i].row < n_out, "spec %d: row %d out of range", i, specs[i].row);
+    VP_REQUIRE(specs[i].thr_off <= specs[i].thr_on, "spec %d: thr_off must not exceed thr_on", i);
+  }
+  for (int i = 0; i < VP_MAX_INFLIGHT; ++i) VP_REQUIRE(!h->slot[i].busy, "uncollected vp_classify_submit on this handle");
+  if (batch <= 0 || batch > net.max_batch) batch = net.max_batch;
+  VP_HIP(hipSetDevice(h->device));
+  const long step = T - overlap;
+
+  // ---- host tables ------------------------------------------------------------------------
+  std::vector<long> wtab;
+  std::vector<vp::StackBlock> blocks(K);
+  int64_t total = 0, span = 0, n_max = 0;
+  for (int k = 0; k < K; ++k) {
+    const int64_t N = lengths[k];
+    VP_REQUIRE(N > 0 && offsets[k] >= 0, "block %d: bad offset / length", k);
+    int64_t n_reg;
+    int tail;
+    const int64_t nw = count_windows(N, T, overlap, &n_reg, &tail);
+    vp::StackBlock& b = blocks[k];
+    b.off = offsets[k];
+    b.N = N;
+    b.n_regular = n_reg;
+    b.has_tail = tail;
+    b.w0 = (long)(wtab.size() / 3);
+    b.cum = total;
+    b.pad = 0;
+    for (int64_t i = 0; i < nw; ++i) {
+      wtab.push_back(offsets[k]);
+      wtab.push_back(N);
+      wtab.push_back(i < n_reg ? i * step : N - T);
+    }
+    if (n_windows) n_windows[k] = nw;
+    if (first_valid) first_valid[k] = nw > 0 ? blind_l : -1;
+    if (last_valid) last_valid[k] = nw > 0 ? (tail ? N - T : (n_reg - 1) * step) + T - blind_r - 1 : -1;
+    total += N;
+    span = std::max<int64_t>(span, offsets[k] + 3 * N);
+    n_max = std::max(n_max, N);
+  }
+  const int64_t W = (int64_t)(wtab.size() / 3);
+  const int R = K * n_specs;
+
+  // ---- device buffers ------------------------------------------------------------------------
+  const float* d_streams = streams;
+  if (stream_mem == VP_MEM_HOST) {
+    int rc = grow(&h->d_in, &h->d_in_cap, std::max((size_t)span, (size_t)net.max_batch * 3 * T));
+    if (rc != VP_OK) return rc;
+    VP_HIP(hipMemcpyAsync(h->d_in, streams, (size_t)span * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    d_streams = h->d_in;
+  }
+  float* d_out = (out && out_mem == VP_MEM_DEVICE) ? out : nullptr;
+  if (!d_out) {
+    int rc = grow(&h->d_out, &h->d_out_cap, (size_t)span);
+    if (rc != VP_OK) return rc;
+    d_out = h->d_out;
+  }
+  const size_t wt_bytes = (wtab.size() * sizeof(long) + 255) / 256 * 256;
+  const size_t bt_bytes = ((size_t)K * sizeof(vp::StackBlock) + 255) / 256 * 256;
+  const size_t rt_bytes = ((size_t)std::max(R, 1) * sizeof(vp::PickArgs) + 255) / 256 * 256;
+  if (wt_bytes + bt_bytes + rt_bytes > h->d_tab_cap) {
+    if (h->d_tab) (void)hipFree(h->d_tab);
+    h->d_tab = nullptr;
+    h->d_tab_cap = 0;
+    VP_HIP(hipMalloc((void**)&h->d_tab, wt_bytes + bt_bytes + rt_bytes));
+    h->d_tab_cap = wt_bytes + bt_bytes + rt_bytes;
+  }
+  long* d_wtab = reinterpret_cast<long*>(h->d_tab);
+  vp::StackBlock* d_blocks = reinterpret_cast<vp::StackBlock*>(h->d_tab + wt_bytes);
+  vp::PickArgs* d_rows = reinterpret_cast<vp::PickArgs*>(h->d_tab + wt_bytes + bt_bytes);
+  const ScanLayout L = scan_layout(std::max(R, 1), cap_per_row);
+  if (L.total > h->m_pick_bytes) {
+    if (h->m_pick_d) (void)hipFree(h->m_pick_d);
+    if (h->m_pick_h) (void)hipHostFree(h->m_pick_h);
+    h->m_pick_d = h->m_pick_h = nullptr;
+    h->m_pick_bytes = 0;
+    VP_HIP(hipMalloc((void**)&h->m_pick_d, L.total));
+    VP_HIP(hipHostMalloc((void**)&h->m_pick_h, L.total, hipHostMallocMapped));
+    h->m_pick_bytes = L.total;
+  }
+  VP_HIP(hipMemsetAsync(h->m_pick_d, 0, L.header, h->stream));  // counters
+  std::vector<vp::PickArgs> rows(R);
+  for (int k = 0; k < K; ++k)
+    for (int i = 0; i < n_specs; ++i) {
+      const int r = k * n_specs + i;
+      char* base = h->m_pick_d + L.header + L.per_spec * r;
+      vp::PickArgs& a = rows[r];
+      a.trace = d_out + offsets[k] + (size_t)specs[i].row * lengths[k];
+      a.n = lengths[k];
+      a.thr_on = specs[i].thr_on;
+      a.thr_off = specs[i].thr_off;
+      a.count = (int*)h->m_pick_d + 2 * r;
+      a.on = (int64_t*)base;
+      a.off = a.on + L.cap;
+      a.peak = a.off + L.cap;
+      a.value = (float*)(a.peak + L.cap);
+      a.cap = cap_per_row;
+    }
+  if (W > 0) VP_HIP(hipMemcpyAsync(d_wtab, wtab.data(), wtab.size() * sizeof(long), hipMemcpyHostToDevice, h->stream));
+  VP_HIP(hipMemcpyAsync(d_blocks, blocks.data(), (size_t)K * sizeof(vp::StackBlock), hipMemcpyHostToDevice, h->stream));
+  if (R > 0) VP_HIP(hipMemcpyAsync(d_rows, rows.data(), (size_t)R * sizeof(vp::PickArgs), hipMemcpyHostToDevice, h->stream));
+  // the three tables above are pageable host memory: the copies are complete when the calls return
+
+  // ---- forward over all windows, stack, scan ------------------------------------------------
+  if (W > 0) {
+    const size_t out_w = (size_t)n_out * T;
+    int rc = grow(&h->d_pred, &h->d_pred_cap, (size_t)W * out_w);
+    if (rc != VP_OK) return rc;
+    float* y_saved = net.y;
+    for (int64_t w0 = 0; w0 < W; w0 += batch) {
+      const int nb = (int)std::min<int64_t>(batch, W - w0);
+      vp::PreArgs pa = pre_args(h, d_streams, 0, 0, step, w0, 1);
+      pa.table = d_wtab;
+      vp::launch_gather_normalize(pa, nb, h->stream);
+      net.y = h->d_pred + (size_t)w0 * out_w;
+      rc = net.run(nb, h->stream);
+      net.y = y_saved;
+      if (rc != VP_OK) return rc;
+    }
+  }
+  vp::StackMultiArgs sa{};
+  sa.pred = h->d_pred;
+  sa.out = d_out;
+  sa.blocks = d_blocks;
+  sa.n_blocks = K;
+  sa.total = total;
+  sa.T = T;
+  sa.n_out = n_out;
+  sa.step = step;
+  sa.blind_l = blind_l;
+  sa.blind_r = blind_r;
+  sa.mode = stacking;
+  vp::launch_stack_multi(sa, h->stream);
+  if (out && out_mem == VP_MEM_HOST)
+    VP_HIP(hipMemcpyAsync(out, d_out, (size_t)span * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (R > 0) {
+    vp::launch_pick_table(d_rows, R, n_max, h->stream);
+    vp::launch_publish_table(h->m_pick_d, h->m_pick_h, R, cap_per_row, (long)L.header, (long)L.per_spec, h->stream);
+  }
+  VP_HIP(hipStreamSynchronize(h->stream));
+
+  // ---- results: per (block, spec) sorted by onset; a row that overflowed its cap_per_row is reported whole
+  // in *n_found (found > written tells the caller to retry with more room) ---------------------------------
+  int total_found = 0, written = 0;
+  for (int r = 0; r < R; ++r) {
+    const int found = ((const int*)h->m_pick_h)[2 * r];
+    total_found += found;
+    const int m = std::min(found, cap_per_row);
+    const char* base = h->m_pick_h + L.header + L.per_spec * r;
+    const int64_t* t_on = (const int64_t*)base;
+    const int64_t* t_off = t_on + L.cap;
+    const int64_t* t_pk = t_off + L.cap;
+    const float* t_v = (const float*)(t_pk + L.cap);
+    std::vector<int> order(m);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return t_on[x] < t_on[y]; });
+    for (int k = 0; k < m && written < cap; ++k, ++written) {
+      on[written] = t_on[order[k]];
+      off[written] = t_off[order[k]];
+      peak[written] = t_pk[order[k]];
+      value[written] = t_v[order[k]];
+      if (spec_of) spec_of[written] = r % n_specs;
+      if (block_of) block_of[written] = r / n_specs;
+    }
+    if (found > cap_per_row) total_found = std::max(total_found, cap + 1);  // forces the retry path
+  }
+  *n_found = total_found;
   return VP_OK;
 }
 

@@ -19,6 +19,8 @@ struct PreArgs {
   float* dst;        // haloed input tensor
   int lsd;
   long wsd;
+  const long* table; // optional, 3 longs per window of the whole call: block offset in src, block length (row stride),
+                     // window start; window w of this launch is entry first_window + w (multi-block classify)
 };
 int launch_gather_normalize(const PreArgs& a, int n_windows, hipStream_t stream);
 
@@ -35,6 +37,24 @@ struct StackArgs {
 };
 int launch_stack(const StackArgs& a, hipStream_t stream);
 
+// Several stream blocks stacked by one launch (vp_classify_multi).  Block k: rows of N samples at float offset
+// `off` of both the input and the output buffer, windows [w0, w0 + n_regular + has_tail) of pred.
+struct StackBlock {
+  long off, N, n_regular, w0, cum;  // cum: samples of all earlier blocks (grid index space)
+  int has_tail, pad;
+};
+struct StackMultiArgs {
+  const float* pred;
+  float* out;
+  const StackBlock* blocks;
+  int n_blocks;
+  long total;  // sum of N
+  int T, n_out;
+  long step;
+  int blind_l, blind_r, mode;
+};
+int launch_stack_multi(const StackMultiArgs& a, hipStream_t stream);
+
 struct PickArgs {
   const float* trace;
   long n;
@@ -50,6 +70,9 @@ struct PickBatch {
   int n;
 };
 int launch_pick(const PickBatch& b, hipStream_t stream);
+// the same scan over a table of rows in device memory (any number of rows; n_max = longest row)
+int launch_pick_table(const PickArgs* rows, int n_rows, long n_max, hipStream_t stream);
+int launch_publish_table(char* dev, char* host, int n_rows, int cap, long header, long per_row, hipStream_t stream);
 struct WindowPickArgs {
   const float* prob;  // [B][n_rows][T]
   int B, n_rows, T, row;

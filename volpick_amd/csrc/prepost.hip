@@ -33,7 +33,12 @@ __global__ __launch_bounds__(1024) void gather_normalize_kernel(const PreArgs a)
   long start = a.dense ? 0 : (long)(a.first_window + w) * a.step;
   if (!a.dense && start > a.N - T) start = a.N - T;  // tail window flush with the end
   const float* src = a.src + (a.dense ? (long)w * 3 * T : start);
-  const long cs = a.dense ? T : a.N;
+  long cs = a.dense ? T : a.N;
+  if (a.table) {  // multi-block call: the window's block and start come from the table
+    const long* e = a.table + 3 * (a.first_window + w);
+    src = a.src + e[0] + e[2];
+    cs = e[1];
+  }
   float* dst = a.dst + (long)w * a.wsd + HALO;
 
   if (!a.preprocess) {
@@ -156,6 +161,59 @@ __global__ __launch_bounds__(256) void stack_kernel(const StackArgs a) {
   a.out[(long)c * a.N + t] = r;
 }
 
+// One thread per (sample of any block, channel): the block is found by bisection over the cumulative lengths.
+__global__ __launch_bounds__(256) void stack_multi_kernel(const StackMultiArgs a) {
+  const long g = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  if (g >= a.total) return;
+  int lo_b = 0, hi_b = a.n_blocks - 1;
+  while (lo_b < hi_b) {
+    const int mid = (lo_b + hi_b + 1) >> 1;
+    if (a.blocks[mid].cum <= g) {
+      lo_b = mid;
+    } else {
+      hi_b = mid - 1;
+    }
+  }
+  const StackBlock b = a.blocks[lo_b];
+  const long t = g - b.cum;
+  const int T = a.T;
+  float acc = (a.mode == VP_STACK_AVG) ? 0.f : -INFINITY;
+  int cnt = 0;
+  if (b.n_regular > 0) {
+    long hi = (t - a.blind_l >= 0) ? (t - a.blind_l) / a.step : -1;
+    const long lo_num = t - T + a.blind_r;
+    const long lo = (lo_num < 0) ? 0 : lo_num / a.step + 1;
+    if (hi > b.n_regular - 1) hi = b.n_regular - 1;
+    for (long i = lo; i <= hi; ++i) {
+      const float v = a.pred[((b.w0 + i) * a.n_out + c) * T + (t - i * a.step)];
+      if (v != v) continue;
+      acc = (a.mode == VP_STACK_AVG) ? acc + v : fmaxf(acc, v);
+      ++cnt;
+    }
+  }
+  if (b.has_tail) {
+    const long j = t - (b.N - T);
+    if (j >= a.blind_l && j < T - a.blind_r) {
+      const float v = a.pred[((b.w0 + b.n_regular) * a.n_out + c) * T + j];
+      if (v == v) {
+        acc = (a.mode == VP_STACK_AVG) ? acc + v : fmaxf(acc, v);
+        ++cnt;
+      }
+    }
+  }
+  float r = NAN;
+  if (cnt > 0) r = (a.mode == VP_STACK_AVG) ? acc / (float)cnt : acc;
+  a.out[b.off + (long)c * b.N + t] = r;
+}
+
+int launch_stack_multi(const StackMultiArgs& a, hipStream_t stream) {
+  if (a.total <= 0) return 0;
+  dim3 grid((unsigned)((a.total + 255) / 256), a.n_out, 1);
+  hipLaunchKernelGGL(stack_multi_kernel, grid, dim3(256), 0, stream, a);
+  return 0;
+}
+
 int launch_stack(const StackArgs& a, hipStream_t stream) {
   dim3 grid((unsigned)((a.N + 255) / 256), a.n_out, 1);
   hipLaunchKernelGGL(stack_kernel, grid, dim3(256), 0, stream, a);
@@ -176,10 +234,9 @@ constexpr int SCAN_CHUNK = 2048;  // samples per workgroup
 // One launch: every workgroup lists the run ENDS inside its 2048-sample chunk in LDS (phase 1,
 // one thread per 8 samples), then its four wavefronts walk those runs backwards through memory
 // (phase 2) -- a run may start in an earlier chunk, only its end decides who owns it.
-__global__ __launch_bounds__(256) void trigger_scan_kernel(const PickBatch batch) {
+__device__ __forceinline__ void trigger_scan_body(const PickArgs& a) {
   __shared__ int n_ends;
   __shared__ int ends[SCAN_CHUNK / 2 + 1];
-  const PickArgs& a = batch.a[blockIdx.y];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long c0 = (long)blockIdx.x * SCAN_CHUNK;
   if (c0 >= a.n) return;
@@ -236,6 +293,16 @@ __global__ __launch_bounds__(256) void trigger_scan_kernel(const PickBatch batch
   }
 }
 
+__global__ __launch_bounds__(256) void trigger_scan_kernel(const PickBatch batch) { trigger_scan_body(batch.a[blockIdx.y]); }
+__global__ __launch_bounds__(256) void trigger_scan_table_kernel(const PickArgs* rows) { trigger_scan_body(rows[blockIdx.y]); }
+
+int launch_pick_table(const PickArgs* rows, int n_rows, long n_max, hipStream_t stream) {
+  if (n_rows <= 0 || n_max <= 0) return 0;
+  hipLaunchKernelGGL(trigger_scan_table_kernel, dim3((unsigned)((n_max + SCAN_CHUNK - 1) / SCAN_CHUNK), n_rows), dim3(256),
+                     0, stream, rows);
+  return 0;
+}
+
 // All rows of one classify call in one launch (blockIdx.y = row).
 int launch_pick(const PickBatch& b, hipStream_t stream) {
   long n_max = 0;
@@ -274,6 +341,37 @@ __global__ __launch_bounds__(256) void publish_kernel(char* dev, char* host, int
   }
   __syncthreads();
   if (tid < 2 * n_specs) cnt[tid] = 0;
+}
+
+// The same hand-off for many rows: one workgroup per row.
+__global__ __launch_bounds__(256) void publish_table_kernel(char* dev, char* host, int cap, long header, long per_row) {
+  const int i = blockIdx.x, tid = threadIdx.x;
+  int* cnt = reinterpret_cast<int*>(dev);
+  int* hcnt = reinterpret_cast<int*>(host);
+  const int found = cnt[2 * i];
+  const int m = found < cap ? found : cap;
+  const int64_t* s_on = reinterpret_cast<const int64_t*>(dev + header + per_row * i);
+  int64_t* d_on = reinterpret_cast<int64_t*>(host + header + per_row * i);
+  const long L = cap > 0 ? cap : 1;
+  for (int k = tid; k < m; k += 256) {
+    d_on[k] = s_on[k];
+    d_on[L + k] = s_on[L + k];
+    d_on[2 * L + k] = s_on[2 * L + k];
+    reinterpret_cast<float*>(d_on + 3 * L)[k] = reinterpret_cast<const float*>(s_on + 3 * L)[k];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    hcnt[2 * i] = found;
+    hcnt[2 * i + 1] = 0;
+    cnt[2 * i] = 0;  // re-armed for the next call
+    cnt[2 * i + 1] = 0;
+  }
+}
+
+int launch_publish_table(char* dev, char* host, int n_rows, int cap, long header, long per_row, hipStream_t stream) {
+  if (n_rows <= 0) return 0;
+  hipLaunchKernelGGL(publish_table_kernel, dim3(n_rows), dim3(256), 0, stream, dev, host, cap, header, per_row);
+  return 0;
 }
 
 int launch_publish(char* dev, char* host, int n_specs, int cap, long header, long per_spec, hipStream_t stream) {
