@@ -167,7 +167,13 @@ def main():
         kernels.append({"name": name.value.decode(), "ms": float(ms[i]), "flop_per_window": fl.value})
     fwd_ms = sum(k["ms"] for k in kernels)
     dom = max(kernels, key=lambda k: k["ms"])
-    dom_tflops = dom["flop_per_window"] * args.batch / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+    # The dominant launch is re-timed IN the pipeline (whole step list in order, events around it only): its inputs
+    # then come from the preceding kernel instead of a warm re-run of itself -- the duration rocprofv3 reports
+    # for it under this same command (profiles/).  The back-to-back figure stays in forward.kernels.
+    dom_ms = C.c_float()
+    _lib.check(lib.vp_profile_step_in_pipeline(h, args.batch, 50, kernels.index(dom), C.byref(dom_ms)),
+               "vp_profile_step_in_pipeline")
+    dom_tflops = dom["flop_per_window"] * args.batch / (dom_ms.value * 1e-3) / 1e12 if dom_ms.value > 0 else 0.0
     flop_w = lib.vp_flops_per_window(h)
     stage = (C.c_float * 4)()
     total_ms = C.c_float()
@@ -209,7 +215,8 @@ def main():
             "unit": "TFLOP/s",
             "frac": dom_tflops / PEAK_FP32_TFLOPS,
             "traffic": traffic_bytes(args.model, dom["name"]),
-            "kernel_ms": dom["ms"],
+            "kernel_ms": dom_ms.value,
+            "kernel_ms_back_to_back": dom["ms"],
         },
         "forward": {
             "flop_per_window": flop_w,

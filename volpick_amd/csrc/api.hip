@@ -866,6 +866,35 @@ int vp_profile_steps(vp_handle* h, int B, int iters, float* step_ms, int cap) {
   return VP_OK;
 }
 
+// Mean duration of ONE step measured where it runs in practice: the whole step list executes in order
+// `iters` times and only step `index` is bracketed by events, so its inputs arrive from the preceding
+// kernel (not from a warm re-run of itself) -- the number rocprofv3's per-kernel AverageNs is compared with.
+int vp_profile_step_in_pipeline(vp_handle* h, int B, int iters, int index, float* ms) {
+  VP_REQUIRE(h && ms && iters > 0, "bad argument");
+  vp::Net& net = h->net;
+  VP_REQUIRE(B > 0 && B <= net.max_batch, "B outside (0, max_batch]");
+  const int n = (int)net.steps.size();
+  VP_REQUIRE(index >= 0 && index < n, "step index %d outside [0, %d)", index, n);
+  VP_HIP(hipSetDevice(h->device));
+  int rc = net.run(B, h->stream);  // warm
+  if (rc != VP_OK) return rc;
+  double total = 0.0;
+  for (int i = 0; i < iters; ++i) {
+    for (int s = 0; s < n; ++s) {
+      if (s == index) VP_HIP(hipEventRecord(h->ev[0], h->stream));
+      rc = net.steps[s].run(net, B, h->stream);
+      if (rc != 0) return rc;
+      if (s == index) VP_HIP(hipEventRecord(h->ev[1], h->stream));
+    }
+    VP_HIP(hipStreamSynchronize(h->stream));
+    float t = 0.f;
+    VP_HIP(hipEventElapsedTime(&t, h->ev[0], h->ev[1]));
+    total += t;
+  }
+  *ms = (float)(total / iters);
+  return VP_OK;
+}
+
 int vp_debug_tensor_count(const vp_handle* h) { return h ? (int)h->net.tensors.size() : VP_ERR_INVALID; }
 
 int vp_debug_tensor_info(const vp_handle* h, int index, const char** name, int* channels, int* length) {
