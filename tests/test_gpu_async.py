@@ -201,3 +201,64 @@ def test_classify_multi_rows_match_annotate_and_argument_errors():
             assert fv[k] <= on[i] <= pk[i] <= off[i] <= lv[k] and row[pk[i]] == val[i] == np.nanmax(row[on[i]:off[i] + 1])
     assert n_trig == found.value > 0
     assert call(0) == -1 and call(K, overlap=3001) == -1 and call(K, cap_row=0) == -1
+
+
+@pytest.mark.parametrize("cls,overlap,blinding,stacking", [(va.PhaseNet, 1500, (0, 0), "avg"),
+                                                           (va.PhaseNet, 2700, (150, 250), "max"),
+                                                           (va.EQTransformer, 5500, (500, 500), "avg")])
+def test_long_block_over_the_contexts_is_bitwise_the_unsplit_result(cls, overlap, blinding, stacking):
+    """A long block is cut into one segment per device context (volpick_amd/segments.py); outputs, valid range and
+    picks equal the single-context result exactly."""
+    from volpick_amd import Stream, Trace, UTCDateTime
+    from volpick_amd.synthetic import synthetic_stream_array
+
+    m = cls.from_pretrained("volpick")
+    m._max_batch = 8
+    m.cuda()
+    T = m.in_samples
+    n = T + (T - overlap) * 130 + 17  # > 2 * batch * contexts windows, tail window off the grid
+    data, _, _ = synthetic_stream_array(n, seed=5, n_events=max(4, n // 60_000))
+    args = m._argdict(dict(overlap=overlap, blinding=blinding, stacking=stacking))
+    assert m._is_long(n, args)
+    a, fa, la, na = m._annotate_block(data, args)
+    b, fb, lb, nb = m._annotate_segments(data, args)
+    assert (fa, la, na) == (fb, lb, nb)
+    assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True)
+    t0 = UTCDateTime("2022-02-02T02:02:02")
+    st = Stream([Trace(data[i], dict(network="XX", station="LONG", location="", channel="HH" + c, starttime=t0,
+                                     sampling_rate=100.0)) for i, c in enumerate("ZNE")])
+    kw = dict(overlap=overlap, blinding=blinding, stacking=stacking, P_threshold=0.2, S_threshold=0.2)
+    long_out = m.classify(st, **kw)
+    m.n_contexts = 1  # never "long": the plain single-block path
+    ref_out = m.classify(st, **kw)
+    m.n_contexts = 3
+    assert len(long_out.picks) == len(ref_out.picks) > 0 and len(long_out.detections) == len(ref_out.detections)
+    for p, q in zip(long_out.picks, ref_out.picks):
+        assert (p.phase, p.start_time, p.end_time, p.peak_time, p.peak_value) == (
+            q.phase, q.start_time, q.end_time, q.peak_time, q.peak_value)
+    ann_a = m.annotate(st, **{k: kw[k] for k in ("overlap", "blinding", "stacking")})
+    m.n_contexts = 1
+    ann_b = m.annotate(st, **{k: kw[k] for k in ("overlap", "blinding", "stacking")})
+    for x, y in zip(ann_a, ann_b):
+        assert x.stats.starttime == y.stats.starttime and np.array_equal(x.data, y.data, equal_nan=True)
+
+
+def test_stream_sharded_entry_point_on_one_rank_equals_classify():
+    """distributed.classify_stream_sharded with the real GPU path (world size 1 here; the two-rank exchange is
+    covered on CPU by tests/test_distributed_cpu.py)."""
+    from volpick_amd import Stream, Trace, UTCDateTime
+    from volpick_amd.distributed import classify_stream_sharded
+    from volpick_amd.synthetic import synthetic_stream_array
+
+    m = va.EQTransformer.from_pretrained("volpick").cuda()
+    n = 6000 * 20 + 123
+    data, _, _ = synthetic_stream_array(n, seed=9, n_events=5)
+    t0 = UTCDateTime("2023-03-03T03:03:03")
+    kw = dict(overlap=5500, blinding=(500, 500), P_threshold=0.2, S_threshold=0.2)
+    got = classify_stream_sharded(m, data, t0, "XX.ONE.", **kw)
+    st = Stream([Trace(data[i], dict(network="XX", station="ONE", location="", channel="HH" + c, starttime=t0,
+                                     sampling_rate=100.0)) for i, c in enumerate("ZNE")])
+    want = m.classify(st, **kw)
+    assert len(got.picks) == len(want.picks) > 0 and len(got.detections) == len(want.detections)
+    for p, q in zip(got.picks, want.picks):
+        assert (p.trace_id, p.phase, p.peak_time, p.peak_value) == (q.trace_id, q.phase, q.peak_time, q.peak_value)

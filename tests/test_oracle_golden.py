@@ -8,6 +8,7 @@ import torch
 
 from oracle import pipeline as OP
 from oracle.models import load_pretrained
+from volpick_amd.synthetic import synthetic_stream_array
 
 GOLD = Path(__file__).parent / "golden"
 
@@ -94,3 +95,40 @@ def test_trigger_onset_known_answers():
     assert OP.trigger_onset(np.zeros(5), .3, .3).shape == (0, 2)
     assert OP.picks_from_trace(x, .3) == [(2, 3, 3, pytest.approx(.6)), (7, 8, 8, pytest.approx(.8)),
                                           (11, 14, 11, pytest.approx(.9))]
+
+
+@pytest.mark.parametrize("model_name,overlap,blinding,stacking,parts", [
+    ("phasenet", 1500, (0, 0), "avg", 3), ("phasenet", 2500, (250, 100), "max", 4),
+    ("eqtransformer", 5500, (500, 500), "avg", 2)])
+def test_segmented_annotate_equals_unsplit(model_name, overlap, blinding, stacking, parts):
+    """volpick_amd.segments: a long stream cut into independently annotated segments gives, after the cut and
+    join, exactly the unsplit stacked output (NaN pattern included) -- checked on the CPU oracle."""
+    from volpick_amd.segments import check_plan, plan_segments
+
+    net = load_pretrained(model_name)
+    T = net.in_samples
+    N = (4 * parts + 1) * T + 1234
+    data, _, _ = synthetic_stream_array(N, seed=77, n_events=5)
+
+    def stacked(block):
+        starts = OP.window_starts(block.shape[1], T, overlap)
+        preds = OP.predict_windows(net, block, starts, blinding, 64)
+        out = OP.reassemble(preds, starts, T, overlap, stacking)  # (length, n_out)
+        full = np.full((block.shape[1], out.shape[1]), np.nan, dtype=out.dtype)
+        full[: out.shape[0]] = out
+        return full
+
+    want = stacked(data)
+    segs = plan_segments(N, T, overlap, blinding, parts)
+    assert len(segs) == parts and check_plan(segs, N, T, overlap, blinding)
+    got = np.full_like(want, np.nan)
+    for s in segs:
+        part = stacked(data[:, s["lo"]:s["hi"]])
+        got[s["keep_lo"]:s["keep_hi"]] = part[s["keep_lo"] - s["lo"]:s["keep_hi"] - s["lo"]]
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    # the oracle itself is not bit-reproducible across batch compositions / nanmean slot order (1 ulp); the HIP path is,
+    # and tests/test_gpu_async.py asserts equality there
+    assert np.abs(got[~np.isnan(got)] - want[~np.isnan(want)]).max() < 5e-7
+    # short streams and degenerate requests fall back to one segment
+    assert len(plan_segments(3 * T, T, overlap, blinding, 8)) == 1
+    assert plan_segments(T - 1, T, overlap, blinding, 4) == [dict(lo=0, hi=T - 1, keep_lo=0, keep_hi=T - 1)]

@@ -70,3 +70,80 @@ def classify_sharded(model, streams, group=None, **kwargs):
     if rank == 0:
         return PickList(sorted(p for part in gathered for p in part))
     return PickList(sorted(mine))
+
+
+def annotate_stream_sharded(model, data, group=None, annotate_fn=None, **kwargs):
+    """ONE long (3, N) block spread over the ranks (BASELINE config 4: a 24 h stream on 8 GPUs): rank r annotates
+    segment r of ``segments.plan_segments`` and keeps the output samples it owns; one gather (RCCL over xGMI under
+    the "nccl" backend -- 13 MB per rank for a station-day on 8 GPUs) brings the pieces to rank 0, which joins them
+    into exactly the unsplit (n_out, N) result.  Every rank passes the same ``data``.
+
+    Returns (array (n_out, N) with NaN outside the valid range, first_valid, last_valid) on rank 0 and
+    (None, first_valid, last_valid) elsewhere.  ``annotate_fn(block) -> (n_out, len)`` replaces the model's GPU
+    path (the CPU tests put the oracle there)."""
+    import torch
+    import torch.distributed as dist
+
+    from .segments import plan_segments
+
+    args = model._argdict(kwargs)
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+    n = int(data.shape[1])
+    T = model.in_samples
+    segs = plan_segments(n, T, args["overlap"], args["blinding"], world)
+    on_gpu = annotate_fn is None
+    if on_gpu:
+        dev = torch.device("cuda", model._device_index if model._device_index is not None else torch.cuda.current_device())
+
+        def annotate_fn(block):
+            fn = model._annotate_segments if model._is_long(block.shape[1], args) else model._annotate_block
+            return fn(block, args)[0]
+    else:
+        dev = torch.device("cpu")
+    width = max(sg["keep_hi"] - sg["keep_lo"] for sg in segs)
+    mine = torch.full((3, width), float("nan"), dtype=torch.float32, device=dev)
+    if rank < len(segs):  # with fewer segments than ranks (short stream) the surplus ranks send NaN
+        sg = segs[rank]
+        block = data[:, sg["lo"]:sg["hi"]]
+        y = annotate_fn(block)
+        y = y if torch.is_tensor(y) else torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32))
+        mine[:, : sg["keep_hi"] - sg["keep_lo"]] = y.to(dev)[:, sg["keep_lo"] - sg["lo"]:sg["keep_hi"] - sg["lo"]]
+    # valid range of the whole stream (SURVEY §8a A6/A7)
+    step = T - args["overlap"]
+    n_reg = (n - T) // step + 1 if n >= T else 0
+    tail = 1 if n_reg > 0 and (n_reg - 1) * step + T < n else 0
+    fv = args["blinding"][0] if n_reg > 0 else -1
+    lv = ((n - T) if tail else (n_reg - 1) * step) + T - args["blinding"][1] - 1 if n_reg > 0 else -1
+    if world == 1:
+        pieces = [mine]
+    else:
+        pieces = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, pieces, dst=0, group=group)
+    if rank != 0:
+        return None, fv, lv
+    out = torch.full((3, n), float("nan"), dtype=torch.float32, device=dev)
+    for sg, piece in zip(segs, pieces):
+        out[:, sg["keep_lo"]:sg["keep_hi"]] = piece[:, : sg["keep_hi"] - sg["keep_lo"]]
+    return out, fv, lv
+
+
+def classify_stream_sharded(model, data, starttime, trace_id, group=None, annotate_fn=None, pick_fn=None, **kwargs):
+    """``annotate_stream_sharded`` + the trigger scan on rank 0 -> ``ClassifyOutput`` there, ``None`` elsewhere.
+    ``pick_fn(rows (n_out, N), specs) -> [(spec_index, on, off, peak, value)]`` replaces the GPU scan in CPU tests."""
+    from .picks import ClassifyOutput, Detection, DetectionList, Pick, PickList
+
+    out, fv, lv = annotate_stream_sharded(model, data, group=group, annotate_fn=annotate_fn, **kwargs)
+    if out is None:
+        return None
+    args = model._argdict(kwargs)
+    specs = model._trigger_specs(args)
+    triggers = (pick_fn or model._pick_rows)(out, specs)
+    sr = model.sampling_rate
+    picks, detections = PickList(), DetectionList()
+    for si, on, off, pk, v in triggers:
+        label = specs[si][1]
+        if label == "Detection":
+            detections.append(Detection(trace_id, starttime + on / sr, starttime + off / sr, v))
+        else:
+            picks.append(Pick(trace_id, starttime + on / sr, starttime + off / sr, starttime + pk / sr, v, label))
+    return ClassifyOutput(model.name, picks=PickList(sorted(picks)), detections=DetectionList(sorted(detections)))

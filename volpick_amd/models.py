@@ -365,6 +365,8 @@ class WaveformModel:
         n = data.shape[1]
         if torch.is_tensor(data):  # assembled on the device by _group_stream
             x = data.to(dev, torch.float32).contiguous()
+        elif isinstance(data, _Rows):
+            x = data.upload(torch, dev)
         else:
             x = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(dev)
         out = torch.empty((3, n), dtype=torch.float32, device=dev)
@@ -377,6 +379,81 @@ class WaveformModel:
                                    C.c_void_p(out.data_ptr()), _lib.VP_MEM_DEVICE, C.byref(fv), C.byref(lv),
                                    C.byref(nw)), "vp_annotate")
         return out, fv.value, lv.value, nw.value
+
+    # ---- one long block spread over the device contexts ---------------------------------------------
+    def _is_long(self, n_samples, args):
+        """Worth splitting: every context gets at least two full forward batches."""
+        step = self.in_samples - int(args["overlap"])
+        batch = max(1, min(int(args["batch_size"]), self._max_batch))
+        return self.n_contexts > 1 and (n_samples - self.in_samples) // step + 1 >= 2 * batch * self.n_contexts
+
+    def _annotate_segments(self, data, args):
+        """Like ``_annotate_block`` for a long (3,N) block: ``segments.plan_segments`` cuts it into one segment
+        per device context; segment r+1 is uploaded while segment r computes, the stacked outputs are cut and
+        joined on the device -- sample for sample the unsplit result (volpick_amd/segments.py)."""
+        from .segments import plan_segments
+
+        torch = _torch()
+        lib = _lib.load()
+        dev = torch.device("cuda", self._device_index)
+        n = data.shape[1]
+        segs = plan_segments(n, self.in_samples, args["overlap"], args["blinding"], self.n_contexts)
+        if len(segs) == 1:
+            return self._annotate_block(data, args)
+        stacking = _lib.VP_STACK_AVG if args["stacking"] == "avg" else _lib.VP_STACK_MAX
+        batch = max(1, min(int(args["batch_size"]), self._max_batch))
+        jobs = []
+        for r, sg in enumerate(segs):
+            lo, hi = sg["lo"], sg["hi"]
+            if torch.is_tensor(data):
+                x = data[:, lo:hi].to(dev, torch.float32).contiguous()
+            elif isinstance(data, _Rows):
+                x = _Rows([p[lo:hi] for p in data.parts]).upload(torch, dev)
+            else:
+                x = torch.from_numpy(np.ascontiguousarray(data[:, lo:hi], dtype=np.float32)).to(dev)
+            y = torch.empty((3, hi - lo), dtype=torch.float32, device=dev)
+            torch.cuda.current_stream(dev).synchronize()
+            _lib.check(lib.vp_classify_submit(self._context(r), 0, C.c_void_p(x.data_ptr()), _lib.VP_MEM_DEVICE, hi - lo,
+                                              args["overlap"], args["blinding"][0], args["blinding"][1], stacking, batch,
+                                              None, 0, C.c_void_p(y.data_ptr()), _lib.VP_MEM_DEVICE, 0),
+                       "vp_classify_submit")
+            jobs.append((x, y))
+        out = torch.empty((3, n), dtype=torch.float32, device=dev)
+        fv = lv = -1
+        found = C.c_int()
+        for r, (sg, (x, y)) in enumerate(zip(segs, jobs)):
+            f, l, w = C.c_int64(), C.c_int64(), C.c_int64()
+            _lib.check(lib.vp_classify_collect(self._context(r), 0, C.byref(f), C.byref(l), C.byref(w), None, None, None,
+                                               None, None, 0, C.byref(found)), "vp_classify_collect")
+            out[:, sg["keep_lo"]:sg["keep_hi"]] = y[:, sg["keep_lo"] - sg["lo"]:sg["keep_hi"] - sg["lo"]]
+            if r == 0:
+                fv = f.value
+            lv = l.value + sg["lo"]
+        n_windows = int(lib.vp_window_starts(n, self.in_samples, args["overlap"], None, 0))
+        torch.cuda.current_stream(dev).synchronize()
+        return out, fv, lv, n_windows
+
+    def _pick_rows(self, dev_out, specs, cap=8192):
+        """Trigger scan of the rows of a device (n_out, N) array -> [(spec_index, on, off, peak, value)]."""
+        lib = _lib.load()
+        h = self._ensure_handle()
+        n = dev_out.shape[1]
+        res = []
+        I64 = C.POINTER(C.c_int64)
+        for si, (row, _, thr_on, thr_off) in enumerate(specs):
+            while True:
+                on, off, peak, val = np.empty(cap, np.int64), np.empty(cap, np.int64), np.empty(cap, np.int64), np.empty(
+                    cap, np.float32)
+                found = C.c_int()
+                _lib.check(lib.vp_pick(h, C.c_void_p(dev_out[row].data_ptr()), _lib.VP_MEM_DEVICE, n, thr_on, thr_off,
+                                       on.ctypes.data_as(I64), off.ctypes.data_as(I64), peak.ctypes.data_as(I64),
+                                       val.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(found)), "vp_pick")
+                if found.value <= cap:
+                    break
+                cap = found.value
+            order = np.argsort(on[:found.value], kind="stable")
+            res += [(si, int(on[i]), int(off[i]), int(peak[i]), float(val[i])) for i in order]
+        return res
 
     def _trigger_specs(self, args):
         """[(row, label, thr_on, thr_off)]: picks use thr/thr, detections thr/(thr/2); 'N' is skipped."""
@@ -401,6 +478,8 @@ class WaveformModel:
         n = data.shape[1]
         if torch.is_tensor(data):  # assembled on the device by _group_stream
             x = data.to(dev, torch.float32).contiguous()
+        elif isinstance(data, _Rows):
+            x = data.upload(torch, dev)
         else:
             x = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(dev)
         torch.cuda.current_stream(dev).synchronize()
@@ -476,7 +555,8 @@ class WaveformModel:
         args = self._argdict(kwargs)
         out = Stream()
         for grp in _group_stream(stream, self.component_order, self.sampling_rate, copy, self.in_samples):
-            dev_out, fv, lv, nw = self._annotate_block(grp["data"], args)
+            long_block = self._is_long(grp["data"].shape[1], args)
+            dev_out, fv, lv, nw = (self._annotate_segments if long_block else self._annotate_block)(grp["data"], args)
             if nw == 0 or fv < 0:
                 continue
             host = dev_out[:, fv : lv + 1].cpu().numpy()
@@ -518,6 +598,13 @@ class WaveformModel:
             chunk.clear()
 
         for i, grp in enumerate(_group_stream(stream, self.component_order, sr, copy, self.in_samples)):
+            if self._is_long(grp["data"].shape[1], args):  # a day-long block: its segments occupy all contexts
+                for g0, job in pending:
+                    emit(g0, self._collect_block(job, args, specs)[0])
+                pending = []
+                dev_out, fv, lv, nw = self._annotate_segments(grp["data"], args)
+                emit(grp, self._pick_rows(dev_out, specs))
+                continue
             if self.batch_across_blocks and torch.is_tensor(grp["data"]):
                 nw = (grp["data"].shape[1] - self.in_samples) // step + 2
                 if chunk and n_win + nw > self._max_windows_per_call:
@@ -593,6 +680,28 @@ class EQTransformer(WaveformModel):
         return tuple(y[:, i] for i in range(3))  # (detection, P, S), each (B, T)
 
 
+class _Rows:
+    """The (C, N) block of one instrument as its C full-length host rows, NOT yet stacked: the upload copies each
+    row straight into the device array (for a day-long stream the host-side ``np.stack`` alone costs ~12 ms)."""
+
+    def __init__(self, parts):
+        self.parts = parts
+        self.shape = (len(parts), len(parts[0]))
+
+    def __array__(self, dtype=None, copy=None):
+        a = np.stack(self.parts).astype(np.float32, copy=False)
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __getitem__(self, idx):
+        return np.asarray(self)[idx]
+
+    def upload(self, torch, dev):
+        x = torch.empty(self.shape, dtype=torch.float32, device=dev)
+        for c, p in enumerate(self.parts):
+            x[c].copy_(torch.from_numpy(np.ascontiguousarray(p)))  # casts int / float64 counts to float32
+        return x
+
+
 # --------------------------------------------------------------------------- stream handling
 def _group_stream(stream, component_order, sampling_rate, copy, in_samples):
     """Yield one dict per contiguous block of one instrument: data (3,N) float32 in
@@ -641,8 +750,7 @@ def _group_stream(stream, component_order, sampling_rate, copy, in_samples):
                 if on_device:
                     data = _torch().stack([p[3]._dev for p in full]).float()
                 else:
-                    parts = [p[3].data.filled(0) if np.ma.isMaskedArray(p[3].data) else p[3].data for p in full]
-                    data = np.stack(parts).astype(np.float32, copy=False)
+                    data = _Rows([p[3].data.filled(0) if np.ma.isMaskedArray(p[3].data) else p[3].data for p in full])
                 yield {
                     "data": data,
                     "starttime": t_start + b0 / sampling_rate,
