@@ -194,6 +194,101 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a) {
   }
 }
 
+// ---- small layers: one launch per direction ---------------------------------------------------
+// For the deep layers (a few thousand to ~100 k samples per channel) the three-launch forms above are pure
+// launch latency.  Here ONE workgroup owns a channel: it reduces, finalises and applies in a single kernel
+// (the second pass over the channel's rows hits L2).  grid (C), 1024 threads.
+__device__ inline void block_sum2_double(double& a, double& b, double* sh /*[32]*/) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    sh[2 * wave] = a;
+    sh[2 * wave + 1] = b;
+  }
+  __syncthreads();
+  a = b = 0.0;
+  for (int w = 0; w < nw; ++w) {  // fixed order
+    a += sh[2 * w];
+    b += sh[2 * w + 1];
+  }
+}
+
+__global__ __launch_bounds__(1024) void bn_fwd_small_kernel(const BnArgs a) {
+  __shared__ double sh[32];
+  const int c = blockIdx.x;
+  const long n_el = (long)a.B * a.Lz;
+  float s = 0.f, q = 0.f;
+  for (long i = threadIdx.x; i < n_el; i += 1024) {
+    const int b = (int)(i / a.Lz), t = (int)(i - (long)b * a.Lz);
+    const float v = a.z.p[(long)b * a.z.ws + (long)c * a.z.ls + HALO + t];
+    s += v;
+    q = fmaf(v, v, q);
+  }
+  double S = s, Q = q;
+  block_sum2_double(S, Q, sh);
+  const double N = (double)n_el;
+  const double mean_d = S / N;
+  double var = Q / N - mean_d * mean_d;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+  if (threadIdx.x == 0) {
+    a.stats[c] = mean;
+    a.stats[a.C + c] = rstd;
+    a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
+    a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)(var * N / (N - 1.0));
+  }
+  const float sc = a.gamma[c] * rstd, shv = a.beta[c] - mean * sc;
+  const long n_a = (long)a.B * a.La;
+  for (long i = threadIdx.x; i < n_a; i += 1024) {
+    const int b = (int)(i / a.La), t = (int)(i - (long)b * a.La);
+    const float v = a.z.p[(long)b * a.z.ws + (long)c * a.z.ls + HALO + a.crop + t];
+    a.a.p[(long)b * a.a.ws + (long)c * a.a.ls + HALO + t] = fmaxf(fmaf(v, sc, shv), 0.f);
+  }
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_small_kernel(const BnArgs a) {
+  __shared__ double sh[32];
+  const int c = blockIdx.x;
+  const float mean = a.stats[c], rstd = a.stats[a.C + c];
+  const long n_a = (long)a.B * a.La;
+  float s1 = 0.f, s2 = 0.f;
+  for (long i = threadIdx.x; i < n_a; i += 1024) {
+    const int b = (int)(i / a.La), t = (int)(i - (long)b * a.La);
+    float g = a.ga1.p[(long)b * a.ga1.ws + (long)c * a.ga1.ls + HALO + t];
+    if (a.ga2.p) g += a.ga2.p[(long)b * a.ga2.ws + (long)c * a.ga2.ls + HALO + t];
+    if (!(a.a.p[(long)b * a.a.ws + (long)c * a.a.ls + HALO + t] > 0.f)) g = 0.f;
+    s1 += g;
+    s2 = fmaf(g, (a.z.p[(long)b * a.z.ws + (long)c * a.z.ls + HALO + a.crop + t] - mean) * rstd, s2);
+  }
+  double S1 = s1, S2 = s2;
+  block_sum2_double(S1, S2, sh);
+  if (threadIdx.x == 0) {
+    a.stats[2 * a.C + c] = (float)S1;
+    a.stats[3 * a.C + c] = (float)S2;
+    a.g_beta[c] = (float)S1;
+    a.g_gamma[c] = (float)S2;
+  }
+  const long n_z = (long)a.B * a.Lz;
+  const float invN = 1.f / (float)n_z;
+  const float m1 = (float)S1 * invN, m2 = (float)S2 * invN, k = a.gamma[c] * rstd;
+  for (long i = threadIdx.x; i < n_z; i += 1024) {
+    const int b = (int)(i / a.Lz), j = (int)(i - (long)b * a.Lz);
+    const int t = j - a.crop;
+    float g = 0.f;
+    if (t >= 0 && t < a.La && a.a.p[(long)b * a.a.ws + (long)c * a.a.ls + HALO + t] > 0.f) {
+      g = a.ga1.p[(long)b * a.ga1.ws + (long)c * a.ga1.ls + HALO + t];
+      if (a.ga2.p) g += a.ga2.p[(long)b * a.ga2.ws + (long)c * a.ga2.ls + HALO + t];
+    }
+    const float xh = (a.z.p[(long)b * a.z.ws + (long)c * a.z.ls + HALO + j] - mean) * rstd;
+    a.gz.p[(long)b * a.gz.ws + (long)c * a.gz.ls + HALO + j] = k * (g - m1 - xh * m2);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Head: logits = W (3x8) a + b, p = softmax, loss = -(1/B) sum_b sum_c (1/T) sum_t y log(p + eps)
 // (vector_cross_entropy, models.py:34-51), and its backward down to ga (8 channels) plus

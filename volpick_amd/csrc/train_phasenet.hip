@@ -557,6 +557,9 @@ BnArgs bn_args(Trainer& tr, const BnOp& b, int B) {
   return a;
 }
 
+// deep layers: enough channels to fill the chip with one workgroup each, few enough samples per channel
+static bool bn_is_small(const BnArgs& a) { return a.C >= 32 && (long)a.B * a.Lz <= 60000; }
+
 int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B, bool update, float lr) {
   hipStream_t s = tr.stream;
   hipLaunchKernelGGL(gather_pack_kernel, dim3((unsigned)((tr.frag_n + 255) / 256)), dim3(256), 0, s, tr.frag_idx, tr.w,
@@ -565,9 +568,13 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
   for (Layer& L : tr.layers) {
     run_conv(tr, L.fwd, B);
     const BnArgs a = bn_args(tr, L.bn, B);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(a.C, a.GB), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(a.C), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((a.La + 1023) / 1024, a.C, B), dim3(256), 0, s, a);
+    if (bn_is_small(a)) {
+      hipLaunchKernelGGL(bn_fwd_small_kernel, dim3(a.C), dim3(1024), 0, s, a);
+    } else {
+      hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(a.C, a.GB), dim3(256), 0, s, a);
+      hipLaunchKernelGGL(bn_stats_final_kernel, dim3(a.C), dim3(64), 0, s, a);
+      hipLaunchKernelGGL(bn_apply_kernel, dim3((a.La + 1023) / 1024, a.C, B), dim3(256), 0, s, a);
+    }
   }
   {
     HeadArgs2 h{};
@@ -597,9 +604,13 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
   for (int li = NLAYER - 1; li >= 0; --li) {
     Layer& L = tr.layers[li];
     const BnArgs a = bn_args(tr, L.bn, B);
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(a.C, a.GB), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(a.C), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((a.Lz + 1023) / 1024, a.C, B), dim3(256), 0, s, a);
+    if (bn_is_small(a)) {
+      hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(a.C), dim3(1024), 0, s, a);
+    } else {
+      hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(a.C, a.GB), dim3(256), 0, s, a);
+      hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(a.C), dim3(64), 0, s, a);
+      hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((a.Lz + 1023) / 1024, a.C, B), dim3(256), 0, s, a);
+    }
     {
       const WgradOp& w = L.wg;
       WgradArgs g{};
