@@ -218,20 +218,33 @@ __device__ inline void block_sum2_double(double& a, double& b, double* sh /*[32]
   }
 }
 
+// (b, t) of flat element i = b * L + t for i = tid, tid + 1024, ...: stepped without a division per element
+struct RowWalk {
+  int b, t, db, dt, L;
+  __device__ RowWalk(int tid, int L_) : b(tid / L_), t(tid - (tid / L_) * L_), db(1024 / L_), dt(1024 - (1024 / L_) * L_), L(L_) {}
+  __device__ __forceinline__ void next() {
+    b += db;
+    t += dt;
+    if (t >= L) {
+      t -= L;
+      ++b;
+    }
+  }
+};
+
 __global__ __launch_bounds__(1024) void bn_fwd_small_kernel(const BnArgs a) {
   __shared__ double sh[32];
   const int c = blockIdx.x;
-  const long n_el = (long)a.B * a.Lz;
+  const float* zc = a.z.p + (long)c * a.z.ls + HALO;
   float s = 0.f, q = 0.f;
-  for (long i = threadIdx.x; i < n_el; i += 1024) {
-    const int b = (int)(i / a.Lz), t = (int)(i - (long)b * a.Lz);
-    const float v = a.z.p[(long)b * a.z.ws + (long)c * a.z.ls + HALO + t];
+  for (RowWalk w(threadIdx.x, a.Lz); w.b < a.B; w.next()) {
+    const float v = zc[(long)w.b * a.z.ws + w.t];
     s += v;
     q = fmaf(v, v, q);
   }
   double S = s, Q = q;
   block_sum2_double(S, Q, sh);
-  const double N = (double)n_el;
+  const double N = (double)a.B * a.Lz;
   const double mean_d = S / N;
   double var = Q / N - mean_d * mean_d;
   if (var < 0.0) var = 0.0;
@@ -243,27 +256,27 @@ __global__ __launch_bounds__(1024) void bn_fwd_small_kernel(const BnArgs a) {
     a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)(var * N / (N - 1.0));
   }
   const float sc = a.gamma[c] * rstd, shv = a.beta[c] - mean * sc;
-  const long n_a = (long)a.B * a.La;
-  for (long i = threadIdx.x; i < n_a; i += 1024) {
-    const int b = (int)(i / a.La), t = (int)(i - (long)b * a.La);
-    const float v = a.z.p[(long)b * a.z.ws + (long)c * a.z.ls + HALO + a.crop + t];
-    a.a.p[(long)b * a.a.ws + (long)c * a.a.ls + HALO + t] = fmaxf(fmaf(v, sc, shv), 0.f);
-  }
+  float* ac = a.a.p + (long)c * a.a.ls + HALO;
+  for (RowWalk w(threadIdx.x, a.La); w.b < a.B; w.next())
+    ac[(long)w.b * a.a.ws + w.t] = fmaxf(fmaf(zc[(long)w.b * a.z.ws + a.crop + w.t], sc, shv), 0.f);
 }
 
 __global__ __launch_bounds__(1024) void bn_bwd_small_kernel(const BnArgs a) {
   __shared__ double sh[32];
   const int c = blockIdx.x;
   const float mean = a.stats[c], rstd = a.stats[a.C + c];
-  const long n_a = (long)a.B * a.La;
+  const float* zc = a.z.p + (long)c * a.z.ls + HALO;
+  const float* ac = a.a.p + (long)c * a.a.ls + HALO;
+  const float* g1 = a.ga1.p + (long)c * a.ga1.ls + HALO;
+  const float* g2 = a.ga2.p ? a.ga2.p + (long)c * a.ga2.ls + HALO : nullptr;
+  float* gzc = a.gz.p + (long)c * a.gz.ls + HALO;
   float s1 = 0.f, s2 = 0.f;
-  for (long i = threadIdx.x; i < n_a; i += 1024) {
-    const int b = (int)(i / a.La), t = (int)(i - (long)b * a.La);
-    float g = a.ga1.p[(long)b * a.ga1.ws + (long)c * a.ga1.ls + HALO + t];
-    if (a.ga2.p) g += a.ga2.p[(long)b * a.ga2.ws + (long)c * a.ga2.ls + HALO + t];
-    if (!(a.a.p[(long)b * a.a.ws + (long)c * a.a.ls + HALO + t] > 0.f)) g = 0.f;
+  for (RowWalk w(threadIdx.x, a.La); w.b < a.B; w.next()) {
+    float g = g1[(long)w.b * a.ga1.ws + w.t];
+    if (g2) g += g2[(long)w.b * a.ga2.ws + w.t];
+    if (!(ac[(long)w.b * a.a.ws + w.t] > 0.f)) g = 0.f;
     s1 += g;
-    s2 = fmaf(g, (a.z.p[(long)b * a.z.ws + (long)c * a.z.ls + HALO + a.crop + t] - mean) * rstd, s2);
+    s2 = fmaf(g, (zc[(long)w.b * a.z.ws + a.crop + w.t] - mean) * rstd, s2);
   }
   double S1 = s1, S2 = s2;
   block_sum2_double(S1, S2, sh);
@@ -273,19 +286,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_small_kernel(const BnArgs a) {
     a.g_beta[c] = (float)S1;
     a.g_gamma[c] = (float)S2;
   }
-  const long n_z = (long)a.B * a.Lz;
-  const float invN = 1.f / (float)n_z;
+  const float invN = 1.f / ((float)a.B * (float)a.Lz);
   const float m1 = (float)S1 * invN, m2 = (float)S2 * invN, k = a.gamma[c] * rstd;
-  for (long i = threadIdx.x; i < n_z; i += 1024) {
-    const int b = (int)(i / a.Lz), j = (int)(i - (long)b * a.Lz);
-    const int t = j - a.crop;
+  for (RowWalk w(threadIdx.x, a.Lz); w.b < a.B; w.next()) {
+    const int t = w.t - a.crop;
     float g = 0.f;
-    if (t >= 0 && t < a.La && a.a.p[(long)b * a.a.ws + (long)c * a.a.ls + HALO + t] > 0.f) {
-      g = a.ga1.p[(long)b * a.ga1.ws + (long)c * a.ga1.ls + HALO + t];
-      if (a.ga2.p) g += a.ga2.p[(long)b * a.ga2.ws + (long)c * a.ga2.ls + HALO + t];
+    if (t >= 0 && t < a.La && ac[(long)w.b * a.a.ws + t] > 0.f) {
+      g = g1[(long)w.b * a.ga1.ws + t];
+      if (g2) g += g2[(long)w.b * a.ga2.ws + t];
     }
-    const float xh = (a.z.p[(long)b * a.z.ws + (long)c * a.z.ls + HALO + j] - mean) * rstd;
-    a.gz.p[(long)b * a.gz.ws + (long)c * a.gz.ls + HALO + j] = k * (g - m1 - xh * m2);
+    const float xh = (zc[(long)w.b * a.z.ws + w.t] - mean) * rstd;
+    gzc[(long)w.b * a.gz.ws + w.t] = k * (g - m1 - xh * m2);
   }
 }
 
