@@ -196,3 +196,29 @@ def test_argument_errors():
         tr.step(np.concatenate([x, x]), np.concatenate([y, y]), 1e-3)  # larger than max_batch
     with pytest.raises(Exception, match="batch"):
         tr.step(x[:1], y[:1], 1e-3)  # BatchNorm statistics need more than one window
+
+
+def test_loss_curve_tracks_torch_from_a_random_initialisation():
+    """40 Adam steps (with the reference's warm-up) from the SAME random weights over the same batches: the HIP
+    step and torch autograd + torch.optim.Adam (CPU) follow the same loss curve."""
+    from oracle.models import PhaseNet as TorchPhaseNet
+
+    torch.manual_seed(1)
+    net = TorchPhaseNet(phases="PSN", norm="peak").train()
+    model = PhaseNet(phases="PSN", norm="peak")
+    model.load_state_dict({k: v.detach().numpy() for k, v in net.state_dict().items()})
+    lit = PhaseNetLit(lr=1e-3, max_batch=8, model=model)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    batches = [make_batch(8, 900 + i) for i in range(4)]
+    ours, theirs = [], []
+    for k in range(40):
+        x, y = batches[k % 4]
+        ours.append(lit.training_step({"X": x, "y": y}, k))
+        for pg in opt.param_groups:
+            pg["lr"] = lit.learning_rate(k)
+        loss, *_ = torch_step(net, x, y, opt=opt)
+        theirs.append(loss)
+    ours, theirs = np.array(ours), np.array(theirs)
+    assert abs(ours[0] - theirs[0]) < 1e-6 * theirs[0]
+    assert np.abs(ours - theirs).max() < 2e-3 * theirs.max(), (ours[-5:], theirs[-5:])
+    assert ours[-1] < 0.97 * ours[0]
