@@ -30,7 +30,7 @@ struct LdsLayer {
 // in1/in2: LDS images (row strides S1/S2, logical 0 at column B1/B2).  afrag: packed A
 // fragments [MT][CB][TAPS][64] in global memory.  store(co, t, v) consumes every output
 // (t = P*col + p + OUT_OFF in the caller's local coordinates) and applies its own masks.
-template <class L, int S1, int B1, int S2, int B2, bool PIPE = true, class Store>
+template <class L, int S1, int B1, int S2, int B2, bool PIPE = true, bool BDB = true, class Store>
 __device__ __forceinline__ void conv_lds(const float* in1, const float* in2, const float* __restrict__ afrag,
                                          const float* __restrict__ bias, const int cols, Store store, const int wave,
                                          const int nwaves, const int lane) {
@@ -55,35 +55,66 @@ __device__ __forceinline__ void conv_lds(const float* in1, const float* in2, con
     // sched_barrier keeps hipcc from sinking the loads back down to their first use (it otherwise
     // emits load -> s_waitcnt 0 -> mfma for every K-step and the wave stalls on every L2 round trip).
     float a0[L::TAPS], a1[L::TAPS];
-    float b0[L::TAPS][L::NB], b1[L::TAPS][L::NB];
-    auto load_ab = [&](float (&av)[L::TAPS], float (&bv)[L::TAPS][L::NB], int cb) {
-      const float* bp = (cb < L::CB1) ? bp1 + cb * 4 * S1 : bp2 + (cb - L::CB1) * 4 * S2;
+    if constexpr (BDB) {
+      float b0[L::TAPS][L::NB], b1[L::TAPS][L::NB];
+      auto load_ab = [&](float (&av)[L::TAPS], float (&bv)[L::TAPS][L::NB], int cb) {
+        const float* bp = (cb < L::CB1) ? bp1 + cb * 4 * S1 : bp2 + (cb - L::CB1) * 4 * S2;
 #pragma unroll
-      for (int tap = 0; tap < L::TAPS; ++tap) av[tap] = ap[(cb * L::TAPS + tap) * 64];
+        for (int tap = 0; tap < L::TAPS; ++tap) av[tap] = ap[(cb * L::TAPS + tap) * 64];
 #pragma unroll
-      for (int tap = 0; tap < L::TAPS; ++tap)
+        for (int tap = 0; tap < L::TAPS; ++tap)
 #pragma unroll
-        for (int j = 0; j < L::NB; ++j) bv[tap][j] = bp[j * 16 * L::SN + tap];
-    };
-    auto mac = [&](const float (&av)[L::TAPS], const float (&bv)[L::TAPS][L::NB]) {
+          for (int j = 0; j < L::NB; ++j) bv[tap][j] = bp[j * 16 * L::SN + tap];
+      };
+      auto mac = [&](const float (&av)[L::TAPS], const float (&bv)[L::TAPS][L::NB]) {
 #pragma unroll
-      for (int tap = 0; tap < L::TAPS; ++tap)
+        for (int tap = 0; tap < L::TAPS; ++tap)
 #pragma unroll
-        for (int j = 0; j < L::NB; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap], bv[tap][j], acc[j], 0, 0, 0);
-    };
-    load_ab(a0, b0, 0);
+          for (int j = 0; j < L::NB; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap], bv[tap][j], acc[j], 0, 0, 0);
+      };
+      load_ab(a0, b0, 0);
 #pragma unroll 1
-    for (int cb = 0; cb < L::CB; cb += 2) {
-      if (cb + 1 < L::CB) load_ab(a1, b1, cb + 1);
-      if (PIPE) __builtin_amdgcn_sched_barrier(0);
-      mac(a0, b0);
-      if (PIPE) __builtin_amdgcn_sched_barrier(0);
-      if (cb + 1 < L::CB) {
-        if (cb + 2 < L::CB) load_ab(a0, b0, cb + 2);
+      for (int cb = 0; cb < L::CB; cb += 2) {
+        if (cb + 1 < L::CB) load_ab(a1, b1, cb + 1);
         if (PIPE) __builtin_amdgcn_sched_barrier(0);
-        mac(a1, b1);
+        mac(a0, b0);
         if (PIPE) __builtin_amdgcn_sched_barrier(0);
+        if (cb + 1 < L::CB) {
+          if (cb + 2 < L::CB) load_ab(a0, b0, cb + 2);
+          if (PIPE) __builtin_amdgcn_sched_barrier(0);
+          mac(a1, b1);
+          if (PIPE) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+      // wide layers (NB = 6): only the weight fragments are fetched a block ahead; the B fragments come out of
+      // LDS tap by tap right before their MFMAs, so that the 24 accumulators + operands fit the 128 registers
+      // a 1024-thread workgroup leaves each wave (the double-buffered form spilled 24 dwords per lane)
+      auto load_a = [&](float (&av)[L::TAPS], int cb) {
+#pragma unroll
+        for (int tap = 0; tap < L::TAPS; ++tap) av[tap] = ap[(cb * L::TAPS + tap) * 64];
+      };
+      auto mac = [&](const float (&av)[L::TAPS], int cb) {
+        const float* bp = (cb < L::CB1) ? bp1 + cb * 4 * S1 : bp2 + (cb - L::CB1) * 4 * S2;
+#pragma unroll
+        for (int tap = 0; tap < L::TAPS; ++tap) {
+          float bv[L::NB];
+#pragma unroll
+          for (int j = 0; j < L::NB; ++j) bv[j] = bp[j * 16 * L::SN + tap];
+#pragma unroll
+          for (int j = 0; j < L::NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap], bv[j], acc[j], 0, 0, 0);
+        }
+      };
+      load_a(a0, 0);
+#pragma unroll 1
+      for (int cb = 0; cb < L::CB; cb += 2) {
+        if (cb + 1 < L::CB) load_a(a1, cb + 1);
+        mac(a0, cb);
+        if (cb + 1 < L::CB) {
+          if (cb + 2 < L::CB) load_a(a0, cb + 2);
+          mac(a1, cb + 1);
+        }
       }
     }
     // Epilogue.  Row m = 16*mt + 4*g + r of the D tile is (co, p) = (m / P, m % P); with P in

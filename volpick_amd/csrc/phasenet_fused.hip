@@ -73,6 +73,10 @@ using C_u1same = LdsLayer<32, 32, 32, 1, 7, 1, -3, 0, 6, 1>;
 using C_u2T = LdsLayer<32, 0, 16, 4, 2, 1, -1, -1, 3, 1>;
 using C_u2same = LdsLayer<16, 16, 16, 1, 7, 1, -3, 0, 6, 1>;
 
+// layers with at least this many n-tiles per item read their B fragments tap by tap instead of double-buffering a
+// whole channel block of them (register budget of a 1024-thread workgroup: 128 per wave)
+constexpr int BDB_MAX_NB = 6;
+
 // LDS arena (floats); lifetimes in the header comment of pn_core_kernel
 constexpr int A_SKIP1 = 0;                       // 16 x 784
 constexpr int A_SKIP2 = A_SKIP1 + 16 * S1_;      // 32 x 240
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(1024) void pn_core_kernel(const CoreArgs a) {
   {                                                                                                                \
     RangeStore<SO, IB> st{lds + (OUT), (LOUT)};                                                                   \
     zero_halo<CO, SO, LOUT>(lds + (OUT), tid, NTH);                                                              \
-    conv_lds<LAYER, SI1, IB, SI2, IB, PIPE>(lds + (IN1), lds + (IN2), a.af[IDX], a.bs[IDX], (COLS), st, wave, NWV, lane); \
+    conv_lds<LAYER, SI1, IB, SI2, IB, PIPE, (LAYER::NB < BDB_MAX_NB)>(lds + (IN1), lds + (IN2), a.af[IDX], a.bs[IDX], (COLS), st, wave, NWV, lane); \
     __syncthreads();                                                                                               \
     CORE_STAMP()                                                                                                   \
     if (a.dbg[DBG]) dump_image<CO, SO>(lds + (OUT), (LOUT), a.dbg[DBG], a.dbg_ls[DBG], a.dbg_ws[DBG], win, tid, NTH); \
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(1024) void pn_core_kernel(const CoreArgs a) {
 #undef CORE_LAYER
   {
     GlobalRowStore st{a.u2s + (long)win * a.ws_u2s + HALO, a.ls_u2s, T1, 0};
-    conv_lds<C_u2same, S1_, IB, S1_, IB, PIPE>(lds + A_SKIP1, lds + A_U2T, a.af[12], a.bs[12], T1, st, wave, NWV, lane);
+    conv_lds<C_u2same, S1_, IB, S1_, IB, PIPE, (C_u2same::NB < BDB_MAX_NB)>(lds + A_SKIP1, lds + A_U2T, a.af[12], a.bs[12], T1, st, wave, NWV, lane);
   }
   __syncthreads();
   CORE_STAMP()
