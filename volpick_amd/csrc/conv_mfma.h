@@ -297,7 +297,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     static_assert(N_THR <= 256 && 4 * (N_THR - 1) + 15 < C::OS, "head epilogue geometry");
     if (tid < N_THR) {
       float acc[4] = {bias_h, bias_h, bias_h, bias_h};
-#pragma unroll
+      // not unrolled over the channels: the fully unrolled form kept 8 x 16 staged values live and took the kernel
+      // to 204 VGPRs (2 waves/SIMD); one channel at a time stays near the main loop's budget
+#pragma unroll 1
       for (int ci = 0; ci < 8; ++ci) {
         float v[16];
 #pragma unroll
