@@ -62,12 +62,12 @@ using G_u1T = ConvCfg<32, 0, 64, 1, 7, 4, 0, 0, 4, 1, 3, 0, EPI_STORE>;
 using G_u2T = ConvCfg<16, 0, 32, 1, 7, 4, 0, 0, 2, 2, 3, 0, EPI_STORE>;
 using G_u3T = ConvCfg<8, 0, 16, 1, 7, 4, 0, 0, 1, 4, 4, 0, EPI_STORE>;
 //                     LO HI1 HI2 K S NWAVE TT [WB windows per item]
-using W_inc = WgradCfg<8, 3, 0, 7, 1, 4, 256>;
-using W_d0s = WgradCfg<8, 8, 0, 7, 1, 4, 256>;
-using W_d0d = WgradCfg<8, 8, 0, 7, 4, 4, 256>;
-using W_d1s = WgradCfg<16, 8, 0, 7, 1, 4, 256>;
-using W_d1d = WgradCfg<16, 16, 0, 7, 4, 4, 96>;
-using W_d2s = WgradCfg<32, 16, 0, 7, 1, 4, 192>;
+using W_inc = WgradCfg<8, 3, 0, 7, 1, 8, 256>;
+using W_d0s = WgradCfg<8, 8, 0, 7, 1, 8, 256>;
+using W_d0d = WgradCfg<8, 8, 0, 7, 4, 8, 256>;
+using W_d1s = WgradCfg<16, 8, 0, 7, 1, 8, 256>;
+using W_d1d = WgradCfg<16, 16, 0, 7, 4, 8, 96>;
+using W_d2s = WgradCfg<32, 16, 0, 7, 1, 8, 192>;
 using W_d2d = WgradCfg<32, 32, 0, 7, 4, 4, 48>;
 using W_d3s = WgradCfg<64, 32, 0, 7, 1, 8, 48>;
 using W_d3d = WgradCfg<64, 64, 0, 7, 4, 16, 12, 2>;
@@ -76,10 +76,10 @@ using W_u0T = WgradCfg<128, 64, 0, 7, 4, 16, 12, 2>;
 using W_u0s = WgradCfg<64, 64, 64, 7, 1, 16, 48>;
 using W_u1T = WgradCfg<64, 32, 0, 7, 4, 8, 48>;
 using W_u1s = WgradCfg<32, 32, 32, 7, 1, 8, 96>;
-using W_u2T = WgradCfg<32, 16, 0, 7, 4, 4, 96>;
-using W_u2s = WgradCfg<16, 16, 16, 7, 1, 4, 256>;
-using W_u3T = WgradCfg<16, 8, 0, 7, 4, 4, 256>;
-using W_u3s = WgradCfg<8, 8, 8, 7, 1, 4, 256>;
+using W_u2T = WgradCfg<32, 16, 0, 7, 4, 8, 96>;
+using W_u2s = WgradCfg<16, 16, 16, 7, 1, 8, 256>;
+using W_u3T = WgradCfg<16, 8, 0, 7, 4, 8, 256>;
+using W_u3s = WgradCfg<8, 8, 8, 7, 1, 8, 256>;
 
 struct ConvOp {
   bool used = false;
