@@ -111,6 +111,7 @@ struct CoreArgs {
   int dbg_ls[12];
   long dbg_ws[12];
   unsigned long long* clk;  // optional [B][32]: [0..14] shader-clock stamps (start, load, 13 layers), [16],[17] 100 MHz wall clock
+  int warm;                 // 1 (default): the first workgroup of each XCD pre-touches the weights
 };
 
 template <int C, int S>
@@ -135,6 +136,20 @@ __global__ __launch_bounds__(1024) void pn_core_kernel(const CoreArgs a) {
   if (a.clk && tid == 0) a.clk[(long)win * 32 + stamp] = __builtin_readcyclecounter(); \
   ++stamp;
   CORE_STAMP()
+
+  // The first workgroup of each XCD (consecutive workgroups go to consecutive XCDs) touches one word of every
+  // 128-byte line of the 1.06 MB of packed weights: kernels of the other contexts have pushed them out of L2 since
+  // the last launch, and the layer chain below would otherwise meet the misses one channel block at a time.
+  if (win < 8 && a.warm) {
+    float sink = 0.f;
+#define CORE_WARM(IDX, LAYER)                                                                          \
+  for (int l = tid; l < LAYER::MT * LAYER::CB * LAYER::TAPS * 2; l += NTH) sink += a.af[IDX][l * 32];
+    CORE_WARM(0, C_d1same) CORE_WARM(1, C_d1down) CORE_WARM(2, C_d2same) CORE_WARM(3, C_d2down) CORE_WARM(4, C_d3same)
+    CORE_WARM(5, C_d3down) CORE_WARM(6, C_d4same) CORE_WARM(7, C_u0T) CORE_WARM(8, C_u0same) CORE_WARM(9, C_u1T)
+    CORE_WARM(10, C_u1same) CORE_WARM(11, C_u2T) CORE_WARM(12, C_u2same)
+#undef CORE_WARM
+    if (sink == 1.2345678e-30f) a.u2s[0] = sink;  // never true: keeps the loads alive
+  }
 
   // ---- load down0.down (8 x 751) -------------------------------------------------------
   {
@@ -674,6 +689,7 @@ int plan_phasenet_fused(Net& net, int debug_flags) {
         }
       }
       a.clk = clk ? reinterpret_cast<unsigned long long*>(clk->d) : nullptr;
+      a.warm = n.cfg.reserved[4] != 1;
       if (pipe) {
         hipLaunchKernelGGL(pn_core_kernel<true>, dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
       } else {

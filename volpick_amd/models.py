@@ -232,7 +232,10 @@ class WaveformModel:
         _lib.check(lib.vp_default_config(self._kind, C.byref(cfg)))
         cfg.norm = _lib.VP_NORM_PEAK if self.norm == "peak" else _lib.VP_NORM_STD
         cfg.max_batch = int(self._max_batch)
-        for i, v in enumerate(self._plan_flags):
+        flags = self._plan_flags
+        if os.environ.get("VOLPICK_PLAN_FLAGS"):  # A/B timing of plan variants through bench.py (debug)
+            flags = tuple(int(v) for v in os.environ["VOLPICK_PLAN_FLAGS"].split(","))
+        for i, v in enumerate(flags):
             cfg.reserved[i] = int(v)
         return cfg
 
