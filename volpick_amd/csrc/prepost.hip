@@ -10,8 +10,8 @@ namespace vp {
 // A2 + A3: one workgroup per window.  Gathers window w of the (3, N) stream (or of a dense
 // (B,3,T) batch), subtracts the per-channel mean, divides by the peak / std amplitude
 // (per channel or over all three channels) + eps, applies the 6-sample half-cosine taper
-// (EQT) and writes the haloed model input row.  Three coalesced passes over <= 72 KB that
-// stay in L2; wavefront shuffle + LDS reductions.
+// (EQT) and writes the haloed model input row.  The window (<= 72 KB) is read once into registers;
+// wavefront shuffle + LDS reductions.
 // ---------------------------------------------------------------------------------------
 __device__ inline float wave_sum(float v) {
 #pragma unroll
@@ -46,13 +46,21 @@ __global__ __launch_bounds__(1024) void gather_normalize_kernel(const PreArgs a)
       for (int t = tid; t < T; t += NTH) dst[(long)c * a.lsd + t] = src[c * cs + t];
     return;
   }
-  // pass 1: mean per channel
+  // The window lives in registers: one read of the stream, all three steps (mean, amplitude, scale) from there.
+  constexpr int MAXE = 6;  // samples per thread and channel: T <= 6144
+  float v[3][MAXE];
   float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
   for (int c = 0; c < 3; ++c)
-    for (int t = tid; t < T; t += NTH) s[c] += src[c * cs + t];
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) {
+      const int t = tid + k * NTH;
+      v[c][k] = t < T ? src[c * cs + t] : 0.f;
+      s[c] += v[c][k];
+    }
   for (int c = 0; c < 3; ++c) {
-    const float v = wave_sum(s[c]);
-    if (lane == 0) red[c][wave] = v;
+    const float r = wave_sum(s[c]);
+    if (lane == 0) red[c][wave] = r;
   }
   __syncthreads();
   if (tid < 3) {
@@ -62,22 +70,26 @@ __global__ __launch_bounds__(1024) void gather_normalize_kernel(const PreArgs a)
   }
   __syncthreads();
   const float mean[3] = {stat[0][0], stat[1][0], stat[2][0]};
-  // pass 2: amplitude of the demeaned window
   float m[3] = {0.f, 0.f, 0.f};
+#pragma unroll
   for (int c = 0; c < 3; ++c)
-    for (int t = tid; t < T; t += NTH) {
-      const float d = src[c * cs + t] - mean[c];
-      if (a.norm == VP_NORM_PEAK) {
-        m[c] = fmaxf(m[c], fabsf(d));
-        if (d != d) m[c] = d;  // propagate NaN like torch.max
-      } else {
-        m[c] += d * d;
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) {
+      const int t = tid + k * NTH;
+      if (t < T) {
+        const float d = v[c][k] - mean[c];
+        if (a.norm == VP_NORM_PEAK) {
+          m[c] = fmaxf(m[c], fabsf(d));
+          if (d != d) m[c] = d;  // propagate NaN like torch.max
+        } else {
+          m[c] += d * d;
+        }
       }
     }
   __syncthreads();
   for (int c = 0; c < 3; ++c) {
-    const float v = (a.norm == VP_NORM_PEAK) ? wave_max(m[c]) : wave_sum(m[c]);
-    if (lane == 0) red[c][wave] = v;
+    const float r = (a.norm == VP_NORM_PEAK) ? wave_max(m[c]) : wave_sum(m[c]);
+    if (lane == 0) red[c][wave] = r;
   }
   __syncthreads();
   if (tid < 3) {
@@ -96,24 +108,32 @@ __global__ __launch_bounds__(1024) void gather_normalize_kernel(const PreArgs a)
                                              : sqrtf((stat[0][1] + stat[1][1] + stat[2][1]) / (float)(3 * T - 1));
     amp[0] = amp[1] = amp[2] = g;
   }
-  // pass 3: scale (+ taper) and write
+#pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float den = amp[c] + a.norm_eps;
-    for (int t = tid; t < T; t += NTH) {
-      float v = (src[c * cs + t] - mean[c]) / den;
-      if (a.taper > 0) {
-        const int e = (t < a.taper) ? t : ((T - 1 - t < a.taper) ? T - 1 - t : -1);
-        if (e >= 0) {  // 0.5 * (1 + cos(linspace(pi, 2 pi, taper)[e]))
-          const float ang = 3.14159265358979323846f * (1.f + (float)e / (float)(a.taper - 1));
-          v *= 0.5f * (1.f + cosf(ang));
+#pragma unroll
+    for (int k = 0; k < MAXE; ++k) {
+      const int t = tid + k * NTH;
+      if (t < T) {
+        float o = (v[c][k] - mean[c]) / den;
+        if (a.taper > 0) {
+          const int e = (t < a.taper) ? t : ((T - 1 - t < a.taper) ? T - 1 - t : -1);
+          if (e >= 0) {  // 0.5 * (1 + cos(linspace(pi, 2 pi, taper)[e]))
+            const float ang = 3.14159265358979323846f * (1.f + (float)e / (float)(a.taper - 1));
+            o *= 0.5f * (1.f + cosf(ang));
+          }
         }
+        dst[(long)c * a.lsd + t] = o;
       }
-      dst[(long)c * a.lsd + t] = v;
     }
   }
 }
 
 int launch_gather_normalize(const PreArgs& a, int n_windows, hipStream_t stream) {
+  if (a.T > 6 * 1024) {  // the kernel keeps a window in registers: 6 samples per thread and channel
+    set_error("gather_normalize: in_samples %d exceeds 6144", a.T);
+    return VP_ERR_UNSUPPORTED;
+  }
   hipLaunchKernelGGL(gather_normalize_kernel, dim3(n_windows), dim3(1024), 0, stream, a);
   return 0;
 }
