@@ -35,7 +35,7 @@ def _oracle_acts(net, x):
     return y, acts
 
 
-@pytest.mark.parametrize("flags", [(0, 1), (1, 0)], ids=["fused+dumps", "layerwise"])
+@pytest.mark.parametrize("flags", [(0, 1), (0, 1, 0, 0, 0, 1), (1, 0)], ids=["fused+dumps", "fused-mfma+dumps", "layerwise"])
 def test_layers_match_oracle(oracle, flags):
     model = PhaseNet.from_pretrained("volpick")
     model._plan_flags = flags
@@ -70,14 +70,21 @@ def test_layers_match_oracle(oracle, flags):
 
 
 def test_fused_equals_layerwise_bitwise(oracle):
-    """Same packed weights, same k-order of every MFMA chain: the two plans must agree exactly."""
+    """Same packed weights, same k-order of every MFMA chain: the all-MFMA fused plan (reserved[5] = 1) and the
+    layer plan must agree exactly; the default plan runs the level-0 layers on the VALU (another summation
+    order) and agrees to rounding."""
     x = synthetic_windows(9, 3001, seed=77)
     xn = OP.batch_pre(oracle, torch.from_numpy(x))
-    fused = PhaseNet.from_pretrained("volpick").cuda()
+    fused = PhaseNet.from_pretrained("volpick")
+    fused._plan_flags = (0, 0, 0, 0, 0, 1)
+    fused.cuda()
     layer = PhaseNet.from_pretrained("volpick")
     layer._plan_flags = (1, 0)
     layer.cuda()
-    assert np.array_equal(fused(xn).numpy(), layer(xn).numpy())
+    want = layer(xn).numpy()
+    assert np.array_equal(fused(xn).numpy(), want)
+    default = PhaseNet.from_pretrained("volpick").cuda()
+    assert np.abs(default(xn).numpy() - want).max() < 5e-6
 
 
 @pytest.mark.parametrize("B", [1, 5, 256, 300])

@@ -38,7 +38,11 @@ for n, c in zip(names, med):
 wall = (clk[:, 17] - clk[:, 16]).astype(np.float64) / 100e6
 cyc = (clk[:, 14] - clk[:, 0]).astype(np.float64)
 print("in-kernel wall us (median)", np.median(wall) * 1e6, " shader clock GHz (median)", np.median(cyc / wall) / 1e9)
-u = np.diff(clk[:, 18:23].astype(np.int64), axis=1)
-print("up3 (tile 2) median cycles: load %d  u3T %d  u3same %d  softmax+store %d" % tuple(np.median(u, axis=0)))
+u = np.diff(clk[:, 18:26].astype(np.int64), axis=1)
+print("up3 VALU form (tile 1) median cycles: load skip rows %d  same(skip) %d  up2.same regs->LDS+barrier %d  convT (MFMA) %d  "
+      "barrier %d  same(convT) %d  1x1+softmax+store %d" % tuple(np.median(u, axis=0)))
+w0, w1 = clk[:, 26].astype(np.float64) / 100e6, clk[:, 27].astype(np.float64) / 100e6
+print("up3 VALU form (tile 1 of every window): workgroup wall us median %.2f; first start -> last end %.2f us; start spread %.2f us"
+      % (np.median(w1 - w0) * 1e6, (w1.max() - w0.min()) * 1e6, (w0.max() - w0.min()) * 1e6))
 print("total", tot, "cycles; window span min/med/max", (clk[:, 14] - clk[:, 0]).min(), np.median(clk[:, 14] - clk[:, 0]),
       (clk[:, 14] - clk[:, 0]).max())

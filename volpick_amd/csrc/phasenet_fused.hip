@@ -12,6 +12,7 @@
 // tiled kernel are local to the tile; ImageStore writes explicit zeros where the global position
 // falls outside the signal so that the next layer sees the reference's zero padding.
 #include "conv_lds.h"
+#include "conv_valu.h"
 #include "net.h"
 
 namespace vp {
@@ -583,6 +584,271 @@ __global__ __launch_bounds__(256) void pn_up3p_kernel(const Up3Args a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// VALU forms of the two level-0 kernels (conv_valu.h): direct convolution, four consecutive samples and all
+// eight output channels per lane, 256 lanes = a 1024-sample span per workgroup.  Layer chains shrink the valid
+// span by 3 samples per side per k7 layer, so consecutive tiles advance by 1008 (down path) / 1016 (up path).
+// ---------------------------------------------------------------------------------------------
+constexpr int VT = 1024, VS = VT + 8;           // lanes x 4 samples; image row stride (local l at column l + 4)
+constexpr int VD_TS = 1008, VD_TILES = (T0 + VD_TS - 1) / VD_TS;  // down0: local 0 <-> global VD_TS * tile - 8
+constexpr int VU_TS = 1016, VU_TILES = (T0 + VU_TS - 1) / VU_TS;  // up3:   local 0 <-> global VU_TS * tile - 4
+constexpr int VU_SX = 272;                      // up2.same image row stride (258 level-1 samples per tile; == 16 mod 32)
+// 45 KB and 50 KB of LDS: the three tiles of a window are resident on one CU together (256 windows on 256 CUs = one round)
+constexpr int VD_LDS_FLOATS = 11 * VS + 64, VU_LDS_FLOATS = 8 * VS + 16 * VU_SX + 64;  // + margin for masked MFMA columns
+// the strided and the transposed conv of the two kernels stay on the MFMA (weights used once per output sample:
+// on the VALU they are bound by scalar-load latency, measured 15 k cycles for 448 packed FMAs per lane)
+using VD_down = LdsLayer<8, 0, 8, 2, 11, 8, 5, 0, 1, 1>;   // out n' = 2n + p reads local 8n + tap + 5
+using VU_T = LdsLayer<16, 0, 8, 4, 2, 1, -1, -2, 5, 1>;    // out local 4m + p - 2 reads level-1 local m + tap - 1
+struct TileRowStore {  // haloed activation row store of one tile: local t in [0, t_hi), global t + t_add in [0, L)
+  float* p;
+  int ls, L, t_add, t_hi;
+  __device__ __forceinline__ void operator()(int co, int t, float v) const {
+    if ((unsigned)t < (unsigned)t_hi && t + t_add < L) p[(long)co * ls + t + t_add] = v;
+  }
+  __device__ __forceinline__ bool all_valid(int t0, int t1) const { return t0 >= 0 && t1 < t_hi && t1 + t_add < L; }
+  __device__ __forceinline__ void unchecked(int co, int t, float v) const { p[(long)co * ls + t + t_add] = v; }
+};
+constexpr int VX_Q = VS / 4;                    // float4 per image row
+static_assert(VD_TILES == 3 && VU_TILES == 3, "three tiles per window");
+
+struct Down0VArgs {
+  Down0Args t;  // tensors as in the MFMA form (af_* / bs_* unused)
+  const f32x2 *w_inc, *b_inc, *w_same, *b_same, *w_down, *b_down;  // [cin][7][4] channel pairs, [4] bias pairs
+  int n_windows;
+};
+
+// relu + zero outside the signal, channel pair c of acc -> two float4 rows
+__device__ __forceinline__ void valu_finish(const f32x2 (&acc)[4][4], int c, int tg, f32x4* lo, f32x4* hi) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool in = (unsigned)(tg + r) < (unsigned)T0;
+    (*lo)[r] = in ? fmaxf(acc[c][r].x, 0.f) : 0.f;
+    (*hi)[r] = in ? fmaxf(acc[c][r].y, 0.f) : 0.f;
+  }
+}
+__device__ __forceinline__ void valu_bias(f32x2 (&acc)[4][4], const f32x2* b) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[c][r] = as_weights(b)[c];
+}
+
+__global__ __launch_bounds__(256) void pn_down0v_kernel(const Down0VArgs a) {
+  extern __shared__ float4 lds_raw[];
+  float* lds = reinterpret_cast<float*>(lds_raw);
+  float *X = lds, *H = lds + 3 * VS;  // down0.same later overwrites the inc image H
+  const int tid = threadIdx.x;
+  // Workgroup -> (window, tile): consecutive workgroups go to consecutive XCDs, and the core kernel runs window w on
+  // XCD w % 8 — with this mapping the rows a window hands from kernel to kernel stay in one XCD's L2.
+  int win, tile;
+  {
+    const int id = blockIdx.x, B = a.n_windows;
+    if ((B & 7) == 0) {
+      const int slot = id >> 3;
+      win = (slot / 3) * 8 + (id & 7);
+      tile = slot % 3;
+    } else {
+      win = id / 3;
+      tile = id % 3;
+    }
+  }
+  const int g0 = VD_TS * tile - 8;  // global sample of local 0
+  {  // x image: local [-4, 1028); physical index of local -4 + 4q = HALO + g0 - 4 + 4q (16-byte aligned)
+    const float* src = a.t.x + (long)win * a.t.ws_x;
+    for (int i = tid; i < 3 * VX_Q; i += 256) {
+      const int c = i / VX_Q, q = i - c * VX_Q;
+      const int p = HALO + g0 - 4 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p >= 0 && p + 3 < a.t.ls_x) v = *reinterpret_cast<const float4*>(src + (long)c * a.t.ls_x + p);
+      *reinterpret_cast<float4*>(X + c * VS + 4 * q) = v;
+    }
+  }
+  __syncthreads();
+  const int t0 = 4 * tid, tg = g0 + t0;
+  const bool own = t0 >= 8 && t0 < 8 + VD_TS && tg < T0;  // samples this tile hands to memory
+  f32x2 acc[4][4];
+  {  // inc: Conv1d(3, 8, 7, same, bias) + BN + ReLU
+    valu_bias(acc, a.b_inc);
+    valu_conv7_r4<3, VS>(X, as_weights(a.w_inc), t0, acc);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4 lo, hi;
+      valu_finish(acc, c, tg, &lo, &hi);
+      *reinterpret_cast<f32x4*>(H + (2 * c) * VS + 4 + t0) = lo;
+      *reinterpret_cast<f32x4*>(H + (2 * c + 1) * VS + 4 + t0) = hi;
+      if (a.t.h0_dbg && own) {
+        float* d = a.t.h0_dbg + (long)win * a.t.ws_h + HALO + tg;
+        *reinterpret_cast<f32x4*>(d + (long)(2 * c) * a.t.ls_h) = lo;
+        *reinterpret_cast<f32x4*>(d + (long)(2 * c + 1) * a.t.ls_h) = hi;
+      }
+    }
+  }
+  __syncthreads();
+  {  // down0.same: Conv1d(8, 8, 7, same) + BN + ReLU -> skip tensor + image for the strided conv
+    valu_bias(acc, a.b_same);
+    valu_conv7_r4<8, VS>(H, as_weights(a.w_same), t0, acc);
+    __syncthreads();  // every lane has read its inc window: the image can be overwritten in place
+    f32x4 lo[4], hi[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      valu_finish(acc, c, tg, &lo[c], &hi[c]);
+      *reinterpret_cast<f32x4*>(H + (2 * c) * VS + 4 + t0) = lo[c];
+      *reinterpret_cast<f32x4*>(H + (2 * c + 1) * VS + 4 + t0) = hi[c];
+    }
+    __syncthreads();
+    // the skip rows go to memory AFTER the barrier (__syncthreads waits for every outstanding store) and drain
+    // behind the strided conv
+    if (own) {  // the float4 holding sample T0 - 1 also rewrites up to three zeros of the row's right margin
+      float* d = a.t.skip0 + (long)win * a.t.ws_s + HALO + tg;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        *reinterpret_cast<f32x4*>(d + (long)(2 * c) * a.t.ls_s) = lo[c];
+        *reinterpret_cast<f32x4*>(d + (long)(2 * c + 1) * a.t.ls_s) = hi[c];
+      }
+    }
+  }
+  {  // down0.down: Conv1d(8, 8, 7, stride 4, pad 3) + BN + ReLU on the MFMA; output n = 252 * tile + n' reads local 4 n' + 5 + k
+    TileRowStore st{a.t.d0 + (long)win * a.t.ws_d + HALO, a.t.ls_d, T1, (VD_TS / 4) * tile, VD_TS / 4};
+    conv_lds<VD_down, VS, 4, VS, 4, false>(H, H, a.t.af_down, a.t.bs_down, VD_TS / 8, st, tid >> 6, 4, tid & 63);
+  }
+}
+
+struct Up3VArgs {
+  Up3Args t;  // tensors as in the MFMA form
+  const f32x2 *w_t, *b_t, *w_same, *b_same;  // up3.convT [16][7][4], up3.same [16][7][4] (skip channels first)
+  int n_windows;
+};
+
+__global__ __launch_bounds__(256) void pn_up3v_kernel(const Up3VArgs a) {
+  extern __shared__ float4 lds_raw[];
+  float* lds = reinterpret_cast<float*>(lds_raw);
+  float *A = lds, *U = lds + 8 * VS;  // A: skip rows, later the up3.convT rows; U: up2.same rows
+  const int tid = threadIdx.x;
+  // Workgroup -> (window, tile): consecutive workgroups go to consecutive XCDs, and the core kernel runs window w on
+  // XCD w % 8 — with this mapping the rows a window hands from kernel to kernel stay in one XCD's L2.
+  int win, tile;
+  {
+    const int id = blockIdx.x, B = a.n_windows;
+    if ((B & 7) == 0) {
+      const int slot = id >> 3;
+      win = (slot / 3) * 8 + (id & 7);
+      tile = slot % 3;
+    } else {
+      win = id / 3;
+      tile = id % 3;
+    }
+  }
+  const int g0 = VU_TS * tile - 4;  // global sample of local 0
+  int stamp = 18;  // debug clock stamps of tile 1 (slots 18..25 of the core's [B][32] block)
+#define UP3V_STAMP()                                                                                  \
+  if (a.t.clk && tid == 0 && tile == 1) a.t.clk[(long)win * 32 + stamp] = __builtin_readcyclecounter(); \
+  ++stamp;
+  UP3V_STAMP()
+  if (a.t.clk && tid == 0 && tile == 1) a.t.clk[(long)win * 32 + 26] = wall_clock64();
+  const int lane = tid & 63, wave = tid >> 6;
+  // skip rows: local [-4, 1028); physical index HALO + g0 - 4 + 4q = VU_TS * tile + 4q
+  constexpr int NSK = (8 * VX_Q + 255) / 256;
+  float4 sk[NSK];
+  {
+    const float* src = a.t.skip0 + (long)win * a.t.ws_s + VU_TS * tile;
+#pragma unroll
+    for (int k = 0; k < NSK; ++k) {
+      const int i = tid + k * 256, c = i / VX_Q, q = i - c * VX_Q;
+      sk[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < 8 * VX_Q && VU_TS * tile + 4 * q + 3 < a.t.ls_s) sk[k] = *reinterpret_cast<const float4*>(src + (long)c * a.t.ls_s + 4 * q);
+    }
+  }
+  // up2.same rows: U[ci][j] = x[ci][(g0 >> 2) - 1 + j], j in [0, 258); physical index HALO + 254 tile - 2 + j >= 6.
+  // Fetched into registers behind the skip rows and written to their image after the skip half of up3.same
+  // (first use: the transposed conv): they stay in flight across the first barrier.
+  constexpr int NU = (16 * 258 + 255) / 256;
+  float u[NU];
+  {
+    const float* us = a.t.u2s + (long)win * a.t.ws_u + HALO + (VU_TS / 4) * tile - 2;
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+      const int i = tid + k * 256, c = i / 258, j = i - c * 258;
+      u[k] = (i < 16 * 258) ? us[(long)c * a.t.ls_u + j] : 0.f;
+    }
+  }
+  // A fragments of the transposed conv (M = 32: waves 0, 2 take m-tile 0, waves 1, 3 m-tile 1), resident in registers
+  float aT[VU_T::CB * VU_T::TAPS], bT[4];
+  load_areg<VU_T>(a.t.af_t, wave & 1, lane, aT);
+  load_biasreg<VU_T>(a.t.bs_t, wave & 1, lane, bT);
+#pragma unroll
+  for (int k = 0; k < NSK; ++k) {
+    const int i = tid + k * 256, c = i / VX_Q, q = i - c * VX_Q;
+    if (i < 8 * VX_Q) *reinterpret_cast<float4*>(A + c * VS + 4 * q) = sk[k];
+  }
+  lds_barrier();  // not __syncthreads(): the up2.same rows and the A fragments are still in flight
+  UP3V_STAMP()
+  const int t0 = 4 * tid, tg = g0 + t0;
+  const bool own = t0 >= 4 && t0 < 4 + VU_TS && tg < T0;
+  f32x2 acc[4][4];
+  // up3.same on cat([skip0, up3.convT]): the skip half first, then the convT rows take the skip image's place
+  valu_bias(acc, a.b_same);
+  valu_conv7_r4<8, VS>(A, as_weights(a.w_same), t0, acc);
+  UP3V_STAMP()
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const int i = tid + k * 256, c = i / 258, j = i - c * 258;
+    if (i < 16 * 258) U[c * VU_SX + j] = u[k];
+  }
+  __syncthreads();
+  UP3V_STAMP()
+  {  // up3.convT: ConvTranspose1d(16, 8, 7, stride 4) + BN + ReLU, crop [1:-2] and centre crop (t = o - 2), on the MFMA
+    ImageStore<VS, 4> st{A, 0, VT, -g0, T0 - g0};
+    conv_lds_areg<VU_T, VU_SX, 1, VU_SX, 1>(U, U, aT, bT, wave & 1, VT / 4 + 1, st, wave >> 1, 2, lane);
+  }
+  UP3V_STAMP()
+  __syncthreads();
+  if (a.t.ut_dbg && own) {
+    float* d = a.t.ut_dbg + (long)win * a.t.ws_t + HALO + tg;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) *reinterpret_cast<f32x4*>(d + (long)c * a.t.ls_t) = *reinterpret_cast<const f32x4*>(A + c * VS + 4 + t0);
+  }
+  UP3V_STAMP()
+  valu_conv7_r4<8, VS>(A, as_weights(a.w_same + 8 * 28), t0, acc);
+  UP3V_STAMP()
+  if (own) {  // BN + ReLU -> Conv1d(8, 3, 1) -> softmax over channels
+    float z[3][4];
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z[o][r] = as_scalars(a.t.b_out)[o];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v0 = fmaxf(acc[c][r].x, 0.f), v1 = fmaxf(acc[c][r].y, 0.f);
+#pragma unroll
+        for (int o = 0; o < 3; ++o)
+          z[o][r] = fmaf(as_scalars(a.t.w_out)[o * 8 + 2 * c + 1], v1, fmaf(as_scalars(a.t.w_out)[o * 8 + 2 * c], v0, z[o][r]));
+      }
+    f32x4 y0, y1, y2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float mx = fmaxf(z[0][r], fmaxf(z[1][r], z[2][r]));
+      const float e0 = __expf(z[0][r] - mx), e1 = __expf(z[1][r] - mx), e2 = __expf(z[2][r] - mx);
+      const float inv = 1.f / (e0 + e1 + e2);
+      y0[r] = e0 * inv, y1[r] = e1 * inv, y2[r] = e2 * inv;
+    }
+    float* y = a.t.y + (long)win * 3 * T0 + tg;
+    if (tg + 3 < T0) {  // dense rows of odd length: 4-byte aligned vector stores
+      *reinterpret_cast<f32x4u*>(y) = y0;
+      *reinterpret_cast<f32x4u*>(y + T0) = y1;
+      *reinterpret_cast<f32x4u*>(y + 2 * T0) = y2;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (tg + r < T0) y[r] = y0[r], y[T0 + r] = y1[r], y[2 * T0 + r] = y2[r];
+    }
+  }
+  UP3V_STAMP()
+  if (a.t.clk && tid == 0 && tile == 1) a.t.clk[(long)win * 32 + 27] = wall_clock64();
+#undef UP3V_STAMP
+}
+
 int tensor_id(const Net& net, const std::string& name) {
   for (size_t i = 0; i < net.tensors.size(); ++i)
     if (net.tensors[i].name == name) return (int)i;
@@ -593,13 +859,47 @@ int tensor_id(const Net& net, const std::string& name) {
 
 // Replaces the 18 layer steps planned by plan_phasenet with the three fused launches.  The
 // packed weights of the layer plan are reused as they are (same P / taps / channel padding).
-int plan_phasenet_fused(Net& net, int debug_flags) {
+namespace {
+// [cout = 8][cin][7] (Conv1d) or [cin][cout = 8][7] (ConvTranspose1d) -> [cin][7][8] with the BatchNorm scale folded in:
+// channel pairs (2c, 2c + 1) are adjacent, one s_load_dwordx8 fetches a (channel, tap) for all outputs
+std::vector<float> pack_valu(const float* W, int cin, bool transposed, const std::vector<float>& scale) {
+  std::vector<float> out((size_t)cin * 7 * 8);
+  for (int ci = 0; ci < cin; ++ci)
+    for (int k = 0; k < 7; ++k)
+      for (int co = 0; co < 8; ++co)
+        out[((size_t)ci * 7 + k) * 8 + co] = scale[co] * (transposed ? W[((size_t)ci * 8 + co) * 7 + k] : W[((size_t)co * cin + ci) * 7 + k]);
+  return out;
+}
+}  // namespace
+
+int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
   const bool debug_dumps = (debug_flags & 1) != 0, debug_clock = (debug_flags & 2) != 0;
   // reserved[2] = 1 selects the hand-pipelined K loop (sched_barrier) for A/B timing; the compiler's own
   // schedule measured 0-5 % faster on every layer (tools/micro/micro_layers.hip), so it is the default.
   const bool pipe = net.cfg.reserved[2] == 1;
   const bool persistent = net.cfg.reserved[3] != 1;  // reserved[3] = 1: one workgroup per tile for up3 too (A/B timing)
   const bool down0_persistent = net.cfg.reserved[3] == 2;
+  // reserved[5] = 1 keeps the MFMA forms of the two level-0 kernels (A/B timing; bit-identical to the layer plan)
+  const bool valu = net.cfg.reserved[5] != 1;
+  HostBlob *vw[5] = {}, *vb[5] = {};
+  if (valu) {
+    const float eps = net.cfg.bn_eps;
+    struct {
+      const char *conv, *bn;
+      int cin;
+      bool transposed, bias;
+    } spec[5] = {{"inc", "in_bn", 3, false, true},
+                 {"down_branch.0.0", "down_branch.0.1", 8, false, false},
+                 {"down_branch.0.2", "down_branch.0.3", 8, false, false},
+                 {"up_branch.3.0", "up_branch.3.1", 16, true, false},
+                 {"up_branch.3.2", "up_branch.3.3", 16, false, false}};
+    for (int i = 0; i < 5; ++i) {
+      std::vector<float> scale, shift;
+      bn_fold(pv, spec[i].bn, 8, eps, spec[i].bias ? pv.get(std::string(spec[i].conv) + ".bias") : nullptr, &scale, &shift);
+      vw[i] = net.add_blob(pack_valu(pv.get(std::string(spec[i].conv) + ".weight"), spec[i].cin, spec[i].transposed, scale));
+      vb[i] = net.add_blob(shift);
+    }
+  }
   if (net.convs.size() != 18) {
     set_error("fused PhaseNet plan expects the 18-layer plan");
     return VP_ERR_INVALID;
@@ -611,6 +911,12 @@ int plan_phasenet_fused(Net& net, int debug_flags) {
   net.need(x, (n_tiles - 1) * TT - 8 + 4 * ((TT + 28) / 4));
   net.need(skip0, HALO + (n_tiles - 1) * TT - 16 + 12 + 4 * 130);
   net.need(u2s, HALO + (n_tiles - 1) * TT / 4 - 4 + 144);
+  if (valu) {
+    net.need(x, HALO + VD_TS * (VD_TILES - 1) - 12 + VS);      // x image float4 loads
+    net.need(skip0, VU_TS * (VU_TILES - 1) + VS);              // skip image float4 loads
+    net.need(skip0, HALO + VD_TS * VD_TILES);                  // skip stores of the last down tile
+    net.need(u2s, HALO + (VU_TS / 4) * (VU_TILES - 1) - 2 + 258);  // up2.same image loads
+  }
   std::vector<Step> steps;
   auto flops = [&](int lo, int hi) {
     double f = 0;
@@ -646,7 +952,18 @@ int plan_phasenet_fused(Net& net, int debug_flags) {
       a.bs_down = n.convs[2]->bias.d;
       // measured (tools/ab_steps.py, one process): the persistent form is 4-15 % SLOWER here (its 46
       // A registers cost occupancy and one-tile workgroups already stagger well); reserved[3] = 2 selects it
-      if (down0_persistent && !debug_dumps) {
+      if (valu) {
+        Down0VArgs v{};
+        v.t = a;
+        v.w_inc = reinterpret_cast<const f32x2*>(vw[0]->d);
+        v.b_inc = reinterpret_cast<const f32x2*>(vb[0]->d);
+        v.w_same = reinterpret_cast<const f32x2*>(vw[1]->d);
+        v.b_same = reinterpret_cast<const f32x2*>(vb[1]->d);
+        v.w_down = reinterpret_cast<const f32x2*>(vw[2]->d);
+        v.b_down = reinterpret_cast<const f32x2*>(vb[2]->d);
+        v.n_windows = B;
+        hipLaunchKernelGGL(pn_down0v_kernel, dim3(VD_TILES * B), dim3(256), VD_LDS_FLOATS * sizeof(float), s, v);
+      } else if (down0_persistent && !debug_dumps) {
         hipLaunchKernelGGL(pn_down0p_kernel, dim3(NSPLIT_D, B), dim3(256), D0_LDS_FLOATS * sizeof(float), s, a);
       } else if (pipe) {
         hipLaunchKernelGGL(pn_down0_kernel<true>, dim3(n_tiles, B), dim3(256), D0_LDS_FLOATS * sizeof(float), s, a);
@@ -727,7 +1044,16 @@ int plan_phasenet_fused(Net& net, int debug_flags) {
       a.w_out = e0->d;
       a.b_out = e1->d;
       a.clk = n.debug_clock ? reinterpret_cast<unsigned long long*>(n.debug_clock->d) : nullptr;
-      if (persistent && !debug_dumps) {
+      if (valu) {
+        Up3VArgs v{};
+        v.t = a;
+        v.w_t = reinterpret_cast<const f32x2*>(vw[3]->d);
+        v.b_t = reinterpret_cast<const f32x2*>(vb[3]->d);
+        v.w_same = reinterpret_cast<const f32x2*>(vw[4]->d);
+        v.b_same = reinterpret_cast<const f32x2*>(vb[4]->d);
+        v.n_windows = B;
+        hipLaunchKernelGGL(pn_up3v_kernel, dim3(VU_TILES * B), dim3(256), VU_LDS_FLOATS * sizeof(float), s, v);
+      } else if (persistent && !debug_dumps) {
         hipLaunchKernelGGL(pn_up3p_kernel, dim3(NSPLIT_U, B), dim3(256), UP3_LDS_FLOATS * sizeof(float), s, a);
       } else if (pipe) {
         hipLaunchKernelGGL(pn_up3_kernel<true>, dim3(n_tiles, B), dim3(256), UP3_LDS_FLOATS * sizeof(float), s, a);
@@ -747,6 +1073,8 @@ int plan_phasenet_fused(Net& net, int debug_flags) {
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_up3_kernel<false>), UP3_LDS_FLOATS * sizeof(float)});
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_down0p_kernel), D0_LDS_FLOATS * sizeof(float)});
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_up3p_kernel), UP3_LDS_FLOATS * sizeof(float)});
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_down0v_kernel), VD_LDS_FLOATS * sizeof(float)});
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_up3v_kernel), VU_LDS_FLOATS * sizeof(float)});
   return VP_OK;
 }
 
