@@ -52,45 +52,50 @@ __device__ __forceinline__ void valu_load_win(ValuWin& w, const float* img, int 
     w.v[4 * v] = q.x, w.v[4 * v + 1] = q.y, w.v[4 * v + 2] = q.z, w.v[4 * v + 3] = q.w;
   }
 }
-// taps [K0, K1) of the window; w holds the channel-pair weights of taps KB, KB + 1, ...
-template <int K0, int K1, int KB, int NW>
-__device__ __forceinline__ void valu_taps(const ValuWin& win, const f32x2 (&w)[NW], f32x2 (&acc)[4][4]) {
+// taps [K0, K1) of the window; w holds NC channel-pair weights of each of the taps KB, KB + 1, ...
+template <int K0, int K1, int KB, int NC, int NW>
+__device__ __forceinline__ void valu_taps(const ValuWin& win, const f32x2 (&w)[NW], f32x2 (&acc)[NC][4]) {
 #pragma unroll
   for (int k = K0; k < K1; ++k)
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const f32x2 x = {win.v[r + k + 1], win.v[r + k + 1]};
-        acc[c][r] = __builtin_elementwise_fma(x, w[(k - KB) * 4 + c], acc[c][r]);
+        acc[c][r] = __builtin_elementwise_fma(x, w[(k - KB) * NC + c], acc[c][r]);
       }
 }
-template <int N>
-__device__ __forceinline__ void valu_load_w(f32x2 (&w)[N], const wptr_t p) {
+// NT taps x NC channel pairs starting at pair C0 of tap 0 of p ([tap][4] pairs in memory)
+template <int NT, int NC, int C0>
+__device__ __forceinline__ void valu_load_w(f32x2 (&w)[NT * NC], const wptr_t p) {
 #pragma unroll
-  for (int i = 0; i < N; ++i) w[i] = p[i];
+  for (int k = 0; k < NT; ++k)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) w[k * NC + c] = p[k * 4 + C0 + c];
 }
 
-template <int CIN, int S>
-__device__ __forceinline__ void valu_conv7_r4(const float* img, const wptr_t w2, const int t0, f32x2 (&acc)[4][4]) {
+// NC = 4: all eight output channels; NC = 2, C0 in {0, 2}: channels 4 C0/2 .. (one half), so that a kernel can hand
+// the first half to memory while it computes the second.
+template <int CIN, int S, int NC = 4, int C0 = 0>
+__device__ __forceinline__ void valu_conv7_r4(const float* img, const wptr_t w2, const int t0, f32x2 (&acc)[NC][4]) {
   ValuWin winA, winB;
-  f32x2 waA[16], waB[16], wb[12];
+  f32x2 waA[4 * NC], waB[4 * NC], wb[3 * NC];
   valu_load_win<S>(winA, img, 0, t0);
-  valu_load_w(waA, w2);
+  valu_load_w<4, NC, C0>(waA, w2);
   // one trip on (win, wa); prefetches channel `nxt` into (winN, waN)
-#define VALU_TRIP(win, wa, winN, waN, ci, nxt)                \
-  valu_taps<0, 1, 0>(win, wa, acc);                               \
-  __builtin_amdgcn_sched_barrier(0);                           \
-  valu_load_w(wb, w2 + (ci) * 28 + 16);                        \
-  __builtin_amdgcn_sched_barrier(0);                           \
-  valu_taps<1, 4, 0>(win, wa, acc);                               \
-  __builtin_amdgcn_sched_barrier(0);                           \
-  valu_taps<4, 5, 4>(win, wb, acc);                               \
-  __builtin_amdgcn_sched_barrier(0);                           \
-  valu_load_win<S>(winN, img, nxt, t0);                        \
-  valu_load_w(waN, w2 + (nxt) * 28);                           \
-  __builtin_amdgcn_sched_barrier(0);                           \
-  valu_taps<5, 7, 4>(win, wb, acc);                               \
+#define VALU_TRIP(win, wa, winN, waN, ci, nxt)                    \
+  valu_taps<0, 1, 0, NC>(win, wa, acc);                           \
+  __builtin_amdgcn_sched_barrier(0);                              \
+  valu_load_w<3, NC, C0>(wb, w2 + (ci) * 28 + 16);                \
+  __builtin_amdgcn_sched_barrier(0);                              \
+  valu_taps<1, 4, 0, NC>(win, wa, acc);                           \
+  __builtin_amdgcn_sched_barrier(0);                              \
+  valu_taps<4, 5, 4, NC>(win, wb, acc);                           \
+  __builtin_amdgcn_sched_barrier(0);                              \
+  valu_load_win<S>(winN, img, nxt, t0);                           \
+  valu_load_w<4, NC, C0>(waN, w2 + (nxt) * 28);                   \
+  __builtin_amdgcn_sched_barrier(0);                              \
+  valu_taps<5, 7, 4, NC>(win, wb, acc);                           \
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
   for (int ci = 0; ci < CIN; ci += 2) {

@@ -593,11 +593,11 @@ constexpr int VT = 1024, VS = VT + 8;           // lanes x 4 samples; image row 
 constexpr int VD_TS = 1008, VD_TILES = (T0 + VD_TS - 1) / VD_TS;  // down0: local 0 <-> global VD_TS * tile - 8
 constexpr int VU_TS = 1016, VU_TILES = (T0 + VU_TS - 1) / VU_TS;  // up3:   local 0 <-> global VU_TS * tile - 4
 constexpr int VU_SX = 272;                      // up2.same image row stride (258 level-1 samples per tile; == 16 mod 32)
-// 45 KB and 50 KB of LDS: the three tiles of a window are resident on one CU together (256 windows on 256 CUs = one round)
-constexpr int VD_LDS_FLOATS = 11 * VS + 64, VU_LDS_FLOATS = 8 * VS + 16 * VU_SX + 64;  // + margin for masked MFMA columns
+// 50 KB and 50 KB of LDS: the three tiles of a window are resident on one CU together (256 windows on 256 CUs = one round)
+constexpr int VD_LDS_FLOATS = 12 * VS + 64, VU_LDS_FLOATS = 8 * VS + 16 * VU_SX + 64;  // + margin for masked MFMA columns
 // the strided and the transposed conv of the two kernels stay on the MFMA (weights used once per output sample:
 // on the VALU they are bound by scalar-load latency, measured 15 k cycles for 448 packed FMAs per lane)
-using VD_down = LdsLayer<8, 0, 8, 2, 11, 8, 5, 0, 1, 1>;   // out n' = 2n + p reads local 8n + tap + 5
+using VD_down = LdsLayer<4, 4, 8, 2, 11, 8, 5, 0, 1, 1>;   // out n' = 2n + p reads local 8n + tap + 5; channels 0-3 / 4-7 in two images
 using VU_T = LdsLayer<16, 0, 8, 4, 2, 1, -1, -2, 5, 1>;    // out local 4m + p - 2 reads level-1 local m + tap - 1
 struct TileRowStore {  // haloed activation row store of one tile: local t in [0, t_hi), global t + t_add in [0, L)
   float* p;
@@ -618,7 +618,8 @@ struct Down0VArgs {
 };
 
 // relu + zero outside the signal, channel pair c of acc -> two float4 rows
-__device__ __forceinline__ void valu_finish(const f32x2 (&acc)[4][4], int c, int tg, f32x4* lo, f32x4* hi) {
+template <int NC>
+__device__ __forceinline__ void valu_finish(const f32x2 (&acc)[NC][4], int c, int tg, f32x4* lo, f32x4* hi) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const bool in = (unsigned)(tg + r) < (unsigned)T0;
@@ -626,9 +627,10 @@ __device__ __forceinline__ void valu_finish(const f32x2 (&acc)[4][4], int c, int
     (*hi)[r] = in ? fmaxf(acc[c][r].y, 0.f) : 0.f;
   }
 }
-__device__ __forceinline__ void valu_bias(f32x2 (&acc)[4][4], const f32x2* b) {
+template <int NC>
+__device__ __forceinline__ void valu_bias(f32x2 (&acc)[NC][4], const f32x2* b) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int c = 0; c < NC; ++c)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[c][r] = as_weights(b)[c];
 }
@@ -636,7 +638,7 @@ __device__ __forceinline__ void valu_bias(f32x2 (&acc)[4][4], const f32x2* b) {
 __global__ __launch_bounds__(256) void pn_down0v_kernel(const Down0VArgs a) {
   extern __shared__ float4 lds_raw[];
   float* lds = reinterpret_cast<float*>(lds_raw);
-  float *X = lds, *H = lds + 3 * VS;  // down0.same later overwrites the inc image H
+  float *X = lds, *H = lds + 4 * VS;  // X: 3 input rows, later rows 0-3 of down0.same; H: inc, later rows 4-7 of down0.same
   const int tid = threadIdx.x;
   // Workgroup -> (window, tile): consecutive workgroups go to consecutive XCDs, and the core kernel runs window w on
   // XCD w % 8 — with this mapping the rows a window hands from kernel to kernel stay in one XCD's L2.
@@ -684,32 +686,45 @@ __global__ __launch_bounds__(256) void pn_down0v_kernel(const Down0VArgs a) {
     }
   }
   __syncthreads();
-  {  // down0.same: Conv1d(8, 8, 7, same) + BN + ReLU -> skip tensor + image for the strided conv
-    valu_bias(acc, a.b_same);
-    valu_conv7_r4<8, VS>(H, as_weights(a.w_same), t0, acc);
-    __syncthreads();  // every lane has read its inc window: the image can be overwritten in place
-    f32x4 lo[4], hi[4];
+  {  // down0.same: Conv1d(8, 8, 7, same) + BN + ReLU -> skip tensor + image for the strided conv.  Two passes of four
+     // output channels: the skip rows of the first pass drain to memory under the FMAs of the second (in one pass the
+     // whole 25 MB of a launch left the chip in one burst after the last FMA, with nothing to hide it).
+    float* d = a.t.skip0 + (long)win * a.t.ws_s + HALO + tg;
+    f32x2 acc2[2][4];
+    f32x4 lo[2], hi[2];
+    valu_bias(acc2, a.b_same);
+    valu_conv7_r4<8, VS, 2, 0>(H, as_weights(a.w_same), t0, acc2);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      valu_finish(acc, c, tg, &lo[c], &hi[c]);
+    for (int c = 0; c < 2; ++c) {  // rows 0-3 take the place of the x image (its last reader finished two barriers ago)
+      valu_finish(acc2, c, tg, &lo[c], &hi[c]);
+      *reinterpret_cast<f32x4*>(X + (2 * c) * VS + 4 + t0) = lo[c];
+      *reinterpret_cast<f32x4*>(X + (2 * c + 1) * VS + 4 + t0) = hi[c];
+      if (own) {  // the float4 holding sample T0 - 1 also rewrites up to three zeros of the row's right margin
+        __builtin_nontemporal_store(lo[c], reinterpret_cast<f32x4*>(d + (long)(2 * c) * a.t.ls_s));
+        __builtin_nontemporal_store(hi[c], reinterpret_cast<f32x4*>(d + (long)(2 * c + 1) * a.t.ls_s));
+      }
+    }
+    valu_bias(acc2, a.b_same + 2);
+    valu_conv7_r4<8, VS, 2, 2>(H, as_weights(a.w_same), t0, acc2);
+    lds_barrier();  // every lane has read its inc window: rows 4-7 overwrite the first rows of that image
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      valu_finish(acc2, c, tg, &lo[c], &hi[c]);
       *reinterpret_cast<f32x4*>(H + (2 * c) * VS + 4 + t0) = lo[c];
       *reinterpret_cast<f32x4*>(H + (2 * c + 1) * VS + 4 + t0) = hi[c];
     }
-    __syncthreads();
-    // the skip rows go to memory AFTER the barrier (__syncthreads waits for every outstanding store) and drain
-    // behind the strided conv
-    if (own) {  // the float4 holding sample T0 - 1 also rewrites up to three zeros of the row's right margin
-      float* d = a.t.skip0 + (long)win * a.t.ws_s + HALO + tg;
+    lds_barrier();
+    if (own) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        *reinterpret_cast<f32x4*>(d + (long)(2 * c) * a.t.ls_s) = lo[c];
-        *reinterpret_cast<f32x4*>(d + (long)(2 * c + 1) * a.t.ls_s) = hi[c];
+      for (int c = 0; c < 2; ++c) {
+        __builtin_nontemporal_store(lo[c], reinterpret_cast<f32x4*>(d + (long)(4 + 2 * c) * a.t.ls_s));
+        __builtin_nontemporal_store(hi[c], reinterpret_cast<f32x4*>(d + (long)(5 + 2 * c) * a.t.ls_s));
       }
     }
   }
   {  // down0.down: Conv1d(8, 8, 7, stride 4, pad 3) + BN + ReLU on the MFMA; output n = 252 * tile + n' reads local 4 n' + 5 + k
     TileRowStore st{a.t.d0 + (long)win * a.t.ws_d + HALO, a.t.ls_d, T1, (VD_TS / 4) * tile, VD_TS / 4};
-    conv_lds<VD_down, VS, 4, VS, 4, false>(H, H, a.t.af_down, a.t.bs_down, VD_TS / 8, st, tid >> 6, 4, tid & 63);
+    conv_lds<VD_down, VS, 4, VS, 4, false>(X, H, a.t.af_down, a.t.bs_down, VD_TS / 8, st, tid >> 6, 4, tid & 63);
   }
 }
 
