@@ -83,8 +83,13 @@ def test_fused_equals_layerwise_bitwise(oracle):
     layer.cuda()
     want = layer(xn).numpy()
     assert np.array_equal(fused(xn).numpy(), want)
-    default = PhaseNet.from_pretrained("volpick").cuda()
-    assert np.abs(default(xn).numpy() - want).max() < 5e-6
+    default = PhaseNet.from_pretrained("volpick").cuda()  # the whole network in one launch
+    got = default(xn).numpy()
+    assert np.abs(got - want).max() < 5e-6
+    three = PhaseNet.from_pretrained("volpick")  # three launches, level-0 stride-1 convs on the VALU
+    three._plan_flags = (0, 0, 0, 0, 0, 2)
+    three.cuda()
+    assert np.abs(three(xn).numpy() - want).max() < 5e-6
 
 
 @pytest.mark.parametrize("B", [1, 5, 256, 300])

@@ -22,14 +22,14 @@ for _ in range(3):
     m._forward_raw(x, preprocess=True)
 # steady state: 200 back-to-back launches of every step, stamps of the last launch survive
 lib = _lib.load()
-n = lib.vp_step_count(m._handle)
+n_steps = n = lib.vp_step_count(m._handle)
 ms = (C.c_float * n)()
 _lib.check(lib.vp_profile_steps(m._handle, B, 200, ms, n))
 print("step ms:", [round(v * 1e3, 1) for v in ms])
 clk = np.zeros((B, 32), np.uint64)
 _lib.check(_lib.load().vp_debug_core_clock(m._handle, B, clk.ctypes.data_as(C.c_void_p)))
 d = np.diff(clk[:, :15].astype(np.int64), axis=1)
-names = ["load d0", "d1same", "d1down", "d2same", "d2down", "d3same", "d3down", "d4same", "u0T", "u0same", "u1T",
+names = ["load d0 / level-0 down", "d1same", "d1down", "d2same", "d2down", "d3same", "d3down", "d4same", "u0T", "u0same", "u1T",
          "u1same", "u2T", "u2same"]
 med = np.median(d, axis=0)
 tot = med.sum()
@@ -38,11 +38,21 @@ for n, c in zip(names, med):
 wall = (clk[:, 17] - clk[:, 16]).astype(np.float64) / 100e6
 cyc = (clk[:, 14] - clk[:, 0]).astype(np.float64)
 print("in-kernel wall us (median)", np.median(wall) * 1e6, " shader clock GHz (median)", np.median(cyc / wall) / 1e9)
-u = np.diff(clk[:, 18:26].astype(np.int64), axis=1)
-print("up3 VALU form (tile 1) median cycles: load skip rows %d  same(skip) %d  up2.same regs->LDS+barrier %d  convT (MFMA) %d  "
-      "barrier %d  same(convT) %d  1x1+softmax+store %d" % tuple(np.median(u, axis=0)))
-w0, w1 = clk[:, 26].astype(np.float64) / 100e6, clk[:, 27].astype(np.float64) / 100e6
-print("up3 VALU form (tile 1 of every window): workgroup wall us median %.2f; first start -> last end %.2f us; start spread %.2f us"
-      % (np.median(w1 - w0) * 1e6, (w1.max() - w0.min()) * 1e6, (w0.max() - w0.min()) * 1e6))
+if n_steps == 1:  # whole-network kernel: slot 1 - slot 0 is the level-0 down phase; 18..22 and 23..28 detail the two level-0 phases
+    dphase = np.diff(clk[:, 18:23].astype(np.int64), axis=1)
+    print("level-0 down phase median cycles: load x %d  inc %d  down0.same (two passes) %d  down0.down (MFMA) %d" % tuple(np.median(dphase, axis=0)))
+    uphase = np.diff(clk[:, 23:29].astype(np.int64), axis=1)
+    print("level-0 up phase median cycles: load skip rows %d  up3.same(skip) %d  up3.convT (MFMA) %d  up3.same(convT) %d  1x1+softmax+store %d"
+          % tuple(np.median(uphase, axis=0)))
+    whole = (clk[:, 28] - clk[:, 0]).astype(np.float64)
+    print("whole window median cycles %d (down %d, core %d, up %d)" % (np.median(whole), np.median(clk[:, 1] - clk[:, 0]),
+          np.median(clk[:, 14] - clk[:, 1]), np.median(clk[:, 28] - clk[:, 14])))
+else:
+    u = np.diff(clk[:, 18:26].astype(np.int64), axis=1)
+    print("up3 VALU form (tile 1) median cycles: load skip rows %d  same(skip) %d  up2.same regs->LDS+barrier %d  convT (MFMA) %d  "
+          "barrier %d  same(convT) %d  1x1+softmax+store %d" % tuple(np.median(u, axis=0)))
+    w0, w1 = clk[:, 26].astype(np.float64) / 100e6, clk[:, 27].astype(np.float64) / 100e6
+    print("up3 VALU form (tile 1 of every window): workgroup wall us median %.2f; first start -> last end %.2f us; start spread %.2f us"
+          % (np.median(w1 - w0) * 1e6, (w1.max() - w0.min()) * 1e6, (w0.max() - w0.min()) * 1e6))
 print("total", tot, "cycles; window span min/med/max", (clk[:, 14] - clk[:, 0]).min(), np.median(clk[:, 14] - clk[:, 0]),
       (clk[:, 14] - clk[:, 0]).max())

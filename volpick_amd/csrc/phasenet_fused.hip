@@ -864,6 +864,259 @@ __global__ __launch_bounds__(256) void pn_up3v_kernel(const Up3VArgs a) {
 #undef UP3V_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------
+// The whole network in ONE launch: one 1024-thread workgroup per window runs the level-0 down path (VALU + MFMA),
+// the 13 core layers and the level-0 up path back to back out of the same 158 KB LDS arena.  Against the three
+// launches above: down0.down and up2.same never leave LDS (18 MB + 24 MB of traffic per 256 windows gone), the skip
+// tensor is written and read back by the SAME CU inside one kernel (no end-of-kernel L2 write-back and invalidate
+// between producer and consumer: it is served from the XCD's L2), there are no tile halos to recompute, and the two
+// memory-bound phases that every workgroup of a level-0 launch entered in lock step (all load, then all compute)
+// shrink to one 36 KB read per window at the start.
+// ---------------------------------------------------------------------------------------------
+constexpr int W0_S = 3024;                 // level-0 image row stride: sample t at column t + 4, t in [-4, 3020); == 16 mod 32
+constexpr int W0_Q = W0_S / 4;             // float4 per row = lanes that store into a row
+constexpr int W_LANES = (T0 + 3) / 4;      // lanes that own signal samples (four each)
+constexpr int W_WAVES = (W0_Q + 63) / 64;  // waves that run the VALU convs (the others only load, store and do MFMA items)
+// down phase: inc (8 rows; down0.same later overwrites it in place) | x (3 rows)
+constexpr int WD_H = 0, WD_X = 8 * W0_S;
+static_assert(11 * W0_S <= CORE_LDS_FLOATS, "level-0 down images must fit the core arena");
+static_assert(WD_X <= A_D0 && A_D0 + 8 * S1_ <= 11 * W0_S, "down0.down lands on the dead x rows");
+// up phase: up2.same (16 x S1_) in the middle of the arena (dead while up2.same is computed), the eight level-0 rows
+// (skip, then up3.convT) in two groups of four around it
+constexpr int WU_U = A_SKIP2, WU_G0 = 0, WU_G1 = WU_U + 16 * S1_;
+static_assert(WU_G0 + 4 * W0_S <= WU_U && WU_U + 16 * S1_ <= A_U2T && WU_G1 + 4 * W0_S <= CORE_LDS_FLOATS, "up-phase regions");
+using W_down = LdsLayer<8, 0, 8, 2, 11, 8, -3, 0, 1, 1>;   // out n' = 2n + p reads sample 8n + tap - 3
+using W_upT = LdsLayer<16, 0, 8, 4, 2, 1, -1, -2, 3, 1>;    // out sample 4m + p - 2 reads level-1 sample m + tap - 1
+
+struct WindowArgs {
+  CoreArgs c;       // d0 / u2s unused (they live in LDS)
+  const float* x;   // [B][3][ls] normalised input
+  int ls_x;
+  long ws_x;
+  float* skip0;     // [B][8][ls] (down0.same): written in the down phase, read back in the up phase
+  int ls_s;
+  long ws_s;
+  float* y;         // dense [B][3][T0]
+  const f32x2 *w_inc, *b_inc, *w_same, *b_same, *w_up, *b_up;  // VALU weights: [cin][7][4] channel pairs, [4] bias pairs
+  const float *af_down, *bs_down, *af_t, *bs_t;                // MFMA fragments of down0.down and up3.convT
+  const float *w_out, *b_out;                                  // 1x1 output conv
+};
+
+struct SplitRowStore {  // up3.convT -> level-0 rows 0-3 (g0) and 4-7 (g1); zero outside the signal
+  float *g0, *g1;
+  __device__ __forceinline__ float* row(int co) const { return (co < 4) ? g0 + co * W0_S : g1 + (co - 4) * W0_S; }
+  __device__ __forceinline__ void operator()(int co, int t, float v) const {
+    if ((unsigned)t < (unsigned)(W0_S - 4)) row(co)[4 + t] = (t < T0) ? v : 0.f;
+  }
+  __device__ __forceinline__ bool all_valid(int t0, int t1) const { return t0 >= 0 && t1 < T0; }
+  __device__ __forceinline__ void unchecked(int co, int t, float v) const { row(co)[4 + t] = v; }
+};
+
+template <bool PIPE>
+__global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
+  extern __shared__ float4 lds_raw[];
+  float* lds = reinterpret_cast<float*>(lds_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, win = blockIdx.x;
+  constexpr int NTH = 1024, NWV = 16;
+  unsigned long long* clk = a.c.clk;
+  if (clk && tid == 0) clk[(long)win * 32 + 16] = wall_clock64();
+#define WIN_STAMP(slot) \
+  if (clk && tid == 0) clk[(long)win * 32 + (slot)] = __builtin_readcyclecounter();
+  WIN_STAMP(0)
+  WIN_STAMP(18)
+  if (win < 8 && a.c.warm) {  // first workgroup of each XCD: touch one word per 128-byte line of the core weights (pn_core_kernel)
+    float sink = 0.f;
+#define CORE_WARM(IDX, LAYER)                                                                          \
+  for (int l = tid; l < LAYER::MT * LAYER::CB * LAYER::TAPS * 2; l += NTH) sink += a.c.af[IDX][l * 32];
+    CORE_WARM(0, C_d1same) CORE_WARM(1, C_d1down) CORE_WARM(2, C_d2same) CORE_WARM(3, C_d2down) CORE_WARM(4, C_d3same)
+    CORE_WARM(5, C_d3down) CORE_WARM(6, C_d4same) CORE_WARM(7, C_u0T) CORE_WARM(8, C_u0same) CORE_WARM(9, C_u1T)
+    CORE_WARM(10, C_u1same) CORE_WARM(11, C_u2T) CORE_WARM(12, C_u2same)
+#undef CORE_WARM
+    if (sink == 1.2345678e-30f) a.y[0] = sink;  // never true: keeps the loads alive
+  }
+  const int t0 = 4 * tid;                    // this lane's level-0 samples t0 .. t0 + 3 (VALU phases)
+  const bool vconv = wave < W_WAVES;         // wave-uniform: runs the VALU convs
+  const bool vstore = tid < W0_Q;            // lanes whose float4 lies inside an image row (751..755 store the zero margin)
+  const bool own = tid < W_LANES;            // lanes holding signal samples
+
+  // ================= level-0 down path: inc -> down0.same -> down0.down =================
+  {
+    float *H = lds + WD_H, *X = lds + WD_X;
+    {  // x rows: sample 4q - 4 .. 4q - 1 at float4 q; physical index HALO + 4q - 4 (16-byte aligned)
+      const float* src = a.x + (long)win * a.ws_x;
+      for (int i = tid; i < 3 * W0_Q; i += NTH) {
+        const int c = i / W0_Q, q = i - c * W0_Q;
+        const int p = 4 * q + HALO - 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p + 3 < a.ls_x) v = *reinterpret_cast<const float4*>(src + (long)c * a.ls_x + p);
+        *reinterpret_cast<float4*>(X + c * W0_S + 4 * q) = v;
+      }
+      if (tid < 8) *reinterpret_cast<float4*>(H + tid * W0_S) = make_float4(0.f, 0.f, 0.f, 0.f);  // samples -4 .. -1: left padding
+    }
+    __syncthreads();
+    WIN_STAMP(19)
+    if (vconv) {  // inc: Conv1d(3, 8, 7, same, bias) + BN + ReLU
+      f32x2 acc[4][4];
+      valu_bias(acc, a.b_inc);
+      valu_conv7_r4<3, W0_S>(X, as_weights(a.w_inc), t0, acc);
+      if (vstore) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          f32x4 lo, hi;
+          valu_finish(acc, c, t0, &lo, &hi);
+          *reinterpret_cast<f32x4*>(H + (2 * c) * W0_S + 4 + t0) = lo;
+          *reinterpret_cast<f32x4*>(H + (2 * c + 1) * W0_S + 4 + t0) = hi;
+        }
+      }
+    }
+    __syncthreads();
+    WIN_STAMP(20)
+    {  // down0.same: Conv1d(8, 8, 7, same) + BN + ReLU; the result overwrites inc in place (image of the strided conv)
+       // and goes to memory as the skip tensor (it stays in this XCD's L2 for the up phase)
+      float aD[W_down::CB * W_down::TAPS], bD[4];  // A fragments of down0.down: fetched under the FMAs of down0.same
+      load_areg<W_down>(a.af_down, 0, lane, aD);
+      load_biasreg<W_down>(a.bs_down, 0, lane, bD);
+      f32x2 acc[4][4];
+      if (vconv) {
+        valu_bias(acc, a.b_same);
+        valu_conv7_r4<8, W0_S>(H, as_weights(a.w_same), t0, acc);
+      }
+      lds_barrier();  // every lane has read its inc window
+      f32x4 lo[4], hi[4];
+      if (vconv) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          valu_finish(acc, c, t0, &lo[c], &hi[c]);
+          if (vstore) {
+            *reinterpret_cast<f32x4*>(H + (2 * c) * W0_S + 4 + t0) = lo[c];
+            *reinterpret_cast<f32x4*>(H + (2 * c + 1) * W0_S + 4 + t0) = hi[c];
+          }
+        }
+      }
+      zero_halo<8, S1_, T1>(lds + A_D0, tid, NTH);  // the x rows are dead: down0.down takes their place
+      lds_barrier();
+      if (own) {  // the float4 holding sample T0 - 1 also rewrites up to three zeros of the row's right margin
+        float* d = a.skip0 + (long)win * a.ws_s + HALO + t0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          *reinterpret_cast<f32x4*>(d + (long)(2 * c) * a.ls_s) = lo[c];
+          *reinterpret_cast<f32x4*>(d + (long)(2 * c + 1) * a.ls_s) = hi[c];
+        }
+      }
+      WIN_STAMP(21)
+      // down0.down: Conv1d(8, 8, 7, stride 4, pad 3) + BN + ReLU on the MFMA, straight into the core's input image
+      RangeStore<S1_, IB> st{lds + A_D0, T1};
+      conv_lds_areg<W_down, W0_S, 4, W0_S, 4>(H, H, aD, bD, 0, (T1 + 1) / 2, st, wave, NWV, lane);
+    }
+    lds_barrier();  // not __syncthreads(): the skip rows drain to memory under the first core layers
+    WIN_STAMP(22)
+    WIN_STAMP(1)
+  }
+
+  // ================= levels 1-4 down, up0 .. up2 (pn_core_kernel) =================
+  int stamp = 2;
+#define CORE_LAYER(IDX, LAYER, IN1, SI1, IN2, SI2, OUT, SO, CO, COLS, LOUT)                                        \
+  {                                                                                                                \
+    RangeStore<SO, IB> st{lds + (OUT), (LOUT)};                                                                   \
+    zero_halo<CO, SO, LOUT>(lds + (OUT), tid, NTH);                                                              \
+    conv_lds<LAYER, SI1, IB, SI2, IB, PIPE, (LAYER::NB < BDB_MAX_NB)>(lds + (IN1), lds + (IN2), a.c.af[IDX], a.c.bs[IDX], (COLS), st, wave, NWV, lane); \
+    __syncthreads();                                                                                               \
+    WIN_STAMP(stamp)                                                                                               \
+    ++stamp;                                                                                                       \
+  }
+  CORE_LAYER(0, C_d1same, A_D0, S1_, A_D0, S1_, A_SKIP1, S1_, 16, T1, T1)
+  CORE_LAYER(1, C_d1down, A_SKIP1, S1_, A_SKIP1, S1_, A_D1, S2_, 16, T2, T2)
+  CORE_LAYER(2, C_d2same, A_D1, S2_, A_D1, S2_, A_SKIP2, S2_, 32, T2, T2)
+  CORE_LAYER(3, C_d2down, A_SKIP2, S2_, A_SKIP2, S2_, A_D2, S3_, 32, T3, T3)
+  CORE_LAYER(4, C_d3same, A_D2, S3_, A_D2, S3_, A_SKIP3, S3_, 64, T3, T3)
+  CORE_LAYER(5, C_d3down, A_SKIP3, S3_, A_SKIP3, S3_, A_D3, S4_, 64, T4, T4)
+  CORE_LAYER(6, C_d4same, A_D3, S4_, A_D3, S4_, A_BOT, S4_, 128, T4, T4)
+  CORE_LAYER(7, C_u0T, A_BOT, S4_, A_BOT, S4_, A_U0T, S3_, 64, T4 + 1, T3)
+  CORE_LAYER(8, C_u0same, A_SKIP3, S3_, A_U0T, S3_, A_U0S, S3_, 64, T3, T3)
+  CORE_LAYER(9, C_u1T, A_U0S, S3_, A_U0S, S3_, A_U1T, S2_, 32, T3 + 1, T2)
+  CORE_LAYER(10, C_u1same, A_SKIP2, S2_, A_U1T, S2_, A_U1S, S2_, 32, T2, T2)
+  CORE_LAYER(11, C_u2T, A_U1S, S2_, A_U1S, S2_, A_U2T, S1_, 16, T2 + 1, T1)
+  CORE_LAYER(12, C_u2same, A_SKIP1, S1_, A_U2T, S1_, WU_U, S1_, 16, T1, T1)
+#undef CORE_LAYER
+
+  // ================= level-0 up path: up3.convT -> cat(skip0, .) -> up3.same -> 1x1 -> softmax =================
+  {
+    float *G0 = lds + WU_G0, *G1 = lds + WU_G1, *U = lds + WU_U;
+    WIN_STAMP(23)
+    {  // skip rows back from memory (L2): rows 0-3 -> G0, 4-7 -> G1
+      const float* src = a.skip0 + (long)win * a.ws_s;
+      for (int i = tid; i < 8 * W0_Q; i += NTH) {
+        const int c = i / W0_Q, q = i - c * W0_Q;
+        const int p = 4 * q + HALO - 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p + 3 < a.ls_s) v = *reinterpret_cast<const float4*>(src + (long)c * a.ls_s + p);
+        *reinterpret_cast<float4*>(((c < 4) ? G0 + c * W0_S : G1 + (c - 4) * W0_S) + 4 * q) = v;
+      }
+    }
+    __syncthreads();
+    WIN_STAMP(24)
+    float aT[W_upT::CB * W_upT::TAPS], bT[4];  // A fragments of up3.convT (waves alternate over its two m-tiles)
+    load_areg<W_upT>(a.af_t, wave & 1, lane, aT);
+    load_biasreg<W_upT>(a.bs_t, wave & 1, lane, bT);
+    f32x2 acc[4][4];
+    if (vconv) {  // up3.same on cat([skip0, up3.convT]): the skip half first, then the convT rows take the skip rows' place
+      valu_bias(acc, a.b_up);
+      valu_conv7_r4<4, W0_S>(G0, as_weights(a.w_up), t0, acc);
+      valu_conv7_r4<4, W0_S>(G1, as_weights(a.w_up + 4 * 28), t0, acc);
+    }
+    __syncthreads();
+    WIN_STAMP(25)
+    {  // up3.convT: ConvTranspose1d(16, 8, 7, stride 4) + BN + ReLU, crop [1:-2] and centre crop (t = o - 2), on the MFMA
+      SplitRowStore st{G0, G1};
+      conv_lds_areg<W_upT, S1_, IB, S1_, IB>(U, U, aT, bT, wave & 1, T1 + 1, st, wave >> 1, NWV / 2, lane);
+    }
+    __syncthreads();
+    WIN_STAMP(26)
+    if (vconv) {
+      valu_conv7_r4<4, W0_S>(G0, as_weights(a.w_up + 8 * 28), t0, acc);
+      valu_conv7_r4<4, W0_S>(G1, as_weights(a.w_up + 12 * 28), t0, acc);
+    }
+    WIN_STAMP(27)
+    if (own) {  // BN + ReLU -> Conv1d(8, 3, 1) -> softmax over channels
+      float z[3][4];
+#pragma unroll
+      for (int o = 0; o < 3; ++o)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[o][r] = as_scalars(a.b_out)[o];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v0 = fmaxf(acc[c][r].x, 0.f), v1 = fmaxf(acc[c][r].y, 0.f);
+#pragma unroll
+          for (int o = 0; o < 3; ++o)
+            z[o][r] = fmaf(as_scalars(a.w_out)[o * 8 + 2 * c + 1], v1, fmaf(as_scalars(a.w_out)[o * 8 + 2 * c], v0, z[o][r]));
+        }
+      f32x4 y0, y1, y2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float mx = fmaxf(z[0][r], fmaxf(z[1][r], z[2][r]));
+        const float e0 = __expf(z[0][r] - mx), e1 = __expf(z[1][r] - mx), e2 = __expf(z[2][r] - mx);
+        const float inv = 1.f / (e0 + e1 + e2);
+        y0[r] = e0 * inv, y1[r] = e1 * inv, y2[r] = e2 * inv;
+      }
+      float* y = a.y + (long)win * 3 * T0 + t0;
+      if (t0 + 3 < T0) {  // dense rows of odd length: 4-byte aligned vector stores
+        *reinterpret_cast<f32x4u*>(y) = y0;
+        *reinterpret_cast<f32x4u*>(y + T0) = y1;
+        *reinterpret_cast<f32x4u*>(y + 2 * T0) = y2;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (t0 + r < T0) y[r] = y0[r], y[T0 + r] = y1[r], y[2 * T0 + r] = y2[r];
+      }
+    }
+    WIN_STAMP(28)
+  }
+  if (clk && tid == 0) clk[(long)win * 32 + 17] = wall_clock64();
+#undef WIN_STAMP
+}
+
 int tensor_id(const Net& net, const std::string& name) {
   for (size_t i = 0; i < net.tensors.size(); ++i)
     if (net.tensors[i].name == name) return (int)i;
@@ -894,8 +1147,11 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
   const bool pipe = net.cfg.reserved[2] == 1;
   const bool persistent = net.cfg.reserved[3] != 1;  // reserved[3] = 1: one workgroup per tile for up3 too (A/B timing)
   const bool down0_persistent = net.cfg.reserved[3] == 2;
-  // reserved[5] = 1 keeps the MFMA forms of the two level-0 kernels (A/B timing; bit-identical to the layer plan)
+  // reserved[5] = 1 keeps the MFMA forms of the two level-0 kernels (A/B timing; bit-identical to the layer plan),
+  // 2 the three-launch plan with the VALU level-0 kernels; default: the whole network in one launch (pn_window_kernel).
+  // The debug dumps of the intermediates exist in the three-launch plans only.
   const bool valu = net.cfg.reserved[5] != 1;
+  const bool whole = valu && net.cfg.reserved[5] != 2 && !debug_dumps;
   HostBlob *vw[5] = {}, *vb[5] = {};
   if (valu) {
     const float eps = net.cfg.bn_eps;
@@ -931,6 +1187,8 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     net.need(skip0, VU_TS * (VU_TILES - 1) + VS);              // skip image float4 loads
     net.need(skip0, HALO + VD_TS * VD_TILES);                  // skip stores of the last down tile
     net.need(u2s, HALO + (VU_TS / 4) * (VU_TILES - 1) - 2 + 258);  // up2.same image loads
+    net.need(x, HALO - 4 + W0_S);      // whole-window float4 loads of pn_window_kernel
+    net.need(skip0, HALO - 4 + W0_S);
   }
   std::vector<Step> steps;
   auto flops = [&](int lo, int hi) {
@@ -1078,6 +1336,53 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
       return 0;
     };
     steps.push_back(std::move(st));
+  }
+  if (whole) {
+    Step st;
+    st.name = "fused.window (whole PhaseNet, one workgroup per window)";
+    st.flops_per_window = flops(0, 17);
+    HostBlob* e0 = &net.convs[17]->e0;
+    HostBlob* e1 = &net.convs[17]->e1;
+    HostBlob* clk = debug_clock ? net.debug_clock : nullptr;
+    st.run = [=](Net& n, int B, hipStream_t s) -> int {
+      WindowArgs a{};
+      const Tensor &tx = n.tensors[x], &ts = n.tensors[skip0];
+      for (int i = 0; i < 13; ++i) {
+        a.c.af[i] = n.convs[3 + i]->afrag.d;
+        a.c.bs[i] = n.convs[3 + i]->bias.d;
+      }
+      a.c.clk = clk ? reinterpret_cast<unsigned long long*>(clk->d) : nullptr;
+      a.c.warm = n.cfg.reserved[4] != 1;
+      a.x = tx.p;
+      a.ls_x = tx.ls;
+      a.ws_x = (long)tx.win_stride();
+      a.skip0 = ts.p;
+      a.ls_s = ts.ls;
+      a.ws_s = (long)ts.win_stride();
+      a.y = n.y;
+      a.w_inc = reinterpret_cast<const f32x2*>(vw[0]->d);
+      a.b_inc = reinterpret_cast<const f32x2*>(vb[0]->d);
+      a.w_same = reinterpret_cast<const f32x2*>(vw[1]->d);
+      a.b_same = reinterpret_cast<const f32x2*>(vb[1]->d);
+      a.w_up = reinterpret_cast<const f32x2*>(vw[4]->d);
+      a.b_up = reinterpret_cast<const f32x2*>(vb[4]->d);
+      a.af_down = n.convs[2]->afrag.d;
+      a.bs_down = n.convs[2]->bias.d;
+      a.af_t = n.convs[16]->afrag.d;
+      a.bs_t = n.convs[16]->bias.d;
+      a.w_out = e0->d;
+      a.b_out = e1->d;
+      if (pipe) {
+        hipLaunchKernelGGL(pn_window_kernel<true>, dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
+      } else {
+        hipLaunchKernelGGL(pn_window_kernel<false>, dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
+      }
+      return 0;
+    };
+    steps.clear();
+    steps.push_back(std::move(st));
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<true>), CORE_LDS_FLOATS * sizeof(float)});
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false>), CORE_LDS_FLOATS * sizeof(float)});
   }
   net.steps = std::move(steps);
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_core_kernel<true>), CORE_LDS_FLOATS * sizeof(float)});
