@@ -105,13 +105,32 @@ def test_forward_parity(model, oracle, B):
     assert np.abs(got_host.sum(1) - 1).max() < 1e-5  # softmax over channels
 
 
-def test_preprocess_matches_annotate_batch_pre(model, oracle):
+def test_preprocess_matches_annotate_batch_pre(oracle):
     x = synthetic_windows(7, 3001, seed=9)
     x[2] += 1234.5  # DC offset
     want = OP.batch_pre(oracle, torch.from_numpy(x)).numpy()
+    model = PhaseNet.from_pretrained("volpick")
+    model._plan_flags = (0, 0, 0, 0, 0, 2)  # a plan that materialises the input tensor (the default cuts and
+    model.cuda()                            # normalises its window inside the forward kernel)
     model._forward_raw(x, preprocess=True)
     got = debug_tensors(model, 7)["input"]
     assert np.abs(got - want).max() < 2e-5
+
+
+def test_in_kernel_preprocessing_is_bitwise_gather_normalize(model):
+    """The default plan runs annotate_batch_pre inside its forward kernel with the arithmetic and reduction order of
+    gather_normalize_kernel: same bits as the plan that goes through the input tensor (reserved[6] = 1)."""
+    data, _, _ = synthetic_stream_array(40_000, seed=77, n_events=4)
+    data[1] += 321.0
+    via_tensor = PhaseNet.from_pretrained("volpick")
+    via_tensor._plan_flags = (0, 0, 0, 0, 0, 0, 1)
+    via_tensor.cuda()
+    args = model._argdict(dict(overlap=1500, blinding=(0, 0), stacking="avg"))
+    a = model._annotate_block(data, args)[0].cpu().numpy()
+    b = via_tensor._annotate_block(data, args)[0].cpu().numpy()
+    assert np.array_equal(a, b, equal_nan=True)
+    x = synthetic_windows(5, 3001, seed=3)
+    assert np.array_equal(model._forward_raw(x, preprocess=True), via_tensor._forward_raw(x, preprocess=True))
 
 
 @pytest.mark.parametrize("overlap,blinding,stacking", [(1500, (0, 0), "avg"), (2500, (500, 500), "avg"),

@@ -87,6 +87,20 @@ vp::PreArgs pre_args(const vp_handle* h, const float* src, int dense, long N, lo
   return a;
 }
 
+// One batch through annotate_batch_pre + the forward pass.  Plans whose first launch gathers and normalises the
+// windows itself take the window description with them; otherwise gather_normalize fills the input tensor first.
+int run_batch(vp_handle* h, const vp::PreArgs& pa, int nb) {
+  vp::Net& net = h->net;
+  if (net.fused_pre && pa.preprocess) {
+    net.pre = &pa;
+    const int rc = net.run(nb, h->stream);
+    net.pre = nullptr;
+    return rc;
+  }
+  vp::launch_gather_normalize(pa, nb, h->stream);
+  return net.run(nb, h->stream);
+}
+
 }  // namespace
 
 extern "C" {
@@ -228,9 +242,8 @@ int vp_forward(vp_handle* h, const float* x, int x_mem, int B, int preprocess, f
       VP_HIP(hipMemcpyAsync(h->d_in, src, nb * in_w * sizeof(float), hipMemcpyHostToDevice, h->stream));
       src = h->d_in;
     }
-    vp::launch_gather_normalize(pre_args(h, src, 1, 0, 0, 0, preprocess), nb, h->stream);
     if (y_mem == VP_MEM_DEVICE) net.y = y + (size_t)b0 * out_w;  // last layer writes straight into y
-    int rc = net.run(nb, h->stream);
+    int rc = run_batch(h, pre_args(h, src, 1, 0, 0, 0, preprocess), nb);
     net.y = y_saved;
     if (rc != VP_OK) return rc;
     if (y_mem == VP_MEM_HOST) {
@@ -303,9 +316,8 @@ static int annotate_device(vp_handle* h, const float* stream, int stream_mem, in
     float* y_saved = net.y;
     for (int64_t w0 = 0; w0 < nwin; w0 += batch) {
       const int nb = (int)std::min<int64_t>(batch, nwin - w0);
-      vp::launch_gather_normalize(pre_args(h, d_stream, 0, N, step, w0, 1), nb, h->stream);
       net.y = h->d_pred + (size_t)w0 * out_w;
-      rc = net.run(nb, h->stream);
+      rc = run_batch(h, pre_args(h, d_stream, 0, N, step, w0, 1), nb);
       net.y = y_saved;
       if (rc != VP_OK) return rc;
     }
@@ -669,9 +681,8 @@ int vp_classify_multi(vp_handle* h, const float* streams, int stream_mem, const 
       const int nb = (int)std::min<int64_t>(batch, W - w0);
       vp::PreArgs pa = pre_args(h, d_streams, 0, 0, step, w0, 1);
       pa.table = d_wtab;
-      vp::launch_gather_normalize(pa, nb, h->stream);
       net.y = h->d_pred + (size_t)w0 * out_w;
-      rc = net.run(nb, h->stream);
+      rc = run_batch(h, pa, nb);
       net.y = y_saved;
       if (rc != VP_OK) return rc;
     }

@@ -5,6 +5,7 @@
 #include <memory>
 
 #include "conv_mfma.h"
+#include "prepost.h"
 
 namespace vp {
 
@@ -54,6 +55,8 @@ struct Net {
   size_t arena_floats = 0;
   double flops_per_window = 0;
   HostBlob* debug_clock = nullptr;  // fused PhaseNet core: per-layer shader-clock stamps (debug plan flag)
+  bool fused_pre = false;           // the plan's first launch can gather + normalise its windows itself (pn_window_kernel)
+  const PreArgs* pre = nullptr;     // set by the caller around run() when fused_pre: where the windows of this batch come from
 
   int add_tensor(const std::string& name, int C, int L, int sets = 1);
   HostBlob* add_blob(std::vector<float> v);

@@ -900,6 +900,8 @@ struct WindowArgs {
   const f32x2 *w_inc, *b_inc, *w_same, *b_same, *w_up, *b_up;  // VALU weights: [cin][7][4] channel pairs, [4] bias pairs
   const float *af_down, *bs_down, *af_t, *bs_t;                // MFMA fragments of down0.down and up3.convT
   const float *w_out, *b_out;                                  // 1x1 output conv
+  PreArgs pre;                                                 // has_pre: the kernel cuts and normalises its window itself
+  int has_pre;                                                 // (annotate_batch_pre, as gather_normalize_kernel); else it reads x
 };
 
 struct SplitRowStore {  // up3.convT -> level-0 rows 0-3 (g0) and 4-7 (g1); zero outside the signal
@@ -942,7 +944,102 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   // ================= level-0 down path: inc -> down0.same -> down0.down =================
   {
     float *H = lds + WD_H, *X = lds + WD_X;
-    {  // x rows: sample 4q - 4 .. 4q - 1 at float4 q; physical index HALO + 4q - 4 (16-byte aligned)
+    if (a.has_pre) {
+      // SeisBench annotate_batch_pre inside the kernel, arithmetic and reduction order of gather_normalize_kernel
+      // (prepost.hip): window cut from the stream, per-channel mean, peak / std amplitude, scale — the window is read
+      // once into registers and the normalised rows go straight into the x image (no input tensor in memory).
+      const PreArgs& p = a.pre;
+      float* red = lds + 11 * W0_S;  // [3][NWV] partials, then stat[3][2] (free arena space behind the x rows)
+      float* stat = red + 3 * NWV;
+      long start = p.dense ? 0 : (long)(p.first_window + win) * p.step;
+      if (!p.dense && start > p.N - T0) start = p.N - T0;  // tail window flush with the end
+      const float* src = p.src + (p.dense ? (long)win * 3 * T0 : start);
+      long cs = p.dense ? T0 : p.N;
+      if (p.table) {
+        const long* e = p.table + 3 * (p.first_window + win);
+        src = p.src + e[0] + e[2];
+        cs = e[1];
+      }
+      constexpr int MAXE = (T0 + NTH - 1) / NTH;
+      float v[3][MAXE], sum[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < MAXE; ++k) {
+          const int t = tid + k * NTH;
+          v[c][k] = t < T0 ? src[c * cs + t] : 0.f;
+          sum[c] += v[c][k];
+        }
+      for (int c = 0; c < 3; ++c) {
+        const float r = wave_sum(sum[c]);
+        if (lane == 0) red[c * NWV + wave] = r;
+      }
+      for (int i = tid; i < 3 * (W0_S - T0); i += NTH) {  // zero margins of the x rows: samples -4 .. -1 and T0 .. 3019
+        const int c = i / (W0_S - T0), k = i - c * (W0_S - T0);
+        X[c * W0_S + (k < 4 ? k : T0 + k)] = 0.f;
+      }
+      __syncthreads();
+      if (tid < 3) {
+        float acc = 0.f;
+        for (int i = 0; i < NWV; ++i) acc += red[tid * NWV + i];
+        stat[tid * 2] = acc / (float)T0;
+      }
+      __syncthreads();
+      const float mean[3] = {stat[0], stat[2], stat[4]};
+      float m[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < MAXE; ++k) {
+          const int t = tid + k * NTH;
+          if (t < T0) {
+            const float d = v[c][k] - mean[c];
+            if (p.norm == VP_NORM_PEAK) {
+              m[c] = fmaxf(m[c], fabsf(d));
+              if (d != d) m[c] = d;  // propagate NaN like torch.max
+            } else {
+              m[c] += d * d;
+            }
+          }
+        }
+      __syncthreads();
+      for (int c = 0; c < 3; ++c) {
+        const float r = (p.norm == VP_NORM_PEAK) ? wave_max(m[c]) : wave_sum(m[c]);
+        if (lane == 0) red[c * NWV + wave] = r;
+      }
+      __syncthreads();
+      if (tid < 3) {
+        const float* r = red + tid * NWV;
+        float acc = r[0];
+        for (int i = 1; i < NWV; ++i) acc = (p.norm == VP_NORM_PEAK) ? fmaxf(acc, r[i]) : acc + r[i];
+        stat[tid * 2 + 1] = acc;
+      }
+      __syncthreads();
+      float amp[3];
+      if (p.per_comp) {
+        for (int c = 0; c < 3; ++c) amp[c] = (p.norm == VP_NORM_PEAK) ? stat[2 * c + 1] : sqrtf(stat[2 * c + 1] / (float)(T0 - 1));
+      } else {
+        const float g = (p.norm == VP_NORM_PEAK) ? fmaxf(stat[1], fmaxf(stat[3], stat[5]))
+                                                 : sqrtf((stat[1] + stat[3] + stat[5]) / (float)(3 * T0 - 1));
+        amp[0] = amp[1] = amp[2] = g;
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float den = amp[c] + p.norm_eps;
+#pragma unroll
+        for (int k = 0; k < MAXE; ++k) {
+          const int t = tid + k * NTH;
+          if (t < T0) {
+            float o = (v[c][k] - mean[c]) / den;
+            if (p.taper > 0) {
+              const int e = (t < p.taper) ? t : ((T0 - 1 - t < p.taper) ? T0 - 1 - t : -1);
+              if (e >= 0) o *= 0.5f * (1.f + cosf(3.14159265358979323846f * (1.f + (float)e / (float)(p.taper - 1))));
+            }
+            X[c * W0_S + 4 + t] = o;
+          }
+        }
+      }
+    } else {  // x rows: sample 4q - 4 .. 4q - 1 at float4 q; physical index HALO + 4q - 4 (16-byte aligned)
       const float* src = a.x + (long)win * a.ws_x;
       for (int i = tid; i < 3 * W0_Q; i += NTH) {
         const int c = i / W0_Q, q = i - c * W0_Q;
@@ -951,6 +1048,8 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
         if (p + 3 < a.ls_x) v = *reinterpret_cast<const float4*>(src + (long)c * a.ls_x + p);
         *reinterpret_cast<float4*>(X + c * W0_S + 4 * q) = v;
       }
+    }
+    {
       if (tid < 8) *reinterpret_cast<float4*>(H + tid * W0_S) = make_float4(0.f, 0.f, 0.f, 0.f);  // samples -4 .. -1: left padding
     }
     __syncthreads();
@@ -1372,6 +1471,10 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
       a.bs_t = n.convs[16]->bias.d;
       a.w_out = e0->d;
       a.b_out = e1->d;
+      if (n.pre) {
+        a.pre = *n.pre;
+        a.has_pre = 1;
+      }
       if (pipe) {
         hipLaunchKernelGGL(pn_window_kernel<true>, dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
       } else {
@@ -1381,6 +1484,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     };
     steps.clear();
     steps.push_back(std::move(st));
+    net.fused_pre = net.cfg.reserved[6] != 1;  // reserved[6] = 1: gather_normalize_kernel fills the input tensor as in the other plans
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<true>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false>), CORE_LDS_FLOATS * sizeof(float)});
   }

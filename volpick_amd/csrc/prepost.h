@@ -24,6 +24,18 @@ struct PreArgs {
 };
 int launch_gather_normalize(const PreArgs& a, int n_windows, hipStream_t stream);
 
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+
 struct StackArgs {
   const float* pred;  // [n_windows][n_out][T]
   float* out;         // [n_out][N]

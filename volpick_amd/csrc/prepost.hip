@@ -13,17 +13,6 @@ namespace vp {
 // (EQT) and writes the haloed model input row.  The window (<= 72 KB) is read once into registers;
 // wavefront shuffle + LDS reductions.
 // ---------------------------------------------------------------------------------------
-__device__ inline float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ inline float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
 __global__ __launch_bounds__(1024) void gather_normalize_kernel(const PreArgs a) {
   constexpr int NTH = 1024, NWV = NTH / 64;
   __shared__ float red[3][NWV];
