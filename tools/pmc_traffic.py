@@ -31,9 +31,7 @@ def main():
                     "--pmc WRITE_SIZE in separate passes of tools/run_forward.py (tools/pmc_traffic.sh, tools/pmc_traffic.py), "
                     "gfx950 FETCH_SIZE x2 correction per MI355X_MICROARCH.md"}
     names = {
-        "phasenet": [("pn_down0v_kernel", "fused.down0 (inc+down0.same+down0.down)"),
-                     ("pn_core_kernel", "fused.core (down1..down4, up0..up2)"),
-                     ("pn_up3v_kernel", "fused.up3 (up3.convT+up3.same+out+softmax)")],
+        "phasenet": [("pn_window_kernel", "fused.window (whole PhaseNet, one workgroup per window)")],
         "eqtransformer": [("ConvCfg<16, 0, 8, 2, 7, 1, -3, 0, 1, 4, 8, 1, 6>", "decoder.6+heads"),
                           ("eqt_res_kernel", "fused.rescnn (7 residual blocks)")],
     }
