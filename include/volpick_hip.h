@@ -52,8 +52,16 @@ typedef struct {
   float norm_eps;             /* x / (amp + norm_eps) */
   int32_t taper_samples;      /* EQT half-cosine taper length (0 for PhaseNet) */
   int32_t reserved[8];        /* [0]: 1 = PhaseNet layer-by-layer plan instead of the fused kernels (debug / A-B);
-                                 [1]: bit0 = fused kernels also dump their LDS intermediates to the debug tensors,
-                                      bit1 = the fused core kernel records per-layer clock stamps */
+                                 [1]: bit0 = fused kernels also dump their LDS intermediates to the debug tensors
+                                      (selects the three-launch plan), bit1 = per-layer clock stamps;
+                                 [2]: 1 = hand-pipelined K loop in the PhaseNet MFMA layers (A/B);
+                                 [3]: tiled level-0 kernel variants of the all-MFMA plan (A/B);
+                                 [4]: 1 = no L2 warm-up of the weight streams;
+                                 [5]: PhaseNet plan: 0 = the whole network in one launch (default), 1 = three launches,
+                                      all MFMA (bit-identical to the layer plan), 2 = three launches, level-0
+                                      stride-1 convs on the VALU;
+                                 [6]: 1 = the one-launch plan reads the input tensor filled by gather_normalize
+                                      instead of cutting and normalising its windows itself */
 } vp_config;
 
 /* Fills cfg with the defaults for model_kind. */
