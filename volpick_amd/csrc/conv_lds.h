@@ -12,6 +12,8 @@
 // Each item keeps NB accumulators (NB*4 VGPRs), loads one A fragment per K-step from L2/L1 and
 // NB B fragments from LDS (per-lane base + immediate offsets).
 #pragma once
+#include <type_traits>
+
 #include "vp_common.h"
 
 namespace vp {
@@ -26,6 +28,77 @@ struct LdsLayer {
   static_assert(M % 16 == 0, "M must be a multiple of the 16-row MFMA tile");
   static_assert(CIN2 == 0 || CIN1 % 4 == 0, "concat boundary must fall on a 4-channel block");
 };
+
+// Strided layers (SN = 4 or 8: Conv1d stride 4, and its two-phase form) read the taps of an output column as ONE run
+// of consecutive floats: fetched tap by tap with ds_read_b32, the 16 columns of a fragment are 4 or 8 floats apart and
+// collide 4- to 8-way on the 32 LDS banks (measured: the level-0 strided conv was LDS-bound at twice its MFMA time).
+// BRun fetches the run as aligned 16-byte chunks instead (lanes 16-32 bytes apart) and hands the taps out of registers.
+template <class L, int B>
+struct BRun {
+  static constexpr bool use = (L::SN % 4 == 0);
+  static constexpr int OFF = (((B + L::IN_OFF) % 4) + 4) % 4;  // position of tap 0 inside its 16-byte chunk
+  static constexpr int NQ = (OFF + L::TAPS + 3) / 4;
+  f32x4 q[NQ];
+  // bp = address of tap 0 (16-byte aligned after subtracting OFF: image rows and SN are multiples of 4 floats)
+  __device__ __forceinline__ void load(const float* bp) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(bp - OFF);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) q[k] = p[k];
+  }
+  __device__ __forceinline__ float tap(int t) const { return q[(OFF + t) / 4][(OFF + t) % 4]; }
+};
+
+// Epilogue shared by conv_lds and conv_lds_areg.  Row m = 16*mt + 4*g + r of the D tile is (co, p) = (m / P, m % P);
+// with P in {1,2,4} both split into a per-lane part and a compile-time part of r, so every store address is a
+// per-lane base plus immediates.  If the whole block of columns is inside the store's unconditional range
+// (wave-uniform test) the per-element range checks are skipped.  With P = 4 the four registers of a lane are four
+// CONSECUTIVE samples of one channel: a store functor that declares `vec4` takes them as one 16-byte value
+// (scalar stores of a four-phase layer are 16 bytes apart across the lanes and collide 8-way on the LDS banks —
+// the epilogue of the level-0 transposed conv took as long as its MFMAs).
+template <class S, class = void>
+struct has_vec4 : std::false_type {};
+template <class S>
+struct has_vec4<S, std::void_t<decltype(&S::vec4)>> : std::true_type {};
+
+template <class L, class Store>
+__device__ __forceinline__ void lds_epilogue(const f32x4 (&acc)[L::NB], const float (&biasv)[4], const int mt, const int colb,
+                                             const int g, const int n, Store& store) {
+  static_assert(L::P == 1 || L::P == 2 || L::P == 4, "P must divide the 4-row register group");
+  const int co_lane = mt * (16 / L::P) + (4 * g) / L::P;
+  const int t_first = L::P * colb + L::OUT_OFF, t_last = L::P * (colb + L::NB * 16) - 1 + L::OUT_OFF;
+  const bool fast = store.all_valid(t_first, t_last);
+  if constexpr (L::P == 4 && has_vec4<Store>::value) {
+    if (fast) {
+#pragma unroll
+      for (int j = 0; j < L::NB; ++j) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[j][r] + biasv[r];
+          if (L::RELU) v[r] = fmaxf(v[r], 0.f);
+        }
+        store.vec4(co_lane, 4 * (colb + j * 16 + n) + L::OUT_OFF, v);
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = co_lane + r / L::P, p = r % L::P;
+    const float b = biasv[r];
+#pragma unroll
+    for (int j = 0; j < L::NB; ++j) {
+      float v = acc[j][r] + b;
+      if (L::RELU) v = fmaxf(v, 0.f);
+      const int t = L::P * (colb + j * 16 + n) + p + L::OUT_OFF;
+      if (fast) {
+        store.unchecked(co, t, v);
+      } else {
+        store(co, t, v);
+      }
+    }
+  }
+}
 
 // in1/in2: LDS images (row strides S1/S2, logical 0 at column B1/B2).  afrag: packed A
 // fragments [MT][CB][TAPS][64] in global memory.  store(co, t, v) consumes every output
@@ -61,10 +134,21 @@ __device__ __forceinline__ void conv_lds(const float* in1, const float* in2, con
         const float* bp = (cb < L::CB1) ? bp1 + cb * 4 * S1 : bp2 + (cb - L::CB1) * 4 * S2;
 #pragma unroll
         for (int tap = 0; tap < L::TAPS; ++tap) av[tap] = ap[(cb * L::TAPS + tap) * 64];
+        if constexpr (BRun<L, B1>::use) {
+          static_assert(BRun<L, B1>::OFF == BRun<L, B2>::OFF, "both images of a strided layer share the tap alignment");
 #pragma unroll
-        for (int tap = 0; tap < L::TAPS; ++tap)
+          for (int j = 0; j < L::NB; ++j) {
+            BRun<L, B1> run;
+            run.load(bp + j * 16 * L::SN);
 #pragma unroll
-          for (int j = 0; j < L::NB; ++j) bv[tap][j] = bp[j * 16 * L::SN + tap];
+            for (int tap = 0; tap < L::TAPS; ++tap) bv[tap][j] = run.tap(tap);
+          }
+        } else {
+#pragma unroll
+          for (int tap = 0; tap < L::TAPS; ++tap)
+#pragma unroll
+            for (int j = 0; j < L::NB; ++j) bv[tap][j] = bp[j * 16 * L::SN + tap];
+        }
       };
       auto mac = [&](const float (&av)[L::TAPS], const float (&bv)[L::TAPS][L::NB]) {
 #pragma unroll
@@ -117,30 +201,7 @@ __device__ __forceinline__ void conv_lds(const float* in1, const float* in2, con
         }
       }
     }
-    // Epilogue.  Row m = 16*mt + 4*g + r of the D tile is (co, p) = (m / P, m % P); with P in
-    // {1,2,4} both split into a per-lane part and a compile-time part of r, so every store address
-    // is a per-lane base plus immediates.  If the whole block of columns is inside the store's
-    // unconditional range (wave-uniform test) the per-element range checks are skipped.
-    static_assert(L::P == 1 || L::P == 2 || L::P == 4, "P must divide the 4-row register group");
-    const int co_lane = mt * (16 / L::P) + (4 * g) / L::P;
-    const int t_first = L::P * colb + L::OUT_OFF, t_last = L::P * (colb + L::NB * 16) - 1 + L::OUT_OFF;
-    const bool fast = store.all_valid(t_first, t_last);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = co_lane + r / L::P, p = r % L::P;
-      const float b = biasv[r];
-#pragma unroll
-      for (int j = 0; j < L::NB; ++j) {
-        float v = acc[j][r] + b;
-        if (L::RELU) v = fmaxf(v, 0.f);
-        const int t = L::P * (colb + j * 16 + n) + p + L::OUT_OFF;
-        if (fast) {
-          store.unchecked(co, t, v);
-        } else {
-          store(co, t, v);
-        }
-      }
-    }
+    lds_epilogue<L>(acc, biasv, mt, colb, g, n, store);
   }
 }
 
@@ -207,30 +268,24 @@ __device__ __forceinline__ void conv_lds_areg(const float* in1, const float* in2
 #pragma unroll
     for (int cb = 0; cb < L::CB; ++cb) {
       const float* bp = (cb < L::CB1) ? bp1 + cb * 4 * S1 : bp2 + (cb - L::CB1) * 4 * S2;
+      if constexpr (BRun<L, B1>::use) {
+        BRun<L, B1> run[L::NB];
 #pragma unroll
-      for (int tap = 0; tap < L::TAPS; ++tap)
+        for (int j = 0; j < L::NB; ++j) run[j].load(bp + j * 16 * L::SN);
 #pragma unroll
-        for (int j = 0; j < L::NB; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[cb * L::TAPS + tap], bp[j * 16 * L::SN + tap], acc[j], 0, 0, 0);
-    }
-    const int co_lane = mt * (16 / L::P) + (4 * g) / L::P;
-    const int t_first = L::P * colb + L::OUT_OFF, t_last = L::P * (colb + L::NB * 16) - 1 + L::OUT_OFF;
-    const bool fast = store.all_valid(t_first, t_last);
+        for (int tap = 0; tap < L::TAPS; ++tap)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = co_lane + r / L::P, p = r % L::P;
+          for (int j = 0; j < L::NB; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[cb * L::TAPS + tap], run[j].tap(tap), acc[j], 0, 0, 0);
+      } else {
 #pragma unroll
-      for (int j = 0; j < L::NB; ++j) {
-        float v = acc[j][r] + biasv[r];
-        if (L::RELU) v = fmaxf(v, 0.f);
-        const int t = L::P * (colb + j * 16 + n) + p + L::OUT_OFF;
-        if (fast) {
-          store.unchecked(co, t, v);
-        } else {
-          store(co, t, v);
-        }
+        for (int tap = 0; tap < L::TAPS; ++tap)
+#pragma unroll
+          for (int j = 0; j < L::NB; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[cb * L::TAPS + tap], bp[j * 16 * L::SN + tap], acc[j], 0, 0, 0);
       }
     }
+    lds_epilogue<L>(acc, biasv, mt, colb, g, n, store);
   }
 }
 

@@ -26,12 +26,12 @@ constexpr int img_stride(int L) { return ((4 + L + 20 - 16 + 31) / 32) * 32 + 16
 constexpr int S1_ = img_stride(T1), S2_ = img_stride(T2), S3_ = img_stride(T3), S4_ = img_stride(T4);
 static_assert(S1_ == 784 && S2_ == 240 && S3_ == 80 && S4_ == 48, "image strides");
 
-template <int C, int S, int L>
+template <int C, int S, int L, int B = IB>
 __device__ __forceinline__ void zero_halo(float* img, int tid, int nth) {
   constexpr int RW = S - L;
   for (int i = tid; i < C * RW; i += nth) {
     const int c = i / RW, k = i - c * RW;
-    img[c * S + (k < IB ? k : L + k)] = 0.f;
+    img[c * S + (k < B ? k : L + k)] = 0.f;
   }
 }
 
@@ -44,6 +44,16 @@ struct RangeStore {  // LDS image store, valid t in [0, L)
   }
   __device__ __forceinline__ bool all_valid(int t0, int t1) const { return t0 >= 0 && t1 < L; }
   __device__ __forceinline__ void unchecked(int co, int t, float v) const { img[co * S + B + t] = v; }
+};
+
+// The images written by the four-phase transposed convs of the core keep sample 0 at column TB = 5: with OUT_OFF = -1
+// a lane's four consecutive outputs 4c - 1 .. 4c + 2 then start on a 16-byte boundary and leave as one ds_write_b128.
+constexpr int TB = 5;
+template <int S, int B>
+struct RangeStoreS : RangeStore<S, B> {};
+template <int S, int B>
+struct RangeStoreV : RangeStore<S, B> {
+  __device__ __forceinline__ void vec4(int co, int t, f32x4 v) const { *reinterpret_cast<f32x4*>(this->img + co * S + B + t) = v; }
 };
 
 struct GlobalRowStore {  // haloed activation tensor row store with a valid range
@@ -115,13 +125,13 @@ struct CoreArgs {
   int warm;                 // 1 (default): the first workgroup of each XCD pre-touches the weights
 };
 
-template <int C, int S>
+template <int C, int S, int B = IB>
 __device__ void dump_image(const float* img, int L, float* dst, int ls, long ws, int win, int tid, int nth) {
   if (!dst) return;
   float* d = dst + (long)win * ws + HALO;
   for (int i = tid; i < C * L; i += nth) {
     const int c = i / L, t = i - c * L;
-    d[(long)c * ls + t] = img[c * S + IB + t];
+    d[(long)c * ls + t] = img[c * S + B + t];
   }
 }
 
@@ -165,32 +175,49 @@ __global__ __launch_bounds__(1024) void pn_core_kernel(const CoreArgs a) {
   __syncthreads();
   CORE_STAMP()
 
-#define CORE_LAYER(IDX, LAYER, IN1, SI1, IN2, SI2, OUT, SO, CO, COLS, LOUT, DBG)                                   \
+#define CORE_LAYER(IDX, LAYER, IN1, SI1, IN2, SI2, B2, OUT, SO, OB, STORE, CO, COLS, LOUT, DBG)                    \
   {                                                                                                                \
-    RangeStore<SO, IB> st{lds + (OUT), (LOUT)};                                                                   \
-    zero_halo<CO, SO, LOUT>(lds + (OUT), tid, NTH);                                                              \
-    conv_lds<LAYER, SI1, IB, SI2, IB, PIPE, (LAYER::NB < BDB_MAX_NB)>(lds + (IN1), lds + (IN2), a.af[IDX], a.bs[IDX], (COLS), st, wave, NWV, lane); \
+    STORE<SO, OB> st{{lds + (OUT), (LOUT)}};                                                                      \
+    zero_halo<CO, SO, LOUT, OB>(lds + (OUT), tid, NTH);                                                          \
+    conv_lds<LAYER, SI1, IB, SI2, B2, PIPE, (LAYER::NB < BDB_MAX_NB)>(lds + (IN1), lds + (IN2), a.af[IDX], a.bs[IDX], (COLS), st, wave, NWV, lane); \
     __syncthreads();                                                                                               \
     CORE_STAMP()                                                                                                   \
-    if (a.dbg[DBG]) dump_image<CO, SO>(lds + (OUT), (LOUT), a.dbg[DBG], a.dbg_ls[DBG], a.dbg_ws[DBG], win, tid, NTH); \
+    if (a.dbg[DBG]) dump_image<CO, SO, OB>(lds + (OUT), (LOUT), a.dbg[DBG], a.dbg_ls[DBG], a.dbg_ws[DBG], win, tid, NTH); \
   }
-  //          idx layer      in1      S    in2      S    out      S    C    cols     Lout dbg
-  CORE_LAYER(0, C_d1same, A_D0, S1_, A_D0, S1_, A_SKIP1, S1_, 16, T1, T1, 0)
-  CORE_LAYER(1, C_d1down, A_SKIP1, S1_, A_SKIP1, S1_, A_D1, S2_, 16, T2, T2, 1)
-  CORE_LAYER(2, C_d2same, A_D1, S2_, A_D1, S2_, A_SKIP2, S2_, 32, T2, T2, 2)
-  CORE_LAYER(3, C_d2down, A_SKIP2, S2_, A_SKIP2, S2_, A_D2, S3_, 32, T3, T3, 3)
-  CORE_LAYER(4, C_d3same, A_D2, S3_, A_D2, S3_, A_SKIP3, S3_, 64, T3, T3, 4)
-  CORE_LAYER(5, C_d3down, A_SKIP3, S3_, A_SKIP3, S3_, A_D3, S4_, 64, T4, T4, 5)
-  CORE_LAYER(6, C_d4same, A_D3, S4_, A_D3, S4_, A_BOT, S4_, 128, T4, T4, 6)
-  CORE_LAYER(7, C_u0T, A_BOT, S4_, A_BOT, S4_, A_U0T, S3_, 64, T4 + 1, T3, 7)
-  CORE_LAYER(8, C_u0same, A_SKIP3, S3_, A_U0T, S3_, A_U0S, S3_, 64, T3, T3, 8)
-  CORE_LAYER(9, C_u1T, A_U0S, S3_, A_U0S, S3_, A_U1T, S2_, 32, T3 + 1, T2, 9)
-  CORE_LAYER(10, C_u1same, A_SKIP2, S2_, A_U1T, S2_, A_U1S, S2_, 32, T2, T2, 10)
-  CORE_LAYER(11, C_u2T, A_U1S, S2_, A_U1S, S2_, A_U2T, S1_, 16, T2 + 1, T1, 11)
+  //          idx layer      in1      S    in2      S    b2  out      S    ob  store        C    cols     Lout dbg
+  CORE_LAYER(0, C_d1same, A_D0, S1_, A_D0, S1_, IB, A_SKIP1, S1_, IB, RangeStoreS, 16, T1, T1, 0)
+  CORE_LAYER(1, C_d1down, A_SKIP1, S1_, A_SKIP1, S1_, IB, A_D1, S2_, IB, RangeStoreS, 16, T2, T2, 1)
+  CORE_LAYER(2, C_d2same, A_D1, S2_, A_D1, S2_, IB, A_SKIP2, S2_, IB, RangeStoreS, 32, T2, T2, 2)
+  CORE_LAYER(3, C_d2down, A_SKIP2, S2_, A_SKIP2, S2_, IB, A_D2, S3_, IB, RangeStoreS, 32, T3, T3, 3)
+  CORE_LAYER(4, C_d3same, A_D2, S3_, A_D2, S3_, IB, A_SKIP3, S3_, IB, RangeStoreS, 64, T3, T3, 4)
+  CORE_LAYER(5, C_d3down, A_SKIP3, S3_, A_SKIP3, S3_, IB, A_D3, S4_, IB, RangeStoreS, 64, T4, T4, 5)
+  CORE_LAYER(6, C_d4same, A_D3, S4_, A_D3, S4_, IB, A_BOT, S4_, IB, RangeStoreS, 128, T4, T4, 6)
+  CORE_LAYER(7, C_u0T, A_BOT, S4_, A_BOT, S4_, IB, A_U0T, S3_, TB, RangeStoreV, 64, T4 + 1, T3, 7)
+  CORE_LAYER(8, C_u0same, A_SKIP3, S3_, A_U0T, S3_, TB, A_U0S, S3_, IB, RangeStoreS, 64, T3, T3, 8)
+  // Two-tap layers with few items: the wave's whole A operand (16-32 fragments) is fetched up front — two fragments per
+  // channel block in flight (the double buffer of conv_lds) left these layers waiting on L2 at every block.
+#define CORE_LAYER_AREG(IDX, LAYER, IN1, SI1, OUT, SO, CO, COLS, LOUT, WMT, WFIRST, WSTEP, DBG)                    \
+  {                                                                                                                \
+    RangeStoreV<SO, TB> st{{lds + (OUT), (LOUT)}};                                                                \
+    zero_halo<CO, SO, LOUT, TB>(lds + (OUT), tid, NTH);                                                          \
+    if ((WMT) < LAYER::MT) {                                                                                       \
+      float ar[LAYER::CB * LAYER::TAPS], br[4];                                                                    \
+      load_areg<LAYER>(a.af[IDX], (WMT), lane, ar);                                                                \
+      load_biasreg<LAYER>(a.bs[IDX], (WMT), lane, br);                                                             \
+      conv_lds_areg<LAYER, SI1, IB, SI1, IB>(lds + (IN1), lds + (IN1), ar, br, (WMT), (COLS), st, (WFIRST), (WSTEP), lane); \
+    }                                                                                                              \
+    __syncthreads();                                                                                               \
+    CORE_STAMP()                                                                                                   \
+    if (a.dbg[DBG]) dump_image<CO, SO, TB>(lds + (OUT), (LOUT), a.dbg[DBG], a.dbg_ls[DBG], a.dbg_ws[DBG], win, tid, NTH); \
+  }
+  CORE_LAYER_AREG(9, C_u1T, A_U0S, S3_, A_U1T, S2_, 32, T3 + 1, T2, wave, 0, 1, 9)        // 8 m-tiles x 1 block
+  CORE_LAYER(10, C_u1same, A_SKIP2, S2_, A_U1T, S2_, TB, A_U1S, S2_, IB, RangeStoreS, 32, T2, T2, 10)
+  CORE_LAYER_AREG(11, C_u2T, A_U1S, S2_, A_U2T, S1_, 16, T2 + 1, T1, wave & 3, wave >> 2, 4, 11)  // 4 m-tiles x 4 blocks
+#undef CORE_LAYER_AREG
 #undef CORE_LAYER
   {
     GlobalRowStore st{a.u2s + (long)win * a.ws_u2s + HALO, a.ls_u2s, T1, 0};
-    conv_lds<C_u2same, S1_, IB, S1_, IB, PIPE, (C_u2same::NB < BDB_MAX_NB)>(lds + A_SKIP1, lds + A_U2T, a.af[12], a.bs[12], T1, st, wave, NWV, lane);
+    conv_lds<C_u2same, S1_, IB, S1_, TB, PIPE, (C_u2same::NB < BDB_MAX_NB)>(lds + A_SKIP1, lds + A_U2T, a.af[12], a.bs[12], T1, st, wave, NWV, lane);
   }
   __syncthreads();
   CORE_STAMP()
@@ -912,6 +939,11 @@ struct SplitRowStore {  // up3.convT -> level-0 rows 0-3 (g0) and 4-7 (g1); zero
   }
   __device__ __forceinline__ bool all_valid(int t0, int t1) const { return t0 >= 0 && t1 < T0; }
   __device__ __forceinline__ void unchecked(int co, int t, float v) const { row(co)[4 + t] = v; }
+  __device__ __forceinline__ void vec4(int co, int t, f32x4 v) const {  // OUT_OFF = -2: two 8-byte aligned halves
+    float* d = row(co) + 4 + t;
+    *reinterpret_cast<f32x2*>(d) = f32x2{v[0], v[1]};
+    *reinterpret_cast<f32x2*>(d + 2) = f32x2{v[2], v[3]};
+  }
 };
 
 template <bool PIPE>
@@ -1114,28 +1146,43 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
 
   // ================= levels 1-4 down, up0 .. up2 (pn_core_kernel) =================
   int stamp = 2;
-#define CORE_LAYER(IDX, LAYER, IN1, SI1, IN2, SI2, OUT, SO, CO, COLS, LOUT)                                        \
+#define CORE_LAYER(IDX, LAYER, IN1, SI1, IN2, SI2, B2, OUT, SO, OB, STORE, CO, COLS, LOUT)                         \
   {                                                                                                                \
-    RangeStore<SO, IB> st{lds + (OUT), (LOUT)};                                                                   \
-    zero_halo<CO, SO, LOUT>(lds + (OUT), tid, NTH);                                                              \
-    conv_lds<LAYER, SI1, IB, SI2, IB, PIPE, (LAYER::NB < BDB_MAX_NB)>(lds + (IN1), lds + (IN2), a.c.af[IDX], a.c.bs[IDX], (COLS), st, wave, NWV, lane); \
+    STORE<SO, OB> st{{lds + (OUT), (LOUT)}};                                                                      \
+    zero_halo<CO, SO, LOUT, OB>(lds + (OUT), tid, NTH);                                                          \
+    conv_lds<LAYER, SI1, IB, SI2, B2, PIPE, (LAYER::NB < BDB_MAX_NB)>(lds + (IN1), lds + (IN2), a.c.af[IDX], a.c.bs[IDX], (COLS), st, wave, NWV, lane); \
     __syncthreads();                                                                                               \
     WIN_STAMP(stamp)                                                                                               \
     ++stamp;                                                                                                       \
   }
-  CORE_LAYER(0, C_d1same, A_D0, S1_, A_D0, S1_, A_SKIP1, S1_, 16, T1, T1)
-  CORE_LAYER(1, C_d1down, A_SKIP1, S1_, A_SKIP1, S1_, A_D1, S2_, 16, T2, T2)
-  CORE_LAYER(2, C_d2same, A_D1, S2_, A_D1, S2_, A_SKIP2, S2_, 32, T2, T2)
-  CORE_LAYER(3, C_d2down, A_SKIP2, S2_, A_SKIP2, S2_, A_D2, S3_, 32, T3, T3)
-  CORE_LAYER(4, C_d3same, A_D2, S3_, A_D2, S3_, A_SKIP3, S3_, 64, T3, T3)
-  CORE_LAYER(5, C_d3down, A_SKIP3, S3_, A_SKIP3, S3_, A_D3, S4_, 64, T4, T4)
-  CORE_LAYER(6, C_d4same, A_D3, S4_, A_D3, S4_, A_BOT, S4_, 128, T4, T4)
-  CORE_LAYER(7, C_u0T, A_BOT, S4_, A_BOT, S4_, A_U0T, S3_, 64, T4 + 1, T3)
-  CORE_LAYER(8, C_u0same, A_SKIP3, S3_, A_U0T, S3_, A_U0S, S3_, 64, T3, T3)
-  CORE_LAYER(9, C_u1T, A_U0S, S3_, A_U0S, S3_, A_U1T, S2_, 32, T3 + 1, T2)
-  CORE_LAYER(10, C_u1same, A_SKIP2, S2_, A_U1T, S2_, A_U1S, S2_, 32, T2, T2)
-  CORE_LAYER(11, C_u2T, A_U1S, S2_, A_U1S, S2_, A_U2T, S1_, 16, T2 + 1, T1)
-  CORE_LAYER(12, C_u2same, A_SKIP1, S1_, A_U2T, S1_, WU_U, S1_, 16, T1, T1)
+  CORE_LAYER(0, C_d1same, A_D0, S1_, A_D0, S1_, IB, A_SKIP1, S1_, IB, RangeStoreS, 16, T1, T1)
+  CORE_LAYER(1, C_d1down, A_SKIP1, S1_, A_SKIP1, S1_, IB, A_D1, S2_, IB, RangeStoreS, 16, T2, T2)
+  CORE_LAYER(2, C_d2same, A_D1, S2_, A_D1, S2_, IB, A_SKIP2, S2_, IB, RangeStoreS, 32, T2, T2)
+  CORE_LAYER(3, C_d2down, A_SKIP2, S2_, A_SKIP2, S2_, IB, A_D2, S3_, IB, RangeStoreS, 32, T3, T3)
+  CORE_LAYER(4, C_d3same, A_D2, S3_, A_D2, S3_, IB, A_SKIP3, S3_, IB, RangeStoreS, 64, T3, T3)
+  CORE_LAYER(5, C_d3down, A_SKIP3, S3_, A_SKIP3, S3_, IB, A_D3, S4_, IB, RangeStoreS, 64, T4, T4)
+  CORE_LAYER(6, C_d4same, A_D3, S4_, A_D3, S4_, IB, A_BOT, S4_, IB, RangeStoreS, 128, T4, T4)
+  CORE_LAYER(7, C_u0T, A_BOT, S4_, A_BOT, S4_, IB, A_U0T, S3_, TB, RangeStoreV, 64, T4 + 1, T3)
+  CORE_LAYER(8, C_u0same, A_SKIP3, S3_, A_U0T, S3_, TB, A_U0S, S3_, IB, RangeStoreS, 64, T3, T3)
+#define CORE_LAYER_AREG(IDX, LAYER, IN1, SI1, OUT, SO, CO, COLS, LOUT, WMT, WFIRST, WSTEP)                         \
+  {                                                                                                                \
+    RangeStoreV<SO, TB> st{{lds + (OUT), (LOUT)}};                                                                \
+    zero_halo<CO, SO, LOUT, TB>(lds + (OUT), tid, NTH);                                                          \
+    if ((WMT) < LAYER::MT) {                                                                                       \
+      float ar[LAYER::CB * LAYER::TAPS], br[4];                                                                    \
+      load_areg<LAYER>(a.c.af[IDX], (WMT), lane, ar);                                                              \
+      load_biasreg<LAYER>(a.c.bs[IDX], (WMT), lane, br);                                                           \
+      conv_lds_areg<LAYER, SI1, IB, SI1, IB>(lds + (IN1), lds + (IN1), ar, br, (WMT), (COLS), st, (WFIRST), (WSTEP), lane); \
+    }                                                                                                              \
+    __syncthreads();                                                                                               \
+    WIN_STAMP(stamp)                                                                                               \
+    ++stamp;                                                                                                       \
+  }
+  CORE_LAYER_AREG(9, C_u1T, A_U0S, S3_, A_U1T, S2_, 32, T3 + 1, T2, wave, 0, 1)        // 8 m-tiles x 1 block (pn_core_kernel)
+  CORE_LAYER(10, C_u1same, A_SKIP2, S2_, A_U1T, S2_, TB, A_U1S, S2_, IB, RangeStoreS, 32, T2, T2)
+  CORE_LAYER_AREG(11, C_u2T, A_U1S, S2_, A_U2T, S1_, 16, T2 + 1, T1, wave & 3, wave >> 2, 4)  // 4 m-tiles x 4 blocks
+#undef CORE_LAYER_AREG
+  CORE_LAYER(12, C_u2same, A_SKIP1, S1_, A_U2T, S1_, TB, WU_U, S1_, IB, RangeStoreS, 16, T1, T1)
 #undef CORE_LAYER
 
   // ================= level-0 up path: up3.convT -> cat(skip0, .) -> up3.same -> 1x1 -> softmax =================
