@@ -184,6 +184,20 @@ __global__ __launch_bounds__(1024) void pn_core_kernel(const CoreArgs a) {
     CORE_STAMP()                                                                                                   \
     if (a.dbg[DBG]) dump_image<CO, SO, OB>(lds + (OUT), (LOUT), a.dbg[DBG], a.dbg_ls[DBG], a.dbg_ws[DBG], win, tid, NTH); \
   }
+#define CORE_LAYER_AREG(IDX, LAYER, IN1, SI1, OUT, SO, OB, STORE, CO, COLS, LOUT, WMT, WFIRST, WSTEP, DBG)                    \
+  {                                                                                                                \
+    STORE<SO, OB> st{{lds + (OUT), (LOUT)}};                                                                      \
+    zero_halo<CO, SO, LOUT, OB>(lds + (OUT), tid, NTH);                                                          \
+    if ((WMT) < LAYER::MT && (WFIRST) < ((((COLS) + 15) >> 4) + LAYER::NB - 1) / LAYER::NB) {                    \
+      float ar[LAYER::CB * LAYER::TAPS], br[4];                                                                    \
+      load_areg<LAYER>(a.af[IDX], (WMT), lane, ar);                                                                \
+      load_biasreg<LAYER>(a.bs[IDX], (WMT), lane, br);                                                             \
+      conv_lds_areg<LAYER, SI1, IB, SI1, IB>(lds + (IN1), lds + (IN1), ar, br, (WMT), (COLS), st, (WFIRST), (WSTEP), lane); \
+    }                                                                                                              \
+    __syncthreads();                                                                                               \
+    CORE_STAMP()                                                                                                   \
+    if (a.dbg[DBG]) dump_image<CO, SO, OB>(lds + (OUT), (LOUT), a.dbg[DBG], a.dbg_ls[DBG], a.dbg_ws[DBG], win, tid, NTH); \
+  }
   //          idx layer      in1      S    in2      S    b2  out      S    ob  store        C    cols     Lout dbg
   CORE_LAYER(0, C_d1same, A_D0, S1_, A_D0, S1_, IB, A_SKIP1, S1_, IB, RangeStoreS, 16, T1, T1, 0)
   CORE_LAYER(1, C_d1down, A_SKIP1, S1_, A_SKIP1, S1_, IB, A_D1, S2_, IB, RangeStoreS, 16, T2, T2, 1)
@@ -196,23 +210,9 @@ __global__ __launch_bounds__(1024) void pn_core_kernel(const CoreArgs a) {
   CORE_LAYER(8, C_u0same, A_SKIP3, S3_, A_U0T, S3_, TB, A_U0S, S3_, IB, RangeStoreS, 64, T3, T3, 8)
   // Two-tap layers with few items: the wave's whole A operand (16-32 fragments) is fetched up front — two fragments per
   // channel block in flight (the double buffer of conv_lds) left these layers waiting on L2 at every block.
-#define CORE_LAYER_AREG(IDX, LAYER, IN1, SI1, OUT, SO, CO, COLS, LOUT, WMT, WFIRST, WSTEP, DBG)                    \
-  {                                                                                                                \
-    RangeStoreV<SO, TB> st{{lds + (OUT), (LOUT)}};                                                                \
-    zero_halo<CO, SO, LOUT, TB>(lds + (OUT), tid, NTH);                                                          \
-    if ((WMT) < LAYER::MT) {                                                                                       \
-      float ar[LAYER::CB * LAYER::TAPS], br[4];                                                                    \
-      load_areg<LAYER>(a.af[IDX], (WMT), lane, ar);                                                                \
-      load_biasreg<LAYER>(a.bs[IDX], (WMT), lane, br);                                                             \
-      conv_lds_areg<LAYER, SI1, IB, SI1, IB>(lds + (IN1), lds + (IN1), ar, br, (WMT), (COLS), st, (WFIRST), (WSTEP), lane); \
-    }                                                                                                              \
-    __syncthreads();                                                                                               \
-    CORE_STAMP()                                                                                                   \
-    if (a.dbg[DBG]) dump_image<CO, SO, TB>(lds + (OUT), (LOUT), a.dbg[DBG], a.dbg_ls[DBG], a.dbg_ws[DBG], win, tid, NTH); \
-  }
-  CORE_LAYER_AREG(9, C_u1T, A_U0S, S3_, A_U1T, S2_, 32, T3 + 1, T2, wave, 0, 1, 9)        // 8 m-tiles x 1 block
+  CORE_LAYER_AREG(9, C_u1T, A_U0S, S3_, A_U1T, S2_, TB, RangeStoreV, 32, T3 + 1, T2, wave, 0, 1, 9)        // 8 m-tiles x 1 block
   CORE_LAYER(10, C_u1same, A_SKIP2, S2_, A_U1T, S2_, TB, A_U1S, S2_, IB, RangeStoreS, 32, T2, T2, 10)
-  CORE_LAYER_AREG(11, C_u2T, A_U1S, S2_, A_U2T, S1_, 16, T2 + 1, T1, wave & 3, wave >> 2, 4, 11)  // 4 m-tiles x 4 blocks
+  CORE_LAYER_AREG(11, C_u2T, A_U1S, S2_, A_U2T, S1_, TB, RangeStoreV, 16, T2 + 1, T1, wave & 3, wave >> 2, 4, 11)  // 4 m-tiles x 4 blocks
 #undef CORE_LAYER_AREG
 #undef CORE_LAYER
   {
@@ -1155,20 +1155,11 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
     WIN_STAMP(stamp)                                                                                               \
     ++stamp;                                                                                                       \
   }
-  CORE_LAYER(0, C_d1same, A_D0, S1_, A_D0, S1_, IB, A_SKIP1, S1_, IB, RangeStoreS, 16, T1, T1)
-  CORE_LAYER(1, C_d1down, A_SKIP1, S1_, A_SKIP1, S1_, IB, A_D1, S2_, IB, RangeStoreS, 16, T2, T2)
-  CORE_LAYER(2, C_d2same, A_D1, S2_, A_D1, S2_, IB, A_SKIP2, S2_, IB, RangeStoreS, 32, T2, T2)
-  CORE_LAYER(3, C_d2down, A_SKIP2, S2_, A_SKIP2, S2_, IB, A_D2, S3_, IB, RangeStoreS, 32, T3, T3)
-  CORE_LAYER(4, C_d3same, A_D2, S3_, A_D2, S3_, IB, A_SKIP3, S3_, IB, RangeStoreS, 64, T3, T3)
-  CORE_LAYER(5, C_d3down, A_SKIP3, S3_, A_SKIP3, S3_, IB, A_D3, S4_, IB, RangeStoreS, 64, T4, T4)
-  CORE_LAYER(6, C_d4same, A_D3, S4_, A_D3, S4_, IB, A_BOT, S4_, IB, RangeStoreS, 128, T4, T4)
-  CORE_LAYER(7, C_u0T, A_BOT, S4_, A_BOT, S4_, IB, A_U0T, S3_, TB, RangeStoreV, 64, T4 + 1, T3)
-  CORE_LAYER(8, C_u0same, A_SKIP3, S3_, A_U0T, S3_, TB, A_U0S, S3_, IB, RangeStoreS, 64, T3, T3)
-#define CORE_LAYER_AREG(IDX, LAYER, IN1, SI1, OUT, SO, CO, COLS, LOUT, WMT, WFIRST, WSTEP)                         \
+#define CORE_LAYER_AREG(IDX, LAYER, IN1, SI1, OUT, SO, OB, STORE, CO, COLS, LOUT, WMT, WFIRST, WSTEP)                       \
   {                                                                                                                \
-    RangeStoreV<SO, TB> st{{lds + (OUT), (LOUT)}};                                                                \
-    zero_halo<CO, SO, LOUT, TB>(lds + (OUT), tid, NTH);                                                          \
-    if ((WMT) < LAYER::MT) {                                                                                       \
+    STORE<SO, OB> st{{lds + (OUT), (LOUT)}};                                                                      \
+    zero_halo<CO, SO, LOUT, OB>(lds + (OUT), tid, NTH);                                                          \
+    if ((WMT) < LAYER::MT && (WFIRST) < ((((COLS) + 15) >> 4) + LAYER::NB - 1) / LAYER::NB) {                    \
       float ar[LAYER::CB * LAYER::TAPS], br[4];                                                                    \
       load_areg<LAYER>(a.c.af[IDX], (WMT), lane, ar);                                                              \
       load_biasreg<LAYER>(a.c.bs[IDX], (WMT), lane, br);                                                           \
@@ -1178,9 +1169,18 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
     WIN_STAMP(stamp)                                                                                               \
     ++stamp;                                                                                                       \
   }
-  CORE_LAYER_AREG(9, C_u1T, A_U0S, S3_, A_U1T, S2_, 32, T3 + 1, T2, wave, 0, 1)        // 8 m-tiles x 1 block (pn_core_kernel)
+  CORE_LAYER(0, C_d1same, A_D0, S1_, A_D0, S1_, IB, A_SKIP1, S1_, IB, RangeStoreS, 16, T1, T1)
+  CORE_LAYER(1, C_d1down, A_SKIP1, S1_, A_SKIP1, S1_, IB, A_D1, S2_, IB, RangeStoreS, 16, T2, T2)
+  CORE_LAYER(2, C_d2same, A_D1, S2_, A_D1, S2_, IB, A_SKIP2, S2_, IB, RangeStoreS, 32, T2, T2)
+  CORE_LAYER(3, C_d2down, A_SKIP2, S2_, A_SKIP2, S2_, IB, A_D2, S3_, IB, RangeStoreS, 32, T3, T3)
+  CORE_LAYER(4, C_d3same, A_D2, S3_, A_D2, S3_, IB, A_SKIP3, S3_, IB, RangeStoreS, 64, T3, T3)
+  CORE_LAYER(5, C_d3down, A_SKIP3, S3_, A_SKIP3, S3_, IB, A_D3, S4_, IB, RangeStoreS, 64, T4, T4)
+  CORE_LAYER(6, C_d4same, A_D3, S4_, A_D3, S4_, IB, A_BOT, S4_, IB, RangeStoreS, 128, T4, T4)
+  CORE_LAYER(7, C_u0T, A_BOT, S4_, A_BOT, S4_, IB, A_U0T, S3_, TB, RangeStoreV, 64, T4 + 1, T3)
+  CORE_LAYER(8, C_u0same, A_SKIP3, S3_, A_U0T, S3_, TB, A_U0S, S3_, IB, RangeStoreS, 64, T3, T3)
+  CORE_LAYER_AREG(9, C_u1T, A_U0S, S3_, A_U1T, S2_, TB, RangeStoreV, 32, T3 + 1, T2, wave, 0, 1)        // 8 m-tiles x 1 block (pn_core_kernel)
   CORE_LAYER(10, C_u1same, A_SKIP2, S2_, A_U1T, S2_, TB, A_U1S, S2_, IB, RangeStoreS, 32, T2, T2)
-  CORE_LAYER_AREG(11, C_u2T, A_U1S, S2_, A_U2T, S1_, 16, T2 + 1, T1, wave & 3, wave >> 2, 4)  // 4 m-tiles x 4 blocks
+  CORE_LAYER_AREG(11, C_u2T, A_U1S, S2_, A_U2T, S1_, TB, RangeStoreV, 16, T2 + 1, T1, wave & 3, wave >> 2, 4)  // 4 m-tiles x 4 blocks
 #undef CORE_LAYER_AREG
   CORE_LAYER(12, C_u2same, A_SKIP1, S1_, A_U2T, S1_, TB, WU_U, S1_, IB, RangeStoreS, 16, T1, T1)
 #undef CORE_LAYER
