@@ -1182,23 +1182,43 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   CORE_LAYER(10, C_u1same, A_SKIP2, S2_, A_U1T, S2_, TB, A_U1S, S2_, IB, RangeStoreS, 32, T2, T2)
   CORE_LAYER_AREG(11, C_u2T, A_U1S, S2_, A_U2T, S1_, TB, RangeStoreV, 16, T2 + 1, T1, wave & 3, wave >> 2, 4)  // 4 m-tiles x 4 blocks
 #undef CORE_LAYER_AREG
-  CORE_LAYER(12, C_u2same, A_SKIP1, S1_, A_U2T, S1_, TB, WU_U, S1_, IB, RangeStoreS, 16, T1, T1)
+  // up2.same has eight items: waves 0-7 run it, waves 8-15 meanwhile fetch the eight skip rows of the up phase into
+  // registers (their LDS destination is still in use by this layer) and park them in LDS right after the barrier —
+  // the read-back of the skip tensor costs the up phase nothing (it was 8 k cycles of exposed memory latency).
+  constexpr int NSKQ = (8 * W0_Q + 511) / 512;
+  {
+    RangeStoreS<S1_, IB> st{{lds + WU_U, T1}};
+    zero_halo<16, S1_, T1, IB>(lds + WU_U, tid, NTH);
+    if (wave >= 8) {
+      float4 skq[NSKQ];
+      const float* src = a.skip0 + (long)win * a.ws_s;
+#pragma unroll
+      for (int k = 0; k < NSKQ; ++k) {
+        const int i = tid - 512 + k * 512, c = i / W0_Q, q = i - c * W0_Q;
+        const int p = 4 * q + HALO - 4;
+        skq[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < 8 * W0_Q && p + 3 < a.ls_s) skq[k] = *reinterpret_cast<const float4*>(src + (long)c * a.ls_s + p);
+      }
+      __syncthreads();  // up2.same done: its inputs give way to the level-0 rows (0-3 -> G0, 4-7 -> G1)
+#pragma unroll
+      for (int k = 0; k < NSKQ; ++k) {
+        const int i = tid - 512 + k * 512, c = i / W0_Q, q = i - c * W0_Q;
+        if (i < 8 * W0_Q)
+          *reinterpret_cast<float4*>(((c < 4) ? lds + WU_G0 + c * W0_S : lds + WU_G1 + (c - 4) * W0_S) + 4 * q) = skq[k];
+      }
+    } else {
+      conv_lds<C_u2same, S1_, IB, S1_, TB, PIPE, (C_u2same::NB < BDB_MAX_NB)>(lds + A_SKIP1, lds + A_U2T, a.c.af[12], a.c.bs[12], T1, st, wave, NWV, lane);
+      __syncthreads();
+    }
+    WIN_STAMP(stamp)
+    ++stamp;
+  }
 #undef CORE_LAYER
 
   // ================= level-0 up path: up3.convT -> cat(skip0, .) -> up3.same -> 1x1 -> softmax =================
   {
     float *G0 = lds + WU_G0, *G1 = lds + WU_G1, *U = lds + WU_U;
     WIN_STAMP(23)
-    {  // skip rows back from memory (L2): rows 0-3 -> G0, 4-7 -> G1
-      const float* src = a.skip0 + (long)win * a.ws_s;
-      for (int i = tid; i < 8 * W0_Q; i += NTH) {
-        const int c = i / W0_Q, q = i - c * W0_Q;
-        const int p = 4 * q + HALO - 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p + 3 < a.ls_s) v = *reinterpret_cast<const float4*>(src + (long)c * a.ls_s + p);
-        *reinterpret_cast<float4*>(((c < 4) ? G0 + c * W0_S : G1 + (c - 4) * W0_S) + 4 * q) = v;
-      }
-    }
     __syncthreads();
     WIN_STAMP(24)
     float aT[W_upT::CB * W_upT::TAPS], bT[4];  // A fragments of up3.convT (waves alternate over its two m-tiles)
