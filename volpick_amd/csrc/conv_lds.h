@@ -103,7 +103,10 @@ __device__ __forceinline__ void lds_epilogue(const f32x4 (&acc)[L::NB], const fl
 // in1/in2: LDS images (row strides S1/S2, logical 0 at column B1/B2).  afrag: packed A
 // fragments [MT][CB][TAPS][64] in global memory.  store(co, t, v) consumes every output
 // (t = P*col + p + OUT_OFF in the caller's local coordinates) and applies its own masks.
-template <class L, int S1, int B1, int S2, int B2, bool PIPE = true, bool BDB = true, class Store>
+// ADEEP: the A fragments are fetched THREE channel blocks ahead (four register buffers) and the B fragments come out of
+// LDS tap by tap — for the layers whose weights do not fit the L1: one block (TAPS * NB MFMAs = 200-1300 cycles) of
+// lead does not cover an L2 round trip under load, and every block then opens with a stall.
+template <class L, int S1, int B1, int S2, int B2, bool PIPE = true, bool BDB = true, bool ADEEP = false, class Store>
 __device__ __forceinline__ void conv_lds(const float* in1, const float* in2, const float* __restrict__ afrag,
                                          const float* __restrict__ bias, const int cols, Store store, const int wave,
                                          const int nwaves, const int lane) {
@@ -128,7 +131,38 @@ __device__ __forceinline__ void conv_lds(const float* in1, const float* in2, con
     // sched_barrier keeps hipcc from sinking the loads back down to their first use (it otherwise
     // emits load -> s_waitcnt 0 -> mfma for every K-step and the wave stalls on every L2 round trip).
     float a0[L::TAPS], a1[L::TAPS];
-    if constexpr (BDB) {
+    if constexpr (ADEEP) {
+      static_assert(!BRun<L, B1>::use, "deep A prefetch is written for the stride-1 layers");
+      float a[4][L::TAPS];
+      auto load_a = [&](float (&av)[L::TAPS], int cb) {
+#pragma unroll
+        for (int tap = 0; tap < L::TAPS; ++tap) av[tap] = ap[(cb * L::TAPS + tap) * 64];
+      };
+      auto mac = [&](const float (&av)[L::TAPS], int cb) {
+        const float* bp = (cb < L::CB1) ? bp1 + cb * 4 * S1 : bp2 + (cb - L::CB1) * 4 * S2;
+#pragma unroll
+        for (int tap = 0; tap < L::TAPS; ++tap) {
+          float bv[L::NB];
+#pragma unroll
+          for (int j = 0; j < L::NB; ++j) bv[j] = bp[j * 16 * L::SN + tap];
+#pragma unroll
+          for (int j = 0; j < L::NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap], bv[j], acc[j], 0, 0, 0);
+        }
+      };
+      load_a(a[0], 0);
+      if (L::CB > 1) load_a(a[1], 1);
+      if (L::CB > 2) load_a(a[2], 2);
+#pragma unroll 1
+      for (int cb = 0; cb < L::CB; cb += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (cb + u < L::CB) {
+            if (cb + u + 3 < L::CB) load_a(a[(u + 3) & 3], cb + u + 3);
+            mac(a[u], cb + u);
+          }
+        }
+      }
+    } else if constexpr (BDB) {
       float b0[L::TAPS][L::NB], b1[L::TAPS][L::NB];
       auto load_ab = [&](float (&av)[L::TAPS], float (&bv)[L::TAPS][L::NB], int cb) {
         const float* bp = (cb < L::CB1) ? bp1 + cb * 4 * S1 : bp2 + (cb - L::CB1) * 4 * S2;
