@@ -193,22 +193,45 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   // ---- epilogue 1: bias (+ReLU), D fragments -> LDS [COUT][OS] ----------------------
   {
     const float* bias = a.bias + (long)set * a.bias_set_stride;
+    if constexpr (C::P == 2) {
+      // two-phase layers: registers (0,1) and (2,3) of a lane are the two phases of one channel, i.e. two CONSECUTIVE
+      // staged samples — one 8-byte store each instead of four scalar stores two floats apart across the lanes
+      // (2-way bank conflicts; the staging of decoder.6 took half as long as its MFMAs)
+      static_assert(C::OS % 2 == 0, "8-byte aligned staging rows");
 #pragma unroll
-    for (int i = 0; i < C::MW; ++i) {
+      for (int i = 0; i < C::MW; ++i) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = (wm * C::MW + i) * 16 + 4 * g + r;
-        const int co = m / C::P, p = m - co * C::P;
-        const float b = bias[co];
+        for (int rr = 0; rr < 4; rr += 2) {
+          const int co = ((wm * C::MW + i) * 16 + 4 * g + rr) / 2;
+          const float b = bias[co];
 #pragma unroll
-        for (int j = 0; j < C::NW; ++j) {
-          float v = acc[i][j][r] + b;
-          if (C::RELU) v = fmaxf(v, 0.f);
-          if constexpr (C::EPI == EPI_HEAD) {  // outside the signal the head must see zero padding
-            const int tg = C::P * (col0 + (wn * C::NW + j) * 16 + n) + p;
-            if (tg < 0 || tg >= a.l_out) v = 0.f;
+          for (int j = 0; j < C::NW; ++j) {
+            const int col = (wn * C::NW + j) * 16 + n;
+            float v0 = acc[i][j][rr] + b, v1 = acc[i][j][rr + 1] + b;
+            if (C::RELU) v0 = fmaxf(v0, 0.f), v1 = fmaxf(v1, 0.f);
+            if constexpr (C::EPI == EPI_HEAD) {  // outside the signal the head must see zero padding
+              const int tg = 2 * (col0 + col);
+              if (tg < 0 || tg >= a.l_out) v0 = 0.f;
+              if (tg + 1 < 0 || tg + 1 >= a.l_out) v1 = 0.f;
+            }
+            *reinterpret_cast<float2*>(lds + co * C::OS + 2 * col) = make_float2(v0, v1);
           }
-          lds[co * C::OS + C::P * ((wn * C::NW + j) * 16 + n) + p] = v;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::MW; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = (wm * C::MW + i) * 16 + 4 * g + r;
+          const int co = m / C::P, p = m - co * C::P;
+          const float b = bias[co];
+#pragma unroll
+          for (int j = 0; j < C::NW; ++j) {
+            float v = acc[i][j][r] + b;
+            if (C::RELU) v = fmaxf(v, 0.f);
+            lds[co * C::OS + C::P * ((wn * C::NW + j) * 16 + n) + p] = v;
+          }
         }
       }
     }
