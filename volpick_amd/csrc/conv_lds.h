@@ -138,18 +138,38 @@ __device__ __forceinline__ void conv_lds(const float* in1, const float* in2, con
 #pragma unroll
         for (int tap = 0; tap < L::TAPS; ++tap) av[tap] = ap[(cb * L::TAPS + tap) * 64];
       };
-      auto mac = [&](const float (&av)[L::TAPS], int cb) {
-        const float* bp = (cb < L::CB1) ? bp1 + cb * 4 * S1 : bp2 + (cb - L::CB1) * 4 * S2;
+      // B fragments one K-step ahead, two register sets, order pinned: the reads of (cb, tap + 1) — or of (cb + 1, 0) —
+      // are issued before the MFMAs of (cb, tap).  Left to itself hipcc issues most reads of a block right in front of
+      // their MFMAs and waits out the LDS round trip six times per block (tools/micro/micro_u0same.hip: 14.2 -> 12.1 us
+      // per pass of up0.same).
+      static_assert(L::TAPS % 2 == 1, "the two B sets alternate per K-step: odd tap count keeps the parity per block pair");
+      float bA[L::NB], bB[L::NB];
+      auto bptr = [&](int cb) { return (cb < L::CB1) ? bp1 + cb * 4 * S1 : bp2 + (cb - L::CB1) * 4 * S2; };
+      auto load_b = [&](float (&bv)[L::NB], const float* bp, int tap) {
+#pragma unroll
+        for (int j = 0; j < L::NB; ++j) bv[j] = bp[j * 16 * L::SN + tap];
+      };
+      // one channel block; EVEN: its tap 0 sits in bA (blocks alternate because TAPS is odd)
+      auto mac = [&](const float (&av)[L::TAPS], int cb, auto even) {
+        const float* bp = bptr(cb);
+        const float* bn = bptr(cb + 1 < L::CB ? cb + 1 : cb);
 #pragma unroll
         for (int tap = 0; tap < L::TAPS; ++tap) {
-          float bv[L::NB];
+          const bool cur_is_a = ((tap & 1) == 0) == decltype(even)::value;
+          if (tap + 1 < L::TAPS) {
+            if (cur_is_a) load_b(bB, bp, tap + 1); else load_b(bA, bp, tap + 1);
+          } else {
+            if (cur_is_a) load_b(bB, bn, 0); else load_b(bA, bn, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < L::NB; ++j) bv[j] = bp[j * 16 * L::SN + tap];
-#pragma unroll
-          for (int j = 0; j < L::NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap], bv[j], acc[j], 0, 0, 0);
+          for (int j = 0; j < L::NB; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap], cur_is_a ? bA[j] : bB[j], acc[j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       };
       load_a(a[0], 0);
+      load_b(bA, bptr(0), 0);
       if (L::CB > 1) load_a(a[1], 1);
       if (L::CB > 2) load_a(a[2], 2);
 #pragma unroll 1
@@ -158,7 +178,11 @@ __device__ __forceinline__ void conv_lds(const float* in1, const float* in2, con
         for (int u = 0; u < 4; ++u) {
           if (cb + u < L::CB) {
             if (cb + u + 3 < L::CB) load_a(a[(u + 3) & 3], cb + u + 3);
-            mac(a[u], cb + u);
+            if ((u & 1) == 0) {
+              mac(a[u], cb + u, std::true_type{});
+            } else {
+              mac(a[u], cb + u, std::false_type{});
+            }
           }
         }
       }
