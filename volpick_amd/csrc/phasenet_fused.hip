@@ -949,7 +949,7 @@ struct SplitRowStore {  // up3.convT -> level-0 rows 0-3 (g0) and 4-7 (g1); zero
 // layers of the whole-network kernel that fetch their weights three channel blocks ahead (conv_lds ADEEP): the three
 // up-path "same" convs (measured: up0.same 31.6 -> 30.4 k cycles, up1.same 29.3 -> 27.5 k, +1.7 % end to end; the
 // down-path layers lose a little)
-#define ADEEP_LAYER(LAYER) (LAYER::CIN2 > 0 && LAYER::SN == 1 && LAYER::TAPS == 7 && LAYER::CB >= 8)
+#define ADEEP_LAYER(LAYER) (LAYER::SN == 1 && LAYER::TAPS == 7 && LAYER::NB >= 3)
 template <bool PIPE>
 __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   extern __shared__ float4 lds_raw[];
