@@ -323,10 +323,10 @@ __device__ __forceinline__ void conv_lds_areg(const float* in1, const float* in2
     for (int j = 0; j < L::NB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* bp1 = in1 + g * S1 + B1 + (colb + n) * L::SN + L::IN_OFF;
     const float* bp2 = in2 + g * S2 + B2 + (colb + n) * L::SN + L::IN_OFF;
+    if constexpr (BRun<L, B1>::use) {
 #pragma unroll
-    for (int cb = 0; cb < L::CB; ++cb) {
-      const float* bp = (cb < L::CB1) ? bp1 + cb * 4 * S1 : bp2 + (cb - L::CB1) * 4 * S2;
-      if constexpr (BRun<L, B1>::use) {
+      for (int cb = 0; cb < L::CB; ++cb) {
+        const float* bp = (cb < L::CB1) ? bp1 + cb * 4 * S1 : bp2 + (cb - L::CB1) * 4 * S2;
         BRun<L, B1> run[L::NB];
 #pragma unroll
         for (int j = 0; j < L::NB; ++j) run[j].load(bp + j * 16 * L::SN);
@@ -335,12 +335,29 @@ __device__ __forceinline__ void conv_lds_areg(const float* in1, const float* in2
 #pragma unroll
           for (int j = 0; j < L::NB; ++j)
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[cb * L::TAPS + tap], run[j].tap(tap), acc[j], 0, 0, 0);
-      } else {
+      }
+    } else {
+      // K-steps (cb, tap) flattened; the B fragments of step s + 1 are read before the MFMAs of step s (order pinned,
+      // two register sets) — see the deep path of conv_lds
+      constexpr int STEPS = L::CB * L::TAPS;
+      float bA[L::NB], bB[L::NB];
+      auto load_b = [&](float (&bv)[L::NB], int s) {
+        const int cb = s / L::TAPS, tap = s - cb * L::TAPS;
+        const float* bp = (cb < L::CB1) ? bp1 + cb * 4 * S1 : bp2 + (cb - L::CB1) * 4 * S2;
 #pragma unroll
-        for (int tap = 0; tap < L::TAPS; ++tap)
+        for (int j = 0; j < L::NB; ++j) bv[j] = bp[j * 16 * L::SN + tap];
+      };
+      load_b(bA, 0);
 #pragma unroll
-          for (int j = 0; j < L::NB; ++j)
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[cb * L::TAPS + tap], bp[j * 16 * L::SN + tap], acc[j], 0, 0, 0);
+      for (int s = 0; s < STEPS; ++s) {
+        if (s + 1 < STEPS) {
+          if (s & 1) load_b(bA, s + 1); else load_b(bB, s + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < L::NB; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[s], (s & 1) ? bB[j] : bA[j], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     lds_epilogue<L>(acc, biasv, mt, colb, g, n, store);
