@@ -142,14 +142,13 @@ __device__ __forceinline__ void conv_lds(const float* in1, const float* in2, con
       // are issued before the MFMAs of (cb, tap).  Left to itself hipcc issues most reads of a block right in front of
       // their MFMAs and waits out the LDS round trip six times per block (tools/micro/micro_u0same.hip: 14.2 -> 12.1 us
       // per pass of up0.same).
-      static_assert(L::TAPS % 2 == 1, "the two B sets alternate per K-step: odd tap count keeps the parity per block pair");
       float bA[L::NB], bB[L::NB];
       auto bptr = [&](int cb) { return (cb < L::CB1) ? bp1 + cb * 4 * S1 : bp2 + (cb - L::CB1) * 4 * S2; };
       auto load_b = [&](float (&bv)[L::NB], const float* bp, int tap) {
 #pragma unroll
         for (int j = 0; j < L::NB; ++j) bv[j] = bp[j * 16 * L::SN + tap];
       };
-      // one channel block; EVEN: its tap 0 sits in bA (blocks alternate because TAPS is odd)
+      // one channel block; EVEN: its tap 0 sits in bA (the sets alternate per K-step: block cb starts in set (cb * TAPS) & 1)
       auto mac = [&](const float (&av)[L::TAPS], int cb, auto even) {
         const float* bp = bptr(cb);
         const float* bn = bptr(cb + 1 < L::CB ? cb + 1 : cb);
@@ -178,7 +177,7 @@ __device__ __forceinline__ void conv_lds(const float* in1, const float* in2, con
         for (int u = 0; u < 4; ++u) {
           if (cb + u < L::CB) {
             if (cb + u + 3 < L::CB) load_a(a[(u + 3) & 3], cb + u + 3);
-            if ((u & 1) == 0) {
+            if (((u * L::TAPS) & 1) == 0) {
               mac(a[u], cb + u, std::true_type{});
             } else {
               mac(a[u], cb + u, std::false_type{});
