@@ -1,7 +1,7 @@
 # Round-1 artifacts of the whole-network PhaseNet kernel: full GPU suite, bench lines (inference both models, training), rocprofv3 kernel stats.
 set -x
 export TMPDIR=/tmp
-O=gpurun_out/r01h; mkdir -p $O
+O=gpurun_out/r01i; mkdir -p $O
 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $O/pytest_gpu.txt
 python bench.py --steps 200 --warmup 20 > $O/pn_bench.json 2>/dev/null
 python bench.py --model eqtransformer --steps 100 --warmup 10 > $O/eqt_bench.json 2>/dev/null
