@@ -1,16 +1,19 @@
-// PhaseNet forward as THREE fused launches instead of 18 (same arithmetic, same packed weights):
+// PhaseNet forward in ONE launch (default) or three (debug dumps, A/B timing) instead of 18 (same packed weights):
 //
-//   pn_down0_kernel  inc -> down0.same -> down0.down, time-tiled over 512 level-0 samples; the two
-//                    8-channel intermediates live in LDS, only the skip tensor (down0.same) and the
-//                    751-sample down0.down rows go back to memory.
+//   pn_window_kernel one 1024-thread workgroup per window: window cut + annotate_batch_pre, the level-0 down path,
+//                    the 13 core layers and the level-0 up path back to back out of one 158 KB LDS arena
+//                    (DESIGN.md 4a); only the skip tensor of level 0 makes a round trip through memory.
+//
+//   pn_down0v_kernel / pn_down0_kernel   inc -> down0.same -> down0.down, time-tiled (stride-1 convs on the VALU /
+//                    all MFMA); only the skip tensor (down0.same) and the 751-sample down0.down rows go to memory.
 //   pn_core_kernel   ONE workgroup per window: levels 1-4 down and up0..up2 (13 layers, 71 % of the
-//                    model's FLOPs) run back to back out of a 158 KB LDS arena; the only traffic is
-//                    the 24 KB input, the 48 KB output and the L2-resident weight stream.
-//   pn_up3_kernel    up3.convT -> concat(skip0) -> up3.same -> 1x1 conv + softmax, time-tiled.
+//                    model's FLOPs) run back to back out of a 158 KB LDS arena.
+//   pn_up3v_kernel / pn_up3p_kernel      up3.convT -> concat(skip0) -> up3.same -> 1x1 conv + softmax, time-tiled.
 //
-// Every layer is conv_lds<> (conv_lds.h): LDS image -> MFMA -> LDS image.  Coordinates inside a
-// tiled kernel are local to the tile; ImageStore writes explicit zeros where the global position
-// falls outside the signal so that the next layer sees the reference's zero padding.
+// The MFMA layers are conv_lds<> (conv_lds.h): LDS image -> MFMA -> LDS image; the 8-channel stride-1 layers of
+// level 0 are direct convolutions on the VALU (conv_valu.h).  Coordinates inside a tiled kernel are local to the
+// tile; ImageStore writes explicit zeros where the global position falls outside the signal so that the next layer
+// sees the reference's zero padding.
 #include "conv_lds.h"
 #include "conv_valu.h"
 #include "net.h"
