@@ -262,6 +262,85 @@ __device__ __forceinline__ void conv_lds(const float* in1, const float* in2, con
   }
 }
 
+// ---- weights as 16-byte loads ---------------------------------------------------------------------------------------
+// Every CU pulls the same weights out of L2.  With one dword per lane per fragment (afrag layout) the weight-heavy layers
+// of the PhaseNet core get 16 B/clk/CU out of that path; the same bytes as one dwordx4 per lane stream at 52-56 B/clk/CU
+// (tools/micro/micro_stream.hip: 256 CUs reading one 606 KB buffer).  afrag4 is the same A operand with the K-steps
+// s = cb * TAPS + tap grouped in fours: [MT][CB * TAPS / 4][64 lanes][4].  A "superblock" is four channel blocks
+// (4 * TAPS K-steps = TAPS loads per lane); the loads of superblock sb + 1 are issued before the MFMAs of sb, and the B
+// fragments run one K-step ahead in two register sets under pinned order (as the deep path of conv_lds).
+template <class L, int S1, int B1, int S2, int B2, class Store>
+__device__ __forceinline__ void conv_lds_q4(const float* in1, const float* in2, const float* __restrict__ afrag4,
+                                            const float* __restrict__ bias, const int cols, Store store, const int wave,
+                                            const int nwaves, const int lane) {
+  static_assert(L::CB % 4 == 0 && L::CB1 % 4 == 0, "superblocks of four channel blocks");
+  constexpr int NQ = L::TAPS, SB_STEPS = 4 * L::TAPS, NSB = L::CB / 4;
+  const int NT = (cols + 15) >> 4;
+  const int NBLK = (NT + L::NB - 1) / L::NB;
+  const int items = L::MT * NBLK;
+  const int g = lane >> 4, n = lane & 15;
+  for (int item = wave; item < items; item += nwaves) {
+    const int mt = item % L::MT, nblk = item / L::MT;
+    const int colb = nblk * L::NB * 16;
+    f32x4 acc[L::NB];
+#pragma unroll
+    for (int j = 0; j < L::NB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4* ap = reinterpret_cast<const f32x4*>(afrag4) + (long)mt * (L::CB * L::TAPS / 4) * 64 + lane;
+    float biasv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) biasv[r] = bias[mt * (16 / L::P) + (4 * g) / L::P + r / L::P];
+    const float* bp1 = in1 + g * S1 + B1 + (colb + n) * L::SN + L::IN_OFF;
+    const float* bp2 = in2 + g * S2 + B2 + (colb + n) * L::SN + L::IN_OFF;
+    auto bptr = [&](int cb) { return (cb < L::CB1) ? bp1 + cb * 4 * S1 : bp2 + (cb - L::CB1) * 4 * S2; };
+    auto load_q = [&](f32x4 (&q)[NQ], int sb) {
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) q[k] = ap[(sb * NQ + k) * 64];
+    };
+    auto load_b = [&](float (&bv)[L::NB], const float* bp, int tap) {
+#pragma unroll
+      for (int j = 0; j < L::NB; ++j) bv[j] = bp[j * 16 * L::SN + tap];
+    };
+    float bA[L::NB], bB[L::NB];
+    auto superblock = [&](const f32x4 (&q)[NQ], int sb) {
+      const float* b0 = bptr(4 * sb);                         // the four channel blocks of a superblock lie in one image
+      const float* bnext = bptr(4 * (sb + 1 < NSB ? sb + 1 : sb));
+      constexpr int CBS = 4 * ((L::CB1 > 0) ? S1 : S2);       // row step between channel blocks (S1 == S2 asserted below)
+#pragma unroll
+      for (int s = 0; s < SB_STEPS; ++s) {
+        const int cbo = s / L::TAPS, tap = s - cbo * L::TAPS;
+        if (s + 1 < SB_STEPS) {
+          const int cbo1 = (s + 1) / L::TAPS, tap1 = (s + 1) - cbo1 * L::TAPS;
+          if (s & 1) load_b(bA, b0 + cbo1 * CBS, tap1); else load_b(bB, b0 + cbo1 * CBS, tap1);
+        } else {
+          if (s & 1) load_b(bA, bnext, 0); else load_b(bB, bnext, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < L::NB; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(q[s >> 2][s & 3], (s & 1) ? bB[j] : bA[j], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        (void)cbo;
+        (void)tap;
+      }
+    };
+    static_assert(L::CIN2 == 0 || S1 == S2, "both images share the row stride");
+    static_assert(SB_STEPS % 2 == 0, "the B sets alternate per K-step");
+    f32x4 qa[NQ], qb[NQ];
+    load_q(qa, 0);
+    load_b(bA, bptr(0), 0);
+#pragma unroll 1
+    for (int sb = 0; sb < NSB; sb += 2) {
+      if (sb + 1 < NSB) load_q(qb, sb + 1);
+      superblock(qa, sb);
+      if (sb + 1 < NSB) {
+        if (sb + 2 < NSB) load_q(qa, sb + 2);
+        superblock(qb, sb + 1);
+      }
+    }
+    lds_epilogue<L>(acc, biasv, mt, colb, g, n, store);
+  }
+}
+
 // Store functor: LDS image with a valid range [lo, hi) in the caller's local coordinates and a
 // "signal" range [sig_lo, sig_hi): positions inside the image but outside the signal are written
 // as zero (they are the next layer's zero padding, not activations of zero-padded input).

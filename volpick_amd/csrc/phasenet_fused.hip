@@ -920,6 +920,7 @@ using W_upT = LdsLayer<16, 0, 8, 4, 2, 1, -1, -2, 3, 1>;    // out sample 4m + p
 
 struct WindowArgs {
   CoreArgs c;       // d0 / u2s unused (they live in LDS)
+  const float* af4[13];  // weights of the core layers regrouped for 16-byte loads (conv_lds_q4), null where unused
   const float* x;   // [B][3][ls] normalised input
   int ls_x;
   long ws_x;
@@ -953,6 +954,9 @@ struct SplitRowStore {  // up3.convT -> level-0 rows 0-3 (g0) and 4-7 (g1); zero
 // up-path "same" convs (measured: up0.same 31.6 -> 30.4 k cycles, up1.same 29.3 -> 27.5 k, +1.7 % end to end; the
 // down-path layers lose a little)
 #define ADEEP_LAYER(LAYER) (LAYER::SN == 1 && LAYER::TAPS == 7 && LAYER::NB >= 3)
+// layers of the whole-network kernel whose weights come as 16-byte loads (conv_lds_q4): the weight-heavy ones
+#define Q4_LAYER(LAYER) (LAYER::CB % 4 == 0 && LAYER::CB >= 8 && LAYER::NB <= 3 && LAYER::P * LAYER::COUT >= 64)
+constexpr bool q4_layer_index(int i) { return i == 4 || i == 5 || i == 6 || i == 7 || i == 8; }  // d3same d3down d4same u0T u0same
 template <bool PIPE>
 __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   extern __shared__ float4 lds_raw[];
@@ -1157,7 +1161,11 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   {                                                                                                                \
     STORE<SO, OB> st{{lds + (OUT), (LOUT)}};                                                                      \
     zero_halo<CO, SO, LOUT, OB>(lds + (OUT), tid, NTH);                                                          \
-    conv_lds<LAYER, SI1, IB, SI2, B2, PIPE, (LAYER::NB < BDB_MAX_NB), ADEEP_LAYER(LAYER)>(lds + (IN1), lds + (IN2), a.c.af[IDX], a.c.bs[IDX], (COLS), st, wave, NWV, lane); \
+    if constexpr (Q4_LAYER(LAYER)) {                                                                              \
+      conv_lds_q4<LAYER, SI1, IB, SI2, B2>(lds + (IN1), lds + (IN2), a.af4[IDX], a.c.bs[IDX], (COLS), st, wave, NWV, lane); \
+    } else {                                                                                                       \
+      conv_lds<LAYER, SI1, IB, SI2, B2, PIPE, (LAYER::NB < BDB_MAX_NB), ADEEP_LAYER(LAYER)>(lds + (IN1), lds + (IN2), a.c.af[IDX], a.c.bs[IDX], (COLS), st, wave, NWV, lane); \
+    }                                                                                                              \
     __syncthreads();                                                                                               \
     WIN_STAMP(stamp)                                                                                               \
     ++stamp;                                                                                                       \
@@ -1517,8 +1525,21 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     HostBlob* e0 = &net.convs[17]->e0;
     HostBlob* e1 = &net.convs[17]->e1;
     HostBlob* clk = debug_clock ? net.debug_clock : nullptr;
+    HostBlob* q4[13] = {};
+    for (int i = 0; i < 13; ++i) {
+      if (!q4_layer_index(i)) continue;
+      const ConvLayer& L = *net.convs[3 + i];
+      const int steps = L.g.cinp() / 4 * L.g.taps, mt_n = L.g.M() / 16;  // afrag: [mt][step][64] -> [mt][step / 4][64][4]
+      std::vector<float> v(L.afrag.h.size());
+      for (int mt = 0; mt < mt_n; ++mt)
+        for (int st_ = 0; st_ < steps; ++st_)
+          for (int l = 0; l < 64; ++l)
+            v[(((size_t)mt * (steps / 4) + st_ / 4) * 64 + l) * 4 + (st_ & 3)] = L.afrag.h[((size_t)mt * steps + st_) * 64 + l];
+      q4[i] = net.add_blob(std::move(v));
+    }
     st.run = [=](Net& n, int B, hipStream_t s) -> int {
       WindowArgs a{};
+      for (int i = 0; i < 13; ++i) a.af4[i] = q4[i] ? q4[i]->d : nullptr;
       const Tensor &tx = n.tensors[x], &ts = n.tensors[skip0];
       for (int i = 0; i < 13; ++i) {
         a.c.af[i] = n.convs[3 + i]->afrag.d;
