@@ -955,8 +955,9 @@ struct SplitRowStore {  // up3.convT -> level-0 rows 0-3 (g0) and 4-7 (g1); zero
 // down-path layers lose a little)
 #define ADEEP_LAYER(LAYER) (LAYER::SN == 1 && LAYER::TAPS == 7 && LAYER::NB >= 3)
 // layers of the whole-network kernel whose weights come as 16-byte loads (conv_lds_q4): the weight-heavy ones
-#define Q4_LAYER(LAYER) (LAYER::CB % 4 == 0 && LAYER::CB >= 8 && LAYER::NB <= 3 && LAYER::P * LAYER::COUT >= 64)
-constexpr bool q4_layer_index(int i) { return i == 4 || i == 5 || i == 6 || i == 7 || i == 8; }  // d3same d3down d4same u0T u0same
+// (the six-tile layers keep their dword path: 14 float4 of weights on top of 24 accumulators spill at 128 registers)
+#define Q4_LAYER(LAYER) (LAYER::CB % 4 == 0 && LAYER::NB <= 3)
+constexpr bool q4_layer_index(int i) { return i >= 1 && i <= 8; }  // d1down .. up0.same
 template <bool PIPE>
 __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   extern __shared__ float4 lds_raw[];
