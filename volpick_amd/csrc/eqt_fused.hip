@@ -27,7 +27,7 @@ struct ResArgs {
   float* out;         // [B][64][ls]
   int ls_out;
   long ws_out;
-  const float* af1[7];
+  const float* af1[7];  // af1 / af2: A operands regrouped for 16-byte loads (regroup_afrag4)
   const float* bs1[7];
   const float* af2[7];
   const float* bs2[7];
@@ -60,9 +60,6 @@ struct ResStore {  // conv2 epilogue: x += v (in place); act = relu(s*x + b) for
   }
   __device__ __forceinline__ bool all_valid(int t0, int t1) const { return t0 >= 0 && t1 < RT; }
 };
-
-// deep weight prefetch + pinned B lead of conv_lds (a win on the seven-tap PhaseNet layers)
-constexpr bool RES_DEEP = false;  // measured 51.6 vs 50.0 us with it: three-tap blocks are too short for the pinned order to pay
 
 __global__ __launch_bounds__(256) void eqt_res_kernel(const ResArgs a) {
   __shared__ __attribute__((aligned(16))) float X[64 * RS];
@@ -102,13 +99,13 @@ __global__ __launch_bounds__(256) void eqt_res_kernel(const ResArgs a) {
     MidStore ms{MID};
     ResStore rs{X, ACT, a.s_next[i], a.b_next[i], i == 6};
     if (kers[i] == 3) {
-      conv_lds<R_k3, RS, RB, RS, RB, false, true, RES_DEEP>(ACT, ACT, a.af1[i], a.bs1[i], RT, ms, wave, 4, lane);
+      conv_lds_q4<R_k3, RS, RB, RS, RB>(ACT, ACT, a.af1[i], a.bs1[i], RT, ms, wave, 4, lane);
       __syncthreads();
-      conv_lds<R_k3n, RS, RB, RS, RB, false, true, RES_DEEP>(MID, MID, a.af2[i], a.bs2[i], RT, rs, wave, 4, lane);
+      conv_lds_q4<R_k3n, RS, RB, RS, RB>(MID, MID, a.af2[i], a.bs2[i], RT, rs, wave, 4, lane);
     } else {
-      conv_lds<R_k2, RS, RB, RS, RB, false, true, RES_DEEP>(ACT, ACT, a.af1[i], a.bs1[i], RT, ms, wave, 4, lane);
+      conv_lds_q4<R_k2, RS, RB, RS, RB>(ACT, ACT, a.af1[i], a.bs1[i], RT, ms, wave, 4, lane);
       __syncthreads();
-      conv_lds<R_k2n, RS, RB, RS, RB, false, true, RES_DEEP>(MID, MID, a.af2[i], a.bs2[i], RT, rs, wave, 4, lane);
+      conv_lds_q4<R_k2n, RS, RB, RS, RB>(MID, MID, a.af2[i], a.bs2[i], RT, rs, wave, 4, lane);
     }
     __syncthreads();
   }
@@ -143,6 +140,12 @@ int plan_eqt_fuse_res(Net& net) {
       return VP_ERR_INVALID;
     }
   const int x0 = c2[0]->res, act0 = c1[0]->src1, out = c2[6]->dst;
+  // every workgroup streams the 690 KB of weights out of L2: as 16-byte loads per lane (conv_lds_q4, micro_stream.hip)
+  std::vector<HostBlob*> q1(7), q2(7);
+  for (int i = 0; i < 7; ++i) {
+    q1[i] = net.add_blob(regroup_afrag4(*c1[i]));
+    q2[i] = net.add_blob(regroup_afrag4(*c2[i]));
+  }
   Step st;
   st.name = "fused.rescnn (7 residual blocks)";
   st.flops_per_window = 0;
@@ -160,9 +163,9 @@ int plan_eqt_fuse_res(Net& net) {
     a.ls_out = to.ls;
     a.ws_out = (long)to.win_stride();
     for (int i = 0; i < 7; ++i) {
-      a.af1[i] = c1[i]->afrag.d;
+      a.af1[i] = q1[i]->d;
       a.bs1[i] = c1[i]->bias.d;
-      a.af2[i] = c2[i]->afrag.d;
+      a.af2[i] = q2[i]->d;
       a.bs2[i] = c2[i]->bias.d;
       a.s_next[i] = c2[i]->e1.d;
       a.b_next[i] = c2[i]->e2.d;

@@ -101,6 +101,10 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags);  // swa
 int plan_eqt(Net& net, const ParamView& pv);
 int plan_eqt_fuse_res(Net& net);  // swaps the 14 ResCNN conv steps for one fused launch
 
+// The A operand of a conv layer regrouped for 16-byte loads (conv_lds_q4): [mt][step][64] -> [mt][step / 4][64][4],
+// step = channel block * taps + tap; needs (channel blocks * taps) % 4 == 0.
+std::vector<float> regroup_afrag4(const ConvLayer& L);
+
 // BatchNorm (eval) folded into the preceding conv: scale = gamma / sqrt(var + eps),
 // shift = beta - mean * scale (+ conv bias * scale).
 void bn_fold(const ParamView& pv, const std::string& bn, int C, float eps, const float* conv_bias,

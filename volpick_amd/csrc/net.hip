@@ -52,6 +52,16 @@ const float* ParamView::get(const std::string& name, const ParamDesc** d) const 
   return it->second.first;
 }
 
+std::vector<float> regroup_afrag4(const ConvLayer& L) {
+  const int steps = L.g.cinp() / 4 * L.g.taps, mt_n = L.g.M() / 16 * L.n_sets;
+  std::vector<float> v(L.afrag.h.size());
+  for (int mt = 0; mt < mt_n; ++mt)
+    for (int st = 0; st < steps; ++st)
+      for (int l = 0; l < 64; ++l)
+        v[(((size_t)mt * (steps / 4) + st / 4) * 64 + l) * 4 + (st & 3)] = L.afrag.h[((size_t)mt * steps + st) * 64 + l];
+  return v;
+}
+
 void bn_fold(const ParamView& pv, const std::string& bn, int C, float eps, const float* conv_bias,
              std::vector<float>* scale, std::vector<float>* shift) {
   const float* w = pv.get(bn + ".weight");

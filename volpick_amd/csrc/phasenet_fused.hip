@@ -1529,13 +1529,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     HostBlob* q4[13] = {};
     for (int i = 0; i < 13; ++i) {
       if (!q4_layer_index(i)) continue;
-      const ConvLayer& L = *net.convs[3 + i];
-      const int steps = L.g.cinp() / 4 * L.g.taps, mt_n = L.g.M() / 16;  // afrag: [mt][step][64] -> [mt][step / 4][64][4]
-      std::vector<float> v(L.afrag.h.size());
-      for (int mt = 0; mt < mt_n; ++mt)
-        for (int st_ = 0; st_ < steps; ++st_)
-          for (int l = 0; l < 64; ++l)
-            v[(((size_t)mt * (steps / 4) + st_ / 4) * 64 + l) * 4 + (st_ & 3)] = L.afrag.h[((size_t)mt * steps + st_) * 64 + l];
+      std::vector<float> v = regroup_afrag4(*net.convs[3 + i]);
       q4[i] = net.add_blob(std::move(v));
     }
     st.run = [=](Net& n, int B, hipStream_t s) -> int {
