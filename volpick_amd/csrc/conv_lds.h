@@ -377,6 +377,18 @@ __device__ __forceinline__ void load_areg(const float* __restrict__ afrag, const
 #pragma unroll
   for (int k = 0; k < L::CB * L::TAPS; ++k) areg[k] = ap[k * 64];
 }
+// the same from the regrouped operand (regroup_afrag4): one 16-byte load per four K-steps
+template <class L>
+__device__ __forceinline__ void load_areg4(const float* __restrict__ afrag4, const int mt, const int lane,
+                                           float (&areg)[L::CB * L::TAPS]) {
+  static_assert((L::CB * L::TAPS) % 4 == 0, "K-steps in groups of four");
+  const f32x4* ap = reinterpret_cast<const f32x4*>(afrag4) + (long)mt * (L::CB * L::TAPS / 4) * 64 + lane;
+#pragma unroll
+  for (int k = 0; k < L::CB * L::TAPS / 4; ++k) {
+    const f32x4 q = ap[k * 64];
+    areg[4 * k] = q.x, areg[4 * k + 1] = q.y, areg[4 * k + 2] = q.z, areg[4 * k + 3] = q.w;
+  }
+}
 template <class L>
 __device__ __forceinline__ void load_biasreg(const float* __restrict__ bias, const int mt, const int lane,
                                              float (&biasv)[4]) {

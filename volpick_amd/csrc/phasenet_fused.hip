@@ -957,7 +957,7 @@ struct SplitRowStore {  // up3.convT -> level-0 rows 0-3 (g0) and 4-7 (g1); zero
 // layers of the whole-network kernel whose weights come as 16-byte loads (conv_lds_q4): the weight-heavy ones
 // (the six-tile layers keep their dword path: 14 float4 of weights on top of 24 accumulators spill at 128 registers)
 #define Q4_LAYER(LAYER) (LAYER::CB % 4 == 0 && LAYER::NB <= 3)
-constexpr bool q4_layer_index(int i) { return i >= 1 && i <= 8; }  // d1down .. up0.same
+constexpr bool q4_layer_index(int i) { return (i >= 1 && i <= 9) || i == 11; }  // d1down .. up0.same, and the two register-resident two-tap layers
 template <bool PIPE>
 __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   extern __shared__ float4 lds_raw[];
@@ -1177,7 +1177,7 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
     zero_halo<CO, SO, LOUT, OB>(lds + (OUT), tid, NTH);                                                          \
     if ((WMT) < LAYER::MT && (WFIRST) < ((((COLS) + 15) >> 4) + LAYER::NB - 1) / LAYER::NB) {                    \
       float ar[LAYER::CB * LAYER::TAPS], br[4];                                                                    \
-      load_areg<LAYER>(a.c.af[IDX], (WMT), lane, ar);                                                              \
+      load_areg4<LAYER>(a.af4[IDX], (WMT), lane, ar);                                                              \
       load_biasreg<LAYER>(a.c.bs[IDX], (WMT), lane, br);                                                           \
       conv_lds_areg<LAYER, SI1, IB, SI1, IB>(lds + (IN1), lds + (IN1), ar, br, (WMT), (COLS), st, (WFIRST), (WSTEP), lane); \
     }                                                                                                              \
