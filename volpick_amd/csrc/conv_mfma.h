@@ -99,7 +99,12 @@ struct ConvCfg {
   static constexpr int OW = P * TN;  // staged output columns per tile
   static constexpr int OS = OW + 4;
   static constexpr int LDS_IN = CINP * S, LDS_OUT = COUT * OS;
-  static constexpr int LDS_FLOATS = LDS_IN > LDS_OUT ? LDS_IN : LDS_OUT;
+  // Plain two-phase layers store straight from the accumulators: registers (0,1) / (2,3) of a lane are two consecutive
+  // samples of one channel, 16 lanes x 8 bytes = one full 128-byte line per channel row and store.  No staging tile
+  // (it was the larger half of the LDS footprint of the EQT decoders: 50 -> 30 KB, 3 -> 5 workgroups per CU), no
+  // staging / store phases and one barrier less per tile.
+  static constexpr bool DIRECT = (EPI == EPI_STORE) && (P == 2) && (OUT_OFF % 2 == 0);
+  static constexpr int LDS_FLOATS = DIRECT ? LDS_IN : (LDS_IN > LDS_OUT ? LDS_IN : LDS_OUT);
   static_assert(WAVES_M * WAVES_N == 4, "256-thread workgroups");
   static_assert(M % (16 * WAVES_M) == 0, "M must tile into 16-row MFMA tiles per wave");
   static_assert(S >= 4 * W4 && S % 32 == 16, "LDS stride");
@@ -186,6 +191,34 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         for (int j = 0; j < C::NW; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
+  }
+  if constexpr (C::DIRECT) {
+    const float* bias = a.bias + (long)set * a.bias_set_stride;
+    float* d = a.dst + (long)win * a.wsd + a.dst_halo;
+#pragma unroll
+    for (int i = 0; i < C::MW; ++i) {
+#pragma unroll
+      for (int rr = 0; rr < 4; rr += 2) {
+        const int co = ((wm * C::MW + i) * 16 + 4 * g + rr) / 2;
+        const float b = bias[co];
+        float* row = d + (long)co * a.lsd;
+#pragma unroll
+        for (int j = 0; j < C::NW; ++j) {
+          const int t = 2 * (col0 + (wn * C::NW + j) * 16 + n) + C::OUT_OFF;
+          float v0 = acc[i][j][rr] + b, v1 = acc[i][j][rr + 1] + b;
+          if (C::RELU) v0 = fmaxf(v0, 0.f), v1 = fmaxf(v1, 0.f);
+          if (t >= 0 && t + 1 < a.l_out) {
+            *reinterpret_cast<float2*>(row + t) = make_float2(v0, v1);
+          } else if (t >= 0 && t < a.l_out) {
+            row[t] = v0;  // odd length: the right margin stays zero
+          }
+        }
+      }
+    }
+    CONV_STAMP()
+    CONV_STAMP()
+    CONV_STAMP()
+    return;
   }
   __syncthreads();  // all B reads done; the LDS image is reused as the output staging tile
   CONV_STAMP()
