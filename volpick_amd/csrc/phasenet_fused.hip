@@ -980,6 +980,15 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
 #undef CORE_WARM
     if (sink == 1.2345678e-30f) a.y[0] = sink;  // never true: keeps the loads alive
   }
+  // Waves without VALU work pull the weights of the NEXT VALU phase through the scalar cache (one dword per 64-byte
+  // line): otherwise the twelve conv waves, in lock step, miss on every line together and each trip of the conv waits
+  // out an L2 round trip (up3.same took 13.6 k cycles for its skip half and 8.5 k for the identical second half).
+#define WIN_WARM_SCALAR(PTR, N_FLOATS)                                                      \
+  {                                                                                         \
+    float warm_ = 0.f;                                                                      \
+    for (int l_ = 0; l_ < (N_FLOATS); l_ += 16) warm_ += as_scalars(reinterpret_cast<const float*>(PTR))[l_]; \
+    asm volatile("" ::"s"(warm_));                                                          \
+  }
   const int t0 = 4 * tid;                    // this lane's level-0 samples t0 .. t0 + 3 (VALU phases)
   const bool vconv = wave < W_WAVES;         // wave-uniform: runs the VALU convs
   const bool vstore = tid < W0_Q;            // lanes whose float4 lies inside an image row (751..755 store the zero margin)
@@ -1111,6 +1120,8 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
           *reinterpret_cast<f32x4*>(H + (2 * c + 1) * W0_S + 4 + t0) = hi;
         }
       }
+    } else {
+      WIN_WARM_SCALAR(a.w_same, 8 * 7 * 8)
     }
     __syncthreads();
     WIN_STAMP(20)
@@ -1215,6 +1226,7 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
         skq[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < 8 * W0_Q && p + 3 < a.ls_s) skq[k] = *reinterpret_cast<const float4*>(src + (long)c * a.ls_s + p);
       }
+      WIN_WARM_SCALAR(a.w_up, 16 * 7 * 8)
       __syncthreads();  // up2.same done: its inputs give way to the level-0 rows (0-3 -> G0, 4-7 -> G1)
 #pragma unroll
       for (int k = 0; k < NSKQ; ++k) {
@@ -1297,6 +1309,7 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   }
   if (clk && tid == 0) clk[(long)win * 32 + 17] = wall_clock64();
 #undef WIN_STAMP
+#undef WIN_WARM_SCALAR
 }
 
 int tensor_id(const Net& net, const std::string& name) {
