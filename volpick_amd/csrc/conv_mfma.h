@@ -303,8 +303,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       const int co = idx / (C::OW / 2), q = idx - co * (C::OW / 2);
       const int t = t0 + 2 * q;
       if (t < a.l_out) {
-        float v = lds[co * C::OS + 2 * q];
-        if (t + 1 < a.l_out) v = fmaxf(v, lds[co * C::OS + 2 * q + 1]);
+        const float2 pr = *reinterpret_cast<const float2*>(lds + co * C::OS + 2 * q);  // one 8-byte read: scalar reads two
+        float v = pr.x;                                                                 // floats apart collide 2-way
+        if (t + 1 < a.l_out) v = fmaxf(v, pr.y);
         d[(long)co * a.lsd + (t >> 1)] = v;
         if constexpr (C::EPI == EPI_POOL2_DUAL) {
           const float s = a.e1[co], b = a.e2[co];
