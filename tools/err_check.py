@@ -1,0 +1,18 @@
+"""Max / 99.99th percentile / mean absolute difference between each PhaseNet plan and the torch-CPU oracle on 512 synthetic
+windows (tolerance of the path: 1e-4 on probabilities).  Run on the GPU box: python tools/err_check.py"""
+import sys, numpy as np, torch
+sys.path.insert(0, "/root/repo")
+from oracle import pipeline as OP
+from oracle.models import load_pretrained
+from volpick_amd import PhaseNet
+from volpick_amd.synthetic import synthetic_windows
+orc = load_pretrained("phasenet")
+x = synthetic_windows(512, 3001, seed=4242)
+xn = OP.batch_pre(orc, torch.from_numpy(x))
+with torch.no_grad():
+    want = orc(xn).double().numpy()
+for name, flags in [("one launch (default)", (0,)), ("three launches, VALU level 0", (0, 0, 0, 0, 0, 2)), ("three launches, all MFMA", (0, 0, 0, 0, 0, 1)), ("layer plan", (1, 0))]:
+    m = PhaseNet.from_pretrained("volpick"); m._plan_flags = flags; m.cuda()
+    got = m(xn).double().numpy()
+    e = np.abs(got - want)
+    print(f"{name:32s} max|err| {e.max():.2e}  99.99th pct {np.quantile(e, 0.9999):.2e}  mean {e.mean():.2e}")
