@@ -183,3 +183,30 @@ def test_short_and_edge_inputs(model):
     assert (nw, fv, lv) == (1, 0, 3000)
     with pytest.raises(ValueError):
         model.annotate(st, overlap=3001)
+
+
+def test_classify_resamples_other_rates(model):
+    """A 200 Hz and a 50 Hz copy of a 100 Hz stream go through SeisBench's resampling rule on the way in; the picks
+    land on the same arrivals (the signal content sits well below 25 Hz)."""
+    from volpick_amd import Stream, Trace, UTCDateTime
+    from volpick_amd.resample import resample_fourier
+
+    data, p_on, s_on = synthetic_stream_array(60_000, seed=1001, n_events=6)
+    t0 = UTCDateTime("2020-01-01T00:00:00")
+
+    def stream(arr, rate):
+        return Stream([Trace(arr[i], dict(network="XX", station="SYN", location="", channel=f"HH{c}", starttime=t0,
+                                          sampling_rate=rate)) for i, c in enumerate("ZNE")])
+
+    ref = model.classify(stream(data, 100.0)).picks
+    assert len(ref) >= 6
+    fast = np.stack([resample_fourier(data[i].astype(np.float64), 100.0, 200.0, window=None) for i in range(3)])
+    got = model.classify(stream(fast, 200.0)).picks  # 200 -> 100 Hz: low-pass + decimation
+    assert len(got) == len(ref)
+    for a, b in zip(sorted(ref, key=lambda p: p.peak_time), sorted(got, key=lambda p: p.peak_time)):
+        assert a.phase == b.phase and abs(a.peak_time - b.peak_time) <= 0.05 and abs(a.peak_value - b.peak_value) < 0.1
+    slow = data[:, ::2]  # 50 Hz (aliased a little: the synthetic bursts reach 8 Hz, the noise is white)
+    got50 = model.classify(stream(slow, 50.0)).picks  # 50 -> 100 Hz: Fourier method
+    p_ref = sorted(p.peak_time - t0 for p in ref if p.phase == "P")
+    p_got = sorted(p.peak_time - t0 for p in got50 if p.phase == "P")
+    assert len(p_got) >= len(p_ref) - 1 and all(min(abs(t - r) for r in p_ref) < 0.3 for t in p_got)

@@ -99,9 +99,12 @@ def test_stream_types_and_grouping():
     with pytest.warns(UserWarning):
         blocks = list(_group_stream(st2, "ZNE", 100.0, True, 3001))
     assert len(blocks) == 1 and blocks[0]["data"].shape == (3, 3200)
-    with pytest.raises(ValueError):
-        list(_group_stream(va.Stream([va.Trace(np.zeros(10), dict(channel="HHZ", sampling_rate=50.0))]), "ZNE", 100.0,
-                           True, 3001))
+    # a trace at another rate is resampled on a copy (SeisBench annotate() semantics), never in place with copy=True
+    slow = va.Trace(np.zeros(2000), dict(channel="HHZ", sampling_rate=50.0))
+    blocks = list(_group_stream(va.Stream([slow]), "ZNE", 100.0, True, 3001))
+    assert len(blocks) == 1 and blocks[0]["data"].shape == (3, 4000) and slow.stats.sampling_rate == 50.0
+    list(_group_stream(va.Stream([slow]), "ZNE", 100.0, False, 3001))
+    assert slow.stats.sampling_rate == 100.0 and len(slow.data) == 4000  # copy=False: in place, as upstream
     merged = va.Stream([mk("HHZ", t0, 100), mk("HHZ", t0 + 1.0, 100)]).merge(-1)
     assert len(merged) == 1 and len(merged[0].data) == 200
 
@@ -199,3 +202,40 @@ def test_training_host_pieces_without_gpu():
     assert all(b >= a for a, b in zip(lrs[1:500], lrs[2:501]))
     with pytest.raises(_lib.VolpickHipError):
         PhaseNetTrainer(va.PhaseNet.from_pretrained("volpick"), max_batch=4)
+
+
+def test_resampling_rule_and_numerics():
+    """volpick_amd/resample.py restates SeisBench's rule (integer ratio: zero-phase low-pass + decimation, otherwise
+    ObsPy's Fourier resampling with a Hann window).  Unpinned like the rest of the stream handling; the checks here are
+    its defining properties on band-limited signals."""
+    from volpick_amd.resample import lowpass_zerophase, resample_array, resample_fourier
+
+    rng = np.random.default_rng(5)
+    t200 = np.arange(24_000) / 200.0
+    sig = lambda t: np.sin(2 * np.pi * 3.0 * t + 0.3) + 0.5 * np.sin(2 * np.pi * 11.0 * t)  # well below 50 Hz
+    # 200 -> 100 Hz: low-pass at 50 Hz (passes 3 / 11 Hz untouched, zero phase), every second sample
+    y = resample_array(sig(t200), 200.0, 100.0)
+    assert len(y) == 12_000
+    assert np.abs(y[500:-500] - sig(np.arange(12_000) / 100.0)[500:-500]).max() < 2e-3
+    # the filter is zero-phase: a symmetric pulse stays symmetric
+    pulse = np.exp(-0.5 * ((np.arange(4001) - 2000) / 40.0) ** 2)
+    lp = lowpass_zerophase(pulse, 25.0, 200.0)
+    assert np.abs(lp - lp[::-1]).max() < 1e-9
+    # 50 -> 100 Hz and 40 -> 100 Hz go through ObsPy's Fourier method: length int(npts / factor); its default Hann window
+    # centred on DC scales a component at f by 0.5 (1 + cos(2 pi f / rate_in)) — the published behaviour, kept as is
+    hann = lambda f, rate: 0.5 * (1 + np.cos(2 * np.pi * f / rate))
+    t50, t100 = np.arange(3000) / 50.0, np.arange(6000) / 100.0
+    up = resample_array(sig(t50), 50.0, 100.0)
+    want = hann(3.0, 50.0) * np.sin(2 * np.pi * 3.0 * t100 + 0.3) + hann(11.0, 50.0) * 0.5 * np.sin(2 * np.pi * 11.0 * t100)
+    assert len(up) == 6000 and np.abs(up[300:-300] - want[300:-300]).max() < 2e-3
+    t40 = np.arange(4000) / 40.0
+    up40 = resample_array(np.sin(2 * np.pi * 1.5 * t40), 40.0, 100.0)
+    want40 = hann(1.5, 40.0) * np.sin(2 * np.pi * 1.5 * np.arange(10_000) / 100.0)
+    assert len(up40) == 10_000 and np.abs(up40[500:-500] - want40[500:-500]).max() < 2e-3
+    # identity rate: untouched; DC gain of the Fourier method is exactly the length ratio rule (mean preserved)
+    x = rng.standard_normal(1000)
+    assert resample_array(x, 100.0, 100.0) is not None and np.array_equal(resample_array(x, 100.0, 100.0), x)
+    c = resample_fourier(np.full(1000, 2.5), 80.0, 100.0)
+    assert len(c) == 1250 and np.abs(c - 2.5).max() < 1e-9
+    with pytest.raises(NotImplementedError):
+        resample_array(np.ma.masked_array(x, mask=x > 2), 50.0, 100.0)

@@ -710,16 +710,16 @@ def _group_stream(stream, component_order, sampling_rate, copy, in_samples):
     """Yield one dict per contiguous block of one instrument: data (3,N) float32 in
     ``component_order`` (missing components / gaps inside a block zero-filled), start time and
     ids.  In-repo twin of the array assembly: volpick/data/convert.py:26-70."""
-    traces = list(stream)  # the input is never modified, so ``copy`` needs no deep copy here
+    from .resample import resample_trace
+
+    # traces at the model's rate are never modified, so ``copy`` needs no deep copy for them; the others are
+    # resampled as SeisBench's annotate() does (on copies, or in place with copy=False)
+    traces = [resample_trace(tr, float(sampling_rate), copy) for tr in stream]
     if len(traces) == 0:
         return
     groups = {}
     for tr in traces:
         s = tr.stats
-        if abs(float(s.sampling_rate) - sampling_rate) > 1e-6:
-            raise ValueError(
-                f"trace {tr.id} has sampling rate {s.sampling_rate} Hz; this path expects {sampling_rate} Hz "
-                "(resample the stream first)")
         groups.setdefault((s.network, s.station, s.location, s.channel[:-1]), []).append(tr)
     comp_alias = {"1": "N", "2": "E", "3": "Z"}  # flexible horizontal components
     for (net, sta, loc, cha), trs in sorted(groups.items()):
