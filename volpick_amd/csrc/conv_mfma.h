@@ -321,8 +321,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       if (t < a.l_out) {
         const float v = lds[co * C::OS + q];
         float* row = d + (long)co * a.lsd;
-        row[2 * t] = v;
-        if (2 * t + 1 < a.l_dst) row[2 * t + 1] = v;
+        if (2 * t + 1 < a.l_dst) {
+          *reinterpret_cast<float2*>(row + 2 * t) = make_float2(v, v);  // one coalesced 8-byte store per pair
+        } else {
+          row[2 * t] = v;
+        }
       }
     }
   } else if constexpr (C::EPI == EPI_RES) {
