@@ -233,6 +233,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.model, data, overlap, blinding, args.batch, args.cpu_seconds)
+        result["pick_parity"] = pick_parity(model, args.model, data, overlap, blinding, args.batch)
     if rank == 0:
         print(json.dumps(result))
     if use_dist:
@@ -251,6 +252,30 @@ def traffic_bytes(model_name, step_name):
         return json.loads(f.read_text()).get(model_name, {}).get(step_name)
     except (ValueError, OSError):
         return None
+
+
+def pick_parity(model, model_name, data, overlap, blinding, batch, n_windows=64):
+    """The second half of BASELINE.json's metric ("P/S pick delta-t vs ref"): the picks of the HIP path on a
+    64-window prefix of the bench stream against the CPU oracle's on the same samples (the oracle stands in for the
+    un-installable SeisBench reference: parity unpinned)."""
+    from oracle import pipeline as OP
+    from oracle.models import load_pretrained
+
+    net = load_pretrained(model_name)
+    T = net.in_samples
+    seg = data[:, : T + (T - overlap) * (n_windows - 1)]
+    want = OP.classify_array(net, seg, overlap=overlap, blinding=blinding, batch_size=batch)["picks"]
+    args = model._argdict(dict(overlap=overlap, blinding=blinding, stacking="avg", batch_size=batch))
+    specs = [s for s in model._trigger_specs(args) if s[1] != "Detection"]
+    got, _ = model._classify_block(seg, args, specs)
+    got = sorted((specs[si][1], on, off, pk, v) for si, on, off, pk, v in got)
+    want = sorted(want)
+    out = {"vs": "CPU oracle (port; parity unpinned)", "windows": n_windows, "picks_hip": len(got), "picks_oracle": len(want)}
+    if len(got) == len(want) and all(g[0] == w[0] for g, w in zip(got, want)):
+        out["max_abs_dt_samples"] = max([abs(g[3] - w[3]) for g, w in zip(got, want)], default=0)
+        out["max_abs_dt_s"] = out["max_abs_dt_samples"] / 100.0
+        out["max_abs_dvalue"] = float(max([abs(g[4] - w[4]) for g, w in zip(got, want)], default=0.0))
+    return out
 
 
 def cpu_baseline(model_name, data, overlap, blinding, batch, budget_s):
