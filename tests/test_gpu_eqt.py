@@ -61,9 +61,8 @@ def _oracle_stages(net, x):
                     u = u[:, :, :-1]
                 ys.append(torch.relu(dec.convs[s](u)))
             hs = ys
-            # stage 1 stores its rows x2-upsampled and cropped (input of the plain-conv stage 2)
             if s < 6:  # decoder.6 never leaves the chip: the sigmoid heads are fused into its epilogue
-                out[f"decoder.{s}"] = torch.cat([up2(y)[:, :, :-1] for y in ys], 0) if s == 1 else torch.cat(ys, 0)
+                out[f"decoder.{s}"] = torch.cat(ys, 0)
         final = net(x)
     return {k: v.numpy() for k, v in out.items()}, [f.numpy() for f in final]
 

@@ -113,9 +113,11 @@ def test_eqt_conv_layers_match_oracle(lib):
         i += 1
     assert len(layers) == 7 + 14 + 7
 
-    def check(name, src, want, **kw):
+    def check(name, src, want, skip_last=0, **kw):
         got = emulate_conv(layers[name], src, **kw)
         assert got.shape == want.shape, (name, got.shape, want.shape)
+        if skip_last:
+            got, want = got[:, :-skip_last], want[:, :-skip_last]
         err = np.abs(got - want).max()
         assert err < 2e-4 * max(1.0, np.abs(want).max()), (name, err)
 
@@ -138,8 +140,9 @@ def test_eqt_conv_layers_match_oracle(lib):
             check(f"res{s}.conv2", m[0].numpy(), c2[0].numpy())
             h = h + c2
         bott = net.bottleneck(x)
-        # decoders: three weight sets per stage.  Every stage but #2 folds Upsample(2) into the conv
-        # (input = the NOT-upsampled rows); stage 2 reads stage 1's x2-upsampled, cropped rows.
+        # decoders: three weight sets per stage, Upsample(2) folded into the conv (input = the NOT-upsampled rows).
+        # Stage 2 crops the upsampled row by one sample: the folded conv is exact up to its last two outputs, which
+        # decoder2_edge_kernel recomputes on the GPU (tests/test_gpu_eqt.py covers the result).
         decs = [net.decoder_d, net.pick_decoders[0], net.pick_decoders[1]]
         for d, dec in enumerate(decs):
             h = bott
@@ -148,6 +151,5 @@ def test_eqt_conv_layers_match_oracle(lib):
                 if s in dec.crops:
                     u = u[:, :, :-1]
                 y = torch.relu(conv(u))
-                src = u if s == 2 else h
-                check(f"decoder.{s}", src[0].numpy(), y[0].numpy(), set_index=d, sets=3)
+                check(f"decoder.{s}", h[0].numpy(), y[0].numpy(), set_index=d, sets=3, skip_last=2 if s == 2 else 0)
                 h = y

@@ -34,13 +34,14 @@ using EQ_r2k2 = ConvCfg<64, 0, 64, 1, 2, 1, 0, 0, 4, 1, 3, 0, EPI_RES>;
 // conv as a 2-phase polyphase filter on the NOT-upsampled input (conv_pack.cpp amat_upconv):
 //   y[co][2n+p] = sum_ci sum_d Wp[co][ci][d] x[ci][n+d],  d in [floor(-pad/2), floor((K-pad)/2)]
 // K = 3/5/7/9/11 -> 3/3/5/5/7 taps for two outputs instead of 2K: 0.6-0.7x the MACs, half the reads,
-// and the x2 intermediate is never written.  Stage 2 (188 -> 375, odd) is the exception: the reference
-// crops the upsampled row by one sample, which a polyphase filter cannot express at the right edge, so
-// stage 1 writes its output x2-upsampled and cropped and stage 2 stays a plain conv.
+// and the x2 intermediate is never written.  Stage 2 (188 -> 375, odd): the reference crops the upsampled row by one
+// sample, which a polyphase filter cannot express at the right edge — its last two outputs would see the cropped
+// copy of the last input sample.  The stage runs folded like the others and decoder2_edge_kernel then recomputes
+// exactly those two samples per channel from the definition (2 x 32 x 320 MACs per decoder and window).
 //                      CIN1 CIN2 COUT P TAPS SN IN_OFF OUT_OFF WM WN NW RELU EPI
 using EQ_d0 = ConvCfg<16, 0, 64, 2, 3, 1, -1, 0, 4, 1, 3, 1, EPI_STORE>;
-using EQ_d1 = ConvCfg<64, 0, 64, 2, 3, 1, -1, 0, 4, 1, 6, 1, EPI_UP2>;
-using EQ_d2 = ConvCfg<64, 0, 32, 1, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
+using EQ_d1 = ConvCfg<64, 0, 64, 2, 3, 1, -1, 0, 4, 1, 6, 1, EPI_STORE>;
+using EQ_d2 = ConvCfg<64, 0, 32, 2, 3, 1, -1, 0, 2, 2, 6, 1, EPI_STORE>;
 using EQ_d3 = ConvCfg<32, 0, 32, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
 using EQ_d4 = ConvCfg<32, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
 using EQ_d5 = ConvCfg<16, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
@@ -50,6 +51,42 @@ using EQ_d3b = ConvCfg<32, 0, 32, 2, 5, 1, -2, 0, 2, 2, 3, 1, EPI_STORE>;
 using EQ_d4b = ConvCfg<32, 0, 16, 2, 5, 1, -2, 0, 2, 2, 3, 1, EPI_STORE>;
 using EQ_d5b = ConvCfg<16, 0, 16, 2, 5, 1, -2, 0, 2, 2, 3, 1, EPI_STORE>;
 using EQ_d6b = ConvCfg<16, 0, 8, 2, 7, 1, -3, 0, 1, 4, 4, 1, EPI_HEAD>;
+
+// Right edge of decoder stage 2 (module comment): y[t] = relu(b + sum_ci sum_k W[co][ci][k] u[t + k - 2]) for the last
+// two samples t = l_out - 2, l_out - 1 (373, 374), with u[i] = x[ci][i >> 1] inside the cropped upsampled row [0, l_out)
+// and 0 outside.  Both samples only see x[ci][185 .. 187]; the taps that hit the same input sample are pre-summed on the
+// host: e[set][ci][thread][3] with thread = 2 co + which.  One 64-thread workgroup per (decoder, window).
+struct EdgeArgs {
+  const float* x;  // stage-1 rows [3 B][64][ls]
+  int ls_x;
+  long ws_x;
+  float* y;        // stage-2 rows [3 B][32][ls]
+  int ls_y;
+  long ws_y;
+  const float* e;  // [3][64][64][3]
+  const float* b;  // [3][32]
+  int win_per_set, l_out;
+};
+__global__ __launch_bounds__(64) void decoder2_edge_kernel(const EdgeArgs a) {
+  __shared__ float xs[64][3];
+  const int win = blockIdx.x, set = win / a.win_per_set, tid = threadIdx.x;
+  const int n0 = (a.l_out - 2 - 2) >> 1;  // first input sample the two outputs see (185)
+  {
+    const float* x = a.x + (long)win * a.ws_x + HALO + (long)tid * a.ls_x + n0;
+    xs[tid][0] = x[0], xs[tid][1] = x[1], xs[tid][2] = x[2];
+  }
+  __syncthreads();
+  const float* e = a.e + ((long)set * 64 * 64 + tid) * 3;
+  float acc = a.b[set * 32 + (tid >> 1)];
+#pragma unroll 8
+  for (int ci = 0; ci < 64; ++ci) {
+    const float* ec = e + (long)ci * 64 * 3;
+    acc = fmaf(ec[0], xs[ci][0], acc);
+    acc = fmaf(ec[1], xs[ci][1], acc);
+    acc = fmaf(ec[2], xs[ci][2], acc);
+  }
+  a.y[(long)win * a.ws_y + HALO + (long)(tid >> 1) * a.ls_y + a.l_out - 2 + (tid & 1)] = fmaxf(acc, 0.f);
+}
 
 std::vector<float> vec(const float* p, size_t n) { return std::vector<float>(p, p + n); }
 
@@ -307,7 +344,7 @@ int plan_eqt(Net& net, const ParamView& pv) {
   }
 
   // ---- three decoders, one launch per stage ----------------------------------------------------
-  const int din[7] = {47, 94, 375, 375, 750, 1500, 3000};    // length of the stage's input rows
+  const int din[7] = {47, 94, 188, 375, 750, 1500, 3000};    // length of the stage's input rows
   const int dout[7] = {94, 188, 375, 750, 1500, 3000, 6000};  // conv output length
   const int dco[7] = {64, 64, 32, 32, 16, 16, 8};
   const int dci[7] = {16, 64, 64, 32, 32, 16, 16};
@@ -316,8 +353,8 @@ int plan_eqt(Net& net, const ParamView& pv) {
   int dsrc = dec_in;
   const bool alt = net.cfg.reserved[3] == 1;
   for (int i = 0; i < 7; ++i) {
-    const bool polyphase = (i != 2);
-    const int dst_len = (i == 1) ? 375 : dout[i];  // stage 1 stores its rows x2-upsampled and cropped
+    const bool polyphase = true;
+    const int dst_len = dout[i];
     const int dst = (i == 6) ? kDenseOut : net.add_tensor("decoder." + std::to_string(i), dco[i], dst_len, 3);
     auto pack3 = [&](const ConvGeom& g, std::vector<float>* af, std::vector<float>* bs) {
       for (int d = 0; d < 3; ++d) {
@@ -333,7 +370,7 @@ int plan_eqt(Net& net, const ParamView& pv) {
     };
     std::vector<float> af, bs;
     const std::string nm = "decoder." + std::to_string(i);
-    const int cols = din[i];  // polyphase: one column per input sample; stage 2: one per output sample
+    const int cols = din[i];  // polyphase: one column per input sample
 #define EQ_DEC(CFG)                                                  \
   pack3(CFG::geom(), &af, &bs);                                      \
   L = net.add_conv<CFG>(nm, dsrc, -1, dst, cols, dout[i], af, bs, 3);
@@ -350,6 +387,46 @@ int plan_eqt(Net& net, const ParamView& pv) {
     L->l_dst = dst_len;
     L->flops_per_window = 3 * 2.0 * dco[i] * dci[i] * dk[i] * dout[i];  // algorithmic (reference) MACs
     net.steps.back().flops_per_window = L->flops_per_window;
+    if (i == 2) {  // the two samples at the cropped right edge, recomputed from the definition
+      std::vector<float> ew((size_t)3 * 64 * 64 * 3), eb;
+      for (int d = 0; d < 3; ++d) {
+        const std::string c = std::string(dec_prefix[d]) + ".convs.2";
+        const float* w = pv.get(c + ".weight");  // [32][64][5]
+        const float* b = pv.get(c + ".bias");
+        for (int ci = 0; ci < 64; ++ci)
+          for (int co = 0; co < 32; ++co) {
+            const float* k = w + ((size_t)co * 64 + ci) * 5;
+            float* e0 = &ew[(((size_t)d * 64 + ci) * 64 + 2 * co) * 3];  // t = 373: u[371..375] = x185 x186 x186 x187 (cropped)
+            e0[0] = k[0], e0[1] = k[1] + k[2], e0[2] = k[3];
+            float* e1 = e0 + 3;                                           // t = 374: u[372..376] = x186 x186 x187 (cropped) (0)
+            e1[0] = 0.f, e1[1] = k[0] + k[1], e1[2] = k[2];
+          }
+        eb.insert(eb.end(), b, b + 32);
+      }
+      HostBlob* hw = net.add_blob(std::move(ew));
+      HostBlob* hb = net.add_blob(std::move(eb));
+      Step st;
+      st.name = "decoder.2.edge";
+      st.flops_per_window = 0;
+      const int src_t = dsrc, dst_t = dst;
+      st.run = [=](Net& n, int B, hipStream_t s_) -> int {
+        EdgeArgs a{};
+        const Tensor &tx = n.tensors[src_t], &ty = n.tensors[dst_t];
+        a.x = tx.p;
+        a.ls_x = tx.ls;
+        a.ws_x = (long)tx.win_stride();
+        a.y = ty.p;
+        a.ls_y = ty.ls;
+        a.ws_y = (long)ty.win_stride();
+        a.e = hw->d;
+        a.b = hb->d;
+        a.win_per_set = B;
+        a.l_out = 375;
+        hipLaunchKernelGGL(decoder2_edge_kernel, dim3(3 * B), dim3(64), 0, s_, a);
+        return 0;
+      };
+      net.steps.push_back(std::move(st));
+    }
     dsrc = dst;
   }
 
