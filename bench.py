@@ -209,7 +209,7 @@ def main():
         },
         "roofline": {
             "bound": "mfma",
-            "kernel": f"conv_mfma_kernel<{dom['name']}>",
+            "kernel": ("pn_window_kernel: " if dom["name"].startswith("fused.window") else "conv_mfma_kernel: ") + dom["name"],
             "achieved": dom_tflops,
             "peak": PEAK_FP32_TFLOPS,
             "unit": "TFLOP/s",
