@@ -84,6 +84,7 @@ vp::PreArgs pre_args(const vp_handle* h, const float* src, int dense, long N, lo
   a.dst = in.p;
   a.lsd = in.ls;
   a.wsd = (long)in.win_stride();
+  a.flags = net.win_flags ? net.win_flags->d : nullptr;
   return a;
 }
 
@@ -98,7 +99,9 @@ int run_batch(vp_handle* h, const vp::PreArgs& pa, int nb) {
     return rc;
   }
   vp::launch_gather_normalize(pa, nb, h->stream);
-  return net.run(nb, h->stream);
+  const int rc = net.run(nb, h->stream);
+  if (rc == VP_OK && pa.flags) vp::launch_poison(net.y, pa.flags, nb, (long)net.n_out * net.in_samples, h->stream);
+  return rc;
 }
 
 }  // namespace

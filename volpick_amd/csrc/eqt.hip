@@ -142,6 +142,7 @@ int plan_eqt(Net& net, const ParamView& pv) {
   const int T = 6000;
   net.in_samples = T;
   net.n_out = 3;
+  net.win_flags = net.add_blob(std::vector<float>((size_t)std::max(net.max_batch, 1), 0.f));
   const int filt[7] = {8, 16, 16, 32, 32, 64, 64};
   const int rker[7] = {3, 3, 3, 3, 2, 3, 2};
   int len[8];

@@ -55,6 +55,7 @@ struct Net {
   size_t arena_floats = 0;
   double flops_per_window = 0;
   HostBlob* debug_clock = nullptr;  // fused PhaseNet core: per-layer shader-clock stamps (debug plan flag)
+  HostBlob* win_flags = nullptr;    // [max_batch]: 1 where annotate_batch_pre met a non-finite window (its predictions become NaN, as the reference's)
   bool fused_pre = false;           // the plan's first launch can gather + normalise its windows itself (pn_window_kernel)
   const PreArgs* pre = nullptr;     // set by the caller around run() when fused_pre: where the windows of this batch come from
 

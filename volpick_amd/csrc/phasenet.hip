@@ -63,6 +63,7 @@ int plan_phasenet(Net& net, const ParamView& pv) {
   const float eps = net.cfg.bn_eps;
   net.in_samples = T0;
   net.n_out = 3;
+  net.win_flags = net.add_blob(std::vector<float>((size_t)std::max(net.max_batch, 1), 0.f));
   const int len[5] = {T0, T1, T2, T3, T4};
   const int ch[5] = {8, 16, 32, 64, 128};
 

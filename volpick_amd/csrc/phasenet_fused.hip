@@ -989,6 +989,7 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
     for (int l_ = 0; l_ < (N_FLOATS); l_ += 16) warm_ += as_scalars(reinterpret_cast<const float*>(PTR))[l_]; \
     asm volatile("" ::"s"(warm_));                                                          \
   }
+  bool poisoned = false;                     // the window holds a NaN / Inf: its predictions are NaN (prepost.h)
   const int t0 = 4 * tid;                    // this lane's level-0 samples t0 .. t0 + 3 (VALU phases)
   const bool vconv = wave < W_WAVES;         // wave-uniform: runs the VALU convs
   const bool vstore = tid < W0_Q;            // lanes whose float4 lies inside an image row (751..755 store the zero margin)
@@ -1068,6 +1069,7 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
         stat[tid * 2 + 1] = acc;
       }
       __syncthreads();
+      for (int c = 0; c < 3; ++c) poisoned |= !isfinite(stat[2 * c]) || !isfinite(stat[2 * c + 1]);
       float amp[3];
       if (p.per_comp) {
         for (int c = 0; c < 3; ++c) amp[c] = (p.norm == VP_NORM_PEAK) ? stat[2 * c + 1] : sqrtf(stat[2 * c + 1] / (float)(T0 - 1));
@@ -1293,6 +1295,7 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
         const float e0 = __expf(z[0][r] - mx), e1 = __expf(z[1][r] - mx), e2 = __expf(z[2][r] - mx);
         const float inv = 1.f / (e0 + e1 + e2);
         y0[r] = e0 * inv, y1[r] = e1 * inv, y2[r] = e2 * inv;
+        if (poisoned) y0[r] = y1[r] = y2[r] = __builtin_nanf("");
       }
       float* y = a.y + (long)win * 3 * T0 + t0;
       if (t0 + 3 < T0) {  // dense rows of odd length: 4-byte aligned vector stores

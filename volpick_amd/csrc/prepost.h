@@ -19,10 +19,15 @@ struct PreArgs {
   float* dst;        // haloed input tensor
   int lsd;
   long wsd;
+  float* flags;      // optional [n_windows]: 1 where the window holds a non-finite sample (NaN / Inf statistics), else 0
   const long* table; // optional, 3 longs per window of the whole call: block offset in src, block length (row stride),
                      // window start; window w of this launch is entry first_window + w (multi-block classify)
 };
 int launch_gather_normalize(const PreArgs& a, int n_windows, hipStream_t stream);
+// The reference (torch) carries a NaN / Inf of the input into every output sample of its window: demeaning spreads it
+// over the channel, the first conv over all channels.  The kernels here lose it at the first ReLU (v_max is maxNum), so the
+// predictions of flagged windows are overwritten with NaN: y[w][0 .. floats_per_window) for every w with flags[w] != 0.
+int launch_poison(float* y, const float* flags, int n_windows, long floats_per_window, hipStream_t stream);
 
 __device__ inline float wave_sum(float v) {
 #pragma unroll

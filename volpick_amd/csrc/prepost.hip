@@ -31,8 +31,17 @@ __global__ __launch_bounds__(1024) void gather_normalize_kernel(const PreArgs a)
   float* dst = a.dst + (long)w * a.wsd + HALO;
 
   if (!a.preprocess) {
+    bool bad = false;
     for (int c = 0; c < 3; ++c)
-      for (int t = tid; t < T; t += NTH) dst[(long)c * a.lsd + t] = src[c * cs + t];
+      for (int t = tid; t < T; t += NTH) {
+        const float x = src[c * cs + t];
+        bad |= !isfinite(x);
+        dst[(long)c * a.lsd + t] = x;
+      }
+    if (a.flags) {
+      const int any = __syncthreads_or(bad);
+      if (tid == 0) a.flags[w] = any ? 1.f : 0.f;
+    }
     return;
   }
   // The window lives in registers: one read of the stream, all three steps (mean, amplitude, scale) from there.
@@ -88,6 +97,11 @@ __global__ __launch_bounds__(1024) void gather_normalize_kernel(const PreArgs a)
     stat[tid][1] = acc;
   }
   __syncthreads();
+  if (a.flags && tid == 0) {  // a non-finite sample shows in the statistics of its channel
+    bool bad = false;
+    for (int c = 0; c < 3; ++c) bad |= !isfinite(stat[c][0]) || !isfinite(stat[c][1]);
+    a.flags[w] = bad ? 1.f : 0.f;
+  }
   float amp[3];
   if (a.per_comp) {
     for (int c = 0; c < 3; ++c)
@@ -116,6 +130,18 @@ __global__ __launch_bounds__(1024) void gather_normalize_kernel(const PreArgs a)
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void poison_kernel(float* y, const float* flags, long n) {
+  if (flags[blockIdx.x] == 0.f) return;
+  float* p = y + (long)blockIdx.x * n;
+  const float q = __builtin_nanf("");
+  for (long i = threadIdx.x; i < n; i += 256) p[i] = q;
+}
+
+int launch_poison(float* y, const float* flags, int n_windows, long floats_per_window, hipStream_t stream) {
+  hipLaunchKernelGGL(poison_kernel, dim3(n_windows), dim3(256), 0, stream, y, flags, floats_per_window);
+  return 0;
 }
 
 int launch_gather_normalize(const PreArgs& a, int n_windows, hipStream_t stream) {
