@@ -207,8 +207,9 @@ int launch_bilstm(const BiLstmArgs& a, int cin, int B, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void transformer_kernel(const TransformerArgs a) {
-  constexpr int NTH = 1024;
+constexpr int TR_NTH = 512;  // threads per window (1024 ran the kernel itself 3 us faster and the pipeline 1 % slower: tools/sweep_pick.sh)
+__global__ __launch_bounds__(TR_NTH) void transformer_kernel(const TransformerArgs a) {
+  constexpr int NTH = TR_NTH;
   __shared__ float xs[T][EQT_H];
   // q / k / e of the attention and, afterwards, the padded feed-forward weights share one pool
   constexpr int POOL = 2 * T * KP + T * 48;
@@ -270,14 +271,15 @@ __global__ __launch_bounds__(1024) void transformer_kernel(const TransformerArgs
 }
 
 int launch_transformer(const TransformerArgs& a, int B, hipStream_t s) {
-  hipLaunchKernelGGL(transformer_kernel, dim3(B), dim3(1024), 0, s, a);
+  hipLaunchKernelGGL(transformer_kernel, dim3(B), dim3(TR_NTH), 0, s, a);
   return 0;
 }
 
 // ---------------------------------------------------------------------------------------
 // P / S branch: LSTM(16,16) -> banded additive attention -> x2-upsampled decoder input.
-__global__ __launch_bounds__(1024) void pick_branch_kernel(const PickBranchArgs a) {
-  constexpr int NTH = 1024;
+constexpr int PICK_NTH = 256;  // threads per (window, branch): 1024 held every wave slot of the chip through the 47 sequential LSTM steps of ONE wave
+__global__ __launch_bounds__(PICK_NTH) void pick_branch_kernel(const PickBranchArgs a) {
+  constexpr int NTH = PICK_NTH;
   __shared__ __attribute__((aligned(16))) float xs[T][EQT_H];
   __shared__ float gx[T * 64];
   __shared__ float hl[EQT_H][48];
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(1024) void pick_branch_kernel(const PickBranchArgs 
 }
 
 int launch_pick_branch(const PickBranchArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(pick_branch_kernel, dim3(a.B, 2), dim3(1024), 0, s, a);
+  hipLaunchKernelGGL(pick_branch_kernel, dim3(a.B, 2), dim3(PICK_NTH), 0, s, a);
   return 0;
 }
 
