@@ -216,6 +216,10 @@ int plan_eqt(Net& net, const ParamView& pv) {
   const int res_out = x_cur;
 
   // ---- BiLSTM stack ---------------------------------------------------------------------
+  std::vector<std::function<BiLstmArgs(Net&)>> mk_lstm;
+  std::vector<std::function<TransformerArgs(Net&)>> mk_tr;
+  int mid_first = -1;  // first of the six steps that eqt_mid_kernel replaces
+  double mid_flops = 0;
   int lstm_in = res_out;
   for (int i = 0; i < 3; ++i) {
     const std::string p = "bi_lstm_stack.members." + std::to_string(i);
@@ -234,7 +238,7 @@ int plan_eqt(Net& net, const ParamView& pv) {
     st.name = "bilstm." + std::to_string(i);
     st.flops_per_window = 2.0 * 2 * EQT_T * (64.0 * cin + 64.0 * 16) + 2.0 * 16 * 32 * EQT_T;
     const int src_t = lstm_in;
-    st.run = [=](Net& n, int B, hipStream_t s_) -> int {
+    auto mk = [=](Net& n) -> BiLstmArgs {
       BiLstmArgs a{};
       const Tensor& s0 = n.tensors[src_t];
       const Tensor& d0 = n.tensors[out];
@@ -248,8 +252,12 @@ int plan_eqt(Net& net, const ParamView& pv) {
       a.bwd = resolve(bw);
       a.wc = wcb->d;
       a.bc = bcb->d;
-      return launch_bilstm(a, cin, B, s_);
+      return a;
     };
+    mk_lstm.push_back(mk);
+    st.run = [=](Net& n, int B, hipStream_t s_) -> int { return launch_bilstm(mk(n), cin, B, s_); };
+    mid_first = (i == 0) ? (int)net.steps.size() : mid_first;
+    mid_flops += st.flops_per_window;
     net.steps.push_back(std::move(st));
     lstm_in = out;
   }
@@ -276,7 +284,7 @@ int plan_eqt(Net& net, const ParamView& pv) {
     const int src_t = tr_in;
     const bool last = (i == 1);
     const float attn_eps = net.cfg.attention_eps, ln_eps = net.cfg.layernorm_eps;
-    st.run = [=](Net& n, int B, hipStream_t s_) -> int {
+    auto mk = [=](Net& n) -> TransformerArgs {
       TransformerArgs a{};
       const Tensor& s0 = n.tensors[src_t];
       const Tensor& d0 = n.tensors[out];
@@ -303,8 +311,11 @@ int plan_eqt(Net& net, const ParamView& pv) {
       a.bb2 = bb2->d;
       a.attn_eps = attn_eps;
       a.ln_eps = ln_eps;
-      return launch_transformer(a, B, s_);
+      return a;
     };
+    mk_tr.push_back(mk);
+    st.run = [=](Net& n, int B, hipStream_t s_) -> int { return launch_transformer(mk(n), B, s_); };
+    mid_flops += st.flops_per_window;
     net.steps.push_back(std::move(st));
     tr_in = out;
   }
@@ -322,7 +333,7 @@ int plan_eqt(Net& net, const ParamView& pv) {
     st.flops_per_window = 2.0 * (2.0 * EQT_T * (64 * 16 + 64 * 16) + 2.0 * (2 * EQT_T * 16 * 32 + EQT_T * EQT_T * 32 * 2 + EQT_T * EQT_T * 16));
     const int src_t = tr_in;
     const float attn_eps = net.cfg.attention_eps;
-    st.run = [=](Net& n, int B, hipStream_t s_) -> int {
+    auto mk_pick = [=](Net& n, int B) -> PickBranchArgs {
       PickBranchArgs a{};
       const Tensor& s0 = n.tensors[src_t];
       const Tensor& u = n.tensors[dec_in];
@@ -339,9 +350,27 @@ int plan_eqt(Net& net, const ParamView& pv) {
       }
       a.attn_eps = attn_eps;
       a.width = 3;
-      return launch_pick_branch(a, s_);
+      return a;
     };
+    st.run = [=](Net& n, int B, hipStream_t s_) -> int { return launch_pick_branch(mk_pick(n, B), s_); };
+    mid_flops += st.flops_per_window;
     net.steps.push_back(std::move(st));
+    // reserved[2] = 1 keeps the six separate launches (A/B timing); default: one launch for the whole latency-bound chain
+    if (net.cfg.reserved[2] != 1 && mid_first >= 0 && (int)net.steps.size() == mid_first + 6) {
+      Step fused;
+      fused.name = "fused.mid (3 BiLSTM + 2 transformer blocks + pick branches)";
+      fused.flops_per_window = mid_flops;
+      fused.run = [=](Net& n, int B, hipStream_t s_) -> int {
+        MidArgs m{};
+        for (int i = 0; i < 3; ++i) m.lstm[i] = mk_lstm[i](n);
+        for (int i = 0; i < 2; ++i) m.tr[i] = mk_tr[i](n);
+        m.pick = mk_pick(n, B);
+        m.clk = n.debug_clock ? reinterpret_cast<unsigned long long*>(n.debug_clock->d) : nullptr;  // slots [B][8] (tools/mid_clock.py)
+        return launch_eqt_mid(m, B, s_);
+      };
+      net.steps.erase(net.steps.begin() + mid_first, net.steps.end());
+      net.steps.push_back(std::move(fused));
+    }
   }
 
   // ---- three decoders, one launch per stage ----------------------------------------------------

@@ -72,6 +72,18 @@ struct PickBranchArgs {
   int width;         // band width (3)
 };
 
+// The three BiLSTM blocks, the two transformer blocks and the two pick branches of one window as ONE launch
+// (eqt_mid_kernel): the six launches it replaces are a chain of latency-bound kernels (47 sequential LSTM steps four
+// times over) that the three device contexts cannot hide behind each other's MFMA work — measured: with them removed
+// from the pipeline a 256-window step takes 510 instead of 615 us.
+struct MidArgs {
+  BiLstmArgs lstm[3];     // lstm[0].src: ResCNN output (64 channels); the others chain through LDS
+  TransformerArgs tr[2];
+  PickBranchArgs pick;
+  unsigned long long* clk;  // optional debug: 8 shader-clock stamps per window (start, after each of the six stages, end)
+};
+int launch_eqt_mid(const MidArgs& a, int B, hipStream_t s);
+
 int launch_bilstm(const BiLstmArgs& a, int cin, int B, hipStream_t s);
 int launch_transformer(const TransformerArgs& a, int B, hipStream_t s);
 int launch_pick_branch(const PickBranchArgs& a, hipStream_t s);

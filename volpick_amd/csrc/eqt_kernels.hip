@@ -34,28 +34,31 @@ __device__ inline float tanh_fast(float z) {
 // four gates of a unit are gathered with three ds_bpermute shuffles, c/h are kept
 // redundantly in all four 16-lane groups.  xs: LDS [T][CIN]; gx: LDS [T][64] per-lane
 // scratch for the input projection; hout: LDS rows [16][hs].
+// Input projection of one direction for the time steps t0, t0 + tstep, ... (any number of waves may share it).
 template <int CIN>
-__device__ void lstm_direction(const float* xs, float* gx, const LstmWeights w, const bool reverse, float* hout,
-                               const int hs) {
+__device__ void lstm_project(const float* xs, float* gx, const LstmWeights w, const int t0, const int tstep) {
   const int lane = threadIdx.x & 63;
-  {
-    float wih[CIN];
+  float wih[CIN];
 #pragma unroll
-    for (int c = 0; c < CIN; ++c) wih[c] = w.w_ih[lane * CIN + c];
-    const float b = w.b[lane];
-    for (int t = 0; t < T; ++t) {
-      float a0 = b, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int c = 0; c < CIN; ++c) wih[c] = w.w_ih[lane * CIN + c];
+  const float b = w.b[lane];
+  for (int t = t0; t < T; t += tstep) {
+    float a0 = b, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-      for (int c = 0; c < CIN; c += 4) {
-        const float4 x = *reinterpret_cast<const float4*>(xs + t * CIN + c);  // same address in every lane
-        a0 = fmaf(wih[c], x.x, a0);
-        a1 = fmaf(wih[c + 1], x.y, a1);
-        a2 = fmaf(wih[c + 2], x.z, a2);
-        a3 = fmaf(wih[c + 3], x.w, a3);
-      }
-      gx[t * 64 + lane] = (a0 + a1) + (a2 + a3);
+    for (int c = 0; c < CIN; c += 4) {
+      const float4 x = *reinterpret_cast<const float4*>(xs + t * CIN + c);  // same address in every lane
+      a0 = fmaf(wih[c], x.x, a0);
+      a1 = fmaf(wih[c + 1], x.y, a1);
+      a2 = fmaf(wih[c + 2], x.z, a2);
+      a3 = fmaf(wih[c + 3], x.w, a3);
     }
+    gx[t * 64 + lane] = (a0 + a1) + (a2 + a3);
   }
+}
+
+// The 47 sequential steps of one direction on ONE wavefront (gx: its input projection).
+__device__ void lstm_recur(const float* gx, const LstmWeights w, const bool reverse, float* hout, const int hs) {
+  const int lane = threadIdx.x & 63;
   float whh[EQT_H];
 #pragma unroll
   for (int u = 0; u < EQT_H; ++u) whh[u] = w.w_hh[lane * EQT_H + u];
@@ -82,6 +85,13 @@ __device__ void lstm_direction(const float* xs, float* gx, const LstmWeights w, 
     h = og * tanh_fast(c);
     if (lane < EQT_H) hout[lane * hs + t] = h;
   }
+}
+
+template <int CIN>
+__device__ void lstm_direction(const float* xs, float* gx, const LstmWeights w, const bool reverse, float* hout,
+                               const int hs) {
+  lstm_project<CIN>(xs, gx, w, 0, 1);
+  lstm_recur(gx, w, reverse, hout, hs);
 }
 
 // Additive self-attention on one window held in LDS (SeisBench SeqSelfAttention):
@@ -308,6 +318,184 @@ __global__ __launch_bounds__(PICK_NTH) void pick_branch_kernel(const PickBranchA
 
 int launch_pick_branch(const PickBranchArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(pick_branch_kernel, dim3(a.B, 2), dim3(PICK_NTH), 0, s, a);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// One workgroup (8 wavefronts) per window walks bilstm.0-2 -> transformer_d0 -> transformer_d -> pick branches.
+// The current activation (16 x 47) travels through LDS (`cur`); every stage still writes its tensor to memory (decoder
+// inputs; the others for the layer-by-layer tests).  Against the separate kernels: the input projections of the LSTMs
+// are spread over all waves instead of running in front of the recurrence on its one wave, the two pick LSTMs run
+// side by side, and five kernel boundaries are gone.
+constexpr int MID_NTH = 512;
+constexpr int MID_WPD = MID_NTH / 128;  // waves per LSTM direction in the input projections
+constexpr int MID_POOL = 16000;  // floats; the stages carve it up in turn
+
+template <int CIN>
+__device__ void mid_bilstm(const BiLstmArgs& a, const int b, float* P, float* cur, const bool from_memory) {
+  const int tid = threadIdx.x, wave = tid >> 6;
+  float* xs = P;                    // [T][CIN]
+  float* gx = P + T * 64;           // [2][T * 64]
+  float* hc = P + 3 * T * 64;       // [32][48]
+  if (from_memory) {
+    const float* src = a.src + (long)b * a.ws_src;
+    for (int idx = tid; idx < CIN * T; idx += MID_NTH) {
+      const int c = idx / T, t = idx - c * T;
+      xs[t * CIN + c] = src[(long)c * a.ls_src + HALO + t];
+    }
+  } else {
+    for (int idx = tid; idx < CIN * T; idx += MID_NTH) {
+      const int c = idx / T, t = idx - c * T;
+      xs[t * CIN + c] = cur[c * 48 + t];
+    }
+  }
+  __syncthreads();
+  lstm_project<CIN>(xs, gx + (wave / MID_WPD) * T * 64, (wave / MID_WPD) ? a.bwd : a.fwd, wave % MID_WPD, MID_WPD);  // first half of the waves: fwd
+  __syncthreads();
+  if (wave < 2) lstm_recur(gx + wave * T * 64, wave ? a.bwd : a.fwd, wave == 1, hc + wave * 16 * 48, 48);
+  __syncthreads();
+  float* dst = a.dst + (long)b * a.ws_dst;
+  for (int idx = tid; idx < EQT_H * T; idx += MID_NTH) {  // Conv1d(32,16,1) + BatchNorm, folded
+    const int co = idx / T, t = idx - co * T;
+    float acc = a.bc[co];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc = fmaf(a.wc[co * 32 + c], hc[c * 48 + t], acc);
+    dst[(long)co * a.ls_dst + HALO + t] = acc;
+    cur[co * 48 + t] = acc;
+  }
+  __syncthreads();
+}
+
+__device__ void mid_transformer(const TransformerArgs& a, const int b, float* P, float* cur) {
+  constexpr int NTH = MID_NTH;
+  const int tid = threadIdx.x;
+  float(*xs)[EQT_H] = reinterpret_cast<float(*)[EQT_H]>(P);
+  constexpr int POOL = 2 * T * KP + T * 48;
+  constexpr int W1S = 17, W2S = 129;
+  static_assert(128 * W1S + EQT_H * W2S <= POOL, "feed-forward weights must fit the attention scratch");
+  float* pool = P + T * EQT_H;
+  float(*q)[KP] = reinterpret_cast<float(*)[KP]>(pool);
+  float(*k)[KP] = reinterpret_cast<float(*)[KP]>(pool + T * KP);
+  float(*e)[48] = reinterpret_cast<float(*)[48]>(pool + 2 * T * KP);
+  float* w1s = pool;
+  float* w2s = pool + 128 * W1S;
+  float(*v)[EQT_H] = reinterpret_cast<float(*)[EQT_H]>(pool + POOL);
+  float(*y1)[EQT_H] = reinterpret_cast<float(*)[EQT_H]>(pool + POOL + T * EQT_H);
+  float(*h1)[128] = reinterpret_cast<float(*)[128]>(pool + POOL + 2 * T * EQT_H);
+  static_assert(T * EQT_H + POOL + 2 * T * EQT_H + T * 128 <= MID_POOL, "transformer stage fits the pool");
+  for (int idx = tid; idx < EQT_H * T; idx += NTH) {
+    const int c = idx / T, t = idx - c * T;
+    xs[t][c] = cur[c * 48 + t];
+  }
+  __syncthreads();
+  attention_core(xs, q, k, e, v, a.att, a.attn_eps, 0);  // ends with a barrier: q / k / e are dead now
+  for (int i = tid; i < 128 * 16; i += NTH) {
+    w1s[(i >> 4) * W1S + (i & 15)] = a.w1[i];
+    w2s[(i >> 7) * W2S + (i & 127)] = a.w2[i];
+  }
+  if (tid < T) {  // y1 = LN1(x + attention(x))
+    float z[EQT_H];
+#pragma unroll
+    for (int c = 0; c < EQT_H; ++c) z[c] = xs[tid][c] + v[tid][c];
+    layer_norm16(z, a.g1, a.b1, a.ln_eps, y1[tid]);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < T * 128; idx += NTH) {  // FF: Linear(16,128) + ReLU
+    const int t = idx >> 7, m = idx & 127;
+    float acc = a.bb1[m];
+#pragma unroll
+    for (int c = 0; c < EQT_H; ++c) acc = fmaf(w1s[m * W1S + c], y1[t][c], acc);
+    h1[t][m] = fmaxf(acc, 0.f);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < T * EQT_H; idx += NTH) {  // Linear(128,16) + residual
+    const int t = idx >> 4, c = idx & 15;
+    float a0 = a.bb2[c], a1 = 0.f;
+#pragma unroll 8
+    for (int m = 0; m < 128; m += 2) {
+      a0 = fmaf(w2s[c * W2S + m], h1[t][m], a0);
+      a1 = fmaf(w2s[c * W2S + m + 1], h1[t][m + 1], a1);
+    }
+    v[t][c] = y1[t][c] + (a0 + a1);
+  }
+  __syncthreads();
+  if (tid < T) layer_norm16(v[tid], a.g2, a.b2, a.ln_eps, xs[tid]);
+  __syncthreads();
+  float* dst = a.dst + (long)b * a.ws_dst;
+  float* up = a.up ? a.up + (long)b * a.ws_up : nullptr;
+  for (int idx = tid; idx < EQT_H * T; idx += NTH) {
+    const int c = idx / T, t = idx - c * T;
+    const float val = xs[t][c];
+    dst[(long)c * a.ls_dst + HALO + t] = val;
+    if (up) up[(long)c * a.ls_up + HALO + t] = val;
+    cur[c * 48 + t] = val;
+  }
+  __syncthreads();
+}
+
+__device__ void mid_pick(const PickBranchArgs& a, const int b, float* P, const float* cur) {
+  constexpr int NTH = MID_NTH;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  float(*xs)[EQT_H] = reinterpret_cast<float(*)[EQT_H]>(P);          // transformer output, [T][16]
+  float* gx = P + T * EQT_H;                                           // [2][T * 64]
+  float* hl = gx + 2 * T * 64;                                         // [2][16][48]
+  float(*x2)[EQT_H] = reinterpret_cast<float(*)[EQT_H]>(hl + 2 * 16 * 48);
+  float(*q)[KP] = reinterpret_cast<float(*)[KP]>(hl + 2 * 16 * 48 + T * EQT_H);
+  float(*k)[KP] = q + T;
+  float(*e)[48] = reinterpret_cast<float(*)[48]>(reinterpret_cast<float*>(k + T));
+  float(*v)[EQT_H] = reinterpret_cast<float(*)[EQT_H]>(reinterpret_cast<float*>(e + T));
+  static_assert(T * EQT_H + 2 * T * 64 + 2 * 16 * 48 + T * EQT_H + 2 * T * KP + T * 48 + T * EQT_H <= MID_POOL, "pick stage fits the pool");
+  for (int idx = tid; idx < EQT_H * T; idx += NTH) {
+    const int c = idx / T, t = idx - c * T;
+    xs[t][c] = cur[c * 48 + t];
+  }
+  __syncthreads();
+  lstm_project<EQT_H>(&xs[0][0], gx + (wave / MID_WPD) * T * 64, a.lstm[wave / MID_WPD], wave % MID_WPD, MID_WPD);  // first half of the waves: P
+  __syncthreads();
+  if (wave < 2) lstm_recur(gx + wave * T * 64, a.lstm[wave], false, hl + wave * 16 * 48, 48);
+  __syncthreads();
+  for (int br = 0; br < 2; ++br) {
+    for (int idx = tid; idx < T * EQT_H; idx += NTH) {
+      const int t = idx >> 4, c = idx & 15;
+      x2[t][c] = hl[(br * 16 + c) * 48 + t];
+    }
+    __syncthreads();
+    attention_core(x2, q, k, e, v, a.att[br], a.attn_eps, a.width);
+    float* up = a.up + (long)((1 + br) * a.B + b) * a.ws_up;
+    for (int idx = tid; idx < EQT_H * T; idx += NTH) {
+      const int c = idx / T, t = idx - c * T;
+      up[(long)c * a.ls_up + HALO + t] = v[t][c];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(MID_NTH) void eqt_mid_kernel(const MidArgs a) {
+  __shared__ __attribute__((aligned(16))) float P[MID_POOL];
+  __shared__ float cur[16 * 48];
+  const int b = blockIdx.x;
+  int stamp = 0;
+#define MID_STAMP()                                                                                   \
+  if (a.clk && threadIdx.x == 0) a.clk[(long)b * 8 + stamp] = __builtin_readcyclecounter();          \
+  ++stamp;
+  MID_STAMP()
+  mid_bilstm<64>(a.lstm[0], b, P, cur, true);
+  MID_STAMP()
+  mid_bilstm<EQT_H>(a.lstm[1], b, P, cur, false);
+  MID_STAMP()
+  mid_bilstm<EQT_H>(a.lstm[2], b, P, cur, false);
+  MID_STAMP()
+  mid_transformer(a.tr[0], b, P, cur);
+  MID_STAMP()
+  mid_transformer(a.tr[1], b, P, cur);
+  MID_STAMP()
+  mid_pick(a.pick, b, P, cur);
+  MID_STAMP()
+#undef MID_STAMP
+}
+
+int launch_eqt_mid(const MidArgs& a, int B, hipStream_t s) {
+  hipLaunchKernelGGL(eqt_mid_kernel, dim3(B), dim3(MID_NTH), 0, s, a);
   return 0;
 }
 
