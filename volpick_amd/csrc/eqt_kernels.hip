@@ -20,13 +20,17 @@ __device__ inline float wave_max64(float v) {
 __device__ inline float lane_bcast(float v, int lane) {  // lane is a compile-time constant
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
+// v_rcp_f32 (1 ulp).  __frcp_rn is the correctly rounded reciprocal: hipcc expands it to the full division sequence
+// (v_div_scale, v_rcp, four FMAs, v_div_fmas, v_div_fixup) — ten instructions on the critical path of every LSTM step
+// and of every element of the attention loop.
+__device__ inline float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ inline float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 // recurrent gates: v_exp_f32 + v_rcp_f32 (abs error ~1e-7); 47 dependent steps make this the critical path
-__device__ inline float sigmoid_fast(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ inline float sigmoid_fast(float x) { return rcp_fast(1.f + __expf(-x)); }
 // tanh via one exp; abs error ~1e-7, saturates correctly at +-inf
 __device__ inline float tanh_fast(float z) {
   const float t = __expf(2.f * z);
-  return 1.f - 2.f * __frcp_rn(t + 1.f);
+  return 1.f - 2.f * rcp_fast(t + 1.f);
 }
 
 // One LSTM direction on ONE wavefront.  Lane j owns gate row j (torch order i,f,g,o x 16
@@ -149,8 +153,8 @@ __device__ void attention_core(const float (*xs)[EQT_H], float (*q)[KP], float (
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int u = 0; u < 32; u += 2) {
-          s0 = fmaf(wa[u], __frcp_rn(fmaf(q[i][u], k[j][u], 1.f)), s0);
-          s1 = fmaf(wa[u + 1], __frcp_rn(fmaf(q[i][u + 1], k[j][u + 1], 1.f)), s1);
+          s0 = fmaf(wa[u], rcp_fast(fmaf(q[i][u], k[j][u], 1.f)), s0);
+          s1 = fmaf(wa[u + 1], rcp_fast(fmaf(q[i][u + 1], k[j][u + 1], 1.f)), s1);
         }
         e[i][j] = -2.f * (s0 + s1);  // = sum_u Wa[u] tanh(q + k) - sum_u Wa[u]
       }
