@@ -1,5 +1,6 @@
 // EQTransformer bottleneck kernels; see eqt_kernels.h.
 #include "eqt_kernels.h"
+#include "prepost.h"
 
 namespace vp {
 
@@ -7,16 +8,8 @@ namespace {
 
 constexpr int T = EQT_T;
 
-__device__ inline float wave_sum64(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ inline float wave_max64(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
+__device__ inline float wave_sum64(float v) { return wave_sum(v); }  // DPP reductions of prepost.h
+__device__ inline float wave_max64(float v) { return wave_max(v); }
 __device__ inline float lane_bcast(float v, int lane) {  // lane is a compile-time constant
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
@@ -166,13 +159,13 @@ __device__ void attention_core(const float (*xs)[EQT_H], float (*q)[KP], float (
     for (int i = wave; i < T; i += nw) {
       const float x = (lane < T) ? e[i][lane] : -INFINITY;
       const float m = wave_max64(x);
-      float ex = (lane < T) ? expf(x - m) : 0.f;
+      float ex = (lane < T) ? __expf(x - m) : 0.f;
       if (width > 0) {
         const int lower = lane - width / 2;  // mask[i][j] = lower_j <= i < lower_j + width
         if (!(lower <= i && i < lower + width)) ex = 0.f;
       }
       const float sum = wave_sum64(ex);
-      if (lane < T) e[i][lane] = ex / (sum + eps);
+      if (lane < T) e[i][lane] = ex * rcp_fast(sum + eps);
     }
   }
   __syncthreads();

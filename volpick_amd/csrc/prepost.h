@@ -29,17 +29,34 @@ int launch_gather_normalize(const PreArgs& a, int n_windows, hipStream_t stream)
 // predictions of flagged windows are overwritten with NaN: y[w][0 .. floats_per_window) for every w with flags[w] != 0.
 int launch_poison(float* y, const float* flags, int n_windows, long floats_per_window, hipStream_t stream);
 
+// Wavefront reductions on the DPP network (six VALU steps: xor 1, xor 2, half-row mirror, row mirror, row broadcast 15,
+// row broadcast 31, then lane 63 holds the result) instead of six ds_bpermute round trips through the LDS hardware
+// (~100 cycles each).  Every lane receives the result.
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_move(float v) {
+  const int x = __float_as_int(v);
+  return __int_as_float(__builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xF, false));
+}
 __device__ inline float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_move<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp_move<0x140, 0xF>(v);  // row_mirror: every lane of a row holds the row's sum
+  const float r1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1, 3
+  v += r1;
+  const float r2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2, 3
+  v += r2;
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ inline float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_move<0xB1, 0xF>(v));
+  v = fmaxf(v, dpp_move<0x4E, 0xF>(v));
+  v = fmaxf(v, dpp_move<0x141, 0xF>(v));
+  v = fmaxf(v, dpp_move<0x140, 0xF>(v));
+  v = fmaxf(v, dpp_move<0x142, 0xA>(v));  // lanes outside the row mask keep their own value
+  v = fmaxf(v, dpp_move<0x143, 0xC>(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-
 
 struct StackArgs {
   const float* pred;  // [n_windows][n_out][T]
