@@ -26,19 +26,28 @@ __device__ inline float tanh_fast(float z) {
   return 1.f - 2.f * rcp_fast(t + 1.f);
 }
 
-// One LSTM direction on ONE wavefront.  Lane j owns gate row j (torch order i,f,g,o x 16
-// units): its W_ih / W_hh rows sit in registers.  h_{t-1} is broadcast with v_readlane, the
-// four gates of a unit are gathered with three ds_bpermute shuffles, c/h are kept
-// redundantly in all four 16-lane groups.  xs: LDS [T][CIN]; gx: LDS [T][64] per-lane
+// One LSTM direction on ONE wavefront.  Every lane owns one gate row (layout below): its W_ih / W_hh rows sit in
+// registers.  h_{t-1} is broadcast with v_readlane, the four gates of a unit are gathered inside their quad, c/h are
+// kept redundantly in the four lanes of a quad.  xs: LDS [T][CIN]; gx: LDS [T][64] per-lane
 // scratch for the input projection; hout: LDS rows [16][hs].
+// LSTM lane layout: lane = 4 * unit + gate (torch gate order i, f, g, o), i.e. lane l owns gate row
+// (l & 3) * 16 + (l >> 2) of W_ih / W_hh / b.  The four gates of a unit sit in one quad, so gathering them is four DPP
+// quad broadcasts instead of four ds_bpermute round trips through the LDS hardware on every one of the 47 dependent steps.
+__device__ inline int lstm_row(int lane) { return (lane & 3) * 16 + (lane >> 2); }
+template <int SEL>
+__device__ inline float quad_bcast(float v) {  // value of lane SEL of the quad, in all four lanes
+  const int x = __float_as_int(v);
+  return __int_as_float(__builtin_amdgcn_update_dpp(x, x, SEL * 0x55, 0xF, 0xF, false));  // quad_perm [SEL,SEL,SEL,SEL]
+}
+
 // Input projection of one direction for the time steps t0, t0 + tstep, ... (any number of waves may share it).
 template <int CIN>
 __device__ void lstm_project(const float* xs, float* gx, const LstmWeights w, const int t0, const int tstep) {
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, row = lstm_row(lane);
   float wih[CIN];
 #pragma unroll
-  for (int c = 0; c < CIN; ++c) wih[c] = w.w_ih[lane * CIN + c];
-  const float b = w.b[lane];
+  for (int c = 0; c < CIN; ++c) wih[c] = w.w_ih[row * CIN + c];
+  const float b = w.b[row];
   for (int t = t0; t < T; t += tstep) {
     float a0 = b, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
@@ -53,34 +62,32 @@ __device__ void lstm_project(const float* xs, float* gx, const LstmWeights w, co
   }
 }
 
-// The 47 sequential steps of one direction on ONE wavefront (gx: its input projection).
+// The 47 sequential steps of one direction on ONE wavefront (gx: its input projection, same lane layout).
 __device__ void lstm_recur(const float* gx, const LstmWeights w, const bool reverse, float* hout, const int hs) {
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, row = lstm_row(lane);
   float whh[EQT_H];
 #pragma unroll
-  for (int u = 0; u < EQT_H; ++u) whh[u] = w.w_hh[lane * EQT_H + u];
-  const int u = lane & 15;
-  const bool is_g = (lane >> 4) == 2;
+  for (int u = 0; u < EQT_H; ++u) whh[u] = w.w_hh[row * EQT_H + u];
+  const bool is_g = (lane & 3) == 2;
   float h = 0.f, c = 0.f;
   for (int s = 0; s < T; ++s) {
     const int t = reverse ? T - 1 - s : s;
     float g0 = gx[t * 64 + lane], g1 = 0.f, g2 = 0.f, g3 = 0.f;
 #pragma unroll
-    for (int k = 0; k < EQT_H; k += 4) {
-      g0 = fmaf(whh[k], lane_bcast(h, k), g0);
-      g1 = fmaf(whh[k + 1], lane_bcast(h, k + 1), g1);
-      g2 = fmaf(whh[k + 2], lane_bcast(h, k + 2), g2);
-      g3 = fmaf(whh[k + 3], lane_bcast(h, k + 3), g3);
+    for (int k = 0; k < EQT_H; k += 4) {  // h of unit k lives in the quad 4k .. 4k + 3
+      g0 = fmaf(whh[k], lane_bcast(h, 4 * k), g0);
+      g1 = fmaf(whh[k + 1], lane_bcast(h, 4 * (k + 1)), g1);
+      g2 = fmaf(whh[k + 2], lane_bcast(h, 4 * (k + 2)), g2);
+      g3 = fmaf(whh[k + 3], lane_bcast(h, 4 * (k + 3)), g3);
     }
     const float g = (g0 + g1) + (g2 + g3);
     // tanh(g) = 2*sigmoid(2g) - 1: one exp + one rcp for every gate lane, no divergence
     const float sg = sigmoid_fast(is_g ? 2.f * g : g);
     const float act = is_g ? 2.f * sg - 1.f : sg;
-    const float ig = __shfl(act, u, 64), fg = __shfl(act, u + 16, 64);
-    const float gg = __shfl(act, u + 32, 64), og = __shfl(act, u + 48, 64);
+    const float ig = quad_bcast<0>(act), fg = quad_bcast<1>(act), gg = quad_bcast<2>(act), og = quad_bcast<3>(act);
     c = fmaf(fg, c, ig * gg);
     h = og * tanh_fast(c);
-    if (lane < EQT_H) hout[lane * hs + t] = h;
+    if ((lane & 3) == 0) hout[(lane >> 2) * hs + t] = h;
   }
 }
 
