@@ -202,9 +202,9 @@ __device__ inline void layer_norm16(const float* z, const float* gamma, const fl
 #pragma unroll
   for (int c = 0; c < EQT_H; ++c) var = fmaf(z[c] - mean, z[c] - mean, var);
   var = var * (1.f / EQT_H) + eps;
-  const float sd = sqrtf(var);
+  const float inv = 1.f / sqrtf(var);  // one division instead of sixteen
 #pragma unroll
-  for (int c = 0; c < EQT_H; ++c) out[c] = (z[c] - mean) / sd * gamma[c] + beta[c];
+  for (int c = 0; c < EQT_H; ++c) out[c] = (z[c] - mean) * inv * gamma[c] + beta[c];
 }
 
 }  // namespace
