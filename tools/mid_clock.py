@@ -22,9 +22,27 @@ for _ in range(3):
     m._forward_raw(x, preprocess=True)
 clk = np.zeros((B, 32), np.uint64)
 _lib.check(_lib.load().vp_debug_core_clock(m._handle, B, clk.ctypes.data_as(C.c_void_p)))
-c = clk.reshape(-1)[: B * 8].reshape(B, 8).astype(np.int64)
+c = clk.astype(np.int64)
 d = np.diff(c[:, :7], axis=1)
 names = ["bilstm.0", "bilstm.1", "bilstm.2", "transformer_d0", "transformer_d", "pick branches"]
 for n, v in zip(names, np.median(d, axis=0)):
     print(f"{n:16s} {v:9.0f} cycles")
 print("total", np.median(c[:, 6] - c[:, 0]))
+
+
+def seg(title, slots, labels):
+    print(title)
+    for (a, b), n in zip(zip(slots[:-1], slots[1:]), labels):
+        print(f"  {n:34s} {np.median(c[:, b] - c[:, a]):9.0f}")
+
+
+seg("bilstm.2 (stage start = slot 2)", [2, 8, 9, 10, 3],
+    ["load x", "input projection", "47 recurrent steps", "1x1 conv + BN + store"])
+seg("transformer_d (stage start = slot 4)", [4, 11, 20, 21, 22, 23, 24, 13, 14, 15, 16, 5],
+    ["load x", "q/k projection", "exp(2q), exp(2k)", "e = Wa . tanh", "softmax rows", "a . x", "LN1 + FF weights to LDS",
+     "FF1 16->128", "FF2 128->16", "LN2", "store"])
+seg("pick branches (stage start = slot 5)", [5, 17, 18, 19],
+    ["load x", "input projection (P and S)", "47 recurrent steps (P | S)"])
+seg("  S branch attention (band 3)", [26, 27, 28, 29, 30],
+    ["exp", "e", "softmax", "a . x"])
+print(f"  S branch total (x2 + q/k + attention + store) ~ {np.median(c[:, 6] - c[:, 19]) / 2:9.0f} per branch")

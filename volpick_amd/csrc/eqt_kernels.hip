@@ -104,7 +104,10 @@ __device__ void lstm_direction(const float* xs, float* gx, const LstmWeights w, 
 // The row max is taken over the FULL row before the band mask, as upstream does.
 constexpr int KP = 33;  // padded row of q/k: consecutive rows hit consecutive LDS banks
 __device__ void attention_core(const float (*xs)[EQT_H], float (*q)[KP], float (*k)[KP], float (*e)[48],
-                               float (*v)[EQT_H], const AttnWeights w, const float eps, const int width) {
+                               float (*v)[EQT_H], const AttnWeights w, const float eps, const int width,
+                               unsigned long long* sub = nullptr) {
+#define ATT_SUB(slot) \
+  if (sub && threadIdx.x == 0) sub[slot] = __builtin_readcyclecounter();
   const int tid = threadIdx.x, nt = blockDim.x;
   // tanh(q + k) = 1 - 2 / (exp(2q) exp(2k) + 1): with E_q = exp(2q), E_k = exp(2k) stored instead of q and k, the 47 x 47 x 32
   // inner loop needs ONE transcendental (v_rcp) per element instead of two (they issue at quarter rate and were 60 % of
@@ -124,6 +127,7 @@ __device__ void attention_core(const float (*xs)[EQT_H], float (*q)[KP], float (
     big |= !(fabsf(aq) <= 30.f) || !(fabsf(ak) <= 30.f);  // also catches NaN
   }
   const bool plain = __syncthreads_or(big);  // barrier: q / k complete
+  ATT_SUB(0)
   if (!plain) {
     for (int idx = tid; idx < T * 32; idx += nt) {
       const int t = idx >> 5, u = idx & 31;
@@ -132,6 +136,7 @@ __device__ void attention_core(const float (*xs)[EQT_H], float (*q)[KP], float (
     }
     __syncthreads();
   }
+  ATT_SUB(1)
   {
     float wa[32];
 #pragma unroll
@@ -161,6 +166,7 @@ __device__ void attention_core(const float (*xs)[EQT_H], float (*q)[KP], float (
     }
   }
   __syncthreads();
+  ATT_SUB(2)
   {
     const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     for (int i = wave; i < T; i += nw) {
@@ -176,6 +182,7 @@ __device__ void attention_core(const float (*xs)[EQT_H], float (*q)[KP], float (
     }
   }
   __syncthreads();
+  ATT_SUB(3)
   for (int idx = tid; idx < T * EQT_H; idx += nt) {
     const int i = idx >> 4, c = idx & 15;
     float acc = 0.f;
@@ -183,6 +190,8 @@ __device__ void attention_core(const float (*xs)[EQT_H], float (*q)[KP], float (
     v[i][c] = acc;
   }
   __syncthreads();
+  ATT_SUB(4)
+#undef ATT_SUB
 }
 
 __device__ inline void load_window_transposed(const float* src, int ls, float (*xs)[EQT_H]) {
@@ -362,8 +371,13 @@ constexpr int MID_NTH = 512;
 constexpr int MID_WPD = MID_NTH / 128;  // waves per LSTM direction in the input projections
 constexpr int MID_POOL = 16000;  // floats; the stages carve it up in turn
 
+// Debug clock stamps inside the stages (slots 8.. of the window's 32; the last caller of a stage wins).
+#define MID_SUB(slot) \
+  if (sub && threadIdx.x == 0) sub[slot] = __builtin_readcyclecounter();
+
 template <int CIN>
-__device__ void mid_bilstm(const BiLstmArgs& a, const int b, float* P, float* cur, const bool from_memory) {
+__device__ void mid_bilstm(const BiLstmArgs& a, const int b, float* P, float* cur, const bool from_memory,
+                           unsigned long long* sub) {
   const int tid = threadIdx.x, wave = tid >> 6;
   float* xs = P;                    // [T][CIN]
   float* gx = P + T * 64;           // [2][T * 64]
@@ -381,10 +395,13 @@ __device__ void mid_bilstm(const BiLstmArgs& a, const int b, float* P, float* cu
     }
   }
   __syncthreads();
+  MID_SUB(8)
   lstm_project<CIN>(xs, gx + (wave / MID_WPD) * T * 64, (wave / MID_WPD) ? a.bwd : a.fwd, wave % MID_WPD, MID_WPD);  // first half of the waves: fwd
   __syncthreads();
+  MID_SUB(9)
   if (wave < 2) lstm_recur(gx + wave * T * 64, wave ? a.bwd : a.fwd, wave == 1, hc + wave * 16 * 48, 48);
   __syncthreads();
+  MID_SUB(10)
   float* dst = a.dst + (long)b * a.ws_dst;
   for (int idx = tid; idx < EQT_H * T; idx += MID_NTH) {  // Conv1d(32,16,1) + BatchNorm, folded
     const int co = idx / T, t = idx - co * T;
@@ -397,7 +414,7 @@ __device__ void mid_bilstm(const BiLstmArgs& a, const int b, float* P, float* cu
   __syncthreads();
 }
 
-__device__ void mid_transformer(const TransformerArgs& a, const int b, float* P, float* cur) {
+__device__ void mid_transformer(const TransformerArgs& a, const int b, float* P, float* cur, unsigned long long* sub) {
   constexpr int NTH = MID_NTH;
   const int tid = threadIdx.x;
   float(*xs)[EQT_H] = reinterpret_cast<float(*)[EQT_H]>(P);
@@ -419,7 +436,9 @@ __device__ void mid_transformer(const TransformerArgs& a, const int b, float* P,
     xs[t][c] = cur[c * 48 + t];
   }
   __syncthreads();
-  attention_core(xs, q, k, e, v, a.att, a.attn_eps, 0);  // ends with a barrier: q / k / e are dead now
+  MID_SUB(11)
+  attention_core(xs, q, k, e, v, a.att, a.attn_eps, 0, sub ? sub + 20 : nullptr);  // ends with a barrier: q / k / e are dead now
+  MID_SUB(12)
   for (int i = tid; i < 128 * 16; i += NTH) {
     w1s[(i >> 4) * W1S + (i & 15)] = a.w1[i];
     w2s[(i >> 7) * W2S + (i & 127)] = a.w2[i];
@@ -431,6 +450,7 @@ __device__ void mid_transformer(const TransformerArgs& a, const int b, float* P,
     layer_norm16(z, a.g1, a.b1, a.ln_eps, y1[tid]);
   }
   __syncthreads();
+  MID_SUB(13)
   for (int idx = tid; idx < T * 128; idx += NTH) {  // FF: Linear(16,128) + ReLU
     const int t = idx >> 7, m = idx & 127;
     float acc = a.bb1[m];
@@ -439,6 +459,7 @@ __device__ void mid_transformer(const TransformerArgs& a, const int b, float* P,
     h1[t][m] = fmaxf(acc, 0.f);
   }
   __syncthreads();
+  MID_SUB(14)
   for (int idx = tid; idx < T * EQT_H; idx += NTH) {  // Linear(128,16) + residual
     const int t = idx >> 4, c = idx & 15;
     float a0 = a.bb2[c], a1 = 0.f;
@@ -450,8 +471,10 @@ __device__ void mid_transformer(const TransformerArgs& a, const int b, float* P,
     v[t][c] = y1[t][c] + (a0 + a1);
   }
   __syncthreads();
+  MID_SUB(15)
   if (tid < T) layer_norm16(v[tid], a.g2, a.b2, a.ln_eps, xs[tid]);
   __syncthreads();
+  MID_SUB(16)
   float* dst = a.dst + (long)b * a.ws_dst;
   float* up = a.up ? a.up + (long)b * a.ws_up : nullptr;
   for (int idx = tid; idx < EQT_H * T; idx += NTH) {
@@ -464,7 +487,7 @@ __device__ void mid_transformer(const TransformerArgs& a, const int b, float* P,
   __syncthreads();
 }
 
-__device__ void mid_pick(const PickBranchArgs& a, const int b, float* P, const float* cur) {
+__device__ void mid_pick(const PickBranchArgs& a, const int b, float* P, const float* cur, unsigned long long* sub) {
   constexpr int NTH = MID_NTH;
   const int tid = threadIdx.x, wave = tid >> 6;
   float(*xs)[EQT_H] = reinterpret_cast<float(*)[EQT_H]>(P);          // transformer output, [T][16]
@@ -481,17 +504,20 @@ __device__ void mid_pick(const PickBranchArgs& a, const int b, float* P, const f
     xs[t][c] = cur[c * 48 + t];
   }
   __syncthreads();
+  MID_SUB(17)
   lstm_project<EQT_H>(&xs[0][0], gx + (wave / MID_WPD) * T * 64, a.lstm[wave / MID_WPD], wave % MID_WPD, MID_WPD);  // first half of the waves: P
   __syncthreads();
+  MID_SUB(18)
   if (wave < 2) lstm_recur(gx + wave * T * 64, a.lstm[wave], false, hl + wave * 16 * 48, 48);
   __syncthreads();
+  MID_SUB(19)
   for (int br = 0; br < 2; ++br) {
     for (int idx = tid; idx < T * EQT_H; idx += NTH) {
       const int t = idx >> 4, c = idx & 15;
       x2[t][c] = hl[(br * 16 + c) * 48 + t];
     }
     __syncthreads();
-    attention_core(x2, q, k, e, v, a.att[br], a.attn_eps, a.width);
+    attention_core(x2, q, k, e, v, a.att[br], a.attn_eps, a.width, sub ? sub + 26 : nullptr);
     float* up = a.up + (long)((1 + br) * a.B + b) * a.ws_up;
     for (int idx = tid; idx < EQT_H * T; idx += NTH) {
       const int c = idx / T, t = idx - c * T;
@@ -506,21 +532,22 @@ __global__ __launch_bounds__(MID_NTH) void eqt_mid_kernel(const MidArgs a) {
   __shared__ float cur[16 * 48];
   const int b = blockIdx.x;
   int stamp = 0;
+  unsigned long long* sub = a.clk ? a.clk + (long)b * 32 : nullptr;
 #define MID_STAMP()                                                                                   \
-  if (a.clk && threadIdx.x == 0) a.clk[(long)b * 8 + stamp] = __builtin_readcyclecounter();          \
+  if (a.clk && threadIdx.x == 0) a.clk[(long)b * 32 + stamp] = __builtin_readcyclecounter();         \
   ++stamp;
   MID_STAMP()
-  mid_bilstm<64>(a.lstm[0], b, P, cur, true);
+  mid_bilstm<64>(a.lstm[0], b, P, cur, true, nullptr);
   MID_STAMP()
-  mid_bilstm<EQT_H>(a.lstm[1], b, P, cur, false);
+  mid_bilstm<EQT_H>(a.lstm[1], b, P, cur, false, nullptr);
   MID_STAMP()
-  mid_bilstm<EQT_H>(a.lstm[2], b, P, cur, false);
+  mid_bilstm<EQT_H>(a.lstm[2], b, P, cur, false, sub);
   MID_STAMP()
-  mid_transformer(a.tr[0], b, P, cur);
+  mid_transformer(a.tr[0], b, P, cur, nullptr);
   MID_STAMP()
-  mid_transformer(a.tr[1], b, P, cur);
+  mid_transformer(a.tr[1], b, P, cur, sub);
   MID_STAMP()
-  mid_pick(a.pick, b, P, cur);
+  mid_pick(a.pick, b, P, cur, sub);
   MID_STAMP()
 #undef MID_STAMP
 }
