@@ -36,13 +36,12 @@ def seg(title, slots, labels):
         print(f"  {n:34s} {np.median(c[:, b] - c[:, a]):9.0f}")
 
 
-seg("bilstm.2 (stage start = slot 2)", [2, 8, 9, 10, 3],
+seg("bilstm.0 (stage start = slot 0)", [0, 8, 9, 10, 1],
     ["load x", "input projection", "47 recurrent steps", "1x1 conv + BN + store"])
-seg("transformer_d (stage start = slot 4)", [4, 11, 20, 21, 22, 23, 24, 13, 14, 15, 16, 5],
-    ["load x", "q/k projection", "exp(2q), exp(2k)", "e = Wa . tanh", "softmax rows", "a . x", "LN1 + FF weights to LDS",
-     "FF1 16->128", "FF2 128->16", "LN2", "store"])
+seg("transformer_d (stage start = slot 4)", [4, 11, 21, 20, 22, 23, 24, 13, 14, 15, 16, 5],
+    ["-", "q/k projection + exp (MFMA)", "requests for the next stage issued", "e = Wa . tanh", "softmax rows", "a . x (MFMA)", "LN1",
+     "FF1 16->128 (MFMA)", "FF2 128->16 (MFMA)", "LN2 + store", "closing barrier"])
 seg("pick branches (stage start = slot 5)", [5, 17, 18, 19],
-    ["load x", "input projection (P and S)", "47 recurrent steps (P | S)"])
-seg("  S branch attention (band 3)", [26, 27, 28, 29, 30],
-    ["exp", "e", "softmax", "a . x"])
-print(f"  S branch total (x2 + q/k + attention + store) ~ {np.median(c[:, 6] - c[:, 19]) / 2:9.0f} per branch")
+    ["-", "weights + input projection (P and S, MFMA)", "47 recurrent steps (P | S)"])
+seg("  S branch attention (band 3)", [27, 28, 29, 30], ["e", "softmax", "a . x (MFMA)"])
+print(f"  per branch (q/k + attention + store) ~ {np.median(c[:, 6] - c[:, 19]) / 2:9.0f}")

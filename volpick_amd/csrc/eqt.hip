@@ -270,10 +270,12 @@ int plan_eqt(Net& net, const ParamView& pv) {
     const std::string p = tr_names[i];
     const int out = net.add_tensor(p, 16, EQT_T);
     AttnWeights aw = attn_weights(net, pv, p + ".attention.");
-    HostBlob* g1 = net.add_blob(vec(pv.get(p + ".norm1.gamma"), 16));
-    HostBlob* b1 = net.add_blob(vec(pv.get(p + ".norm1.beta"), 16));
-    HostBlob* g2 = net.add_blob(vec(pv.get(p + ".norm2.gamma"), 16));
-    HostBlob* b2 = net.add_blob(vec(pv.get(p + ".norm2.beta"), 16));
+    std::vector<float> ln4;  // gamma1 | beta1 | gamma2 | beta2 in ONE blob: eqt_mid_kernel fetches it as ln4[lane]
+    for (const char* nm : {".norm1.gamma", ".norm1.beta", ".norm2.gamma", ".norm2.beta"}) {
+      const std::vector<float> part = vec(pv.get(p + nm), 16);
+      ln4.insert(ln4.end(), part.begin(), part.end());
+    }
+    HostBlob* ln = net.add_blob(ln4);
     HostBlob* w1 = net.add_blob(vec(pv.get(p + ".ff.lin1.weight"), 128 * 16));
     HostBlob* bb1 = net.add_blob(vec(pv.get(p + ".ff.lin1.bias"), 128));
     HostBlob* w2 = net.add_blob(vec(pv.get(p + ".ff.lin2.weight"), 16 * 128));
@@ -301,10 +303,10 @@ int plan_eqt(Net& net, const ParamView& pv) {
         a.ws_up = (long)u.win_stride();
       }
       a.att = resolve(aw);
-      a.g1 = g1->d;
-      a.b1 = b1->d;
-      a.g2 = g2->d;
-      a.b2 = b2->d;
+      a.g1 = ln->d;
+      a.b1 = ln->d + 16;
+      a.g2 = ln->d + 32;
+      a.b2 = ln->d + 48;
       a.w1 = w1->d;
       a.bb1 = bb1->d;
       a.w2 = w2->d;

@@ -50,7 +50,7 @@ struct TransformerArgs {
   int ls_up;
   long ws_up;
   AttnWeights att;
-  const float *g1, *b1, *g2, *b2;  // LayerNormalization gamma/beta [16]
+  const float *g1, *b1, *g2, *b2;  // LayerNormalization gamma/beta [16]; contiguous: g1[0..64) = g1 | b1 | g2 | b2
   const float* w1;   // [128][16]
   const float* bb1;  // [128]
   const float* w2;   // [16][128]

@@ -1,6 +1,7 @@
 // EQTransformer bottleneck kernels; see eqt_kernels.h.
 #include "eqt_kernels.h"
 #include "prepost.h"
+#include "conv_valu.h"
 
 namespace vp {
 
@@ -63,23 +64,37 @@ __device__ void lstm_project(const float* xs, float* gx, const LstmWeights w, co
 }
 
 // The 47 sequential steps of one direction on ONE wavefront (gx: its input projection, same lane layout).
-__device__ void lstm_recur(const float* gx, const LstmWeights w, const bool reverse, float* hout, const int hs) {
-  const int lane = threadIdx.x & 63, row = lstm_row(lane);
-  float whh[EQT_H];
+// W_hh of the lane's gate row as the eight unit PAIRS the packed FMAs of the recurrence consume, in memory order:
+// the registers of the 16-byte loads are used as they arrive.  (As sixteen scalars hipcc re-paired them with v_mov
+// right behind the loads, i.e. waited for them at the point of issue -- which defeats requesting them a stage ahead.)
+__device__ inline void lstm_load_whh(f32x2 (&whh)[EQT_H / 2], const LstmWeights w) {
+  const int row = lstm_row(threadIdx.x & 63);
+  const f32x2* p = reinterpret_cast<const f32x2*>(w.w_hh + row * EQT_H);
 #pragma unroll
-  for (int u = 0; u < EQT_H; ++u) whh[u] = w.w_hh[row * EQT_H + u];
+  for (int j = 0; j < EQT_H / 2; ++j) whh[j] = p[j];
+}
+// GS: row stride of gx (64, or 65 where the projection writes it with lane = time step).
+template <int GS = 64>
+__device__ void lstm_recur(const float* gx, const f32x2 (&whh)[EQT_H / 2], const bool reverse, float* hout, const int hs) {
+  const int lane = threadIdx.x & 63;
   const bool is_g = (lane & 3) == 2;
   float h = 0.f, c = 0.f;
+  float gnext = gx[(reverse ? T - 1 : 0) * GS + lane];
   for (int s = 0; s < T; ++s) {
     const int t = reverse ? T - 1 - s : s;
-    float g0 = gx[t * 64 + lane], g1 = 0.f, g2 = 0.f, g3 = 0.f;
-#pragma unroll
-    for (int k = 0; k < EQT_H; k += 4) {  // h of unit k lives in the quad 4k .. 4k + 3
-      g0 = fmaf(whh[k], lane_bcast(h, 4 * k), g0);
-      g1 = fmaf(whh[k + 1], lane_bcast(h, 4 * (k + 1)), g1);
-      g2 = fmaf(whh[k + 2], lane_bcast(h, 4 * (k + 2)), g2);
-      g3 = fmaf(whh[k + 3], lane_bcast(h, 4 * (k + 3)), g3);
+    f32x2 ga = {gnext, 0.f}, gb = {0.f, 0.f};  // partial sums over the units = 0, 1 | 2, 3 (mod 4)
+    {  // the next step's input projection is on its way while this step computes (clamped: a harmless re-read at the end)
+      const int sn = s + 1 < T ? s + 1 : s;
+      gnext = gx[(reverse ? T - 1 - sn : sn) * GS + lane];
     }
+#pragma unroll
+    for (int j = 0; j < EQT_H / 2; j += 2) {  // h of unit u lives in the quad 4u .. 4u + 3
+      const f32x2 ha = {lane_bcast(h, 8 * j), lane_bcast(h, 8 * j + 4)};
+      const f32x2 hb = {lane_bcast(h, 8 * j + 8), lane_bcast(h, 8 * j + 12)};
+      ga = __builtin_elementwise_fma(whh[j], ha, ga);
+      gb = __builtin_elementwise_fma(whh[j + 1], hb, gb);
+    }
+    const float g0 = ga.x, g1 = ga.y, g2 = gb.x, g3 = gb.y;
     const float g = (g0 + g1) + (g2 + g3);
     // tanh(g) = 2*sigmoid(2g) - 1: one exp + one rcp for every gate lane, no divergence
     const float sg = sigmoid_fast(is_g ? 2.f * g : g);
@@ -94,8 +109,78 @@ __device__ void lstm_recur(const float* gx, const LstmWeights w, const bool reve
 template <int CIN>
 __device__ void lstm_direction(const float* xs, float* gx, const LstmWeights w, const bool reverse, float* hout,
                                const int hs) {
+  f32x2 whh[EQT_H / 2];
+  lstm_load_whh(whh, w);
   lstm_project<CIN>(xs, gx, w, 0, 1);
-  lstm_recur(gx, w, reverse, hout, hs);
+  lstm_recur(gx, whh, reverse, hout, hs);
+}
+
+// ---- small dense products of the middle stages on the matrix cores -------------------------------------------------
+// out[16 rows][16 cols] += A[16][K] B[K][16] with v_mfma_f32_16x16x4_f32: lane l holds A(row l % 16, k = 4 ks + l / 16),
+// B(k = 4 ks + l / 16, col l % 16) and, of the result, rows 4 (l / 16) + 0..3 of column l % 16.  The activations of
+// a window sit in LDS as [channel][48] rows (columns = time steps; column 47 is padding and only ever feeds output
+// column 47, which nobody stores), the weights come per lane from memory, four loads per 16 input channels.
+// The K index a lane group g = l / 16 covers in step ks is g * KS + ks (any bijection serves, A and B only have to
+// agree): the KS weights of a lane are then contiguous in a row-major matrix and come as 16-byte loads -- 4x fewer
+// memory instructions and cache-line touches than the canonical 4 ks + g, which matters because a stage requests
+// ~40 registers of operands per lane in one burst.
+template <int KS>
+__device__ __forceinline__ void mfma_load_a(float (&a)[KS], const float* w, const int row_stride) {  // K contiguous
+  static_assert(KS % 4 == 0, "16-byte loads");
+  const int lane = threadIdx.x & 63;
+  const float4* p = reinterpret_cast<const float4*>(w + (lane & 15) * row_stride + (lane >> 4) * KS);
+#pragma unroll
+  for (int i = 0; i < KS / 4; ++i) {
+    const float4 v = p[i];
+    a[4 * i] = v.x, a[4 * i + 1] = v.y, a[4 * i + 2] = v.z, a[4 * i + 3] = v.w;
+  }
+}
+template <int KS>
+__device__ __forceinline__ void mfma_load_a_t(float (&a)[KS], const float* w, const int k_stride) {  // rows contiguous
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) a[ks] = w[(lane & 15) + ((lane >> 4) * KS + ks) * k_stride];
+}
+__device__ __forceinline__ void load4(float (&v)[4], const float* p) {  // p 16-byte aligned
+  const float4 q = *reinterpret_cast<const float4*>(p);
+  v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+}
+template <int KS>
+__device__ __forceinline__ f32x4 mfma_tile(const float (&a)[KS], const float* b, const int bs, const int n0, f32x4 acc) {
+  const int lane = threadIdx.x & 63;
+  const float* bp = b + (lane >> 4) * KS * bs + n0 + (lane & 15);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bp[ks * bs], acc, 0, 0, 0);
+  return acc;
+}
+
+// Input projection of one gate block (16 torch rows q * 16 .. of W_ih, i.e. gate q of every unit) for all time steps:
+// gx[t][lane of (unit, gate q) in lstm_recur] = b + W_ih x_t.  xs: [CIN][48] in LDS.
+constexpr int GXS = 65;  // gx row stride: the stores of a tile spread over the banks
+template <int CIN>
+struct ProjFrag {
+  float a[CIN / 4];
+  float bias[4];
+};
+template <int CIN>
+__device__ __forceinline__ void lstm_project_load(ProjFrag<CIN>& f, const LstmWeights w, const int q) {
+  const int lane = threadIdx.x & 63;
+  mfma_load_a<CIN / 4>(f.a, w.w_ih + q * 16 * CIN, CIN);
+  load4(f.bias, w.b + q * 16 + 4 * (lane >> 4));
+}
+template <int CIN>
+__device__ __forceinline__ void lstm_project_mfma(const ProjFrag<CIN>& f, const float* xs, float* gx, const int q) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt) {
+    f32x4 acc = {f.bias[0], f.bias[1], f.bias[2], f.bias[3]};
+    acc = mfma_tile<CIN / 4>(f.a, xs, 48, 16 * nt, acc);
+    const int t = 16 * nt + (lane & 15);
+    if (t < T) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gx[t * GXS + 4 * (4 * (lane >> 4) + r) + q] = acc[r];
+    }
+  }
 }
 
 // Additive self-attention on one window held in LDS (SeisBench SeqSelfAttention):
@@ -103,16 +188,81 @@ __device__ void lstm_direction(const float* xs, float* gx, const LstmWeights w, 
 //   a = exp(e - rowmax) [band mask] / (sum + eps),  v = a x.
 // The row max is taken over the FULL row before the band mask, as upstream does.
 constexpr int KP = 33;  // padded row of q/k: consecutive rows hit consecutive LDS banks
-__device__ void attention_core(const float (*xs)[EQT_H], float (*q)[KP], float (*k)[KP], float (*e)[48],
-                               float (*v)[EQT_H], const AttnWeights w, const float eps, const int width,
-                               unsigned long long* sub = nullptr) {
-#define ATT_SUB(slot) \
-  if (sub && threadIdx.x == 0) sub[slot] = __builtin_readcyclecounter();
+// wa_lane = Wa[lane & 31], requested long before: the 32 weights become wave-uniform operands
+__device__ __forceinline__ void attn_wa(float (&wa)[32], const float wa_lane) {
+#pragma unroll
+  for (int u = 0; u < 32; ++u) wa[u] = lane_bcast(wa_lane, u);
+}
+// e[i * ES + j] = sum_u Wa[u] tanh(q_i[u] + k_j[u]) up to a constant per row (it cancels in e - rowmax).
+// tanh(q + k) = 1 - 2 / (exp(2q) exp(2k) + 1): with E_q = exp(2q), E_k = exp(2k) stored instead of q and k (plain = false) the
+// 47 x 47 x 32 inner loop needs ONE transcendental (v_rcp) per element instead of two (they issue at quarter rate and
+// were 60 % of its cycles), and the constant sum_u Wa[u] drops out.  plain = true: q, k hold the raw projections.
+template <int ES>
+__device__ __forceinline__ void attn_scores(const float (*q)[KP], const float (*k)[KP], float* e, const float (&wa)[32], const bool plain) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  // tanh(q + k) = 1 - 2 / (exp(2q) exp(2k) + 1): with E_q = exp(2q), E_k = exp(2k) stored instead of q and k, the 47 x 47 x 32
-  // inner loop needs ONE transcendental (v_rcp) per element instead of two (they issue at quarter rate and were 60 % of
-  // its cycles), and the constant sum_u Wa[u] drops out of e - rowmax.  Guard: |q|, |k| <= 30 (E within 1e+-26, no
-  // inf x 0); a window beyond that takes the plain form.
+  if (plain) {
+    for (int idx = tid; idx < T * T; idx += nt) {
+      const int i = idx / T, j = idx - i * T;
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int u = 0; u < 32; u += 2) {
+        s0 = fmaf(wa[u], tanh_fast(q[i][u] + k[j][u]), s0);
+        s1 = fmaf(wa[u + 1], tanh_fast(q[i][u + 1] + k[j][u + 1]), s1);
+      }
+      e[i * ES + j] = s0 + s1;
+    }
+  } else {
+    for (int idx = tid; idx < T * T; idx += nt) {
+      const int i = idx / T, j = idx - i * T;
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int u = 0; u < 32; u += 2) {
+        s0 = fmaf(wa[u], rcp_fast(fmaf(q[i][u], k[j][u], 1.f)), s0);
+        s1 = fmaf(wa[u + 1], rcp_fast(fmaf(q[i][u + 1], k[j][u + 1], 1.f)), s1);
+      }
+      e[i * ES + j] = -2.f * (s0 + s1);  // = sum_u Wa[u] tanh(q + k) - sum_u Wa[u]
+    }
+  }
+}
+
+// a = exp(e - rowmax) [band mask] / (sum + eps), in place; the row max is taken over the FULL row before the band
+// mask, as upstream does.  ZERO_PAD: column 47 of every row is set to 0 (the K padding of the matrix-core a.x).
+template <int ES, bool ZERO_PAD>
+__device__ __forceinline__ void attn_softmax(float* e, const float eps, const int width) {
+  // three rows per trip: their reductions are independent chains the scheduler interleaves
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  constexpr int R = 3;
+  const int lower = lane - width / 2;  // mask[i][j] = lower_j <= i < lower_j + width
+  for (int i0 = wave; i0 < T; i0 += R * nw) {
+    float x[R], m[R], ex[R], sum[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = i0 + r * nw;
+      x[r] = (lane < T && i < T) ? e[i * ES + lane] : -INFINITY;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) m[r] = wave_max64(x[r]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = i0 + r * nw;
+      ex[r] = (lane < T && i < T) ? __expf(x[r] - m[r]) : 0.f;
+      if (width > 0 && !(lower <= i && i < lower + width)) ex[r] = 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) sum[r] = wave_sum64(ex[r]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = i0 + r * nw;
+      if (lane < (ZERO_PAD ? T + 1 : T) && i < T) e[i * ES + lane] = ex[r] * rcp_fast(sum[r] + eps);  // ex = 0 in lane 47
+    }
+  }
+}
+
+__device__ void attention_core(const float (*xs)[EQT_H], float (*q)[KP], float (*k)[KP], float (*e)[48],
+                               float (*v)[EQT_H], const AttnWeights w, const float eps, const int width) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const float wa_lane = w.Wa[tid & 31];
+  // Guard of the E_q E_k form: |q|, |k| <= 30 (E within 1e+-26, no inf x 0); a window beyond that takes the plain form.
   bool big = false;
   for (int idx = tid; idx < T * 32; idx += nt) {
     const int t = idx >> 5, u = idx & 31;
@@ -127,7 +277,6 @@ __device__ void attention_core(const float (*xs)[EQT_H], float (*q)[KP], float (
     big |= !(fabsf(aq) <= 30.f) || !(fabsf(ak) <= 30.f);  // also catches NaN
   }
   const bool plain = __syncthreads_or(big);  // barrier: q / k complete
-  ATT_SUB(0)
   if (!plain) {
     for (int idx = tid; idx < T * 32; idx += nt) {
       const int t = idx >> 5, u = idx & 31;
@@ -136,58 +285,104 @@ __device__ void attention_core(const float (*xs)[EQT_H], float (*q)[KP], float (
     }
     __syncthreads();
   }
-  ATT_SUB(1)
-  {
-    float wa[32];
-#pragma unroll
-    for (int u = 0; u < 32; ++u) wa[u] = w.Wa[u];
-    if (plain) {
-      for (int idx = tid; idx < T * T; idx += nt) {
-        const int i = idx / T, j = idx - i * T;
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int u = 0; u < 32; u += 2) {
-          s0 = fmaf(wa[u], tanh_fast(q[i][u] + k[j][u]), s0);
-          s1 = fmaf(wa[u + 1], tanh_fast(q[i][u + 1] + k[j][u + 1]), s1);
-        }
-        e[i][j] = s0 + s1;
-      }
-    } else {
-      for (int idx = tid; idx < T * T; idx += nt) {
-        const int i = idx / T, j = idx - i * T;
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int u = 0; u < 32; u += 2) {
-          s0 = fmaf(wa[u], rcp_fast(fmaf(q[i][u], k[j][u], 1.f)), s0);
-          s1 = fmaf(wa[u + 1], rcp_fast(fmaf(q[i][u + 1], k[j][u + 1], 1.f)), s1);
-        }
-        e[i][j] = -2.f * (s0 + s1);  // = sum_u Wa[u] tanh(q + k) - sum_u Wa[u]
-      }
-    }
-  }
+  float wa[32];
+  attn_wa(wa, wa_lane);
+  attn_scores<48>(q, k, &e[0][0], wa, plain);
   __syncthreads();
-  ATT_SUB(2)
-  {
-    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
-    for (int i = wave; i < T; i += nw) {
-      const float x = (lane < T) ? e[i][lane] : -INFINITY;
-      const float m = wave_max64(x);
-      float ex = (lane < T) ? __expf(x - m) : 0.f;
-      if (width > 0) {
-        const int lower = lane - width / 2;  // mask[i][j] = lower_j <= i < lower_j + width
-        if (!(lower <= i && i < lower + width)) ex = 0.f;
-      }
-      const float sum = wave_sum64(ex);
-      if (lane < T) e[i][lane] = ex * rcp_fast(sum + eps);
-    }
-  }
+  attn_softmax<48, false>(&e[0][0], eps, width);
   __syncthreads();
-  ATT_SUB(3)
   for (int idx = tid; idx < T * EQT_H; idx += nt) {
     const int i = idx >> 4, c = idx & 15;
     float acc = 0.f;
-    for (int j = 0; j < T; ++j) acc = fmaf(e[i][j], xs[j][c], acc);
+    // banded attention: a[i][j] is exactly 0 outside j in [i - (width - 1 - width / 2), i + width / 2]
+    const int j0 = width > 0 ? max(0, i - (width - 1 - width / 2)) : 0, j1 = width > 0 ? min(T - 1, i + width / 2) : T - 1;
+    for (int j = j0; j <= j1; ++j) acc = fmaf(e[i][j], xs[j][c], acc);
     v[i][c] = acc;
+  }
+  __syncthreads();
+}
+
+// The attention of the fused kernel: every dense product on the matrix cores, activations as [channel][48] rows.
+//   x:  [16][48] input rows (column 47 must be finite: it meets the zero column of a in the a.x product)
+//   vT: [16][48] result rows,  q, k: [T][KP],  e: [T][AES]
+constexpr int AES = 49;  // row stride of e: the B fragments of a.x (lane -> row) spread over the banks
+struct AttnFrag {
+  float a[4], bias[4];
+};
+// fragments of the q / k projection of this wave: m-tile mt = wave & 3 (q rows 0-15, 16-31, k rows 0-15, 16-31)
+__device__ __forceinline__ void attn_load(AttnFrag& f, const AttnWeights w) {
+  const int lane = threadIdx.x & 63, mt = (threadIdx.x >> 6) & 3;
+  mfma_load_a_t<4>(f.a, (mt < 2 ? w.Wt : w.Wx) + 16 * (mt & 1), 32);
+  // loaded unconditionally (q rows ignore it at use): a select on a loaded value would make the wave wait for the
+  // load right here, at the point that exists to leave it in flight
+  load4(f.bias, w.bh + 16 * (mt & 1) + 4 * (lane >> 4));
+}
+struct NoPrefetch {
+  __device__ void operator()() const {}
+};
+// `prefetch` runs at the start of the score loop, the longest stretch of pure arithmetic of the stage: the caller
+// requests the NEXT stage's weights there.
+template <class Prefetch>
+__device__ void mid_attention(const AttnFrag& f, const float wa_lane, const float* x, float (*q)[KP], float (*k)[KP],
+                              float* e, float* vT, const float eps, const int width, Prefetch&& prefetch,
+                              unsigned long long* sub) {
+#define ATT_SUB(slot) \
+  if (sub && threadIdx.x == 0) sub[slot] = __builtin_readcyclecounter();
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  {  // q / k projection: waves 0-3 take the column tiles 0 and 1 of their m-tile, waves 4-7 tile 2
+    const int mt = wave & 3;
+    float(*dstp)[KP] = mt < 2 ? q : k;
+    f32x4 acc[2];
+    const int ntiles = wave < 4 ? 2 : 1, nt0 = wave < 4 ? 0 : 2;
+    bool big = false;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      acc[n] = mt < 2 ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{f.bias[0], f.bias[1], f.bias[2], f.bias[3]};  // bh belongs to k
+      if (n < ntiles) {
+        acc[n] = mfma_tile<4>(f.a, x, 48, 16 * (nt0 + n), acc[n]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) big |= !(fabsf(acc[n][r]) <= 30.f) && (16 * (nt0 + n) + (lane & 15) < T);
+      }
+    }
+    const bool plain = __syncthreads_or(big);  // only the vote: nothing has been written yet
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int t = 16 * (nt0 + n) + (lane & 15);
+      if (n < ntiles && t < T) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          dstp[t][16 * (mt & 1) + 4 * (lane >> 4) + r] = plain ? acc[n][r] : __expf(2.f * acc[n][r]);
+      }
+    }
+    __syncthreads();
+    ATT_SUB(1)
+    // Loads complete in order: whatever the wave still needs from EARLIER requests is taken out of its registers
+    // before the new requests go out, or its first use would wait for them as well.
+    float wa[32];
+    attn_wa(wa, wa_lane);
+    __builtin_amdgcn_sched_barrier(0);
+    prefetch();
+    __builtin_amdgcn_sched_barrier(0);
+    ATT_SUB(0)
+    attn_scores<AES>(q, k, e, wa, plain);
+  }
+  __syncthreads();
+  ATT_SUB(2)
+  attn_softmax<AES, true>(e, eps, width);
+  __syncthreads();
+  ATT_SUB(3)
+  if (wave < 3) {  // vT[c][i] = sum_j x[c][j] a[i][j]: A = x rows out of LDS, B(k = j, n = i) = a[i][j]
+    const int n0 = 16 * wave;
+    const float* ap = x + (lane & 15) * 48 + (lane >> 4) * 12;       // K index of (lane group g, step ks) = 12 g + ks
+    const float* bp = e + (n0 + (lane & 15)) * AES + (lane >> 4) * 12;  // rows 47 .. of the last tile: stale data, column never stored
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[ks], bp[ks], acc, 0, 0, 0);
+    const int i = n0 + (lane & 15);
+    if (i < T) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vT[(4 * (lane >> 4) + r) * 48 + i] = acc[r];
+    }
   }
   __syncthreads();
   ATT_SUB(4)
@@ -368,160 +563,251 @@ int launch_pick_branch(const PickBranchArgs& a, hipStream_t s) {
 // are spread over all waves instead of running in front of the recurrence on its one wave, the two pick LSTMs run
 // side by side, and five kernel boundaries are gone.
 constexpr int MID_NTH = 512;
-constexpr int MID_WPD = MID_NTH / 128;  // waves per LSTM direction in the input projections
 constexpr int MID_POOL = 16000;  // floats; the stages carve it up in turn
 
 // Debug clock stamps inside the stages (slots 8.. of the window's 32; the last caller of a stage wins).
 #define MID_SUB(slot) \
   if (sub && threadIdx.x == 0) sub[slot] = __builtin_readcyclecounter();
 
+// The operands a stage reads from memory, as registers: requested one stage ahead (under the 47 sequential LSTM steps
+// or the attention score loop of the stage before), so that no stage but the first waits for memory.
 template <int CIN>
-__device__ void mid_bilstm(const BiLstmArgs& a, const int b, float* P, float* cur, const bool from_memory,
-                           unsigned long long* sub) {
-  const int tid = threadIdx.x, wave = tid >> 6;
-  float* xs = P;                    // [T][CIN]
-  float* gx = P + T * 64;           // [2][T * 64]
-  float* hc = P + 3 * T * 64;       // [32][48]
-  if (from_memory) {
-    const float* src = a.src + (long)b * a.ws_src;
-    for (int idx = tid; idx < CIN * T; idx += MID_NTH) {
-      const int c = idx / T, t = idx - c * T;
-      xs[t * CIN + c] = src[(long)c * a.ls_src + HALO + t];
+struct BiFrags {
+  ProjFrag<CIN> f;      // wave = (direction, gate block)
+  f32x2 whh[EQT_H / 2];  // waves 0, 1: the recurrence of the forward / backward direction
+  float ac[8], bcv[4];  // waves 2-4: the three column tiles of Conv1d(32,16,1)
+};
+template <int CIN>
+__device__ __forceinline__ void bi_load(BiFrags<CIN>& g, const BiLstmArgs& a) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // no branches (waves that do not need an operand fetch it anyway): in one basic block the reads of the argument
+  // block cluster into a single wait; behind wave-dependent branches they serialised, ~1 k cycles apiece
+  lstm_project_load<CIN>(g.f, (wave >> 2) ? a.bwd : a.fwd, wave & 3);
+  lstm_load_whh(g.whh, (wave & 1) ? a.bwd : a.fwd);
+  mfma_load_a<8>(g.ac, a.wc, 32);
+  load4(g.bcv, a.bc + 4 * (lane >> 4));
+}
+
+template <int CIN, class Prefetch>
+__device__ void mid_bilstm(const BiLstmArgs& a, BiFrags<CIN>& g, const int b, float* P, float* cur,
+                           const bool from_memory, Prefetch&& prefetch, unsigned long long* sub) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* gx = P;                    // [2][T * GXS]
+  float* hc = P + 2 * T * GXS;      // [32][48]
+  float* xs = hc + 32 * 48;         // [CIN][48], first stage only (later stages read `cur`)
+  static_assert(2 * T * GXS + 32 * 48 + 64 * 48 <= MID_POOL, "BiLSTM stage fits the pool");
+  static_assert(MID_NTH == 512, "eight waves: one gate block of one direction each");
+  const int dir = wave >> 2, q = wave & 3;
+  const float* x = cur;
+  if (from_memory) {  // first stage: the window's own rows first (loads return in order), then its weights
+    constexpr int NX = (CIN * T + MID_NTH - 1) / MID_NTH;
+    float xr[NX];
+    const float* src = a.src + (long)b * a.ws_src + HALO;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int idx = tid + k * MID_NTH, c = idx / T, t = idx - c * T;
+      xr[k] = idx < CIN * T ? src[(long)c * a.ls_src + t] : 0.f;
     }
-  } else {
-    for (int idx = tid; idx < CIN * T; idx += MID_NTH) {
-      const int c = idx / T, t = idx - c * T;
-      xs[t * CIN + c] = cur[c * 48 + t];
+    bi_load<CIN>(g, a);
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      const int idx = tid + k * MID_NTH, c = idx / T, t = idx - c * T;
+      if (idx < CIN * T) xs[c * 48 + t] = xr[k];
     }
+    lds_barrier();  // not __syncthreads(): the weight loads stay in flight
+    x = xs;
   }
-  __syncthreads();
   MID_SUB(8)
-  lstm_project<CIN>(xs, gx + (wave / MID_WPD) * T * 64, (wave / MID_WPD) ? a.bwd : a.fwd, wave % MID_WPD, MID_WPD);  // first half of the waves: fwd
+  lstm_project_mfma<CIN>(g.f, x, gx + dir * T * GXS, q);
   __syncthreads();
   MID_SUB(9)
-  if (wave < 2) lstm_recur(gx + wave * T * 64, wave ? a.bwd : a.fwd, wave == 1, hc + wave * 16 * 48, 48);
+  if (wave < 2) {  // W_hh has arrived long ago; say so before the new requests queue up behind it (loads complete in order)
+#pragma unroll
+    for (int j = 0; j < EQT_H / 2; ++j) asm volatile("" ::"v"(g.whh[j]));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  prefetch();
+  __builtin_amdgcn_sched_barrier(0);
+  if (wave < 2) lstm_recur<GXS>(gx + wave * T * GXS, g.whh, wave == 1, hc + wave * 16 * 48, 48);
   __syncthreads();
   MID_SUB(10)
-  float* dst = a.dst + (long)b * a.ws_dst;
-  for (int idx = tid; idx < EQT_H * T; idx += MID_NTH) {  // Conv1d(32,16,1) + BatchNorm, folded
-    const int co = idx / T, t = idx - co * T;
-    float acc = a.bc[co];
+  if (wave >= 2 && wave < 5) {  // Conv1d(32,16,1) + BatchNorm, folded
+    float* dst = a.dst + (long)b * a.ws_dst;
+    const int n0 = 16 * (wave - 2), t = n0 + (lane & 15);
+    f32x4 acc = {g.bcv[0], g.bcv[1], g.bcv[2], g.bcv[3]};
+    acc = mfma_tile<8>(g.ac, hc, 48, n0, acc);
+    if (t < T) {
 #pragma unroll
-    for (int c = 0; c < 32; ++c) acc = fmaf(a.wc[co * 32 + c], hc[c * 48 + t], acc);
-    dst[(long)co * a.ls_dst + HALO + t] = acc;
-    cur[co * 48 + t] = acc;
+      for (int r = 0; r < 4; ++r) {
+        const int co = 4 * (lane >> 4) + r;
+        dst[(long)co * a.ls_dst + HALO + t] = acc[r];
+        cur[co * 48 + t] = acc[r];
+      }
+    }
   }
   __syncthreads();
 }
 
-__device__ void mid_transformer(const TransformerArgs& a, const int b, float* P, float* cur, unsigned long long* sub) {
-  constexpr int NTH = MID_NTH;
-  const int tid = threadIdx.x;
-  float(*xs)[EQT_H] = reinterpret_cast<float(*)[EQT_H]>(P);
-  constexpr int POOL = 2 * T * KP + T * 48;
-  constexpr int W1S = 17, W2S = 129;
-  static_assert(128 * W1S + EQT_H * W2S <= POOL, "feed-forward weights must fit the attention scratch");
-  float* pool = P + T * EQT_H;
-  float(*q)[KP] = reinterpret_cast<float(*)[KP]>(pool);
-  float(*k)[KP] = reinterpret_cast<float(*)[KP]>(pool + T * KP);
-  float(*e)[48] = reinterpret_cast<float(*)[48]>(pool + 2 * T * KP);
-  float* w1s = pool;
-  float* w2s = pool + 128 * W1S;
-  float(*v)[EQT_H] = reinterpret_cast<float(*)[EQT_H]>(pool + POOL);
-  float(*y1)[EQT_H] = reinterpret_cast<float(*)[EQT_H]>(pool + POOL + T * EQT_H);
-  float(*h1)[128] = reinterpret_cast<float(*)[128]>(pool + POOL + 2 * T * EQT_H);
-  static_assert(T * EQT_H + POOL + 2 * T * EQT_H + T * 128 <= MID_POOL, "transformer stage fits the pool");
-  for (int idx = tid; idx < EQT_H * T; idx += NTH) {
-    const int c = idx / T, t = idx - c * T;
-    xs[t][c] = cur[c * 48 + t];
-  }
-  __syncthreads();
+// LayerNormalization of the 16 channels of column t = lane, gamma / beta as lanes of `par` (gamma at lane G0 + c, beta at
+// G0 + 16 + c): z in, normalised values out, arithmetic of layer_norm16.
+template <int G0>
+__device__ __forceinline__ void layer_norm_lane(float (&z)[EQT_H], const float par, const float eps) {
+  float mean = 0.f;
+#pragma unroll
+  for (int c = 0; c < EQT_H; ++c) mean += z[c];
+  mean *= (1.f / EQT_H);
+  float var = 0.f;
+#pragma unroll
+  for (int c = 0; c < EQT_H; ++c) var = fmaf(z[c] - mean, z[c] - mean, var);
+  var = var * (1.f / EQT_H) + eps;
+  const float inv = 1.f / sqrtf(var);
+#pragma unroll
+  for (int c = 0; c < EQT_H; ++c) z[c] = (z[c] - mean) * inv * lane_bcast(par, G0 + c) + lane_bcast(par, G0 + 16 + c);
+}
+
+struct TrFrags {
+  AttnFrag af;
+  float wa_lane, ln_par;
+  float a1[4], b1v[4];   // Linear(16,128): m-tile = wave
+  float a2[16], b2v[4];  // Linear(128,16): waves 0-5 = (column tile, K half)
+};
+// early: what the stage needs up to its score loop and right after it (requested during the stage before);
+// late: the operands of its last phases, requested by the stage itself at the start of its score loop -- fewer
+// registers are live across that loop than with everything fetched a stage ahead.
+__device__ __forceinline__ void tr_load_early(TrFrags& g, const TransformerArgs& a) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  attn_load(g.af, a.att);
+  g.wa_lane = a.att.Wa[lane & 31];
+  mfma_load_a<4>(g.a1, a.w1 + wave * 16 * EQT_H, EQT_H);
+  load4(g.b1v, a.bb1 + 16 * wave + 4 * (lane >> 4));
+}
+__device__ __forceinline__ void tr_load_late(TrFrags& g, const TransformerArgs& a) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  g.ln_par = a.g1[lane];  // g1 | b1 | g2 | b2 are one blob (eqt_kernels.h)
+  const int half = wave >= 3;
+  mfma_load_a<16>(g.a2, a.w2 + 64 * half, 128);  // waves 6, 7 too: no branch, see bi_load
+  load4(g.b2v, a.bb2 + 4 * (lane >> 4));           // the second K half ignores it at use
+}
+
+template <class Prefetch>
+__device__ void mid_transformer(const TransformerArgs& a, TrFrags& g, const int b, float* P, float* cur,
+                                Prefetch&& prefetch, unsigned long long* sub) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float(*q)[KP] = reinterpret_cast<float(*)[KP]>(P);
+  float(*k)[KP] = q + T;
+  float* e = P + 2 * T * KP;        // [48][AES]
+  float* vT = e + 48 * AES;         // [16][48] attention output
+  float* y1T = vT + 16 * 48;        // [16][48] LN1 output
+  float* h1T = y1T + 16 * 48;       // [128][48] hidden layer
+  float* rT = h1T + 128 * 48;       // [2][16][48] the two K halves of the second linear layer
+  static_assert(2 * T * KP + 48 * AES + 2 * 16 * 48 + 128 * 48 + 2 * 16 * 48 <= MID_POOL, "transformer stage fits the pool");
+  const int half = wave >= 3, nt2 = wave - 3 * half;
+  const float (&a1)[4] = g.a1, (&b1v)[4] = g.b1v, (&a2)[16] = g.a2, (&b2v)[4] = g.b2v;
   MID_SUB(11)
-  attention_core(xs, q, k, e, v, a.att, a.attn_eps, 0, sub ? sub + 20 : nullptr);  // ends with a barrier: q / k / e are dead now
+  mid_attention(g.af, g.wa_lane, cur, q, k, e, vT, a.attn_eps, 0,
+                [&] {
+                  tr_load_late(g, a);
+                  prefetch();
+                },
+                sub ? sub + 20 : nullptr);
+  const float ln_par = g.ln_par;
   MID_SUB(12)
-  for (int i = tid; i < 128 * 16; i += NTH) {
-    w1s[(i >> 4) * W1S + (i & 15)] = a.w1[i];
-    w2s[(i >> 7) * W2S + (i & 127)] = a.w2[i];
-  }
-  if (tid < T) {  // y1 = LN1(x + attention(x))
+  const int t = lane;
+  if (wave == 0) {  // y1 = LN1(x + attention(x)), lane = time step (lane 47..: padding columns, finite or not, never stored)
     float z[EQT_H];
 #pragma unroll
-    for (int c = 0; c < EQT_H; ++c) z[c] = xs[tid][c] + v[tid][c];
-    layer_norm16(z, a.g1, a.b1, a.ln_eps, y1[tid]);
+    for (int c = 0; c < EQT_H; ++c) z[c] = t < 48 ? cur[c * 48 + t] + vT[c * 48 + t] : 0.f;
+    layer_norm_lane<0>(z, ln_par, a.ln_eps);
+    if (t < 48) {
+#pragma unroll
+      for (int c = 0; c < EQT_H; ++c) y1T[c * 48 + t] = z[c];
+    }
   }
   __syncthreads();
   MID_SUB(13)
-  for (int idx = tid; idx < T * 128; idx += NTH) {  // FF: Linear(16,128) + ReLU
-    const int t = idx >> 7, m = idx & 127;
-    float acc = a.bb1[m];
 #pragma unroll
-    for (int c = 0; c < EQT_H; ++c) acc = fmaf(w1s[m * W1S + c], y1[t][c], acc);
-    h1[t][m] = fmaxf(acc, 0.f);
+  for (int nt = 0; nt < 3; ++nt) {  // FF: Linear(16,128) + ReLU
+    f32x4 acc = {b1v[0], b1v[1], b1v[2], b1v[3]};
+    acc = mfma_tile<4>(a1, y1T, 48, 16 * nt, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h1T[(16 * wave + 4 * (lane >> 4) + r) * 48 + 16 * nt + (lane & 15)] = fmaxf(acc[r], 0.f);
   }
   __syncthreads();
   MID_SUB(14)
-  for (int idx = tid; idx < T * EQT_H; idx += NTH) {  // Linear(128,16) + residual
-    const int t = idx >> 4, c = idx & 15;
-    float a0 = a.bb2[c], a1 = 0.f;
-#pragma unroll 8
-    for (int m = 0; m < 128; m += 2) {
-      a0 = fmaf(w2s[c * W2S + m], h1[t][m], a0);
-      a1 = fmaf(w2s[c * W2S + m + 1], h1[t][m + 1], a1);
-    }
-    v[t][c] = y1[t][c] + (a0 + a1);
+  if (wave < 6) {  // Linear(128,16), K split in two
+    f32x4 acc = half ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{b2v[0], b2v[1], b2v[2], b2v[3]};
+    acc = mfma_tile<16>(a2, h1T + 64 * half * 48, 48, 16 * nt2, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rT[(half * 16 + 4 * (lane >> 4) + r) * 48 + 16 * nt2 + (lane & 15)] = acc[r];
   }
   __syncthreads();
   MID_SUB(15)
-  if (tid < T) layer_norm16(v[tid], a.g2, a.b2, a.ln_eps, xs[tid]);
-  __syncthreads();
-  MID_SUB(16)
-  float* dst = a.dst + (long)b * a.ws_dst;
-  float* up = a.up ? a.up + (long)b * a.ws_up : nullptr;
-  for (int idx = tid; idx < EQT_H * T; idx += NTH) {
-    const int c = idx / T, t = idx - c * T;
-    const float val = xs[t][c];
-    dst[(long)c * a.ls_dst + HALO + t] = val;
-    if (up) up[(long)c * a.ls_up + HALO + t] = val;
-    cur[c * 48 + t] = val;
+  if (wave == 0) {  // LN2(y1 + FF(y1)) and the stage's outputs
+    float z[EQT_H];
+#pragma unroll
+    for (int c = 0; c < EQT_H; ++c)
+      z[c] = t < 48 ? y1T[c * 48 + t] + (rT[c * 48 + t] + rT[(16 + c) * 48 + t]) : 0.f;
+    layer_norm_lane<32>(z, ln_par, a.ln_eps);
+    if (t < T) {
+      float* dst = a.dst + (long)b * a.ws_dst + HALO + t;
+      float* up = a.up ? a.up + (long)b * a.ws_up + HALO + t : nullptr;
+#pragma unroll
+      for (int c = 0; c < EQT_H; ++c) {
+        dst[(long)c * a.ls_dst] = z[c];
+        if (up) up[(long)c * a.ls_up] = z[c];
+        cur[c * 48 + t] = z[c];
+      }
+    }
   }
+  MID_SUB(16)
   __syncthreads();
 }
 
-__device__ void mid_pick(const PickBranchArgs& a, const int b, float* P, const float* cur, unsigned long long* sub) {
-  constexpr int NTH = MID_NTH;
-  const int tid = threadIdx.x, wave = tid >> 6;
-  float(*xs)[EQT_H] = reinterpret_cast<float(*)[EQT_H]>(P);          // transformer output, [T][16]
-  float* gx = P + T * EQT_H;                                           // [2][T * 64]
-  float* hl = gx + 2 * T * 64;                                         // [2][16][48]
-  float(*x2)[EQT_H] = reinterpret_cast<float(*)[EQT_H]>(hl + 2 * 16 * 48);
-  float(*q)[KP] = reinterpret_cast<float(*)[KP]>(hl + 2 * 16 * 48 + T * EQT_H);
-  float(*k)[KP] = q + T;
-  float(*e)[48] = reinterpret_cast<float(*)[48]>(reinterpret_cast<float*>(k + T));
-  float(*v)[EQT_H] = reinterpret_cast<float(*)[EQT_H]>(reinterpret_cast<float*>(e + T));
-  static_assert(T * EQT_H + 2 * T * 64 + 2 * 16 * 48 + T * EQT_H + 2 * T * KP + T * 48 + T * EQT_H <= MID_POOL, "pick stage fits the pool");
-  for (int idx = tid; idx < EQT_H * T; idx += NTH) {
-    const int c = idx / T, t = idx - c * T;
-    xs[t][c] = cur[c * 48 + t];
+struct PickFrags {
+  ProjFrag<EQT_H> f;  // waves 0-3: P branch, 4-7: S branch
+  f32x2 whh[EQT_H / 2];  // waves 0, 1
+  AttnFrag af[2];
+  float wa_lane[2];
+};
+__device__ __forceinline__ void pick_load(PickFrags& g, const PickBranchArgs& a) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // static offsets into the argument block + selects (a wave-dependent index would be a second, dependent read)
+  lstm_project_load<EQT_H>(g.f, (wave >> 2) ? a.lstm[1] : a.lstm[0], wave & 3);
+  lstm_load_whh(g.whh, (wave & 1) ? a.lstm[1] : a.lstm[0]);  // every wave: no branch, see bi_load
+#pragma unroll
+  for (int br = 0; br < 2; ++br) {
+    attn_load(g.af[br], a.att[br]);
+    g.wa_lane[br] = a.att[br].Wa[lane & 31];
   }
-  __syncthreads();
+}
+
+__device__ void mid_pick(const PickBranchArgs& a, const PickFrags& g, const int b, float* P, const float* cur,
+                         unsigned long long* sub) {
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* gx = P;                                   // [2][T * GXS]
+  float* hl = gx + 2 * T * GXS;                    // [2][16][48] LSTM outputs of the P and the S branch
+  float(*q)[KP] = reinterpret_cast<float(*)[KP]>(hl + 2 * 16 * 48);
+  float(*k)[KP] = q + T;
+  float* e = hl + 2 * 16 * 48 + 2 * T * KP;        // [48][AES]
+  float* vT = e + 48 * AES;                        // [16][48]
+  static_assert(2 * T * GXS + 2 * 16 * 48 + 2 * T * KP + 48 * AES + 16 * 48 <= MID_POOL, "pick stage fits the pool");
   MID_SUB(17)
-  lstm_project<EQT_H>(&xs[0][0], gx + (wave / MID_WPD) * T * 64, a.lstm[wave / MID_WPD], wave % MID_WPD, MID_WPD);  // first half of the waves: P
+  const int br_w = wave >> 2, gq = wave & 3;
+  if (tid < 32) hl[tid * 48 + 47] = 0.f;  // K padding of the a.x products
+  lstm_project_mfma<EQT_H>(g.f, cur, gx + br_w * T * GXS, gq);
   __syncthreads();
   MID_SUB(18)
-  if (wave < 2) lstm_recur(gx + wave * T * 64, a.lstm[wave], false, hl + wave * 16 * 48, 48);
+  if (wave < 2) lstm_recur<GXS>(gx + wave * T * GXS, g.whh, false, hl + wave * 16 * 48, 48);
   __syncthreads();
   MID_SUB(19)
+#pragma unroll
   for (int br = 0; br < 2; ++br) {
-    for (int idx = tid; idx < T * EQT_H; idx += NTH) {
-      const int t = idx >> 4, c = idx & 15;
-      x2[t][c] = hl[(br * 16 + c) * 48 + t];
-    }
-    __syncthreads();
-    attention_core(x2, q, k, e, v, a.att[br], a.attn_eps, a.width, sub ? sub + 26 : nullptr);
-    float* up = a.up + (long)((1 + br) * a.B + b) * a.ws_up;
-    for (int idx = tid; idx < EQT_H * T; idx += NTH) {
-      const int c = idx / T, t = idx - c * T;
-      up[(long)c * a.ls_up + HALO + t] = v[t][c];
+    mid_attention(g.af[br], g.wa_lane[br], hl + br * 16 * 48, q, k, e, vT, a.attn_eps, a.width, NoPrefetch(),
+                  sub && br ? sub + 26 : nullptr);
+    float* up = a.up + (long)((1 + br) * a.B + b) * a.ws_up + HALO;
+    for (int idx = tid; idx < EQT_H * 48; idx += MID_NTH) {
+      const int c = idx / 48, t = idx - c * 48;
+      if (t < T) up[(long)c * a.ls_up + t] = vT[c * 48 + t];
     }
     __syncthreads();
   }
@@ -533,21 +819,37 @@ __global__ __launch_bounds__(MID_NTH) void eqt_mid_kernel(const MidArgs a) {
   const int b = blockIdx.x;
   int stamp = 0;
   unsigned long long* sub = a.clk ? a.clk + (long)b * 32 : nullptr;
+  if (threadIdx.x < 16) cur[threadIdx.x * 48 + 47] = 0.f;  // K padding of the a.x products; no stage writes column 47
+  {  // The argument block is 13 cache lines and every stage reads its own part of it when it starts: a cold line
+     // costs ~3.5 k cycles (measured: the stage that first touched another stage's arguments grew by that much).
+     // All lines are requested here at once, so the later reads hit the scalar cache.
+    typedef const unsigned __attribute__((address_space(4))) * uptr_t;
+    const uptr_t ka = (uptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned acc = 0;
+#pragma unroll
+    for (unsigned i = 0; i < (sizeof(MidArgs) + 63) / 64; ++i) acc |= ka[16 * i];
+    asm volatile("" ::"s"(acc));
+  }
 #define MID_STAMP()                                                                                   \
   if (a.clk && threadIdx.x == 0) a.clk[(long)b * 32 + stamp] = __builtin_readcyclecounter();         \
   ++stamp;
   MID_STAMP()
-  mid_bilstm<64>(a.lstm[0], b, P, cur, true, nullptr);
+  // each stage requests the next one's weights under its own longest arithmetic phase (see BiFrags)
+  BiFrags<64> g0;
+  BiFrags<EQT_H> g1, g2;
+  TrFrags t0, t1;
+  PickFrags pf;
+  mid_bilstm<64>(a.lstm[0], g0, b, P, cur, true, [&] { bi_load<EQT_H>(g1, a.lstm[1]); }, sub);
   MID_STAMP()
-  mid_bilstm<EQT_H>(a.lstm[1], b, P, cur, false, nullptr);
+  mid_bilstm<EQT_H>(a.lstm[1], g1, b, P, cur, false, [&] { bi_load<EQT_H>(g2, a.lstm[2]); }, nullptr);
   MID_STAMP()
-  mid_bilstm<EQT_H>(a.lstm[2], b, P, cur, false, sub);
+  mid_bilstm<EQT_H>(a.lstm[2], g2, b, P, cur, false, [&] { tr_load_early(t0, a.tr[0]); }, nullptr);
   MID_STAMP()
-  mid_transformer(a.tr[0], b, P, cur, nullptr);
+  mid_transformer(a.tr[0], t0, b, P, cur, [&] { tr_load_early(t1, a.tr[1]); }, nullptr);
   MID_STAMP()
-  mid_transformer(a.tr[1], b, P, cur, sub);
+  mid_transformer(a.tr[1], t1, b, P, cur, [&] { pick_load(pf, a.pick); }, sub);
   MID_STAMP()
-  mid_pick(a.pick, b, P, cur, sub);
+  mid_pick(a.pick, pf, b, P, cur, sub);
   MID_STAMP()
 #undef MID_STAMP
 }
