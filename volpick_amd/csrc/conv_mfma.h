@@ -136,7 +136,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const float* s2 = (C::CIN2 > 0) ? a.src2 + (long)win * a.ws2 + a0 : nullptr;
     // All of a thread's loads are issued before its first LDS write (chunks of 8 x 16 B in flight):
     // the rolled form serialised load -> wait -> ds_write and cost 5-17k cycles of pure latency per tile.
-    constexpr int TOT = C::CINP * C::W4, N_IT = (TOT + 255) / 256, CH = 8;
+    // (a tile of 9 or 13 quads per thread -- decoder.6, decoder.2 -- takes them in ONE chunk: a second chunk of one or
+    // five loads behind the first chunk's LDS writes was a second, fully exposed memory round trip: 13.7 k cycles of
+    // load phase against 6 k for the layers with <= 8 quads, tools/conv_clock.py)
+    constexpr int TOT = C::CINP * C::W4, N_IT = (TOT + 255) / 256, CH = (N_IT <= 13) ? N_IT : 8;
 #pragma unroll
     for (int it0 = 0; it0 < N_IT; it0 += CH) {
       float4 v[CH];
