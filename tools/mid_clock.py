@@ -39,8 +39,8 @@ def seg(title, slots, labels):
 seg("bilstm.0 (stage start = slot 0)", [0, 8, 9, 10, 1],
     ["load x", "input projection", "47 recurrent steps", "1x1 conv + BN + store"])
 seg("transformer_d (stage start = slot 4)", [4, 11, 21, 20, 22, 23, 24, 13, 14, 15, 16, 5],
-    ["-", "q/k projection + exp (MFMA)", "requests for the next stage issued", "e = Wa . tanh", "softmax rows", "a . x (MFMA)", "LN1",
-     "FF1 16->128 (MFMA)", "FF2 128->16 (MFMA)", "LN2 + store", "closing barrier"])
+    ["-", "q/k projection + exp (MFMA)", "requests for the next stage issued", "e = Wa . tanh", "softmax rows", "a . x (MFMA) + LN1", "-",
+     "FF1 16->128 (MFMA)", "FF2 128->16 (MFMA)", "LN2 + store (3 waves)", "closing barrier"])
 seg("pick branches (stage start = slot 5)", [5, 17, 18, 19],
     ["-", "weights + input projection (P and S, MFMA)", "47 recurrent steps (P | S)"])
 seg("  S branch attention (band 3)", [27, 28, 29, 30], ["e", "softmax", "a . x (MFMA)"])

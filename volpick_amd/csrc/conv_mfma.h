@@ -82,8 +82,9 @@ struct ConvGeom {  // runtime mirror of the template parameters (planning / pack
 };
 
 template <int CIN1_, int CIN2_, int COUT_, int P_, int TAPS_, int SN_, int IN_OFF_, int OUT_OFF_, int WAVES_M_,
-          int WAVES_N_, int NW_, int RELU_, int EPI_>
+          int WAVES_N_, int NW_, int RELU_, int EPI_, int APRE_ = 0>
 struct ConvCfg {
+  static constexpr bool APRE = APRE_ != 0;  // A fragments of channel block 0 requested ahead of the input tile
   static constexpr int CIN1 = CIN1_, CIN2 = CIN2_, CIN = CIN1_ + CIN2_, CINP = (CIN + 3) / 4 * 4, CB = CINP / 4;
   static constexpr int COUT = COUT_, P = P_, TAPS = TAPS_, SN = SN_, IN_OFF = IN_OFF_, OUT_OFF = OUT_OFF_;
   static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, NW = NW_, RELU = RELU_, EPI = EPI_;
@@ -129,6 +130,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   ++stamp_i;
   CONV_STAMP()
 
+  // The A fragments of the first channel block are requested BEFORE the input tile (template flag of the layer): their
+  // L2 round trip then runs under the tile's; otherwise it starts behind the barrier, fully exposed, and for the
+  // layers with one or two channel blocks (encoder.0 / .1) it was most of the "MFMA" phase (tools/conv_clock.py).
+  const int wm = wave % C::WAVES_M, wn = wave / C::WAVES_M;
+  const int g = lane >> 4, n = lane & 15;
+  const float* ap = a.afrag + (long)set * a.afrag_set_stride + (long)(wm * C::MW) * C::CB * C::TAPS * 64 + lane;
+  float a0[C::TAPS][C::MW];
+  if constexpr (C::APRE) {
+#pragma unroll
+    for (int tap = 0; tap < C::TAPS; ++tap)
+#pragma unroll
+      for (int i = 0; i < C::MW; ++i) a0[tap][i] = ap[((long)i * C::CB) * C::TAPS * 64 + tap * 64];
+  }
   // ---- stage the input tile: CINP rows x 4*W4 floats, aligned 16-byte loads --------------
   {
     const int a0 = HALO + C::SN * col0 + C::IN_OFF_F4;  // multiple of 4 by construction
@@ -170,17 +184,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   CONV_STAMP()
 
   // ---- MFMA main loop ---------------------------------------------------------------
-  const int wm = wave % C::WAVES_M, wn = wave / C::WAVES_M;
-  const int g = lane >> 4, n = lane & 15;
   f32x4 acc[C::MW][C::NW];
 #pragma unroll
   for (int i = 0; i < C::MW; ++i)
 #pragma unroll
     for (int j = 0; j < C::NW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const float* ap = a.afrag + (long)set * a.afrag_set_stride + (long)(wm * C::MW) * C::CB * C::TAPS * 64 + lane;
   const float* bp = lds + g * C::S + (wn * C::NW * 16 + n) * C::SN + C::SHIFT;
-  for (int cb = 0; cb < C::CB; ++cb) {
+  if constexpr (C::APRE) {  // channel block 0 out of the registers fetched above
+#pragma unroll
+    for (int tap = 0; tap < C::TAPS; ++tap) {
+      float bv[C::NW];
+#pragma unroll
+      for (int j = 0; j < C::NW; ++j) bv[j] = bp[j * 16 * C::SN + tap];
+#pragma unroll
+      for (int i = 0; i < C::MW; ++i)
+#pragma unroll
+        for (int j = 0; j < C::NW; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[tap][i], bv[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  for (int cb = C::APRE ? 1 : 0; cb < C::CB; ++cb) {
 #pragma unroll
     for (int tap = 0; tap < C::TAPS; ++tap) {
       float av[C::MW], bv[C::NW];

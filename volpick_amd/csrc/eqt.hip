@@ -18,9 +18,10 @@ namespace vp {
 
 namespace {
 
-//                      CIN1 CIN2 COUT P TAPS SN IN_OFF OUT_OFF WM WN NW RELU EPI
-using EQ_e0 = ConvCfg<3, 0, 8, 2, 12, 2, -5, 0, 1, 4, 8, 1, EPI_POOL2>;
-using EQ_e1 = ConvCfg<8, 0, 16, 1, 9, 1, -4, 0, 1, 4, 8, 1, EPI_POOL2>;
+// APRE (conv_mfma.h) where it measured faster: encoder.0 / .1 and decoder.6; it cost 2-4 us on the decoder stages 2-5.
+//                      CIN1 CIN2 COUT P TAPS SN IN_OFF OUT_OFF WM WN NW RELU EPI APRE
+using EQ_e0 = ConvCfg<3, 0, 8, 2, 12, 2, -5, 0, 1, 4, 8, 1, EPI_POOL2, 1>;
+using EQ_e1 = ConvCfg<8, 0, 16, 1, 9, 1, -4, 0, 1, 4, 8, 1, EPI_POOL2, 1>;
 using EQ_e2 = ConvCfg<16, 0, 16, 1, 7, 1, -3, 0, 1, 4, 6, 1, EPI_POOL2>;
 using EQ_e3 = ConvCfg<16, 0, 32, 1, 7, 1, -3, 0, 2, 2, 6, 1, EPI_POOL2>;
 using EQ_e4 = ConvCfg<32, 0, 32, 1, 5, 1, -2, 0, 2, 2, 6, 1, EPI_POOL2>;
@@ -45,7 +46,7 @@ using EQ_d2 = ConvCfg<64, 0, 32, 2, 3, 1, -1, 0, 2, 2, 6, 1, EPI_STORE>;
 using EQ_d3 = ConvCfg<32, 0, 32, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
 using EQ_d4 = ConvCfg<32, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
 using EQ_d5 = ConvCfg<16, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
-using EQ_d6 = ConvCfg<16, 0, 8, 2, 7, 1, -3, 0, 1, 4, 8, 1, EPI_HEAD>;  // + Conv1d(8,1,11) + sigmoid head
+using EQ_d6 = ConvCfg<16, 0, 8, 2, 7, 1, -3, 0, 1, 4, 8, 1, EPI_HEAD, 1>;  // + Conv1d(8,1,11) + sigmoid head
 // A/B tile variants (plan flag reserved[3] = 1): half-width tiles, twice the workgroups per CU
 using EQ_d3b = ConvCfg<32, 0, 32, 2, 5, 1, -2, 0, 2, 2, 3, 1, EPI_STORE>;
 using EQ_d4b = ConvCfg<32, 0, 16, 2, 5, 1, -2, 0, 2, 2, 3, 1, EPI_STORE>;

@@ -225,11 +225,31 @@ __device__ __forceinline__ void attn_scores(const float (*q)[KP], const float (*
   }
 }
 
+// Three independent wave reductions, interleaved by hand: every step is ONE DPP instruction per row and the two
+// instructions of the other rows in between cover the two wait states a DPP read needs after a VALU write.  (From
+// wave_max / wave_sum hipcc made mov_dpp + canonicalising max + max + s_nop per step and did not interleave the rows:
+// ~80 serial instructions per row, 3.6 k cycles for the six rows of a wave.)
+#define VP_DPP3(OP, CTRL)                                                                            \
+  "v_" OP "_dpp %0, %0, %0 " CTRL "\n\tv_" OP "_dpp %1, %1, %1 " CTRL "\n\tv_" OP "_dpp %2, %2, %2 " CTRL "\n\t"
+#define VP_REDUCE3(OP)                                                           \
+  asm volatile("s_nop 1\n\t" VP_DPP3(OP, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")      \
+               VP_DPP3(OP, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")                     \
+               VP_DPP3(OP, "row_half_mirror row_mask:0xf bank_mask:0xf")                         \
+               VP_DPP3(OP, "row_mirror row_mask:0xf bank_mask:0xf")                              \
+               VP_DPP3(OP, "row_bcast:15 row_mask:0xa bank_mask:0xf")                            \
+               VP_DPP3(OP, "row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"                  \
+               : "+v"(a), "+v"(b), "+v"(c));                                                    \
+  a = lane_bcast(a, 63), b = lane_bcast(b, 63), c = lane_bcast(c, 63);
+__device__ __forceinline__ void wave_max3(float& a, float& b, float& c) { VP_REDUCE3("max_f32") }
+__device__ __forceinline__ void wave_sum3(float& a, float& b, float& c) { VP_REDUCE3("add_f32") }
+#undef VP_REDUCE3
+#undef VP_DPP3
+
 // a = exp(e - rowmax) [band mask] / (sum + eps), in place; the row max is taken over the FULL row before the band
 // mask, as upstream does.  ZERO_PAD: column 47 of every row is set to 0 (the K padding of the matrix-core a.x).
 template <int ES, bool ZERO_PAD>
 __device__ __forceinline__ void attn_softmax(float* e, const float eps, const int width) {
-  // three rows per trip: their reductions are independent chains the scheduler interleaves
+  // three rows per trip (wave_max3 / wave_sum3)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
   constexpr int R = 3;
   const int lower = lane - width / 2;  // mask[i][j] = lower_j <= i < lower_j + width
@@ -240,16 +260,16 @@ __device__ __forceinline__ void attn_softmax(float* e, const float eps, const in
       const int i = i0 + r * nw;
       x[r] = (lane < T && i < T) ? e[i * ES + lane] : -INFINITY;
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r) m[r] = wave_max64(x[r]);
+    m[0] = x[0], m[1] = x[1], m[2] = x[2];
+    wave_max3(m[0], m[1], m[2]);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int i = i0 + r * nw;
       ex[r] = (lane < T && i < T) ? __expf(x[r] - m[r]) : 0.f;
       if (width > 0 && !(lower <= i && i < lower + width)) ex[r] = 0.f;
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r) sum[r] = wave_sum64(ex[r]);
+    sum[0] = ex[0], sum[1] = ex[1], sum[2] = ex[2];
+    wave_sum3(sum[0], sum[1], sum[2]);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int i = i0 + r * nw;
@@ -322,9 +342,10 @@ struct NoPrefetch {
 };
 // `prefetch` runs at the start of the score loop, the longest stretch of pure arithmetic of the stage: the caller
 // requests the NEXT stage's weights there.
-template <class Prefetch>
+// `finish(acc, n0)`: what waves 0-2 do with their tile of the result (rows = channels 4 (l / 16) + r, column n0 + l % 16).
+template <class Prefetch, class Finish>
 __device__ void mid_attention(const AttnFrag& f, const float wa_lane, const float* x, float (*q)[KP], float (*k)[KP],
-                              float* e, float* vT, const float eps, const int width, Prefetch&& prefetch,
+                              float* e, const float eps, const int width, Prefetch&& prefetch, Finish&& finish,
                               unsigned long long* sub) {
 #define ATT_SUB(slot) \
   if (sub && threadIdx.x == 0) sub[slot] = __builtin_readcyclecounter();
@@ -378,11 +399,7 @@ __device__ void mid_attention(const AttnFrag& f, const float wa_lane, const floa
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 12; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[ks], bp[ks], acc, 0, 0, 0);
-    const int i = n0 + (lane & 15);
-    if (i < T) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) vT[(4 * (lane >> 4) + r) * 48 + i] = acc[r];
-    }
+    finish(acc, n0);
   }
   __syncthreads();
   ATT_SUB(4)
@@ -648,23 +665,6 @@ __device__ void mid_bilstm(const BiLstmArgs& a, BiFrags<CIN>& g, const int b, fl
   __syncthreads();
 }
 
-// LayerNormalization of the 16 channels of column t = lane, gamma / beta as lanes of `par` (gamma at lane G0 + c, beta at
-// G0 + 16 + c): z in, normalised values out, arithmetic of layer_norm16.
-template <int G0>
-__device__ __forceinline__ void layer_norm_lane(float (&z)[EQT_H], const float par, const float eps) {
-  float mean = 0.f;
-#pragma unroll
-  for (int c = 0; c < EQT_H; ++c) mean += z[c];
-  mean *= (1.f / EQT_H);
-  float var = 0.f;
-#pragma unroll
-  for (int c = 0; c < EQT_H; ++c) var = fmaf(z[c] - mean, z[c] - mean, var);
-  var = var * (1.f / EQT_H) + eps;
-  const float inv = 1.f / sqrtf(var);
-#pragma unroll
-  for (int c = 0; c < EQT_H; ++c) z[c] = (z[c] - mean) * inv * lane_bcast(par, G0 + c) + lane_bcast(par, G0 + 16 + c);
-}
-
 struct TrFrags {
   AttnFrag af;
   float wa_lane, ln_par;
@@ -689,6 +689,25 @@ __device__ __forceinline__ void tr_load_late(TrFrags& g, const TransformerArgs& 
   load4(g.b2v, a.bb2 + 4 * (lane >> 4));           // the second K half ignores it at use
 }
 
+// LayerNormalization of a column whose 16 channels sit as z[r] = channel 4 (l / 16) + r in the lanes l, l ^ 16, l ^ 32,
+// l ^ 48 (the result layout of the matrix-core products); gamma at lane G0 + c of `par`, beta at G0 + 16 + c.
+template <int G0>
+__device__ __forceinline__ void layer_norm_mfma(float (&z)[4], const float par, const float eps) {
+  const int g = (threadIdx.x & 63) >> 4;
+  float s = (z[0] + z[1]) + (z[2] + z[3]);
+  s += __shfl_xor(s, 16);
+  s += __shfl_xor(s, 32);
+  const float mean = s * (1.f / EQT_H);
+  float d[4], v = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) d[r] = z[r] - mean, v = fmaf(d[r], d[r], v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  const float inv = 1.f / sqrtf(v * (1.f / EQT_H) + eps);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) z[r] = d[r] * inv * __shfl(par, G0 + 4 * g + r) + __shfl(par, G0 + 16 + 4 * g + r);
+}
+
 template <class Prefetch>
 __device__ void mid_transformer(const TransformerArgs& a, TrFrags& g, const int b, float* P, float* cur,
                                 Prefetch&& prefetch, unsigned long long* sub) {
@@ -696,34 +715,31 @@ __device__ void mid_transformer(const TransformerArgs& a, TrFrags& g, const int 
   float(*q)[KP] = reinterpret_cast<float(*)[KP]>(P);
   float(*k)[KP] = q + T;
   float* e = P + 2 * T * KP;        // [48][AES]
-  float* vT = e + 48 * AES;         // [16][48] attention output
-  float* y1T = vT + 16 * 48;        // [16][48] LN1 output
+  float* y1T = e + 48 * AES;        // [16][48] LN1 output
   float* h1T = y1T + 16 * 48;       // [128][48] hidden layer
-  float* rT = h1T + 128 * 48;       // [2][16][48] the two K halves of the second linear layer
-  static_assert(2 * T * KP + 48 * AES + 2 * 16 * 48 + 128 * 48 + 2 * 16 * 48 <= MID_POOL, "transformer stage fits the pool");
+  float* rT = h1T + 128 * 48;       // [16][48] the second K half of the second linear layer
+  static_assert(2 * T * KP + 48 * AES + 16 * 48 + 128 * 48 + 16 * 48 <= MID_POOL, "transformer stage fits the pool");
   const int half = wave >= 3, nt2 = wave - 3 * half;
   const float (&a1)[4] = g.a1, (&b1v)[4] = g.b1v, (&a2)[16] = g.a2, (&b2v)[4] = g.b2v;
   MID_SUB(11)
-  mid_attention(g.af, g.wa_lane, cur, q, k, e, vT, a.attn_eps, 0,
-                [&] {
-                  tr_load_late(g, a);
-                  prefetch();
-                },
-                sub ? sub + 20 : nullptr);
+  // y1 = LN1(x + attention(x)) right in the epilogue of the a.x product (three waves, four channels per lane)
+  mid_attention(
+      g.af, g.wa_lane, cur, q, k, e, a.attn_eps, 0,
+      [&] {
+        tr_load_late(g, a);
+        prefetch();
+      },
+      [&](const f32x4 acc, const int n0) {
+        const int col = n0 + (lane & 15), c0 = 4 * (lane >> 4);
+        float z[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[r] = cur[(c0 + r) * 48 + col] + acc[r];
+        layer_norm_mfma<0>(z, g.ln_par, a.ln_eps);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y1T[(c0 + r) * 48 + col] = z[r];  // all 48 columns: column 47 is padding
+      },
+      sub ? sub + 20 : nullptr);
   const float ln_par = g.ln_par;
-  MID_SUB(12)
-  const int t = lane;
-  if (wave == 0) {  // y1 = LN1(x + attention(x)), lane = time step (lane 47..: padding columns, finite or not, never stored)
-    float z[EQT_H];
-#pragma unroll
-    for (int c = 0; c < EQT_H; ++c) z[c] = t < 48 ? cur[c * 48 + t] + vT[c * 48 + t] : 0.f;
-    layer_norm_lane<0>(z, ln_par, a.ln_eps);
-    if (t < 48) {
-#pragma unroll
-      for (int c = 0; c < EQT_H; ++c) y1T[c * 48 + t] = z[c];
-    }
-  }
-  __syncthreads();
   MID_SUB(13)
 #pragma unroll
   for (int nt = 0; nt < 3; ++nt) {  // FF: Linear(16,128) + ReLU
@@ -734,28 +750,30 @@ __device__ void mid_transformer(const TransformerArgs& a, TrFrags& g, const int 
   }
   __syncthreads();
   MID_SUB(14)
-  if (wave < 6) {  // Linear(128,16), K split in two
-    f32x4 acc = half ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{b2v[0], b2v[1], b2v[2], b2v[3]};
-    acc = mfma_tile<16>(a2, h1T + 64 * half * 48, 48, 16 * nt2, acc);
+  f32x4 acc2 = half ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{b2v[0], b2v[1], b2v[2], b2v[3]};
+  if (wave < 6) {  // Linear(128,16), K split in two: waves 3-5 hand their half over through LDS
+    acc2 = mfma_tile<16>(a2, h1T + 64 * half * 48, 48, 16 * nt2, acc2);
+    if (half) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rT[(half * 16 + 4 * (lane >> 4) + r) * 48 + 16 * nt2 + (lane & 15)] = acc[r];
+      for (int r = 0; r < 4; ++r) rT[(4 * (lane >> 4) + r) * 48 + 16 * nt2 + (lane & 15)] = acc2[r];
+    }
   }
   __syncthreads();
   MID_SUB(15)
-  if (wave == 0) {  // LN2(y1 + FF(y1)) and the stage's outputs
-    float z[EQT_H];
+  if (wave < 3) {  // LN2(y1 + FF(y1)) and the stage's outputs, from the accumulators of the first K half
+    const int col = 16 * nt2 + (lane & 15), c0 = 4 * (lane >> 4);
+    float z[4];
 #pragma unroll
-    for (int c = 0; c < EQT_H; ++c)
-      z[c] = t < 48 ? y1T[c * 48 + t] + (rT[c * 48 + t] + rT[(16 + c) * 48 + t]) : 0.f;
-    layer_norm_lane<32>(z, ln_par, a.ln_eps);
-    if (t < T) {
-      float* dst = a.dst + (long)b * a.ws_dst + HALO + t;
-      float* up = a.up ? a.up + (long)b * a.ws_up + HALO + t : nullptr;
+    for (int r = 0; r < 4; ++r) z[r] = y1T[(c0 + r) * 48 + col] + (acc2[r] + rT[(c0 + r) * 48 + col]);
+    layer_norm_mfma<32>(z, ln_par, a.ln_eps);
+    if (col < T) {
+      float* dst = a.dst + (long)b * a.ws_dst + HALO + col;
+      float* up = a.up ? a.up + (long)b * a.ws_up + HALO + col : nullptr;
 #pragma unroll
-      for (int c = 0; c < EQT_H; ++c) {
-        dst[(long)c * a.ls_dst] = z[c];
-        if (up) up[(long)c * a.ls_up] = z[c];
-        cur[c * 48 + t] = z[c];
+      for (int r = 0; r < 4; ++r) {
+        dst[(long)(c0 + r) * a.ls_dst] = z[r];
+        if (up) up[(long)(c0 + r) * a.ls_up] = z[r];
+        cur[(c0 + r) * 48 + col] = z[r];
       }
     }
   }
@@ -774,14 +792,11 @@ __device__ __forceinline__ void pick_load(PickFrags& g, const PickBranchArgs& a)
   // static offsets into the argument block + selects (a wave-dependent index would be a second, dependent read)
   lstm_project_load<EQT_H>(g.f, (wave >> 2) ? a.lstm[1] : a.lstm[0], wave & 3);
   lstm_load_whh(g.whh, (wave & 1) ? a.lstm[1] : a.lstm[0]);  // every wave: no branch, see bi_load
-#pragma unroll
-  for (int br = 0; br < 2; ++br) {
-    attn_load(g.af[br], a.att[br]);
-    g.wa_lane[br] = a.att[br].Wa[lane & 31];
-  }
+  attn_load(g.af[0], a.att[0]);  // the S branch's attention operands follow under the stage's own recurrence
+  g.wa_lane[0] = a.att[0].Wa[lane & 31];
 }
 
-__device__ void mid_pick(const PickBranchArgs& a, const PickFrags& g, const int b, float* P, const float* cur,
+__device__ void mid_pick(const PickBranchArgs& a, PickFrags& g, const int b, float* P, const float* cur,
                          unsigned long long* sub) {
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* gx = P;                                   // [2][T * GXS]
@@ -797,13 +812,29 @@ __device__ void mid_pick(const PickBranchArgs& a, const PickFrags& g, const int 
   lstm_project_mfma<EQT_H>(g.f, cur, gx + br_w * T * GXS, gq);
   __syncthreads();
   MID_SUB(18)
+  if (wave < 2) {
+#pragma unroll
+    for (int j = 0; j < EQT_H / 2; ++j) asm volatile("" ::"v"(g.whh[j]));  // see mid_bilstm
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  attn_load(g.af[1], a.att[1]);
+  g.wa_lane[1] = a.att[1].Wa[tid & 31];
+  __builtin_amdgcn_sched_barrier(0);
   if (wave < 2) lstm_recur<GXS>(gx + wave * T * GXS, g.whh, false, hl + wave * 16 * 48, 48);
   __syncthreads();
   MID_SUB(19)
 #pragma unroll
   for (int br = 0; br < 2; ++br) {
-    mid_attention(g.af[br], g.wa_lane[br], hl + br * 16 * 48, q, k, e, vT, a.attn_eps, a.width, NoPrefetch(),
-                  sub && br ? sub + 26 : nullptr);
+    mid_attention(
+        g.af[br], g.wa_lane[br], hl + br * 16 * 48, q, k, e, a.attn_eps, a.width, NoPrefetch(),
+        [&](const f32x4 acc, const int n0) {
+          const int i = n0 + (tid & 15);
+          if (i < T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vT[(4 * ((tid & 63) >> 4) + r) * 48 + i] = acc[r];
+          }
+        },
+        sub && br ? sub + 26 : nullptr);
     float* up = a.up + (long)((1 + br) * a.B + b) * a.ws_up + HALO;
     for (int idx = tid; idx < EQT_H * 48; idx += MID_NTH) {
       const int c = idx / 48, t = idx - c * 48;
