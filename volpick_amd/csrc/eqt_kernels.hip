@@ -187,7 +187,7 @@ __device__ __forceinline__ void lstm_project_mfma(const ProjFrag<CIN>& f, const 
 //   e[i][j] = Wa . tanh(x_i Wt + x_j Wx + bh)   (+ ba, which cancels in e - max_j e)
 //   a = exp(e - rowmax) [band mask] / (sum + eps),  v = a x.
 // The row max is taken over the FULL row before the band mask, as upstream does.
-constexpr int KP = 33;  // padded row of q/k: consecutive rows hit consecutive LDS banks
+constexpr int KP = 34;  // padded row of q/k (even: the score loop reads channel PAIRS as 8-byte words)
 // wa_lane = Wa[lane & 31], requested long before: the 32 weights become wave-uniform operands
 __device__ __forceinline__ void attn_wa(float (&wa)[32], const float wa_lane) {
 #pragma unroll
@@ -212,15 +212,20 @@ __device__ __forceinline__ void attn_scores(const float (*q)[KP], const float (*
       e[i * ES + j] = s0 + s1;
     }
   } else {
+    // channel pairs through the packed FMA: per pair 2 v_pk_fma_f32 + 2 v_rcp_f32 instead of 4 FMAs + 2 reciprocals
+    // (the loop is bound by VALU issue), same two partial sums (even / odd channels) as the scalar form
     for (int idx = tid; idx < T * T; idx += nt) {
       const int i = idx / T, j = idx - i * T;
-      float s0 = 0.f, s1 = 0.f;
+      const f32x2* qi = reinterpret_cast<const f32x2*>(&q[i][0]);
+      const f32x2* kj = reinterpret_cast<const f32x2*>(&k[j][0]);
+      f32x2 s = {0.f, 0.f};
 #pragma unroll
-      for (int u = 0; u < 32; u += 2) {
-        s0 = fmaf(wa[u], rcp_fast(fmaf(q[i][u], k[j][u], 1.f)), s0);
-        s1 = fmaf(wa[u + 1], rcp_fast(fmaf(q[i][u + 1], k[j][u + 1], 1.f)), s1);
+      for (int u = 0; u < 16; ++u) {
+        const f32x2 d = __builtin_elementwise_fma(qi[u], kj[u], f32x2{1.f, 1.f});
+        const f32x2 r = {rcp_fast(d.x), rcp_fast(d.y)};
+        s = __builtin_elementwise_fma(f32x2{wa[2 * u], wa[2 * u + 1]}, r, s);
       }
-      e[i * ES + j] = -2.f * (s0 + s1);  // = sum_u Wa[u] tanh(q + k) - sum_u Wa[u]
+      e[i * ES + j] = -2.f * (s.x + s.y);  // = sum_u Wa[u] tanh(q + k) - sum_u Wa[u]
     }
   }
 }
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(PICK_NTH) void pick_branch_kernel(const PickBranchA
   __shared__ float gx[T * 64];
   __shared__ float hl[EQT_H][48];
   __shared__ float x2[T][EQT_H];
-  __shared__ float q[T][KP], k[T][KP];
+  __shared__ __attribute__((aligned(8))) float q[T][KP], k[T][KP];
   __shared__ float e[T][48];
   __shared__ float v[T][EQT_H];
   const int tid = threadIdx.x, b = blockIdx.x, br = blockIdx.y;
