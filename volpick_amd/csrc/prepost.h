@@ -58,6 +58,29 @@ __device__ inline float wave_max(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// Three independent wave reductions, interleaved by hand: every step is ONE DPP instruction per row and the two
+// instructions of the other rows in between cover the two wait states a DPP read needs after a VALU write.  (From
+// wave_max / wave_sum above hipcc makes mov_dpp + canonicalising max + max + s_nop per step and did not interleave the rows:
+// ~80 serial instructions per row, 3.6 k cycles for the six rows of a wave.)
+#define VP_DPP3(OP, CTRL)                                                                            \
+  "v_" OP "_dpp %0, %0, %0 " CTRL "\n\tv_" OP "_dpp %1, %1, %1 " CTRL "\n\tv_" OP "_dpp %2, %2, %2 " CTRL "\n\t"
+#define VP_REDUCE3(OP)                                                           \
+  asm volatile("s_nop 1\n\t" VP_DPP3(OP, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")      \
+               VP_DPP3(OP, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")                     \
+               VP_DPP3(OP, "row_half_mirror row_mask:0xf bank_mask:0xf")                         \
+               VP_DPP3(OP, "row_mirror row_mask:0xf bank_mask:0xf")                              \
+               VP_DPP3(OP, "row_bcast:15 row_mask:0xa bank_mask:0xf")                            \
+               VP_DPP3(OP, "row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"                  \
+               : "+v"(a), "+v"(b), "+v"(c));                                                    \
+  a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));                            \
+  b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));                            \
+  c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63));
+__device__ __forceinline__ void wave_max3(float& a, float& b, float& c) { VP_REDUCE3("max_f32") }
+__device__ __forceinline__ void wave_sum3(float& a, float& b, float& c) { VP_REDUCE3("add_f32") }
+#undef VP_REDUCE3
+#undef VP_DPP3
+
+
 struct StackArgs {
   const float* pred;  // [n_windows][n_out][T]
   float* out;         // [n_out][N]
