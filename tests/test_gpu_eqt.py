@@ -100,6 +100,24 @@ def test_forward_parity(model, oracle, B):
         assert (g > 0).all() and (g < 1).all()
 
 
+def test_six_launch_plan_matches_fused_middle_kernel(model, oracle):
+    """reserved[2] = 1 keeps the BiLSTM / transformer / pick-branch launches that eqt_mid_kernel replaces (scalar FMA
+    chains instead of matrix-core tiles, same algorithm): both plans within the oracle tolerance, and of each other."""
+    B = 5
+    x = synthetic_windows(B, 6000, seed=77)
+    xn = OP.batch_pre(oracle, torch.from_numpy(x))
+    with torch.no_grad():
+        want = oracle(xn)
+    six = EQTransformer.from_pretrained("volpick")
+    six._plan_flags = (0, 0, 1)
+    six.cuda()
+    got6 = six(xn.cuda())
+    got1 = model(xn.cuda())
+    for g6, g1, w in zip(got6, got1, want):
+        assert np.abs(g6.cpu().numpy() - w.numpy()).max() < TOL
+        assert np.abs(g6.cpu().numpy() - g1.cpu().numpy()).max() < 2e-5
+
+
 @pytest.mark.parametrize("per_comp", [False, True])
 def test_preprocess_matches_annotate_batch_pre(oracle, per_comp):
     m = EQTransformer.from_pretrained("volpick")
