@@ -1,5 +1,5 @@
-"""Max / 99.99th percentile / mean absolute difference between each PhaseNet plan and the torch-CPU oracle on 512 synthetic
-windows (tolerance of the path: 1e-4 on probabilities).  Run on the GPU box: python tools/err_check.py"""
+"""Max / 99.99th percentile / mean absolute difference between each PhaseNet / EQTransformer plan and the torch-CPU oracle on
+512 / 256 synthetic windows (tolerance of the path: 1e-4 on probabilities).  Run on the GPU box: python tools/err_check.py"""
 import sys, numpy as np, torch
 sys.path.insert(0, "/root/repo")
 from oracle import pipeline as OP
@@ -16,3 +16,15 @@ for name, flags in [("one launch (default)", (0,)), ("three launches, VALU level
     got = m(xn).double().numpy()
     e = np.abs(got - want)
     print(f"{name:32s} max|err| {e.max():.2e}  99.99th pct {np.quantile(e, 0.9999):.2e}  mean {e.mean():.2e}")
+
+from volpick_amd import EQTransformer
+orc = load_pretrained("eqtransformer")
+x = synthetic_windows(256, 6000, seed=4243)
+xn = OP.batch_pre(orc, torch.from_numpy(x))
+with torch.no_grad():
+    want = [w.double().numpy() for w in orc(xn)]
+for name, flags in [("EQT fused middle kernel (default)", (0,)), ("EQT six middle launches", (0, 0, 1))]:
+    m = EQTransformer.from_pretrained("volpick"); m._plan_flags = flags; m.cuda()
+    got = [g.double().cpu().numpy() for g in m(xn.cuda())]
+    e = np.concatenate([np.abs(g - w).ravel() for g, w in zip(got, want)])
+    print(f"{name:34s} max|err| {e.max():.2e}  99.99th pct {np.quantile(e, 0.9999):.2e}  mean {e.mean():.2e}")
