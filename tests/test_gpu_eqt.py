@@ -118,6 +118,41 @@ def test_six_launch_plan_matches_fused_middle_kernel(model, oracle):
         assert np.abs(g6.cpu().numpy() - g1.cpu().numpy()).max() < 2e-5
 
 
+@pytest.mark.parametrize("flags", [(0,), (0, 0, 1)])
+def test_attention_beyond_the_exp_product_guard(oracle, flags):
+    """The score loop works on exp(2q) * exp(2k) while |q|, |k| <= 30 and falls back to tanh(q + k) per window beyond
+    (eqt_kernels.hip attn_scores).  Projection weights scaled by 40 push q and k past the guard in one transformer block
+    and one pick branch: same answer as the oracle with the same weights, in the fused and in the six-launch plan."""
+    import copy
+
+    big = copy.deepcopy(oracle)
+    names = ["transformer_d.attention.Wx", "transformer_d.attention.Wt", "pick_attentions.1.Wx", "pick_attentions.1.Wt"]
+    params = dict(big.named_parameters())
+    with torch.no_grad():
+        for n in names:
+            params[n].mul_(40.0)
+    m = EQTransformer.from_pretrained("volpick")
+    sd = m.state_dict()
+    for n in names:
+        sd[n] = sd[n] * 40.0
+    m.load_state_dict(sd)
+    m._plan_flags = flags
+    m.cuda()
+    B = 3
+    x = synthetic_windows(B, 6000, seed=91)
+    xn = OP.batch_pre(big, torch.from_numpy(x))
+    with torch.no_grad():
+        want = big(xn)
+        h = big.transformer_d0(big.bi_lstm_stack(big.res_cnn_stack(big.encoder(xn))))
+        att = big.transformer_d.attention
+        q = torch.matmul(h.permute(0, 2, 1), att.Wt)
+        assert float(q.abs().max()) > 30.0, "the test must leave the guarded range"
+    got = m(xn.cuda())
+    for g, w in zip(got, want):
+        assert np.isfinite(g.cpu().numpy()).all()
+        assert np.abs(g.cpu().numpy() - w.numpy()).max() < TOL
+
+
 @pytest.mark.parametrize("per_comp", [False, True])
 def test_preprocess_matches_annotate_batch_pre(oracle, per_comp):
     m = EQTransformer.from_pretrained("volpick")
