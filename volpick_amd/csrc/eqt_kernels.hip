@@ -582,10 +582,17 @@ int launch_pick_branch(const PickBranchArgs& a, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------
 // One workgroup (8 wavefronts) per window walks bilstm.0-2 -> transformer_d0 -> transformer_d -> pick branches.
-// The current activation (16 x 47) travels through LDS (`cur`); every stage still writes its tensor to memory (decoder
-// inputs; the others for the layer-by-layer tests).  Against the separate kernels: the input projections of the LSTMs
-// are spread over all waves instead of running in front of the recurrence on its one wave, the two pick LSTMs run
-// side by side, and five kernel boundaries are gone.
+// The current activation travels through LDS as [16 channels][48] rows (`cur`; column 47 is the zero K-padding of the
+// a.x products); every stage still writes its tensor to memory (decoder inputs; the others for the layer tests).
+// Against the separate kernels above (kept as the six-launch plan, reserved[2] = 1):
+//   * every dense product is a set of 16x16x4 fp32 matrix-core tiles with the time steps as columns (mfma_tile):
+//     LSTM input projections, Conv1d(32,16,1), q / k projections, a.x, both feed-forward layers; LayerNorm runs in the
+//     epilogues of a.x and of the second feed-forward product (layer_norm_mfma);
+//   * the operands of a stage (BiFrags / TrFrags / PickFrags) are requested one stage ahead, under the 47 LSTM steps or
+//     the attention score loop of the stage before, as 16-byte loads in fragment order;
+//   * the two pick LSTMs run side by side and five kernel boundaries are gone.
+// Serial or transcendental work stays on the VALU: the recurrences (one wave per direction), the 47 x 47 x 32 score
+// loops, the row softmax.  DESIGN.md section 6 lists what each of these steps was worth in cycles.
 constexpr int MID_NTH = 512;
 constexpr int MID_POOL = 16000;  // floats; the stages carve it up in turn
 
