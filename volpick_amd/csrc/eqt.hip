@@ -46,7 +46,9 @@ using EQ_d2 = ConvCfg<64, 0, 32, 2, 3, 1, -1, 0, 2, 2, 6, 1, EPI_STORE>;
 using EQ_d3 = ConvCfg<32, 0, 32, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
 using EQ_d4 = ConvCfg<32, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
 using EQ_d5 = ConvCfg<16, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
-using EQ_d6 = ConvCfg<16, 0, 8, 2, 7, 1, -3, 0, 1, 4, 8, 1, EPI_HEAD, 1>;  // + Conv1d(8,1,11) + sigmoid head
+// NW = 6 (376-column steps): 8 tiles x 768 rows = 6144 workgroups at 6 per CU = exactly four residencies of the chip
+// (NW = 8: 4608 workgroups at 4 per CU = 4.5, the last one half empty); 96.6 -> 95 us.
+using EQ_d6 = ConvCfg<16, 0, 8, 2, 7, 1, -3, 0, 1, 4, 6, 1, EPI_HEAD, 1>;  // + Conv1d(8,1,11) + sigmoid head
 // A/B tile variants (plan flag reserved[3] = 1): half-width tiles, twice the workgroups per CU
 using EQ_d3b = ConvCfg<32, 0, 32, 2, 5, 1, -2, 0, 2, 2, 3, 1, EPI_STORE>;
 using EQ_d4b = ConvCfg<32, 0, 16, 2, 5, 1, -2, 0, 2, 2, 3, 1, EPI_STORE>;
