@@ -32,8 +32,9 @@ def main():
                     "gfx950 FETCH_SIZE x2 correction per MI355X_MICROARCH.md"}
     names = {
         "phasenet": [("pn_window_kernel", "fused.window (whole PhaseNet, one workgroup per window)")],
-        "eqtransformer": [("ConvCfg<16, 0, 8, 2, 7, 1, -3, 0, 1, 4, 8, 1, 6>", "decoder.6+heads"),
-                          ("eqt_res_kernel", "fused.rescnn (7 residual blocks)")],
+        "eqtransformer": [("ConvCfg<16, 0, 8, 2, 7, 1, -3, 0, 1, 4, 6, 1, 6, 1>", "decoder.6+heads"),
+                          ("eqt_res_kernel", "fused.rescnn (7 residual blocks)"),
+                          ("eqt_mid_kernel", "fused.mid (3 BiLSTM + 2 transformer blocks + pick branches)")],
     }
     for model, tag in (("phasenet", "pn"), ("eqtransformer", "eqt")):
         fetch = per_kernel(next(d.glob(f"{tag}_fetch/**/*counter_collection.csv")), "FETCH_SIZE")
