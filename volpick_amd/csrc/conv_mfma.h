@@ -326,7 +326,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     // MaxPool1d(2) over the ReLU output; an odd tail is pooled with the -1e10 pad, i.e. alone.
     float* d = a.dst + (long)win * a.wsd + a.dst_halo;
     float* d2 = (C::EPI == EPI_POOL2_DUAL) ? a.dst2 + (long)win * a.wsd2 + HALO : nullptr;
-    for (int idx = tid; idx < C::COUT * (C::OW / 2); idx += 256) {
+#pragma unroll 4
+    for (int idx = tid; idx < C::COUT * (C::OW / 2); idx += 256) {  // four LDS reads in flight per trip
       const int co = idx / (C::OW / 2), q = idx - co * (C::OW / 2);
       const int t = t0 + 2 * q;
       if (t < a.l_out) {
