@@ -26,7 +26,7 @@ using EQ_e2 = ConvCfg<16, 0, 16, 1, 7, 1, -3, 0, 1, 4, 6, 1, EPI_POOL2>;
 using EQ_e3 = ConvCfg<16, 0, 32, 1, 7, 1, -3, 0, 2, 2, 6, 1, EPI_POOL2>;
 using EQ_e4 = ConvCfg<32, 0, 32, 1, 5, 1, -2, 0, 2, 2, 6, 1, EPI_POOL2>;
 using EQ_e5 = ConvCfg<32, 0, 64, 1, 5, 1, -2, 0, 4, 1, 6, 1, EPI_POOL2>;
-using EQ_e6 = ConvCfg<64, 0, 64, 1, 3, 1, -1, 0, 4, 1, 6, 1, EPI_POOL2_DUAL>;
+using EQ_e6 = ConvCfg<64, 0, 64, 1, 3, 1, -1, 0, 4, 1, 3, 1, EPI_POOL2_DUAL>;  // two 48-column tiles per window (one 96-column tile: 11.8 vs 10.5 us)
 using EQ_r1k3 = ConvCfg<64, 0, 64, 1, 3, 1, -1, 0, 4, 1, 3, 1, EPI_STORE>;
 using EQ_r1k2 = ConvCfg<64, 0, 64, 1, 2, 1, 0, 0, 4, 1, 3, 1, EPI_STORE>;
 using EQ_r2k3 = ConvCfg<64, 0, 64, 1, 3, 1, -1, 0, 4, 1, 3, 0, EPI_RES>;
