@@ -82,9 +82,13 @@ struct ConvGeom {  // runtime mirror of the template parameters (planning / pack
 };
 
 template <int CIN1_, int CIN2_, int COUT_, int P_, int TAPS_, int SN_, int IN_OFF_, int OUT_OFF_, int WAVES_M_,
-          int WAVES_N_, int NW_, int RELU_, int EPI_, int APRE_ = 0>
+          int WAVES_N_, int NW_, int RELU_, int EPI_, int APRE_ = 0, int AQ4_ = 0>
 struct ConvCfg {
   static constexpr bool APRE = APRE_ != 0;  // A fragments of channel block 0 requested ahead of the input tile
+  // AQ4: the A operand comes regrouped [m-tile][K-step / 4][lane][4] (regroup_afrag4) as one 16-byte load per four
+  // K-steps -- the weight-heavy layers (64 -> 64 channels: 98 KB of fragments per workgroup) issue 4x fewer memory
+  // instructions for it (tools/micro/micro_stream.hip: 19 vs 52-56 B/clk/CU out of L2).
+  static constexpr bool AQ4 = AQ4_ != 0;
   static constexpr int CIN1 = CIN1_, CIN2 = CIN2_, CIN = CIN1_ + CIN2_, CINP = (CIN + 3) / 4 * 4, CB = CINP / 4;
   static constexpr int COUT = COUT_, P = P_, TAPS = TAPS_, SN = SN_, IN_OFF = IN_OFF_, OUT_OFF = OUT_OFF_;
   static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, NW = NW_, RELU = RELU_, EPI = EPI_;
@@ -204,6 +208,33 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[tap][i], bv[j], acc[i][j], 0, 0, 0);
     }
   }
+  if constexpr (C::AQ4) {
+    static_assert(!C::AQ4 || (C::CB % 4 == 0 && !C::APRE), "AQ4 walks four channel blocks per trip");
+    constexpr int SB = C::CB * C::TAPS / 4;  // 16-byte groups per m-tile
+    const float4* ap4 = reinterpret_cast<const float4*>(a.afrag + (long)set * a.afrag_set_stride) +
+                        (long)(wm * C::MW) * SB * 64 + lane;
+    for (int cb0 = 0; cb0 < C::CB; cb0 += 4) {
+      float4 a4[C::MW];
+#pragma unroll
+      for (int s = 0; s < 4 * C::TAPS; ++s) {  // the K-steps of these four channel blocks, same order as below
+        const int cbl = s / C::TAPS, tap = s % C::TAPS;
+        if ((s & 3) == 0) {
+#pragma unroll
+          for (int i = 0; i < C::MW; ++i) a4[i] = ap4[((long)i * SB + (cb0 * C::TAPS + s) / 4) * 64];
+        }
+        float bv[C::NW];
+#pragma unroll
+        for (int j = 0; j < C::NW; ++j) bv[j] = bp[(cb0 + cbl) * 4 * C::S + j * 16 * C::SN + tap];
+#pragma unroll
+        for (int i = 0; i < C::MW; ++i) {
+          const float av = (s & 3) == 0 ? a4[i].x : (s & 3) == 1 ? a4[i].y : (s & 3) == 2 ? a4[i].z : a4[i].w;
+#pragma unroll
+          for (int j = 0; j < C::NW; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  } else
   for (int cb = C::APRE ? 1 : 0; cb < C::CB; ++cb) {
 #pragma unroll
     for (int tap = 0; tap < C::TAPS; ++tap) {

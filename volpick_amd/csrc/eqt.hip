@@ -19,14 +19,16 @@ namespace vp {
 namespace {
 
 // APRE (conv_mfma.h) where it measured faster: encoder.0 / .1 and decoder.6; it cost 2-4 us on the decoder stages 2-5.
-//                      CIN1 CIN2 COUT P TAPS SN IN_OFF OUT_OFF WM WN NW RELU EPI APRE
+// AQ4 (16-byte weight loads) where it measured faster: encoder.4-6, decoder.1 / .2 / .4 / .5 (same-box A/B per launch:
+// -0.1 .. -3.0 us); not decoder.3.
+//                      CIN1 CIN2 COUT P TAPS SN IN_OFF OUT_OFF WM WN NW RELU EPI APRE AQ4
 using EQ_e0 = ConvCfg<3, 0, 8, 2, 12, 2, -5, 0, 1, 4, 8, 1, EPI_POOL2, 1>;
 using EQ_e1 = ConvCfg<8, 0, 16, 1, 9, 1, -4, 0, 1, 4, 8, 1, EPI_POOL2, 1>;
 using EQ_e2 = ConvCfg<16, 0, 16, 1, 7, 1, -3, 0, 1, 4, 6, 1, EPI_POOL2>;
 using EQ_e3 = ConvCfg<16, 0, 32, 1, 7, 1, -3, 0, 2, 2, 6, 1, EPI_POOL2>;
-using EQ_e4 = ConvCfg<32, 0, 32, 1, 5, 1, -2, 0, 2, 2, 6, 1, EPI_POOL2>;
-using EQ_e5 = ConvCfg<32, 0, 64, 1, 5, 1, -2, 0, 4, 1, 6, 1, EPI_POOL2>;
-using EQ_e6 = ConvCfg<64, 0, 64, 1, 3, 1, -1, 0, 4, 1, 3, 1, EPI_POOL2_DUAL>;  // two 48-column tiles per window (one 96-column tile: 11.8 vs 10.5 us)
+using EQ_e4 = ConvCfg<32, 0, 32, 1, 5, 1, -2, 0, 2, 2, 6, 1, EPI_POOL2, 0, 1>;
+using EQ_e5 = ConvCfg<32, 0, 64, 1, 5, 1, -2, 0, 4, 1, 6, 1, EPI_POOL2, 0, 1>;
+using EQ_e6 = ConvCfg<64, 0, 64, 1, 3, 1, -1, 0, 4, 1, 3, 1, EPI_POOL2_DUAL, 0, 1>;  // two 48-column tiles per window (one 96-column tile: 11.8 vs 10.5 us)
 using EQ_r1k3 = ConvCfg<64, 0, 64, 1, 3, 1, -1, 0, 4, 1, 3, 1, EPI_STORE>;
 using EQ_r1k2 = ConvCfg<64, 0, 64, 1, 2, 1, 0, 0, 4, 1, 3, 1, EPI_STORE>;
 using EQ_r2k3 = ConvCfg<64, 0, 64, 1, 3, 1, -1, 0, 4, 1, 3, 0, EPI_RES>;
@@ -41,11 +43,11 @@ using EQ_r2k2 = ConvCfg<64, 0, 64, 1, 2, 1, 0, 0, 4, 1, 3, 0, EPI_RES>;
 // exactly those two samples per channel from the definition (2 x 32 x 320 MACs per decoder and window).
 //                      CIN1 CIN2 COUT P TAPS SN IN_OFF OUT_OFF WM WN NW RELU EPI
 using EQ_d0 = ConvCfg<16, 0, 64, 2, 3, 1, -1, 0, 4, 1, 3, 1, EPI_STORE>;
-using EQ_d1 = ConvCfg<64, 0, 64, 2, 3, 1, -1, 0, 4, 1, 6, 1, EPI_STORE>;
-using EQ_d2 = ConvCfg<64, 0, 32, 2, 3, 1, -1, 0, 2, 2, 6, 1, EPI_STORE>;
-using EQ_d3 = ConvCfg<32, 0, 32, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
-using EQ_d4 = ConvCfg<32, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
-using EQ_d5 = ConvCfg<16, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;
+using EQ_d1 = ConvCfg<64, 0, 64, 2, 3, 1, -1, 0, 4, 1, 6, 1, EPI_STORE, 0, 1>;
+using EQ_d2 = ConvCfg<64, 0, 32, 2, 3, 1, -1, 0, 2, 2, 6, 1, EPI_STORE, 0, 1>;
+using EQ_d3 = ConvCfg<32, 0, 32, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE>;  // AQ4 measured 62.5 vs 58.4 us here (MW = 2 with 6 n-tiles: registers)
+using EQ_d4 = ConvCfg<32, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE, 0, 1>;
+using EQ_d5 = ConvCfg<16, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE, 0, 1>;
 // NW = 6 (376-column steps): 8 tiles x 768 rows = 6144 workgroups at 6 per CU = exactly four residencies of the chip
 // (NW = 8: 4608 workgroups at 4 per CU = 4.5, the last one half empty); 96.6 -> 95 us.
 using EQ_d6 = ConvCfg<16, 0, 8, 2, 7, 1, -3, 0, 1, 4, 6, 1, EPI_HEAD, 1>;  // + Conv1d(8,1,11) + sigmoid head

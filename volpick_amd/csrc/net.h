@@ -23,6 +23,7 @@ struct ConvLayer {
   int cols = 0, l_out = 0, l_dst = 0;
   int n_sets = 1;  // weight sets (EQT decoders x3); windows = n_sets * B
   HostBlob afrag, bias, e0, e1, e2;
+  HostBlob* afrag_q4 = nullptr;  // ConvCfg AQ4: the A operand regrouped for 16-byte loads (what the kernel reads)
   int (*launch)(const ConvArgs&, int, hipStream_t) = nullptr;
   const void* kernel = nullptr;
   size_t lds_bytes = 0;
@@ -36,6 +37,10 @@ struct Step {
 };
 
 constexpr int kDenseOut = -2;
+
+// The A operand of a conv layer regrouped for 16-byte loads (conv_lds_q4): [mt][step][64] -> [mt][step / 4][64][4],
+// step = channel block * taps + tap; needs (channel blocks * taps) % 4 == 0.
+std::vector<float> regroup_afrag4(const ConvLayer& L);
 
 struct Net {
   int model_kind = 0;
@@ -87,6 +92,7 @@ struct Net {
     need(src2, L->g.src_need(cols));
     ConvLayer* raw = L.get();
     convs.push_back(std::move(L));
+    if constexpr (Cfg::AQ4) raw->afrag_q4 = add_blob(regroup_afrag4(*raw));  // the kernel reads this copy (16-byte groups)
     add_conv_step(raw);
     return raw;
   }
@@ -102,9 +108,6 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags);  // swa
 int plan_eqt(Net& net, const ParamView& pv);
 int plan_eqt_fuse_res(Net& net);  // swaps the 14 ResCNN conv steps for one fused launch
 
-// The A operand of a conv layer regrouped for 16-byte loads (conv_lds_q4): [mt][step][64] -> [mt][step / 4][64][4],
-// step = channel block * taps + tap; needs (channel blocks * taps) % 4 == 0.
-std::vector<float> regroup_afrag4(const ConvLayer& L);
 
 // BatchNorm (eval) folded into the preceding conv: scale = gamma / sqrt(var + eps),
 // shift = beta - mean * scale (+ conv bias * scale).

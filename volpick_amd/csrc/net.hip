@@ -127,7 +127,7 @@ void Net::add_conv_step(ConvLayer* L) {
       a.lsd2 = d2.ls;
       a.wsd2 = (long)d2.win_stride();
     }
-    a.afrag = L->afrag.d;
+    a.afrag = L->afrag_q4 ? L->afrag_q4->d : L->afrag.d;
     a.bias = L->bias.d;
     a.afrag_set_stride = (long)(L->afrag.h.size() / L->n_sets);
     a.bias_set_stride = (long)(L->bias.h.size() / L->n_sets);
