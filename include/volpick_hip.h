@@ -44,7 +44,8 @@ enum { VP_MEM_HOST = 0, VP_MEM_DEVICE = 1 };
  * published SeisBench values, filled in by vp_default_config(). */
 typedef struct {
   int32_t norm;               /* VP_NORM_*  — model_args.norm, Final_models/ ** /volpick.json.v1:6 */
-  int32_t norm_amp_per_comp;  /* EQT only: 1 = per-channel amplitude, 0 = one amplitude over all channels */
+  int32_t norm_amp_per_comp;  /* EQT only: 1 = per-channel PEAK amplitude (whatever `norm` says, as SeisBench's
+                                 annotate_batch_pre), 0 = one peak / std amplitude over all channels */
   int32_t max_batch;          /* windows the workspace is sized for per forward pass */
   float bn_eps;               /* BatchNorm eps, folded into the conv weights at load time */
   float attention_eps;        /* EQT additive attention denominator eps */
@@ -111,7 +112,8 @@ int vp_annotate(vp_handle* h, const float* stream, int stream_mem, int64_t N, in
  * picks_from_annotations / detections_from_annotations and by the reference's own
  * get_picks_from_prob (volpick/model/eval_taks0.py:46-56).  trace: n samples (may hold
  * NaN).  A trigger opens at the first sample > thr_on and closes at the last sample of
- * the run of samples > thr_off.  Writes up to cap triggers; *n_found is the total. */
+ * the run of samples > thr_off.  Writes the earliest (by onset) min(cap, total) triggers in onset order;
+ * *n_found is the total. */
 int vp_pick(vp_handle* h, const float* trace, int trace_mem, int64_t n, float thr_on, float thr_off,
             int64_t* on, int64_t* off, int64_t* peak, float* value, int cap, int* n_found);
 
@@ -198,6 +200,10 @@ int vp_synchronize(vp_handle* h);
 int vp_step_count(const vp_handle* h);
 int vp_step_info(const vp_handle* h, int index, const char** name, double* flops_per_window);
 double vp_flops_per_window(const vp_handle* h);
+/* The MFMA work a conv launch actually issues per window (whole 16-column tiles, channels padded to 4, the folded
+ * taps of the polyphase forms) -- the denominator of "fraction of the matrix pipes' time"; 0 for launches that are
+ * not a single MFMA convolution (fused kernels, recurrences). */
+int vp_step_issued_flops(const vp_handle* h, int index, double* issued_flops_per_window);
 int vp_profile_steps(vp_handle* h, int B, int iters, float* step_ms, int cap);
 /* One step timed IN the pipeline: the whole list runs in order `iters` times, only step `index` is bracketed by
  * events (its inputs come from the preceding kernel, as under rocprofv3). */
@@ -217,6 +223,13 @@ int vp_debug_plan_conv(int model_kind, const float* weights, size_t n_floats, co
 int vp_debug_tensor_count(const vp_handle* h);
 int vp_debug_tensor_info(const vp_handle* h, int index, const char** name, int* channels, int* length);
 int vp_debug_tensor_read(vp_handle* h, int index, int B, float* host_out);
+
+/* Debug guard of the data-layout invariant the conv loaders rely on: the margins of every
+ * activation row -- [0, 8) and [8 + L, row stride) -- are the convolution padding, zeroed once at vp_create and never
+ * written again.  Scans every row of every tensor; *n_bad = margin words that are not +-0.0, *first_bad_tensor (may be
+ * NULL) the name of the first offending tensor.  Meant to be run after calls on ragged sizes.  self_test = k > 0 plants
+ * one stray word in a margin of tensor k - 1 for the duration of the scan (the checker checking itself: expect 1). */
+int vp_debug_check_halos(vp_handle* h, int self_test, int64_t* n_bad, const char** first_bad_tensor);
 
 /* Debug (handles created with reserved[1] & 2): B x 32 words per window of the fused PhaseNet core
  * kernel: [0..14] shader-clock stamps (kernel start, input loaded, after each of the 13 layers),
@@ -296,6 +309,22 @@ int vp_train_tensor_count(const vp_trainer* t);
 int vp_train_tensor_info(const vp_trainer* t, int index, const char** name, int* channels, int* length);
 int vp_train_tensor_read(vp_trainer* t, int index, int B, float* out);
 void* vp_train_stream(const vp_trainer* t);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-GPU bring-up.  The reference is single-GPU; windows are independent given the
+ * weights, so the one exchange is the start-up broadcast of the flat weight blob from the root rank: a single
+ * ncclBroadcast over RCCL (xGMI inside a node), after which vp_create(..., VP_MEM_DEVICE, ...) builds the plan from the
+ * received buffer.  One process per GPU.  RCCL is bound at run time (dlopen librccl.so.1).
+ *
+ * vp_rccl_unique_id: the root fills 128 bytes that every rank must receive out of band (a file, a socket,
+ *   torch.distributed's store ...).  vp_rccl_comm_init: collective over the n_ranks processes, binds the communicator
+ *   to device_id.  vp_bcast_weights: in place -- the root sends weights_dev, every other rank receives into it;
+ *   returns when the data has arrived.  vp_rccl_comm_destroy releases the communicator. */
+#define VP_RCCL_UNIQUE_ID_BYTES 128
+int vp_rccl_unique_id(void* id128);
+int vp_rccl_comm_init(int device_id, int n_ranks, const void* id128, int rank, void** comm);
+int vp_rccl_comm_destroy(void* comm);
+int vp_bcast_weights(void* rccl_comm, float* weights_dev, size_t n_floats, int root);
 
 const char* vp_last_error(void);
 const char* vp_version(void);

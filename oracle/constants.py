@@ -1,8 +1,10 @@
 """Named switches for every constant the reference repository does not pin.
 
 Each value is the one SeisBench / ObsPy publish (see oracle/__init__.py for
-why they cannot be verified offline).  The product keeps its own copy in
-``volpick_amd/constants.py``; ``tests/test_constants.py`` checks both agree.
+why they cannot be verified offline).  The product keeps its own copies: the numerical ones are the
+defaults of ``vp_default_config`` (volpick_amd/csrc/api.hip), the annotate defaults are the class-level
+``_annotate_args`` of ``volpick_amd/models.py``; ``tests/test_host_logic.py::test_constants_agree_with_product``
+checks both agree.
 """
 
 # --- model numerics -------------------------------------------------------

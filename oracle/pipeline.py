@@ -41,9 +41,12 @@ def batch_pre(model, batch: torch.Tensor) -> torch.Tensor:
     """``annotate_batch_pre`` of PhaseNet / EQTransformer on a (B,C,T) float32 tensor."""
     batch = batch - batch.mean(dim=-1, keepdim=True)
     per_comp = model.name == "PhaseNet" or getattr(model, "norm_amp_per_comp", False)
-    if model.norm == "peak":
+    norm = model.norm
+    if model.name == "EQTransformer" and per_comp:
+        norm = "peak"  # EQTransformer.annotate_batch_pre: norm_amp_per_comp always uses the per-channel peak
+    if norm == "peak":
         amp = batch.abs().amax(dim=-1 if per_comp else (-2, -1), keepdim=True)
-    elif model.norm == "std":
+    elif norm == "std":
         amp = batch.std(dim=-1 if per_comp else (-2, -1), keepdim=True)  # unbiased, as torch.std
     else:
         raise ValueError(model.norm)

@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 import torch.multiprocessing as mp
 
-from volpick_amd.distributed import shard_range
+from oracle import pipeline as OP
+from volpick_amd.distributed import _head_run_end, shard_range, stitch_triggers
 
 
 def test_shard_range_partitions():
@@ -20,6 +21,43 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(5, 2, 2)
+
+
+def test_stitch_triggers_equals_unsplit_scan():
+    """Triggers found rank by rank on the owned ranges + the head-run ends, stitched, are exactly the triggers of
+    the unsplit trace: runs crossing one or several cuts, thr_off < thr_on, NaN gaps, a run open at the end."""
+    import torch
+
+    rng = np.random.default_rng(5)
+
+    def pick_fn(rows, specs):
+        rows = rows.numpy() if torch.is_tensor(rows) else rows
+        return [(si, *t) for si, (row, _, t_on, t_off) in enumerate(specs) for t in OP.picks_from_trace(rows[row], t_on, t_off)]
+
+    for trial in range(120):
+        n = int(rng.integers(200, 3000))
+        x = np.clip(np.cumsum(rng.standard_normal(n)) * 0.12 + 0.35, 0, 1).astype(np.float32)
+        if trial % 4 == 0:
+            x[rng.integers(0, n, size=5)] = np.nan
+        if trial % 5 == 0:
+            x[int(n * 0.3):int(n * 0.9)] = 0.95  # one run across several cuts
+        if trial % 7 == 0:
+            x[-50:] = 0.9  # open at the end
+        thr = float(rng.uniform(0.2, 0.7))
+        specs = [(0, "P", thr, thr), (1, "Detection", thr, thr / 2)]
+        rows = np.stack([x, x[::-1].copy()])
+        parts_n = int(rng.integers(2, 7))
+        cuts = [0] + sorted(rng.choice(np.arange(1, n), size=parts_n - 1, replace=False).tolist()) + [n]
+        parts = []
+        for k in range(parts_n):
+            a, b = cuts[k], cuts[k + 1]
+            found = pick_fn(rows[:, a:b], specs)
+            head = [(-1 if k == 0 else _head_run_end(pick_fn, torch.from_numpy(rows), sp, a, b)) for sp in specs]
+            parts.append(dict(keep_lo=a, keep_hi=b, head_end=head,
+                              triggers=[(si, on + a, off + a, pk + a, v) for si, on, off, pk, v in found]))
+        got = stitch_triggers(parts, len(specs))
+        want = sorted(pick_fn(rows, specs), key=lambda t: (t[0], t[1]))
+        assert got == want, (trial, cuts)
 
 
 def _worker(rank, world, port, q):
@@ -113,7 +151,15 @@ def _stream_worker(rank, world, port, q):
 
         t0 = UTCDateTime("2020-02-02T00:00:00")
         kw = dict(overlap=overlap, blinding=blinding, P_threshold=0.3, S_threshold=0.3)
-        got = classify_stream_sharded(model, data, t0, "XX.ONE.", annotate_fn=oracle_annotate, pick_fn=oracle_pick, **kw)
+        touched = []
+
+        def load(lo, hi):  # a rank is handed its segment + halo only
+            touched.append((lo, hi))
+            return data[:, lo:hi]
+
+        got = classify_stream_sharded(model, (n, load), t0, "XX.ONE.", annotate_fn=oracle_annotate, pick_fn=oracle_pick,
+                                      **kw)
+        assert len(touched) == 1 and (touched[0][0] > 0 if rank else touched[0][1] < n)
         if rank == 0:
             want_rows = torch.from_numpy(np.ascontiguousarray(oracle_annotate(data)))
             want = oracle_pick(want_rows, model._trigger_specs(model._argdict(kw)))
@@ -126,8 +172,9 @@ def _stream_worker(rank, world, port, q):
 
 
 def test_one_stream_sharded_over_two_ranks_gloo():
-    """BASELINE config 4 in miniature: ONE stream split over the ranks by segments.plan_segments, the pieces
-    gathered to rank 0 and picked there -- equal to the unsplit result (oracle on CPU standing in for the GPU path)."""
+    """BASELINE config 4 in miniature: ONE stream split over the ranks by segments.plan_segments, every rank reads
+    only its segment, scans the output range it owns, and rank 0 stitches the trigger lists -- equal to the unsplit
+    result (oracle on CPU standing in for the GPU path)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

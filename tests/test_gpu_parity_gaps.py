@@ -1,0 +1,339 @@
+"""GPU: the parity cases round 1 left uncovered ("next round" item 1), all through the C ABI.
+
+(a) the DEVICE trigger scan (trigger_scan_kernel) bit-exact against oracle.pipeline.picks_from_trace on identical
+    traces: chunk-boundary runs, NaN inside / between runs, a run open at the last sample, thr_off < thr_on,
+    cap < count, a multi-million-sample trace;
+(b) the RCCL weight broadcast (vp_bcast_weights) -> vp_create(VP_MEM_DEVICE) path, world size 1, in process;
+(c) BASELINE configs[3] at full size on one GPU: a 24 h stream, 17,269 EQTransformer windows;
+(d) norm="std" (and EQT norm_amp_per_comp) against the oracle;
+(e) a dormant known-answer test for the one answer the reference publishes (Final_models/demo.ipynb:397-413);
+    plus the halo-is-padding invariant after calls on ragged sizes (item 8).
+"""
+import ctypes as C
+import os
+import socket
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import volpick_amd as va
+from oracle import pipeline as OP
+from oracle.models import load_pretrained
+from volpick_amd import _lib
+from volpick_amd.synthetic import synthetic_stream_array, synthetic_windows
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+@pytest.fixture(scope="module")
+def pn():
+    return va.PhaseNet.from_pretrained("volpick").cuda()
+
+
+@pytest.fixture(scope="module")
+def eqt():
+    return va.EQTransformer.from_pretrained("volpick").cuda()
+
+
+# ------------------------------------------------------------------------------------------- (a)
+def _pick_dev(model, x, thr_on, thr_off, cap=None):
+    """vp_pick on a DEVICE trace -> ([(on, off, peak, value)], n_found)."""
+    lib = _lib.load()
+    x = np.ascontiguousarray(x, np.float32)
+    d = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    cap = len(x) // 2 + 2 if cap is None else cap
+    on, off, pk = np.empty(cap, np.int64), np.empty(cap, np.int64), np.empty(cap, np.int64)
+    val, n = np.empty(cap, np.float32), C.c_int()
+    I64, F32 = C.POINTER(C.c_int64), C.POINTER(C.c_float)
+    _lib.check(lib.vp_pick(model._handle, C.c_void_p(d.data_ptr()), _lib.VP_MEM_DEVICE, len(x), thr_on, thr_off,
+                           on.ctypes.data_as(I64), off.ctypes.data_as(I64), pk.ctypes.data_as(I64),
+                           val.ctypes.data_as(F32), cap, C.byref(n)), "vp_pick")
+    m = min(n.value, cap)
+    return [(int(on[i]), int(off[i]), int(pk[i]), float(val[i])) for i in range(m)], n.value
+
+
+def _same(got, want):
+    assert len(got) == len(want), (len(got), len(want))
+    for g, w in zip(got, want):
+        assert g[:3] == w[:3], (g, w)
+        assert np.float32(g[3]) == np.float32(w[3]), (g, w)  # the value is a sample of the trace: bit-exact
+
+
+def test_device_trigger_scan_exact_on_random_traces(pn):
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        n_s = int(rng.integers(1, 400)) if trial < 100 else int(rng.integers(1500, 12000))
+        x = np.clip(np.cumsum(rng.standard_normal(n_s)) * 0.15 + 0.3, 0, 1).astype(np.float32)
+        if trial % 3 == 0:
+            x[rng.integers(0, n_s, size=max(1, n_s // 20))] = np.nan
+        thr = float(rng.uniform(0.1, 0.8))
+        for off_thr in (thr, thr / 2):
+            got, n = _pick_dev(pn, x, thr, off_thr)
+            want = OP.picks_from_trace(x, thr, off_thr)
+            assert n == len(want)
+            _same(got, want)
+
+
+def test_device_trigger_scan_edge_cases(pn):
+    """Runs against the 2048-sample chunk grid of trigger_scan_kernel and the 64-sample walk-back."""
+    CH = 2048
+    base = np.full(5 * CH + 300, 0.05, np.float32)
+
+    def case(edit, thr=0.5, off=None):
+        x = base.copy()
+        edit(x)
+        for o in ((thr, thr / 2) if off is None else (off,)):
+            got, n = _pick_dev(pn, x, thr, o)
+            want = OP.picks_from_trace(x, thr, o)
+            assert n == len(want) and len(want) > 0
+            _same(got, want)
+        return want
+
+    def put(x, a, b, v=0.9):
+        x[a:b + 1] = v
+
+    case(lambda x: put(x, CH - 8, CH + 12))                    # straddles one chunk boundary
+    case(lambda x: put(x, CH - 1, CH))                         # two samples, one on each side
+    case(lambda x: put(x, CH - 5, CH - 1))                     # ends exactly on the last sample of a chunk
+    case(lambda x: put(x, CH, CH + 5))                         # starts exactly on the first sample of a chunk
+    case(lambda x: put(x, 1000, 3 * CH + 77))                  # spans several chunks (walk-back over > 6000 samples)
+    case(lambda x: (put(x, 0, 10), put(x, len(x) - 30, len(x) - 1)))  # run at sample 0; run open at the last sample
+    case(lambda x: put(x, 0, len(x) - 1))                      # the whole trace is one run
+    case(lambda x: (put(x, CH - 70, CH + 70), x.__setitem__(CH, np.nan)))          # NaN inside a run splits it
+    case(lambda x: (put(x, 100, 200), x.__setitem__(slice(300, 400), np.nan), put(x, 500, 600)))  # NaN between runs
+    case(lambda x: (put(x, CH - 64, CH - 1), put(x, CH + 1, CH + 64)))             # 64-sample runs around a gap of one
+    for k in (62, 63, 64, 65, 127, 128, 129):                                      # walk-back block edges
+        case(lambda x, k=k: put(x, 3000, 3000 + k - 1))
+
+    # thr_off = thr / 2 re-arming: two bumps > thr_on joined by samples in (thr_off, thr_on] are ONE trigger whose
+    # onset is the first bump; separated by a sample <= thr_off they are two
+    def bumps(x):
+        put(x, CH - 40, CH - 30, 0.9)
+        put(x, CH - 29, CH + 20, 0.3)   # > 0.25, <= 0.5
+        put(x, CH + 21, CH + 30, 0.95)
+        put(x, 4000, 4010, 0.9)
+        x[4011] = 0.2                   # <= thr_off: closes
+        put(x, 4012, 4020, 0.8)
+    w = case(bumps, thr=0.5, off=0.25)
+    assert (w[0][0], w[0][1], w[0][2]) == (CH - 40, CH + 30, CH + 21) and len(w) == 3
+
+    # a run above thr_off that never exceeds thr_on is no trigger; a plateau's peak is its FIRST sample
+    def plateau(x):
+        put(x, 100, 300, 0.4)
+        put(x, CH - 20, CH + 20, 0.7)
+        put(x, CH - 3, CH + 3, 0.8)
+    w = case(plateau, thr=0.5, off=0.25)
+    assert len(w) == 1 and w[0][2] == CH - 3
+
+
+def test_device_trigger_scan_cap_and_long_trace(pn):
+    rng = np.random.default_rng(7)
+    # many short triggers, cap smaller than the count: the earliest `cap` by onset, in order, and the true total
+    x = np.full(40_000, 0.1, np.float32)
+    starts = np.arange(50, 39_900, 97)
+    for s in starts:
+        x[s:s + 1 + (s % 5)] = 0.6 + 0.3 * rng.random()
+    want = OP.picks_from_trace(x, 0.5, 0.5)
+    assert len(want) == len(starts)
+    for cap in (1, 7, 64, len(want) - 1, len(want), len(want) + 5):
+        got, n = _pick_dev(pn, x, 0.5, 0.5, cap=cap)
+        assert n == len(want)
+        _same(got, want[:cap])
+    got, n = _pick_dev(pn, x, 0.5, 0.5, cap=0)  # count only
+    assert n == len(want) and got == []
+    # a multi-million-sample trace (half a day of one probability row) with NaN-blinded ends
+    n_s = 4_321_987
+    y = np.clip(np.cumsum(rng.standard_normal(n_s).astype(np.float32)) * 0.02 % 1.4 - 0.2, 0, 1).astype(np.float32)
+    y[:500] = np.nan
+    y[-500:] = np.nan
+    y[rng.integers(0, n_s, size=200)] = np.nan
+    for thr, off in ((0.6, 0.6), (0.6, 0.3)):
+        want = OP.picks_from_trace(y, thr, off)
+        got, n = _pick_dev(pn, y, thr, off, cap=len(want) + 8)
+        assert n == len(want) > 100
+        _same(got, want)
+
+
+# ------------------------------------------------------------------------------------------- (b)
+def test_rccl_broadcast_then_create_from_device_weights(pn):
+    """World size 1, "nccl" backend, in process: broadcast_weights -> vp_rccl_comm_init + vp_bcast_weights
+    (ncclBroadcast) -> vp_create(VP_MEM_DEVICE); the forward pass is bitwise the host-created handle's."""
+    import torch.distributed as dist
+
+    from volpick_amd.distributed import broadcast_weights
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        other = va.PhaseNet.from_pretrained("volpick")
+        ref = other._weights.copy()
+        buf = broadcast_weights(other, src=0)
+        assert buf.is_cuda and np.array_equal(other._weights, ref) and np.array_equal(buf.cpu().numpy(), ref)
+        assert other._handle is not None and other._device_index == 0
+        x = synthetic_windows(5, 3001, seed=77)
+        assert np.array_equal(other._forward_raw(x, preprocess=True), pn._forward_raw(x, preprocess=True))
+        # the raw C ABI, as a binder without torch would drive it: a second communicator, a zeroed receive buffer
+        lib = _lib.load()
+        ident = C.create_string_buffer(128)
+        _lib.check(lib.vp_rccl_unique_id(ident))
+        comm = C.c_void_p()
+        _lib.check(lib.vp_rccl_comm_init(0, 1, ident, 0, C.byref(comm)))
+        w = torch.from_numpy(ref).cuda()
+        torch.cuda.synchronize()
+        _lib.check(lib.vp_bcast_weights(comm, C.c_void_p(w.data_ptr()), w.numel(), 0))
+        assert np.array_equal(w.cpu().numpy(), ref)
+        assert lib.vp_bcast_weights(comm, None, 0, 0) < 0 and lib.vp_rccl_comm_init(0, 1, ident, 3, C.byref(comm)) < 0
+        _lib.check(lib.vp_rccl_comm_destroy(comm))
+    finally:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------- (c)
+def test_24h_stream_full_size_one_gpu(eqt):
+    """BASELINE configs[3]'s workload on ONE GPU: 8,640,000 samples, overlap 5500, blinding (500, 500):
+    17,269 windows.  Window count and valid range; bitwise determinism; the stream split over the device
+    contexts (_annotate_segments) == the unsplit call (_annotate_block); device stacking == numpy stacking
+    (oracle reassemble) of the device's own window predictions on three stretches of the day."""
+    T, overlap, blinding = 6000, 5500, (500, 500)
+    n = 8_640_000
+    data, _, _ = synthetic_stream_array(n, seed=1004, n_events=600)
+    args = eqt._argdict(dict(overlap=overlap, blinding=blinding, stacking="avg", batch_size=256))
+    assert eqt._is_long(n, args)
+    x = torch.from_numpy(data).cuda()
+    one, fv, lv, nw = eqt._annotate_block(x, args)
+    starts = OP.window_starts(n, T, overlap)
+    assert nw == len(starts) == 17_269 and starts[-1] == n - T
+    assert (fv, lv) == (500, n - 501)
+    assert torch.isnan(one[:, :fv]).all() and torch.isnan(one[:, lv + 1:]).all() and not torch.isnan(one[:, fv:lv + 1]).any()
+    two, *_ = eqt._annotate_block(x, args)
+    assert torch.equal(one.view(torch.int32), two.view(torch.int32))  # bitwise reproducible
+    del two
+    seg, fv2, lv2, nw2 = eqt._annotate_segments(x, args)
+    assert (fv2, lv2, nw2) == (fv, lv, nw)
+    assert torch.equal(one.view(torch.int32), seg.view(torch.int32))  # split over three contexts == unsplit
+    del seg
+    step = T - overlap
+    for a in (0, 4_000_000, n - 30_000):  # start, middle, end (with the tail window) of the day
+        b = a + 30_000
+        idx = np.nonzero((starts + T > a) & (starts < b))[0]
+        wins = np.stack([data[:, s:s + T] for s in starts[idx]])
+        preds = eqt._forward_raw(wins, preprocess=True).transpose(0, 2, 1).copy()  # (W, T, 3)
+        preds[:, :blinding[0]] = np.nan
+        preds[:, -blinding[1]:] = np.nan
+        lo = int(starts[idx[0]])
+        want = OP.reassemble(preds, starts[idx] - lo, T, overlap, "avg").T  # rows from sample `lo`
+        got = one[:, a:b].cpu().numpy()
+        w = want[:, a - lo:b - lo]
+        assert np.array_equal(np.isnan(w), np.isnan(got))
+        assert np.nanmax(np.abs(w - got)) < 2e-6
+    # picks of the day through the public API == trigger scan of the unsplit rows
+    st = va.Stream([va.Trace(data[i], dict(network="XX", station="DAY", channel=f"HH{c}", sampling_rate=100.0))
+                    for i, c in enumerate("ZNE")])
+    res = eqt.classify(st, overlap=overlap, blinding=blinding, batch_size=256)
+    specs = eqt._trigger_specs(args)
+    want = eqt._pick_rows(one, specs)
+    n_picks = sum(1 for t in want if specs[t[0]][1] != "Detection")
+    assert len(res.picks) == n_picks > 500 and len(res.detections) == len(want) - n_picks
+
+
+# ------------------------------------------------------------------------------------------- (d)
+@pytest.mark.parametrize("kind", ["phasenet", "eqtransformer", "eqtransformer_per_comp"])
+def test_norm_std_matches_oracle(kind):
+    """VP_NORM_STD (unbiased std, per channel for PhaseNet, over all channels for EQT) and EQT's
+    norm_amp_per_comp (per-channel PEAK whatever `norm` says) on the GPU vs the oracle's annotate_batch_pre."""
+    name = kind.split("_")[0]
+    cls = va.PhaseNet if name == "phasenet" else va.EQTransformer
+    model = cls.from_pretrained("volpick")
+    net = load_pretrained(name)
+    model.norm = net.norm = "std"
+    if kind.endswith("per_comp"):
+        model.norm_amp_per_comp = net.norm_amp_per_comp = True
+    model.cuda()
+    T = model.in_samples
+    x = synthetic_windows(6, T, seed=5150)
+    x[1, 1] *= 30.0  # unequal channel amplitudes: per-channel and global normalisation differ
+    xn = OP.batch_pre(net, torch.from_numpy(x))
+    with torch.no_grad():
+        y = net(xn)
+    want = torch.stack(y, 1).numpy() if isinstance(y, tuple) else y.numpy()
+    got = model._forward_raw(x, preprocess=True)
+    assert np.abs(got - want).max() < 1e-4
+    # and the normalised rows themselves (input tensor of the layer plan / gather_normalize path)
+    peak = va.PhaseNet.from_pretrained("volpick").cuda() if name == "phasenet" else va.EQTransformer.from_pretrained("volpick").cuda()
+    assert np.abs(peak._forward_raw(x, preprocess=True) - got).max() > 1e-3  # the switch is not a no-op
+    # annotate() on a stream goes through the same preprocessing
+    data, _, _ = synthetic_stream_array(2 * T + 500, seed=12)
+    data[2] *= 0.01
+    args = model._argdict({})
+    out, fv, lv, nw = model._annotate_block(data, args)
+    ann = OP.annotate_array(net, data, overlap=args["overlap"], blinding=args["blinding"])
+    for i, (label, off, tr) in enumerate(ann):
+        assert off == fv
+        assert np.abs(out[i, fv:lv + 1].cpu().numpy() - tr).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------- (e)
+def test_demo_notebook_known_answer():
+    """The ONE answer the reference publishes for this path (Final_models/demo.ipynb:397-413):
+    volpick_eqt.classify(stream, overlap=1000, blinding=[500, 500], P_threshold=0.15, S_threshold=0.15) on
+    NC.MMT..EHZ, 6890 samples from 2005-05-31T21:04:52.11 (demo.ipynb:242), prints P 21:05:10.97 and S 21:05:15.48.
+    The waveform is an FDSN download and is not in the reference; drop its 6890 samples (key "data", optional
+    "starttime" as an ISO string) into tests/golden/demo_NC_MMT_EHZ.npz and this test pins the whole path."""
+    f = GOLD / "demo_NC_MMT_EHZ.npz"
+    if not f.exists():
+        pytest.skip("tests/golden/demo_NC_MMT_EHZ.npz not supplied (NCEDC waveform cannot be fetched offline)")
+    z = np.load(f, allow_pickle=False)
+    data = np.asarray(z["data"]).ravel()
+    assert data.size == 6890
+    t0 = va.UTCDateTime(str(z["starttime"]) if "starttime" in z.files else "2005-05-31T21:04:52.110000Z")
+    st = va.Stream([va.Trace(data, dict(network="NC", station="MMT", location="", channel="EHZ", starttime=t0,
+                                        sampling_rate=100.0))])
+    model = va.EQTransformer.from_pretrained("volpick").cuda()
+    picks = model.classify(st, overlap=1000, blinding=[500, 500], P_threshold=0.15, S_threshold=0.15).picks
+    assert str(picks) == ("PickList with 2 entries:\n\nNC.MMT.\t2005-05-31T21:05:10.970000Z\tP\n"
+                          "NC.MMT.\t2005-05-31T21:05:15.480000Z\tS")
+
+
+# ------------------------------------------------------------------------------------------- item 8
+@pytest.mark.parametrize("name", ["phasenet", "eqtransformer"])
+def test_halo_margins_stay_zero_after_ragged_calls(name):
+    """The conv loaders read the zero margins of every activation row as padding; no kernel
+    may ever store into them.  After forward passes on ragged batch sizes and annotate calls with tail windows, on
+    every plan variant, vp_debug_check_halos finds every margin word still zero."""
+    lib = _lib.load()
+    cls = va.PhaseNet if name == "phasenet" else va.EQTransformer
+    plans = [(0, 0), (0, 0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 2), (1, 0)] if name == "phasenet" else [(0, 0), (0, 0, 1)]
+    for flags in plans:
+        model = cls.from_pretrained("volpick")
+        model._plan_flags = flags
+        model.cuda()
+        T = model.in_samples
+        for B in (300, 1, 255):
+            model._forward_raw(synthetic_windows(3, T, seed=B)[np.arange(B) % 3], preprocess=True)
+        data, _, _ = synthetic_stream_array(T + (T // 2) * 40 + 123, seed=9)
+        model.classify(va.Stream([va.Trace(data[i], dict(network="XX", station="HALO", channel=f"HH{c}",
+                                                          sampling_rate=100.0)) for i, c in enumerate("ZNE")]))
+        bad, where = C.c_int64(-1), C.c_char_p()
+        for ctx in range(1 + len(model._extra_handles)):
+            _lib.check(lib.vp_debug_check_halos(model._context(ctx), 0, C.byref(bad), C.byref(where)),
+                       "vp_debug_check_halos")
+            assert bad.value == 0, (name, flags, where.value)
+        # the checker checking itself: one stray word planted in a margin of the last / the first tensor is found
+        h = model._handle
+        for k in (lib.vp_debug_tensor_count(h), 1):
+            _lib.check(lib.vp_debug_check_halos(h, k, C.byref(bad), C.byref(where)))
+            nm = C.c_char_p()
+            _lib.check(lib.vp_debug_tensor_info(h, k - 1, C.byref(nm), None, None))
+            assert bad.value == 1 and where.value == nm.value
+        _lib.check(lib.vp_debug_check_halos(h, 0, C.byref(bad), C.byref(where)))
+        assert bad.value == 0  # and the planted word was taken out again
+        model._release()

@@ -157,8 +157,8 @@ def test_adam_steps_and_running_statistics_match_torch(setup):
 
 def test_training_reduces_the_loss_and_lit_schedule():
     lit = PhaseNetLit(lr=1e-3, max_batch=16, model=PhaseNet.from_pretrained("volpick"))
-    assert lit.learning_rate(0) == 1e-3 and abs(lit.learning_rate(1) - 1e-3 * 2 / 500) < 1e-12
-    assert lit.learning_rate(498) == pytest.approx(1e-3 * 499 / 500) and lit.learning_rate(499) == 1e-3
+    assert lit.learning_rate(0) == 1e-3 and abs(lit.learning_rate(1) - 1e-3 * 1 / 500) < 1e-12
+    assert lit.learning_rate(499) == pytest.approx(1e-3 * 499 / 500) and lit.learning_rate(500) == 1e-3
     x, y = make_batch(16, 21)
     batch = {"X": torch.from_numpy(x).cuda(), "y": torch.from_numpy(y).cuda()}  # device-resident batch
     first = lit.training_step(batch, 0)

@@ -38,6 +38,27 @@ def test_default_config_and_error_paths(lib):
     assert lib.vp_weight_count(_lib.VP_MODEL_EQTRANSFORMER) == 378823
 
 
+def test_constants_agree_with_product(lib):
+    """oracle/constants.py (the named switches of SURVEY A.7) == what the product computes with."""
+    from oracle import constants as K
+
+    for kind, taper in ((_lib.VP_MODEL_PHASENET, 0), (_lib.VP_MODEL_EQTRANSFORMER, K.EQT_TAPER_SAMPLES)):
+        cfg = _lib.VpConfig()
+        assert lib.vp_default_config(kind, C.byref(cfg)) == 0
+        assert cfg.bn_eps == np.float32(K.BN_EPS) and cfg.attention_eps == np.float32(K.EQT_ATTENTION_EPS)
+        assert cfg.layernorm_eps == np.float32(K.EQT_LAYERNORM_EPS) and cfg.norm_eps == np.float32(K.NORM_EPS)
+        assert cfg.taper_samples == taper and cfg.max_batch == K.DEFAULT_BATCH_SIZE
+    pn, eq = va.PhaseNet._annotate_args, va.EQTransformer._annotate_args
+    assert (pn["overlap"], tuple(pn["blinding"]), pn["*_threshold"]) == (
+        K.PN_DEFAULTS["overlap"], K.PN_DEFAULTS["blinding"], K.PN_DEFAULTS["threshold"])
+    assert (eq["overlap"], tuple(eq["blinding"]), eq["*_threshold"], eq["detection_threshold"]) == (
+        K.EQT_DEFAULTS["overlap"], K.EQT_DEFAULTS["blinding"], K.EQT_DEFAULTS["threshold"],
+        K.EQT_DEFAULTS["detection_threshold"])
+    assert pn["batch_size"] == K.DEFAULT_BATCH_SIZE and pn["stacking"] == K.DEFAULT_STACKING
+    assert (va.PhaseNet.in_samples, va.EQTransformer.in_samples) == (K.PN_IN_SAMPLES, K.EQT_IN_SAMPLES)
+    assert va.PhaseNet.sampling_rate == K.SAMPLING_RATE
+
+
 @pytest.mark.parametrize("N,T,ov", [(6890, 6000, 1000), (60_000, 3001, 1500), (3001, 3001, 0), (3000, 3001, 0),
                                     (8_640_000, 6000, 5500), (10_000, 3001, 3000)])
 def test_window_starts_matches_oracle(lib, N, T, ov):
@@ -198,7 +219,9 @@ def test_training_host_pieces_without_gpu():
     assert abs(lab[0, 0, 120] - np.exp(-0.5)) < 1e-6 and np.allclose(lab.sum(1), 1.0, atol=1e-6)
     lit = PhaseNetLit(lr=5e-4, model=va.PhaseNet.from_pretrained("volpick"))
     lrs = [lit.learning_rate(k) for k in range(0, 600)]
-    assert lrs[0] == 5e-4 and lrs[1] == pytest.approx(5e-4 * 2 / 500) and lrs[499] == 5e-4 and lrs[599] == 5e-4
+    # step 0 at lr; the hook after 0-based step k (trainer.global_step == k there) sets lr * (k + 1) / 500 for step k + 1
+    assert lrs[0] == 5e-4 and lrs[1] == pytest.approx(5e-4 * 1 / 500) and lrs[499] == pytest.approx(5e-4 * 499 / 500)
+    assert lrs[500] == 5e-4 and lrs[599] == 5e-4
     assert all(b >= a for a, b in zip(lrs[1:500], lrs[2:501]))
     with pytest.raises(_lib.VolpickHipError):
         PhaseNetTrainer(va.PhaseNet.from_pretrained("volpick"), max_batch=4)

@@ -128,6 +128,7 @@ SIGNATURES = {
     "vp_step_count": (C.c_int, [_H]),
     "vp_step_info": (C.c_int, [_H, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double)]),
     "vp_flops_per_window": (C.c_double, [_H]),
+    "vp_step_issued_flops": (C.c_int, [_H, C.c_int, C.POINTER(C.c_double)]),
     "vp_profile_steps": (C.c_int, [_H, C.c_int, C.c_int, _FP, C.c_int]),
     "vp_profile_step_in_pipeline": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, _FP]),
     "vp_debug_tensor_count": (C.c_int, [_H]),
@@ -138,6 +139,11 @@ SIGNATURES = {
         [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(VpConfig), C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_size_t,
          C.c_void_p, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     ),
+    "vp_debug_check_halos": (C.c_int, [_H, C.c_int, _I64P, C.POINTER(C.c_char_p)]),
+    "vp_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "vp_rccl_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "vp_rccl_comm_destroy": (C.c_int, [C.c_void_p]),
+    "vp_bcast_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "vp_debug_core_clock": (C.c_int, [_H, C.c_int, C.c_void_p]),
     "vp_debug_conv_clock": (C.c_int, [_H, C.c_void_p, C.c_int]),
     "vp_mseed_scan": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(VpMseedRecord), C.c_int64, _I64P]),

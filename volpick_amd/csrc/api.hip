@@ -79,6 +79,9 @@ vp::PreArgs pre_args(const vp_handle* h, const float* src, int dense, long N, lo
   a.preprocess = preprocess;
   a.norm = net.cfg.norm;
   a.per_comp = (net.model_kind == VP_MODEL_PHASENET) ? 1 : net.cfg.norm_amp_per_comp;
+  // SeisBench EQTransformer.annotate_batch_pre: norm_amp_per_comp divides by the per-channel PEAK whatever `norm`
+  // says; `norm` only selects peak / std for the amplitude taken over all three channels.
+  if (net.model_kind == VP_MODEL_EQTRANSFORMER && net.cfg.norm_amp_per_comp) a.norm = VP_NORM_PEAK;
   a.taper = net.cfg.taper_samples;
   a.norm_eps = net.cfg.norm_eps;
   a.dst = in.p;
@@ -777,7 +780,26 @@ int vp_pick(vp_handle* h, const float* trace, int trace_mem, int64_t n, float th
   if (rc != VP_OK) return rc;
   VP_HIP(hipStreamSynchronize(h->stream));
   if (h->timing) (void)hipEventElapsedTime(&h->stage_ms[3], h->ev[3], h->ev[4]);
-  return scan_collect(sl, on, off, peak, value, nullptr, cap, n_found);
+  rc = scan_collect(sl, on, off, peak, value, nullptr, cap, n_found);
+  if (rc != VP_OK || *n_found <= cap || cap == 0) return rc;
+  // More triggers than `cap`: the device kept whichever `cap` of them were appended first.  The contract (and the
+  // host mirror) is the EARLIEST cap by onset, so scan again with room for all and hand out the head of the list.
+  const int all = *n_found;
+  std::vector<int64_t> t_on(all), t_off(all), t_pk(all);
+  std::vector<float> t_v(all);
+  rc = scan_submit(h, sl, rows, lens, &thr_on, &thr_off, 1, all);
+  if (rc != VP_OK) return rc;
+  VP_HIP(hipStreamSynchronize(h->stream));
+  int again = 0;
+  rc = scan_collect(sl, t_on.data(), t_off.data(), t_pk.data(), t_v.data(), nullptr, all, &again);
+  if (rc != VP_OK) return rc;
+  for (int i = 0; i < cap && i < again; ++i) {
+    on[i] = t_on[i];
+    off[i] = t_off[i];
+    peak[i] = t_pk[i];
+    value[i] = t_v[i];
+  }
+  return VP_OK;
 }
 
 // Replaces the per-sample Python loop of the reference's evaluate() (eval_taks0.py:96-142).
@@ -855,6 +877,12 @@ int vp_step_info(const vp_handle* h, int index, const char** name, double* flops
   return VP_OK;
 }
 
+int vp_step_issued_flops(const vp_handle* h, int index, double* issued_flops_per_window) {
+  VP_REQUIRE(h && issued_flops_per_window && index >= 0 && index < (int)h->net.steps.size(), "bad step index");
+  *issued_flops_per_window = h->net.steps[index].issued_flops_per_window;
+  return VP_OK;
+}
+
 double vp_flops_per_window(const vp_handle* h) { return h ? h->net.flops_per_window : 0.0; }
 
 // Runs every launch of the forward pass `iters` times on B windows (whatever the input
@@ -929,6 +957,44 @@ int vp_debug_tensor_read(vp_handle* h, int index, int B, float* host_out) {
   // strided copy: (B*C rows) x L floats out of rows of stride ls, skipping the halo
   VP_HIP(hipMemcpy2D(host_out, (size_t)t.L * sizeof(float), t.p + vp::HALO, (size_t)t.ls * sizeof(float),
                      (size_t)t.L * sizeof(float), (size_t)B * t.C, hipMemcpyDeviceToHost));
+  return VP_OK;
+}
+
+// Debug guard of the halo-is-padding invariant (vp_common.h): the margins of every activation row are zeroed once
+// at vp_create and no kernel may ever write them.  Scans all rows of all tensors of the handle's arena.
+int vp_debug_check_halos(vp_handle* h, int self_test, int64_t* n_bad, const char** first_bad_tensor) {
+  VP_REQUIRE(h && n_bad, "null argument");
+  VP_HIP(hipSetDevice(h->device));
+  vp::Net& net = h->net;
+  const size_t nt = net.tensors.size();
+  VP_REQUIRE(self_test >= 0 && self_test <= (int)nt, "self_test names tensor %d of %zu", self_test - 1, nt);
+  float* planted = nullptr;
+  if (self_test > 0) {  // plant ONE stray word in the right margin of the tensor's last row, restored below
+    const vp::Tensor& t = net.tensors[self_test - 1];
+    const size_t rows = (size_t)t.C * net.max_batch * net.tensor_sets[self_test - 1];
+    planted = t.p + (rows - 1) * t.ls + vp::HALO + t.L;
+    const float one = 1.f;
+    VP_HIP(hipMemcpyAsync(planted, &one, sizeof(float), hipMemcpyHostToDevice, h->stream));
+  }
+  int* d_bad = nullptr;
+  VP_HIP(hipMalloc((void**)&d_bad, (nt + 1) * sizeof(int)));
+  VP_HIP(hipMemsetAsync(d_bad, 0, (nt + 1) * sizeof(int), h->stream));
+  for (size_t i = 0; i < nt; ++i) {
+    const vp::Tensor& t = net.tensors[i];
+    vp::launch_halo_check(t.p, (long)t.C * net.max_batch * net.tensor_sets[i], t.ls, t.L, d_bad + i, h->stream);
+  }
+  std::vector<int> bad(nt + 1, 0);
+  hipError_t e = hipMemcpyAsync(bad.data(), d_bad, (nt + 1) * sizeof(int), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess && planted) e = hipMemsetAsync(planted, 0, sizeof(float), h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(d_bad);
+  VP_HIP(e);
+  *n_bad = 0;
+  if (first_bad_tensor) *first_bad_tensor = nullptr;
+  for (size_t i = 0; i < nt; ++i) {
+    if (bad[i] && *n_bad == 0 && first_bad_tensor) *first_bad_tensor = net.tensors[i].name.c_str();
+    *n_bad += bad[i];
+  }
   return VP_OK;
 }
 

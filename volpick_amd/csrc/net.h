@@ -34,6 +34,7 @@ struct Step {
   std::string name;
   std::function<int(Net&, int /*B*/, hipStream_t)> run;
   double flops_per_window = 0;
+  double issued_flops_per_window = 0;  // MFMA work actually issued (padded tiles, folded taps); 0 = not an MFMA conv step
 };
 
 constexpr int kDenseOut = -2;

@@ -143,6 +143,9 @@ struct WindowPickArgs {
 };
 int launch_window_pick(const WindowPickArgs& a, hipStream_t stream);
 int launch_publish(char* dev, char* host, int n_specs, int cap, long header, long per_spec, hipStream_t stream);
+// Debug guard of the halo-is-padding invariant (vp_common.h): counts the non-zero words in the margins
+// [0, HALO) and [HALO + L, ls) of `rows` rows of stride ls; adds the count to *bad (device int).
+int launch_halo_check(const float* rows_base, long rows, int ls, int L, int* bad, hipStream_t stream);
 int pick_host(const float* x, int64_t n, float thr_on, float thr_off, int64_t* on, int64_t* off, int64_t* peak,
               float* value, int cap, int* n_found);
 

@@ -414,6 +414,28 @@ int launch_publish(char* dev, char* host, int n_specs, int cap, long header, lon
   return 0;
 }
 
+// Debug: one wavefront per row scans the two margins of the row; anything but +0.0 / -0.0 is counted
+// (a NaN or a denormal left by a stray store would corrupt the padding of every later convolution).
+__global__ __launch_bounds__(256) void halo_check_kernel(const float* base, long rows, int ls, int L, int* bad) {
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const unsigned* row = reinterpret_cast<const unsigned*>(base + r * ls);
+  int n = 0;
+  for (int i = lane; i < ls; i += 64) {
+    const bool margin = i < HALO || i >= HALO + L;
+    if (margin && (row[i] & 0x7fffffffu) != 0u) ++n;
+  }
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+  if (lane == 0 && n) atomicAdd(bad, n);
+}
+
+int launch_halo_check(const float* rows_base, long rows, int ls, int L, int* bad, hipStream_t stream) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(halo_check_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, rows_base, rows, ls, L, bad);
+  return 0;
+}
+
 // Host mirror of ObsPy's trigger_onset for host-resident traces (general thresholds).
 int pick_host(const float* x, int64_t n, float thr_on, float thr_off, int64_t* on, int64_t* off, int64_t* peak,
               float* value, int cap, int* n_found) {

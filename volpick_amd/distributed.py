@@ -1,5 +1,5 @@
 """Multi-GPU use of the path: one process per GPU, weights broadcast once, station streams
-(or contiguous window ranges) partitioned with no data-path collective.
+(or contiguous window ranges of one stream) partitioned with no data-path collective.
 
 The reference is single-GPU; windows are independent given the weights,
 so the only exchange is the start-up broadcast of the flat fp32 weight blob (1.08 MB PhaseNet /
@@ -21,10 +21,61 @@ def shard_range(n_items: int, rank: int, world_size: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class RcclCommunicator:
+    """An RCCL communicator owned by libvolpick_hip (``vp_rccl_comm_init``), spanning the ranks of a
+    ``torch.distributed`` group.  torch.distributed only carries the 128-byte unique id to the other ranks (the
+    out-of-band step any binder has to provide); the collective itself is the library's ``ncclBroadcast``."""
+
+    def __init__(self, device_index: int, src: int = 0, group=None):
+        import ctypes as C
+
+        import torch.distributed as dist
+
+        from . import _lib
+
+        lib = _lib.load()
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ident = C.create_string_buffer(128)
+        if rank == src:
+            _lib.check(lib.vp_rccl_unique_id(ident), "vp_rccl_unique_id")
+        box = [ident.raw if rank == src else None]
+        dist.broadcast_object_list(box, src=src, group=group)
+        self._comm = C.c_void_p()
+        _lib.check(lib.vp_rccl_comm_init(int(device_index), world, box[0], rank, C.byref(self._comm)), "vp_rccl_comm_init")
+
+    def broadcast(self, tensor, root: int = 0):
+        """In-place broadcast of a contiguous fp32 CUDA tensor (``vp_bcast_weights``)."""
+        import ctypes as C
+
+        from . import _lib
+
+        assert tensor.is_cuda and tensor.is_contiguous() and tensor.dtype.itemsize == 4
+        _lib.check(_lib.load().vp_bcast_weights(self._comm, C.c_void_p(tensor.data_ptr()), tensor.numel(), int(root)),
+                   "vp_bcast_weights")
+        return tensor
+
+    def close(self):
+        from . import _lib
+
+        if self._comm:
+            _lib.load().vp_rccl_comm_destroy(self._comm)
+            self._comm = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def broadcast_weights(model, src: int = 0, group=None, create_handle: bool = True):
     """Broadcast ``model``'s flat weight blob from ``src`` and (on GPU) build the device plan
     straight from the broadcast buffer.  Every rank must hold a model of the same class; ranks
-    other than ``src`` may hold arbitrary (e.g. zero) weights of the right size."""
+    other than ``src`` may hold arbitrary (e.g. zero) weights of the right size.
+
+    Backend "nccl": the collective is the library's own ``vp_bcast_weights`` (one ``ncclBroadcast`` over RCCL,
+    include/volpick_hip.h) and ``vp_create(VP_MEM_DEVICE)`` plans from the received device buffer.  Backend "gloo"
+    (CPU tests): a host broadcast of the same blob."""
     import torch
     import torch.distributed as dist
 
@@ -34,10 +85,11 @@ def broadcast_weights(model, src: int = 0, group=None, create_handle: bool = Tru
     n = int(model._weights.size)
     if backend == "nccl":
         dev = torch.device("cuda", torch.cuda.current_device())
-        buf = torch.from_numpy(model._weights).to(dev) if dist.get_rank(group) == src else torch.empty(
+        buf = torch.from_numpy(model._weights).to(dev) if dist.get_rank(group) == src else torch.zeros(
             n, dtype=torch.float32, device=dev)
-        dist.broadcast(buf, src=src, group=group)
-        torch.cuda.current_stream(dev).synchronize()
+        torch.cuda.current_stream(dev).synchronize()  # the upload is done before RCCL touches the buffer
+        with RcclCommunicator(dev.index, src=src, group=group) as comm:
+            comm.broadcast(buf, root=src)
         model._weights = buf.cpu().numpy()
         if create_handle:
             model._release()
@@ -127,17 +179,108 @@ def annotate_stream_sharded(model, data, group=None, annotate_fn=None, **kwargs)
     return out, fv, lv
 
 
-def classify_stream_sharded(model, data, starttime, trace_id, group=None, annotate_fn=None, pick_fn=None, **kwargs):
-    """``annotate_stream_sharded`` + the trigger scan on rank 0 -> ``ClassifyOutput`` there, ``None`` elsewhere.
-    ``pick_fn(rows (n_out, N), specs) -> [(spec_index, on, off, peak, value)]`` replaces the GPU scan in CPU tests."""
-    from .picks import ClassifyOutput, Detection, DetectionList, Pick, PickList
+def stitch_triggers(parts, n_specs):
+    """Join the per-rank trigger lists of ONE stream into the unsplit list.
 
-    out, fv, lv = annotate_stream_sharded(model, data, group=group, annotate_fn=annotate_fn, **kwargs)
-    if out is None:
-        return None
+    ``parts`` (in segment order): dicts with ``keep_lo``/``keep_hi`` (the owned output range), ``triggers``
+    [(spec, on, off, peak, value)] in stream sample indices found by scanning the owned range only, and
+    ``head_end`` [per spec: last sample of the run of samples > thr_off that starts at ``keep_lo``, or -1 if
+    sample ``keep_lo`` is not above thr_off].  A trigger whose ``off`` is the last owned sample is open: it
+    continues into the next part when that part's head run exists, taking the head run's end as its own, the
+    earlier onset, and the larger peak (the earlier one on a tie -- first argmax, as the unsplit scan)."""
+    out = []
+    for si in range(n_specs):
+        open_t = None  # [on, off, peak, value] ending at a cut
+        for k, part in enumerate(parts):
+            trig = sorted(list(t[1:]) for t in part["triggers"] if t[0] == si)
+            he = part["head_end"][si] if k > 0 else -1
+            if open_t is not None:
+                if he >= 0:  # the run continues across the cut
+                    m = next((t for t in trig if t[1] == he), None)  # the head run's own trigger, if it has one
+                    if m is not None:
+                        trig.remove(m)
+                        if m[3] > open_t[3]:
+                            open_t[2], open_t[3] = m[2], m[3]
+                    open_t[1] = he
+                    if he == part["keep_hi"] - 1 and k + 1 < len(parts):
+                        continue  # the whole part is inside the run: still open
+                out.append((si, *open_t))
+                open_t = None
+            if trig and trig[-1][1] == part["keep_hi"] - 1 and k + 1 < len(parts):
+                open_t = trig.pop()
+            out += [(si, *t) for t in trig]
+        if open_t is not None:
+            out.append((si, *open_t))
+    return sorted(out, key=lambda t: (t[0], t[1]))
+
+
+def _head_run_end(pick_fn, rows, spec, lo, hi):
+    """Last sample (index into ``rows``) of the run of samples > thr_off that starts at ``lo``, or -1; scans a
+    doubling prefix of [lo, hi) with the trigger scan at (thr_off, thr_off), where runs and triggers coincide."""
+    row, label, _, thr_off = spec
+    n = 4096
+    while True:
+        end = min(hi, lo + n)
+        found = pick_fn(rows[:, lo:end], [(row, label, thr_off, thr_off)])
+        first = min(found, key=lambda t: t[1]) if found else None
+        if first is None or first[1] != 0:
+            return -1
+        if first[2] < end - lo - 1 or end == hi:
+            return lo + first[2]
+        n *= 4
+
+
+def classify_stream_sharded(model, data, starttime, trace_id, group=None, annotate_fn=None, pick_fn=None, **kwargs):
+    """ONE long (3, N) block spread over the ranks (BASELINE config 4: a 24 h stream on 8 GPUs) ->
+    ``ClassifyOutput`` on rank 0, ``None`` elsewhere.
+
+    Rank r takes segment r of ``segments.plan_segments`` -- only its samples [lo, hi) (owned range + halo) are read
+    from ``data`` and uploaded -- annotates it, and scans the output range it owns.  What travels is the trigger list
+    of each rank plus, per trigger spec, where the run that starts at the rank's first owned sample ends
+    (``stitch_triggers`` joins runs that cross a cut): a few hundred bytes through the host, no probability rows and no
+    data-path collective.  ``data``: a (3, N) array / tensor, or ``(N, load)`` with
+    ``load(lo, hi) -> (3, hi - lo)`` for callers that never hold the whole stream.
+    ``annotate_fn(block) -> (n_out, len)`` and ``pick_fn(rows, specs) -> [(spec, on, off, peak, value)]`` replace the
+    GPU path in the CPU tests (the oracle stands there)."""
+    import torch
+    import torch.distributed as dist
+
+    from .picks import ClassifyOutput, Detection, DetectionList, Pick, PickList
+    from .segments import plan_segments
+
     args = model._argdict(kwargs)
     specs = model._trigger_specs(args)
-    triggers = (pick_fn or model._pick_rows)(out, specs)
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+    if isinstance(data, tuple):
+        n, load = int(data[0]), data[1]
+    else:
+        n, load = int(data.shape[1]), (lambda lo, hi: data[:, lo:hi])
+    segs = plan_segments(n, model.in_samples, args["overlap"], args["blinding"], world)
+    if annotate_fn is None:
+        def annotate_fn(block):
+            fn = model._annotate_segments if model._is_long(block.shape[1], args) else model._annotate_block
+            return fn(block, args)[0]
+    pick_fn = pick_fn or model._pick_rows
+    mine = None
+    if rank < len(segs):  # a short stream has fewer segments than ranks: the surplus ranks own nothing
+        sg = segs[rank]
+        rows = annotate_fn(load(sg["lo"], sg["hi"]))
+        rows = rows if torch.is_tensor(rows) else torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32))
+        a, b = sg["keep_lo"] - sg["lo"], sg["keep_hi"] - sg["lo"]
+        found = pick_fn(rows[:, a:b], specs)
+        head = [(-1 if rank == 0 else _head_run_end(pick_fn, rows, sp, a, b)) for sp in specs]
+        mine = dict(keep_lo=sg["keep_lo"], keep_hi=sg["keep_hi"],
+                    triggers=[(si, on + sg["keep_lo"], off + sg["keep_lo"], pk + sg["keep_lo"], v)
+                              for si, on, off, pk, v in found],
+                    head_end=[(-1 if h < 0 else h + sg["lo"]) for h in head])
+    if world == 1:
+        parts = [mine]
+    else:
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object(mine, parts, dst=0, group=group)
+    if rank != 0:
+        return None
+    triggers = stitch_triggers([p for p in parts if p is not None], len(specs))
     sr = model.sampling_rate
     picks, detections = PickList(), DetectionList()
     for si, on, off, pk, v in triggers:

@@ -223,7 +223,8 @@ class WaveformModel:
 
     def train(self, mode=True):
         if mode:
-            raise NotImplementedError("this package implements the inference path only")
+            raise NotImplementedError("model objects run the inference path; the PhaseNet training step lives in "
+                                      "volpick_amd.train (PhaseNetTrainer / PhaseNetLit)")
         return self.eval()
 
     def _config(self):
@@ -590,7 +591,7 @@ class WaveformModel:
         # against 2.5 ms of GPU work).
         torch = _torch()
         step = self.in_samples - int(args["overlap"])
-        chunk, n_win, pending = [], 0, []
+        chunk, n_win, pending, n_host = [], 0, [], 0
 
         def flush_chunk():
             if len(chunk) == 1:
@@ -600,7 +601,7 @@ class WaveformModel:
                     emit(g0, triggers)
             chunk.clear()
 
-        for i, grp in enumerate(_group_stream(stream, self.component_order, sr, copy, self.in_samples)):
+        for grp in _group_stream(stream, self.component_order, sr, copy, self.in_samples):
             if self._is_long(grp["data"].shape[1], args):  # a day-long block: its segments occupy all contexts
                 for g0, job in pending:
                     emit(g0, self._collect_block(job, args, specs)[0])
@@ -619,7 +620,8 @@ class WaveformModel:
             if len(pending) == max(1, self.n_contexts):
                 g0, job = pending.pop(0)
                 emit(g0, self._collect_block(job, args, specs)[0])
-            pending.append((grp, self._submit_block(i % max(1, self.n_contexts), grp["data"], args, specs, 8192)))
+            pending.append((grp, self._submit_block(n_host % max(1, self.n_contexts), grp["data"], args, specs, 8192)))
+            n_host += 1  # host blocks only: device-resident blocks take the chunk path and must not advance the context
         for g0, job in pending:
             emit(g0, self._collect_block(job, args, specs)[0])
         flush_chunk()

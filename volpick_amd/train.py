@@ -90,15 +90,21 @@ class PhaseNetTrainer:
         yk, yp, ym = self._arg(y)
         if xm != ym:
             raise ValueError("x and y must both be host arrays or both be device tensors")
+        if xm == _lib.VP_MEM_DEVICE:
+            # the trainer runs on its own stream: x / y (or their fp32 copies made above) must be complete first
+            _torch().cuda.current_stream(xk.device).synchronize()
         loss = C.c_double(float("nan"))
         _lib.check(self._lib.vp_train_step(self._h, xp, yp, xm, int(x.shape[0]), float(lr), int(bool(update)),
                                            C.byref(loss) if want_loss else None), "vp_train_step")
+        if xm == _lib.VP_MEM_DEVICE and not want_loss:
+            self._inputs_in_flight = (xk, yk)  # kept alive until the next step / synchronize(): the kernels still read them
         if update:
             self.global_step += 1
         return loss.value if want_loss else None
 
     def synchronize(self):
         _lib.check(self._lib.vp_train_synchronize(self._h))
+        self._inputs_in_flight = None
 
     def _read(self, which):
         out = np.empty(self.n_params, dtype=np.float32)
@@ -147,10 +153,11 @@ class PhaseNetTrainer:
             out[name.value.decode()] = a
         return out
 
-    def export(self):
-        """Copy the trained weights (and BatchNorm running statistics) back into ``self.model``."""
+    def export(self, ema=False):
+        """Copy the trained weights (and BatchNorm running statistics) back into ``self.model``;
+        ``ema=True`` exports the EMA weights instead (``enable_ema`` must have been called)."""
         sd = self.model.state_dict()
-        sd.update(self.weights())
+        sd.update(self.ema_weights() if ema else self.weights())
         for k in sd:
             if k.endswith("num_batches_tracked"):
                 sd[k] = np.asarray(sd[k] + self.global_step - getattr(self, "_exported_at", 0))
@@ -178,6 +185,7 @@ class PhaseNetLit:
         self.sigma = sigma
         self.model = model if model is not None else PhaseNet(**model_kwargs)
         self._trainer = None
+        self._ema = False
         self._max_batch, self._device = max_batch, device
 
     def _ensure(self):
@@ -186,21 +194,30 @@ class PhaseNetLit:
         return self._trainer
 
     def learning_rate(self, step):
-        """lr used by optimiser step number ``step`` (0-based).  Step 0 runs at ``lr`` (the optimiser's
-        initial value); after every step < 500 the reference sets lr * min(1, (global_step + 1) / 500)
-        with global_step = steps completed."""
-        if step == 0 or step > self.WARMUP_STEPS:
+        """lr used by optimiser step number ``step`` (0-based).  Step 0 runs at ``lr`` (the optimiser's initial
+        value).  The reference's ``optimizer_step`` hook (models.py:177-185) runs with ``trainer.global_step`` = the
+        steps completed BEFORE the current one (Lightning counts the step after the hook returns), so after step k it
+        sets lr * (k + 1) / 500 for step k + 1: step s >= 1 uses lr * s / 500, and the full lr is reached at step 500."""
+        if step == 0 or step >= self.WARMUP_STEPS:
             return self.lr
-        return self.lr * min(1.0, (step + 1) / float(self.WARMUP_STEPS))
+        return self.lr * step / float(self.WARMUP_STEPS)
 
     def training_step(self, batch, batch_idx=None):
         tr = self._ensure()
         return tr.step(batch["X"], batch["y"], self.learning_rate(tr.global_step), update=True)
 
     def validation_step(self, batch, batch_idx=None):
-        """Loss in eval mode (running statistics), as Lightning's validation loop computes it: the
-        current weights go through the inference path (``vp_forward``)."""
-        model = self._ensure().export()
+        """Loss in eval mode (running statistics), as Lightning's validation loop computes it: the current weights
+        go through the inference path (``vp_forward``).  The device plan is rebuilt only when an optimiser step
+        has happened since the last validation batch.  With EMA enabled (``enable_ema``) the EMA weights are the
+        ones validated, as the reference's EMA callback does with ``validate_original_weights=False``
+        (volpick/model/ema.py)."""
+        tr = self._ensure()
+        if getattr(self, "_validated_at", None) != tr.global_step:
+            model = tr.export(ema=self._ema)
+            self._validated_at = tr.global_step
+        else:
+            model = self.model
         if model._device_index is None:
             model.cuda(self._device)
         p = model(batch["X"])
@@ -208,6 +225,10 @@ class PhaseNetLit:
         y = batch["y"]
         y = y.cpu().numpy() if hasattr(y, "cpu") else np.asarray(y)
         return vector_cross_entropy(p.astype(np.float64), y.astype(np.float64))
+
+    def enable_ema(self, decay=0.999):
+        self._ensure().enable_ema(decay)
+        self._ema = True
 
     @property
     def trainer_state(self):
