@@ -62,7 +62,9 @@ typedef struct {
                                       all MFMA (bit-identical to the layer plan), 2 = three launches, level-0
                                       stride-1 convs on the VALU;
                                  [6]: 1 = the one-launch plan reads the input tensor filled by gather_normalize
-                                      instead of cutting and normalising its windows itself */
+                                      instead of cutting and normalising its windows itself;
+                                 [7]: EQTransformer: bit0 = decoder stages 4-6 + heads as three launches instead of the
+                                      time-tiled fused kernel (bit-identical; layer tests, A/B timing) */
 } vp_config;
 
 /* Fills cfg with the defaults for model_kind. */
@@ -222,7 +224,7 @@ int vp_debug_plan_conv(int model_kind, const float* weights, size_t n_floats, co
  * one of them as a dense (B, C, L) host array (used by the layer-by-layer parity tests). */
 int vp_debug_tensor_count(const vp_handle* h);
 int vp_debug_tensor_info(const vp_handle* h, int index, const char** name, int* channels, int* length);
-int vp_debug_tensor_read(vp_handle* h, int index, int B, float* host_out);
+int vp_debug_tensor_read(vp_handle* h, int index, int B, float* host_out);  /* VP_ERR_UNSUPPORTED: the plan keeps it in LDS */
 
 /* Debug guard of the data-layout invariant the conv loaders rely on: the margins of every
  * activation row -- [0, 8) and [8 + L, row stride) -- are the convolution padding, zeroed once at vp_create and never
@@ -238,6 +240,10 @@ int vp_debug_core_clock(vp_handle* h, int B, unsigned long long* out32);
 /* Same flag: 8 stamps per conv_mfma_kernel launch (in plan order of the conv layers) of one probe
  * workgroup: start, input staged, MFMA loop done, output staged, stored.  Returns the layer count. */
 int vp_debug_conv_clock(vp_handle* h, unsigned long long* out, int max_layers);
+/* Same flag, EQTransformer: B x 32 words of eqt_tail_kernel, one row per workgroup: six stamps for each of its first
+ * four tiles (tile start, image parked, after stage 4 / 5 / 6, heads done); [30], [31] the 100 MHz wall clock at kernel
+ * start / end. */
+int vp_debug_tail_clock(vp_handle* h, int B, unsigned long long* out32);
 
 /* ---------------------------------------------------------------------------------------------
  * Waveform-file ingestion: miniSEED 2 records -> sample arrays, the step the

@@ -15,7 +15,10 @@ def debug_tensors(model, B):
         name, c, l = C.c_char_p(), C.c_int(), C.c_int()
         _lib.check(lib.vp_debug_tensor_info(h, i, C.byref(name), C.byref(c), C.byref(l)))
         a = np.empty((B, c.value, l.value), np.float32)
-        _lib.check(lib.vp_debug_tensor_read(h, i, B, a.ctypes.data_as(C.c_void_p)))
+        rc = lib.vp_debug_tensor_read(h, i, B, a.ctypes.data_as(C.c_void_p))
+        if rc == -4:  # VP_ERR_UNSUPPORTED: the plan keeps this tensor in LDS (fused kernels)
+            continue
+        _lib.check(rc)
         out[name.value.decode()] = a
     return out
 

@@ -67,7 +67,16 @@ def _oracle_stages(net, x):
     return {k: v.numpy() for k, v in out.items()}, [f.numpy() for f in final]
 
 
-def test_layers_match_oracle(model, oracle):
+UNFUSED_TAIL = (0, 0, 0, 0, 0, 0, 0, 1)  # vp_config.reserved[7] bit 0: decoder.4 / .5 / .6+heads as three launches
+
+
+def test_layers_match_oracle(oracle):
+    """Every tensor the layer plan materialises, stage by stage.  The default plan never writes decoder.4 / .5 (they
+    live in LDS inside eqt_tail_kernel), so this runs the plan that keeps those launches; the next test ties the
+    fused kernel to it bit for bit."""
+    model = EQTransformer.from_pretrained("volpick")
+    model._plan_flags = UNFUSED_TAIL
+    model.cuda()
     B = 3
     x = synthetic_windows(B, 6000, seed=21)
     xn = OP.batch_pre(oracle, torch.from_numpy(x))
@@ -83,6 +92,23 @@ def test_layers_match_oracle(model, oracle):
         assert e <= 3e-4 * max(1.0, m), (n, e)
     for got, w in zip((det, p, s), final):
         assert np.abs(got.cpu().numpy() - w).max() < TOL
+
+
+@pytest.mark.parametrize("B", [1, 2, 5, 86, 256, 300])
+def test_fused_decoder_tail_is_bitwise_the_three_launches(model, B):
+    """eqt_tail_kernel (decoder stages 4-6 + heads per 2000-sample time tile, halos recomputed) uses the same packed
+    fragments, the same K order and the same head arithmetic as the conv_mfma_kernel launches it replaces: identical
+    bits, for every tile of every row (first / middle / last tile: left edge, interior, right edge of the signal), for
+    batch sizes that leave the persistent grid partly filled (B < 29), exactly filled, and wrapped several times."""
+    three = EQTransformer.from_pretrained("volpick")
+    three._plan_flags = UNFUSED_TAIL
+    three.cuda()
+    x = synthetic_windows(7, 6000, seed=640 + B)[np.arange(B) % 7] * np.linspace(0.5, 2.0, B, dtype=np.float32)[:, None, None]
+    xd = torch.from_numpy(x).cuda()
+    got = model._forward_raw(xd, preprocess=True)
+    want = three._forward_raw(xd, preprocess=True)
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    assert (got > 0).all() and (got < 1).all()
 
 
 @pytest.mark.parametrize("B", [1, 4, 256, 270])

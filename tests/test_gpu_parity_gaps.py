@@ -311,7 +311,7 @@ def test_halo_margins_stay_zero_after_ragged_calls(name):
     every plan variant, vp_debug_check_halos finds every margin word still zero."""
     lib = _lib.load()
     cls = va.PhaseNet if name == "phasenet" else va.EQTransformer
-    plans = [(0, 0), (0, 0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 2), (1, 0)] if name == "phasenet" else [(0, 0), (0, 0, 1)]
+    plans = [(0, 0), (0, 0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 2), (1, 0)] if name == "phasenet" else [(0, 0), (0, 0, 1), (0, 0, 0, 0, 0, 0, 0, 1)]
     for flags in plans:
         model = cls.from_pretrained("volpick")
         model._plan_flags = flags
@@ -327,13 +327,19 @@ def test_halo_margins_stay_zero_after_ragged_calls(name):
             _lib.check(lib.vp_debug_check_halos(model._context(ctx), 0, C.byref(bad), C.byref(where)),
                        "vp_debug_check_halos")
             assert bad.value == 0, (name, flags, where.value)
-        # the checker checking itself: one stray word planted in a margin of the last / the first tensor is found
+        # the checker checking itself: one stray word planted in a margin of any tensor is found, there and only there
         h = model._handle
-        for k in (lib.vp_debug_tensor_count(h), 1):
-            _lib.check(lib.vp_debug_check_halos(h, k, C.byref(bad), C.byref(where)))
+        planted = 0
+        for k in range(lib.vp_debug_tensor_count(h), 0, -1):
+            rc = lib.vp_debug_check_halos(h, k, C.byref(bad), C.byref(where))
+            if rc < 0:  # a tensor this plan keeps in LDS (decoder.4 / .5 under eqt_tail_kernel) has no rows to plant in
+                assert b"not materialised" in lib.vp_last_error()
+                continue
             nm = C.c_char_p()
             _lib.check(lib.vp_debug_tensor_info(h, k - 1, C.byref(nm), None, None))
             assert bad.value == 1 and where.value == nm.value
+            planted += 1
+        assert planted >= 2
         _lib.check(lib.vp_debug_check_halos(h, 0, C.byref(bad), C.byref(where)))
         assert bad.value == 0  # and the planted word was taken out again
         model._release()

@@ -146,6 +146,7 @@ SIGNATURES = {
     "vp_bcast_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "vp_debug_core_clock": (C.c_int, [_H, C.c_int, C.c_void_p]),
     "vp_debug_conv_clock": (C.c_int, [_H, C.c_void_p, C.c_int]),
+    "vp_debug_tail_clock": (C.c_int, [_H, C.c_int, C.c_void_p]),
     "vp_mseed_scan": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(VpMseedRecord), C.c_int64, _I64P]),
     "vp_mseed_decode": (
         C.c_int,

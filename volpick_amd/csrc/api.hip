@@ -951,6 +951,10 @@ int vp_debug_tensor_info(const vp_handle* h, int index, const char** name, int* 
 int vp_debug_tensor_read(vp_handle* h, int index, int B, float* host_out) {
   VP_REQUIRE(h && host_out && index >= 0 && index < (int)h->net.tensors.size(), "bad argument");
   const vp::Tensor& t = h->net.tensors[index];
+  if (h->net.tensor_sets[index] == 0) {  // lives in LDS only under this plan (e.g. decoder.4 / .5 inside eqt_tail_kernel)
+    vp::set_error("tensor %s is not materialised by this plan", t.name.c_str());
+    return VP_ERR_UNSUPPORTED;
+  }
   VP_REQUIRE(B > 0 && B <= h->net.max_batch * h->net.tensor_sets[index], "bad B");
   VP_HIP(hipSetDevice(h->device));
   VP_HIP(hipStreamSynchronize(h->stream));
@@ -972,6 +976,7 @@ int vp_debug_check_halos(vp_handle* h, int self_test, int64_t* n_bad, const char
   if (self_test > 0) {  // plant ONE stray word in the right margin of the tensor's last row, restored below
     const vp::Tensor& t = net.tensors[self_test - 1];
     const size_t rows = (size_t)t.C * net.max_batch * net.tensor_sets[self_test - 1];
+    VP_REQUIRE(rows > 0, "tensor %s is not materialised by this plan", t.name.c_str());
     planted = t.p + (rows - 1) * t.ls + vp::HALO + t.L;
     const float one = 1.f;
     VP_HIP(hipMemcpyAsync(planted, &one, sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -1016,6 +1021,18 @@ int vp_debug_core_clock(vp_handle* h, int B, unsigned long long* out32) {
   VP_HIP(hipSetDevice(h->device));
   VP_HIP(hipStreamSynchronize(h->stream));
   VP_HIP(hipMemcpy(out32, h->net.debug_clock->d, (size_t)B * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return VP_OK;
+}
+
+// Debug: the stamps of eqt_tail_kernel (third region of the EQTransformer debug clock buffer, eqt.hip).
+int vp_debug_tail_clock(vp_handle* h, int B, unsigned long long* out32) {
+  VP_REQUIRE(h && out32 && h->net.debug_clock && h->net.debug_clock->d, "no clock stamps (create with reserved[1] & 2)");
+  VP_REQUIRE(h->net.model_kind == VP_MODEL_EQTRANSFORMER && B > 0 && B <= h->net.max_batch, "EQTransformer handles only");
+  VP_HIP(hipSetDevice(h->device));
+  VP_HIP(hipStreamSynchronize(h->stream));
+  const unsigned long long* src =
+      reinterpret_cast<const unsigned long long*>(h->net.debug_clock->d) + (size_t)h->net.max_batch * 32 + 64 * 8;
+  VP_HIP(hipMemcpy(out32, src, (size_t)B * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return VP_OK;
 }
 

@@ -82,6 +82,23 @@ __device__ __forceinline__ void lds_epilogue(const f32x4 (&acc)[L::NB], const fl
       return;
     }
   }
+  // two copies of the loop nest, not one nest with the test inside: per element hipcc otherwise emits a branch around
+  // the range checks plus an exec-masked store (12 instructions and a taken branch per value, ~2 k cycles per block
+  // of 16 values with the matrix pipe idle -- tools/tail_clock.py)
+  if (fast) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co_lane + r / L::P, p = r % L::P;
+      const float b = biasv[r];
+#pragma unroll
+      for (int j = 0; j < L::NB; ++j) {
+        float v = acc[j][r] + b;
+        if (L::RELU) v = fmaxf(v, 0.f);
+        store.unchecked(co, L::P * (colb + j * 16 + n) + p + L::OUT_OFF, v);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int co = co_lane + r / L::P, p = r % L::P;
@@ -90,12 +107,7 @@ __device__ __forceinline__ void lds_epilogue(const f32x4 (&acc)[L::NB], const fl
     for (int j = 0; j < L::NB; ++j) {
       float v = acc[j][r] + b;
       if (L::RELU) v = fmaxf(v, 0.f);
-      const int t = L::P * (colb + j * 16 + n) + p + L::OUT_OFF;
-      if (fast) {
-        store.unchecked(co, t, v);
-      } else {
-        store(co, t, v);
-      }
+      store(co, L::P * (colb + j * 16 + n) + p + L::OUT_OFF, v);
     }
   }
 }

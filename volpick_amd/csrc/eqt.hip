@@ -484,11 +484,17 @@ int plan_eqt(Net& net, const ParamView& pv) {
   net.flops_per_window = 0;
   for (auto& s : net.steps) net.flops_per_window += s.flops_per_window;
   if (net.cfg.reserved[1] & 2)  // debug clock stamps of every conv launch (tools/conv_clock.py)
-    net.debug_clock = net.add_blob(std::vector<float>(((size_t)net.max_batch * 32 + 64 * 8) * 2, 0.f));
+    // [max_batch][32] eqt_mid_kernel | [64][8] conv launches | [max_batch][32] eqt_tail_kernel  (64-bit words)
+    net.debug_clock = net.add_blob(std::vector<float>(((size_t)net.max_batch * 64 + 64 * 8) * 2, 0.f));
   // reserved[0] = 1 keeps the 14 ResCNN conv launches (layer-by-layer debug / A-B plan)
   if (net.cfg.reserved[0] != 1) {
     int rc = plan_eqt_fuse_res(net);
-    return rc;
+    if (rc != VP_OK) return rc;
+  }
+  // reserved[7] bit 0 keeps decoder.4 / .5 / .6+heads as three launches (layer tests, A/B timing)
+  if (!(net.cfg.reserved[7] & 1) && !alt) {
+    int rc = plan_eqt_fuse_tail(net);
+    if (rc != VP_OK) return rc;
   }
   return VP_OK;
 }

@@ -108,6 +108,7 @@ int plan_phasenet(Net& net, const ParamView& pv);
 int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags);  // swaps the 18 layer steps for 3 fused launches; bit0: dump LDS intermediates, bit1: clock stamps
 int plan_eqt(Net& net, const ParamView& pv);
 int plan_eqt_fuse_res(Net& net);  // swaps the 14 ResCNN conv steps for one fused launch
+int plan_eqt_fuse_tail(Net& net);  // swaps decoder.4 / .5 / .6+heads for one time-tiled fused launch (eqt_tail.hip)
 
 
 // BatchNorm (eval) folded into the preceding conv: scale = gamma / sqrt(var + eps),
