@@ -60,9 +60,30 @@ struct has_vec4 : std::false_type {};
 template <class S>
 struct has_vec4<S, std::void_t<decltype(&S::vec4)>> : std::true_type {};
 
+// A store functor may bring its own epilogue for a whole block (`block_epilogue` member template): output layouts whose
+// addresses are cheap per block but not per element (eqt_tail.hip: the heads' transposed staging of stage 6).
+template <class S, class = void>
+struct has_block_epilogue : std::false_type {};
+template <class S>
+struct has_block_epilogue<S, std::void_t<decltype(S::custom_block_epilogue)>> : std::true_type {};
+
+template <class L, class Store>
+__device__ __forceinline__ void lds_epilogue_default(const f32x4 (&acc)[L::NB], const float (&biasv)[4], const int mt,
+                                                     const int colb, const int g, const int n, Store& store);
+
 template <class L, class Store>
 __device__ __forceinline__ void lds_epilogue(const f32x4 (&acc)[L::NB], const float (&biasv)[4], const int mt, const int colb,
                                              const int g, const int n, Store& store) {
+  if constexpr (has_block_epilogue<Store>::value) {
+    store.template block_epilogue<L>(acc, biasv, mt, colb, g, n);
+  } else {
+    lds_epilogue_default<L>(acc, biasv, mt, colb, g, n, store);
+  }
+}
+
+template <class L, class Store>
+__device__ __forceinline__ void lds_epilogue_default(const f32x4 (&acc)[L::NB], const float (&biasv)[4], const int mt,
+                                                     const int colb, const int g, const int n, Store& store) {
   static_assert(L::P == 1 || L::P == 2 || L::P == 4, "P must divide the 4-row register group");
   const int co_lane = mt * (16 / L::P) + (4 * g) / L::P;
   const int t_first = L::P * colb + L::OUT_OFF, t_last = L::P * (colb + L::NB * 16) - 1 + L::OUT_OFF;
