@@ -64,7 +64,8 @@ typedef struct {
                                  [6]: 1 = the one-launch plan reads the input tensor filled by gather_normalize
                                       instead of cutting and normalising its windows itself;
                                  [7]: EQTransformer: bit0 = decoder stages 4-6 + heads as three launches instead of the
-                                      time-tiled fused kernel (bit-identical; layer tests, A/B timing) */
+                                      time-tiled fused kernel, bit1 = decoder stages 0-3 as five launches instead of one
+                                      per-row fused kernel (all bit-identical; layer tests, A/B timing) */
 } vp_config;
 
 /* Fills cfg with the defaults for model_kind. */

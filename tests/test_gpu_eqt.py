@@ -67,15 +67,16 @@ def _oracle_stages(net, x):
     return {k: v.numpy() for k, v in out.items()}, [f.numpy() for f in final]
 
 
-UNFUSED_TAIL = (0, 0, 0, 0, 0, 0, 0, 1)  # vp_config.reserved[7] bit 0: decoder.4 / .5 / .6+heads as three launches
+# vp_config.reserved[7]: bit 0 = decoder.4 / .5 / .6+heads as three launches, bit 1 = decoder.0 .. .3 as five launches
+UNFUSED = (0, 0, 0, 0, 0, 0, 0, 3)
 
 
 def test_layers_match_oracle(oracle):
-    """Every tensor the layer plan materialises, stage by stage.  The default plan never writes decoder.4 / .5 (they
-    live in LDS inside eqt_tail_kernel), so this runs the plan that keeps those launches; the next test ties the
-    fused kernel to it bit for bit."""
+    """Every tensor the layer plan materialises, stage by stage.  The default plan never writes decoder.0 - .2 and
+    .4 / .5 (they live in LDS inside eqt_dec03_kernel / eqt_tail_kernel), so this runs the plan that keeps those
+    launches; the next test ties the fused kernels to it bit for bit."""
     model = EQTransformer.from_pretrained("volpick")
-    model._plan_flags = UNFUSED_TAIL
+    model._plan_flags = UNFUSED
     model.cuda()
     B = 3
     x = synthetic_windows(B, 6000, seed=21)
@@ -94,19 +95,22 @@ def test_layers_match_oracle(oracle):
         assert np.abs(got.cpu().numpy() - w).max() < TOL
 
 
+@pytest.mark.parametrize("keep", [1, 2, 3])
 @pytest.mark.parametrize("B", [1, 2, 5, 86, 256, 300])
-def test_fused_decoder_tail_is_bitwise_the_three_launches(model, B):
-    """eqt_tail_kernel (decoder stages 4-6 + heads per 2000-sample time tile, halos recomputed) uses the same packed
-    fragments, the same K order and the same head arithmetic as the conv_mfma_kernel launches it replaces: identical
-    bits, for every tile of every row (first / middle / last tile: left edge, interior, right edge of the signal), for
-    batch sizes that leave the persistent grid partly filled (B < 29), exactly filled, and wrapped several times."""
-    three = EQTransformer.from_pretrained("volpick")
-    three._plan_flags = UNFUSED_TAIL
-    three.cuda()
+def test_fused_decoder_kernels_are_bitwise_the_layer_launches(model, B, keep):
+    """eqt_dec03_kernel (decoder stages 0-3, one row per workgroup, intermediates in LDS, the cropped edge of stage 2
+    beside it) and eqt_tail_kernel (stages 4-6 + heads per 2000-sample time tile, halos recomputed, heads as a Toeplitz
+    product on the matrix cores) use the same packed fragments and the same K order as the conv_mfma_kernel launches
+    they replace: identical bits, for every tile of every row (left edge, interior, right edge of the signal), for
+    batch sizes that leave the persistent grids partly filled, exactly filled, and wrapped several times.  `keep`
+    (vp_config.reserved[7]) un-fuses the tail, the stages 0-3, or both."""
+    other = EQTransformer.from_pretrained("volpick")
+    other._plan_flags = (0, 0, 0, 0, 0, 0, 0, keep)
+    other.cuda()
     x = synthetic_windows(7, 6000, seed=640 + B)[np.arange(B) % 7] * np.linspace(0.5, 2.0, B, dtype=np.float32)[:, None, None]
     xd = torch.from_numpy(x).cuda()
     got = model._forward_raw(xd, preprocess=True)
-    want = three._forward_raw(xd, preprocess=True)
+    want = other._forward_raw(xd, preprocess=True)
     assert torch.equal(got.view(torch.int32), want.view(torch.int32))
     assert (got > 0).all() and (got < 1).all()
 

@@ -442,6 +442,8 @@ int plan_eqt(Net& net, const ParamView& pv) {
       }
       HostBlob* hw = net.add_blob(std::move(ew));
       HostBlob* hb = net.add_blob(std::move(eb));
+      net.named["decoder.2.edge.w"] = hw;
+      net.named["decoder.2.edge.b"] = hb;
       Step st;
       st.name = "decoder.2.edge";
       st.flops_per_window = 0;
@@ -494,6 +496,11 @@ int plan_eqt(Net& net, const ParamView& pv) {
   // reserved[7] bit 0 keeps decoder.4 / .5 / .6+heads as three launches (layer tests, A/B timing)
   if (!(net.cfg.reserved[7] & 1) && !alt) {
     int rc = plan_eqt_fuse_tail(net);
+    if (rc != VP_OK) return rc;
+  }
+  // bit 1 keeps decoder.0 .. .3 (+ the stage-2 edge fix) as five launches
+  if (!(net.cfg.reserved[7] & 2)) {
+    int rc = plan_eqt_fuse_dec03(net);
     if (rc != VP_OK) return rc;
   }
   return VP_OK;

@@ -1,0 +1,262 @@
+// EQTransformer decoder stages 0-3 as ONE launch: per (decoder, window) row the four stages (Upsample(2) + Conv1d + ReLU,
+// folded into two-phase filters, eqt.hip) run back to back inside one workgroup with every intermediate row in LDS:
+//
+//   decoder.in 16 x 47 -> stage 0: 64 x 94 -> stage 1: 64 x 188 -> stage 2: 32 x 375 (+ the cropped edge) -> stage 3: 32 x 750 -> memory
+//
+// As five launches (four conv_mfma_kernel + decoder2_edge_kernel) these stages took 148 us per 256 windows for 88 us of
+// MFMA issue: the rows are short (47 .. 375 columns), every launch is one or two residencies of the chip with its load
+// phase in lock step, and every intermediate made a round trip through memory (0.19 GB per step).  Here one 512-thread
+// workgroup per CU owns a row: 138 KB of LDS images, A operands of a stage (12 / 48 / 48 / 40 fragments per lane: every
+// wave keeps one m-tile) in registers, fetched as 16-byte loads while the stage before runs, B fragments out of LDS one
+// K-step ahead (conv_lds_areg).  The two outputs at the cropped right edge of stage 2 (eqt.hip: decoder2_edge_kernel)
+// are computed by one wave beside the stage itself, from the definition, with the same pre-summed taps.
+// Same packed fragments, same K order: bit-identical to the launches it replaces (plan flag reserved[7] & 2 keeps them).
+#include "conv_lds.h"
+#include "eqt_kernels.h"
+#include "net.h"
+
+namespace vp {
+
+namespace {
+
+constexpr int D03_NTH = 512, D03_WAVES = 8;
+//                      CIN1 CIN2 COUT P TAPS SN IN_OFF OUT_OFF NB RELU
+using D_0 = LdsLayer<16, 0, 64, 2, 3, 1, -1, 0, 3, 1>;  // 8 m-tiles x 1 block of 3 n-tiles: one block per wave
+using D_1 = LdsLayer<64, 0, 64, 2, 3, 1, -1, 0, 6, 1>;  // 8 m-tiles x 1 block of 6
+using D_2 = LdsLayer<64, 0, 32, 2, 3, 1, -1, 0, 6, 1>;  // 4 m-tiles x 2 blocks of 6
+using D_3 = LdsLayer<32, 0, 32, 2, 5, 1, -2, 0, 6, 1>;  // 4 m-tiles x 4 blocks of 6: two per wave
+constexpr int L0 = 47, L1 = 94, L2 = 188, L3 = 375, L4 = 750;  // row lengths: stage inputs and the final output
+constexpr int C0 = 48, C1 = 96, C2 = 192, C3 = 384;              // MFMA columns per stage
+// images: row strides == 16 mod 32, logical column 0 at physical column 4; wide enough for every column a stage computes
+constexpr int S0 = 80, S1 = 112, S2 = 208, S3 = 400, BI = 4;
+static_assert(S0 >= BI + C0 + 1 && S1 >= BI + 2 * C0 + 1 && S1 >= BI + C1 + 1 && S2 >= BI + 2 * C1 + 1 && S2 >= BI + C2 + 1 &&
+                  S3 >= BI + 2 * C2 + 2 && S3 >= BI + C3 + 2,
+              "image widths");
+static_assert(S0 % 32 == 16 && S1 % 32 == 16 && S2 % 32 == 16 && S3 % 32 == 16, "bank-conflict-free strides");
+constexpr int OFF0 = 0, OFF1 = OFF0 + 16 * S0, OFF2 = OFF1 + 64 * S1, OFF3 = OFF2 + 64 * S2, D03_LDS_FLOATS = OFF3 + 32 * S3;
+static_assert(D03_LDS_FLOATS * 4 <= 160 * 1024 && OFF1 % 4 == 0 && OFF2 % 4 == 0 && OFF3 % 4 == 0, "LDS budget");
+
+struct Dec03Args {
+  const float* x;  // decoder.in rows [3 B][16][ls]
+  int ls_x;
+  long ws_x;
+  float* y;        // decoder.3 rows [3 B][32][ls]
+  int ls_y;
+  long ws_y;
+  const float* af[4];  // A fragments regrouped for 16-byte loads [set][MT][CB * TAPS / 4][64][4]
+  const float* bs[4];  // bias [set][COUT]
+  long af_stride[4];
+  const float* edge_w;  // [3][64][64][3] pre-summed taps of the two edge outputs of stage 2 (eqt.hip)
+  const float* edge_b;  // [3][32]
+  int B, n_rows;
+};
+
+// Stage output t = 2 * column + phase at img[co * S + t]; [0, len) is the row, beyond it the next stage's zero padding.
+template <int S>
+struct RowStore {
+  float* img;  // image + BI
+  unsigned len;
+  __device__ __forceinline__ void operator()(int co, int t, float v) const { img[co * S + t] = ((unsigned)t < len) ? v : 0.f; }
+  __device__ __forceinline__ bool all_valid(int t0, int t1) const { return (unsigned)t1 < len; }
+  __device__ __forceinline__ void unchecked(int co, int t, float v) const { img[co * S + t] = v; }
+};
+// Stage 2: the samples from `hi` on belong to the edge fix (written beside this stage) or to the zero padding
+// (never written by anybody): they are skipped, not zeroed.
+template <int S>
+struct ClipStore {
+  float* img;
+  int hi;
+  __device__ __forceinline__ void operator()(int co, int t, float v) const {
+    if (t < hi) img[co * S + t] = v;
+  }
+  __device__ __forceinline__ bool all_valid(int t0, int t1) const { return t1 < hi; }
+  __device__ __forceinline__ void unchecked(int co, int t, float v) const { img[co * S + t] = v; }
+};
+// Stage 3 -> memory: registers (0, 1) / (2, 3) of a lane are two consecutive samples of one channel: 8-byte stores,
+// 16 lanes = one full 128-byte line per channel row.
+struct RowOut {
+  static constexpr bool custom_block_epilogue = true;
+  float* row0;  // y + win * ws + HALO
+  int ls;
+  template <class L>
+  __device__ __forceinline__ void block_epilogue(const f32x4 (&acc)[L::NB], const float (&biasv)[4], const int mt, const int colb,
+                                                 const int g, const int n) const {
+    static_assert(L::P == 2 && L::RELU == 1 && L::OUT_OFF == 0 && L4 % 2 == 0, "stage 3 of the decoder");
+#pragma unroll
+    for (int rr = 0; rr < 4; rr += 2) {
+      float* row = row0 + (long)(mt * 8 + 2 * g + rr / 2) * ls;
+#pragma unroll
+      for (int j = 0; j < L::NB; ++j) {
+        const int t = 2 * (colb + j * 16 + n);
+        if (t < L4)
+          *reinterpret_cast<float2*>(row + t) =
+              make_float2(fmaxf(acc[j][rr] + biasv[rr], 0.f), fmaxf(acc[j][rr + 1] + biasv[rr + 1], 0.f));
+      }
+    }
+  }
+};
+
+__global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
+  extern __shared__ float4 d03_lds_raw[];
+  float* lds = reinterpret_cast<float*>(d03_lds_raw);
+  // image offsets through an opaque register (eqt_tail.hip: keeps the B fragments' addresses inside the DS immediates)
+  int off1 = OFF1 / 4, off2 = OFF2 / 4, off3 = OFF3 / 4;
+  asm volatile("" : "+v"(off1), "+v"(off2), "+v"(off3));
+  float* X0 = lds + OFF0;
+  float* X1 = lds + 4 * off1;
+  float* X2 = lds + 4 * off2;
+  float* X3 = lds + 4 * off3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int row = blockIdx.x;  // row = d * B + b
+  if (row >= a.n_rows) return;
+  // every column no stage ever writes is convolution padding: zero once, for all rows of this workgroup
+  for (int i = tid; i < D03_LDS_FLOATS / 4; i += D03_NTH) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // the row's input: 16 x 47 samples, two per thread (rows of 47 + 1 slots), requested a row ahead
+  float pre[2];
+  auto request = [&](int r) {
+    const float* src = a.x + (long)r * a.ws_x + HALO;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int idx = tid + k * D03_NTH, c = idx / 48, t = idx - c * 48;
+      pre[k] = (idx < 16 * 48 && t < L0) ? src[(long)c * a.ls_x + t] : 0.f;
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int idx = tid + k * D03_NTH, c = idx / 48, t = idx - c * 48;
+      if (idx < 16 * 48) X0[c * S0 + BI + t] = pre[k];
+    }
+  };
+  request(row);
+  int d = row / a.B;
+  float areg0[D_0::CB * D_0::TAPS], bias0[4];
+  load_areg4<D_0>(a.af[0] + d * a.af_stride[0], wave_u, lane, areg0);
+  load_biasreg<D_0>(a.bs[0] + d * 64, wave_u, lane, bias0);
+  __syncthreads();  // the zero fill is complete before anybody parks or stores
+
+  const int mt23 = wave_u & 3, blk23 = wave_u >> 2;
+  while (true) {
+    const int next = row + gridDim.x;
+    const bool more = next < a.n_rows;
+    const int nd = more ? next / a.B : d;
+    park();
+    float areg1[D_1::CB * D_1::TAPS], bias1[4];
+    load_areg4<D_1>(a.af[1] + d * a.af_stride[1], wave_u, lane, areg1);
+    load_biasreg<D_1>(a.bs[1] + d * 64, wave_u, lane, bias1);
+    __syncthreads();
+    {  // stage 0: 16 x 47 -> 64 x 94
+      RowStore<S1> st{X1 + BI, (unsigned)L1};
+      conv_lds_areg<D_0, S0, BI, S0, BI>(X0, X0, areg0, bias0, wave_u, C0, st, 0, 1, lane);
+    }
+    float areg2[D_2::CB * D_2::TAPS], bias2[4];
+    load_areg4<D_2>(a.af[2] + d * a.af_stride[2], mt23, lane, areg2);
+    load_biasreg<D_2>(a.bs[2] + d * 32, mt23, lane, bias2);
+    __syncthreads();
+    {  // stage 1: 64 x 94 -> 64 x 188
+      RowStore<S2> st{X2 + BI, (unsigned)L2};
+      conv_lds_areg<D_1, S1, BI, S1, BI>(X1, X1, areg1, bias1, wave_u, C1, st, 0, 1, lane);
+    }
+    float areg3[D_3::CB * D_3::TAPS], bias3[4];
+    load_areg4<D_3>(a.af[3] + d * a.af_stride[3], mt23, lane, areg3);
+    load_biasreg<D_3>(a.bs[3] + d * 32, mt23, lane, bias3);
+    __syncthreads();
+    {  // stage 2: 64 x 188 -> 32 x 375; the folded filter is wrong for the two samples at the cropped edge (373, 374)
+      ClipStore<S3> st{X3 + BI, L3 - 2};
+      conv_lds_areg<D_2, S2, BI, S2, BI>(X2, X2, areg2, bias2, mt23, C2, st, blk23, 2, lane);
+      if (wave_u == D03_WAVES - 1) {  // ... which one wave computes from the definition (decoder2_edge_kernel, eqt.hip)
+        constexpr int n0 = (L3 - 2 - 2) >> 1;  // first stage-1 sample the two outputs see (185)
+        const float* e = a.edge_w + ((long)d * 64 * 64 + lane) * 3;
+        float acc = a.edge_b[d * 32 + (lane >> 1)];
+#pragma unroll 8
+        for (int ci = 0; ci < 64; ++ci) {
+          const float* ec = e + (long)ci * 64 * 3;
+          const float* xs = X2 + ci * S2 + BI + n0;
+          acc = fmaf(ec[0], xs[0], acc);
+          acc = fmaf(ec[1], xs[1], acc);
+          acc = fmaf(ec[2], xs[2], acc);
+        }
+        X3[(lane >> 1) * S3 + BI + L3 - 2 + (lane & 1)] = fmaxf(acc, 0.f);
+      }
+    }
+    if (more) {
+      request(next);
+      load_areg4<D_0>(a.af[0] + nd * a.af_stride[0], wave_u, lane, areg0);
+      load_biasreg<D_0>(a.bs[0] + nd * 64, wave_u, lane, bias0);
+    }
+    __syncthreads();
+    {  // stage 3: 32 x 375 -> 32 x 750, straight to memory
+      RowOut st{a.y + (long)row * a.ws_y + HALO, a.ls_y};
+      conv_lds_areg<D_3, S3, BI, S3, BI>(X3, X3, areg3, bias3, mt23, C3, st, blk23, 2, lane);
+    }
+    if (!more) break;
+    row = next;
+    d = nd;
+    // no barrier here: the next row's park writes X0 and its stage 0 writes X1, which nobody still reads; stage 3's
+    // readers of X3 are two barriers ahead of the next writer of X3
+  }
+}
+
+}  // namespace
+
+// Replaces the steps "decoder.0", "decoder.1", "decoder.2", "decoder.2.edge", "decoder.3" of the plan by one fused step.
+int plan_eqt_fuse_dec03(Net& net) {
+  int first = -1;
+  for (size_t i = 0; i < net.steps.size(); ++i)
+    if (net.steps[i].name == "decoder.0") first = (int)i;
+  if (first < 0 || first + 5 > (int)net.steps.size() || net.steps[first + 3].name != "decoder.2.edge" ||
+      net.steps[first + 4].name != "decoder.3") {
+    set_error("fused decoder stages 0-3: layer plan not found");
+    return VP_ERR_INVALID;
+  }
+  ConvLayer* c[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (auto& l : net.convs)
+    for (int i = 0; i < 4; ++i)
+      if (l->name == "decoder." + std::to_string(i)) c[i] = l.get();
+  HostBlob* ew = net.named.count("decoder.2.edge.w") ? net.named["decoder.2.edge.w"] : nullptr;
+  HostBlob* eb = net.named.count("decoder.2.edge.b") ? net.named["decoder.2.edge.b"] : nullptr;
+  if (!c[0] || !c[1] || !c[2] || !c[3] || !ew || !eb || c[0]->n_sets != 3) {
+    set_error("fused decoder stages 0-3: conv layers missing");
+    return VP_ERR_INVALID;
+  }
+  HostBlob* q[4];
+  for (int i = 0; i < 4; ++i) q[i] = c[i]->afrag_q4 ? c[i]->afrag_q4 : net.add_blob(regroup_afrag4(*c[i]));
+  const int x_in = c[0]->src1, y_out = c[3]->dst;
+  for (int i = 0; i < 3; ++i) net.tensor_sets[c[i]->dst] = 0;  // stages 0-2 live in LDS under this plan
+  Step st;
+  st.name = "fused.dec03 (decoder.0-3, one row per workgroup)";
+  st.flops_per_window = 0;
+  for (int i = 0; i < 5; ++i) st.flops_per_window += net.steps[first + i].flops_per_window;
+  // issued MFMA work per row: 8 m-tiles x 3 n-tiles x 12 K-steps, 8 x 6 x 48, 4 x 12 x 48, 4 x 24 x 40 (2048 FLOP each)
+  st.issued_flops_per_window = 3.0 * (8.0 * 3 * 12 + 8.0 * 6 * 48 + 4.0 * 12 * 48 + 4.0 * 24 * 40) * 2048.0;
+  st.run = [=](Net& n, int B, hipStream_t s) -> int {
+    Dec03Args a{};
+    const Tensor &tx = n.tensors[x_in], &ty = n.tensors[y_out];
+    a.x = tx.p;
+    a.ls_x = tx.ls;
+    a.ws_x = (long)tx.win_stride();
+    a.y = ty.p;
+    a.ls_y = ty.ls;
+    a.ws_y = (long)ty.win_stride();
+    for (int i = 0; i < 4; ++i) {
+      a.af[i] = q[i]->d;
+      a.bs[i] = c[i]->bias.d;
+      a.af_stride[i] = (long)(c[i]->afrag.h.size() / 3);
+    }
+    a.edge_w = ew->d;
+    a.edge_b = eb->d;
+    a.B = B;
+    a.n_rows = 3 * B;
+    const int grid = a.n_rows < 256 ? a.n_rows : 256;
+    hipLaunchKernelGGL(eqt_dec03_kernel, dim3(grid), dim3(D03_NTH), D03_LDS_FLOATS * sizeof(float), s, a);
+    return 0;
+  };
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_dec03_kernel), D03_LDS_FLOATS * sizeof(float)});
+  net.steps.erase(net.steps.begin() + first, net.steps.begin() + first + 5);
+  net.steps.insert(net.steps.begin() + first, std::move(st));
+  return VP_OK;
+}
+
+}  // namespace vp

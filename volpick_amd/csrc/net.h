@@ -55,6 +55,7 @@ struct Net {
   std::vector<std::unique_ptr<HostBlob>> extra;
   std::vector<Step> steps;
   std::vector<std::pair<const void*, size_t>> extra_kernels;  // (kernel, dynamic LDS bytes) needing the LDS attribute
+  std::map<std::string, HostBlob*> named;  // constant arrays a later fusion pass looks up by name (e.g. "decoder.2.edge.w")
   int input = -1;          // tensor id of the normalised haloed input windows
   float* y = nullptr;      // dense output [max_batch][n_out][in_samples]
   float* arena = nullptr;  // one device allocation for tensors + constants
@@ -109,6 +110,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags);  // swa
 int plan_eqt(Net& net, const ParamView& pv);
 int plan_eqt_fuse_res(Net& net);  // swaps the 14 ResCNN conv steps for one fused launch
 int plan_eqt_fuse_tail(Net& net);  // swaps decoder.4 / .5 / .6+heads for one time-tiled fused launch (eqt_tail.hip)
+int plan_eqt_fuse_dec03(Net& net);  // swaps decoder.0 / .1 / .2 / .2.edge / .3 for one launch per (decoder, window) row (eqt_dec03.hip)
 
 
 // BatchNorm (eval) folded into the preceding conv: scale = gamma / sqrt(var + eps),
