@@ -65,7 +65,8 @@ typedef struct {
                                       instead of cutting and normalising its windows itself;
                                  [7]: EQTransformer: bit0 = decoder stages 4-6 + heads as three launches instead of the
                                       time-tiled fused kernel, bit1 = decoder stages 0-3 as five launches instead of one
-                                      per-row fused kernel (all bit-identical; layer tests, A/B timing) */
+                                      per-row fused kernel, bit2 = encoder stages 0-2 as three launches instead of the
+                                      time-tiled fused kernel (all bit-identical; layer tests, A/B timing) */
 } vp_config;
 
 /* Fills cfg with the defaults for model_kind. */

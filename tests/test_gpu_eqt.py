@@ -67,13 +67,14 @@ def _oracle_stages(net, x):
     return {k: v.numpy() for k, v in out.items()}, [f.numpy() for f in final]
 
 
-# vp_config.reserved[7]: bit 0 = decoder.4 / .5 / .6+heads as three launches, bit 1 = decoder.0 .. .3 as five launches
-UNFUSED = (0, 0, 0, 0, 0, 0, 0, 3)
+# vp_config.reserved[7]: bit 0 = decoder.4 / .5 / .6+heads as three launches, bit 1 = decoder.0 .. .3 as five launches,
+# bit 2 = encoder.0 .. .2 as three launches
+UNFUSED = (0, 0, 0, 0, 0, 0, 0, 7)
 
 
 def test_layers_match_oracle(oracle):
     """Every tensor the layer plan materialises, stage by stage.  The default plan never writes decoder.0 - .2 and
-    .4 / .5 (they live in LDS inside eqt_dec03_kernel / eqt_tail_kernel), so this runs the plan that keeps those
+    .4 / .5 nor encoder.0 / .1 (they live in LDS inside the fused kernels), so this runs the plan that keeps those
     launches; the next test ties the fused kernels to it bit for bit."""
     model = EQTransformer.from_pretrained("volpick")
     model._plan_flags = UNFUSED
@@ -95,15 +96,16 @@ def test_layers_match_oracle(oracle):
         assert np.abs(got.cpu().numpy() - w).max() < TOL
 
 
-@pytest.mark.parametrize("keep", [1, 2, 3])
+@pytest.mark.parametrize("keep", [1, 2, 4, 7])
 @pytest.mark.parametrize("B", [1, 2, 5, 86, 256, 300])
 def test_fused_decoder_kernels_are_bitwise_the_layer_launches(model, B, keep):
-    """eqt_dec03_kernel (decoder stages 0-3, one row per workgroup, intermediates in LDS, the cropped edge of stage 2
+    """eqt_front_kernel (encoder stages 0-2 per 250-sample time tile, halos recomputed, MaxPool in registers / across
+    neighbouring lanes), eqt_dec03_kernel (decoder stages 0-3, one row per workgroup, intermediates in LDS, the cropped edge of stage 2
     beside it) and eqt_tail_kernel (stages 4-6 + heads per 2000-sample time tile, halos recomputed, heads as a Toeplitz
     product on the matrix cores) use the same packed fragments and the same K order as the conv_mfma_kernel launches
     they replace: identical bits, for every tile of every row (left edge, interior, right edge of the signal), for
     batch sizes that leave the persistent grids partly filled, exactly filled, and wrapped several times.  `keep`
-    (vp_config.reserved[7]) un-fuses the tail, the stages 0-3, or both."""
+    (vp_config.reserved[7]) un-fuses the tail, the decoder stages 0-3, the encoder front, or all of them."""
     other = EQTransformer.from_pretrained("volpick")
     other._plan_flags = (0, 0, 0, 0, 0, 0, 0, keep)
     other.cuda()

@@ -498,6 +498,11 @@ int plan_eqt(Net& net, const ParamView& pv) {
     int rc = plan_eqt_fuse_tail(net);
     if (rc != VP_OK) return rc;
   }
+  // bit 2 keeps encoder.0 .. .2 as three launches
+  if (!(net.cfg.reserved[7] & 4)) {
+    int rc = plan_eqt_fuse_front(net);
+    if (rc != VP_OK) return rc;
+  }
   // bit 1 keeps decoder.0 .. .3 (+ the stage-2 edge fix) as five launches
   if (!(net.cfg.reserved[7] & 2)) {
     int rc = plan_eqt_fuse_dec03(net);

@@ -1,0 +1,245 @@
+// EQTransformer encoder stages 0-2 (Conv1d + ReLU + MaxPool1d(2) each: 3 x 6000 -> 8 x 3000 -> 16 x 1500 -> 16 x 750)
+// as ONE launch per TIME TILE of a window.
+//
+// As three conv_mfma_kernel launches these stages took 67 us per 256 windows for 28 us of MFMA issue: their K is short
+// (48 / 72 / 112), so a launch is mostly its load phase, its pooled store and the kernel boundary, and the 8 x 3000 and
+// 16 x 1500 rows made a round trip through memory (0.1 GB per step).  Here a workgroup reads 3 x 2060 input samples,
+// runs the three stages LDS to LDS with the halo each needs recomputed (1-2 % extra MFMA work) and writes 16 x 250
+// pooled samples of stage 2.
+//
+//   tile of stage-2 pooled outputs [j0, j0 + 250) of the 750-sample row, j0 = 250 i:
+//     stage 2 columns  c2 = 2 j0      + [0,  500 /  512)   reads stage-1 pooled [c2 - 3, c2 + 3]
+//     stage 1 columns  c1 = 4 j0 - 6  + [0, 1012 / 1024)   reads stage-0 pooled [c1 - 4, c1 + 4]
+//     stage 0 columns  n0 = 4 j0 - 10 + [0, 1020 / 1024)   (two conv outputs 2 n0, 2 n0 + 1 per column = one pooled
+//                                                           sample) reads input samples [2 n0 - 5, 2 n0 + 6]
+//   Conv outputs outside a row's signal are zeroed before pooling: ReLU outputs are >= 0, so that is MaxPool's -1e10 pad
+//   for the odd tail and at the same time the next stage's zero padding.
+//
+// One 512-thread workgroup (8 wavefronts) per CU, persistent over the tiles.  All three stages have M = 16 (one m-tile):
+// the 12 + 18 + 28 A fragments stay in registers for the whole kernel and every wave takes one block of 8 / 8 / 4
+// n-tiles per stage.  MaxPool: stage 0 pools the two output phases of a column (two registers of a lane); stages 1 and 2
+// pool neighbouring columns = neighbouring lanes (one DPP move) and the even lane stores.
+// Same packed fragments, same K order, same max / ReLU arithmetic: bit-identical to the launches it replaces
+// (plan flag reserved[7] & 4 keeps them).
+#include "conv_lds.h"
+#include "eqt_kernels.h"
+#include "net.h"
+#include "prepost.h"
+
+namespace vp {
+
+namespace {
+
+constexpr int FR_NTH = 512, FR_WAVES = 8;
+constexpr int FW = 250, FR_TILES = 3;          // stage-2 pooled samples per tile; tiles per window
+constexpr int T_IN = 6000, L0P = 3000, L1P = 1500;  // row lengths: input, pooled stage 0 (= conv length of stage 1), pooled stage 1
+//                       CIN1 CIN2 COUT P TAPS SN IN_OFF OUT_OFF NB RELU
+using F_e0 = LdsLayer<3, 0, 8, 2, 12, 2, -5, 0, 8, 1>;
+using F_e1 = LdsLayer<8, 0, 16, 1, 9, 1, -4, 0, 8, 1>;
+using F_e2 = LdsLayer<16, 0, 16, 1, 7, 1, -3, 0, 4, 1>;
+constexpr int C0 = 1024, C1 = 1024, C2 = 512;  // MFMA columns per stage
+// images: the input with SN = 2 wants a row stride == 17 mod 32 (lanes read every second word: even banks for one
+// channel row of a half-wave, odd banks for the other), the others == 16 mod 32
+constexpr int SI = 2065, BII = 8, S0P = 1040, S1P = 528, BI = 4;
+static_assert(SI % 32 == 17 && S0P % 32 == 16 && S1P % 32 == 16, "bank-conflict-free strides");
+static_assert(SI >= BII + 2 * (C0 - 1) + 12 - 5 && S0P >= BI + C1 + 4 && S0P >= C0 && S1P >= BI + C2 + 3 && S1P >= 1 + C1 / 2,
+              "image widths");
+constexpr int OFFI = 0, OFF0P = 4 * SI + 4 - (4 * SI) % 4, OFF1P = OFF0P + 8 * S0P, FR_LDS_FLOATS = OFF1P + 16 * S1P;
+static_assert(FR_LDS_FLOATS * 4 <= 160 * 1024 && OFF0P % 4 == 0 && OFF1P % 4 == 0, "LDS budget");
+constexpr int PRE = (3 * SI + FR_NTH - 1) / FR_NTH;  // input samples a thread carries for the next tile
+
+struct FrontArgs {
+  const float* x;  // input rows [B][3][ls]
+  int ls_x;
+  long ws_x;
+  float* y;        // encoder.2 rows [B][16][ls]
+  int ls_y;
+  long ws_y;
+  const float* af[3];  // packed A fragments [CB][TAPS][64]
+  const float* bs[3];
+  int n_tiles;
+};
+
+__device__ __forceinline__ float lane_xor1(float v) { return dpp_move<0xB1, 0xF>(v); }  // quad_perm [1,0,3,2]
+
+// Stage 0: the two phases of a column (registers r, r + 1 of a lane) are the conv outputs 2 n0, 2 n0 + 1 = one pooled sample.
+struct Pool0Store {
+  static constexpr bool custom_block_epilogue = true;
+  float* img;      // image + shift: pooled sample of column c at img[co * S0P + c]
+  int s_lo;        // pooled sample index of column 0
+  template <class L>
+  __device__ __forceinline__ void block_epilogue(const f32x4 (&acc)[L::NB], const float (&biasv)[4], const int mt, const int colb,
+                                                 const int g, const int n) const {
+    static_assert(L::P == 2 && L::MT == 1 && L::RELU == 1, "stage 0 of the encoder");
+    (void)mt;
+    const bool fast = (unsigned)(s_lo + colb) < (unsigned)L0P && (unsigned)(s_lo + colb + L::NB * 16 - 1) < (unsigned)L0P;
+#pragma unroll
+    for (int rr = 0; rr < 4; rr += 2) {
+      float* row = img + (2 * g + rr / 2) * S0P + colb + n;
+#pragma unroll
+      for (int j = 0; j < L::NB; ++j) {
+        float v = fmaxf(fmaxf(acc[j][rr] + biasv[rr], 0.f), fmaxf(acc[j][rr + 1] + biasv[rr + 1], 0.f));
+        if (!fast) v = ((unsigned)(s_lo + colb + j * 16 + n) < (unsigned)L0P) ? v : 0.f;
+        row[j * 16] = v;
+      }
+    }
+  }
+};
+
+// Stages 1 / 2: neighbouring columns (lanes n, n ^ 1) pool; conv outputs outside the signal count as zero.
+template <bool TO_MEMORY>
+struct Pool1Store {
+  static constexpr bool custom_block_epilogue = true;
+  float* img;      // LDS: pooled sample of columns (c, c + 1) at img[co * stride + c / 2]; memory: row base of channel 0
+  int stride;
+  int cs_lo;       // conv sample index of column 0
+  unsigned len;    // conv row length
+  int cols;        // columns that exist (TO_MEMORY: the tile's share)
+  template <class L>
+  __device__ __forceinline__ void block_epilogue(const f32x4 (&acc)[L::NB], const float (&biasv)[4], const int mt, const int colb,
+                                                 const int g, const int n) const {
+    static_assert(L::P == 1 && L::MT == 1 && L::RELU == 1, "stages 1 / 2 of the encoder");
+    (void)mt;
+    const bool fast = (unsigned)(cs_lo + colb) < len && (unsigned)(cs_lo + colb + L::NB * 16 - 1) < len &&
+                      colb + L::NB * 16 <= cols;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* row = img + (long)(4 * g + r) * stride + ((colb + n) >> 1);
+#pragma unroll
+      for (int j = 0; j < L::NB; ++j) {
+        float v = fmaxf(acc[j][r] + biasv[r], 0.f);
+        if (!fast) v = ((unsigned)(cs_lo + colb + j * 16 + n) < len) ? v : 0.f;
+        const float m = fmaxf(v, lane_xor1(v));
+        if (!(n & 1) && (fast || colb + j * 16 + n < cols)) row[j * 8] = m;
+      }
+    }
+  }
+};
+
+__global__ __launch_bounds__(FR_NTH) void eqt_front_kernel(const FrontArgs a) {
+  extern __shared__ float4 fr_lds_raw[];
+  float* lds = reinterpret_cast<float*>(fr_lds_raw);
+  int off0 = OFF0P / 4, off1 = OFF1P / 4;  // opaque image offsets (eqt_tail.hip)
+  asm volatile("" : "+v"(off0), "+v"(off1));
+  float* XI = lds + OFFI;
+  float* E0P = lds + 4 * off0;
+  float* E1P = lds + 4 * off1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile = blockIdx.x;
+  if (tile >= a.n_tiles) return;
+  // the fourth channel row of the input image pads K to the 4-channel MFMA step: zero, once
+  for (int i = tid; i < SI + 4; i += FR_NTH) XI[3 * SI + i] = 0.f;
+
+  // input samples of a tile: 3 rows x the SI physical columns of the image; column p <-> sample 8 j0 - 28 + p of the row,
+  // zero outside [0, 6000)
+  float pre[PRE];
+  auto request = [&](int t) {
+    const int win = t / FR_TILES, j0 = (t - win * FR_TILES) * FW;
+    const float* src = a.x + (long)win * a.ws_x + HALO;
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const int idx = tid + k * FR_NTH, c = idx / SI, p = idx - c * SI;
+      const int smp = 8 * j0 - 28 + p;
+      pre[k] = (idx < 3 * SI && (unsigned)smp < (unsigned)T_IN) ? src[(long)c * a.ls_x + smp] : 0.f;
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const int idx = tid + k * FR_NTH;
+      if (idx < 3 * SI) XI[idx] = pre[k];  // rows are contiguous: image index == idx
+    }
+  };
+  request(tile);
+
+  // one m-tile per stage, the same weights for every window: all A fragments live in registers for the whole kernel
+  float areg0[F_e0::CB * F_e0::TAPS], areg1[F_e1::CB * F_e1::TAPS], areg2[F_e2::CB * F_e2::TAPS];
+  float bias0[4], bias1[4], bias2[4];
+  load_areg<F_e0>(a.af[0], 0, lane, areg0);
+  load_areg<F_e1>(a.af[1], 0, lane, areg1);
+  load_areg<F_e2>(a.af[2], 0, lane, areg2);
+  load_biasreg<F_e0>(a.bs[0], 0, lane, bias0);
+  load_biasreg<F_e1>(a.bs[1], 0, lane, bias1);
+  load_biasreg<F_e2>(a.bs[2], 0, lane, bias2);
+
+  while (true) {
+    const int next = tile + gridDim.x;
+    const bool more = next < a.n_tiles;
+    const int win = tile / FR_TILES, j0 = (tile - win * FR_TILES) * FW;
+    park();
+    __syncthreads();
+    {  // stage 0: column c <-> pooled sample 4 j0 - 10 + c = stage-1 logical column c - 4
+      Pool0Store st{E0P + BI - 4, 4 * j0 - 10};
+      conv_lds_areg<F_e0, SI, BII, SI, BII>(XI, XI, areg0, bias0, 0, C0, st, wave_u, FR_WAVES, lane);
+    }
+    __syncthreads();
+    if (more) request(next);  // travels under stages 1 and 2
+    __builtin_amdgcn_sched_barrier(0);
+    {  // stage 1: column c <-> conv sample 4 j0 - 6 + c; pooled sample 2 j0 - 3 + c / 2 = stage-2 logical column c / 2 - 3
+      Pool1Store<false> st{E1P + BI - 3, S1P, 4 * j0 - 6, (unsigned)L0P, C1};
+      conv_lds_areg<F_e1, S0P, BI, S0P, BI>(E0P, E0P, areg1, bias1, 0, C1, st, wave_u, FR_WAVES, lane);
+    }
+    __syncthreads();
+    {  // stage 2: column c <-> conv sample 2 j0 + c; pooled sample j0 + c / 2 of the window's encoder.2 row
+      Pool1Store<true> st{a.y + (long)win * a.ws_y + HALO + j0, a.ls_y, 2 * j0, (unsigned)L1P, 2 * FW};
+      conv_lds_areg<F_e2, S1P, BI, S1P, BI>(E1P, E1P, areg2, bias2, 0, C2, st, wave_u, FR_WAVES, lane);
+    }
+    if (!more) break;
+    tile = next;
+    // no barrier: the next park writes the input image, whose last readers (stage 0) are two barriers back
+  }
+}
+
+}  // namespace
+
+// Replaces the steps "encoder.0", "encoder.1", "encoder.2" of the plan by one fused step.
+int plan_eqt_fuse_front(Net& net) {
+  int first = -1;
+  for (size_t i = 0; i < net.steps.size(); ++i)
+    if (net.steps[i].name == "encoder.0") first = (int)i;
+  if (first < 0 || first + 3 > (int)net.steps.size() || net.steps[first + 2].name != "encoder.2") {
+    set_error("fused encoder front: layer plan not found");
+    return VP_ERR_INVALID;
+  }
+  ConvLayer* c[3] = {nullptr, nullptr, nullptr};
+  for (auto& l : net.convs)
+    for (int i = 0; i < 3; ++i)
+      if (l->name == "encoder." + std::to_string(i)) c[i] = l.get();
+  if (!c[0] || !c[1] || !c[2]) {
+    set_error("fused encoder front: conv layers missing");
+    return VP_ERR_INVALID;
+  }
+  const int x_in = c[0]->src1, y_out = c[2]->dst;
+  net.tensor_sets[c[0]->dst] = 0;  // encoder.0 / .1 live in LDS under this plan
+  net.tensor_sets[c[1]->dst] = 0;
+  Step st;
+  st.name = "fused.front (encoder.0-2, time-tiled)";
+  st.flops_per_window = 0;
+  for (int i = 0; i < 3; ++i) st.flops_per_window += net.steps[first + i].flops_per_window;
+  st.issued_flops_per_window = FR_TILES * (64.0 * 12 + 64.0 * 18 + 32.0 * 28) * 2048.0;
+  st.run = [=](Net& n, int B, hipStream_t s) -> int {
+    FrontArgs a{};
+    const Tensor &tx = n.tensors[x_in], &ty = n.tensors[y_out];
+    a.x = tx.p;
+    a.ls_x = tx.ls;
+    a.ws_x = (long)tx.win_stride();
+    a.y = ty.p;
+    a.ls_y = ty.ls;
+    a.ws_y = (long)ty.win_stride();
+    for (int i = 0; i < 3; ++i) {
+      a.af[i] = c[i]->afrag.d;
+      a.bs[i] = c[i]->bias.d;
+    }
+    a.n_tiles = B * FR_TILES;
+    const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
+    hipLaunchKernelGGL(eqt_front_kernel, dim3(grid), dim3(FR_NTH), FR_LDS_FLOATS * sizeof(float), s, a);
+    return 0;
+  };
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_front_kernel), FR_LDS_FLOATS * sizeof(float)});
+  net.steps.erase(net.steps.begin() + first, net.steps.begin() + first + 3);
+  net.steps.insert(net.steps.begin() + first, std::move(st));
+  return VP_OK;
+}
+
+}  // namespace vp
