@@ -66,7 +66,8 @@ typedef struct {
                                  [7]: EQTransformer: bit0 = decoder stages 4-6 + heads as three launches instead of the
                                       time-tiled fused kernel, bit1 = decoder stages 0-3 as five launches instead of one
                                       per-row fused kernel, bit2 = encoder stages 0-2 as three launches instead of the
-                                      time-tiled fused kernel (all bit-identical; layer tests, A/B timing) */
+                                      time-tiled fused kernel, bit3 = encoder stages 3-6 as four launches instead of one
+                                      per-window fused kernel (all bit-identical; layer tests, A/B timing) */
 } vp_config;
 
 /* Fills cfg with the defaults for model_kind. */

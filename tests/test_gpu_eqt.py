@@ -68,8 +68,8 @@ def _oracle_stages(net, x):
 
 
 # vp_config.reserved[7]: bit 0 = decoder.4 / .5 / .6+heads as three launches, bit 1 = decoder.0 .. .3 as five launches,
-# bit 2 = encoder.0 .. .2 as three launches
-UNFUSED = (0, 0, 0, 0, 0, 0, 0, 7)
+# bit 2 = encoder.0 .. .2 as three launches, bit 3 = encoder.3 .. .6 as four launches
+UNFUSED = (0, 0, 0, 0, 0, 0, 0, 15)
 
 
 def test_layers_match_oracle(oracle):
@@ -96,16 +96,16 @@ def test_layers_match_oracle(oracle):
         assert np.abs(got.cpu().numpy() - w).max() < TOL
 
 
-@pytest.mark.parametrize("keep", [1, 2, 4, 7])
+@pytest.mark.parametrize("keep", [1, 2, 4, 8, 15])
 @pytest.mark.parametrize("B", [1, 2, 5, 86, 256, 300])
 def test_fused_decoder_kernels_are_bitwise_the_layer_launches(model, B, keep):
     """eqt_front_kernel (encoder stages 0-2 per 250-sample time tile, halos recomputed, MaxPool in registers / across
-    neighbouring lanes), eqt_dec03_kernel (decoder stages 0-3, one row per workgroup, intermediates in LDS, the cropped edge of stage 2
+    neighbouring lanes), eqt_enc36_kernel (encoder stages 3-6, one window per workgroup), eqt_dec03_kernel (decoder stages 0-3, one row per workgroup, intermediates in LDS, the cropped edge of stage 2
     beside it) and eqt_tail_kernel (stages 4-6 + heads per 2000-sample time tile, halos recomputed, heads as a Toeplitz
     product on the matrix cores) use the same packed fragments and the same K order as the conv_mfma_kernel launches
     they replace: identical bits, for every tile of every row (left edge, interior, right edge of the signal), for
     batch sizes that leave the persistent grids partly filled, exactly filled, and wrapped several times.  `keep`
-    (vp_config.reserved[7]) un-fuses the tail, the decoder stages 0-3, the encoder front, or all of them."""
+    (vp_config.reserved[7]) un-fuses the tail, the decoder stages 0-3, the encoder front, the encoder stages 3-6, or all of them."""
     other = EQTransformer.from_pretrained("volpick")
     other._plan_flags = (0, 0, 0, 0, 0, 0, 0, keep)
     other.cuda()

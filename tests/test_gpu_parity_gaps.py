@@ -311,7 +311,7 @@ def test_halo_margins_stay_zero_after_ragged_calls(name):
     every plan variant, vp_debug_check_halos finds every margin word still zero."""
     lib = _lib.load()
     cls = va.PhaseNet if name == "phasenet" else va.EQTransformer
-    plans = [(0, 0), (0, 0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 2), (1, 0)] if name == "phasenet" else [(0, 0), (0, 0, 1), (0, 0, 0, 0, 0, 0, 0, 7)]
+    plans = [(0, 0), (0, 0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 2), (1, 0)] if name == "phasenet" else [(0, 0), (0, 0, 1), (0, 0, 0, 0, 0, 0, 0, 15)]
     for flags in plans:
         model = cls.from_pretrained("volpick")
         model._plan_flags = flags

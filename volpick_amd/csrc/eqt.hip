@@ -503,6 +503,11 @@ int plan_eqt(Net& net, const ParamView& pv) {
     int rc = plan_eqt_fuse_front(net);
     if (rc != VP_OK) return rc;
   }
+  // bit 3 keeps encoder.3 .. .6 as four launches
+  if (!(net.cfg.reserved[7] & 8)) {
+    int rc = plan_eqt_fuse_enc36(net);
+    if (rc != VP_OK) return rc;
+  }
   // bit 1 keeps decoder.0 .. .3 (+ the stage-2 edge fix) as five launches
   if (!(net.cfg.reserved[7] & 2)) {
     int rc = plan_eqt_fuse_dec03(net);
