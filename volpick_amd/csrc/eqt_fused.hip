@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void eqt_res_kernel(const ResArgs a) {
   __shared__ __attribute__((aligned(16))) float X[64 * RS];
   __shared__ __attribute__((aligned(16))) float ACT[64 * RS];
   __shared__ __attribute__((aligned(16))) float MID[64 * RS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, win = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), win = blockIdx.x;
   // The 14 convs are a chain of short K loops over 690 KB of weights that the kernels before this one have pushed
   // out of L2: every workgroup would wait out the same HBM round trips, one channel block after the other
   // (91 us in the pipeline against 52 us on warm weights).  The first eight workgroups -- one per XCD, since

@@ -142,7 +142,9 @@ template <bool PIPE>
 __global__ __launch_bounds__(1024) void pn_core_kernel(const CoreArgs a) {
   extern __shared__ float4 lds_raw[];
   float* lds = reinterpret_cast<float*>(lds_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, win = blockIdx.x;
+  // (the wave index as a scalar: item loops, block indices and the epilogues' "whole block in range" tests become
+  // scalar code instead of per-lane predicates)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), win = blockIdx.x;
   constexpr int NTH = 1024, NWV = 16;
   int stamp = 0;
   if (a.clk && tid == 0) a.clk[(long)win * 32 + 16] = wall_clock64();  // 100 MHz constant clock
@@ -962,7 +964,9 @@ template <bool PIPE>
 __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   extern __shared__ float4 lds_raw[];
   float* lds = reinterpret_cast<float*>(lds_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, win = blockIdx.x;
+  // (the wave index as a scalar: item loops, block indices and the epilogues' "whole block in range" tests become
+  // scalar code instead of per-lane predicates)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), win = blockIdx.x;
   constexpr int NTH = 1024, NWV = 16;
   unsigned long long* clk = a.c.clk;
   if (clk && tid == 0) clk[(long)win * 32 + 16] = wall_clock64();
