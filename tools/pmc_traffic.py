@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""HBM bytes per launch from two rocprofv3 counter passes -> profiles/r01_traffic.json.
+"""HBM bytes per launch from two rocprofv3 counter passes -> profiles/r02_traffic.json.
 
     tools/pmc_traffic.sh            (on the GPU box: four --pmc runs of tools/run_forward.py, counters only)
     python tools/pmc_traffic.py gpurun_out/pmc
 
 bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: both counters are in KiB, and FETCH_SIZE under-reports by 2x on
 gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section).  The first launch of every kernel (cold caches, plan
-warm-up) is dropped; kernels are mapped to plan step names by their order in the forward pass."""
+warm-up) is dropped; kernels are mapped to plan step names by a substring of their name.  "_step_total" is the sum
+over every kernel of one forward pass (256 windows: annotate_batch_pre + the model)."""
 import csv
 import json
 import sys
@@ -14,6 +15,7 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
+OUT = ROOT / "profiles" / "r02_traffic.json"
 
 
 def per_kernel(path, counter):
@@ -25,27 +27,41 @@ def per_kernel(path, counter):
     return {k: [v for _, v in sorted(vs)][1:] for k, vs in vals.items()}  # drop the first launch
 
 
+NAMES = {
+    "phasenet": [("pn_window_kernel", "fused.window (whole PhaseNet, one workgroup per window)")],
+    "eqtransformer": [("eqt_front_kernel", "fused.front (encoder.0-2, time-tiled)"),
+                      ("eqt_enc36_kernel", "fused.enc36 (encoder.3-6, one window per workgroup)"),
+                      ("eqt_res_kernel", "fused.rescnn (7 residual blocks)"),
+                      ("eqt_mid_kernel", "fused.mid (3 BiLSTM + 2 transformer blocks + pick branches)"),
+                      ("eqt_dec03_kernel", "fused.dec03 (decoder.0-3, one row per workgroup)"),
+                      ("eqt_tail_kernel", "fused.tail (decoder.4-6 + heads, time-tiled)")],
+}
+
+
 def main():
     d = Path(sys.argv[1])
     out = {"_note": "HBM bytes per launch at 256 windows = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, rocprofv3 --pmc FETCH_SIZE / "
                     "--pmc WRITE_SIZE in separate passes of tools/run_forward.py (tools/pmc_traffic.sh, tools/pmc_traffic.py), "
-                    "gfx950 FETCH_SIZE x2 correction per MI355X_MICROARCH.md"}
-    names = {
-        "phasenet": [("pn_window_kernel", "fused.window (whole PhaseNet, one workgroup per window)")],
-        "eqtransformer": [("ConvCfg<16, 0, 8, 2, 7, 1, -3, 0, 1, 4, 6, 1, 6, 1>", "decoder.6+heads"),
-                          ("eqt_res_kernel", "fused.rescnn (7 residual blocks)"),
-                          ("eqt_mid_kernel", "fused.mid (3 BiLSTM + 2 transformer blocks + pick branches)")],
-    }
+                    "gfx950 FETCH_SIZE x2 correction per MI355X_MICROARCH.md; _step_total = all kernels of one forward pass"}
     for model, tag in (("phasenet", "pn"), ("eqtransformer", "eqt")):
         fetch = per_kernel(next(d.glob(f"{tag}_fetch/**/*counter_collection.csv")), "FETCH_SIZE")
         write = per_kernel(next(d.glob(f"{tag}_write/**/*counter_collection.csv")), "WRITE_SIZE")
         out[model] = {}
-        for needle, step in names[model]:
-            k = next(k for k in fetch if needle in k)
+        total = 0.0
+        for k in fetch:
+            if not fetch[k] or k not in write or not write[k]:
+                continue
+            total += (2 * sum(fetch[k]) / len(fetch[k]) + sum(write[k]) / len(write[k])) * 1024
+        for needle, step in NAMES[model]:
+            ks = [k for k in fetch if needle in k]
+            if not ks:
+                continue
+            k = ks[0]
             f = sum(fetch[k]) / len(fetch[k])
             w = sum(write[k]) / len(write[k])
             out[model][step] = int(round((2 * f + w) * 1024, -5))
-    (ROOT / "profiles" / "r01_traffic.json").write_text(json.dumps(out, indent=2) + "\n")
+        out[model]["_step_total"] = int(round(total, -5))
+    OUT.write_text(json.dumps(out, indent=2) + "\n")
     print(json.dumps(out, indent=2))
 
 

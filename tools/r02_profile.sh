@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round-2 artifact set, on the GPU box: gpurun --timeout 1200 -- 'bash tools/r02_profile.sh TAG'
+# -> gpurun_out/r02_TAG/: GPU suite, the default bench line (both models), rocprofv3 --kernel-trace --stats of the same
+# command, bench --strong at N = 1, phase clocks of eqt_tail_kernel / pn_window_kernel, the same-box A/B of the fused
+# EQTransformer plan against the layer launches.  PMC traffic: tools/pmc_traffic.sh (separate call).
+export TMPDIR=/tmp
+T=${1:-a}; R=$PWD; O=$R/gpurun_out/r02_$T; mkdir -p $O
+timeout -k 10 500 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_gpu.txt
+timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof.err
+cd $R
+find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats.csv \;
+rm -rf $O/prof
+timeout -k 10 200 python bench.py --strong --steps 10 --warmup 2 > $O/bench_strong_n1.json 2> $O/strong.err; echo "strong rc=$?"
+timeout -k 10 100 python tools/tail_clock.py 10 > $O/eqt_tail_kernel_phases.txt 2>&1
+timeout -k 10 100 python tools/core_clock.py > $O/phasenet_window_kernel_phases.txt 2>&1
+tools/ab_e2e.sh 3 0 0,0,0,0,0,0,0,15 > $O/eqt_fused_vs_layer_launches_e2e.txt 2>&1
+timeout -k 10 200 python tools/ab_steps.py eqtransformer "0" "0,0,0,0,0,0,0,15" > $O/eqt_fused_vs_layer_launches_steps.txt 2>&1
+ls -la $O
