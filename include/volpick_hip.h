@@ -290,7 +290,12 @@ int vp_mseed_decode_bench(int device_id, const uint8_t* buf_dev, size_t nbytes, 
  * PhaseNet training step (BASELINE config 5): what one
  * PhaseNetLit.training_step + Adam optimizer.step of the reference computes
  * (/root/reference volpick/model/models.py:34-51 vector_cross_entropy, :160-164 training_step,
- * :177-185 torch.optim.Adam).  fp32 throughout.
+ * :177-185 torch.optim.Adam).  vp_train_create: fp32 throughout (what the reference trains in: no autocast).
+ * vp_train_create_dtype(..., VP_TRAIN_BF16, ...): the activation and gradient rows of every layer (z, a, gz, ga -- all
+ * of the step's HBM traffic but the weights) rest in memory as bfloat16, round-to-nearest-even on store; weights,
+ * weight gradients, BatchNorm statistics, the loss and the Adam state stay fp32 and every product accumulates in
+ * fp32 (BASELINE config 5's dtype).  Inputs, labels, predictions and everything vp_train_read returns are fp32 in
+ * both modes; vp_train_tensor_read widens.
  *
  * vp_train_create uploads the flat weight blob (same order as vp_create; BatchNorm running
  * statistics included) and sizes the workspace for max_batch windows.  vp_train_step runs
@@ -301,8 +306,13 @@ int vp_mseed_decode_bench(int device_id, const uint8_t* buf_dev, size_t nbytes, 
  * NULL; non-NULL synchronises) receives the batch loss.  vp_train_read copies out 0 = weights,
  * 1 = gradients of the last step, 2/3 = Adam first/second moments, 4 = EMA weights. */
 typedef struct vp_trainer vp_trainer;
+#define VP_TRAIN_FP32 0
+#define VP_TRAIN_BF16 1
 int vp_train_create(int device_id, int model_kind, const float* weights, size_t n_floats, int max_batch,
                     vp_trainer** out);
+int vp_train_create_dtype(int device_id, int model_kind, const float* weights, size_t n_floats, int max_batch, int dtype,
+                          vp_trainer** out);
+int vp_train_dtype(const vp_trainer* t); /* VP_TRAIN_FP32 / VP_TRAIN_BF16 */
 int vp_train_destroy(vp_trainer* t);
 int vp_train_set_hyper(vp_trainer* t, float beta1, float beta2, float adam_eps, float bn_momentum, float loss_eps);
 /* Optional exponential moving average of the weights after every update (the reference's EMA callback,

@@ -2,7 +2,7 @@
 VCSEIS-shaped synthetic batches resident in HBM, next to the same step through torch autograd on the
 host cores (the oracle module, `kind: "port"`).
 
-    python tools/bench_train.py [--batch 512] [--steps 30] [--warmup 5] [--no-cpu-baseline]
+    python tools/bench_train.py [--batch 512] [--dtype fp32|bf16] [--steps 30] [--warmup 5] [--no-cpu-baseline]
 """
 import argparse
 import json
@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="storage of the activation / gradient tensors (bf16 = BASELINE config 5; accumulation is fp32 either way)")
+    ap.add_argument("--torch-gpu-autocast", action="store_true", help="with --torch-gpu: run the torch step under bf16 autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--torch-gpu", action="store_true", help="also time stock PyTorch-ROCm on the same GPU")
@@ -44,7 +47,7 @@ def main():
     B = a.batch
     x, y = make_batch(B)
     xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
-    tr = PhaseNetTrainer(PhaseNet.from_pretrained("volpick"), max_batch=B)
+    tr = PhaseNetTrainer(PhaseNet.from_pretrained("volpick"), max_batch=B, dtype=a.dtype)
     for _ in range(a.warmup):
         tr.step(xd, yd, 1e-4, want_loss=False)
     tr.synchronize()
@@ -55,8 +58,8 @@ def main():
     dt = (time.perf_counter() - t0) / a.steps
     loss = tr.step(xd, yd, 1e-4)
     out = {
-        "metric": "PhaseNet training windows/sec (fwd+loss+bwd+Adam, fp32)", "value": B / dt, "unit": "windows/s",
-        "ms_per_step": dt * 1e3, "batch": B, "steps": a.steps, "warmup": a.warmup, "dtype": "f32", "data": "synthetic",
+        "metric": f"PhaseNet training windows/sec (fwd+loss+bwd+Adam, {a.dtype})", "value": B / dt, "unit": "windows/s",
+        "ms_per_step": dt * 1e3, "batch": B, "steps": a.steps, "warmup": a.warmup, "dtype": "f32" if a.dtype == "fp32" else "bf16 storage / f32 accumulate", "data": "synthetic",
         "loss_after": loss,
         "roofline": {"bound": "mfma", "achieved": 3 * FLOP_FWD * B / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                      "frac": 3 * FLOP_FWD * B / dt / 157.3e12,
@@ -94,8 +97,9 @@ def main():
 
         def gpu_step():
             gopt.zero_grad(set_to_none=True)
-            pred = gnet(xd)
-            l = -(yd * torch.log(pred + 1e-5)).mean(-1).sum(-1).mean()
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.torch_gpu_autocast):
+                pred = gnet(xd)
+            l = -(yd * torch.log(pred.float() + 1e-5)).mean(-1).sum(-1).mean()
             l.backward()
             gopt.step()
 
@@ -108,7 +112,7 @@ def main():
         torch.cuda.synchronize()
         gt = (time.perf_counter() - t0) / 10
         out["torch_rocm_same_gpu"] = {"value": B / gt, "unit": "windows/s", "ms_per_step": gt * 1e3,
-                                      "note": f"torch {torch.__version__} eager, fp32, batch {B}"}
+                                      "note": f"torch {torch.__version__} eager, {'bf16 autocast' if a.torch_gpu_autocast else 'fp32'}, batch {B}"}
     print(json.dumps(out))
 
 

@@ -13,6 +13,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("VOLPICK_HIP_LIB", _HERE / "libvolpick_hip.so"))
 
 VP_MODEL_PHASENET, VP_MODEL_EQTRANSFORMER = 0, 1
+VP_TRAIN_FP32, VP_TRAIN_BF16 = 0, 1
 VP_NORM_PEAK, VP_NORM_STD = 0, 1
 VP_STACK_AVG, VP_STACK_MAX = 0, 1
 VP_MEM_HOST, VP_MEM_DEVICE = 0, 1
@@ -159,6 +160,8 @@ SIGNATURES = {
          C.c_int, _FP],
     ),
     "vp_train_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(_H)]),
+    "vp_train_create_dtype": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(_H)]),
+    "vp_train_dtype": (C.c_int, [_H]),
     "vp_train_destroy": (C.c_int, [_H]),
     "vp_train_set_hyper": (C.c_int, [_H, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
     "vp_train_set_ema": (C.c_int, [_H, C.c_float]),

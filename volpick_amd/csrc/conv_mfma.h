@@ -21,6 +21,7 @@
 // The input image is fetched with unguarded, 16-byte coalesced loads because every
 // activation row carries zeroed halos (vp_common.h).
 #pragma once
+#include "bf16.h"
 #include "vp_common.h"
 
 namespace vp {
@@ -82,8 +83,12 @@ struct ConvGeom {  // runtime mirror of the template parameters (planning / pack
 };
 
 template <int CIN1_, int CIN2_, int COUT_, int P_, int TAPS_, int SN_, int IN_OFF_, int OUT_OFF_, int WAVES_M_,
-          int WAVES_N_, int NW_, int RELU_, int EPI_, int APRE_ = 0, int AQ4_ = 0>
+          int WAVES_N_, int NW_, int RELU_, int EPI_, int APRE_ = 0, int AQ4_ = 0, int BF16_ = 0>
 struct ConvCfg {
+  // BF16: source and destination rows rest in memory as bfloat16 (training step, bf16.h): the loader widens 8-byte
+  // groups of four samples into the fp32 LDS image, the EPI_STORE epilogues round on the way out; strides (ls, ws) count
+  // elements.  The MFMA loop, the fragments and the bias are fp32 either way.
+  static constexpr bool BF16 = BF16_ != 0;
   static constexpr bool APRE = APRE_ != 0;  // A fragments of channel block 0 requested ahead of the input tile
   // AQ4: the A operand comes regrouped [m-tile][K-step / 4][lane][4] (regroup_afrag4) as one 16-byte load per four
   // K-steps -- the weight-heavy layers (64 -> 64 channels: 98 KB of fragments per workgroup) issue 4x fewer memory
@@ -114,6 +119,7 @@ struct ConvCfg {
   static_assert(M % (16 * WAVES_M) == 0, "M must tile into 16-row MFMA tiles per wave");
   static_assert(S >= 4 * W4 && S % 32 == 16, "LDS stride");
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+  static_assert(!BF16 || EPI == EPI_STORE, "bf16 rows: plain stores only (training step)");
   static ConvGeom geom() {
     return ConvGeom{CIN1, CIN2, COUT, P, TAPS, SN, IN_OFF, OUT_OFF, WAVES_M, WAVES_N, NW, RELU, EPI};
   }
@@ -150,14 +156,44 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   // ---- stage the input tile: CINP rows x 4*W4 floats, aligned 16-byte loads --------------
   {
     const int a0 = HALO + C::SN * col0 + C::IN_OFF_F4;  // multiple of 4 by construction
-    const float* s1 = a.src1 + (long)win * a.ws1 + a0;
-    const float* s2 = (C::CIN2 > 0) ? a.src2 + (long)win * a.ws2 + a0 : nullptr;
     // All of a thread's loads are issued before its first LDS write (chunks of 8 x 16 B in flight):
     // the rolled form serialised load -> wait -> ds_write and cost 5-17k cycles of pure latency per tile.
     // (a tile of 9 or 13 quads per thread -- decoder.6, decoder.2 -- takes them in ONE chunk: a second chunk of one or
     // five loads behind the first chunk's LDS writes was a second, fully exposed memory round trip: 13.7 k cycles of
     // load phase against 6 k for the layers with <= 8 quads, tools/conv_clock.py)
     constexpr int TOT = C::CINP * C::W4, N_IT = (TOT + 255) / 256, CH = (N_IT <= 13) ? N_IT : 8;
+    if constexpr (C::BF16) {
+      const bf16_t* s1 = reinterpret_cast<const bf16_t*>(a.src1) + (long)win * a.ws1 + a0;
+      const bf16_t* s2 = (C::CIN2 > 0) ? reinterpret_cast<const bf16_t*>(a.src2) + (long)win * a.ws2 + a0 : nullptr;
+#pragma unroll
+      for (int it0 = 0; it0 < N_IT; it0 += CH) {
+        uint2 v[CH];  // four samples each
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const int idx = tid + (it0 + k) * 256;
+          v[k] = make_uint2(0u, 0u);
+          if (it0 + k < N_IT && idx < TOT) {
+            const int c = idx / C::W4, q = idx - c * C::W4;
+            if (c < C::CIN1) {
+              v[k] = *reinterpret_cast<const uint2*>(s1 + (long)c * a.ls1 + 4 * q);
+            } else if (c < C::CIN) {
+              v[k] = *reinterpret_cast<const uint2*>(s2 + (long)(c - C::CIN1) * a.ls2 + 4 * q);
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const int idx = tid + (it0 + k) * 256;
+          if (it0 + k < N_IT && idx < TOT) {
+            const int c = idx / C::W4, q = idx - c * C::W4;
+            *reinterpret_cast<float4*>(lds + c * C::S + 4 * q) =
+                make_float4(bf16_lo(v[k].x), bf16_hi(v[k].x), bf16_lo(v[k].y), bf16_hi(v[k].y));
+          }
+        }
+      }
+    } else {
+    const float* s1 = a.src1 + (long)win * a.ws1 + a0;
+    const float* s2 = (C::CIN2 > 0) ? a.src2 + (long)win * a.ws2 + a0 : nullptr;
 #pragma unroll
     for (int it0 = 0; it0 < N_IT; it0 += CH) {
       float4 v[CH];
@@ -182,6 +218,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
           *reinterpret_cast<float4*>(lds + c * C::S + 4 * q) = v[k];
         }
       }
+    }
     }
   }
   __syncthreads();
@@ -265,7 +302,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
           const int t = 2 * (col0 + (wn * C::NW + j) * 16 + n) + C::OUT_OFF;
           float v0 = acc[i][j][rr] + b, v1 = acc[i][j][rr + 1] + b;
           if (C::RELU) v0 = fmaxf(v0, 0.f), v1 = fmaxf(v1, 0.f);
-          if (t >= 0 && t + 1 < a.l_out) {
+          if constexpr (C::BF16) {
+            bf16_t* rowb = reinterpret_cast<bf16_t*>(a.dst) + (long)win * a.wsd + a.dst_halo + (long)co * a.lsd;
+            if (t >= 0 && t + 1 < a.l_out) {
+              *reinterpret_cast<unsigned*>(rowb + t) = pack_bf16x2(v0, v1);
+            } else if (t >= 0 && t < a.l_out) {
+              rowb[t] = to_bf16(v0);
+            }
+          } else if (t >= 0 && t + 1 < a.l_out) {
             *reinterpret_cast<float2*>(row + t) = make_float2(v0, v1);
           } else if (t >= 0 && t < a.l_out) {
             row[t] = v0;  // odd length: the right margin stays zero
@@ -332,7 +376,42 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 
   // ---- epilogue 2: coalesced stores of the staged tile -----------------------------
   const int t0 = C::P * col0 + C::OUT_OFF;  // global output index of staged column 0
-  if constexpr (C::EPI == EPI_STORE) {
+  if constexpr (C::EPI == EPI_STORE && C::BF16) {
+    bf16_t* d = reinterpret_cast<bf16_t*>(a.dst) + (long)win * a.wsd + a.dst_halo;
+    if constexpr (C::OUT_OFF % 4 == 0) {
+      for (int idx = tid; idx < C::COUT * (C::OW / 4); idx += 256) {
+        const int co = idx / (C::OW / 4), q = idx - co * (C::OW / 4);
+        const int t = t0 + 4 * q;
+        if (t < a.l_out) {
+          float4 v = *reinterpret_cast<const float4*>(lds + co * C::OS + 4 * q);
+          if (t + 1 >= a.l_out) v.y = 0.f;  // keep the right margin zero
+          if (t + 2 >= a.l_out) v.z = 0.f;
+          if (t + 3 >= a.l_out) v.w = 0.f;
+          *reinterpret_cast<uint2*>(d + (long)co * a.lsd + t) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        }
+      }
+    } else {
+      // the tile starts OUT_OFF samples off the four-sample grid: even-aligned pairs (4-byte stores); a pair that
+      // straddles the tile's edge or the row's ends is written sample by sample (the other half belongs to the
+      // neighbouring tile, or stays zero)
+      constexpr int PAR = ((C::OUT_OFF % 2) + 2) % 2;  // parity of t0 (P * col0 is even)
+      static_assert(C::P % 2 == 0 && C::OW % 2 == 0, "pair stores");
+      constexpr int NP = C::OW / 2 + PAR;
+      for (int idx = tid; idx < C::COUT * NP; idx += 256) {
+        const int co = idx / NP, q = 2 * (idx - co * NP) - PAR;
+        const int t = t0 + q;  // even
+        const bool ok0 = q >= 0 && t >= 0 && t < a.l_out, ok1 = q + 1 < C::OW && t + 1 >= 0 && t + 1 < a.l_out;
+        bf16_t* row = d + (long)co * a.lsd;
+        if (ok0 && ok1) {
+          *reinterpret_cast<unsigned*>(row + t) = pack_bf16x2(lds[co * C::OS + q], lds[co * C::OS + q + 1]);
+        } else if (ok0) {
+          row[t] = to_bf16(lds[co * C::OS + q]);
+        } else if (ok1) {
+          row[t + 1] = to_bf16(lds[co * C::OS + q + 1]);
+        }
+      }
+    }
+  } else if constexpr (C::EPI == EPI_STORE) {
     float* d = a.dst + (long)win * a.wsd + a.dst_halo;
     if constexpr (C::OUT_OFF % 4 == 0) {
       for (int idx = tid; idx < C::COUT * (C::OW / 4); idx += 256) {

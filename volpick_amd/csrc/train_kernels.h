@@ -5,16 +5,25 @@
 // GEMM on the fp32 matrix cores, weight packing, deterministic partial-sum reduction and Adam
 // (models.py:177-185 configure_optimizers).  All arithmetic is fp32; reductions finish in fp64.
 #pragma once
+#include <type_traits>
+
+#include "bf16.h"
 #include "vp_common.h"
 
 namespace vp {
 
 // ------------------------------------------------------------------------------------------
 // rows of an activation / gradient tensor: element (b, c, t) at p[b * ws + c * ls + HALO + t]
+// (bf16 storage mode: p holds the address of bf16_t elements, strides count elements; the *_v kernels below take the
+// element type as a template parameter and cast)
 struct Rows {
   float* p;
   int ls;
   long ws;
+  template <class T>
+  __device__ __forceinline__ T* row(int b, int c) const {
+    return reinterpret_cast<T*>(p) + (long)b * ws + (long)c * ls + HALO;
+  }
 };
 
 struct BnArgs {
@@ -194,6 +203,181 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a) {
   }
 }
 
+// ---- vectorised forms (bf16 storage mode; T = float works too) -----------------------------------------------------
+// grid (C, GB), 256 threads: a WAVE owns a row (b, c) at a time and walks it in 8-sample vectors (16 bytes of bf16),
+// rows b = j + GB * (wave + 4 k).  A few thousand long-lived workgroups instead of one short block per 1024 samples:
+// the per-1024-sample grids of the kernels above were bound by workgroup dispatch, not by memory, once the rows shrank
+// to half the bytes.  Margins: a row's samples behind its logical length are zero and stay zero (the consumers'
+// padding): vectors are read whole, written with the tail masked.
+//
+// CROP (ConvTranspose layers: a = relu(bn(z[CROP + t]))) shifts z against a / ga by one or two samples: the shifted
+// operand is read as two aligned vectors and re-indexed in registers.
+template <class T, int CROP>
+__device__ __forceinline__ void load8_at(const T* row, int t0, float (&v)[8]) {  // v[i] = row[t0 + CROP + i], t0 % 8 == 0
+  if constexpr (CROP == 0) {
+    Elem<T>::load8(row + t0, v);
+  } else if constexpr (CROP > 0) {
+    float f[16];
+    Elem<T>::load8(row + t0, f);
+    Elem<T>::load8(row + t0 + 8, f + 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = f[CROP + i];
+  } else {  // CROP < 0: the vector starts -CROP samples before t0 (t0 = 0 reads the row's zero halo)
+    float f[16];
+    Elem<T>::load8(row + t0 - 8, f);
+    Elem<T>::load8(row + t0, f + 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = f[8 + CROP + i];
+  }
+}
+
+__device__ inline void block_sum2_f64_4waves(double& x, double& y, double* sh /*[8]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    x += __shfl_xor(x, o, 64);
+    y += __shfl_xor(y, o, 64);
+  }
+  if (lane == 0) {
+    sh[2 * wave] = x;
+    sh[2 * wave + 1] = y;
+  }
+  __syncthreads();
+  x = (sh[0] + sh[2]) + (sh[4] + sh[6]);
+  y = (sh[1] + sh[3]) + (sh[5] + sh[7]);
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void bnv_stats_partial_kernel(const BnArgs a) {
+  __shared__ double sh[8];
+  const int c = blockIdx.x, j = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = (a.Lz + 7) >> 3;
+  float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
+  for (int b = j + wave * a.GB; b < a.B; b += 4 * a.GB) {
+    const T* z = a.z.row<T>(b, c);
+    for (int v0 = lane; v0 < nv; v0 += 128) {  // two vectors in flight
+      float f[2][8];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int v = v0 + 64 * u;
+        if (v < nv) {
+          Elem<T>::load8(z + 8 * v, f[u]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[u][i] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          s[u] += f[u][i];
+          q[u] = fmaf(f[u][i], f[u][i], q[u]);
+        }
+    }
+  }
+  double S = (double)(s[0] + s[1]), Q = (double)(q[0] + q[1]);
+  block_sum2_f64_4waves(S, Q, sh);
+  if (threadIdx.x == 0) {
+    a.partial[((long)c * a.GB + j) * 2] = S;
+    a.partial[((long)c * a.GB + j) * 2 + 1] = Q;
+  }
+}
+
+template <class T, int CROP>
+__global__ __launch_bounds__(256) void bnv_apply_kernel(const BnArgs a) {
+  const int c = blockIdx.x, j = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float mean = a.stats[c], rstd = a.stats[a.C + c];
+  const float sc = a.gamma[c] * rstd, sh = a.beta[c] - mean * sc;
+  const int nv = (a.La + 7) >> 3;
+  for (int b = j + wave * a.GB; b < a.B; b += 4 * a.GB) {
+    const T* z = a.z.row<T>(b, c);
+    T* o = a.a.row<T>(b, c);
+    for (int v = lane; v < nv; v += 64) {
+      float f[8], r[8];
+      load8_at<T, CROP>(z, 8 * v, f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) r[i] = (8 * v + i < a.La) ? fmaxf(fmaf(f[i], sc, sh), 0.f) : 0.f;
+      Elem<T>::store8(o + 8 * v, r);
+    }
+  }
+}
+
+template <class T, int CROP>
+__global__ __launch_bounds__(256) void bnv_bwd_partial_kernel(const BnArgs a) {
+  __shared__ double sh[8];
+  const int c = blockIdx.x, j = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float mean = a.stats[c], rstd = a.stats[a.C + c];
+  const int nv = (a.La + 7) >> 3;
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = j + wave * a.GB; b < a.B; b += 4 * a.GB) {
+    const T* z = a.z.row<T>(b, c);
+    const T* act = a.a.row<T>(b, c);
+    const T* g1 = a.ga1.row<T>(b, c);
+    const T* g2 = a.ga2.p ? a.ga2.row<T>(b, c) : nullptr;
+    for (int v = lane; v < nv; v += 64) {
+      float fz[8], fa[8], fg[8];
+      load8_at<T, CROP>(z, 8 * v, fz);
+      Elem<T>::load8(act + 8 * v, fa);
+      Elem<T>::load8(g1 + 8 * v, fg);
+      if (g2) {
+        float f2[8];
+        Elem<T>::load8(g2 + 8 * v, f2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fg[i] += f2[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float g = (fa[i] > 0.f) ? fg[i] : 0.f;  // a's margin is zero: nothing behind La counts
+        s1 += g;
+        s2 = fmaf(g, (fz[i] - mean) * rstd, s2);
+      }
+    }
+  }
+  double S1 = (double)s1, S2 = (double)s2;
+  block_sum2_f64_4waves(S1, S2, sh);
+  if (threadIdx.x == 0) {
+    a.partial[((long)c * a.GB + j) * 2] = S1;
+    a.partial[((long)c * a.GB + j) * 2 + 1] = S2;
+  }
+}
+
+template <class T, int CROP>
+__global__ __launch_bounds__(256) void bnv_bwd_apply_kernel(const BnArgs a) {
+  const int c = blockIdx.x, j = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float mean = a.stats[c], rstd = a.stats[a.C + c];
+  const float invN = 1.f / ((float)a.B * (float)a.Lz);
+  const float m1 = a.stats[2 * a.C + c] * invN, m2 = a.stats[3 * a.C + c] * invN;
+  const float k = a.gamma[c] * rstd;
+  const int nv = (a.Lz + 7) >> 3;
+  for (int b = j + wave * a.GB; b < a.B; b += 4 * a.GB) {
+    const T* z = a.z.row<T>(b, c);
+    const T* act = a.a.row<T>(b, c);
+    const T* g1 = a.ga1.row<T>(b, c);
+    const T* g2 = a.ga2.p ? a.ga2.row<T>(b, c) : nullptr;
+    T* gz = a.gz.row<T>(b, c);
+    for (int v = lane; v < nv; v += 64) {
+      float fz[8], fa[8], fg[8], r[8];
+      Elem<T>::load8(z + 8 * v, fz);
+      load8_at<T, -CROP>(act, 8 * v, fa);  // a / ga at t = j - CROP
+      load8_at<T, -CROP>(g1, 8 * v, fg);
+      if (g2) {
+        float f2[8];
+        load8_at<T, -CROP>(g2, 8 * v, f2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fg[i] += f2[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float g = (fa[i] > 0.f) ? fg[i] : 0.f;  // zero halo / zero margin of a: nothing outside [0, La) counts
+        const float xh = (fz[i] - mean) * rstd;
+        r[i] = (8 * v + i < a.Lz) ? k * (g - m1 - xh * m2) : 0.f;
+      }
+      Elem<T>::store8(gz + 8 * v, r);
+    }
+  }
+}
+
 // ---- small layers: one launch per direction ---------------------------------------------------
 // For the deep layers (a few thousand to ~100 k samples per channel) the three-launch forms above are pure
 // launch latency.  Here ONE workgroup owns a channel: it reduces, finalises and applies in a single kernel
@@ -232,13 +416,14 @@ struct RowWalk {
   }
 };
 
+template <class T>
 __global__ __launch_bounds__(1024) void bn_fwd_small_kernel(const BnArgs a) {
   __shared__ double sh[32];
   const int c = blockIdx.x;
-  const float* zc = a.z.p + (long)c * a.z.ls + HALO;
+  const T* zc = reinterpret_cast<const T*>(a.z.p) + (long)c * a.z.ls + HALO;
   float s = 0.f, q = 0.f;
   for (RowWalk w(threadIdx.x, a.Lz); w.b < a.B; w.next()) {
-    const float v = zc[(long)w.b * a.z.ws + w.t];
+    const float v = Elem<T>::load(zc + (long)w.b * a.z.ws + w.t);
     s += v;
     q = fmaf(v, v, q);
   }
@@ -256,27 +441,29 @@ __global__ __launch_bounds__(1024) void bn_fwd_small_kernel(const BnArgs a) {
     a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)(var * N / (N - 1.0));
   }
   const float sc = a.gamma[c] * rstd, shv = a.beta[c] - mean * sc;
-  float* ac = a.a.p + (long)c * a.a.ls + HALO;
+  T* ac = reinterpret_cast<T*>(a.a.p) + (long)c * a.a.ls + HALO;
   for (RowWalk w(threadIdx.x, a.La); w.b < a.B; w.next())
-    ac[(long)w.b * a.a.ws + w.t] = fmaxf(fmaf(zc[(long)w.b * a.z.ws + a.crop + w.t], sc, shv), 0.f);
+    Elem<T>::store(ac + (long)w.b * a.a.ws + w.t,
+                   fmaxf(fmaf(Elem<T>::load(zc + (long)w.b * a.z.ws + a.crop + w.t), sc, shv), 0.f));
 }
 
+template <class T>
 __global__ __launch_bounds__(1024) void bn_bwd_small_kernel(const BnArgs a) {
   __shared__ double sh[32];
   const int c = blockIdx.x;
   const float mean = a.stats[c], rstd = a.stats[a.C + c];
-  const float* zc = a.z.p + (long)c * a.z.ls + HALO;
-  const float* ac = a.a.p + (long)c * a.a.ls + HALO;
-  const float* g1 = a.ga1.p + (long)c * a.ga1.ls + HALO;
-  const float* g2 = a.ga2.p ? a.ga2.p + (long)c * a.ga2.ls + HALO : nullptr;
-  float* gzc = a.gz.p + (long)c * a.gz.ls + HALO;
+  const T* zc = reinterpret_cast<const T*>(a.z.p) + (long)c * a.z.ls + HALO;
+  const T* ac = reinterpret_cast<const T*>(a.a.p) + (long)c * a.a.ls + HALO;
+  const T* g1 = reinterpret_cast<const T*>(a.ga1.p) + (long)c * a.ga1.ls + HALO;
+  const T* g2 = a.ga2.p ? reinterpret_cast<const T*>(a.ga2.p) + (long)c * a.ga2.ls + HALO : nullptr;
+  T* gzc = reinterpret_cast<T*>(a.gz.p) + (long)c * a.gz.ls + HALO;
   float s1 = 0.f, s2 = 0.f;
   for (RowWalk w(threadIdx.x, a.La); w.b < a.B; w.next()) {
-    float g = g1[(long)w.b * a.ga1.ws + w.t];
-    if (g2) g += g2[(long)w.b * a.ga2.ws + w.t];
-    if (!(ac[(long)w.b * a.a.ws + w.t] > 0.f)) g = 0.f;
+    float g = Elem<T>::load(g1 + (long)w.b * a.ga1.ws + w.t);
+    if (g2) g += Elem<T>::load(g2 + (long)w.b * a.ga2.ws + w.t);
+    if (!(Elem<T>::load(ac + (long)w.b * a.a.ws + w.t) > 0.f)) g = 0.f;
     s1 += g;
-    s2 = fmaf(g, (zc[(long)w.b * a.z.ws + a.crop + w.t] - mean) * rstd, s2);
+    s2 = fmaf(g, (Elem<T>::load(zc + (long)w.b * a.z.ws + a.crop + w.t) - mean) * rstd, s2);
   }
   double S1 = s1, S2 = s2;
   block_sum2_double(S1, S2, sh);
@@ -291,12 +478,12 @@ __global__ __launch_bounds__(1024) void bn_bwd_small_kernel(const BnArgs a) {
   for (RowWalk w(threadIdx.x, a.Lz); w.b < a.B; w.next()) {
     const int t = w.t - a.crop;
     float g = 0.f;
-    if (t >= 0 && t < a.La && ac[(long)w.b * a.a.ws + t] > 0.f) {
-      g = g1[(long)w.b * a.ga1.ws + t];
-      if (g2) g += g2[(long)w.b * a.ga2.ws + t];
+    if (t >= 0 && t < a.La && Elem<T>::load(ac + (long)w.b * a.a.ws + t) > 0.f) {
+      g = Elem<T>::load(g1 + (long)w.b * a.ga1.ws + t);
+      if (g2) g += Elem<T>::load(g2 + (long)w.b * a.ga2.ws + t);
     }
-    const float xh = (zc[(long)w.b * a.z.ws + w.t] - mean) * rstd;
-    gzc[(long)w.b * a.gz.ws + w.t] = k * (g - m1 - xh * m2);
+    const float xh = (Elem<T>::load(zc + (long)w.b * a.z.ws + w.t) - mean) * rstd;
+    Elem<T>::store(gzc + (long)w.b * a.gz.ws + w.t, k * (g - m1 - xh * m2));
   }
 }
 
@@ -368,6 +555,86 @@ __global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const HeadArgs2 h) {
     }
   }
   // 28 block sums: wavefront butterflies, then the four wave results through LDS (one barrier)
+  __shared__ float shv[4][28];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 28; ++i) {
+    float v = vals[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) shv[wave][i] = v;
+  }
+  __syncthreads();
+  const long blk = (long)blockIdx.y * gridDim.x + blockIdx.x;
+  if (threadIdx.x < 28)
+    h.partial[blk * 28 + threadIdx.x] = ((double)shv[0][threadIdx.x] + (double)shv[1][threadIdx.x]) +
+                                        ((double)shv[2][threadIdx.x] + (double)shv[3][threadIdx.x]);
+}
+
+// The same head with two consecutive samples per thread (even-aligned pairs: 4-byte accesses of bf16 rows).
+// grid (ceil(T / 512), B), 256 threads.
+template <class T>
+__global__ __launch_bounds__(256) void head_fwd_bwd_pair_kernel(const HeadArgs2 h) {
+  const int b = blockIdx.y, t0 = 2 * (blockIdx.x * 256 + threadIdx.x);
+  float w[3][8], bb[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    bb[c] = h.b[c];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[c][k] = h.w[c * 8 + k];
+  }
+  float vals[28];
+#pragma unroll
+  for (int i = 0; i < 28; ++i) vals[i] = 0.f;
+  if (t0 < h.T) {
+    float x[8][2], ga[8][2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) Elem<T>::load2(h.a.row<T>(b, k) + t0, x[k]);
+    const float scale = 1.f / ((float)h.B * (float)h.T);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = t0 + u;
+      if (t < h.T) {
+        float z[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          z[c] = bb[c];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) z[c] = fmaf(w[c][k], x[k][u], z[c]);
+        }
+        const float mx = fmaxf(z[0], fmaxf(z[1], z[2]));
+        float e[3] = {expf(z[0] - mx), expf(z[1] - mx), expf(z[2] - mx)};
+        const float inv = 1.f / (e[0] + e[1] + e[2]);
+        float p[3], g[3], gl[3];
+        float dot = 0.f, loss = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          p[c] = e[c] * inv;
+          const float yv = h.y[((long)b * 3 + c) * h.T + t];
+          loss -= yv * logf(p[c] + h.eps);
+          g[c] = -yv / (p[c] + h.eps) * scale;
+          dot = fmaf(g[c], p[c], dot);
+          if (h.p) h.p[((long)b * 3 + c) * h.T + t] = p[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gl[c] = p[c] * (g[c] - dot);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ga[k][u] = w[0][k] * gl[0] + w[1][k] * gl[1] + w[2][k] * gl[2];
+        vals[0] += loss * scale;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          vals[1 + c] += gl[c];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) vals[4 + c * 8 + k] = fmaf(gl[c], x[k][u], vals[4 + c * 8 + k]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ga[k][u] = 0.f;  // the row's margin stays zero
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) Elem<T>::store2(h.ga.row<T>(b, k) + t0, ga[k][0], ga[k][1]);
+  }
   __shared__ float shv[4][28];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -456,6 +723,27 @@ __global__ __launch_bounds__(256) void channel_sum_partial_kernel(const Rows r, 
   if (threadIdx.x == 0) partial[(long)j * gridDim.x + c] = s;  // [GB][C]
 }
 
+// the same over 8-sample vectors, a wave per row (bf16 storage mode; the rows' margins are zero)
+template <class T>
+__global__ __launch_bounds__(256) void channel_sum_partial_v_kernel(const Rows r, int B, int L, int GB, double* partial) {
+  __shared__ double sh[8];
+  const int c = blockIdx.x, j = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = (L + 7) >> 3;
+  float acc = 0.f;
+  for (int b = j + wave * GB; b < B; b += 4 * GB) {
+    const T* p = r.row<T>(b, c);
+    for (int v = lane; v < nv; v += 64) {
+      float f[8];
+      Elem<T>::load8(p + 8 * v, f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc += f[i];
+    }
+  }
+  double s = (double)acc, zero = 0.0;
+  block_sum2_f64_4waves(s, zero, sh);
+  if (threadIdx.x == 0) partial[(long)j * gridDim.x + c] = s;  // [GB][C]
+}
+
 // packed MFMA A-fragments of every conv from the current weights: idx[i] = 1 + flat weight index, 0 = structural zero
 __global__ __launch_bounds__(256) void gather_pack_kernel(const int* __restrict__ idx, const float* __restrict__ w,
                                                           float* __restrict__ out, long n) {
@@ -536,14 +824,23 @@ struct WgradCfg {
   static_assert(LDS_FLOATS * 4 <= 64 * 1024, "static LDS budget");
 };
 
-template <class C>
+template <class C, class T = float>
 __global__ __launch_bounds__(64 * C::NWAVE) void wgrad_kernel(const WgradArgs a) {
-  __shared__ float lds[C::LDS_FLOATS];
+  // bf16 rows are fetched as even-aligned PAIRS (4-byte loads) and widened while they are parked in LDS: a hi window
+  // whose first sample is odd (tap offsets -3 / -1) is staged from the sample before it, so a window holds WHS >= WH
+  // samples and every B read is shifted by that one sample (par).  fp32 rows: sample by sample, as before.
+  constexpr bool PAIRS = sizeof(T) == 2;
+  constexpr int WHS = PAIRS ? (C::WH + 2) / 2 * 2 : C::WH;
+  constexpr int S_HI = PAIRS ? ((C::WB * WHS) | 1) + 2 : C::S_HI;
+  constexpr int LDS_FLOATS = C::LOP * C::S_LO + C::HI * S_HI;
+  static_assert(LDS_FLOATS * 4 <= 64 * 1024 && (!C::SPLITK || C::TILES * 256 <= LDS_FLOATS), "static LDS budget");
+  __shared__ float lds[LDS_FLOATS];
   float* lo_s = lds;
   float* hi_s = lds + C::LOP * C::S_LO;
   constexpr int NTH = 64 * C::NWAVE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l16 = lane & 15;
+  const int par = PAIRS ? (a.off & 1) : 0;
   const int my_mt = C::SPLITK ? 0 : wave % C::MT, my_ng = C::SPLITK ? 0 : wave / C::MT;
   auto tile_of = [&](const int i, int* mt, int* nt) __attribute__((always_inline)) {
     if (C::SPLITK) {
@@ -564,42 +861,50 @@ __global__ __launch_bounds__(64 * C::NWAVE) void wgrad_kernel(const WgradArgs a)
     int col = nt * 16 + l16;
     if (col >= C::COLS) col = 0;  // padding columns compute garbage that is never stored
     const int k = col / C::HI, h = col - k * C::HI;
-    b_base[i] = h * C::S_HI + C::S * g + k;
+    b_base[i] = h * S_HI + C::S * g + k + par;
   }
   for (int i = tid; i < (C::LOP - C::LO) * C::S_LO; i += NTH) lo_s[C::LO * C::S_LO + i] = 0.f;  // padding rows
   // The next item's lo / hi chunks are fetched into registers while the MFMAs of the current one run
   // (all loads of an item are issued back to back: a load -> LDS-store loop exposes the full HBM latency
   // once per element and made this kernel 3-5x slower).
-  constexpr int N_LO = C::LO * C::WB * C::TT, N_HI = C::HI * C::WB * C::WH;
+  constexpr int EPL = PAIRS ? 2 : 1;  // elements per load
+  constexpr int N_LO = C::LO * C::WB * C::TT / EPL, N_HI = C::HI * C::WB * WHS / EPL;
   constexpr int NLO = (N_LO + NTH - 1) / NTH, NHI = (N_HI + NTH - 1) / NTH;
-  float pre_lo[NLO], pre_hi[NHI];
+  static_assert(C::TT % 2 == 0 && WHS % EPL == 0, "pairs never straddle rows");
+  typedef typename std::conditional<PAIRS, unsigned, float>::type raw_t;
+  raw_t pre_lo[NLO], pre_hi[NHI];
   const int groups = (a.B + C::WB - 1) / C::WB;
   const int items = groups * a.chunks;
+  const T* lo_p = reinterpret_cast<const T*>(a.lo.p);
+  const T* hi1_p = reinterpret_cast<const T*>(a.hi1.p);
+  const T* hi2_p = reinterpret_cast<const T*>(a.hi2.p);
   auto fetch = [&](const int item) __attribute__((always_inline)) {
     const int grp = item / a.chunks, n_start = (item - grp * a.chunks) * C::TT;
     const int b0 = grp * C::WB;
 #pragma unroll
     for (int k = 0; k < NLO; ++k) {
-      const int i = tid + k * NTH;
+      const int i = (tid + k * NTH) * EPL;
       const int m = i / (C::WB * C::TT), r = i - m * (C::WB * C::TT);
       const int w = r / C::TT, n = r - w * C::TT;
-      pre_lo[k] = (i < N_LO && b0 + w < a.B && n_start + n < a.Ln)
-                      ? a.lo.p[(long)(b0 + w) * a.lo.ws + (long)m * a.lo.ls + HALO + n_start + n]
-                      : 0.f;
+      raw_t v = 0;
+      if (i < N_LO * EPL && b0 + w < a.B && n_start + n < a.Ln)  // (a pair's second sample behind Ln is the row's zero margin)
+        v = *reinterpret_cast<const raw_t*>(lo_p + (long)(b0 + w) * a.lo.ws + (long)m * a.lo.ls + HALO + n_start + n);
+      pre_lo[k] = v;
     }
-    const int s0 = C::S * n_start + a.off;  // hi sample index of staged column 0
+    const int s0 = C::S * n_start + a.off - par;  // hi sample index of staged column 0 (even for pairs)
 #pragma unroll
     for (int k = 0; k < NHI; ++k) {
-      const int i = tid + k * NTH;
-      const int h = i / (C::WB * C::WH), r = i - h * (C::WB * C::WH);
-      const int w = r / C::WH, j = r - w * C::WH;
+      const int i = (tid + k * NTH) * EPL;
+      const int h = i / (C::WB * WHS), r = i - h * (C::WB * WHS);
+      const int w = r / WHS, j = r - w * WHS;
       const int idx = s0 + j;
-      float v = 0.f;
-      if (i < N_HI && b0 + w < a.B && idx >= -HALO) {
+      raw_t v = 0;
+      if (i < N_HI * EPL && b0 + w < a.B && idx >= -HALO) {
         if (h < C::HI1) {
-          if (idx < a.lim_hi1) v = a.hi1.p[(long)(b0 + w) * a.hi1.ws + (long)h * a.hi1.ls + HALO + idx];
+          if (idx < a.lim_hi1) v = *reinterpret_cast<const raw_t*>(hi1_p + (long)(b0 + w) * a.hi1.ws + (long)h * a.hi1.ls + HALO + idx);
         } else {
-          if (idx < a.lim_hi2) v = a.hi2.p[(long)(b0 + w) * a.hi2.ws + (long)(h - C::HI1) * a.hi2.ls + HALO + idx];
+          if (idx < a.lim_hi2)
+            v = *reinterpret_cast<const raw_t*>(hi2_p + (long)(b0 + w) * a.hi2.ws + (long)(h - C::HI1) * a.hi2.ls + HALO + idx);
         }
       }
       pre_hi[k] = v;
@@ -611,15 +916,29 @@ __global__ __launch_bounds__(64 * C::NWAVE) void wgrad_kernel(const WgradArgs a)
     __syncthreads();  // previous item's MFMA reads are done
 #pragma unroll
     for (int k = 0; k < NLO; ++k) {
-      const int i = tid + k * NTH;
+      const int i = (tid + k * NTH) * EPL;
       const int m = i / (C::WB * C::TT), r = i - m * (C::WB * C::TT);
-      if (i < N_LO) lo_s[m * C::S_LO + r] = pre_lo[k];
+      if (i < N_LO * EPL) {
+        if constexpr (PAIRS) {
+          lo_s[m * C::S_LO + r] = bf16_lo(pre_lo[k]);
+          lo_s[m * C::S_LO + r + 1] = bf16_hi(pre_lo[k]);
+        } else {
+          lo_s[m * C::S_LO + r] = pre_lo[k];
+        }
+      }
     }
 #pragma unroll
     for (int k = 0; k < NHI; ++k) {
-      const int i = tid + k * NTH;
-      const int h = i / (C::WB * C::WH), r = i - h * (C::WB * C::WH);
-      if (i < N_HI) hi_s[h * C::S_HI + r] = pre_hi[k];
+      const int i = (tid + k * NTH) * EPL;
+      const int h = i / (C::WB * WHS), r = i - h * (C::WB * WHS);
+      if (i < N_HI * EPL) {
+        if constexpr (PAIRS) {
+          hi_s[h * S_HI + r] = bf16_lo(pre_hi[k]);
+          hi_s[h * S_HI + r + 1] = bf16_hi(pre_hi[k]);
+        } else {
+          hi_s[h * S_HI + r] = pre_hi[k];
+        }
+      }
     }
     __syncthreads();
     if (item + (int)gridDim.x < items) fetch(item + gridDim.x);
@@ -628,7 +947,7 @@ __global__ __launch_bounds__(64 * C::NWAVE) void wgrad_kernel(const WgradArgs a)
 #pragma unroll
     for (int w = 0; w < C::WB; ++w) {
       const float* lo_w = lo_s + w * C::TT + g;
-      const float* hi_w = hi_s + w * C::WH;
+      const float* hi_w = hi_s + w * WHS;
       if constexpr (C::SPLITK) {
         for (int n0 = 4 * wave; n0 < n_len; n0 += 4 * C::NWAVE) {
           float av[C::MT];
@@ -685,9 +1004,9 @@ __global__ __launch_bounds__(64 * C::NWAVE) void wgrad_kernel(const WgradArgs a)
   }
 }
 
-template <class C>
+template <class C, class T = float>
 int launch_wgrad(const WgradArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL(wgrad_kernel<C>, dim3(grid), dim3(64 * C::NWAVE), 0, s, a);
+  hipLaunchKernelGGL((wgrad_kernel<C, T>), dim3(grid), dim3(64 * C::NWAVE), 0, s, a);
   return 0;
 }
 

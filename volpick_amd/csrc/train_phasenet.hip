@@ -22,45 +22,46 @@ constexpr int T0 = 3001, T1 = 751, T2 = 188, T3 = 47, T4 = 12;
 constexpr int NLAYER = 18;
 
 //                    CIN1 CIN2 COUT P TAPS SN IN_OFF OUT_OFF WM WN NW RELU EPI
+// (BF = 1: rows stored as bf16, conv_mfma.h)
 // forward (no activation: BatchNorm needs the raw output)
-using F_inc = ConvCfg<3, 0, 8, 2, 8, 2, -3, 0, 1, 4, 8, 0, EPI_STORE>;
-using F_d0s = ConvCfg<8, 0, 8, 2, 8, 2, -3, 0, 1, 4, 8, 0, EPI_STORE>;
-using F_d0d = ConvCfg<8, 0, 8, 2, 11, 8, -3, 0, 1, 4, 2, 0, EPI_STORE>;
-using F_d1s = ConvCfg<8, 0, 16, 1, 7, 1, -3, 0, 1, 4, 4, 0, EPI_STORE>;
-using F_d1d = ConvCfg<16, 0, 16, 1, 7, 4, -2, 0, 1, 4, 1, 0, EPI_STORE>;
-using F_d2s = ConvCfg<16, 0, 32, 1, 7, 1, -3, 0, 2, 2, 3, 0, EPI_STORE>;
-using F_d2d = ConvCfg<32, 0, 32, 1, 7, 4, -1, 0, 2, 2, 1, 0, EPI_STORE>;
-using F_d3s = ConvCfg<32, 0, 64, 1, 7, 1, -3, 0, 4, 1, 3, 0, EPI_STORE>;
-using F_d3d = ConvCfg<64, 0, 64, 1, 7, 4, -2, 0, 4, 1, 1, 0, EPI_STORE>;
-using F_d4s = ConvCfg<64, 0, 128, 1, 7, 1, -3, 0, 4, 1, 1, 0, EPI_STORE>;
-using F_u0T = ConvCfg<128, 0, 64, 4, 2, 1, -1, 0, 4, 1, 1, 0, EPI_STORE>;
-using F_u0s = ConvCfg<64, 64, 64, 1, 7, 1, -3, 0, 4, 1, 3, 0, EPI_STORE>;
-using F_u1T = ConvCfg<64, 0, 32, 4, 2, 1, -1, 0, 4, 1, 3, 0, EPI_STORE>;
-using F_u1s = ConvCfg<32, 32, 32, 1, 7, 1, -3, 0, 2, 2, 3, 0, EPI_STORE>;
-using F_u2T = ConvCfg<32, 0, 16, 4, 2, 1, -1, 0, 4, 1, 4, 0, EPI_STORE>;
-using F_u2s = ConvCfg<16, 16, 16, 1, 7, 1, -3, 0, 1, 4, 4, 0, EPI_STORE>;
-using F_u3T = ConvCfg<16, 0, 8, 4, 2, 1, -1, 0, 2, 2, 4, 0, EPI_STORE>;
-using F_u3s = ConvCfg<8, 8, 8, 2, 8, 2, -3, 0, 1, 4, 8, 0, EPI_STORE>;
+template <int BF> using F_inc = ConvCfg<3, 0, 8, 2, 8, 2, -3, 0, 1, 4, 8, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using F_d0s = ConvCfg<8, 0, 8, 2, 8, 2, -3, 0, 1, 4, 8, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using F_d0d = ConvCfg<8, 0, 8, 2, 11, 8, -3, 0, 1, 4, 2, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using F_d1s = ConvCfg<8, 0, 16, 1, 7, 1, -3, 0, 1, 4, 4, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using F_d1d = ConvCfg<16, 0, 16, 1, 7, 4, -2, 0, 1, 4, 1, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using F_d2s = ConvCfg<16, 0, 32, 1, 7, 1, -3, 0, 2, 2, 3, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using F_d2d = ConvCfg<32, 0, 32, 1, 7, 4, -1, 0, 2, 2, 1, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using F_d3s = ConvCfg<32, 0, 64, 1, 7, 1, -3, 0, 4, 1, 3, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using F_d3d = ConvCfg<64, 0, 64, 1, 7, 4, -2, 0, 4, 1, 1, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using F_d4s = ConvCfg<64, 0, 128, 1, 7, 1, -3, 0, 4, 1, 1, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using F_u0T = ConvCfg<128, 0, 64, 4, 2, 1, -1, 0, 4, 1, 1, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using F_u0s = ConvCfg<64, 64, 64, 1, 7, 1, -3, 0, 4, 1, 3, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using F_u1T = ConvCfg<64, 0, 32, 4, 2, 1, -1, 0, 4, 1, 3, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using F_u1s = ConvCfg<32, 32, 32, 1, 7, 1, -3, 0, 2, 2, 3, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using F_u2T = ConvCfg<32, 0, 16, 4, 2, 1, -1, 0, 4, 1, 4, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using F_u2s = ConvCfg<16, 16, 16, 1, 7, 1, -3, 0, 1, 4, 4, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using F_u3T = ConvCfg<16, 0, 8, 4, 2, 1, -1, 0, 2, 2, 4, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using F_u3s = ConvCfg<8, 8, 8, 2, 8, 2, -3, 0, 1, 4, 8, 0, EPI_STORE, 0, 0, BF>;
 // input gradients: conv(k7, same) -> conv with the flipped, transposed kernel
-using G_d0s = ConvCfg<8, 0, 8, 2, 8, 2, -3, 0, 1, 4, 8, 0, EPI_STORE>;
-using G_d1s = ConvCfg<16, 0, 8, 2, 8, 2, -3, 0, 1, 4, 2, 0, EPI_STORE>;
-using G_d2s = ConvCfg<32, 0, 16, 1, 7, 1, -3, 0, 1, 4, 3, 0, EPI_STORE>;
-using G_d3s = ConvCfg<64, 0, 32, 1, 7, 1, -3, 0, 2, 2, 2, 0, EPI_STORE>;
-using G_d4s = ConvCfg<128, 0, 64, 1, 7, 1, -3, 0, 4, 1, 1, 0, EPI_STORE>;
-using G_u0s = ConvCfg<64, 0, 128, 1, 7, 1, -3, 0, 4, 1, 3, 0, EPI_STORE>;
-using G_u1s = ConvCfg<32, 0, 64, 1, 7, 1, -3, 0, 2, 2, 3, 0, EPI_STORE>;
-using G_u2s = ConvCfg<16, 0, 32, 1, 7, 1, -3, 0, 2, 2, 4, 0, EPI_STORE>;
-using G_u3s = ConvCfg<8, 0, 16, 1, 7, 1, -3, 0, 1, 4, 8, 0, EPI_STORE>;
+template <int BF> using G_d0s = ConvCfg<8, 0, 8, 2, 8, 2, -3, 0, 1, 4, 8, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using G_d1s = ConvCfg<16, 0, 8, 2, 8, 2, -3, 0, 1, 4, 2, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using G_d2s = ConvCfg<32, 0, 16, 1, 7, 1, -3, 0, 1, 4, 3, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using G_d3s = ConvCfg<64, 0, 32, 1, 7, 1, -3, 0, 2, 2, 2, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using G_d4s = ConvCfg<128, 0, 64, 1, 7, 1, -3, 0, 4, 1, 1, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using G_u0s = ConvCfg<64, 0, 128, 1, 7, 1, -3, 0, 4, 1, 3, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using G_u1s = ConvCfg<32, 0, 64, 1, 7, 1, -3, 0, 2, 2, 3, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using G_u2s = ConvCfg<16, 0, 32, 1, 7, 1, -3, 0, 2, 2, 4, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using G_u3s = ConvCfg<8, 0, 16, 1, 7, 1, -3, 0, 1, 4, 8, 0, EPI_STORE, 0, 0, BF>;
 // conv(k7, s4, left pad p) -> ConvTranspose(k7, s4) of the same kernel, output shifted by -p
-using G_d0d = ConvCfg<8, 0, 8, 4, 2, 1, -1, -3, 2, 2, 4, 0, EPI_STORE>;
-using G_d1d = ConvCfg<16, 0, 16, 4, 2, 1, -1, -2, 4, 1, 4, 0, EPI_STORE>;
-using G_d2d = ConvCfg<32, 0, 32, 4, 2, 1, -1, -1, 4, 1, 3, 0, EPI_STORE>;
-using G_d3d = ConvCfg<64, 0, 64, 4, 2, 1, -1, -2, 4, 1, 1, 0, EPI_STORE>;
+template <int BF> using G_d0d = ConvCfg<8, 0, 8, 4, 2, 1, -1, -3, 2, 2, 4, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using G_d1d = ConvCfg<16, 0, 16, 4, 2, 1, -1, -2, 4, 1, 4, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using G_d2d = ConvCfg<32, 0, 32, 4, 2, 1, -1, -1, 4, 1, 3, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using G_d3d = ConvCfg<64, 0, 64, 4, 2, 1, -1, -2, 4, 1, 1, 0, EPI_STORE, 0, 0, BF>;
 // ConvTranspose(k7, s4) -> conv(k7, s4, no pad) of the same kernel over the full-length gradient
-using G_u0T = ConvCfg<64, 0, 128, 1, 7, 4, 0, 0, 4, 1, 1, 0, EPI_STORE>;
-using G_u1T = ConvCfg<32, 0, 64, 1, 7, 4, 0, 0, 4, 1, 3, 0, EPI_STORE>;
-using G_u2T = ConvCfg<16, 0, 32, 1, 7, 4, 0, 0, 2, 2, 3, 0, EPI_STORE>;
-using G_u3T = ConvCfg<8, 0, 16, 1, 7, 4, 0, 0, 1, 4, 4, 0, EPI_STORE>;
+template <int BF> using G_u0T = ConvCfg<64, 0, 128, 1, 7, 4, 0, 0, 4, 1, 1, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using G_u1T = ConvCfg<32, 0, 64, 1, 7, 4, 0, 0, 4, 1, 3, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using G_u2T = ConvCfg<16, 0, 32, 1, 7, 4, 0, 0, 2, 2, 3, 0, EPI_STORE, 0, 0, BF>;
+template <int BF> using G_u3T = ConvCfg<8, 0, 16, 1, 7, 4, 0, 0, 1, 4, 4, 0, EPI_STORE, 0, 0, BF>;
 //                     LO HI1 HI2 K S NWAVE TT [WB windows per item]
 using W_inc = WgradCfg<8, 3, 0, 7, 1, 8, 256>;
 using W_d0s = WgradCfg<8, 8, 0, 7, 1, 8, 256>;
@@ -130,9 +131,9 @@ void set_conv(ConvOp* op, int src1, int src2, int dst, int cols, int l_out) {
   op->l_out = l_out;
 }
 
-template <class Cfg>
+template <class Cfg, class T>
 void set_wgrad(WgradOp* op, int lo, int hi1, int hi2, int Ln, int off) {
-  op->launch = &launch_wgrad<Cfg>;
+  op->launch = &launch_wgrad<Cfg, T>;
   op->lo = lo;
   op->hi1 = hi1;
   op->hi2 = hi2;
@@ -149,11 +150,22 @@ __global__ __launch_bounds__(256) void load_rows_kernel(const float* __restrict_
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t < T) r.p[(long)b * r.ws + (long)c * r.ls + HALO + t] = x[((long)b * C + c) * T + t];
 }
+// the same into bf16 rows, an even-aligned pair per thread: grid (ceil(T / 512), C, B)
+__global__ __launch_bounds__(256) void load_rows_bf16_kernel(const float* __restrict__ x, Rows r, int C, int T) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int t = 2 * (blockIdx.x * 256 + threadIdx.x);
+  if (t < T) {
+    const float* xp = x + ((long)b * C + c) * T + t;
+    Elem<bf16_t>::store2(r.row<bf16_t>(b, c) + t, xp[0], t + 1 < T ? xp[1] : 0.f);
+  }
+}
 
 }  // namespace
 
 struct Trainer {
   int device = 0, max_batch = 0;
+  bool bf16 = false;  // activation / gradient rows stored as bfloat16 (weights, gradients, statistics, Adam: fp32)
+  int esize = 4;      // bytes per row element
   hipStream_t stream = nullptr;
   std::vector<Tensor> tensors;
   std::vector<Layer> layers;
@@ -194,7 +206,8 @@ struct Trainer {
     t.name = name;
     t.C = C;
     t.L = L;
-    t.need = HALO + round_up(L, 4) + 4;
+    // bf16 rows are walked in 8-sample vectors, a cropped operand one vector further (train_kernels.h load8_at)
+    t.need = bf16 ? HALO + round_up(L, 8) + 16 : HALO + round_up(L, 4) + 4;
     tensors.push_back(t);
     return (int)tensors.size() - 1;
   }
@@ -202,8 +215,8 @@ struct Trainer {
     if (id >= 0 && tensors[id].need < phys) tensors[id].need = phys;
   }
   Rows rows(int id, int ch = 0) const {
-    const Tensor& t = tensors[id];
-    return Rows{t.p + (long)ch * t.ls, t.ls, (long)t.win_stride()};
+    const Tensor& t = tensors[id];  // (t.p is a byte address in disguise when the rows are bf16)
+    return Rows{reinterpret_cast<float*>(reinterpret_cast<char*>(t.p) + (long)ch * t.ls * esize), t.ls, (long)t.win_stride()};
   }
   ~Trainer() {
     for (void* p : {(void*)arena, (void*)w, (void*)grad, (void*)adam_m, (void*)adam_v, (void*)mask, (void*)ema, (void*)frag_idx,
@@ -242,7 +255,9 @@ void append_frag(Trainer& tr, ConvOp* op, const std::vector<float>& amat) {
   tr.frag_idx_host.insert(tr.frag_idx_host.end(), idx.begin(), idx.end());
 }
 
+template <int BF>
 int build_plan(Trainer& tr) {
+  using ET = typename std::conditional<BF != 0, bf16_t, float>::type;
   const ParamDesc* table;
   const int np = param_table(VP_MODEL_PHASENET, &table);
   long off = 0;
@@ -329,24 +344,24 @@ int build_plan(Trainer& tr) {
   // ---- convolutions: forward, input gradient, weight gradient ------------------------------
   auto W = [&](const std::string& n) { return index_weights(P(n), tr.psize.at(n)); };
 #define FWD_CONV(LI, CFG, WNAME, COUT, CIN, STRIDE, SRC1, SRC2, COLS)                                        \
-  set_conv<CFG>(&Ls[LI].fwd, SRC1, SRC2, Ls[LI].bn.z, COLS, Ls[LI].bn.Lz);                                    \
-  append_frag(tr, &Ls[LI].fwd, amat_conv(W(WNAME).data(), COUT, CIN, 7, STRIDE, CFG::P, CFG::CINP, nullptr));
+  set_conv<CFG<BF>>(&Ls[LI].fwd, SRC1, SRC2, Ls[LI].bn.z, COLS, Ls[LI].bn.Lz);                                    \
+  append_frag(tr, &Ls[LI].fwd, amat_conv(W(WNAME).data(), COUT, CIN, 7, STRIDE, CFG<BF>::P, CFG<BF>::CINP, nullptr));
 #define FWD_CONVT(LI, CFG, WNAME, CIN, COUT, SRC, LIN)                                                       \
-  set_conv<CFG>(&Ls[LI].fwd, SRC, -1, Ls[LI].bn.z, (LIN) + 1, Ls[LI].bn.Lz);                                  \
-  append_frag(tr, &Ls[LI].fwd, amat_convT_k7s4(W(WNAME).data(), CIN, COUT, CFG::CINP, nullptr));
+  set_conv<CFG<BF>>(&Ls[LI].fwd, SRC, -1, Ls[LI].bn.z, (LIN) + 1, Ls[LI].bn.Lz);                                  \
+  append_frag(tr, &Ls[LI].fwd, amat_convT_k7s4(W(WNAME).data(), CIN, COUT, CFG<BF>::CINP, nullptr));
   // dgrad of a stride-1 conv W[COUT][CIN][7]: conv of gz (COUT channels) with the flipped transpose -> CIN channels
 #define BWD_SAME(LI, CFG, WNAME, COUT, CIN, DST, LDST)                                                       \
-  set_conv<CFG>(&Ls[LI].dgrad, Ls[LI].bn.gz, -1, DST, ((LDST) + CFG::P - 1) / CFG::P, LDST);                  \
+  set_conv<CFG<BF>>(&Ls[LI].dgrad, Ls[LI].bn.gz, -1, DST, ((LDST) + CFG<BF>::P - 1) / CFG<BF>::P, LDST);                  \
   append_frag(tr, &Ls[LI].dgrad,                                                                             \
-              amat_conv(flip_transpose(W(WNAME), COUT, CIN, 7).data(), CIN, COUT, 7, 1, CFG::P, CFG::CINP, nullptr));
+              amat_conv(flip_transpose(W(WNAME), COUT, CIN, 7).data(), CIN, COUT, 7, 1, CFG<BF>::P, CFG<BF>::CINP, nullptr));
   // dgrad of a stride-4 conv W[C][C][7] with left pad PADL: transposed conv of gz, output index shifted by -PADL
 #define BWD_DOWN(LI, CFG, WNAME, C, DST, LDST, PADL)                                                         \
-  set_conv<CFG>(&Ls[LI].dgrad, Ls[LI].bn.gz, -1, DST, ((LDST)-1 + (PADL)) / 4 + 1, LDST);                     \
-  append_frag(tr, &Ls[LI].dgrad, amat_convT_k7s4(W(WNAME).data(), C, C, CFG::CINP, nullptr));
+  set_conv<CFG<BF>>(&Ls[LI].dgrad, Ls[LI].bn.gz, -1, DST, ((LDST)-1 + (PADL)) / 4 + 1, LDST);                     \
+  append_frag(tr, &Ls[LI].dgrad, amat_convT_k7s4(W(WNAME).data(), C, C, CFG<BF>::CINP, nullptr));
   // dgrad of ConvTranspose Wt[CIN][COUT][7]: stride-4 conv of the full-length gz (COUT channels) -> CIN channels
 #define BWD_UPT(LI, CFG, WNAME, CIN, COUT, DST, LIN)                                                         \
-  set_conv<CFG>(&Ls[LI].dgrad, Ls[LI].bn.gz, -1, DST, LIN, LIN);                                              \
-  append_frag(tr, &Ls[LI].dgrad, amat_conv(W(WNAME).data(), CIN, COUT, 7, 4, 1, CFG::CINP, nullptr));
+  set_conv<CFG<BF>>(&Ls[LI].dgrad, Ls[LI].bn.gz, -1, DST, LIN, LIN);                                              \
+  append_frag(tr, &Ls[LI].dgrad, amat_conv(W(WNAME).data(), CIN, COUT, 7, 4, 1, CFG<BF>::CINP, nullptr));
 
   const int x = tr.t_x;
   auto A = [&](int li) { return Ls[li].bn.a; };
@@ -395,7 +410,7 @@ int build_plan(Trainer& tr) {
 
   auto GZ = [&](int li) { return Ls[li].bn.gz; };
 #define WG(LI, CFG, WNAME, LO, HI1, HI2, LN, OFF)            \
-  set_wgrad<CFG>(&Ls[LI].wg, LO, HI1, HI2, LN, OFF);          \
+  set_wgrad<CFG, ET>(&Ls[LI].wg, LO, HI1, HI2, LN, OFF);          \
   Ls[LI].wg.grad_off = P(WNAME);
   WG(0, W_inc, "inc.weight", GZ(0), x, -1, T0, -3)
   WG(1, W_d0s, "down_branch.0.0.weight", GZ(1), A(0), -1, T0, -3)
@@ -446,14 +461,15 @@ int upload(Trainer& tr, const float* weights) {
   std::vector<size_t> toff(tr.tensors.size());
   for (size_t i = 0; i < tr.tensors.size(); ++i) {
     Tensor& t = tr.tensors[i];
-    t.ls = round_up(t.need, 4);
+    t.ls = round_up(t.need, tr.bf16 ? 8 : 4);  // rows start on 16-byte boundaries either way
     toff[i] = total;
     total += (size_t)t.C * t.ls * B;
     total = (total + 63) / 64 * 64;
   }
-  TR_HIP(hipMalloc(&tr.arena, total * sizeof(float)));
-  TR_HIP(hipMemset(tr.arena, 0, total * sizeof(float)));
-  for (size_t i = 0; i < tr.tensors.size(); ++i) tr.tensors[i].p = tr.arena + toff[i];
+  TR_HIP(hipMalloc(&tr.arena, total * tr.esize));
+  TR_HIP(hipMemset(tr.arena, 0, total * tr.esize));  // (a zero of either type)
+  for (size_t i = 0; i < tr.tensors.size(); ++i)
+    tr.tensors[i].p = reinterpret_cast<float*>(reinterpret_cast<char*>(tr.arena) + toff[i] * tr.esize);
   const size_t np = tr.n_params;
   for (float** p : {&tr.w, &tr.grad, &tr.adam_m, &tr.adam_v, &tr.mask}) {
     TR_HIP(hipMalloc(p, np * sizeof(float)));
@@ -550,6 +566,11 @@ BnArgs bn_args(Trainer& tr, const BnOp& b, int B) {
   a.stats = tr.stats + b.stats_off;
   a.partial = tr.bn_partial;
   a.GB = b.Lz >= 1024 ? (B < 256 ? B : 256) : (B < 64 ? B : 64);  // more blocks for the long, few-channel layers
+  if (tr.bf16) {  // wave-per-row kernels: four rows per workgroup and trip, ~2 k workgroups per launch at most
+    int gb = 2048 / b.C;
+    if (gb > (B + 3) / 4) gb = (B + 3) / 4;
+    a.GB = gb < 1 ? 1 : (gb > 256 ? 256 : gb);
+  }
   a.g_gamma = tr.grad + b.gamma_off;
   a.g_beta = tr.grad + b.beta_off;
   a.eps = tr.bn_eps;
@@ -560,16 +581,64 @@ BnArgs bn_args(Trainer& tr, const BnOp& b, int B) {
 // deep layers: enough channels to fill the chip with one workgroup each, few enough samples per channel
 static bool bn_is_small(const BnArgs& a) { return a.C >= 32 && (long)a.B * a.Lz <= 60000; }
 
+// vectorised BatchNorm passes (bf16 rows): the crop of the ConvTranspose layers (0, 1 or 2 samples) selects the instantiation
+template <class T>
+void bn_forward_v(const BnArgs& a, hipStream_t s) {
+  if (bn_is_small(a)) {
+    hipLaunchKernelGGL(bn_fwd_small_kernel<T>, dim3(a.C), dim3(1024), 0, s, a);
+    return;
+  }
+  hipLaunchKernelGGL(bnv_stats_partial_kernel<T>, dim3(a.C, a.GB), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(a.C), dim3(64), 0, s, a);
+  const dim3 grid(a.C, a.GB);
+  if (a.crop == 0) {
+    hipLaunchKernelGGL((bnv_apply_kernel<T, 0>), grid, dim3(256), 0, s, a);
+  } else if (a.crop == 1) {
+    hipLaunchKernelGGL((bnv_apply_kernel<T, 1>), grid, dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((bnv_apply_kernel<T, 2>), grid, dim3(256), 0, s, a);
+  }
+}
+template <class T>
+void bn_backward_v(const BnArgs& a, hipStream_t s) {
+  if (bn_is_small(a)) {
+    hipLaunchKernelGGL(bn_bwd_small_kernel<T>, dim3(a.C), dim3(1024), 0, s, a);
+    return;
+  }
+  const dim3 grid(a.C, a.GB);
+  if (a.crop == 0) {
+    hipLaunchKernelGGL((bnv_bwd_partial_kernel<T, 0>), grid, dim3(256), 0, s, a);
+  } else if (a.crop == 1) {
+    hipLaunchKernelGGL((bnv_bwd_partial_kernel<T, 1>), grid, dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((bnv_bwd_partial_kernel<T, 2>), grid, dim3(256), 0, s, a);
+  }
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(a.C), dim3(64), 0, s, a);
+  if (a.crop == 0) {
+    hipLaunchKernelGGL((bnv_bwd_apply_kernel<T, 0>), grid, dim3(256), 0, s, a);
+  } else if (a.crop == 1) {
+    hipLaunchKernelGGL((bnv_bwd_apply_kernel<T, 1>), grid, dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((bnv_bwd_apply_kernel<T, 2>), grid, dim3(256), 0, s, a);
+  }
+}
+
 int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B, bool update, float lr) {
   hipStream_t s = tr.stream;
   hipLaunchKernelGGL(gather_pack_kernel, dim3((unsigned)((tr.frag_n + 255) / 256)), dim3(256), 0, s, tr.frag_idx, tr.w,
                      tr.frag, (long)tr.frag_n);
-  hipLaunchKernelGGL(load_rows_kernel, dim3((T0 + 255) / 256, 3, B), dim3(256), 0, s, x_dev, tr.rows(tr.t_x), 3, T0);
+  if (tr.bf16) {
+    hipLaunchKernelGGL(load_rows_bf16_kernel, dim3((T0 + 511) / 512, 3, B), dim3(256), 0, s, x_dev, tr.rows(tr.t_x), 3, T0);
+  } else {
+    hipLaunchKernelGGL(load_rows_kernel, dim3((T0 + 255) / 256, 3, B), dim3(256), 0, s, x_dev, tr.rows(tr.t_x), 3, T0);
+  }
   for (Layer& L : tr.layers) {
     run_conv(tr, L.fwd, B);
     const BnArgs a = bn_args(tr, L.bn, B);
-    if (bn_is_small(a)) {
-      hipLaunchKernelGGL(bn_fwd_small_kernel, dim3(a.C), dim3(1024), 0, s, a);
+    if (tr.bf16) {
+      bn_forward_v<bf16_t>(a, s);
+    } else if (bn_is_small(a)) {
+      hipLaunchKernelGGL(bn_fwd_small_kernel<float>, dim3(a.C), dim3(1024), 0, s, a);
     } else {
       hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(a.C, a.GB), dim3(256), 0, s, a);
       hipLaunchKernelGGL(bn_stats_final_kernel, dim3(a.C), dim3(64), 0, s, a);
@@ -588,8 +657,13 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     h.B = B;
     h.T = T0;
     h.eps = tr.loss_eps;
-    const int gx = (T0 + 255) / 256;
-    hipLaunchKernelGGL(head_fwd_bwd_kernel, dim3(gx, B), dim3(256), 0, s, h);
+    int gx = (T0 + 255) / 256;
+    if (tr.bf16) {
+      gx = (T0 + 511) / 512;
+      hipLaunchKernelGGL(head_fwd_bwd_pair_kernel<bf16_t>, dim3(gx, B), dim3(256), 0, s, h);
+    } else {
+      hipLaunchKernelGGL(head_fwd_bwd_kernel, dim3(gx, B), dim3(256), 0, s, h);
+    }
     // two stages: 64 row groups, then the 64 group sums
     hipLaunchKernelGGL((sum_rows_kernel<double, double>), dim3(1, 64), dim3(256), 0, s, tr.head_partial, gx * B, 28,
                        tr.head_stage);
@@ -604,8 +678,10 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
   for (int li = NLAYER - 1; li >= 0; --li) {
     Layer& L = tr.layers[li];
     const BnArgs a = bn_args(tr, L.bn, B);
-    if (bn_is_small(a)) {
-      hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(a.C), dim3(1024), 0, s, a);
+    if (tr.bf16) {
+      bn_backward_v<bf16_t>(a, s);
+    } else if (bn_is_small(a)) {
+      hipLaunchKernelGGL(bn_bwd_small_kernel<float>, dim3(a.C), dim3(1024), 0, s, a);
     } else {
       hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(a.C, a.GB), dim3(256), 0, s, a);
       hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(a.C), dim3(64), 0, s, a);
@@ -640,8 +716,13 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     }
     if (li == 0) {  // conv bias of `inc`: sum of gz per channel (zero up to rounding: BatchNorm removes the mean)
       const int GB = B < 64 ? B : 64;
-      hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(8, GB), dim3(256), 0, s, tr.rows(L.bn.gz), B, T0, GB,
-                         tr.bn_partial);
+      if (tr.bf16) {
+        hipLaunchKernelGGL(channel_sum_partial_v_kernel<bf16_t>, dim3(8, GB), dim3(256), 0, s, tr.rows(L.bn.gz), B, T0, GB,
+                           tr.bn_partial);
+      } else {
+        hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(8, GB), dim3(256), 0, s, tr.rows(L.bn.gz), B, T0, GB,
+                           tr.bn_partial);
+      }
       hipLaunchKernelGGL((sum_rows_kernel<double, float>), dim3(1, 1), dim3(256), 0, s, tr.bn_partial, GB, 8,
                          tr.grad + tr.poff.at("inc.bias"));
     }
@@ -673,7 +754,17 @@ extern "C" {
 
 int vp_train_create(int device_id, int model_kind, const float* weights, size_t n_floats, int max_batch,
                     vp_trainer** out) {
+  return vp_train_create_dtype(device_id, model_kind, weights, n_floats, max_batch, VP_TRAIN_FP32, out);
+}
+
+int vp_train_dtype(const vp_trainer* h) {
+  return h ? (reinterpret_cast<const Trainer*>(h)->bf16 ? VP_TRAIN_BF16 : VP_TRAIN_FP32) : VP_ERR_INVALID;
+}
+
+int vp_train_create_dtype(int device_id, int model_kind, const float* weights, size_t n_floats, int max_batch, int dtype,
+                          vp_trainer** out) {
   VP_REQUIRE(out && weights && max_batch > 0, "vp_train_create: bad argument");
+  VP_REQUIRE(dtype == VP_TRAIN_FP32 || dtype == VP_TRAIN_BF16, "vp_train_create: dtype %d is neither VP_TRAIN_FP32 nor VP_TRAIN_BF16", dtype);
   if (model_kind != VP_MODEL_PHASENET) {
     set_error("vp_train_create: only PhaseNet has a training step");
     return VP_ERR_UNSUPPORTED;
@@ -681,7 +772,9 @@ int vp_train_create(int device_id, int model_kind, const float* weights, size_t 
   auto tr = std::make_unique<Trainer>();
   tr->device = device_id;
   tr->max_batch = max_batch;
-  int rc = build_plan(*tr);
+  tr->bf16 = dtype == VP_TRAIN_BF16;
+  tr->esize = tr->bf16 ? 2 : 4;
+  int rc = tr->bf16 ? build_plan<1>(*tr) : build_plan<0>(*tr);
   if (rc != VP_OK) return rc;
   VP_REQUIRE(n_floats == tr->n_params, "vp_train_create: expected %zu weights, got %zu", tr->n_params, n_floats);
   VP_HIP(hipSetDevice(device_id));
@@ -800,6 +893,17 @@ int vp_train_tensor_read(vp_trainer* h, int index, int B, float* out) {
   const Tensor& t = tr.tensors[index];
   VP_HIP(hipSetDevice(tr.device));
   VP_HIP(hipStreamSynchronize(tr.stream));
+  if (tr.bf16) {
+    const size_t n = (size_t)B * t.C * t.L;
+    std::vector<uint16_t> raw(n);
+    VP_HIP(hipMemcpy2D(raw.data(), (size_t)t.L * 2, reinterpret_cast<const uint16_t*>(t.p) + HALO, (size_t)t.ls * 2, (size_t)t.L * 2,
+                       (size_t)B * t.C, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) {
+      const uint32_t u = (uint32_t)raw[i] << 16;
+      memcpy(out + i, &u, 4);
+    }
+    return VP_OK;
+  }
   VP_HIP(hipMemcpy2D(out, (size_t)t.L * sizeof(float), t.p + HALO, (size_t)t.ls * sizeof(float), (size_t)t.L * sizeof(float),
                      (size_t)B * t.C, hipMemcpyDeviceToHost));
   return VP_OK;

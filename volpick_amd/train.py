@@ -47,8 +47,17 @@ def gaussian_labels(p_samples, s_samples, n_samples=3001, sigma=20.0):
 class PhaseNetTrainer:
     """One device-resident PhaseNet with its gradients and Adam state."""
 
+    DTYPES = {"fp32": _lib.VP_TRAIN_FP32, "float32": _lib.VP_TRAIN_FP32, "32": _lib.VP_TRAIN_FP32, "32-true": _lib.VP_TRAIN_FP32,
+              "bf16": _lib.VP_TRAIN_BF16, "bfloat16": _lib.VP_TRAIN_BF16, "bf16-mixed": _lib.VP_TRAIN_BF16}
+
     def __init__(self, model: PhaseNet, max_batch=512, device=0, betas=(0.9, 0.999), eps=1e-8, bn_momentum=0.1,
-                 loss_eps=1e-5):
+                 loss_eps=1e-5, dtype="fp32"):
+        """``dtype="bf16"``: activation and gradient tensors stored as bfloat16 with fp32 accumulation, fp32 master
+        weights, statistics and Adam state (Lightning's ``precision="bf16-mixed"`` in spirit; BASELINE config 5);
+        ``"fp32"`` (default) is what the reference's trainer runs."""
+        if str(dtype) not in self.DTYPES:
+            raise ValueError(f"dtype must be one of {sorted(self.DTYPES)}, got {dtype!r}")
+        self.dtype = "bf16" if self.DTYPES[str(dtype)] == _lib.VP_TRAIN_BF16 else "fp32"
         if not isinstance(model, PhaseNet):
             raise TypeError("the training step is implemented for PhaseNet")
         if model._weights is None:
@@ -60,8 +69,8 @@ class PhaseNetTrainer:
         self.n_params = int(model._weights.size)
         self._h = C.c_void_p()
         w = np.ascontiguousarray(model._weights, dtype=np.float32)
-        _lib.check(self._lib.vp_train_create(int(device), _lib.VP_MODEL_PHASENET, w.ctypes.data_as(C.c_void_p), w.size,
-                                             self.max_batch, C.byref(self._h)), "vp_train_create")
+        _lib.check(self._lib.vp_train_create_dtype(int(device), _lib.VP_MODEL_PHASENET, w.ctypes.data_as(C.c_void_p), w.size,
+                                                   self.max_batch, self.DTYPES[str(dtype)], C.byref(self._h)), "vp_train_create")
         _lib.check(self._lib.vp_train_set_hyper(self._h, betas[0], betas[1], eps, bn_momentum, loss_eps))
         self.global_step = 0
 
@@ -180,8 +189,9 @@ class PhaseNetLit:
 
     WARMUP_STEPS = 500
 
-    def __init__(self, lr=1e-2, sigma=20, max_batch=512, model=None, device=0, **model_kwargs):
+    def __init__(self, lr=1e-2, sigma=20, max_batch=512, model=None, device=0, precision="32", **model_kwargs):
         self.lr = float(lr)
+        self.precision = str(precision)  # "32" (the reference's) or "bf16-mixed" (PhaseNetTrainer dtype="bf16")
         self.sigma = sigma
         self.model = model if model is not None else PhaseNet(**model_kwargs)
         self._trainer = None
@@ -190,7 +200,7 @@ class PhaseNetLit:
 
     def _ensure(self):
         if self._trainer is None:
-            self._trainer = PhaseNetTrainer(self.model, max_batch=self._max_batch, device=self._device)
+            self._trainer = PhaseNetTrainer(self.model, max_batch=self._max_batch, device=self._device, dtype=self.precision)
         return self._trainer
 
     def learning_rate(self, step):
