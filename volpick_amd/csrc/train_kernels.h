@@ -39,22 +39,11 @@ struct BnArgs {
   float* stats;     // [4][C]: batch mean, rstd, S1 = sum(da'), S2 = sum(da' * xhat)
   double* partial;  // [C][GB][2]
   int GB;
+  int sl2;          // vector kernels: log2 of the lanes that share a row (VecWalk)
   float* g_gamma;   // gradient blob slots
   float* g_beta;
   float eps, momentum;
 };
-
-__device__ inline double block_sum_double(double v, double* sh) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  __syncthreads();
-  if (lane == 0) sh[wave] = v;
-  __syncthreads();
-  double s = 0.0;
-  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
-  return s;
-}
 
 // one wavefront per channel: totals of the GB partial pairs (fixed order), valid in lane 0
 __device__ inline void channel_totals(const BnArgs& a, int c, double* s0, double* s1) {
@@ -72,143 +61,17 @@ __device__ inline void channel_totals(const BnArgs& a, int c, double* s0, double
   *s1 = y;
 }
 
-// grid (C), 64 threads: batch mean / biased variance -> mean, rstd; running statistics as torch
-// (momentum 0.1, unbiased variance).  (A last-block-finalises scheme with __threadfence + an arrival
-// counter was 4-5x SLOWER here: the device-scope fence costs tens of microseconds per launch.)
-__global__ __launch_bounds__(64) void bn_stats_final_kernel(const BnArgs a) {
-  const int c = blockIdx.x;
-  double S, Q;
-  channel_totals(a, c, &S, &Q);
-  if (threadIdx.x != 0) return;
-  const double N = (double)a.B * a.Lz;
-  const double mean = S / N;
-  double var = Q / N - mean * mean;
-  if (var < 0.0) var = 0.0;
-  a.stats[c] = (float)mean;
-  a.stats[a.C + c] = (float)(1.0 / sqrt(var + (double)a.eps));
-  a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
-  a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)(var * N / (N - 1.0));
-}
-
-__global__ __launch_bounds__(64) void bn_bwd_final_kernel(const BnArgs a) {
-  const int c = blockIdx.x;
-  double S1, S2;
-  channel_totals(a, c, &S1, &S2);
-  if (threadIdx.x != 0) return;
-  a.stats[2 * a.C + c] = (float)S1;
-  a.stats[3 * a.C + c] = (float)S2;
-  a.g_beta[c] = (float)S1;
-  a.g_gamma[c] = (float)S2;
-}
-
-// grid (C, GB), 256 threads: block (c, j) sums channel c over windows j, j + GB, ...
-__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const BnArgs a) {
-  __shared__ double sh[4];
-  const int c = blockIdx.x, j = blockIdx.y;
-  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int b = j; b < a.B; b += a.GB) {
-    const float* z = a.z.p + (long)b * a.z.ws + (long)c * a.z.ls + HALO;
-    for (int t0 = threadIdx.x; t0 < a.Lz; t0 += 1024) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {  // four independent loads in flight
-        const int t = t0 + u * 256;
-        const float v = t < a.Lz ? z[t] : 0.f;
-        s[u] += v;
-        q[u] = fmaf(v, v, q[u]);
-      }
-    }
-  }
-  const double S = block_sum_double((double)((s[0] + s[1]) + (s[2] + s[3])), sh);
-  const double Q = block_sum_double((double)((q[0] + q[1]) + (q[2] + q[3])), sh);
-  if (threadIdx.x == 0) {
-    a.partial[((long)c * a.GB + j) * 2] = S;
-    a.partial[((long)c * a.GB + j) * 2 + 1] = Q;
-  }
-}
-
-// grid (ceil(La / 1024), C, B)
-__global__ __launch_bounds__(256) void bn_apply_kernel(const BnArgs a) {
-  const int c = blockIdx.y, b = blockIdx.z;
-  const float mean = a.stats[c], rstd = a.stats[a.C + c];
-  const float sc = a.gamma[c] * rstd, sh = a.beta[c] - mean * sc;
-  const float* z = a.z.p + (long)b * a.z.ws + (long)c * a.z.ls + HALO + a.crop;
-  float* o = a.a.p + (long)b * a.a.ws + (long)c * a.a.ls + HALO;
-  const int t0 = blockIdx.x * 1024 + threadIdx.x;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int t = t0 + k * 256;
-    if (t < a.La) o[t] = fmaxf(fmaf(z[t], sc, sh), 0.f);
-  }
-}
-
-// grid (C, GB): S1 = sum da', S2 = sum da' * xhat with da' = ga * [a > 0]
-__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const BnArgs a) {
-  __shared__ double sh[4];
-  const int c = blockIdx.x, j = blockIdx.y;
-  const float mean = a.stats[c], rstd = a.stats[a.C + c];
-  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-  for (int b = j; b < a.B; b += a.GB) {
-    const float* z = a.z.p + (long)b * a.z.ws + (long)c * a.z.ls + HALO + a.crop;
-    const float* act = a.a.p + (long)b * a.a.ws + (long)c * a.a.ls + HALO;
-    const float* g1 = a.ga1.p + (long)b * a.ga1.ws + (long)c * a.ga1.ls + HALO;
-    const float* g2 = a.ga2.p ? a.ga2.p + (long)b * a.ga2.ws + (long)c * a.ga2.ls + HALO : nullptr;
-    for (int t0 = threadIdx.x; t0 < a.La; t0 += 512) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int t = t0 + u * 256;
-        if (t < a.La) {
-          float g = g1[t];
-          if (g2) g += g2[t];
-          if (!(act[t] > 0.f)) g = 0.f;
-          s1[u] += g;
-          s2[u] = fmaf(g, (z[t] - mean) * rstd, s2[u]);
-        }
-      }
-    }
-  }
-  const double S1 = block_sum_double((double)(s1[0] + s1[1]), sh), S2 = block_sum_double((double)(s2[0] + s2[1]), sh);
-  if (threadIdx.x == 0) {
-    a.partial[((long)c * a.GB + j) * 2] = S1;
-    a.partial[((long)c * a.GB + j) * 2 + 1] = S2;
-  }
-}
-
-// grid (ceil(Lz / 1024), C, B): gz = gamma * rstd * (da' - S1/N - xhat * S2/N) over the FULL conv output
-// (positions cropped away before the next layer still receive gradient through the statistics).
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnArgs a) {
-  const int c = blockIdx.y, b = blockIdx.z;
-  const float mean = a.stats[c], rstd = a.stats[a.C + c];
-  const float invN = 1.f / ((float)a.B * (float)a.Lz);
-  const float m1 = a.stats[2 * a.C + c] * invN, m2 = a.stats[3 * a.C + c] * invN;
-  const float k = a.gamma[c] * rstd;
-  const float* z = a.z.p + (long)b * a.z.ws + (long)c * a.z.ls + HALO;
-  const float* act = a.a.p + (long)b * a.a.ws + (long)c * a.a.ls + HALO;
-  const float* g1 = a.ga1.p + (long)b * a.ga1.ws + (long)c * a.ga1.ls + HALO;
-  const float* g2 = a.ga2.p ? a.ga2.p + (long)b * a.ga2.ws + (long)c * a.ga2.ls + HALO : nullptr;
-  float* gz = a.gz.p + (long)b * a.gz.ws + (long)c * a.gz.ls + HALO;
-  const int j0 = blockIdx.x * 1024 + threadIdx.x;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int j = j0 + u * 256;
-    if (j < a.Lz) {
-      const int t = j - a.crop;
-      float g = 0.f;
-      if (t >= 0 && t < a.La && act[t] > 0.f) {
-        g = g1[t];
-        if (g2) g += g2[t];
-      }
-      const float xh = (z[j] - mean) * rstd;
-      gz[j] = k * (g - m1 - xh * m2);
-    }
-  }
-}
-
-// ---- vectorised forms (bf16 storage mode; T = float works too) -----------------------------------------------------
-// grid (C, GB), 256 threads: a WAVE owns a row (b, c) at a time and walks it in 8-sample vectors (16 bytes of bf16),
-// rows b = j + GB * (wave + 4 k).  A few thousand long-lived workgroups instead of one short block per 1024 samples:
-// the per-1024-sample grids of the kernels above were bound by workgroup dispatch, not by memory, once the rows shrank
-// to half the bytes.  Margins: a row's samples behind its logical length are zero and stay zero (the consumers'
-// padding): vectors are read whole, written with the tail masked.
+// ---- BatchNorm passes, T = float or bf16_t rows ---------------------------------------------------------------------
+// Rows are walked in 8-sample vectors (16 bytes of bf16).  A wave covers 64 >> sl2 rows at a time with 1 << sl2 lanes
+// each (BnArgs::sl2: 6 = a whole wave per row for the 3001-sample rows ... 1 = 32 rows of 12 samples per wave), so the
+// short rows of the deep layers keep all lanes busy.  grid (C, GB), 256 threads: block j, wave w take rows
+// (j + GB * (w + 4 k)) * RP + lane / slots.  A few thousand long-lived workgroups instead of one short block per 1024
+// samples: such per-1024-sample grids (round 1) were bound by workgroup dispatch, not by memory, once the rows shrank
+// to half the bytes (fp32 rows through these kernels: 2.45 vs 2.68 ms per 512-window step).  Margins: a row's samples behind its logical length are zero and stay zero (the
+// consumers' padding): vectors are read whole, written with the tail masked.
+// The per-channel finalisation (mean / rstd / running statistics; S1, S2 and the gamma / beta gradients) is done by every
+// apply block for itself from the GB partial sums (fixed order: deterministic, and every block gets the same values);
+// block 0 of a channel writes them out.  That removes two launches per layer and direction.
 //
 // CROP (ConvTranspose layers: a = relu(bn(z[CROP + t]))) shifts z against a / ga by one or two samples: the shifted
 // operand is read as two aligned vectors and re-indexed in registers.
@@ -231,69 +94,72 @@ __device__ __forceinline__ void load8_at(const T* row, int t0, float (&v)[8]) { 
   }
 }
 
-__device__ inline void block_sum2_f64_4waves(double& x, double& y, double* sh /*[8]*/) {
+// sums of two per-thread values over a block of NW waves (fixed order), valid in every thread
+template <int NW>
+__device__ inline void block_sum2_f64(double& x, double& y, double* sh /*[2 * NW]*/) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     x += __shfl_xor(x, o, 64);
     y += __shfl_xor(y, o, 64);
   }
+  __syncthreads();
   if (lane == 0) {
     sh[2 * wave] = x;
     sh[2 * wave + 1] = y;
   }
   __syncthreads();
-  x = (sh[0] + sh[2]) + (sh[4] + sh[6]);
-  y = (sh[1] + sh[3]) + (sh[5] + sh[7]);
+  x = y = 0.0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    x += sh[2 * w];
+    y += sh[2 * w + 1];
+  }
 }
 
-template <class T>
-__global__ __launch_bounds__(256) void bnv_stats_partial_kernel(const BnArgs a) {
-  __shared__ double sh[8];
-  const int c = blockIdx.x, j = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nv = (a.Lz + 7) >> 3;
-  float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
-  for (int b = j + wave * a.GB; b < a.B; b += 4 * a.GB) {
-    const T* z = a.z.row<T>(b, c);
-    for (int v0 = lane; v0 < nv; v0 += 128) {  // two vectors in flight
-      float f[2][8];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int v = v0 + 64 * u;
-        if (v < nv) {
-          Elem<T>::load8(z + 8 * v, f[u]);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) f[u][i] = 0.f;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          s[u] += f[u][i];
-          q[u] = fmaf(f[u][i], f[u][i], q[u]);
-        }
-    }
+// row walker of the vector kernels: rows b (lane group rs of wave-pass b0), vectors v = vs, vs + slots, ...
+struct VecWalk {
+  int vs, rs, slots, RP;
+  __device__ explicit VecWalk(int sl2) {
+    const int lane = threadIdx.x & 63;
+    slots = 1 << sl2;
+    RP = 64 >> sl2;
+    vs = lane & (slots - 1);
+    rs = lane >> sl2;
   }
-  double S = (double)(s[0] + s[1]), Q = (double)(q[0] + q[1]);
-  block_sum2_f64_4waves(S, Q, sh);
-  if (threadIdx.x == 0) {
-    a.partial[((long)c * a.GB + j) * 2] = S;
-    a.partial[((long)c * a.GB + j) * 2 + 1] = Q;
+};
+
+// the four per-element passes: rows b0 + rs for b0 = first, first + stride, ...
+// (one 1024-thread workgroup per channel doing reduce + finalise + apply in a single launch was tried for the deep
+// layers, as round 1 had it: 1.90 vs 1.86 ms per step -- the chip-wide grids win even at 12 samples per row)
+template <class T>
+__device__ __forceinline__ void bnv_pass_stats(const BnArgs& a, int c, const VecWalk& w, int first, int stride, float& s, float& q) {
+  const int nv = (a.Lz + 7) >> 3;
+  for (int b0 = first; b0 < a.B; b0 += stride) {
+    const int b = b0 + w.rs;
+    if (b >= a.B) continue;
+    const T* z = a.z.row<T>(b, c);
+    for (int v = w.vs; v < nv; v += w.slots) {
+      float f[8];
+      Elem<T>::load8(z + 8 * v, f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        s += f[i];
+        q = fmaf(f[i], f[i], q);
+      }
+    }
   }
 }
 
 template <class T, int CROP>
-__global__ __launch_bounds__(256) void bnv_apply_kernel(const BnArgs a) {
-  const int c = blockIdx.x, j = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float mean = a.stats[c], rstd = a.stats[a.C + c];
-  const float sc = a.gamma[c] * rstd, sh = a.beta[c] - mean * sc;
+__device__ __forceinline__ void bnv_pass_apply(const BnArgs& a, int c, const VecWalk& w, int first, int stride, float sc, float sh) {
   const int nv = (a.La + 7) >> 3;
-  for (int b = j + wave * a.GB; b < a.B; b += 4 * a.GB) {
+  for (int b0 = first; b0 < a.B; b0 += stride) {
+    const int b = b0 + w.rs;
+    if (b >= a.B) continue;
     const T* z = a.z.row<T>(b, c);
     T* o = a.a.row<T>(b, c);
-    for (int v = lane; v < nv; v += 64) {
+    for (int v = w.vs; v < nv; v += w.slots) {
       float f[8], r[8];
       load8_at<T, CROP>(z, 8 * v, f);
 #pragma unroll
@@ -304,18 +170,17 @@ __global__ __launch_bounds__(256) void bnv_apply_kernel(const BnArgs a) {
 }
 
 template <class T, int CROP>
-__global__ __launch_bounds__(256) void bnv_bwd_partial_kernel(const BnArgs a) {
-  __shared__ double sh[8];
-  const int c = blockIdx.x, j = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float mean = a.stats[c], rstd = a.stats[a.C + c];
+__device__ __forceinline__ void bnv_pass_bwd_sums(const BnArgs& a, int c, const VecWalk& w, int first, int stride, float mean,
+                                                  float rstd, float& s1, float& s2) {
   const int nv = (a.La + 7) >> 3;
-  float s1 = 0.f, s2 = 0.f;
-  for (int b = j + wave * a.GB; b < a.B; b += 4 * a.GB) {
+  for (int b0 = first; b0 < a.B; b0 += stride) {
+    const int b = b0 + w.rs;
+    if (b >= a.B) continue;
     const T* z = a.z.row<T>(b, c);
     const T* act = a.a.row<T>(b, c);
     const T* g1 = a.ga1.row<T>(b, c);
     const T* g2 = a.ga2.p ? a.ga2.row<T>(b, c) : nullptr;
-    for (int v = lane; v < nv; v += 64) {
+    for (int v = w.vs; v < nv; v += w.slots) {
       float fz[8], fa[8], fg[8];
       load8_at<T, CROP>(z, 8 * v, fz);
       Elem<T>::load8(act + 8 * v, fa);
@@ -334,29 +199,21 @@ __global__ __launch_bounds__(256) void bnv_bwd_partial_kernel(const BnArgs a) {
       }
     }
   }
-  double S1 = (double)s1, S2 = (double)s2;
-  block_sum2_f64_4waves(S1, S2, sh);
-  if (threadIdx.x == 0) {
-    a.partial[((long)c * a.GB + j) * 2] = S1;
-    a.partial[((long)c * a.GB + j) * 2 + 1] = S2;
-  }
 }
 
 template <class T, int CROP>
-__global__ __launch_bounds__(256) void bnv_bwd_apply_kernel(const BnArgs a) {
-  const int c = blockIdx.x, j = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float mean = a.stats[c], rstd = a.stats[a.C + c];
-  const float invN = 1.f / ((float)a.B * (float)a.Lz);
-  const float m1 = a.stats[2 * a.C + c] * invN, m2 = a.stats[3 * a.C + c] * invN;
-  const float k = a.gamma[c] * rstd;
+__device__ __forceinline__ void bnv_pass_bwd_apply(const BnArgs& a, int c, const VecWalk& w, int first, int stride, float mean,
+                                                   float rstd, float m1, float m2, float k) {
   const int nv = (a.Lz + 7) >> 3;
-  for (int b = j + wave * a.GB; b < a.B; b += 4 * a.GB) {
+  for (int b0 = first; b0 < a.B; b0 += stride) {
+    const int b = b0 + w.rs;
+    if (b >= a.B) continue;
     const T* z = a.z.row<T>(b, c);
     const T* act = a.a.row<T>(b, c);
     const T* g1 = a.ga1.row<T>(b, c);
     const T* g2 = a.ga2.p ? a.ga2.row<T>(b, c) : nullptr;
     T* gz = a.gz.row<T>(b, c);
-    for (int v = lane; v < nv; v += 64) {
+    for (int v = w.vs; v < nv; v += w.slots) {
       float fz[8], fa[8], fg[8], r[8];
       Elem<T>::load8(z + 8 * v, fz);
       load8_at<T, -CROP>(act, 8 * v, fa);  // a / ga at t = j - CROP
@@ -378,113 +235,101 @@ __global__ __launch_bounds__(256) void bnv_bwd_apply_kernel(const BnArgs a) {
   }
 }
 
-// ---- small layers: one launch per direction ---------------------------------------------------
-// For the deep layers (a few thousand to ~100 k samples per channel) the three-launch forms above are pure
-// launch latency.  Here ONE workgroup owns a channel: it reduces, finalises and applies in a single kernel
-// (the second pass over the channel's rows hits L2).  grid (C), 1024 threads.
-__device__ inline void block_sum2_double(double& a, double& b, double* sh /*[32]*/) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    a += __shfl_xor(a, o, 64);
-    b += __shfl_xor(b, o, 64);
-  }
-  __syncthreads();
-  if (lane == 0) {
-    sh[2 * wave] = a;
-    sh[2 * wave + 1] = b;
-  }
-  __syncthreads();
-  a = b = 0.0;
-  for (int w = 0; w < nw; ++w) {  // fixed order
-    a += sh[2 * w];
-    b += sh[2 * w + 1];
-  }
-}
-
-// (b, t) of flat element i = b * L + t for i = tid, tid + 1024, ...: stepped without a division per element
-struct RowWalk {
-  int b, t, db, dt, L;
-  __device__ RowWalk(int tid, int L_) : b(tid / L_), t(tid - (tid / L_) * L_), db(1024 / L_), dt(1024 - (1024 / L_) * L_), L(L_) {}
-  __device__ __forceinline__ void next() {
-    b += db;
-    t += dt;
-    if (t >= L) {
-      t -= L;
-      ++b;
-    }
-  }
-};
-
-template <class T>
-__global__ __launch_bounds__(1024) void bn_fwd_small_kernel(const BnArgs a) {
-  __shared__ double sh[32];
-  const int c = blockIdx.x;
-  const T* zc = reinterpret_cast<const T*>(a.z.p) + (long)c * a.z.ls + HALO;
-  float s = 0.f, q = 0.f;
-  for (RowWalk w(threadIdx.x, a.Lz); w.b < a.B; w.next()) {
-    const float v = Elem<T>::load(zc + (long)w.b * a.z.ws + w.t);
-    s += v;
-    q = fmaf(v, v, q);
-  }
-  double S = s, Q = q;
-  block_sum2_double(S, Q, sh);
+// finalisations from the channel's sums: batch mean / biased variance -> mean, rstd; running statistics as torch
+// (momentum 0.1, unbiased variance); S1, S2 = the beta / gamma gradients
+__device__ __forceinline__ void bn_finish_stats(const BnArgs& a, int c, double S, double Q, bool write, float* mean_out, float* rstd_out) {
   const double N = (double)a.B * a.Lz;
-  const double mean_d = S / N;
-  double var = Q / N - mean_d * mean_d;
+  const double mean = S / N;
+  double var = Q / N - mean * mean;
   if (var < 0.0) var = 0.0;
-  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-  if (threadIdx.x == 0) {
-    a.stats[c] = mean;
-    a.stats[a.C + c] = rstd;
-    a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
+  *mean_out = (float)mean;
+  *rstd_out = (float)(1.0 / sqrt(var + (double)a.eps));
+  if (write) {
+    a.stats[c] = *mean_out;
+    a.stats[a.C + c] = *rstd_out;
+    a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
     a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)(var * N / (N - 1.0));
   }
-  const float sc = a.gamma[c] * rstd, shv = a.beta[c] - mean * sc;
-  T* ac = reinterpret_cast<T*>(a.a.p) + (long)c * a.a.ls + HALO;
-  for (RowWalk w(threadIdx.x, a.La); w.b < a.B; w.next())
-    Elem<T>::store(ac + (long)w.b * a.a.ws + w.t,
-                   fmaxf(fmaf(Elem<T>::load(zc + (long)w.b * a.z.ws + a.crop + w.t), sc, shv), 0.f));
 }
-
-template <class T>
-__global__ __launch_bounds__(1024) void bn_bwd_small_kernel(const BnArgs a) {
-  __shared__ double sh[32];
-  const int c = blockIdx.x;
-  const float mean = a.stats[c], rstd = a.stats[a.C + c];
-  const T* zc = reinterpret_cast<const T*>(a.z.p) + (long)c * a.z.ls + HALO;
-  const T* ac = reinterpret_cast<const T*>(a.a.p) + (long)c * a.a.ls + HALO;
-  const T* g1 = reinterpret_cast<const T*>(a.ga1.p) + (long)c * a.ga1.ls + HALO;
-  const T* g2 = a.ga2.p ? reinterpret_cast<const T*>(a.ga2.p) + (long)c * a.ga2.ls + HALO : nullptr;
-  T* gzc = reinterpret_cast<T*>(a.gz.p) + (long)c * a.gz.ls + HALO;
-  float s1 = 0.f, s2 = 0.f;
-  for (RowWalk w(threadIdx.x, a.La); w.b < a.B; w.next()) {
-    float g = Elem<T>::load(g1 + (long)w.b * a.ga1.ws + w.t);
-    if (g2) g += Elem<T>::load(g2 + (long)w.b * a.ga2.ws + w.t);
-    if (!(Elem<T>::load(ac + (long)w.b * a.a.ws + w.t) > 0.f)) g = 0.f;
-    s1 += g;
-    s2 = fmaf(g, (Elem<T>::load(zc + (long)w.b * a.z.ws + a.crop + w.t) - mean) * rstd, s2);
-  }
-  double S1 = s1, S2 = s2;
-  block_sum2_double(S1, S2, sh);
-  if (threadIdx.x == 0) {
+__device__ __forceinline__ void bn_finish_bwd(const BnArgs& a, int c, double S1, double S2, bool write) {
+  if (write) {
     a.stats[2 * a.C + c] = (float)S1;
     a.stats[3 * a.C + c] = (float)S2;
     a.g_beta[c] = (float)S1;
     a.g_gamma[c] = (float)S2;
   }
-  const float invN = 1.f / ((float)a.B * (float)a.Lz);
-  const float m1 = (float)S1 * invN, m2 = (float)S2 * invN, k = a.gamma[c] * rstd;
-  for (RowWalk w(threadIdx.x, a.Lz); w.b < a.B; w.next()) {
-    const int t = w.t - a.crop;
-    float g = 0.f;
-    if (t >= 0 && t < a.La && Elem<T>::load(ac + (long)w.b * a.a.ws + t) > 0.f) {
-      g = Elem<T>::load(g1 + (long)w.b * a.ga1.ws + t);
-      if (g2) g += Elem<T>::load(g2 + (long)w.b * a.ga2.ws + t);
+}
+// totals of the GB partial pairs of channel c, the same values in every thread of the block (fixed order)
+__device__ inline void channel_totals_block(const BnArgs& a, int c, double* sh /*[2]*/, double* s0, double* s1) {
+  if (threadIdx.x < 64) {
+    double x, y;
+    channel_totals(a, c, &x, &y);
+    if (threadIdx.x == 0) {
+      sh[0] = x;
+      sh[1] = y;
     }
-    const float xh = (Elem<T>::load(zc + (long)w.b * a.z.ws + w.t) - mean) * rstd;
-    Elem<T>::store(gzc + (long)w.b * a.gz.ws + w.t, k * (g - m1 - xh * m2));
   }
+  __syncthreads();
+  *s0 = sh[0];
+  *s1 = sh[1];
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void bnv_stats_partial_kernel(const BnArgs a) {
+  __shared__ double sh[8];
+  const int c = blockIdx.x, j = blockIdx.y, wave = threadIdx.x >> 6;
+  const VecWalk w(a.sl2);
+  float s = 0.f, q = 0.f;
+  bnv_pass_stats<T>(a, c, w, (j + wave * a.GB) * w.RP, 4 * a.GB * w.RP, s, q);
+  double S = (double)s, Q = (double)q;
+  block_sum2_f64<4>(S, Q, sh);
+  if (threadIdx.x == 0) {
+    a.partial[((long)c * a.GB + j) * 2] = S;
+    a.partial[((long)c * a.GB + j) * 2 + 1] = Q;
+  }
+}
+
+template <class T, int CROP>
+__global__ __launch_bounds__(256) void bnv_apply_kernel(const BnArgs a) {
+  __shared__ double sh[2];
+  const int c = blockIdx.x, j = blockIdx.y, wave = threadIdx.x >> 6;
+  double S, Q;
+  channel_totals_block(a, c, sh, &S, &Q);
+  float mean, rstd;
+  bn_finish_stats(a, c, S, Q, j == 0 && threadIdx.x == 0, &mean, &rstd);
+  const float sc = a.gamma[c] * rstd, shv = a.beta[c] - mean * sc;
+  const VecWalk w(a.sl2);
+  bnv_pass_apply<T, CROP>(a, c, w, (j + wave * a.GB) * w.RP, 4 * a.GB * w.RP, sc, shv);
+}
+
+template <class T, int CROP>
+__global__ __launch_bounds__(256) void bnv_bwd_partial_kernel(const BnArgs a) {
+  __shared__ double sh[8];
+  const int c = blockIdx.x, j = blockIdx.y, wave = threadIdx.x >> 6;
+  const float mean = a.stats[c], rstd = a.stats[a.C + c];
+  const VecWalk w(a.sl2);
+  float s1 = 0.f, s2 = 0.f;
+  bnv_pass_bwd_sums<T, CROP>(a, c, w, (j + wave * a.GB) * w.RP, 4 * a.GB * w.RP, mean, rstd, s1, s2);
+  double S1 = (double)s1, S2 = (double)s2;
+  block_sum2_f64<4>(S1, S2, sh);
+  if (threadIdx.x == 0) {
+    a.partial[((long)c * a.GB + j) * 2] = S1;
+    a.partial[((long)c * a.GB + j) * 2 + 1] = S2;
+  }
+}
+
+template <class T, int CROP>
+__global__ __launch_bounds__(256) void bnv_bwd_apply_kernel(const BnArgs a) {
+  __shared__ double sh[2];
+  const int c = blockIdx.x, j = blockIdx.y, wave = threadIdx.x >> 6;
+  double S1, S2;
+  channel_totals_block(a, c, sh, &S1, &S2);
+  bn_finish_bwd(a, c, S1, S2, j == 0 && threadIdx.x == 0);
+  const float mean = a.stats[c], rstd = a.stats[a.C + c];
+  const float invN = 1.f / ((float)a.B * (float)a.Lz);
+  const float m1 = (float)S1 * invN, m2 = (float)S2 * invN;
+  const VecWalk w(a.sl2);
+  bnv_pass_bwd_apply<T, CROP>(a, c, w, (j + wave * a.GB) * w.RP, 4 * a.GB * w.RP, mean, rstd, m1, m2, a.gamma[c] * rstd);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -676,29 +521,58 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const T* __restrict__ par
 struct SumJob {
   const float* partial;
   float* out;
-  int rows, n, first_block;  // blocks [first_block, next job's first_block) own 32 columns each
+  int rows, n, first_block;  // blocks [first_block, next job's first_block) own SUM_COLS columns each
 };
 constexpr int MAX_SUM_JOBS = 24;
 struct SumJobs {
   SumJob job[MAX_SUM_JOBS];
   int count;
 };
+constexpr int SUM_COLS = 128;  // columns per block: 32 lanes x 16 bytes
 __global__ __launch_bounds__(256) void sum_rows_multi_kernel(const SumJobs jobs) {
-  __shared__ double sh[8][33];
+  __shared__ double sh[8][SUM_COLS + 4];
   int j = 0;
   while (j + 1 < jobs.count && (int)blockIdx.x >= jobs.job[j + 1].first_block) ++j;
   const SumJob jb = jobs.job[j];
-  const int col = ((int)blockIdx.x - jb.first_block) * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
-  double s = 0.0;
-  if (col < jb.n)
-    for (int g = rl; g < jb.rows; g += 8) s += (double)jb.partial[(long)g * jb.n + col];
-  sh[rl][threadIdx.x & 31] = s;
+  const int cl = 4 * (threadIdx.x & 31), col = ((int)blockIdx.x - jb.first_block) * SUM_COLS + cl, rl = threadIdx.x >> 5;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  if (col < jb.n) {  // n is a multiple of 4: a quad is inside or outside
+    const float* p = jb.partial + col;
+    int g = rl;
+    for (; g + 24 < jb.rows; g += 32) {  // four 16-byte loads in flight
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(g + 8 * u) * jb.n);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s[0] += (double)v[u].x;
+        s[1] += (double)v[u].y;
+        s[2] += (double)v[u].z;
+        s[3] += (double)v[u].w;
+      }
+    }
+    for (; g < jb.rows; g += 8) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (long)g * jb.n);
+      s[0] += (double)v.x;
+      s[1] += (double)v.y;
+      s[2] += (double)v.z;
+      s[3] += (double)v.w;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sh[rl][cl + i] = s[i];
   __syncthreads();
   if (rl == 0 && col < jb.n) {
-    double t = 0.0;
+    float4 o;
+    float* op = &o.x;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += sh[k][threadIdx.x & 31];
-    jb.out[col] = (float)t;
+    for (int i = 0; i < 4; ++i) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += sh[k][cl + i];
+      op[i] = (float)t;
+    }
+    *reinterpret_cast<float4*>(jb.out + col) = o;
   }
 }
 
@@ -710,20 +584,8 @@ __global__ void head_final_kernel(const double* __restrict__ sums, double* loss,
   if (i >= 4 && i < 28) g_w[i - 4] = (float)sums[i];
 }
 
-// per-channel sum over (B, L) of a tensor (the conv bias gradient of `inc`): grid (C, GB) partials, then sum_rows
-__global__ __launch_bounds__(256) void channel_sum_partial_kernel(const Rows r, int B, int L, int GB, double* partial) {
-  __shared__ double sh[4];
-  const int c = blockIdx.x, j = blockIdx.y;
-  float acc = 0.f;
-  for (int b = j; b < B; b += GB) {
-    const float* p = r.p + (long)b * r.ws + (long)c * r.ls + HALO;
-    for (int t = threadIdx.x; t < L; t += 256) acc += p[t];
-  }
-  const double s = block_sum_double((double)acc, sh);
-  if (threadIdx.x == 0) partial[(long)j * gridDim.x + c] = s;  // [GB][C]
-}
-
-// the same over 8-sample vectors, a wave per row (bf16 storage mode; the rows' margins are zero)
+// per-channel sum over (B, L) of a tensor (the conv bias gradient of `inc`): grid (C, GB) partials, then sum_rows;
+// 8-sample vectors, a wave per row (the rows' margins are zero)
 template <class T>
 __global__ __launch_bounds__(256) void channel_sum_partial_v_kernel(const Rows r, int B, int L, int GB, double* partial) {
   __shared__ double sh[8];
@@ -740,7 +602,7 @@ __global__ __launch_bounds__(256) void channel_sum_partial_v_kernel(const Rows r
     }
   }
   double s = (double)acc, zero = 0.0;
-  block_sum2_f64_4waves(s, zero, sh);
+  block_sum2_f64<4>(s, zero, sh);
   if (threadIdx.x == 0) partial[(long)j * gridDim.x + c] = s;  // [GB][C]
 }
 

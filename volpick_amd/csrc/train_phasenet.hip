@@ -206,8 +206,8 @@ struct Trainer {
     t.name = name;
     t.C = C;
     t.L = L;
-    // bf16 rows are walked in 8-sample vectors, a cropped operand one vector further (train_kernels.h load8_at)
-    t.need = bf16 ? HALO + round_up(L, 8) + 16 : HALO + round_up(L, 4) + 4;
+    // rows are walked in 8-sample vectors, a cropped operand one vector further (train_kernels.h load8_at)
+    t.need = HALO + round_up(L, 8) + 16;
     tensors.push_back(t);
     return (int)tensors.size() - 1;
   }
@@ -565,10 +565,12 @@ BnArgs bn_args(Trainer& tr, const BnOp& b, int B) {
   a.running_var = tr.w + b.rv_off;
   a.stats = tr.stats + b.stats_off;
   a.partial = tr.bn_partial;
-  a.GB = b.Lz >= 1024 ? (B < 256 ? B : 256) : (B < 64 ? B : 64);  // more blocks for the long, few-channel layers
-  if (tr.bf16) {  // wave-per-row kernels: four rows per workgroup and trip, ~2 k workgroups per launch at most
+  {  // 64 >> sl2 rows per wave and trip, ~2 k workgroups per launch at most
+    const int nv = (b.Lz + 7) / 8;
+    a.sl2 = nv <= 2 ? 1 : nv <= 4 ? 2 : nv <= 8 ? 3 : nv <= 16 ? 4 : nv <= 32 ? 5 : 6;
+    const int rows_per_block = 4 * (64 >> a.sl2);
     int gb = 2048 / b.C;
-    if (gb > (B + 3) / 4) gb = (B + 3) / 4;
+    if (gb > (B + rows_per_block - 1) / rows_per_block) gb = (B + rows_per_block - 1) / rows_per_block;
     a.GB = gb < 1 ? 1 : (gb > 256 ? 256 : gb);
   }
   a.g_gamma = tr.grad + b.gamma_off;
@@ -578,50 +580,30 @@ BnArgs bn_args(Trainer& tr, const BnOp& b, int B) {
   return a;
 }
 
-// deep layers: enough channels to fill the chip with one workgroup each, few enough samples per channel
-static bool bn_is_small(const BnArgs& a) { return a.C >= 32 && (long)a.B * a.Lz <= 60000; }
-
-// vectorised BatchNorm passes (bf16 rows): the crop of the ConvTranspose layers (0, 1 or 2 samples) selects the instantiation
+// BatchNorm passes: the crop of the ConvTranspose layers (0, 1 or 2 samples) selects the instantiation
+#define BN_CROP_LAUNCH(KERNEL, GRID, NTH)                                              \
+  do {                                                                                 \
+    if (a.crop == 0) {                                                                 \
+      hipLaunchKernelGGL((KERNEL<T, 0>), GRID, dim3(NTH), 0, s, a);                     \
+    } else if (a.crop == 1) {                                                          \
+      hipLaunchKernelGGL((KERNEL<T, 1>), GRID, dim3(NTH), 0, s, a);                     \
+    } else {                                                                           \
+      hipLaunchKernelGGL((KERNEL<T, 2>), GRID, dim3(NTH), 0, s, a);                     \
+    }                                                                                  \
+  } while (0)
 template <class T>
 void bn_forward_v(const BnArgs& a, hipStream_t s) {
-  if (bn_is_small(a)) {
-    hipLaunchKernelGGL(bn_fwd_small_kernel<T>, dim3(a.C), dim3(1024), 0, s, a);
-    return;
-  }
-  hipLaunchKernelGGL(bnv_stats_partial_kernel<T>, dim3(a.C, a.GB), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(a.C), dim3(64), 0, s, a);
   const dim3 grid(a.C, a.GB);
-  if (a.crop == 0) {
-    hipLaunchKernelGGL((bnv_apply_kernel<T, 0>), grid, dim3(256), 0, s, a);
-  } else if (a.crop == 1) {
-    hipLaunchKernelGGL((bnv_apply_kernel<T, 1>), grid, dim3(256), 0, s, a);
-  } else {
-    hipLaunchKernelGGL((bnv_apply_kernel<T, 2>), grid, dim3(256), 0, s, a);
-  }
+  hipLaunchKernelGGL(bnv_stats_partial_kernel<T>, grid, dim3(256), 0, s, a);
+  BN_CROP_LAUNCH(bnv_apply_kernel, grid, 256);
 }
 template <class T>
 void bn_backward_v(const BnArgs& a, hipStream_t s) {
-  if (bn_is_small(a)) {
-    hipLaunchKernelGGL(bn_bwd_small_kernel<T>, dim3(a.C), dim3(1024), 0, s, a);
-    return;
-  }
   const dim3 grid(a.C, a.GB);
-  if (a.crop == 0) {
-    hipLaunchKernelGGL((bnv_bwd_partial_kernel<T, 0>), grid, dim3(256), 0, s, a);
-  } else if (a.crop == 1) {
-    hipLaunchKernelGGL((bnv_bwd_partial_kernel<T, 1>), grid, dim3(256), 0, s, a);
-  } else {
-    hipLaunchKernelGGL((bnv_bwd_partial_kernel<T, 2>), grid, dim3(256), 0, s, a);
-  }
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(a.C), dim3(64), 0, s, a);
-  if (a.crop == 0) {
-    hipLaunchKernelGGL((bnv_bwd_apply_kernel<T, 0>), grid, dim3(256), 0, s, a);
-  } else if (a.crop == 1) {
-    hipLaunchKernelGGL((bnv_bwd_apply_kernel<T, 1>), grid, dim3(256), 0, s, a);
-  } else {
-    hipLaunchKernelGGL((bnv_bwd_apply_kernel<T, 2>), grid, dim3(256), 0, s, a);
-  }
+  BN_CROP_LAUNCH(bnv_bwd_partial_kernel, grid, 256);
+  BN_CROP_LAUNCH(bnv_bwd_apply_kernel, grid, 256);
 }
+#undef BN_CROP_LAUNCH
 
 int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B, bool update, float lr) {
   hipStream_t s = tr.stream;
@@ -637,12 +619,8 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     const BnArgs a = bn_args(tr, L.bn, B);
     if (tr.bf16) {
       bn_forward_v<bf16_t>(a, s);
-    } else if (bn_is_small(a)) {
-      hipLaunchKernelGGL(bn_fwd_small_kernel<float>, dim3(a.C), dim3(1024), 0, s, a);
     } else {
-      hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(a.C, a.GB), dim3(256), 0, s, a);
-      hipLaunchKernelGGL(bn_stats_final_kernel, dim3(a.C), dim3(64), 0, s, a);
-      hipLaunchKernelGGL(bn_apply_kernel, dim3((a.La + 1023) / 1024, a.C, B), dim3(256), 0, s, a);
+      bn_forward_v<float>(a, s);
     }
   }
   {
@@ -680,12 +658,8 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     const BnArgs a = bn_args(tr, L.bn, B);
     if (tr.bf16) {
       bn_backward_v<bf16_t>(a, s);
-    } else if (bn_is_small(a)) {
-      hipLaunchKernelGGL(bn_bwd_small_kernel<float>, dim3(a.C), dim3(1024), 0, s, a);
     } else {
-      hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(a.C, a.GB), dim3(256), 0, s, a);
-      hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(a.C), dim3(64), 0, s, a);
-      hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((a.Lz + 1023) / 1024, a.C, B), dim3(256), 0, s, a);
+      bn_backward_v<float>(a, s);
     }
     {
       const WgradOp& w = L.wg;
@@ -712,7 +686,7 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
       jb.rows = grid;
       jb.n = w.out_n;
       jb.first_block = sum_blocks;
-      sum_blocks += (w.out_n + 31) / 32;
+      sum_blocks += (w.out_n + SUM_COLS - 1) / SUM_COLS;
     }
     if (li == 0) {  // conv bias of `inc`: sum of gz per channel (zero up to rounding: BatchNorm removes the mean)
       const int GB = B < 64 ? B : 64;
@@ -720,7 +694,7 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
         hipLaunchKernelGGL(channel_sum_partial_v_kernel<bf16_t>, dim3(8, GB), dim3(256), 0, s, tr.rows(L.bn.gz), B, T0, GB,
                            tr.bn_partial);
       } else {
-        hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(8, GB), dim3(256), 0, s, tr.rows(L.bn.gz), B, T0, GB,
+        hipLaunchKernelGGL(channel_sum_partial_v_kernel<float>, dim3(8, GB), dim3(256), 0, s, tr.rows(L.bn.gz), B, T0, GB,
                            tr.bn_partial);
       }
       hipLaunchKernelGGL((sum_rows_kernel<double, float>), dim3(1, 1), dim3(256), 0, s, tr.bn_partial, GB, 8,
