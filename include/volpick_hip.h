@@ -213,6 +213,8 @@ int vp_profile_steps(vp_handle* h, int B, int iters, float* step_ms, int cap);
 /* One step timed IN the pipeline: the whole list runs in order `iters` times, only step `index` is bracketed by
  * events (its inputs come from the preceding kernel, as under rocprofv3). */
 int vp_profile_step_in_pipeline(vp_handle* h, int B, int iters, int index, float* ms);
+/* launch `index` alone, iters times back to back (two handles on two host threads: do two kernels share the chip?) */
+int vp_profile_one_step(vp_handle* h, int B, int iters, int index, float* ms);
 
 /* Host-only (no GPU): plans the model and returns conv layer `conv_index`'s geometry
  * (13 ints: cin1,cin2,cout,P,taps,sn,in_off,out_off,waves_m,waves_n,nw,relu,epi), packed

@@ -132,6 +132,7 @@ SIGNATURES = {
     "vp_step_issued_flops": (C.c_int, [_H, C.c_int, C.POINTER(C.c_double)]),
     "vp_profile_steps": (C.c_int, [_H, C.c_int, C.c_int, _FP, C.c_int]),
     "vp_profile_step_in_pipeline": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, _FP]),
+    "vp_profile_one_step": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, _FP]),
     "vp_debug_tensor_count": (C.c_int, [_H]),
     "vp_debug_tensor_info": (C.c_int, [_H, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vp_debug_tensor_read": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),

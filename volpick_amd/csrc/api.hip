@@ -908,6 +908,25 @@ int vp_profile_steps(vp_handle* h, int B, int iters, float* step_ms, int cap) {
   return VP_OK;
 }
 
+// One launch of the plan, `iters` times back to back on the handle's stream (inputs = whatever the buffers hold).
+// Two handles driven from two host threads show whether two kernels share the chip (tools/overlap_probe.py).
+int vp_profile_one_step(vp_handle* h, int B, int iters, int index, float* ms) {
+  VP_REQUIRE(h && ms && iters > 0, "bad argument");
+  vp::Net& net = h->net;
+  VP_REQUIRE(B > 0 && B <= net.max_batch, "B outside (0, max_batch]");
+  VP_REQUIRE(index >= 0 && index < (int)net.steps.size(), "step index %d outside [0, %d)", index, (int)net.steps.size());
+  VP_HIP(hipSetDevice(h->device));
+  int rc = net.steps[index].run(net, B, h->stream);  // warm
+  if (rc != 0) return rc;
+  VP_HIP(hipEventRecord(h->ev[0], h->stream));
+  for (int i = 0; i < iters; ++i) net.steps[index].run(net, B, h->stream);
+  VP_HIP(hipEventRecord(h->ev[1], h->stream));
+  VP_HIP(hipStreamSynchronize(h->stream));
+  VP_HIP(hipEventElapsedTime(ms, h->ev[0], h->ev[1]));
+  *ms /= iters;
+  return VP_OK;
+}
+
 // Mean duration of ONE step measured where it runs in practice: the whole step list executes in order
 // `iters` times and only step `index` is bracketed by events, so its inputs arrive from the preceding
 // kernel (not from a warm re-run of itself) -- the number rocprofv3's per-kernel AverageNs is compared with.
