@@ -33,7 +33,11 @@ import sys
 import time
 from pathlib import Path
 
-import numpy as np
+# hardware queues for the device contexts' streams (volpick_amd/__init__.py sets the same default; here it is set before
+# anything can start the HIP runtime)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+
+import numpy as np  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
@@ -52,7 +56,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU budget of the baseline legs, all models together")
-    ap.add_argument("--contexts", type=int, default=3, help="device contexts (stream + workspace) steps alternate over")
+    ap.add_argument("--contexts", type=int, default=0,
+                    help="device contexts (stream + workspace) steps alternate over; 0 = the model's default (PhaseNet 3, EQTransformer 4)")
     ap.add_argument("--strong", action="store_true", help="time configs[3]: one 24 h stream sharded over the ranks")
     args = ap.parse_args()
 
@@ -158,11 +163,12 @@ def bench_model(model_name, env, cpu_budget_s):
     found = C.c_int()
     fv, lv, nw = C.c_int64(), C.c_int64(), C.c_int64()
 
-    # Three device contexts (HIP stream + workspace each; 3 measured best, 4+ share hardware queues), two
+    # Three (PhaseNet) or four (EQTransformer) device contexts (HIP stream + workspace each; tools/ctx_sweep.sh: more
+    # only add queueing, and four need more than HIP's default four hardware queues -- GPU_MAX_HW_QUEUES above), two
     # submits in flight per context: the host enqueues ahead of the GPU, and one context's latency-bound stages
     # (LSTM/attention, small tail kernels) overlap the other's MFMA-bound ones.  Every step is still one full pass
     # over one batch, and every step is collected inside the timed region.
-    NCTX, DEPTH = max(1, args.contexts), 2
+    NCTX, DEPTH = (args.contexts if args.contexts > 0 else model.n_contexts), 2
     ctxs = [model._context(k) for k in range(NCTX)]
     outs = [out] + [torch.empty_like(out) for _ in range(NCTX - 1)]
 
@@ -276,6 +282,7 @@ def bench_model(model_name, env, cpu_budget_s):
             "in_samples": T,
             "parallelism": f"stream-sharded x{world}, weights broadcast once (RCCL)",
             "device_contexts": NCTX,
+            "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
             "inflight_steps_per_context": DEPTH,
             "input_residency": "every step re-reads the same device-resident stream (18 / 1.6 MB): Infinity-Cache "
                                "resident; the kernels are compute-bound, so this does not flatter the number",

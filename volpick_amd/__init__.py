@@ -7,6 +7,14 @@ Drop-in for the ``seisbench.models`` picker API volpick users call:
     picks = picker.classify(stream, batch_size=256, overlap=5500, blinding=(500, 500),
                             stacking="avg", P_threshold=0.2, S_threshold=0.2).picks
 """
+import os as _os
+
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) when the runtime starts.  classify()
+# alternates blocks over up to four device contexts, each with its own stream; with four queues for them, the null stream
+# and the framework's streams, two contexts end up behind one another on one queue (EQTransformer, four contexts:
+# 506 k windows/s at 4 queues, 528 k at 5-8; tools/ctx_sweep.sh).  Only takes effect if no HIP call has been made yet.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+
 from .models import EQTransformer, PhaseNet, WaveformModel  # noqa: F401
 from .picks import ClassifyOutput, Detection, DetectionList, Pick, PickList  # noqa: F401
 from .stream import Stream, Trace, UTCDateTime  # noqa: F401

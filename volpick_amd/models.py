@@ -53,6 +53,7 @@ class WaveformModel:
     _kind = -1
     _weights_subdir = ""
     in_samples = 0
+    default_contexts = 3
     sampling_rate = 100.0
     # class-level annotate defaults (SeisBench ``_annotate_args``), overridden by the JSON's default_args
     _annotate_args = {
@@ -77,7 +78,9 @@ class WaveformModel:
         self._extra_handles = []
         self.batch_across_blocks = True  # classify(): windows of several device-resident blocks share the forward batches
         self._max_windows_per_call = 32768  # bounds the prediction buffer of one multi-block call (2.4 GB for EQT)
-        self.n_contexts = 3  # device contexts classify() pipelines station blocks over (3 measured best: 4+ share HW queues)
+        # device contexts classify() pipelines station blocks over (tools/ctx_sweep.sh: PhaseNet 3, EQTransformer 4 with
+        # >= 5 hardware queues -- volpick_amd/__init__.py; more contexts than that only add queueing)
+        self.n_contexts = self.default_contexts
         self._device_index = None
         self._max_batch = 256
         self._plan_flags = (0, 0)  # vp_config.reserved[0:2]: (layer-by-layer plan, dump fused intermediates)
@@ -654,6 +657,7 @@ class EQTransformer(WaveformModel):
     _kind = _lib.VP_MODEL_EQTRANSFORMER
     _weights_subdir = "eqtransformer"
     in_samples = 6000
+    default_contexts = 4
     _annotate_args = dict(WaveformModel._annotate_args, overlap=1800, blinding=(500, 500))
     _annotate_args["*_threshold"] = 0.1
     _annotate_args["detection_threshold"] = 0.3
