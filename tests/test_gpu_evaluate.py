@@ -49,3 +49,36 @@ def test_evaluate_windows_matches_reference_protocol(name, T):
             len(want) == len(got[0][i]) and all(abs(w[2] - g) <= 1 for w, g in zip(want, got[0][i])))
     assert n_same >= n_tot - 1
     assert len(got) == 4 and all(len(g) == n for g in got)
+
+
+def test_evaluation_protocol_at_its_real_size():
+    """model_training/test.ipynb:624 of the reference evaluates 35,120 windows at batch 1024.  Same size here (PhaseNet):
+    1,024 distinct synthetic windows tiled to 35,120, so the answer is known without an oracle run of that length -- window
+    i must give exactly what window i % 1024 gives whatever batch it lands in (34 full batches and one of 304) -- and the
+    first 48 are checked against the reference's rule on the oracle-independent probabilities as above."""
+    T, n_base, n = 3001, 1024, 35_120
+    model = va.PhaseNet.from_pretrained("volpick").cuda()
+    x = synthetic_windows(n_base, T, seed=11)
+    xn = x - x.mean(-1, keepdims=True)
+    xn = (xn / (np.abs(xn).max(-1, keepdims=True) + 1e-10)).astype(np.float32)
+    rng = np.random.default_rng(3)
+    b_base = np.stack([rng.integers(0, 400, n_base), rng.integers(T - 600, T + 1, n_base)], 1)
+    reps = -(-n // n_base)
+    X = np.tile(xn, (reps, 1, 1))[:n]
+    borders = np.tile(b_base, (reps, 1))[:n]
+    thr = [0.39, 0.34]
+    got = evaluate_windows(model, X, borders, threshold=thr, batch_size=1024)
+    assert len(got) == 4 and all(len(g) == n for g in got)
+    n_picks = 0
+    for k in range(4):
+        for i in range(n_base, n):
+            assert np.array_equal(got[k][i], got[k][i - n_base]), (k, i)
+        n_picks += sum(len(g) for g in got[k][:n_base]) if k % 2 == 0 else 0
+    assert n_picks > n_base // 2  # the synthetic events are found
+    y = model._forward_raw(xn[:48])
+    rows = (model.labels.index("P"), model.labels.index("S"))
+    for i in range(48):
+        s, e = b_base[i]
+        for k, (row, t) in enumerate(zip(rows, thr)):
+            want = OP.picks_from_trace(y[i, row, s:e], t, t / 2)
+            assert got[2 * k][i].tolist() == [w[2] for w in want], (i, k)
