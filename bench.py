@@ -35,7 +35,7 @@ from pathlib import Path
 
 # hardware queues for the device contexts' streams (volpick_amd/__init__.py sets the same default; here it is set before
 # anything can start the HIP runtime)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 import numpy as np  # noqa: E402
 
@@ -51,7 +51,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--repeats", type=int, default=7, help="the K steps are timed this many times; value = median")
+    ap.add_argument("--repeats", type=int, default=21,
+                    help="the K steps are timed this many times, each between two synchronisations; value = median "
+                         "(the first ~6 regions after an idle GPU run at ramping clocks: timing.windows_per_s_first)")
     ap.add_argument("--model", default="both", choices=["both", "phasenet", "eqtransformer"])
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -98,8 +100,17 @@ def main():
         dist.destroy_process_group()
 
 
+def _bcast_path():
+    from volpick_amd import distributed
+
+    return distributed.LAST_BROADCAST_PATH
+
+
 def timed_repeats(run_once, sync_all, repeats, use_dist, dev):
-    """R x (sync, K steps, sync) -> list of seconds, each the max over ranks."""
+    """R x (barrier + synchronize, K steps, synchronize + barrier) -> list of seconds, each the max over ranks.
+    The clock stops when this rank's device has drained, in front of the closing barrier: the ranks started together, so
+    the maximum over ranks of those spans is the job's span, without the latency of the barrier collective itself
+    (0.1-0.2 ms, 5-8 % of a 20-step PhaseNet region)."""
     import torch
     import torch.distributed as dist
 
@@ -108,8 +119,9 @@ def timed_repeats(run_once, sync_all, repeats, use_dist, dev):
         sync_all()
         t0 = time.perf_counter()
         run_once()
-        sync_all()
+        torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
+        sync_all()
     if use_dist:
         tt = torch.tensor(times, dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -234,9 +246,11 @@ def bench_model(model_name, env, cpu_budget_s):
            for k in kernels if k not in cand and k["ms"] >= 0.5 * dom["ms"]]
     # The dominant launch is re-timed IN the pipeline (whole step list in order, events around it only): its inputs
     # then come from the preceding kernel instead of a warm re-run of itself -- the duration rocprofv3 reports
-    # for it under this same command (profiles/).  The back-to-back figure stays in forward.kernels.
+    # for it under this same command (profiles/).  200 passes enqueued back to back, one synchronisation: the launch
+    # runs at the clock it has in the timed loop (a synchronisation per pass, as in round 1, lets the GPU idle in
+    # between and times it 5-8 % slower).  The back-to-back figure stays in forward.kernels.
     dom_ms = C.c_float()
-    _lib.check(lib.vp_profile_step_in_pipeline(h, args.batch, 50, kernels.index(dom), C.byref(dom_ms)),
+    _lib.check(lib.vp_profile_step_in_pipeline(h, args.batch, 200, kernels.index(dom), C.byref(dom_ms)),
                "vp_profile_step_in_pipeline")
     per_s = args.batch / (dom_ms.value * 1e-3) / 1e12 if dom_ms.value > 0 else 0.0
     dom_tflops = dom["flop_per_window"] * per_s
@@ -273,6 +287,7 @@ def bench_model(model_name, env, cpu_budget_s):
             "statistic": "median over the repeats of the max-over-ranks time of K steps",
             "windows_per_s_min": windows / max(times),
             "windows_per_s_max": windows / min(times),
+            "windows_per_s_first": windows / times[0],
             "ms_per_step_all": [t / args.steps * 1e3 for t in times],
         },
         "config": {
@@ -314,6 +329,7 @@ def bench_model(model_name, env, cpu_budget_s):
             "kernels": kernels,
         },
         "weight_broadcast_s": t_bcast,
+        "weight_broadcast_path": _bcast_path(),
     }
     if cpu_budget_s > 0:
         result["cpu_baseline"] = cpu_baseline(model_name, data, overlap, blinding, args.batch, cpu_budget_s)
@@ -401,6 +417,7 @@ def bench_strong(env):
             "segment_samples_this_rank": (sg["hi"] - sg["lo"]) if sg else 0,
         },
         "weight_broadcast_s": t_bcast,
+        "weight_broadcast_path": _bcast_path(),
     }
     if rank == 0:
         out["picks"] = len(res[0].picks)

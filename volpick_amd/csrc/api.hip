@@ -931,7 +931,7 @@ int vp_profile_one_step(vp_handle* h, int B, int iters, int index, float* ms) {
 // `iters` times and only step `index` is bracketed by events, so its inputs arrive from the preceding
 // kernel (not from a warm re-run of itself) -- the number rocprofv3's per-kernel AverageNs is compared with.
 int vp_profile_step_in_pipeline(vp_handle* h, int B, int iters, int index, float* ms) {
-  VP_REQUIRE(h && ms && iters > 0, "bad argument");
+  VP_REQUIRE(h && ms && iters > 0 && iters <= 4096, "bad argument");
   vp::Net& net = h->net;
   VP_REQUIRE(B > 0 && B <= net.max_batch, "B outside (0, max_batch]");
   const int n = (int)net.steps.size();
@@ -939,19 +939,27 @@ int vp_profile_step_in_pipeline(vp_handle* h, int B, int iters, int index, float
   VP_HIP(hipSetDevice(h->device));
   int rc = net.run(B, h->stream);  // warm
   if (rc != VP_OK) return rc;
-  double total = 0.0;
-  for (int i = 0; i < iters; ++i) {
-    for (int s = 0; s < n; ++s) {
-      if (s == index) VP_HIP(hipEventRecord(h->ev[0], h->stream));
+  // every pass is enqueued before the first one is waited for: the launch is timed the way it runs in a busy
+  // pipeline (a synchronisation per pass lets the GPU idle between passes, and its clock with it)
+  std::vector<hipEvent_t> ev(2 * (size_t)iters, nullptr);
+  for (auto& e : ev) VP_HIP(hipEventCreate(&e));
+  for (int i = 0; i < iters && rc == VP_OK; ++i) {
+    for (int s = 0; s < n && rc == VP_OK; ++s) {
+      if (s == index) (void)hipEventRecord(ev[2 * i], h->stream);
       rc = net.steps[s].run(net, B, h->stream);
-      if (rc != 0) return rc;
-      if (s == index) VP_HIP(hipEventRecord(h->ev[1], h->stream));
+      if (s == index) (void)hipEventRecord(ev[2 * i + 1], h->stream);
     }
-    VP_HIP(hipStreamSynchronize(h->stream));
+  }
+  hipError_t err = hipStreamSynchronize(h->stream);
+  double total = 0.0;
+  for (int i = 0; i < iters && rc == VP_OK && err == hipSuccess; ++i) {
     float t = 0.f;
-    VP_HIP(hipEventElapsedTime(&t, h->ev[0], h->ev[1]));
+    err = hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]);
     total += t;
   }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (rc != VP_OK) return rc;
+  VP_HIP(err);
   *ms = (float)(total / iters);
   return VP_OK;
 }

@@ -68,6 +68,9 @@ class RcclCommunicator:
         self.close()
 
 
+LAST_BROADCAST_PATH = None  # which collective the last "nccl" broadcast_weights used (bench.py reports it)
+
+
 def broadcast_weights(model, src: int = 0, group=None, create_handle: bool = True):
     """Broadcast ``model``'s flat weight blob from ``src`` and (on GPU) build the device plan
     straight from the broadcast buffer.  Every rank must hold a model of the same class; ranks
@@ -88,8 +91,17 @@ def broadcast_weights(model, src: int = 0, group=None, create_handle: bool = Tru
         buf = torch.from_numpy(model._weights).to(dev) if dist.get_rank(group) == src else torch.zeros(
             n, dtype=torch.float32, device=dev)
         torch.cuda.current_stream(dev).synchronize()  # the upload is done before RCCL touches the buffer
-        with RcclCommunicator(dev.index, src=src, group=group) as comm:
-            comm.broadcast(buf, root=src)
+        global LAST_BROADCAST_PATH
+        try:
+            with RcclCommunicator(dev.index, src=src, group=group) as comm:
+                comm.broadcast(buf, root=src)
+            LAST_BROADCAST_PATH = "vp_bcast_weights (ncclBroadcast through the C ABI)"
+        except Exception as e:  # the library's communicator did not come up (on every rank alike): the group's own RCCL one still works
+            import sys
+
+            print(f"volpick_amd: vp_bcast_weights failed ({e}); broadcasting through torch.distributed", file=sys.stderr)
+            dist.broadcast(buf, src=src, group=group)
+            LAST_BROADCAST_PATH = "torch.distributed.broadcast (RCCL), after vp_bcast_weights failed: " + str(e)[:200]
         model._weights = buf.cpu().numpy()
         if create_handle:
             model._release()
