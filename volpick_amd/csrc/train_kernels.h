@@ -866,6 +866,245 @@ __global__ __launch_bounds__(64 * C::NWAVE) void wgrad_kernel(const WgradArgs a)
   }
 }
 
+// ---- the same weight gradient on the bf16 matrix cores (bf16 rows only) ------------------------------------------------
+// Stored activations and gradients ARE bfloat16, so lo[n] * hi[n] is exact in fp32 and v_mfma_f32_16x16x32_bf16
+// (16 cycles for 32 time samples: 16x the rate of the fp32 form) accumulates the same products in fp32 -- the result
+// differs from the fp32-MFMA kernel above by summation order only.
+//   K of an instruction = 32 consecutive time samples; lane (l & 15, g = l >> 4) supplies samples 8 g .. 8 g + 7:
+//     A: row m of lo                      -> one 16-byte LDS read
+//     B: column = input channel h, one TAP per output tile: hi[h][S (n + .) + k]
+//        S = 1: the 8 samples of tap k start k (+ parity) samples into a 16-sample window = two aligned 16-byte reads per
+//               lane for ALL seven taps; an even shift is a register renaming, an odd one four v_alignbit_b32
+//        S = 4: the staging de-interleaves a hi row into four phase planes (plane p holds samples 4 j + p), tap k reads
+//               plane (k + parity) & 3 shifted by (k + parity) >> 2 in {0, 1}: a 16-byte and a 4-byte read per plane
+//   Output tiles are (m-tile, tap, 16-channel group); a "unit" = the seven taps of one (m-tile, channel group).  Waves
+//   own units (all K-steps), or -- fewer units than waves -- share one and split the (window, K-step) pairs, folded
+//   through LDS at the end.  LDS images are bf16, zero-initialised once: the padding (rows up to 16, samples up to a
+//   multiple of 32) never holds anything else, so the padded products are 0 * 0.
+typedef __bf16 bf16x8_native __attribute__((ext_vector_type(8)));
+
+template <class C>
+struct WgradB {
+  static constexpr int NWAVE = C::NWAVE > 8 ? 8 : C::NWAVE;  // 512 threads at most: 256 registers per lane for up to 28 accumulators
+  static constexpr int LOP = C::LOP, MT = C::MT, HIP = (C::HI + 15) / 16 * 16, HG = HIP / 16, NU = MT * HG;
+  static constexpr int TTP = (C::TT + 31) / 32 * 32, KS = TTP / 32;
+  static constexpr int WHP = (C::S == 1) ? TTP + 16 : TTP + 8;  // staged samples per window (and plane)
+  static constexpr int PLANES = (C::S == 1) ? 1 : 4;
+  static constexpr int RS_LO = (C::WB * TTP + 127) / 128 * 128 + 8;  // row strides == 8 elements (16 bytes) mod 128:
+  static constexpr int RS_HI = (C::WB * WHP + 127) / 128 * 128 + 8;  // the 16 rows of a 16-byte read fall on disjoint banks
+  static constexpr int PLANE = HIP * RS_HI + 16;                      // planes 32 bytes apart mod 256: their writes spread too
+  static constexpr int LDS_ELEMS = (LOP * RS_LO + PLANES * PLANE + 7) / 8 * 8;
+  static constexpr int UPW = (NU >= NWAVE) ? NU / NWAVE : 1;      // units per wave
+  static constexpr int KSPLIT = (NU >= NWAVE) ? 1 : NWAVE / NU;   // waves sharing a unit
+  // samples fetched per window: even-aligned pairs (S = 1), groups of eight (S = 4: a lane takes samples j, j + 1, j + 4,
+  // j + 5 and writes one dword to each of two planes)
+  static constexpr int WHS = (C::S == 1) ? (C::WH + 2) / 2 * 2 : (C::WH + 1 + 7) / 8 * 8;
+  static_assert(C::S == 1 || C::S == 4, "stride 1 or 4");
+  static_assert((NU >= NWAVE) ? (NU % NWAVE == 0) : (NWAVE % NU == 0), "units over waves");
+  static_assert(HG % UPW == 0 || UPW % HG == 0, "a wave's units share an m-tile or cover whole channel-group rows");
+  static_assert(LDS_ELEMS * 2 <= 160 * 1024 && (KSPLIT == 1 || NU * 7 * 256 * 4 <= LDS_ELEMS * 2), "LDS budget; the fold reuses the images");
+  static_assert(C::S == 1 ? WHS <= WHP : WHS / 4 <= WHP, "a staged window fits its image");
+};
+
+template <class C, int PAR>
+__global__ __launch_bounds__(64 * WgradB<C>::NWAVE) void wgrad_bf16_kernel(const WgradArgs a) {
+  using W = WgradB<C>;
+  extern __shared__ uint4 wg_lds_raw[];
+  bf16_t* lo_s = reinterpret_cast<bf16_t*>(wg_lds_raw);
+  bf16_t* hi_s = lo_s + W::LOP * W::RS_LO;
+  constexpr int NTH = 64 * W::NWAVE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, l16 = lane & 15;
+  for (int i = tid; i < W::LDS_ELEMS / 8; i += NTH) wg_lds_raw[i] = make_uint4(0u, 0u, 0u, 0u);
+  // units of this wave: u = u0 .. u0 + UPW - 1, u = mt * HG + hg; ksub = its share of the (window, K-step) pairs
+  const int u0 = (W::KSPLIT == 1) ? wave * W::UPW : wave / W::KSPLIT;
+  const int ksub = (W::KSPLIT == 1) ? 0 : wave % W::KSPLIT;
+  f32x4 acc[W::UPW][7];
+#pragma unroll
+  for (int u = 0; u < W::UPW; ++u)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc[u][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fetch units: lo = an even-aligned pair; hi = a pair (S = 1) or two pairs four samples apart (S = 4)
+  constexpr int HP = (C::S == 1) ? 1 : 2;                                  // pair loads per hi unit
+  constexpr int N_LO = C::LO * C::WB * C::TT / 2, N_HI = C::HI * C::WB * W::WHS / (2 * HP);
+  constexpr int NLO = (N_LO + NTH - 1) / NTH, NHI = (N_HI + NTH - 1) / NTH;
+  unsigned pre_lo[NLO], pre_hi[NHI][HP];
+  const int groups = (a.B + C::WB - 1) / C::WB;
+  const int items = groups * a.chunks;
+  const bf16_t* lo_p = reinterpret_cast<const bf16_t*>(a.lo.p);
+  const bf16_t* hi1_p = reinterpret_cast<const bf16_t*>(a.hi1.p);
+  const bf16_t* hi2_p = reinterpret_cast<const bf16_t*>(a.hi2.p);
+  // hi unit i -> (row h, window w, first sample j of its first pair)
+  auto hi_unit = [&](const int i, int* h, int* w, int* j) __attribute__((always_inline)) {
+    constexpr int UPWIN = W::WHS / (2 * HP);  // units per (row, window)
+    *h = i / (C::WB * UPWIN);
+    const int r = i - *h * (C::WB * UPWIN);
+    *w = r / UPWIN;
+    const int q = r - *w * UPWIN;
+    *j = (C::S == 1) ? 2 * q : 8 * (q >> 1) + 2 * (q & 1);
+  };
+  auto fetch = [&](const int item) __attribute__((always_inline)) {
+    const int grp = item / a.chunks, n_start = (item - grp * a.chunks) * C::TT;
+    const int b0 = grp * C::WB;
+#pragma unroll
+    for (int k = 0; k < NLO; ++k) {
+      const int i = (tid + k * NTH) * 2;
+      const int m = i / (C::WB * C::TT), r = i - m * (C::WB * C::TT);
+      const int w = r / C::TT, n = r - w * C::TT;
+      unsigned v = 0u;
+      if (i < N_LO * 2 && b0 + w < a.B && n_start + n < a.Ln)
+        v = *reinterpret_cast<const unsigned*>(lo_p + (long)(b0 + w) * a.lo.ws + (long)m * a.lo.ls + HALO + n_start + n);
+      pre_lo[k] = v;
+    }
+    const int s0 = C::S * n_start + a.off - PAR;  // hi sample of staged position 0 (even)
+#pragma unroll
+    for (int k = 0; k < NHI; ++k) {
+      int h, w, j;
+      hi_unit(tid + k * NTH, &h, &w, &j);
+      const bool in = tid + k * NTH < N_HI && b0 + w < a.B;
+      const bf16_t* row = (h < C::HI1) ? hi1_p + (long)(b0 + w) * a.hi1.ws + (long)h * a.hi1.ls + HALO
+                                       : hi2_p + (long)(b0 + w) * a.hi2.ws + (long)(h - C::HI1) * a.hi2.ls + HALO;
+      const int lim = (h < C::HI1) ? a.lim_hi1 : a.lim_hi2;
+#pragma unroll
+      for (int e = 0; e < HP; ++e) {
+        const int idx = s0 + j + 4 * e;
+        pre_hi[k][e] = (in && idx >= -HALO && idx < lim) ? *reinterpret_cast<const unsigned*>(row + idx) : 0u;
+      }
+    }
+  };
+  if ((int)blockIdx.x < items) fetch(blockIdx.x);
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    __syncthreads();  // the zero fill (first trip) / the previous item's reads are done
+#pragma unroll
+    for (int k = 0; k < NLO; ++k) {
+      const int i = (tid + k * NTH) * 2;
+      const int m = i / (C::WB * C::TT), r = i - m * (C::WB * C::TT);
+      const int w = r / C::TT, n = r - w * C::TT;
+      if (i < N_LO * 2) *reinterpret_cast<unsigned*>(lo_s + m * W::RS_LO + w * W::TTP + n) = pre_lo[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NHI; ++k) {
+      int h, w, j;
+      hi_unit(tid + k * NTH, &h, &w, &j);
+      if (tid + k * NTH < N_HI) {
+        if constexpr (C::S == 1) {
+          *reinterpret_cast<unsigned*>(hi_s + h * W::RS_HI + w * W::WHP + j) = pre_hi[k][0];
+        } else {  // samples (j, j + 1) and (j + 4, j + 5): plane j & 3 gets (j, j + 4), plane (j & 3) + 1 gets (j + 1, j + 5)
+          bf16_t* row = hi_s + (j & 3) * W::PLANE + h * W::RS_HI + w * W::WHP + (j >> 2);
+          const unsigned p0 = pre_hi[k][0], p1 = pre_hi[k][HP - 1];
+          *reinterpret_cast<unsigned*>(row) = (p0 & 0xffffu) | (p1 << 16);
+          *reinterpret_cast<unsigned*>(row + W::PLANE) = (p0 >> 16) | (p1 & 0xffff0000u);
+        }
+      }
+    }
+    __syncthreads();
+    if (item + (int)gridDim.x < items) fetch(item + gridDim.x);
+    for (int q = ksub; q < C::WB * W::KS; q += W::KSPLIT) {
+      const int w = q / W::KS, ks = q - w * W::KS;
+      // A: one fragment per distinct m-tile of this wave's units (consecutive units share the m-tile while hg runs)
+      constexpr int NA = (W::UPW + W::HG - 1) / W::HG, NBG = (W::UPW < W::HG) ? W::UPW : W::HG;
+      bf16x8_native av[NA];
+#pragma unroll
+      for (int ia = 0; ia < NA; ++ia) {
+        const int mt = (u0 + ia * W::HG) / W::HG;
+        av[ia] = __builtin_bit_cast(bf16x8_native, *reinterpret_cast<const uint4*>(lo_s + (mt * 16 + l16) * W::RS_LO + w * W::TTP + ks * 32 + 8 * g));
+      }
+#pragma unroll
+      for (int ib = 0; ib < NBG; ++ib) {
+        const int hg = (u0 + ib) % W::HG;
+        const bf16_t* hrow = hi_s + (hg * 16 + l16) * W::RS_HI + w * W::WHP + ks * 32 + 8 * g;
+        uint4 bop[7];
+        if constexpr (C::S == 1) {
+          const uint4 q0 = *reinterpret_cast<const uint4*>(hrow), q1 = *reinterpret_cast<const uint4*>(hrow + 8);
+          const unsigned d[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+          for (int k = 0; k < 7; ++k) {
+            const int sh = k + PAR;  // samples
+            unsigned r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              r[j] = (sh & 1) ? __builtin_amdgcn_alignbit(d[(sh >> 1) + j + 1], d[(sh >> 1) + j], 16) : d[(sh >> 1) + j];
+            bop[k] = make_uint4(r[0], r[1], r[2], r[3]);
+          }
+        } else {
+          uint4 pq[4];
+          unsigned px[4];
+#pragma unroll
+          for (int pl = 0; pl < 4; ++pl) {
+            const bf16_t* pr = hrow + pl * W::PLANE;
+            pq[pl] = *reinterpret_cast<const uint4*>(pr);
+            px[pl] = *reinterpret_cast<const unsigned*>(pr + 8);
+          }
+#pragma unroll
+          for (int k = 0; k < 7; ++k) {
+            const int kk = k + PAR, pl = kk & 3, sh = kk >> 2;  // sh in {0, 1}
+            const uint4 q4 = pq[pl];
+            bop[k] = sh ? make_uint4(__builtin_amdgcn_alignbit(q4.y, q4.x, 16), __builtin_amdgcn_alignbit(q4.z, q4.y, 16),
+                                     __builtin_amdgcn_alignbit(q4.w, q4.z, 16), __builtin_amdgcn_alignbit(px[pl], q4.w, 16))
+                        : q4;
+          }
+        }
+        // the units of this wave with channel group hg: local index ib + HG * ia
+#pragma unroll
+        for (int ia = 0; ia < NA; ++ia) {
+          const int u = ib + W::HG * ia;
+          if (u < W::UPW) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+              acc[u][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ia], __builtin_bit_cast(bf16x8_native, bop[k]), acc[u][k], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  float* fold = reinterpret_cast<float*>(wg_lds_raw);
+  if constexpr (W::KSPLIT > 1) {  // fold the waves that share a unit into the first of them, one wave per round
+    for (int r = 1; r < W::KSPLIT; ++r) {
+      __syncthreads();
+      if (ksub == r) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) *reinterpret_cast<f32x4*>(fold + ((u0 * 7 + k) * 64 + lane) * 4) = acc[0][k];
+      }
+      __syncthreads();
+      if (ksub == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc[0][k] += *reinterpret_cast<const f32x4*>(fold + ((u0 * 7 + k) * 64 + lane) * 4);
+      }
+    }
+    if (ksub != 0) return;
+  }
+  float* out = a.partial + (long)blockIdx.x * C::OUT;
+#pragma unroll
+  for (int u = 0; u < W::UPW; ++u) {
+    const int mt = (u0 + u) / W::HG, hg = (u0 + u) % W::HG;
+    const int h = hg * 16 + l16;
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mt * 16 + 4 * g + r;
+        if (m < C::LO && h < C::HI) out[((long)m * C::HI + h) * C::K + k] = acc[u][k][r];
+      }
+  }
+}
+
+template <class C>
+int launch_wgrad_bf16(const WgradArgs& a, int grid, hipStream_t s) {
+  static bool attr = false;
+  constexpr size_t lds = (size_t)WgradB<C>::LDS_ELEMS * 2;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<C, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<C, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  if (a.off & 1) {
+    hipLaunchKernelGGL((wgrad_bf16_kernel<C, 1>), dim3(grid), dim3(64 * WgradB<C>::NWAVE), lds, s, a);
+  } else {
+    hipLaunchKernelGGL((wgrad_bf16_kernel<C, 0>), dim3(grid), dim3(64 * WgradB<C>::NWAVE), lds, s, a);
+  }
+  return 0;
+}
+
 template <class C, class T = float>
 int launch_wgrad(const WgradArgs& a, int grid, hipStream_t s) {
   hipLaunchKernelGGL((wgrad_kernel<C, T>), dim3(grid), dim3(64 * C::NWAVE), 0, s, a);

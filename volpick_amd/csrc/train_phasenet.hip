@@ -133,7 +133,15 @@ void set_conv(ConvOp* op, int src1, int src2, int dst, int cols, int l_out) {
 
 template <class Cfg, class T>
 void set_wgrad(WgradOp* op, int lo, int hi1, int hi2, int Ln, int off) {
-  op->launch = &launch_wgrad<Cfg, T>;
+  // bf16 rows: exact products on the bf16 matrix cores (wgrad_bf16_kernel), except for the four deepest layers (>= 4096
+  // channel pairs, <= 48 samples per row): their cost is the 115-230 KB partial result every workgroup writes, not the
+  // arithmetic, and the fp32-MFMA kernel with its smaller LDS images gets through that faster (21-37 us against 30-42)
+  constexpr bool deep = Cfg::LO * Cfg::HI >= 4096 && Cfg::TT <= 48;
+  if constexpr (sizeof(T) == 2 && !deep) {
+    op->launch = &launch_wgrad_bf16<Cfg>;
+  } else {
+    op->launch = &launch_wgrad<Cfg, T>;
+  }
   op->lo = lo;
   op->hi1 = hi1;
   op->hi2 = hi2;
