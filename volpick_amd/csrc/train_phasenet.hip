@@ -508,7 +508,7 @@ int upload(Trainer& tr, const float* weights) {
   size_t wtot = 0;
   for (Layer& L : tr.layers) {
     L.wg.partial_off = wtot;
-    wtot += (size_t)(L.wg.out_n > 30000 ? 256 : 512) * (size_t)L.wg.out_n;
+    wtot += (size_t)(L.wg.out_n > 10000 ? 256 : 512) * (size_t)L.wg.out_n;
   }
   tr.wg_partial_floats = wtot;
   TR_HIP(hipMalloc(&tr.wg_partial, wtot * sizeof(float)));
@@ -685,7 +685,7 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
       g.chunks = (w.Ln + w.TT - 1) / w.TT;
       g.partial = tr.wg_partial + w.partial_off;
       const int items = ((B + w.WB - 1) / w.WB) * g.chunks;
-      const int cap = w.out_n > 30000 ? 256 : 512;
+      const int cap = w.out_n > 10000 ? 256 : 512;  // one partial result per workgroup: fewer, longer-lived workgroups for the big weight tensors
       const int grid = items < cap ? items : cap;
       w.launch(g, grid, s);
       SumJob& jb = jobs.job[jobs.count++];
