@@ -207,12 +207,21 @@ __device__ __forceinline__ void store3(bf16_t* img, const int col, const int ch,
 template <int TAPS>
 struct Res3A {
   uint4 q[TAPS * 2][3];
-  __device__ __forceinline__ void load(const uint4* af, const int mt, const int lane) {
+  float bias[4], sn[4], bn[4];  // this lane's four output channels: conv bias; scale / shift of the next block's BatchNorm (conv2)
+  // everything a conv needs from memory, requested together one conv ahead
+  __device__ __forceinline__ void load(const uint4* af, const float* b, const float* s, const float* sh, const int mt, const int lane) {
     const uint4* p = af + (long)mt * (TAPS * 2 * 3 * 64) + lane;
 #pragma unroll
-    for (int s = 0; s < TAPS * 2; ++s)
+    for (int st = 0; st < TAPS * 2; ++st)
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) q[s][pc] = p[(s * 3 + pc) * 64];
+      for (int pc = 0; pc < 3; ++pc) q[st][pc] = p[(st * 3 + pc) * 64];
+    const int co = mt * 16 + 4 * (lane >> 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      bias[r] = b[co + r];
+      sn[r] = s ? s[co + r] : 0.f;
+      bn[r] = sh ? sh[co + r] : 0.f;
+    }
   }
 };
 
@@ -240,15 +249,17 @@ __device__ __forceinline__ void res3_mac(const bf16_t* src, const Res3A<TAPS>& A
       if (s & 1) load_b(bA, s + 1); else load_b(bB, s + 1);
     }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const uint4(&b)[3] = (s & 1) ? bB[j] : bA[j];
-      // (w piece, x piece), smallest products first
+    {
+      // (w piece, x piece), smallest products first; the three n-tiles interleaved: consecutive MFMAs never share an accumulator
       constexpr int WP[6] = {2, 1, 0, 1, 0, 0}, XP[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
       for (int t = 0; t < 6; ++t)
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_res, A.q[s][WP[t]]),
-                                                        __builtin_bit_cast(bf16x8_res, b[XP[t]]), acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const uint4(&b)[3] = (s & 1) ? bB[j] : bA[j];
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_res, A.q[s][WP[t]]),
+                                                          __builtin_bit_cast(bf16x8_res, b[XP[t]]), acc[j], 0, 0, 0);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -295,10 +306,7 @@ __global__ __launch_bounds__(256) void eqt_res3_kernel(const Res3Args a) {
   const int co = wave * 16 + 4 * g;  // this lane's four output channels
   f32x4 acc[3];
   // conv1: MID = relu(conv(ACT) + b) (BatchNorm folded); conv2: X += conv(MID) + b, ACT = relu(s X + b') for the next block
-  auto conv1_epilogue = [&](const float* bias) {
-    float bv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = bias[co + r];
+  auto conv1_epilogue = [&](const float (&bv)[4]) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int t = j * 16 + n;
@@ -308,14 +316,7 @@ __global__ __launch_bounds__(256) void eqt_res3_kernel(const Res3Args a) {
       store3(MID, t + 1, co, v);
     }
   };
-  auto conv2_epilogue = [&](const float* bias, const float* sn, const float* bn, const bool last) {
-    float bv[4], sv[4], ov[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      bv[r] = bias[co + r];
-      sv[r] = last ? 0.f : sn[co + r];
-      ov[r] = last ? 0.f : bn[co + r];
-    }
+  auto conv2_epilogue = [&](const float (&bv)[4], const float (&sv)[4], const float (&ov)[4], const bool last) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int t = j * 16 + n;
@@ -332,33 +333,33 @@ __global__ __launch_bounds__(256) void eqt_res3_kernel(const Res3Args a) {
       if (!last) store3(ACT, t + 1, co, v);
     }
   };
-#define R3_BLOCK(I, TAPS, NEXT_LOAD)                                        \
-  {                                                                         \
-    Res3A<TAPS> w2;                                                         \
-    w2.load(a.af2[I], wave, lane);                                          \
-    res3_mac<TAPS>(ACT, w1_##I, acc, lane);                                 \
-    conv1_epilogue(a.bs1[I]);                                               \
-    __syncthreads();                                                        \
-    NEXT_LOAD                                                               \
-    res3_mac<TAPS>(MID, w2, acc, lane);                                     \
-    conv2_epilogue(a.bs2[I], a.s_next[I], a.b_next[I], (I) == 6);           \
-    __syncthreads();                                                        \
+#define R3_BLOCK(I, TAPS, NEXT_LOAD)                                                              \
+  {                                                                                               \
+    Res3A<TAPS> w2;                                                                               \
+    w2.load(a.af2[I], a.bs2[I], (I) == 6 ? nullptr : a.s_next[I], (I) == 6 ? nullptr : a.b_next[I], wave, lane); \
+    res3_mac<TAPS>(ACT, w1_##I, acc, lane);                                                       \
+    conv1_epilogue(w1_##I.bias);                                                                  \
+    __syncthreads();                                                                              \
+    NEXT_LOAD                                                                                     \
+    res3_mac<TAPS>(MID, w2, acc, lane);                                                           \
+    conv2_epilogue(w2.bias, w2.sn, w2.bn, (I) == 6);                                              \
+    __syncthreads();                                                                              \
   }
   // kernel sizes of the seven blocks: 3 3 3 3 2 3 2; the next block's conv1 operand is requested before this block's conv2
   Res3A<3> w1_0;
-  w1_0.load(a.af1[0], wave, lane);
+  w1_0.load(a.af1[0], a.bs1[0], nullptr, nullptr, wave, lane);
   Res3A<3> w1_1;
-  R3_BLOCK(0, 3, w1_1.load(a.af1[1], wave, lane);)
+  R3_BLOCK(0, 3, w1_1.load(a.af1[1], a.bs1[1], nullptr, nullptr, wave, lane);)
   Res3A<3> w1_2;
-  R3_BLOCK(1, 3, w1_2.load(a.af1[2], wave, lane);)
+  R3_BLOCK(1, 3, w1_2.load(a.af1[2], a.bs1[2], nullptr, nullptr, wave, lane);)
   Res3A<3> w1_3;
-  R3_BLOCK(2, 3, w1_3.load(a.af1[3], wave, lane);)
+  R3_BLOCK(2, 3, w1_3.load(a.af1[3], a.bs1[3], nullptr, nullptr, wave, lane);)
   Res3A<2> w1_4;
-  R3_BLOCK(3, 3, w1_4.load(a.af1[4], wave, lane);)
+  R3_BLOCK(3, 3, w1_4.load(a.af1[4], a.bs1[4], nullptr, nullptr, wave, lane);)
   Res3A<3> w1_5;
-  R3_BLOCK(4, 2, w1_5.load(a.af1[5], wave, lane);)
+  R3_BLOCK(4, 2, w1_5.load(a.af1[5], a.bs1[5], nullptr, nullptr, wave, lane);)
   Res3A<2> w1_6;
-  R3_BLOCK(5, 3, w1_6.load(a.af1[6], wave, lane);)
+  R3_BLOCK(5, 3, w1_6.load(a.af1[6], a.bs1[6], nullptr, nullptr, wave, lane);)
   R3_BLOCK(6, 2, )
 #undef R3_BLOCK
   float* out = a.out + (long)win * a.ws_out + HALO;
