@@ -58,9 +58,10 @@ typedef struct {
                                  [2]: 1 = hand-pipelined K loop in the PhaseNet MFMA layers (A/B);
                                  [3]: tiled level-0 kernel variants of the all-MFMA plan (A/B);
                                  [4]: 1 = no L2 warm-up of the weight streams;
-                                 [5]: PhaseNet plan: 0 = the whole network in one launch (default), 1 = three launches,
+                                 [5]: PhaseNet plan: 0 = the whole network in one launch, its five deepest layers on the
+                                      bf16 matrix cores with exact three-piece operands (default), 1 = three launches,
                                       all MFMA (bit-identical to the layer plan), 2 = three launches, level-0
-                                      stride-1 convs on the VALU;
+                                      stride-1 convs on the VALU, 3 = one launch, every core layer on the fp32 MFMA;
                                  [6]: 1 = the one-launch plan reads the input tensor filled by gather_normalize
                                       instead of cutting and normalising its windows itself;
                                  [7]: EQTransformer: bit0 = decoder stages 4-6 + heads as three launches instead of the

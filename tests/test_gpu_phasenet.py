@@ -83,9 +83,14 @@ def test_fused_equals_layerwise_bitwise(oracle):
     layer.cuda()
     want = layer(xn).numpy()
     assert np.array_equal(fused(xn).numpy(), want)
-    default = PhaseNet.from_pretrained("volpick").cuda()  # the whole network in one launch
-    got = default(xn).numpy()
+    default = PhaseNet.from_pretrained("volpick").cuda()  # the whole network in one launch; its five deepest layers run on
+    got = default(xn).numpy()                              # the bf16 matrix cores with exact three-piece operands
     assert np.abs(got - want).max() < 5e-6
+    one32 = PhaseNet.from_pretrained("volpick")  # the same launch with every core layer on the fp32 MFMA
+    one32._plan_flags = (0, 0, 0, 0, 0, 3)
+    one32.cuda()
+    got32 = one32(xn).numpy()
+    assert np.abs(got32 - want).max() < 5e-6 and np.abs(got32 - got).max() < 5e-6
     three = PhaseNet.from_pretrained("volpick")  # three launches, level-0 stride-1 convs on the VALU
     three._plan_flags = (0, 0, 0, 0, 0, 2)
     three.cuda()

@@ -11,11 +11,11 @@ x = synthetic_windows(512, 3001, seed=4242)
 xn = OP.batch_pre(orc, torch.from_numpy(x))
 with torch.no_grad():
     want = orc(xn).double().numpy()
-for name, flags in [("one launch (default)", (0,)), ("three launches, VALU level 0", (0, 0, 0, 0, 0, 2)), ("three launches, all MFMA", (0, 0, 0, 0, 0, 1)), ("layer plan", (1, 0))]:
+for name, flags in [("one launch, deep layers on bf16 pieces (default)", (0,)), ("one launch, all core layers fp32 MFMA", (0, 0, 0, 0, 0, 3)), ("three launches, VALU level 0", (0, 0, 0, 0, 0, 2)), ("three launches, all MFMA", (0, 0, 0, 0, 0, 1)), ("layer plan", (1, 0))]:
     m = PhaseNet.from_pretrained("volpick"); m._plan_flags = flags; m.cuda()
     got = m(xn).double().numpy()
     e = np.abs(got - want)
-    print(f"{name:32s} max|err| {e.max():.2e}  99.99th pct {np.quantile(e, 0.9999):.2e}  mean {e.mean():.2e}")
+    print(f"{name:50s} max|err| {e.max():.2e}  99.99th pct {np.quantile(e, 0.9999):.2e}  mean {e.mean():.2e}")
 
 from volpick_amd import EQTransformer
 orc = load_pretrained("eqtransformer")

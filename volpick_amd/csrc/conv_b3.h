@@ -1,0 +1,184 @@
+// Convolutions on the bf16 matrix cores with EXACT operands (the PhaseNet core's five deepest layers; the EQTransformer
+// ResCNN kernel in eqt_fused.hip is the same idea written out by hand).
+//
+// An fp32 number is exactly the sum of three bfloat16 pieces (hi = rne(x), mid = rne(x - hi), lo = x - hi - mid: 8 + 8 + 8
+// significant bits), bf16 x bf16 products are exact in fp32, and v_mfma_f32_16x16x32_bf16 runs at 16x the rate of the
+// fp32 MFMA.  Of the nine piece products of w x, the six with i + j <= 2 carry everything down to 2^-24 |w x| (what is
+// dropped is of the order of the rounding of one fp32 product), so a conv computed this way agrees with the fp32-MFMA
+// form to fp32 rounding at 6 / 16 of its matrix time.
+//
+// Layout.  K of an instruction = 32 input channels at ONE tap; a lane supplies 8 consecutive channels.  Conv inputs
+// therefore rest in LDS as three bf16 images [piece][column][C + 8 channels]: a B fragment is one 16-byte read per piece
+// (column stride (C + 8) * 2 bytes = 16 mod 32 bytes for C = 32, 64, 128: the 16 columns of a read fall on disjoint
+// banks), and a lane's four accumulator rows -- four consecutive output channels of one column -- leave as one 8-byte
+// store per piece.  Transposed (four-phase) layers order their GEMM rows (phase, channel) instead of (channel, phase) for
+// that.  The A operand: [m-tile][tap * KS + channel step][piece][lane][8 bf16], streamed from L2 three K-steps ahead.
+#pragma once
+#include "bf16.h"
+#include "conv_lds.h"
+
+namespace vp {
+
+typedef __bf16 bf16x8_b3 __attribute__((ext_vector_type(8)));
+
+// a three-piece image: element (piece, column, channel) at img[piece * ps + column * CS + channel]; logical sample t
+// sits in column t + c0
+template <int C>
+struct B3Image {
+  static constexpr int CS = C + 8;
+  bf16_t* img;
+  int ps, c0;
+};
+
+__device__ __forceinline__ void b3_split(const float v, unsigned short& h, unsigned short& m, unsigned short& l) {
+  h = to_bf16(v);
+  const float r1 = v - from_bf16(h);
+  m = to_bf16(r1);
+  l = to_bf16(r1 - from_bf16(m));
+}
+// four consecutive channels ch .. ch + 3 of column col: one 8-byte store per piece
+__device__ __forceinline__ void b3_store4(bf16_t* img, const int ps, const int cs, const int col, const int ch, const float (&v)[4]) {
+  unsigned short h[4], m[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b3_split(v[i], h[i], m[i], l[i]);
+  bf16_t* p = img + col * cs + ch;
+  *reinterpret_cast<uint2*>(p) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+  *reinterpret_cast<uint2*>(p + ps) = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
+  *reinterpret_cast<uint2*>(p + 2 * ps) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+}
+
+// Output side of a layer: a three-piece image.  Columns [col_lo, col_hi) are the ones the layer's tiles write (zeros
+// where the sample lies outside [0, L)); zero_rest() clears every other column (the next layer's padding) and may run
+// beside the layer: the two sets are disjoint.
+template <int C>
+struct B3Store {
+  static constexpr int CS = C + 8;
+  bf16_t* img;
+  int ps, c0, L, ncols;
+  __device__ __forceinline__ void quad(const int co, const int t, const float (&v)[4]) const {
+    const int col = t + c0;
+    if ((unsigned)col >= (unsigned)ncols) return;
+    const bool in = (unsigned)t < (unsigned)L;
+    const float z[4] = {in ? v[0] : 0.f, in ? v[1] : 0.f, in ? v[2] : 0.f, in ? v[3] : 0.f};
+    b3_store4(img, ps, CS, col, co, z);
+  }
+  __device__ __forceinline__ void zero_rest(const int col_lo, const int col_hi, const int tid, const int nth) const {
+    constexpr int Q = CS / 8;  // 16-byte chunks per column
+    for (int i = tid; i < 3 * ncols * Q; i += nth) {
+      const int pc = i / (ncols * Q), r = i - pc * (ncols * Q), col = r / Q, q = r - col * Q;
+      if (col < col_lo || col >= col_hi) *reinterpret_cast<uint4*>(img + pc * ps + col * CS + 8 * q) = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+};
+
+// Output side: an fp32 image [channel][S], sample t at column B + t (the layers behind the bf16 chain)
+template <int S, int B>
+struct F32QuadStore {
+  float* img;
+  int L;
+  __device__ __forceinline__ void quad(const int co, const int t, const float (&v)[4]) const {
+    if ((unsigned)t < (unsigned)L) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) img[(co + r) * S + B + t] = v[r];
+    }
+  }
+};
+
+// lds_epilogue hook (conv_lds.h) for an fp32-MFMA layer whose OUTPUT feeds the bf16 chain (P = 1)
+template <int C>
+struct B3BlockStore : B3Store<C> {
+  static constexpr bool custom_block_epilogue = true;
+  template <class L>
+  __device__ __forceinline__ void block_epilogue(const f32x4 (&acc)[L::NB], const float (&biasv)[4], const int mt, const int colb,
+                                                 const int g, const int n) const {
+    static_assert(L::P == 1 && L::OUT_OFF == 0, "plain conv");
+#pragma unroll
+    for (int j = 0; j < L::NB; ++j) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[j][r] + biasv[r];
+        if (L::RELU) v[r] = fmaxf(v[r], 0.f);
+      }
+      this->quad(mt * 16 + 4 * g, colb + j * 16 + n, v);
+    }
+  }
+};
+
+// The conv.  L = LdsLayer (conv_lds.h) with CIN1, CIN2 multiples of 32; MPERM: GEMM rows ordered (phase, channel).
+// Items = (m-tile, block of NB n-tiles); wave w takes items w, w + nwaves, ...
+template <class L, bool MPERM, int C1, int C2, class Store>
+__device__ __forceinline__ void conv_b3(const B3Image<C1> i1, const B3Image<C2> i2, const uint4* __restrict__ af3,
+                                        const float* __restrict__ bias, const int cols, const Store store, const int wave,
+                                        const int nwaves, const int lane) {
+  static_assert(L::CIN1 % 32 == 0 && L::CIN2 % 32 == 0 && L::CIN1 == C1 && (L::CIN2 == 0 || L::CIN2 == C2), "32-channel K-steps");
+  static_assert(MPERM || L::P == 1, "multi-phase layers order their rows (phase, channel)");
+  constexpr int KS1 = L::CIN1 / 32, KS = (L::CIN1 + L::CIN2) / 32, STEPS = L::TAPS * KS, NB = L::NB, PF = 3;
+  constexpr int MT = L::M / 16, MT_PER_PHASE = L::COUT / 16;
+  const int NT = (cols + 15) >> 4, NBLK = (NT + NB - 1) / NB, items = MT * NBLK;
+  const int g = lane >> 4, n = lane & 15;
+  for (int item = wave; item < items; item += nwaves) {
+    const int mt = item % MT, nblk = item / MT, colb = nblk * NB * 16;
+    const int phase = MPERM ? mt / MT_PER_PHASE : 0, co0 = (MPERM ? (mt % MT_PER_PHASE) : mt) * 16 + 4 * g;
+    f32x4 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float biasv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) biasv[r] = bias[co0 + r];
+    const uint4* ap = af3 + (long)mt * (STEPS * 3 * 64) + lane;
+    uint4 q[PF + 1][3];  // A pieces of K-steps s .. s + PF
+    auto load_a = [&](const int s) {
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) q[s % (PF + 1)][pc] = ap[(s * 3 + pc) * 64];
+    };
+#pragma unroll
+    for (int s = 0; s < PF && s < STEPS; ++s) load_a(s);
+    // B: the (K-step, n-tile) pairs as one sequence, the fragment of pair i + 1 read before the MFMAs of pair i
+    uint4 b[2][3];
+    auto load_b = [&](uint4 (&bv)[3], const int s, const int j) {
+      const int tap = s / KS, ks = s - tap * KS;
+      const int col = (colb + j * 16 + n) * L::SN + tap + L::IN_OFF;
+      if (ks < KS1) {
+        const bf16_t* p = i1.img + (col + i1.c0) * (C1 + 8) + ks * 32 + 8 * g;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) bv[pc] = *reinterpret_cast<const uint4*>(p + pc * i1.ps);
+      } else {
+        const bf16_t* p = i2.img + (col + i2.c0) * (C2 + 8) + (ks - KS1) * 32 + 8 * g;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) bv[pc] = *reinterpret_cast<const uint4*>(p + pc * i2.ps);
+      }
+    };
+    load_b(b[0], 0, 0);
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      if (s + PF < STEPS) load_a(s + PF);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int i = s * NB + j;
+        if (i + 1 < STEPS * NB) load_b(b[(i + 1) & 1], (i + 1) / NB, (i + 1) % NB);
+        __builtin_amdgcn_sched_barrier(0);
+        // (w piece, x piece), smallest products first
+        constexpr int WP[6] = {2, 1, 0, 1, 0, 0}, XP[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, q[s % (PF + 1)][WP[t]]),
+                                                          __builtin_bit_cast(bf16x8_b3, b[i & 1][XP[t]]), acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[j][r] + biasv[r];
+        if (L::RELU) v[r] = fmaxf(v[r], 0.f);
+      }
+      const int c = colb + j * 16 + n;
+      store.quad(co0, MPERM ? L::P * c + phase + L::OUT_OFF : c + L::OUT_OFF, v);
+    }
+  }
+}
+
+}  // namespace vp

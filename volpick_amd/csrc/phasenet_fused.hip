@@ -14,6 +14,7 @@
 // level 0 are direct convolutions on the VALU (conv_valu.h).  Coordinates inside a tiled kernel are local to the
 // tile; ImageStore writes explicit zeros where the global position falls outside the signal so that the next layer
 // sees the reference's zero padding.
+#include "conv_b3.h"
 #include "conv_lds.h"
 #include "conv_valu.h"
 #include "net.h"
@@ -923,6 +924,8 @@ using W_upT = LdsLayer<16, 0, 8, 4, 2, 1, -1, -2, 3, 1>;    // out sample 4m + p
 struct WindowArgs {
   CoreArgs c;       // d0 / u2s unused (they live in LDS)
   const float* af4[13];  // weights of the core layers regrouped for 16-byte loads (conv_lds_q4), null where unused
+  const uint4* af3[5];   // down3.same .. up0.same as three-piece bf16 operands (conv_b3.h), B3 instantiation
+  int af3_lines[5];      // their sizes in 128-byte lines (L2 warm-up)
   const float* x;   // [B][3][ls] normalised input
   int ls_x;
   long ws_x;
@@ -960,7 +963,18 @@ struct SplitRowStore {  // up3.convT -> level-0 rows 0-3 (g0) and 4-7 (g1); zero
 // (the six-tile layers keep their dword path: 14 float4 of weights on top of 24 accumulators spill at 128 registers)
 #define Q4_LAYER(LAYER) (LAYER::CB % 4 == 0 && LAYER::NB <= 3)
 constexpr bool q4_layer_index(int i) { return (i >= 1 && i <= 9) || i == 11; }  // d1down .. up0.same, and the two register-resident two-tap layers
-template <bool PIPE>
+// B3: the five deepest layers (down3.same .. up0.same: 28 % of the kernel's cycles, 40 % of its fp32 MFMA issue) run on the
+// bf16 matrix cores with exact three-piece operands (conv_b3.h); their images are the three-piece kind, placed in the
+// same arena: down2.down's output / down3.down's output / up0.convT's output at A_R one after the other, the skip-3
+// image at the end of the arena, the bottom image in the old skip-3 slot (A_Q), which then takes up0.same's fp32 output.
+constexpr int B3_D2_NC = 54, B3_SK3_NC = 68, B3_D3_NC = 22, B3_BOT_NC = 18, B3_U0T_NC = 54;  // columns per image
+constexpr int B3_D2_PS = B3_D2_NC * 40, B3_SK3_PS = B3_SK3_NC * 72, B3_D3_PS = B3_D3_NC * 72, B3_BOT_PS = B3_BOT_NC * 136,
+              B3_U0T_PS = B3_U0T_NC * 72;                                                      // elements per piece
+constexpr int B3_SK3_OFF = CORE_LDS_FLOATS * 2 - 3 * B3_SK3_PS;  // bf16 elements from the arena start
+static_assert(B3_SK3_OFF % 8 == 0 && (A_R * 2) % 8 == 0 && (A_Q * 2) % 8 == 0, "16-byte aligned images");
+static_assert(A_R * 2 + 3 * B3_U0T_PS <= B3_SK3_OFF && A_R * 2 + 3 * B3_D2_PS <= B3_SK3_OFF && 3 * B3_BOT_PS <= (A_R - A_Q) * 2,
+              "three-piece images of the deep layers fit their slots");
+template <bool PIPE, bool B3>
 __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   extern __shared__ float4 lds_raw[];
   float* lds = reinterpret_cast<float*>(lds_raw);
@@ -978,9 +992,15 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
     float sink = 0.f;
 #define CORE_WARM(IDX, LAYER)                                                                          \
   for (int l = tid; l < LAYER::MT * LAYER::CB * LAYER::TAPS * 2; l += NTH) sink += a.c.af[IDX][l * 32];
-    CORE_WARM(0, C_d1same) CORE_WARM(1, C_d1down) CORE_WARM(2, C_d2same) CORE_WARM(3, C_d2down) CORE_WARM(4, C_d3same)
-    CORE_WARM(5, C_d3down) CORE_WARM(6, C_d4same) CORE_WARM(7, C_u0T) CORE_WARM(8, C_u0same) CORE_WARM(9, C_u1T)
-    CORE_WARM(10, C_u1same) CORE_WARM(11, C_u2T) CORE_WARM(12, C_u2same)
+    CORE_WARM(0, C_d1same) CORE_WARM(1, C_d1down) CORE_WARM(2, C_d2same) CORE_WARM(3, C_d2down)
+    if constexpr (B3) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+        for (int l = tid; l < a.af3_lines[i]; l += NTH) sink += __uint_as_float(reinterpret_cast<const unsigned*>(a.af3[i])[l * 32]);
+    } else {
+      CORE_WARM(4, C_d3same) CORE_WARM(5, C_d3down) CORE_WARM(6, C_d4same) CORE_WARM(7, C_u0T) CORE_WARM(8, C_u0same)
+    }
+    CORE_WARM(9, C_u1T) CORE_WARM(10, C_u1same) CORE_WARM(11, C_u2T) CORE_WARM(12, C_u2same)
 #undef CORE_WARM
     if (sink == 1.2345678e-30f) a.y[0] = sink;  // never true: keeps the loads alive
   }
@@ -1205,14 +1225,63 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   CORE_LAYER(0, C_d1same, A_D0, S1_, A_D0, S1_, IB, A_SKIP1, S1_, IB, RangeStoreS, 16, T1, T1)
   CORE_LAYER(1, C_d1down, A_SKIP1, S1_, A_SKIP1, S1_, IB, A_D1, S2_, IB, RangeStoreS, 16, T2, T2)
   CORE_LAYER(2, C_d2same, A_D1, S2_, A_D1, S2_, IB, A_SKIP2, S2_, IB, RangeStoreS, 32, T2, T2)
+  constexpr int X_U0S = B3 ? A_Q : A_U0S, X_U1T = A_U1T;  // B3: up0.same lands in the old skip-3 slot (up1.same's output slot later on)
+  if constexpr (B3) {
+    bf16_t* l16 = reinterpret_cast<bf16_t*>(lds);
+    const B3Image<32> iD2{l16 + A_R * 2, B3_D2_PS, 3};
+    const B3Image<64> iSK3{l16 + B3_SK3_OFF, B3_SK3_PS, 3}, iD3{l16 + A_R * 2, B3_D3_PS, 3}, iU0T{l16 + A_R * 2, B3_U0T_PS, 3};
+    const B3Image<128> iBOT{l16 + A_Q * 2, B3_BOT_PS, 1};
+#define B3_END          \
+  __syncthreads();      \
+  WIN_STAMP(stamp)      \
+  ++stamp;
+    {  // down2.down (fp32 MFMA, strided) -> three-piece image
+      B3BlockStore<32> st{{iD2.img, iD2.ps, iD2.c0, T3, B3_D2_NC}};
+      st.zero_rest(3, 3 + 48, tid, NTH);
+      conv_lds_q4<C_d2down, S2_, IB, S2_, IB>(lds + A_SKIP2, lds + A_SKIP2, a.af4[3], a.c.bs[3], T3, st, wave, NWV, lane);
+      B3_END
+    }
+    {  // down3.same
+      B3Store<64> st{iSK3.img, iSK3.ps, iSK3.c0, T3, B3_SK3_NC};
+      st.zero_rest(3, 3 + 48, tid, NTH);
+      conv_b3<C_d3same, false, 32, 32>(iD2, iD2, a.af3[0], a.c.bs[4], T3, st, wave, NWV, lane);
+      B3_END
+    }
+    {  // down3.down
+      B3Store<64> st{iD3.img, iD3.ps, iD3.c0, T4, B3_D3_NC};
+      st.zero_rest(3, 3 + 16, tid, NTH);
+      conv_b3<C_d3down, false, 64, 64>(iSK3, iSK3, a.af3[1], a.c.bs[5], T4, st, wave, NWV, lane);
+      B3_END
+    }
+    {  // down4.same
+      B3Store<128> st{iBOT.img, iBOT.ps, iBOT.c0, T4, B3_BOT_NC};
+      st.zero_rest(1, 1 + 16, tid, NTH);
+      conv_b3<C_d4same, false, 64, 64>(iD3, iD3, a.af3[2], a.c.bs[6], T4, st, wave, NWV, lane);
+      B3_END
+    }
+    {  // up0.convT: rows ordered (phase, channel); samples 4 c + phase - 1, columns c in [0, 16)
+      B3Store<64> st{iU0T.img, iU0T.ps, iU0T.c0, T3, B3_U0T_NC};
+      st.zero_rest(2, B3_U0T_NC, tid, NTH);
+      conv_b3<C_u0T, true, 128, 128>(iBOT, iBOT, a.af3[3], a.c.bs[7], T4 + 1, st, wave, NWV, lane);
+      B3_END
+    }
+    {  // up0.same: cat(skip 3, up0.convT) -> fp32 image for up1.convT
+      F32QuadStore<S3_, IB> st{lds + X_U0S, T3};
+      zero_halo<64, S3_, T3, IB>(lds + X_U0S, tid, NTH);
+      conv_b3<C_u0same, false, 64, 64>(iSK3, iU0T, a.af3[4], a.c.bs[8], T3, st, wave, NWV, lane);
+      B3_END
+    }
+#undef B3_END
+  } else {
   CORE_LAYER(3, C_d2down, A_SKIP2, S2_, A_SKIP2, S2_, IB, A_D2, S3_, IB, RangeStoreS, 32, T3, T3)
   CORE_LAYER(4, C_d3same, A_D2, S3_, A_D2, S3_, IB, A_SKIP3, S3_, IB, RangeStoreS, 64, T3, T3)
   CORE_LAYER(5, C_d3down, A_SKIP3, S3_, A_SKIP3, S3_, IB, A_D3, S4_, IB, RangeStoreS, 64, T4, T4)
   CORE_LAYER(6, C_d4same, A_D3, S4_, A_D3, S4_, IB, A_BOT, S4_, IB, RangeStoreS, 128, T4, T4)
   CORE_LAYER(7, C_u0T, A_BOT, S4_, A_BOT, S4_, IB, A_U0T, S3_, TB, RangeStoreV, 64, T4 + 1, T3)
   CORE_LAYER(8, C_u0same, A_SKIP3, S3_, A_U0T, S3_, TB, A_U0S, S3_, IB, RangeStoreS, 64, T3, T3)
-  CORE_LAYER_AREG(9, C_u1T, A_U0S, S3_, A_U1T, S2_, TB, RangeStoreV, 32, T3 + 1, T2, wave, 0, 1)        // 8 m-tiles x 1 block (pn_core_kernel)
-  CORE_LAYER(10, C_u1same, A_SKIP2, S2_, A_U1T, S2_, TB, A_U1S, S2_, IB, RangeStoreS, 32, T2, T2)
+  }
+  CORE_LAYER_AREG(9, C_u1T, X_U0S, S3_, X_U1T, S2_, TB, RangeStoreV, 32, T3 + 1, T2, wave, 0, 1)        // 8 m-tiles x 1 block (pn_core_kernel)
+  CORE_LAYER(10, C_u1same, A_SKIP2, S2_, X_U1T, S2_, TB, A_U1S, S2_, IB, RangeStoreS, 32, T2, T2)
   CORE_LAYER_AREG(11, C_u2T, A_U1S, S2_, A_U2T, S1_, TB, RangeStoreV, 16, T2 + 1, T1, wave & 3, wave >> 2, 4)  // 4 m-tiles x 4 blocks
 #undef CORE_LAYER_AREG
   // up2.same has eight items: waves 0-7 run it, waves 8-15 meanwhile fetch the eight skip rows of the up phase into
@@ -1342,6 +1411,49 @@ std::vector<float> pack_valu(const float* W, int cin, bool transposed, const std
 }
 }  // namespace
 
+namespace {
+// fp32 MFMA-order fragments [mt][cb][tap][64] (pack_afrag) -> three-piece bf16 operand [mt'][tap * KS + step][piece][64][8]
+// (conv_b3.h); mperm: rows regrouped (channel, phase) -> (phase, channel)
+std::vector<float> b3_operand(const ConvLayer& L, bool mperm) {
+  const int cinp = L.g.cinp(), taps = L.g.taps, M = L.g.M(), P = L.g.P, cout = L.g.cout, CB = cinp / 4, KS = cinp / 32, MT = M / 16;
+  auto rne = [](float x) -> uint16_t {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  };
+  auto widen = [](uint16_t h) -> float {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+  };
+  const std::vector<float>& af = L.afrag.h;
+  std::vector<uint16_t> o((size_t)MT * taps * KS * 3 * 64 * 8);
+  for (int mt = 0; mt < MT; ++mt)
+    for (int tap = 0; tap < taps; ++tap)
+      for (int ks = 0; ks < KS; ++ks)
+        for (int l = 0; l < 64; ++l)
+          for (int i = 0; i < 8; ++i) {
+            const int mp = mt * 16 + (l & 15);
+            const int m = mperm ? (mp % cout) * P + mp / cout : mp;  // row of the packed fp32 operand
+            const int ci = ks * 32 + 8 * (l >> 4) + i;
+            const float w = af[(((size_t)(m / 16) * CB + ci / 4) * taps + tap) * 64 + (ci % 4) * 16 + (m % 16)];
+            const uint16_t h = rne(w);
+            const float r1 = w - widen(h);
+            const uint16_t md = rne(r1);
+            const uint16_t lo = rne(r1 - widen(md));
+            const size_t base = ((((size_t)mt * taps * KS + tap * KS + ks) * 3) * 64 + l) * 8 + i;
+            o[base] = h;
+            o[base + 64 * 8] = md;
+            o[base + 2 * 64 * 8] = lo;
+          }
+  std::vector<float> f(o.size() / 2);
+  memcpy(f.data(), o.data(), o.size() * 2);
+  return f;
+}
+}  // namespace
+
 int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
   const bool debug_dumps = (debug_flags & 1) != 0, debug_clock = (debug_flags & 2) != 0;
   // reserved[2] = 1 selects the hand-pipelined K loop (sched_barrier) for A/B timing; the compiler's own
@@ -1354,6 +1466,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
   // The debug dumps of the intermediates exist in the three-launch plans only.
   const bool valu = net.cfg.reserved[5] != 1;
   const bool whole = valu && net.cfg.reserved[5] != 2 && !debug_dumps;
+  const bool b3 = whole && net.cfg.reserved[5] != 3;  // reserved[5] = 3: the one-launch kernel with all core layers on the fp32 MFMA
   HostBlob *vw[5] = {}, *vb[5] = {};
   if (valu) {
     const float eps = net.cfg.bn_eps;
@@ -1552,9 +1665,16 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
       std::vector<float> v = regroup_afrag4(*net.convs[3 + i]);
       q4[i] = net.add_blob(std::move(v));
     }
+    HostBlob* p3[5] = {};
+    if (b3)
+      for (int i = 0; i < 5; ++i) p3[i] = net.add_blob(b3_operand(*net.convs[3 + 4 + i], i == 3));
     st.run = [=](Net& n, int B, hipStream_t s) -> int {
       WindowArgs a{};
       for (int i = 0; i < 13; ++i) a.af4[i] = q4[i] ? q4[i]->d : nullptr;
+      for (int i = 0; i < 5; ++i) {
+        a.af3[i] = p3[i] ? reinterpret_cast<const uint4*>(p3[i]->d) : nullptr;
+        a.af3_lines[i] = p3[i] ? (int)(p3[i]->h.size() * 4 / 128) : 0;
+      }
       const Tensor &tx = n.tensors[x], &ts = n.tensors[skip0];
       for (int i = 0; i < 13; ++i) {
         a.c.af[i] = n.convs[3 + i]->afrag.d;
@@ -1585,18 +1705,21 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         a.pre = *n.pre;
         a.has_pre = 1;
       }
-      if (pipe) {
-        hipLaunchKernelGGL(pn_window_kernel<true>, dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
+      if (b3) {
+        hipLaunchKernelGGL((pn_window_kernel<false, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
+      } else if (pipe) {
+        hipLaunchKernelGGL((pn_window_kernel<true, false>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
       } else {
-        hipLaunchKernelGGL(pn_window_kernel<false>, dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
+        hipLaunchKernelGGL((pn_window_kernel<false, false>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
       }
       return 0;
     };
     steps.clear();
     steps.push_back(std::move(st));
     net.fused_pre = net.cfg.reserved[6] != 1;  // reserved[6] = 1: gather_normalize_kernel fills the input tensor as in the other plans
-    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<true>), CORE_LDS_FLOATS * sizeof(float)});
-    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false>), CORE_LDS_FLOATS * sizeof(float)});
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<true, false>), CORE_LDS_FLOATS * sizeof(float)});
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, false>), CORE_LDS_FLOATS * sizeof(float)});
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true>), CORE_LDS_FLOATS * sizeof(float)});
   }
   net.steps = std::move(steps);
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_core_kernel<true>), CORE_LDS_FLOATS * sizeof(float)});
