@@ -113,7 +113,9 @@ __device__ __forceinline__ void conv_b3(const B3Image<C1> i1, const B3Image<C2> 
                                         const int nwaves, const int lane) {
   static_assert(L::CIN1 % 32 == 0 && L::CIN2 % 32 == 0 && L::CIN1 == C1 && (L::CIN2 == 0 || L::CIN2 == C2), "32-channel K-steps");
   static_assert(MPERM || L::P == 1, "multi-phase layers order their rows (phase, channel)");
-  constexpr int KS1 = L::CIN1 / 32, KS = (L::CIN1 + L::CIN2) / 32, STEPS = L::TAPS * KS, NB = L::NB, PF = 3;
+  constexpr int KS1 = L::CIN1 / 32, KS = (L::CIN1 + L::CIN2) / 32, STEPS = L::TAPS * KS, NB = L::NB;
+  constexpr int PF = 3;  // K-steps of A in flight ahead of the MFMAs (4 and 5 measured the same: the layers with one n-tile per
+                         // item run at the rate the weights stream out of L2, 34-44 B/clk/CU)
   constexpr int MT = L::M / 16, MT_PER_PHASE = L::COUT / 16;
   const int NT = (cols + 15) >> 4, NBLK = (NT + NB - 1) / NB, items = MT * NBLK;
   const int g = lane >> 4, n = lane & 15;
