@@ -510,7 +510,7 @@ int plan_eqt(Net& net, const ParamView& pv) {
   }
   // bit 1 keeps decoder.0 .. .3 (+ the stage-2 edge fix) as five launches
   if (!(net.cfg.reserved[7] & 2)) {
-    int rc = plan_eqt_fuse_dec03(net);
+    int rc = plan_eqt_fuse_dec03(net, !(net.cfg.reserved[7] & 32));  // bit 5: every stage on the fp32 MFMA
     if (rc != VP_OK) return rc;
   }
   return VP_OK;

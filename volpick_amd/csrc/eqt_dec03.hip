@@ -11,6 +11,7 @@
 // K-step ahead (conv_lds_areg).  The two outputs at the cropped right edge of stage 2 (eqt.hip: decoder2_edge_kernel)
 // are computed by one wave beside the stage itself, from the definition, with the same pre-summed taps.
 // Same packed fragments, same K order: bit-identical to the launches it replaces (plan flag reserved[7] & 2 keeps them).
+#include "conv_b3.h"
 #include "conv_lds.h"
 #include "eqt_kernels.h"
 #include "net.h"
@@ -36,6 +37,19 @@ static_assert(S0 % 32 == 16 && S1 % 32 == 16 && S2 % 32 == 16 && S3 % 32 == 16, 
 constexpr int OFF0 = 0, OFF1 = OFF0 + 16 * S0, OFF2 = OFF1 + 64 * S1, OFF3 = OFF2 + 64 * S2, D03_LDS_FLOATS = OFF3 + 32 * S3;
 static_assert(D03_LDS_FLOATS * 4 <= 160 * 1024 && OFF1 % 4 == 0 && OFF2 % 4 == 0 && OFF3 % 4 == 0, "LDS budget");
 
+// B3 instantiation: stages 1 and 2 (64 -> 64 and 64 -> 32 channels, 53 % of the row's MFMA issue) on the bf16 matrix cores with
+// exact three-piece operands (conv_b3.h).  Stage 0 (fp32 MFMA, its GEMM rows regrouped (phase, channel)) writes its output as
+// a three-piece image, stage 1 reads and writes piece images, stage 2 reads one and writes the fp32 image of stage 3 as
+// before.  LDS: the stage-2 input image (85 KB), and behind it the stage-3 fp32 image, which takes the place of the
+// (dead) stage-0 input and stage-1 input images -- one more barrier per row, 136 KB in all.
+constexpr int B3_X1_NC = 100, B3_X2_NC = 196;                          // columns: sample t at column t + 1
+constexpr int B3_X1_PS = B3_X1_NC * 72, B3_X2_PS = B3_X2_NC * 72;      // bf16 elements per piece
+constexpr int B3_OFF_X2 = 0, B3_OFF_R = 3 * B3_X2_PS * 2;              // bytes
+constexpr int B3_OFF_X0 = B3_OFF_R, B3_OFF_X1 = B3_OFF_X0 + 16 * S0 * 4, B3_OFF_X3 = B3_OFF_R;
+constexpr int B3_LDS_BYTES = B3_OFF_X3 + 32 * S3 * 4;
+static_assert(B3_OFF_X1 + 3 * B3_X1_PS * 2 <= B3_LDS_BYTES && B3_LDS_BYTES <= 160 * 1024 && B3_OFF_R % 16 == 0 && B3_OFF_X1 % 16 == 0,
+              "LDS budget of the bf16-piece variant");
+
 struct Dec03Args {
   const float* x;  // decoder.in rows [3 B][16][ls]
   int ls_x;
@@ -46,6 +60,8 @@ struct Dec03Args {
   const float* af[4];  // A fragments regrouped for 16-byte loads [set][MT][CB * TAPS / 4][64][4]
   const float* bs[4];  // bias [set][COUT]
   long af_stride[4];
+  const uint4* af3[2];  // B3: three-piece operands of stages 1 and 2 [set][MT][TAPS * 2][piece][64] (conv_b3.h)
+  long af3_stride[2];   // uint4 per set
   const float* edge_w;  // [3][64][64][3] pre-summed taps of the two edge outputs of stage 2 (eqt.hip)
   const float* edge_b;  // [3][32]
   int B, n_rows;
@@ -96,9 +112,139 @@ struct RowOut {
   }
 };
 
+// B3, stage 0: rows (phase, channel): m-tile mt holds phase mt / 4, channels (mt % 4) * 16 ..; -> three-piece image
+struct Stage0Pieces : B3Store<64> {
+  static constexpr bool custom_block_epilogue = true;
+  template <class L>
+  __device__ __forceinline__ void block_epilogue(const f32x4 (&acc)[L::NB], const float (&biasv)[4], const int mt, const int colb,
+                                                 const int g, const int n) const {
+    static_assert(L::P == 2 && L::RELU == 1 && L::OUT_OFF == 0 && L::COUT == 64, "stage 0 of the decoder");
+#pragma unroll
+    for (int j = 0; j < L::NB; ++j) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[j][r] + biasv[r], 0.f);  // biasv: the caller's (phase, channel) order
+      this->quad((mt & 3) * 16 + 4 * g, 2 * (colb + j * 16 + n) + (mt >> 2), v);
+    }
+  }
+};
+// B3, stage 2 -> the fp32 image of stage 3; samples from `hi` on are the edge fix's / padding (ClipStore)
+struct ClipQuad {
+  float* img;  // image + BI
+  int hi;
+  __device__ __forceinline__ void quad(const int co, const int t, const float (&v)[4]) const {
+    if (t < hi) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) img[(co + r) * S3 + t] = v[r];
+    }
+  }
+};
+
+template <bool B3>
 __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
   extern __shared__ float4 d03_lds_raw[];
   float* lds = reinterpret_cast<float*>(d03_lds_raw);
+  if constexpr (B3) {
+    char* base = reinterpret_cast<char*>(d03_lds_raw);
+    int o_r = B3_OFF_R / 16;  // opaque: keeps the fp32 images' addresses inside the DS immediates (as below)
+    asm volatile("" : "+v"(o_r));
+    float* X0 = reinterpret_cast<float*>(base + 16 * o_r);
+    float* X3 = X0;
+    const B3Image<64> iX1{reinterpret_cast<bf16_t*>(base + B3_OFF_X1), B3_X1_PS, 1}, iX2{reinterpret_cast<bf16_t*>(base + B3_OFF_X2), B3_X2_PS, 1};
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int row = blockIdx.x;
+    if (row >= a.n_rows) return;
+    for (int i = tid; i < B3_LDS_BYTES / 16; i += D03_NTH) d03_lds_raw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float pre[3];  // the row's input as a whole 16 x 80 image (zero outside the 47 samples: the image is rewritten every row)
+    auto request = [&](int r) {
+      const float* src = a.x + (long)r * a.ws_x + HALO;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int idx = tid + k * D03_NTH, c = idx / S0, t = idx - c * S0 - BI;
+        pre[k] = (idx < 16 * S0 && (unsigned)t < (unsigned)L0) ? src[(long)c * a.ls_x + t] : 0.f;
+      }
+    };
+    auto park = [&]() {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int idx = tid + k * D03_NTH;
+        if (idx < 16 * S0) X0[idx] = pre[k];
+      }
+    };
+    request(row);
+    int d = row / a.B;
+    float areg0[D_0::CB * D_0::TAPS], bias0[4];
+    auto load_stage0 = [&](int dd) {
+      load_areg4<D_0>(a.af[0] + dd * a.af_stride[0], wave_u, lane, areg0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias0[r] = a.bs[0][dd * 64 + (wave_u & 3) * 16 + 4 * g + r];
+    };
+    load_stage0(d);
+    __syncthreads();
+    const int mt23 = wave_u & 3, blk23 = wave_u >> 2;
+    while (true) {
+      const int next = row + gridDim.x;
+      const bool more = next < a.n_rows;
+      const int nd = more ? next / a.B : d;
+      park();
+      __syncthreads();
+      {  // stage 0: 16 x 47 -> 64 x 94, three pieces
+        Stage0Pieces st{{iX1.img, iX1.ps, iX1.c0, L1, B3_X1_NC}};
+        st.zero_rest(1, 1 + 2 * C0, tid, D03_NTH);
+        conv_lds_areg<D_0, S0, BI, S0, BI>(X0, X0, areg0, bias0, wave_u, C0, st, 0, 1, lane);
+      }
+      float areg3[D_3::CB * D_3::TAPS], bias3[4];
+      load_areg4<D_3>(a.af[3] + d * a.af_stride[3], mt23, lane, areg3);
+      load_biasreg<D_3>(a.bs[3] + d * 32, mt23, lane, bias3);
+      __syncthreads();
+      {  // stage 1: 64 x 94 -> 64 x 188 on the bf16 matrix cores
+        const B3Store<64> st{iX2.img, iX2.ps, iX2.c0, L2, B3_X2_NC};
+        conv_b3<D_1, true, 64, 64>(iX1, iX1, a.af3[0] + d * a.af3_stride[0], a.bs[1] + d * 64, C1, st, wave_u, D03_WAVES, lane);
+      }
+      __syncthreads();
+      {  // stage 2: 64 x 188 -> 32 x 375 (fp32 image in the place of the dead stage-0 / stage-1 inputs: its padding
+         // columns are cleared here, every row) + the two samples at the cropped edge from the definition
+        constexpr int W = S3 - L3;  // BI columns on the left, the rest behind sample 374
+        for (int i = tid; i < 32 * W; i += D03_NTH) {
+          const int c = i / W, k = i - c * W;
+          X3[c * S3 + (k < BI ? k : L3 + k)] = 0.f;
+        }
+        const ClipQuad st{X3 + BI, L3 - 2};
+        conv_b3<D_2, true, 64, 64>(iX2, iX2, a.af3[1] + d * a.af3_stride[1], a.bs[2] + d * 32, C2, st, wave_u, D03_WAVES, lane);
+        if (wave_u == D03_WAVES - 1) {
+          constexpr int n0 = (L3 - 2 - 2) >> 1;
+          const float* e = a.edge_w + ((long)d * 64 * 64 + lane) * 3;
+          float acc = a.edge_b[d * 32 + (lane >> 1)];
+#pragma unroll 8
+          for (int ci = 0; ci < 64; ++ci) {
+            const float* ec = e + (long)ci * 64 * 3;
+            const bf16_t* xs = iX2.img + (n0 + iX2.c0) * 72 + ci;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const float x = (from_bf16(xs[k * 72]) + from_bf16(xs[k * 72 + iX2.ps])) + from_bf16(xs[k * 72 + 2 * iX2.ps]);  // exact
+              acc = fmaf(ec[k], x, acc);
+            }
+          }
+          X3[(lane >> 1) * S3 + BI + L3 - 2 + (lane & 1)] = fmaxf(acc, 0.f);
+        }
+      }
+      if (more) {
+        request(next);
+        load_stage0(nd);
+      }
+      __syncthreads();
+      {  // stage 3: 32 x 375 -> 32 x 750, straight to memory
+        RowOut st{a.y + (long)row * a.ws_y + HALO, a.ls_y};
+        conv_lds_areg<D_3, S3, BI, S3, BI>(X3, X3, areg3, bias3, mt23, C3, st, blk23, 2, lane);
+      }
+      if (!more) break;
+      row = next;
+      d = nd;
+      __syncthreads();  // the next row's input and stage-0 output land where stage 3 has just read
+    }
+    return;
+  }
   // image offsets through an opaque register (eqt_tail.hip: keeps the B fragments' addresses inside the DS immediates)
   int off1 = OFF1 / 4, off2 = OFF2 / 4, off3 = OFF3 / 4;
   asm volatile("" : "+v"(off1), "+v"(off2), "+v"(off3));
@@ -202,7 +348,7 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
 }  // namespace
 
 // Replaces the steps "decoder.0", "decoder.1", "decoder.2", "decoder.2.edge", "decoder.3" of the plan by one fused step.
-int plan_eqt_fuse_dec03(Net& net) {
+int plan_eqt_fuse_dec03(Net& net, bool b3) {
   int first = -1;
   for (size_t i = 0; i < net.steps.size(); ++i)
     if (net.steps[i].name == "decoder.0") first = (int)i;
@@ -223,6 +369,11 @@ int plan_eqt_fuse_dec03(Net& net) {
   }
   HostBlob* q[4];
   for (int i = 0; i < 4; ++i) q[i] = c[i]->afrag_q4 ? c[i]->afrag_q4 : net.add_blob(regroup_afrag4(*c[i]));
+  HostBlob* p3[2] = {nullptr, nullptr};
+  if (b3) {  // stage 0 with its rows regrouped (phase, channel), stages 1 and 2 as three-piece operands
+    q[0] = net.add_blob(regroup_afrag4_phase_major(*c[0]));
+    for (int i = 0; i < 2; ++i) p3[i] = net.add_blob(b3_operand(*c[1 + i], true));
+  }
   const int x_in = c[0]->src1, y_out = c[3]->dst;
   for (int i = 0; i < 3; ++i) net.tensor_sets[c[i]->dst] = 0;  // stages 0-2 live in LDS under this plan
   Step st;
@@ -250,10 +401,21 @@ int plan_eqt_fuse_dec03(Net& net) {
     a.B = B;
     a.n_rows = 3 * B;
     const int grid = a.n_rows < 256 ? a.n_rows : 256;
-    hipLaunchKernelGGL(eqt_dec03_kernel, dim3(grid), dim3(D03_NTH), D03_LDS_FLOATS * sizeof(float), s, a);
+    if (b3) {
+      for (int i = 0; i < 2; ++i) {
+        a.af3[i] = reinterpret_cast<const uint4*>(p3[i]->d);
+        a.af3_stride[i] = (long)(p3[i]->h.size() / 3 / 4);
+      }
+      hipLaunchKernelGGL(eqt_dec03_kernel<true>, dim3(grid), dim3(D03_NTH), B3_LDS_BYTES, s, a);
+    } else {
+      hipLaunchKernelGGL(eqt_dec03_kernel<false>, dim3(grid), dim3(D03_NTH), D03_LDS_FLOATS * sizeof(float), s, a);
+    }
     return 0;
   };
-  net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_dec03_kernel), D03_LDS_FLOATS * sizeof(float)});
+  if (b3)
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_dec03_kernel<true>), (size_t)B3_LDS_BYTES});
+  else
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_dec03_kernel<false>), D03_LDS_FLOATS * sizeof(float)});
   net.steps.erase(net.steps.begin() + first, net.steps.begin() + first + 5);
   net.steps.insert(net.steps.begin() + first, std::move(st));
   return VP_OK;

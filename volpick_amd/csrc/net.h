@@ -42,6 +42,9 @@ constexpr int kDenseOut = -2;
 // The A operand of a conv layer regrouped for 16-byte loads (conv_lds_q4): [mt][step][64] -> [mt][step / 4][64][4],
 // step = channel block * taps + tap; needs (channel blocks * taps) % 4 == 0.
 std::vector<float> regroup_afrag4(const ConvLayer& L);
+// three-piece bf16 operands of every weight set of a layer (conv_b3.h) / the fp32 operand with phase-major rows (net.hip)
+std::vector<float> b3_operand(const ConvLayer& L, bool mperm);
+std::vector<float> regroup_afrag4_phase_major(const ConvLayer& L);
 
 struct Net {
   int model_kind = 0;
@@ -112,7 +115,7 @@ int plan_eqt_fuse_res(Net& net);  // swaps the 14 ResCNN conv steps for one fuse
 int plan_eqt_fuse_tail(Net& net);  // swaps decoder.4 / .5 / .6+heads for one time-tiled fused launch (eqt_tail.hip)
 int plan_eqt_fuse_front(Net& net);  // swaps encoder.0 / .1 / .2 for one time-tiled fused launch (eqt_front.hip)
 int plan_eqt_fuse_enc36(Net& net);  // swaps encoder.3 .. .6 for one launch per window (eqt_enc36.hip)
-int plan_eqt_fuse_dec03(Net& net);  // swaps decoder.0 / .1 / .2 / .2.edge / .3 for one launch per (decoder, window) row (eqt_dec03.hip)
+int plan_eqt_fuse_dec03(Net& net, bool b3);  // swaps decoder.0 / .1 / .2 / .2.edge / .3 for one launch per (decoder, window) row (eqt_dec03.hip)
 
 
 // BatchNorm (eval) folded into the preceding conv: scale = gamma / sqrt(var + eps),

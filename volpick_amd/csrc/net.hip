@@ -62,6 +62,69 @@ std::vector<float> regroup_afrag4(const ConvLayer& L) {
   return v;
 }
 
+// fp32 MFMA-order fragments [set][mt][cb][tap][64] (pack_afrag) -> three-piece bf16 operands
+// [set][mt'][tap * KS + step][piece][64][8] (conv_b3.h): an fp32 weight is exactly hi + mid + lo in bfloat16.
+// mperm: GEMM rows regrouped (channel, phase) -> (phase, channel).  Two bf16 per float slot of the blob.
+std::vector<float> b3_operand(const ConvLayer& L, bool mperm) {
+  const int cinp = L.g.cinp(), taps = L.g.taps, M = L.g.M(), P = L.g.P, cout = L.g.cout, CB = cinp / 4, KS = cinp / 32, MT = M / 16;
+  auto rne = [](float x) -> uint16_t {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  };
+  auto widen = [](uint16_t h) -> float {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+  };
+  const size_t set_in = (size_t)M * cinp * taps, set_out = (size_t)MT * taps * KS * 3 * 64 * 8;
+  std::vector<uint16_t> o(set_out * L.n_sets);
+  for (int set = 0; set < L.n_sets; ++set) {
+    const float* af = L.afrag.h.data() + set * set_in;
+    uint16_t* os = o.data() + set * set_out;
+    for (int mt = 0; mt < MT; ++mt)
+      for (int tap = 0; tap < taps; ++tap)
+        for (int ks = 0; ks < KS; ++ks)
+          for (int l = 0; l < 64; ++l)
+            for (int i = 0; i < 8; ++i) {
+              const int mp = mt * 16 + (l & 15);
+              const int m = mperm ? (mp % cout) * P + mp / cout : mp;  // row of the packed fp32 operand
+              const int ci = ks * 32 + 8 * (l >> 4) + i;
+              const float w = af[(((size_t)(m / 16) * CB + ci / 4) * taps + tap) * 64 + (ci % 4) * 16 + (m % 16)];
+              const uint16_t h = rne(w);
+              const float r1 = w - widen(h);
+              const uint16_t md = rne(r1);
+              const uint16_t lo = rne(r1 - widen(md));
+              const size_t base = ((((size_t)mt * taps * KS + tap * KS + ks) * 3) * 64 + l) * 8 + i;
+              os[base] = h;
+              os[base + 64 * 8] = md;
+              os[base + 2 * 64 * 8] = lo;
+            }
+  }
+  std::vector<float> f(o.size() / 2);
+  memcpy(f.data(), o.data(), o.size() * 2);
+  return f;
+}
+
+// the fp32 operand with its GEMM rows regrouped (channel, phase) -> (phase, channel), in the 16-byte-load order of
+// regroup_afrag4: for a P-phase layer whose epilogue wants a lane's four rows to be four consecutive channels
+std::vector<float> regroup_afrag4_phase_major(const ConvLayer& L) {
+  const int cinp = L.g.cinp(), taps = L.g.taps, M = L.g.M(), P = L.g.P, cout = L.g.cout, steps = cinp / 4 * taps, MT = M / 16;
+  const size_t set = (size_t)M * cinp * taps;
+  std::vector<float> v(L.afrag.h.size());
+  for (int s = 0; s < L.n_sets; ++s)
+    for (int mt = 0; mt < MT; ++mt)
+      for (int st = 0; st < steps; ++st)
+        for (int l = 0; l < 64; ++l) {
+          const int mp = mt * 16 + (l & 15), m = (mp % cout) * P + mp / cout;
+          v[s * set + (((size_t)mt * (steps / 4) + st / 4) * 64 + l) * 4 + (st & 3)] =
+              L.afrag.h[s * set + ((size_t)(m / 16) * steps + st) * 64 + (l & 48) + (m % 16)];
+        }
+  return v;
+}
+
 void bn_fold(const ParamView& pv, const std::string& bn, int C, float eps, const float* conv_bias,
              std::vector<float>* scale, std::vector<float>* shift) {
   const float* w = pv.get(bn + ".weight");

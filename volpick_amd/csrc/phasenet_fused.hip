@@ -1411,49 +1411,6 @@ std::vector<float> pack_valu(const float* W, int cin, bool transposed, const std
 }
 }  // namespace
 
-namespace {
-// fp32 MFMA-order fragments [mt][cb][tap][64] (pack_afrag) -> three-piece bf16 operand [mt'][tap * KS + step][piece][64][8]
-// (conv_b3.h); mperm: rows regrouped (channel, phase) -> (phase, channel)
-std::vector<float> b3_operand(const ConvLayer& L, bool mperm) {
-  const int cinp = L.g.cinp(), taps = L.g.taps, M = L.g.M(), P = L.g.P, cout = L.g.cout, CB = cinp / 4, KS = cinp / 32, MT = M / 16;
-  auto rne = [](float x) -> uint16_t {
-    uint32_t u;
-    memcpy(&u, &x, 4);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-  };
-  auto widen = [](uint16_t h) -> float {
-    const uint32_t u = (uint32_t)h << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-  };
-  const std::vector<float>& af = L.afrag.h;
-  std::vector<uint16_t> o((size_t)MT * taps * KS * 3 * 64 * 8);
-  for (int mt = 0; mt < MT; ++mt)
-    for (int tap = 0; tap < taps; ++tap)
-      for (int ks = 0; ks < KS; ++ks)
-        for (int l = 0; l < 64; ++l)
-          for (int i = 0; i < 8; ++i) {
-            const int mp = mt * 16 + (l & 15);
-            const int m = mperm ? (mp % cout) * P + mp / cout : mp;  // row of the packed fp32 operand
-            const int ci = ks * 32 + 8 * (l >> 4) + i;
-            const float w = af[(((size_t)(m / 16) * CB + ci / 4) * taps + tap) * 64 + (ci % 4) * 16 + (m % 16)];
-            const uint16_t h = rne(w);
-            const float r1 = w - widen(h);
-            const uint16_t md = rne(r1);
-            const uint16_t lo = rne(r1 - widen(md));
-            const size_t base = ((((size_t)mt * taps * KS + tap * KS + ks) * 3) * 64 + l) * 8 + i;
-            o[base] = h;
-            o[base + 64 * 8] = md;
-            o[base + 2 * 64 * 8] = lo;
-          }
-  std::vector<float> f(o.size() / 2);
-  memcpy(f.data(), o.data(), o.size() * 2);
-  return f;
-}
-}  // namespace
-
 int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
   const bool debug_dumps = (debug_flags & 1) != 0, debug_clock = (debug_flags & 2) != 0;
   // reserved[2] = 1 selects the hand-pipelined K loop (sched_barrier) for A/B timing; the compiler's own
