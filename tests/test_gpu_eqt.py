@@ -69,16 +69,17 @@ def _oracle_stages(net, x):
 
 # vp_config.reserved[7]: bit 0 = decoder.4 / .5 / .6+heads as three launches, bit 1 = decoder.0 .. .3 as five launches,
 # bit 2 = encoder.0 .. .2 as three launches, bit 3 = encoder.3 .. .6 as four launches; bit 4 = ResCNN on the fp32 MFMA,
-# bit 5 = every stage of the fused decoder.0 .. .3 on the fp32 MFMA (the default runs stages 1 and 2, the ResCNN too, on
-# the bf16 matrix cores with exact three-piece operands: fp32-accurate, different rounding)
+# bit 5 = every stage of the fused decoder.0 .. .3 on the fp32 MFMA, bit 6 = the fused decoder tail on the fp32 MFMA (the
+# default runs decoder stages 1, 2, 4, 5, 6, the heads and the ResCNN on the bf16 matrix cores with exact three-piece
+# operands: fp32-accurate, different rounding)
 UNFUSED = (0, 0, 0, 0, 0, 0, 0, 15)
-FP32_DEC03 = 32
+FP32_MFMA = 32 | 64
 
 
 @pytest.fixture(scope="module")
-def model_fp32_dec03():
+def model_fp32_mfma():
     m = EQTransformer.from_pretrained("volpick")
-    m._plan_flags = (0, 0, 0, 0, 0, 0, 0, FP32_DEC03)
+    m._plan_flags = (0, 0, 0, 0, 0, 0, 0, FP32_MFMA)
     return m.cuda()
 
 
@@ -108,7 +109,7 @@ def test_layers_match_oracle(oracle):
 
 @pytest.mark.parametrize("keep", [1, 2, 4, 8, 15])
 @pytest.mark.parametrize("B", [1, 2, 5, 86, 256, 300])
-def test_fused_decoder_kernels_are_bitwise_the_layer_launches(model_fp32_dec03, B, keep):
+def test_fused_decoder_kernels_are_bitwise_the_layer_launches(model_fp32_mfma, B, keep):
     """eqt_front_kernel (encoder stages 0-2 per 250-sample time tile, halos recomputed, MaxPool in registers / across
     neighbouring lanes), eqt_enc36_kernel (encoder stages 3-6, one window per workgroup), eqt_dec03_kernel (decoder stages 0-3, one row per workgroup, intermediates in LDS, the cropped edge of stage 2
     beside it) and eqt_tail_kernel (stages 4-6 + heads per 2000-sample time tile, halos recomputed, heads as a Toeplitz
@@ -117,9 +118,9 @@ def test_fused_decoder_kernels_are_bitwise_the_layer_launches(model_fp32_dec03, 
     batch sizes that leave the persistent grids partly filled, exactly filled, and wrapped several times.  `keep`
     (vp_config.reserved[7]) un-fuses the tail, the decoder stages 0-3, the encoder front, the encoder stages 3-6, or all of them.
     The fused side is the plan with eqt_dec03_kernel's stages all on the fp32 MFMA (the next test covers the default)."""
-    model = model_fp32_dec03
+    model = model_fp32_mfma
     other = EQTransformer.from_pretrained("volpick")
-    other._plan_flags = (0, 0, 0, 0, 0, 0, 0, keep | FP32_DEC03)
+    other._plan_flags = (0, 0, 0, 0, 0, 0, 0, keep | FP32_MFMA)
     other.cuda()
     x = synthetic_windows(7, 6000, seed=640 + B)[np.arange(B) % 7] * np.linspace(0.5, 2.0, B, dtype=np.float32)[:, None, None]
     xd = torch.from_numpy(x).cuda()
@@ -130,15 +131,15 @@ def test_fused_decoder_kernels_are_bitwise_the_layer_launches(model_fp32_dec03, 
 
 
 @pytest.mark.parametrize("B", [1, 2, 5, 86, 256, 300])
-def test_bf16_piece_decoder_stages_agree_with_the_fp32_mfma_form(model, model_fp32_dec03, B):
+def test_bf16_piece_decoder_stages_agree_with_the_fp32_mfma_form(model, model_fp32_mfma, B):
     """The default eqt_dec03_kernel runs stages 1 and 2 as six bf16 MFMAs per K-step over exact three-piece operands
-    (conv_b3.h): what it drops is below the rounding of one fp32 product, so the two forms differ by fp32 rounding
+    (conv_b3.h), eqt_tail3_kernel its three stages and the heads: what they drop is below the rounding of one fp32 product, so the two forms differ by fp32 rounding
     only -- for every row of batches that leave the persistent grid partly filled, filled, and wrapped (the fp32 image
     of stage 3 is rebuilt in the place of the stage-0 / stage-1 images every row)."""
     x = synthetic_windows(7, 6000, seed=640 + B)[np.arange(B) % 7] * np.linspace(0.5, 2.0, B, dtype=np.float32)[:, None, None]
     xd = torch.from_numpy(x).cuda()
     got = model._forward_raw(xd, preprocess=True)
-    want = model_fp32_dec03._forward_raw(xd, preprocess=True)
+    want = model_fp32_mfma._forward_raw(xd, preprocess=True)
     assert (got - want).abs().max().item() < 2e-6
     assert (got > 0).all() and (got < 1).all()
     again = model._forward_raw(xd, preprocess=True)

@@ -183,4 +183,57 @@ __device__ __forceinline__ void conv_b3(const B3Image<C1> i1, const B3Image<C2> 
   }
 }
 
+// ---- one item per wave, the operand in registers (time-tiled kernels whose weights do not change from tile to tile) --------
+// K-steps of a layer with C input channels: C >= 32: (tap, 32-channel step); C = 16 / 8: all channels of 2 / 4 consecutive
+// taps per step (net.hip: b3_operand pads the filter with zero taps), lane group g = lane / 16 supplies tap `tap_of_lane`,
+// channels `ch_of_lane` .. + 7 of it.
+template <int C, int TAPS>
+struct B3Steps {
+  static constexpr int KS = C >= 32 ? C / 32 : 1, TPK = C >= 32 ? 1 : 32 / C, LPT = C >= 32 ? 4 : C / 8;
+  static constexpr int STEPS = C >= 32 ? TAPS * KS : (TAPS + TPK - 1) / TPK;
+  __device__ static __forceinline__ int tap_of_lane(const int g) { return C >= 32 ? 0 : g / LPT; }
+  __device__ static __forceinline__ int ch_of_lane(const int g) { return C >= 32 ? 8 * g : 8 * (g % LPT); }
+  // element offset of K-step s relative to the lane's pointer
+  static constexpr int step_off(const int s) { return C >= 32 ? (s / KS) * (C + 8) + (s % KS) * 32 : s * TPK * (C + 8); }
+};
+template <int C, int TAPS>
+__device__ __forceinline__ void b3_load_a(const uint4* __restrict__ af3, const int mt, const int lane,
+                                          uint4 (&a)[B3Steps<C, TAPS>::STEPS * 3]) {
+  constexpr int N = B3Steps<C, TAPS>::STEPS * 3;
+  const uint4* p = af3 + (long)mt * (N * 64) + lane;
+#pragma unroll
+  for (int i = 0; i < N; ++i) a[i] = p[i * 64];
+}
+// acc[j] += W x over all K-steps for the n-tiles j = 0 .. NB - 1; p0 / p1 / p2: the lane's pointers into the three piece
+// planes at (column of n-tile 0 + lane % 16 + tap_of_lane, channel ch_of_lane)
+template <int C, int TAPS, int NB>
+__device__ __forceinline__ void b3_mac_areg(const bf16_t* p0, const bf16_t* p1, const bf16_t* p2,
+                                            const uint4 (&a)[B3Steps<C, TAPS>::STEPS * 3], f32x4 (&acc)[NB]) {
+  using G = B3Steps<C, TAPS>;
+  constexpr int STEPS = G::STEPS;
+  uint4 b[2][3];
+  auto load_b = [&](uint4 (&bv)[3], const int s, const int j) {
+    const int off = G::step_off(s) + j * 16 * (C + 8);
+    bv[0] = *reinterpret_cast<const uint4*>(p0 + off);
+    bv[1] = *reinterpret_cast<const uint4*>(p1 + off);
+    bv[2] = *reinterpret_cast<const uint4*>(p2 + off);
+  };
+  load_b(b[0], 0, 0);
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int i = s * NB + j;
+      if (i + 1 < STEPS * NB) load_b(b[(i + 1) & 1], (i + 1) / NB, (i + 1) % NB);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int WP[6] = {2, 1, 0, 1, 0, 0}, XP[6] = {0, 1, 2, 0, 1, 0};  // (w piece, x piece), smallest products first
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, a[s * 3 + WP[t]]),
+                                                        __builtin_bit_cast(bf16x8_b3, b[i & 1][XP[t]]), acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 }  // namespace vp

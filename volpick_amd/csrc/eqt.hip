@@ -495,7 +495,7 @@ int plan_eqt(Net& net, const ParamView& pv) {
   }
   // reserved[7] bit 0 keeps decoder.4 / .5 / .6+heads as three launches (layer tests, A/B timing)
   if (!(net.cfg.reserved[7] & 1) && !alt) {
-    int rc = plan_eqt_fuse_tail(net);
+    int rc = (net.cfg.reserved[7] & 64) ? plan_eqt_fuse_tail(net) : plan_eqt_fuse_tail_b3(net);  // bit 6: the fp32-MFMA kernel
     if (rc != VP_OK) return rc;
   }
   // bit 2 keeps encoder.0 .. .2 as three launches

@@ -1,0 +1,350 @@
+// EQTransformer decoder tail (stages 4, 5, 6 + the sigmoid heads) on the bf16 matrix cores with exact three-piece
+// operands (conv_b3.h): same time tiling as eqt_tail.hip -- a tile's rows never leave the CU, the halo every stage needs
+// is recomputed -- but every product is six v_mfma_f32_16x16x32_bf16 over (hi, mid, lo) pieces instead of eight fp32
+// MFMAs: 6 / 16 of the matrix time at fp32 accuracy (what is dropped is below the rounding of one fp32 product).
+//
+//   tile of outputs [t0, t0 + 1200) of the 6000-sample row, t0 = 1200 j (five tiles per row: 15 tiles per CU at 256 windows):
+//     stage 6 columns n6 = t0/2 - 3 + [0, 606 / 640)  reads stage-5 samples [n6 - 3, n6 + 3]  (K = 11 folded to 7 taps)
+//     stage 5 columns n5 = t0/4 - 3 + [0, 306 / 320)  reads stage-4 samples [n5 - 2, n5 + 2]  (K = 9 folded to 5 taps)
+//     stage 4 columns n4 = t0/8 - 3 + [0, 156 / 192)  reads stage-3 samples [n4 - 2, n4 + 2]  (K = 7 folded to 5 taps)
+//   (needed / computed: every wave takes one block of 3 / 5 / 5 n-tiles of one m-tile per stage)
+//
+// LDS (154 KB).  Three-piece images [piece][column][C + 8 channels] take 1.5 x the bytes of fp32 rows (and the padding that
+// keeps the 16-byte fragment reads off each other's banks is 8 channels of 16 or 32), so a 2000-sample tile no longer
+// fits: 1200-sample tiles, and two regions used twice per tile --
+//     R0 (93 KB): the stage-3 image (32 ch x 196 columns), then the stage-5 output = stage-6 input (16 ch x 648 columns)
+//     R1 (62 KB): the stage-4 output = stage-5 input (16 ch x 328 columns), then the stage-6 output staged for the heads
+// Nothing is zero-filled per tile: everything LDS ever holds is a bfloat16 piece of a finite number (or the zeros of the
+// one fill at kernel start), a column a stage reads beyond what its producer wrote meets a zero weight (the padded taps)
+// or feeds an output nobody keeps, and samples outside a row's signal are WRITTEN as zeros by the producing stage.
+//
+// Weights.  16-channel layers pack two taps into the K = 32 of one instruction (conv_b3.h: B3Steps); the operands of
+// the three stages are 15 + 9 + 12 16-byte registers per lane and stay resident over all tiles of a workgroup (reloaded
+// when the decoder changes: twice per workgroup at most).  The heads (8 -> 1, k = 11) are the Toeplitz product of
+// eqt_tail.hip with K ordered (tap, channel): a B fragment = the 8 channels of one staged sample (one 16-byte read, staging
+// [sample % 16][sample / 16] so that 16 lanes read 256 consecutive bytes), an A fragment = w[.][tap - m] or zero: a 43-entry
+// table per piece in LDS, read with a per-lane offset.
+//
+// Plan flag reserved[7] & 64 keeps the fp32-MFMA kernel of eqt_tail.hip (bit-identical to the layer launches); this one
+// agrees with it to fp32 rounding (tests/test_gpu_eqt.py).
+#include "conv_b3.h"
+#include "eqt_kernels.h"
+#include "net.h"
+
+namespace vp {
+
+namespace {
+
+constexpr int TW = 1200, TILES_PER_ROW = 5, T_OUT = 6000;
+constexpr int T3_NTH = 512, T3_WAVES = 8;
+constexpr int NB4 = 3, NB5 = 5, NB6 = 5;                                         // n-tiles per wave and stage
+constexpr int C4 = 4 * NB4 * 16, C5 = 4 * NB5 * 16, C6 = T3_WAVES * NB6 * 16;    // columns computed: 192, 320, 640
+constexpr int PARK_COLS = 160;                                                   // stage-3 samples a tile needs
+constexpr int NC4 = C4 + 4, NC5 = C5 + 8, NC6 = C6 + 8;                          // image columns (every one a stage may read)
+constexpr int CS4 = 32 + 8, CS5 = 16 + 8, CS6 = 16 + 8;                          // bf16 per column
+constexpr int PS4 = NC4 * CS4, PS5 = NC5 * CS5, PS6 = NC6 * CS6;                 // bf16 per piece
+constexpr int HSB = 81, OUT_PS = 16 * HSB;                                       // heads' staging: 16-byte chunks per row / piece
+constexpr int HT_N = 43;                                                         // head table entries: k = -15 .. 27
+constexpr int R0_BYTES = 3 * PS6 * 2, R1_BYTES = 3 * OUT_PS * 16;
+constexpr int OFF_R1 = R0_BYTES, OFF_HT = OFF_R1 + R1_BYTES, T3_LDS_BYTES = OFF_HT + 3 * HT_N * 16;
+static_assert(3 * PS4 * 2 <= R0_BYTES && 3 * PS5 * 2 <= R1_BYTES && T3_LDS_BYTES <= 160 * 1024 && OFF_R1 % 16 == 0 && OFF_HT % 16 == 0,
+              "LDS budget");
+static_assert(TILES_PER_ROW * TW == T_OUT && TW % 16 == 0 && TW % 8 == 0, "tile grid");
+// what a tile needs (file comment) is computed, and what is computed has a place
+static_assert(TW + 11 <= 2 * C6 && C6 / 8 <= HSB - 1 && (TW / 16 + 15) / 16 <= T3_WAVES, "stage 6 / heads");
+static_assert(TW / 2 + 6 + 6 <= 2 * C5 && TW / 4 + 6 + 5 <= 2 * C4 && TW / 8 + 6 + 4 <= PARK_COLS && PARK_COLS <= NC4, "halo chain");
+static_assert(PARK_COLS * 8 <= 3 * T3_NTH, "three (four channels x one sample) items per thread");
+
+struct Tail3Args {
+  const float* x3;  // stage-3 rows [3 B][32][ls]
+  int ls3;
+  long ws3;
+  float* y;         // dense (B, 3, 6000)
+  const uint4 *af4, *af5, *af6;  // three-piece operands [set][MT][STEPS][piece][64] (net.hip: b3_operand, rows (phase, channel))
+  long af4_stride, af5_stride, af6_stride;  // uint4 per set
+  const float *bs4, *bs5, *bs6;  // bias [set][COUT]
+  const uint4* head_t;           // [3][piece][HT_N]: the 8 channels' w[.][k] as bf16 pieces, k = entry - 15 (zero outside 0 .. 10)
+  const float* head_b;           // [3]
+  int B, n_tiles;
+};
+
+struct Tile3 {
+  int d, win, t0;
+};
+__device__ __forceinline__ Tile3 tile3_id(const int tile, const int B) {
+  const int row = tile / TILES_PER_ROW, j = tile - row * TILES_PER_ROW;  // row = d * B + b
+  return Tile3{row / B, row, j * TW};
+}
+
+// relu(acc + bias) of the lane's four rows; zero outside the row's signal
+__device__ __forceinline__ void t3_finish(const f32x4 acc, const float (&bias)[4], const bool in, float (&v)[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = in ? fmaxf(acc[r] + bias[r], 0.f) : 0.f;
+}
+
+__global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
+  extern __shared__ uint4 t3_lds[];
+  char* base = reinterpret_cast<char*>(t3_lds);
+  bf16_t* IN4 = reinterpret_cast<bf16_t*>(base);            // R0
+  bf16_t* IN6 = IN4;
+  bf16_t* IN5 = reinterpret_cast<bf16_t*>(base + OFF_R1);   // R1
+  uint4* OUT6 = reinterpret_cast<uint4*>(base + OFF_R1);
+  uint4* HT = reinterpret_cast<uint4*>(base + OFF_HT);
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile = blockIdx.x;
+  if (tile >= a.n_tiles) return;
+  for (int i = tid; i < T3_LDS_BYTES / 16; i += T3_NTH) t3_lds[i] = make_uint4(0u, 0u, 0u, 0u);
+  Tile3 id = tile3_id(tile, a.B);
+
+  // stage-3 samples of a tile: image column x <-> sample t0/8 - 5 + x of the row; an item = four channels of one sample
+  float pre[3][4];
+  auto request = [&](const Tile3& t) {
+    const float* src = a.x3 + (long)t.win * a.ws3 + (HALO - 5 + t.t0 / 8);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int item = tid + k * T3_NTH, cq = item / PARK_COLS, x = item - cq * PARK_COLS;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pre[k][r] = item < 8 * PARK_COLS ? src[(long)(4 * cq + r) * a.ls3 + x] : 0.f;
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int item = tid + k * T3_NTH, cq = item / PARK_COLS, x = item - cq * PARK_COLS;
+      if (item < 8 * PARK_COLS) b3_store4(IN4, PS4, CS4, x, 4 * cq, pre[k]);
+    }
+  };
+  request(id);
+
+  uint4 a4[B3Steps<32, 5>::STEPS * 3], a5[B3Steps<16, 5>::STEPS * 3], a6[B3Steps<16, 7>::STEPS * 3];
+  float bias4[4], bias5[4], bias6[4], bh;
+  auto load_weights = [&](const int d) {
+    b3_load_a<32, 5>(a.af4 + d * a.af4_stride, w & 1, lane, a4);
+    b3_load_a<16, 5>(a.af5 + d * a.af5_stride, w & 1, lane, a5);
+    b3_load_a<16, 7>(a.af6 + d * a.af6_stride, 0, lane, a6);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      bias4[r] = a.bs4[d * 16 + 4 * g + r];
+      bias5[r] = a.bs5[d * 16 + 4 * g + r];
+      bias6[r] = a.bs6[d * 8 + 4 * (g & 1) + r];
+    }
+    bh = a.head_b[d];
+    if (tid < 3 * HT_N) HT[tid] = a.head_t[d * 3 * HT_N + tid];
+  };
+  __syncthreads();  // the zero fill is through before the table lands
+  load_weights(id.d);
+
+  while (true) {
+    const int next = tile + gridDim.x;
+    const bool more = next < a.n_tiles;
+    const Tile3 nid = more ? tile3_id(next, a.B) : id;
+    const int t0 = id.t0;
+    park();
+    __syncthreads();
+    {  // stage 4: column c, phase p -> stage-4 sample t0/4 - 6 + t, t = 2 c + p: column t of the stage-5 input image
+      const int ph = w & 1, colb = (w >> 1) * (NB4 * 16);
+      const bf16_t* p = IN4 + (colb + n) * CS4 + 8 * g;
+      f32x4 acc[NB4];
+#pragma unroll
+      for (int j = 0; j < NB4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      b3_mac_areg<32, 5, NB4>(p, p + PS4, p + 2 * PS4, a4, acc);
+      const int lo = 6 - t0 / 4;
+#pragma unroll
+      for (int j = 0; j < NB4; ++j) {
+        const int t = 2 * (colb + j * 16 + n) + ph;
+        float v[4];
+        t3_finish(acc[j], bias4, (unsigned)(t - lo) < 1500u, v);
+        if (t < NC5) b3_store4(IN5, PS5, CS5, t, 4 * g, v);
+      }
+    }
+    __syncthreads();
+    {  // stage 5: column c reads the image columns c + 1 + tap; output t = 2 c + p -> column t of the stage-6 input image
+      const int ph = w & 1, colb = (w >> 1) * (NB5 * 16);
+      const bf16_t* p = IN5 + (colb + n + 1 + (g >> 1)) * CS5 + 8 * (g & 1);
+      f32x4 acc[NB5];
+#pragma unroll
+      for (int j = 0; j < NB5; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      b3_mac_areg<16, 5, NB5>(p, p + PS5, p + 2 * PS5, a5, acc);
+      const int lo = 6 - t0 / 2;
+#pragma unroll
+      for (int j = 0; j < NB5; ++j) {
+        const int t = 2 * (colb + j * 16 + n) + ph;
+        float v[4];
+        t3_finish(acc[j], bias5, (unsigned)(t - lo) < 3000u, v);
+        if (t < NC6) b3_store4(IN6, PS6, CS6, t, 4 * g, v);
+      }
+    }
+    __syncthreads();
+    if (more) request(nid);  // travels under stage 6 and the heads
+    {  // stage 6: column c reads the image columns c + tap; one m-tile: lane group g holds phase g / 2, channels 4 (g % 2) ..;
+       // output t = 2 c + p = sample t0 - 6 + t of the row -> 16-byte chunk (t % 16) * HSB + t / 16 of the staging
+      const int colb = w * (NB6 * 16), ph = g >> 1;
+      const bf16_t* p = IN6 + (colb + n + (g >> 1)) * CS6 + 8 * (g & 1);
+      f32x4 acc[NB6];
+#pragma unroll
+      for (int j = 0; j < NB6; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      b3_mac_areg<16, 7, NB6>(p, p + PS6, p + 2 * PS6, a6, acc);
+      const int lo = 6 - t0;
+      // t = 2 colb + 32 j + (2 n + p): t % 16 is the lane's, t / 16 = colb / 8 + 2 j + n / 8
+      char* q = reinterpret_cast<char*>(OUT6 + ((2 * n + ph) & 15) * HSB + (n >> 3) + colb / 8) + 8 * (g & 1);
+#pragma unroll
+      for (int j = 0; j < NB6; ++j) {
+        const int t = 2 * (colb + j * 16 + n) + ph;
+        float v[4];
+        t3_finish(acc[j], bias6, (unsigned)(t - lo) < (unsigned)T_OUT, v);
+        unsigned short h[4], m[4], l[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b3_split(v[r], h[r], m[r], l[r]);
+        char* qj = q + 2 * j * 16;
+        *reinterpret_cast<uint2*>(qj) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+        *reinterpret_cast<uint2*>(qj + OUT_PS * 16) = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
+        *reinterpret_cast<uint2*>(qj + 2 * OUT_PS * 16) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+      }
+    }
+    __syncthreads();
+    if (w < (TW / 16 + 15) / 16) {
+      // heads: wave w owns the 16-sample blocks 16 w .. 16 w + 15 of the tile: y[t0 + 16 blk + m] = b + sum_tap sum_ci
+      // w[ci][tap - m] x_ci[staged 16 blk + tap + 1]; K-step s = taps 4 s .. 4 s + 3, lane group g the tap 4 s + g
+      f32x4 acc = {bh, bh, bh, bh};
+      const uint4* bp = OUT6 + (16 * w + n);
+      const uint4* ap = HT + (g - n + 15);
+      uint4 av[2][3], bv[2][3];
+      auto load_ab = [&](const int s, uint4 (&aa)[3], uint4 (&bb)[3]) {
+        const int e = 4 * s + g + 1, chunk = (e & 15) * HSB + (e >> 4);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          aa[pc] = ap[pc * HT_N + 4 * s];
+          bb[pc] = bp[pc * OUT_PS + chunk];
+        }
+      };
+      load_ab(0, av[0], bv[0]);
+#pragma unroll
+      for (int s = 0; s < 7; ++s) {
+        if (s + 1 < 7) load_ab(s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int WP[6] = {2, 1, 0, 1, 0, 0}, XP[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, av[s & 1][WP[t]]),
+                                                       __builtin_bit_cast(bf16x8_b3, bv[s & 1][XP[t]]), acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int blk = 16 * w + n;
+      if (blk < TW / 16) {
+        const int b = id.win - id.d * a.B;
+        float4 r;
+        r.x = 1.f / (1.f + expf(-acc[0]));
+        r.y = 1.f / (1.f + expf(-acc[1]));
+        r.z = 1.f / (1.f + expf(-acc[2]));
+        r.w = 1.f / (1.f + expf(-acc[3]));
+        *reinterpret_cast<float4*>(a.y + ((long)b * 3 + id.d) * T_OUT + t0 + 16 * blk + 4 * g) = r;
+      }
+    }
+    if (!more) break;
+    if (nid.d != id.d) {  // uniform over the workgroup
+      __syncthreads();    // every wave is through with the head table
+      load_weights(nid.d);
+    }
+    tile = next;
+    id = nid;
+    // no barrier here: the next tile's stage-3 image lands in R0, which nobody has read since the barrier behind stage 6
+  }
+}
+
+}  // namespace
+
+// Replaces the steps "decoder.4", "decoder.5", "decoder.6+heads" of the plan by one fused step (bf16-piece form).
+int plan_eqt_fuse_tail_b3(Net& net) {
+  int first = -1;
+  for (size_t i = 0; i < net.steps.size(); ++i)
+    if (net.steps[i].name == "decoder.4") first = (int)i;
+  if (first < 0 || first + 3 != (int)net.steps.size() || net.steps[first + 2].name != "decoder.6+heads") {
+    set_error("fused decoder tail: layer plan not found");
+    return VP_ERR_INVALID;
+  }
+  ConvLayer *c4 = nullptr, *c5 = nullptr, *c6 = nullptr;
+  for (auto& c : net.convs) {
+    if (c->name == "decoder.4") c4 = c.get();
+    if (c->name == "decoder.5") c5 = c.get();
+    if (c->name == "decoder.6") c6 = c.get();
+  }
+  if (!c4 || !c5 || !c6 || c4->n_sets != 3 || c4->g.cinp() != 32 || c5->g.cinp() != 16 || c6->g.cinp() != 16 || c4->g.taps != 5 ||
+      c5->g.taps != 5 || c6->g.taps != 7 || c6->g.M() != 16) {
+    set_error("fused decoder tail: conv layers missing");
+    return VP_ERR_INVALID;
+  }
+  const int x3 = c4->src1;
+  net.need(x3, HALO - 5 + (TILES_PER_ROW - 1) * TW / 8 + PARK_COLS);  // the last tile reads past the row: zero margin
+  net.tensor_sets[c4->dst] = 0;  // stages 4 and 5 are never materialised by this plan
+  net.tensor_sets[c5->dst] = 0;
+  HostBlob* p4 = net.add_blob(b3_operand(*c4, true));
+  HostBlob* p5 = net.add_blob(b3_operand(*c5, true));
+  HostBlob* p6 = net.add_blob(b3_operand(*c6, true));
+  // head table: [decoder][piece][entry e][8 channels] bf16, entry e <-> k = e - 15: w[ci][k] for 0 <= k <= 10, else zero
+  std::vector<uint16_t> ht((size_t)3 * 3 * HT_N * 8, 0);
+  auto rne = [](float x) -> uint16_t {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  };
+  auto widen = [](uint16_t h) -> float {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+  };
+  for (int d = 0; d < 3; ++d)
+    for (int k = 0; k <= 10; ++k)
+      for (int ci = 0; ci < 8; ++ci) {
+        const float wv = c6->e0.h[(size_t)d * 88 + ci * 11 + k];
+        const uint16_t h = rne(wv);
+        const float r1 = wv - widen(h);
+        const uint16_t md = rne(r1);
+        const uint16_t lo = rne(r1 - widen(md));
+        const size_t e = ((size_t)d * 3 * HT_N + (k + 15)) * 8 + ci;
+        ht[e] = h;
+        ht[e + (size_t)HT_N * 8] = md;
+        ht[e + (size_t)2 * HT_N * 8] = lo;
+      }
+  std::vector<float> htf(ht.size() / 2);
+  memcpy(htf.data(), ht.data(), ht.size() * 2);
+  HostBlob* head_t = net.add_blob(std::move(htf));
+  Step st;
+  st.name = "fused.tail (decoder.4-6 + heads, time-tiled)";
+  st.flops_per_window = 0;
+  for (int i = 0; i < 3; ++i) st.flops_per_window += net.steps[first + i].flops_per_window;
+  {  // matrix work issued per tile, as fp32-equivalent FLOP: one group of six bf16 MFMAs = one 16 x 16 x 32 fp32-accurate product
+    const double groups = 8.0 * NB4 * 5 + 8.0 * NB5 * 3 + 8.0 * NB6 * 4 + 5.0 * 7;
+    st.issued_flops_per_window = 3.0 * TILES_PER_ROW * groups * 16384.0;
+  }
+  st.run = [=](Net& n, int B, hipStream_t s) -> int {
+    Tail3Args a{};
+    const Tensor& t3 = n.tensors[x3];
+    a.x3 = t3.p;
+    a.ls3 = t3.ls;
+    a.ws3 = (long)t3.win_stride();
+    a.y = n.y;
+    a.af4 = reinterpret_cast<const uint4*>(p4->d);
+    a.af5 = reinterpret_cast<const uint4*>(p5->d);
+    a.af6 = reinterpret_cast<const uint4*>(p6->d);
+    a.af4_stride = (long)(p4->h.size() / 3 / 4);
+    a.af5_stride = (long)(p5->h.size() / 3 / 4);
+    a.af6_stride = (long)(p6->h.size() / 3 / 4);
+    a.bs4 = c4->bias.d, a.bs5 = c5->bias.d, a.bs6 = c6->bias.d;
+    a.head_t = reinterpret_cast<const uint4*>(head_t->d);
+    a.head_b = c6->e1.d;
+    a.B = B;
+    a.n_tiles = 3 * B * TILES_PER_ROW;
+    const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
+    hipLaunchKernelGGL(eqt_tail3_kernel, dim3(grid), dim3(T3_NTH), T3_LDS_BYTES, s, a);
+    return 0;
+  };
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_tail3_kernel), (size_t)T3_LDS_BYTES});
+  net.steps.erase(net.steps.begin() + first, net.steps.begin() + first + 3);
+  net.steps.push_back(std::move(st));
+  return VP_OK;
+}
+
+}  // namespace vp

@@ -66,7 +66,11 @@ std::vector<float> regroup_afrag4(const ConvLayer& L) {
 // [set][mt'][tap * KS + step][piece][64][8] (conv_b3.h): an fp32 weight is exactly hi + mid + lo in bfloat16.
 // mperm: GEMM rows regrouped (channel, phase) -> (phase, channel).  Two bf16 per float slot of the blob.
 std::vector<float> b3_operand(const ConvLayer& L, bool mperm) {
-  const int cinp = L.g.cinp(), taps = L.g.taps, M = L.g.M(), P = L.g.P, cout = L.g.cout, CB = cinp / 4, KS = cinp / 32, MT = M / 16;
+  const int cinp = L.g.cinp(), taps = L.g.taps, M = L.g.M(), P = L.g.P, cout = L.g.cout, CB = cinp / 4, MT = M / 16;
+  // K of one instruction = 32: cinp >= 32: 32 channels of one tap, steps (tap, channel step); cinp = 16 / 8: all channels of
+  // 2 / 4 consecutive taps (taps beyond the filter carry zero weights), a lane's eight values = eight channels of one tap
+  const int KS = cinp >= 32 ? cinp / 32 : 1, TPK = cinp >= 32 ? 1 : 32 / cinp, LPT = cinp >= 32 ? 4 : cinp / 8;  // lanes groups per tap
+  const int steps = cinp >= 32 ? taps * KS : (taps + TPK - 1) / TPK;
   auto rne = [](float x) -> uint16_t {
     uint32_t u;
     memcpy(&u, &x, 4);
@@ -79,29 +83,29 @@ std::vector<float> b3_operand(const ConvLayer& L, bool mperm) {
     memcpy(&f, &u, 4);
     return f;
   };
-  const size_t set_in = (size_t)M * cinp * taps, set_out = (size_t)MT * taps * KS * 3 * 64 * 8;
+  const size_t set_in = (size_t)M * cinp * taps, set_out = (size_t)MT * steps * 3 * 64 * 8;
   std::vector<uint16_t> o(set_out * L.n_sets);
   for (int set = 0; set < L.n_sets; ++set) {
     const float* af = L.afrag.h.data() + set * set_in;
     uint16_t* os = o.data() + set * set_out;
     for (int mt = 0; mt < MT; ++mt)
-      for (int tap = 0; tap < taps; ++tap)
-        for (int ks = 0; ks < KS; ++ks)
-          for (int l = 0; l < 64; ++l)
-            for (int i = 0; i < 8; ++i) {
-              const int mp = mt * 16 + (l & 15);
-              const int m = mperm ? (mp % cout) * P + mp / cout : mp;  // row of the packed fp32 operand
-              const int ci = ks * 32 + 8 * (l >> 4) + i;
-              const float w = af[(((size_t)(m / 16) * CB + ci / 4) * taps + tap) * 64 + (ci % 4) * 16 + (m % 16)];
-              const uint16_t h = rne(w);
-              const float r1 = w - widen(h);
-              const uint16_t md = rne(r1);
-              const uint16_t lo = rne(r1 - widen(md));
-              const size_t base = ((((size_t)mt * taps * KS + tap * KS + ks) * 3) * 64 + l) * 8 + i;
-              os[base] = h;
-              os[base + 64 * 8] = md;
-              os[base + 2 * 64 * 8] = lo;
-            }
+      for (int st = 0; st < steps; ++st)
+        for (int l = 0; l < 64; ++l)
+          for (int i = 0; i < 8; ++i) {
+            const int mp = mt * 16 + (l & 15), g = l >> 4;
+            const int m = mperm ? (mp % cout) * P + mp / cout : mp;  // row of the packed fp32 operand
+            const int tap = cinp >= 32 ? st / KS : st * TPK + g / LPT;
+            const int ci = cinp >= 32 ? (st % KS) * 32 + 8 * g + i : 8 * (g % LPT) + i;
+            const float w = tap < taps ? af[(((size_t)(m / 16) * CB + ci / 4) * taps + tap) * 64 + (ci % 4) * 16 + (m % 16)] : 0.f;
+            const uint16_t h = rne(w);
+            const float r1 = w - widen(h);
+            const uint16_t md = rne(r1);
+            const uint16_t lo = rne(r1 - widen(md));
+            const size_t base = ((((size_t)mt * steps + st) * 3) * 64 + l) * 8 + i;
+            os[base] = h;
+            os[base + 64 * 8] = md;
+            os[base + 2 * 64 * 8] = lo;
+          }
   }
   std::vector<float> f(o.size() / 2);
   memcpy(f.data(), o.data(), o.size() * 2);
