@@ -40,15 +40,20 @@ constexpr int T3_NTH = 512, T3_WAVES = 8;
 constexpr int NB4 = 3, NB5 = 5, NB6 = 5;                                         // n-tiles per wave and stage
 constexpr int C4 = 4 * NB4 * 16, C5 = 4 * NB5 * 16, C6 = T3_WAVES * NB6 * 16;    // columns computed: 192, 320, 640
 constexpr int PARK_COLS = 160;                                                   // stage-3 samples a tile needs
-constexpr int NC4 = C4 + 4, NC5 = C5 + 8, NC6 = C6 + 8;                          // image columns (every one a stage may read)
-constexpr int CS4 = 32 + 8, CS5 = 16 + 8, CS6 = 16 + 8;                          // bf16 per column
-constexpr int PS4 = NC4 * CS4, PS5 = NC5 * CS5, PS6 = NC6 * CS6;                 // bf16 per piece
-constexpr int HSB = 81, OUT_PS = 16 * HSB;                                       // heads' staging: 16-byte chunks per row / piece
+constexpr int NC4 = 200, NC5 = C5 + 8, NC6 = C6 + 8;                            // image columns (every one a stage may read), 8 mod 16
+using Q4 = B3Quad<32, NC4>;                                                      // quad-plane images (conv_b3.h)
+using Q5 = B3Quad<16, NC5>;
+using Q6 = B3Quad<16, NC6>;
+constexpr int HSB = 81, OUT_QS = 16 * HSB, OUT_PS = 2 * OUT_QS;                  // heads' staging: 8-byte units per row / quad plane / piece
 constexpr int HT_N = 43;                                                         // head table entries: k = -15 .. 27
-constexpr int R0_BYTES = 3 * PS6 * 2, R1_BYTES = 3 * OUT_PS * 16;
-constexpr int OFF_R1 = R0_BYTES, OFF_HT = OFF_R1 + R1_BYTES, T3_LDS_BYTES = OFF_HT + 3 * HT_N * 16;
-static_assert(3 * PS4 * 2 <= R0_BYTES && 3 * PS5 * 2 <= R1_BYTES && T3_LDS_BYTES <= 160 * 1024 && OFF_R1 % 16 == 0 && OFF_HT % 16 == 0,
+constexpr int R0_BYTES = 3 * Q6::PS * 2, R1_BYTES = 3 * OUT_PS * 8;
+constexpr int A5_N = 2 * B3Steps<16, 5>::STEPS * 3 * 64, A6_N = B3Steps<16, 7>::STEPS * 3 * 64;  // uint4: operands of stages 5 and 6
+constexpr int OFF_R1 = R0_BYTES, OFF_HT = OFF_R1 + R1_BYTES, OFF_A5 = OFF_HT + 3 * HT_N * 16 + 48, OFF_A6 = OFF_A5 + A5_N * 16;
+constexpr int T3_LDS_BYTES = OFF_A6 + A6_N * 16;
+static_assert(OFF_A5 % 16 == 0, "16-byte fragments");
+static_assert(3 * Q4::PS * 2 <= R0_BYTES && 3 * Q5::PS * 2 <= R1_BYTES && T3_LDS_BYTES <= 160 * 1024 && OFF_R1 % 16 == 0 && OFF_HT % 16 == 0,
               "LDS budget");
+static_assert(NC4 >= C4 + 4 && NC5 >= C5 + 6 && NC6 >= C6 + 8 && HSB % 2 == 1, "every column a stage reads has a place");
 static_assert(TILES_PER_ROW * TW == T_OUT && TW % 16 == 0 && TW % 8 == 0, "tile grid");
 // what a tile needs (file comment) is computed, and what is computed has a place
 static_assert(TW + 11 <= 2 * C6 && C6 / 8 <= HSB - 1 && (TW / 16 + 15) / 16 <= T3_WAVES, "stage 6 / heads");
@@ -66,6 +71,7 @@ struct Tail3Args {
   const uint4* head_t;           // [3][piece][HT_N]: the 8 channels' w[.][k] as bf16 pieces, k = entry - 15 (zero outside 0 .. 10)
   const float* head_b;           // [3]
   int B, n_tiles;
+  unsigned long long* clk;  // debug (plan flag reserved[1] & 2): the stamps of eqt_tail.hip's TailArgs::clk, same slots
 };
 
 struct Tile3 {
@@ -88,14 +94,21 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
   bf16_t* IN4 = reinterpret_cast<bf16_t*>(base);            // R0
   bf16_t* IN6 = IN4;
   bf16_t* IN5 = reinterpret_cast<bf16_t*>(base + OFF_R1);   // R1
-  uint4* OUT6 = reinterpret_cast<uint4*>(base + OFF_R1);
+  uint2* OUT6 = reinterpret_cast<uint2*>(base + OFF_R1);
   uint4* HT = reinterpret_cast<uint4*>(base + OFF_HT);
+  uint4* A5 = reinterpret_cast<uint4*>(base + OFF_A5);
+  uint4* A6 = reinterpret_cast<uint4*>(base + OFF_A6);
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tile = blockIdx.x;
   if (tile >= a.n_tiles) return;
   for (int i = tid; i < T3_LDS_BYTES / 16; i += T3_NTH) t3_lds[i] = make_uint4(0u, 0u, 0u, 0u);
   Tile3 id = tile3_id(tile, a.B);
+  unsigned long long* clk = (a.clk && tid == 0 && (int)blockIdx.x < a.B) ? a.clk + (long)blockIdx.x * 32 : nullptr;
+  int n_done = 0;
+#define T3_STAMP(k) \
+  if (clk && n_done < 4) clk[n_done * 6 + (k)] = __builtin_readcyclecounter();
+  if (clk) clk[30] = __builtin_amdgcn_s_memrealtime();
 
   // stage-3 samples of a tile: image column x <-> sample t0/8 - 5 + x of the row; an item = four channels of one sample
   float pre[3][4];
@@ -112,17 +125,17 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int item = tid + k * T3_NTH, cq = item / PARK_COLS, x = item - cq * PARK_COLS;
-      if (item < 8 * PARK_COLS) b3_store4(IN4, PS4, CS4, x, 4 * cq, pre[k]);
+      if (item < 8 * PARK_COLS) b3q_store4<32, NC4>(IN4, x, cq, pre[k]);
     }
   };
   request(id);
 
-  uint4 a4[B3Steps<32, 5>::STEPS * 3], a5[B3Steps<16, 5>::STEPS * 3], a6[B3Steps<16, 7>::STEPS * 3];
+  uint4 a4[B3Steps<32, 5>::STEPS * 3];
   float bias4[4], bias5[4], bias6[4], bh;
   auto load_weights = [&](const int d) {
     b3_load_a<32, 5>(a.af4 + d * a.af4_stride, w & 1, lane, a4);
-    b3_load_a<16, 5>(a.af5 + d * a.af5_stride, w & 1, lane, a5);
-    b3_load_a<16, 7>(a.af6 + d * a.af6_stride, 0, lane, a6);
+    for (int i = tid; i < A5_N; i += T3_NTH) A5[i] = a.af5[d * a.af5_stride + i];
+    for (int i = tid; i < A6_N; i += T3_NTH) A6[i] = a.af6[d * a.af6_stride + i];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       bias4[r] = a.bs4[d * 16 + 4 * g + r];
@@ -140,74 +153,76 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
     const bool more = next < a.n_tiles;
     const Tile3 nid = more ? tile3_id(next, a.B) : id;
     const int t0 = id.t0;
+    T3_STAMP(0)
     park();
     __syncthreads();
+    T3_STAMP(1)
     {  // stage 4: column c, phase p -> stage-4 sample t0/4 - 6 + t, t = 2 c + p: column t of the stage-5 input image
       const int ph = w & 1, colb = (w >> 1) * (NB4 * 16);
-      const bf16_t* p = IN4 + (colb + n) * CS4 + 8 * g;
       f32x4 acc[NB4];
 #pragma unroll
       for (int j = 0; j < NB4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      b3_mac_areg<32, 5, NB4>(p, p + PS4, p + 2 * PS4, a4, acc);
+      b3q_mac_areg<32, NC4, 5, NB4>(b3q_lane_ptr<32, NC4, 5>(IN4, colb, lane), a4, acc);
       const int lo = 6 - t0 / 4;
 #pragma unroll
       for (int j = 0; j < NB4; ++j) {
         const int t = 2 * (colb + j * 16 + n) + ph;
         float v[4];
         t3_finish(acc[j], bias4, (unsigned)(t - lo) < 1500u, v);
-        if (t < NC5) b3_store4(IN5, PS5, CS5, t, 4 * g, v);
+        if (t < NC5) b3q_store4<16, NC5>(IN5, t, g, v);
       }
     }
     __syncthreads();
+    T3_STAMP(2)
     {  // stage 5: column c reads the image columns c + 1 + tap; output t = 2 c + p -> column t of the stage-6 input image
       const int ph = w & 1, colb = (w >> 1) * (NB5 * 16);
-      const bf16_t* p = IN5 + (colb + n + 1 + (g >> 1)) * CS5 + 8 * (g & 1);
       f32x4 acc[NB5];
 #pragma unroll
       for (int j = 0; j < NB5; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      b3_mac_areg<16, 5, NB5>(p, p + PS5, p + 2 * PS5, a5, acc);
+      b3q_mac_alds<16, NC5, 5, NB5>(b3q_lane_ptr<16, NC5, 5>(IN5, colb + 1, lane), A5 + ph * (A5_N / 2) + lane, acc);
       const int lo = 6 - t0 / 2;
 #pragma unroll
       for (int j = 0; j < NB5; ++j) {
         const int t = 2 * (colb + j * 16 + n) + ph;
         float v[4];
         t3_finish(acc[j], bias5, (unsigned)(t - lo) < 3000u, v);
-        if (t < NC6) b3_store4(IN6, PS6, CS6, t, 4 * g, v);
+        if (t < NC6) b3q_store4<16, NC6>(IN6, t, g, v);
       }
     }
     __syncthreads();
+    T3_STAMP(3)
     if (more) request(nid);  // travels under stage 6 and the heads
     {  // stage 6: column c reads the image columns c + tap; one m-tile: lane group g holds phase g / 2, channels 4 (g % 2) ..;
        // output t = 2 c + p = sample t0 - 6 + t of the row -> 16-byte chunk (t % 16) * HSB + t / 16 of the staging
       const int colb = w * (NB6 * 16), ph = g >> 1;
-      const bf16_t* p = IN6 + (colb + n + (g >> 1)) * CS6 + 8 * (g & 1);
       f32x4 acc[NB6];
 #pragma unroll
       for (int j = 0; j < NB6; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      b3_mac_areg<16, 7, NB6>(p, p + PS6, p + 2 * PS6, a6, acc);
+      b3q_mac_alds<16, NC6, 7, NB6>(b3q_lane_ptr<16, NC6, 7>(IN6, colb, lane), A6 + lane, acc);
       const int lo = 6 - t0;
       // t = 2 colb + 32 j + (2 n + p): t % 16 is the lane's, t / 16 = colb / 8 + 2 j + n / 8
-      char* q = reinterpret_cast<char*>(OUT6 + ((2 * n + ph) & 15) * HSB + (n >> 3) + colb / 8) + 8 * (g & 1);
+      uint2* q = OUT6 + (g & 1) * OUT_QS + ((2 * n + ph) & 15) * HSB + (n >> 3) + colb / 8;
 #pragma unroll
       for (int j = 0; j < NB6; ++j) {
         const int t = 2 * (colb + j * 16 + n) + ph;
         float v[4];
         t3_finish(acc[j], bias6, (unsigned)(t - lo) < (unsigned)T_OUT, v);
-        unsigned short h[4], m[4], l[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) b3_split(v[r], h[r], m[r], l[r]);
-        char* qj = q + 2 * j * 16;
-        *reinterpret_cast<uint2*>(qj) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-        *reinterpret_cast<uint2*>(qj + OUT_PS * 16) = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
-        *reinterpret_cast<uint2*>(qj + 2 * OUT_PS * 16) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+        const unsigned h0 = pack_bf16x2(v[0], v[1]), h1 = pack_bf16x2(v[2], v[3]);
+        const float r0 = v[0] - bf16_lo(h0), r1 = v[1] - bf16_hi(h0), r2 = v[2] - bf16_lo(h1), r3 = v[3] - bf16_hi(h1);
+        const unsigned m0 = pack_bf16x2(r0, r1), m1 = pack_bf16x2(r2, r3);
+        const unsigned l0 = pack_bf16x2(r0 - bf16_lo(m0), r1 - bf16_hi(m0)), l1 = pack_bf16x2(r2 - bf16_lo(m1), r3 - bf16_hi(m1));
+        q[2 * j] = make_uint2(h0, h1);
+        q[2 * j + OUT_PS] = make_uint2(m0, m1);
+        q[2 * j + 2 * OUT_PS] = make_uint2(l0, l1);
       }
     }
     __syncthreads();
+    T3_STAMP(4)
     if (w < (TW / 16 + 15) / 16) {
       // heads: wave w owns the 16-sample blocks 16 w .. 16 w + 15 of the tile: y[t0 + 16 blk + m] = b + sum_tap sum_ci
       // w[ci][tap - m] x_ci[staged 16 blk + tap + 1]; K-step s = taps 4 s .. 4 s + 3, lane group g the tap 4 s + g
       f32x4 acc = {bh, bh, bh, bh};
-      const uint4* bp = OUT6 + (16 * w + n);
+      const uint2* bp = OUT6 + (16 * w + n);
       const uint4* ap = HT + (g - n + 15);
       uint4 av[2][3], bv[2][3];
       auto load_ab = [&](const int s, uint4 (&aa)[3], uint4 (&bb)[3]) {
@@ -215,7 +230,8 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) {
           aa[pc] = ap[pc * HT_N + 4 * s];
-          bb[pc] = bp[pc * OUT_PS + chunk];
+          const uint2 c0 = bp[pc * OUT_PS + chunk], c1 = bp[pc * OUT_PS + OUT_QS + chunk];  // channels 0-3, 4-7
+          bb[pc] = make_uint4(c0.x, c0.y, c1.x, c1.y);
         }
       };
       load_ab(0, av[0], bv[0]);
@@ -241,6 +257,8 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
         *reinterpret_cast<float4*>(a.y + ((long)b * 3 + id.d) * T_OUT + t0 + 16 * blk + 4 * g) = r;
       }
     }
+    T3_STAMP(5)
+    ++n_done;
     if (!more) break;
     if (nid.d != id.d) {  // uniform over the workgroup
       __syncthreads();    // every wave is through with the head table
@@ -250,6 +268,8 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
     id = nid;
     // no barrier here: the next tile's stage-3 image lands in R0, which nobody has read since the barrier behind stage 6
   }
+  if (clk) clk[31] = __builtin_amdgcn_s_memrealtime();
+#undef T3_STAMP
 }
 
 }  // namespace
@@ -337,6 +357,9 @@ int plan_eqt_fuse_tail_b3(Net& net) {
     a.head_b = c6->e1.d;
     a.B = B;
     a.n_tiles = 3 * B * TILES_PER_ROW;
+    a.clk = (n.debug_clock && n.debug_clock->d)
+                ? reinterpret_cast<unsigned long long*>(n.debug_clock->d) + (size_t)n.max_batch * 32 + 64 * 8
+                : nullptr;
     const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
     hipLaunchKernelGGL(eqt_tail3_kernel, dim3(grid), dim3(T3_NTH), T3_LDS_BYTES, s, a);
     return 0;
