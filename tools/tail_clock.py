@@ -38,6 +38,14 @@ for t in range(4):
           f"   total {np.median(s[:, 5] - s[:, 0]):7.0f}")
     if t < 3:
         print(f"        gap to the next tile {np.median(c[:, 6 * t + 6] - s[:, 5]):7.0f}")
+if c[:, 24].any():  # eqt_tail3_kernel, second tile: end of each stage's MFMA loop / epilogue (before the barrier) of wave (workgroup % 8),
+    # relative to wave 0's stamp behind the barrier that starts the stage
+    s1 = c[:, 6:12]
+    for k, st in enumerate(("stage 4", "stage 5", "stage 6")):
+        for wv in range(8):
+            sel = np.arange(B) % 8 == wv
+            print(f"tile 1 {st} wave {wv}: MFMA loop ends {np.median(c[sel, 24 + 2 * k] - s1[sel, 1 + k]):6.0f}  epilogue ends "
+                  f"{np.median(c[sel, 25 + 2 * k] - s1[sel, 1 + k]):6.0f}  stage ends {np.median(s1[sel, 2 + k] - s1[sel, 1 + k]):6.0f}")
 wall = (c[:, 31] - c[:, 30]) * 10e-9  # 100 MHz ticks
 cyc4 = c[:, 23] - c[:, 0]
 print(f"kernel wall time per workgroup: median {np.median(wall) * 1e6:.1f} us (9 tiles); first four tiles "

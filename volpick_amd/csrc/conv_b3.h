@@ -321,4 +321,108 @@ __device__ __forceinline__ void b3q_mac_alds(const bf16_t* p, const uint4* al, f
   b3q_mac<C, NC, TAPS, NB, true>(p, al, acc);
 }
 
+// n-tile after n-tile: the accumulator of n-tile j goes to `finish(j, acc)` as soon as its last K-step is through, so that a
+// wave's epilogue work (VALU + LDS stores) falls between its MFMA groups, where the SIMD's other wave has the matrix pipe,
+// instead of behind the whole block, where nobody has.  (With all accumulators finished at once the SIMD's second wave
+// -- the older wave issues first -- leaves its MFMA loop when the first is already through its epilogue: 900 of the 4400
+// cycles of a stage of eqt_tail3_kernel had the matrix pipe idle, tools/tail_clock.py.)  The operand in registers.
+template <int C, int NC, int TAPS, int NB, class Finish>
+__device__ __forceinline__ void b3q_mac_tiles(const bf16_t* p, const uint4 (&a)[B3Steps<C, TAPS>::STEPS * 3], Finish finish) {
+  using G = B3Steps<C, TAPS>;
+  using Q = B3Quad<C, NC>;
+  static_assert(G::KS == 1, "one 32-channel step per tap");
+  constexpr int STEPS = G::STEPS;
+  uint4 b[2][3];
+  auto load_b = [&](uint4 (&bv)[3], const int s, const int j) {
+    const int off = (s * G::TPK + j * 16) * 4;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+      const uint2 lo = *reinterpret_cast<const uint2*>(p + pc * Q::PS + off);
+      const uint2 hi = *reinterpret_cast<const uint2*>(p + pc * Q::PS + Q::QS + off);
+      bv[pc] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+  };
+  load_b(b[0], 0, 0);
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      const int i = j * STEPS + s;
+      if (i + 1 < STEPS * NB) load_b(b[(i + 1) & 1], (i + 1) % STEPS, (i + 1) / STEPS);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int WP[6] = {2, 1, 0, 1, 0, 0}, XP[6] = {0, 1, 2, 0, 1, 0};  // (w piece, x piece), smallest products first
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, a[s * 3 + WP[t]]),
+                                                     __builtin_bit_cast(bf16x8_b3, b[i & 1][XP[t]]), acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    finish(j, acc);
+  }
+}
+
+// ---- chunk-plane images: [piece][8-channel chunk][column][8 channels] --------------------------------------------------------
+// one ds_read_b128 per fragment piece (16 lanes read 256 consecutive bytes; chunk planes a multiple of 256 bytes apart keep
+// the mixed lane groups of the instruction on disjoint banks); the 8-byte stores of a lane's four channels run 4-way conflicted.
+template <int C, int NC>
+struct B3Chunk {
+  static_assert(NC % 16 == 0, "chunk plane stride = 0 mod 256 bytes");
+  static constexpr int CHS = NC * 8, PS = (C / 8) * CHS;  // bf16 per chunk plane / per piece
+};
+template <int C, int NC>
+__device__ __forceinline__ void b3c_store4(bf16_t* img, const int col, const int quad, const float (&v)[4]) {
+  using Q = B3Chunk<C, NC>;
+  const unsigned h0 = pack_bf16x2(v[0], v[1]), h1 = pack_bf16x2(v[2], v[3]);
+  const float r0 = v[0] - bf16_lo(h0), r1 = v[1] - bf16_hi(h0), r2 = v[2] - bf16_lo(h1), r3 = v[3] - bf16_hi(h1);
+  const unsigned m0 = pack_bf16x2(r0, r1), m1 = pack_bf16x2(r2, r3);
+  const unsigned l0 = pack_bf16x2(r0 - bf16_lo(m0), r1 - bf16_hi(m0)), l1 = pack_bf16x2(r2 - bf16_lo(m1), r3 - bf16_hi(m1));
+  bf16_t* p = img + (quad >> 1) * Q::CHS + col * 8 + (quad & 1) * 4;
+  *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(p + Q::PS) = make_uint2(m0, m1);
+  *reinterpret_cast<uint2*>(p + 2 * Q::PS) = make_uint2(l0, l1);
+}
+template <int C, int NC, int TAPS>
+__device__ __forceinline__ const bf16_t* b3c_lane_ptr(const bf16_t* img, const int col0, const int lane) {
+  using G = B3Steps<C, TAPS>;
+  const int g = lane >> 4;
+  return img + (G::ch_of_lane(g) / 8) * B3Chunk<C, NC>::CHS + (col0 + (lane & 15) + G::tap_of_lane(g)) * 8;
+}
+template <int C, int NC, int TAPS, int NB, class Finish>
+__device__ __forceinline__ void b3c_mac_tiles(const bf16_t* p, const uint4 (&a)[B3Steps<C, TAPS>::STEPS * 3], Finish finish) {
+  using G = B3Steps<C, TAPS>;
+  using Q = B3Chunk<C, NC>;
+  static_assert(G::KS == 1, "one 32-channel step per tap");
+  constexpr int STEPS = G::STEPS;
+  // fragments two (K-step, n-tile) pairs ahead of the MFMAs: one pair ahead (96 cycles of MFMA) does not cover the LDS
+  // latency of a loaded CU -- the older wave of a SIMD then ran at 24 cycles per MFMA instead of 16 (tools/tail_clock.py)
+  constexpr int AHEAD = 2, NBUF = AHEAD + 1, PAIRS = STEPS * NB;
+  uint4 b[NBUF][3];
+  auto load_b = [&](const int i) {
+    const int s = i % STEPS, j = i / STEPS;
+    const int off = (s * G::TPK + j * 16) * 8;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) b[i % NBUF][pc] = *reinterpret_cast<const uint4*>(p + pc * Q::PS + off);
+  };
+#pragma unroll
+  for (int i = 0; i < AHEAD && i < PAIRS; ++i) load_b(i);
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      const int i = j * STEPS + s;
+      if (i + AHEAD < PAIRS) load_b(i + AHEAD);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int WP[6] = {2, 1, 0, 1, 0, 0}, XP[6] = {0, 1, 2, 0, 1, 0};  // (w piece, x piece), smallest products first
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, a[s * 3 + WP[t]]),
+                                                     __builtin_bit_cast(bf16x8_b3, b[i % NBUF][XP[t]]), acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    finish(j, acc);
+  }
+}
+
 }  // namespace vp

@@ -40,10 +40,10 @@ constexpr int T3_NTH = 512, T3_WAVES = 8;
 constexpr int NB4 = 3, NB5 = 5, NB6 = 5;                                         // n-tiles per wave and stage
 constexpr int C4 = 4 * NB4 * 16, C5 = 4 * NB5 * 16, C6 = T3_WAVES * NB6 * 16;    // columns computed: 192, 320, 640
 constexpr int PARK_COLS = 160;                                                   // stage-3 samples a tile needs
-constexpr int NC4 = 200, NC5 = C5 + 8, NC6 = C6 + 8;                            // image columns (every one a stage may read), 8 mod 16
-using Q4 = B3Quad<32, NC4>;                                                      // quad-plane images (conv_b3.h)
-using Q5 = B3Quad<16, NC5>;
-using Q6 = B3Quad<16, NC6>;
+constexpr int NC4 = 208, NC5 = C5 + 16, NC6 = C6 + 16;                            // image columns (every one a stage may read), 8 mod 16
+using Q4 = B3Chunk<32, NC4>;                                                      // quad-plane images (conv_b3.h)
+using Q5 = B3Chunk<16, NC5>;
+using Q6 = B3Chunk<16, NC6>;
 constexpr int HSB = 81, OUT_QS = 16 * HSB, OUT_PS = 2 * OUT_QS;                  // heads' staging: 8-byte units per row / quad plane / piece
 constexpr int HT_N = 43;                                                         // head table entries: k = -15 .. 27
 constexpr int R0_BYTES = 3 * Q6::PS * 2, R1_BYTES = 3 * OUT_PS * 8;
@@ -108,24 +108,34 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
   int n_done = 0;
 #define T3_STAMP(k) \
   if (clk && n_done < 4) clk[n_done * 6 + (k)] = __builtin_readcyclecounter();
+  unsigned long long* clk2 =  // lane 0 of wave (workgroup % 8)
+      (a.clk && lane == 0 && w == ((int)blockIdx.x & 7) && (int)blockIdx.x < a.B) ? a.clk + (long)blockIdx.x * 32 : nullptr;
+#define T3_STAMP2(k) /* second tile only: end of a stage's MFMAs / of its epilogue (slots 24 .. 29), of wave (workgroup % 8) */ \
+  if (clk2 && n_done == 1) clk2[k] = __builtin_readcyclecounter();
   if (clk) clk[30] = __builtin_amdgcn_s_memrealtime();
 
   // stage-3 samples of a tile: image column x <-> sample t0/8 - 5 + x of the row; an item = four channels of one sample
   float pre[3][4];
+  unsigned pre_off[3];  // per-lane part of an item's address; the row of channel r is a uniform step on the base
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int item = tid + k * T3_NTH, cq = item / PARK_COLS, x = item - cq * PARK_COLS;
+    pre_off[k] = (unsigned)(4 * cq * a.ls3 + x);
+  }
   auto request = [&](const Tile3& t) {
     const float* src = a.x3 + (long)t.win * a.ws3 + (HALO - 5 + t.t0 / 8);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int item = tid + k * T3_NTH, cq = item / PARK_COLS, x = item - cq * PARK_COLS;
+    for (int r = 0; r < 4; ++r) {
+      const float* row = src + (long)r * a.ls3;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pre[k][r] = item < 8 * PARK_COLS ? src[(long)(4 * cq + r) * a.ls3 + x] : 0.f;
+      for (int k = 0; k < 3; ++k) pre[k][r] = (k < 2 || tid + 2 * T3_NTH < 8 * PARK_COLS) ? row[pre_off[k]] : 0.f;
     }
   };
   auto park = [&]() {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int item = tid + k * T3_NTH, cq = item / PARK_COLS, x = item - cq * PARK_COLS;
-      if (item < 8 * PARK_COLS) b3q_store4<32, NC4>(IN4, x, cq, pre[k]);
+      if (item < 8 * PARK_COLS) b3c_store4<32, NC4>(IN4, x, cq, pre[k]);
     }
   };
   request(id);
@@ -159,35 +169,30 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
     T3_STAMP(1)
     {  // stage 4: column c, phase p -> stage-4 sample t0/4 - 6 + t, t = 2 c + p: column t of the stage-5 input image
       const int ph = w & 1, colb = (w >> 1) * (NB4 * 16);
-      f32x4 acc[NB4];
-#pragma unroll
-      for (int j = 0; j < NB4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      b3q_mac_areg<32, NC4, 5, NB4>(b3q_lane_ptr<32, NC4, 5>(IN4, colb, lane), a4, acc);
       const int lo = 6 - t0 / 4;
-#pragma unroll
-      for (int j = 0; j < NB4; ++j) {
+      b3c_mac_tiles<32, NC4, 5, NB4>(b3c_lane_ptr<32, NC4, 5>(IN4, colb, lane), a4, [&](const int j, const f32x4 acc) {
         const int t = 2 * (colb + j * 16 + n) + ph;
         float v[4];
-        t3_finish(acc[j], bias4, (unsigned)(t - lo) < 1500u, v);
-        if (t < NC5) b3q_store4<16, NC5>(IN5, t, g, v);
-      }
+        t3_finish(acc, bias4, (unsigned)(t - lo) < 1500u, v);
+        if (t < NC5) b3c_store4<16, NC5>(IN5, t, g, v);
+      });
+      T3_STAMP2(25)
     }
     __syncthreads();
     T3_STAMP(2)
     {  // stage 5: column c reads the image columns c + 1 + tap; output t = 2 c + p -> column t of the stage-6 input image
       const int ph = w & 1, colb = (w >> 1) * (NB5 * 16);
-      f32x4 acc[NB5];
+      uint4 a5[B3Steps<16, 5>::STEPS * 3];  // this wave's operand: LDS -> registers for the stage
 #pragma unroll
-      for (int j = 0; j < NB5; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      b3q_mac_alds<16, NC5, 5, NB5>(b3q_lane_ptr<16, NC5, 5>(IN5, colb + 1, lane), A5 + ph * (A5_N / 2) + lane, acc);
+      for (int i = 0; i < B3Steps<16, 5>::STEPS * 3; ++i) a5[i] = A5[ph * (A5_N / 2) + i * 64 + lane];
       const int lo = 6 - t0 / 2;
-#pragma unroll
-      for (int j = 0; j < NB5; ++j) {
+      b3c_mac_tiles<16, NC5, 5, NB5>(b3c_lane_ptr<16, NC5, 5>(IN5, colb + 1, lane), a5, [&](const int j, const f32x4 acc) {
         const int t = 2 * (colb + j * 16 + n) + ph;
         float v[4];
-        t3_finish(acc[j], bias5, (unsigned)(t - lo) < 3000u, v);
-        if (t < NC6) b3q_store4<16, NC6>(IN6, t, g, v);
-      }
+        t3_finish(acc, bias5, (unsigned)(t - lo) < 3000u, v);
+        if (t < NC6) b3c_store4<16, NC6>(IN6, t, g, v);
+      });
+      T3_STAMP2(27)
     }
     __syncthreads();
     T3_STAMP(3)
@@ -195,18 +200,16 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
     {  // stage 6: column c reads the image columns c + tap; one m-tile: lane group g holds phase g / 2, channels 4 (g % 2) ..;
        // output t = 2 c + p = sample t0 - 6 + t of the row -> 16-byte chunk (t % 16) * HSB + t / 16 of the staging
       const int colb = w * (NB6 * 16), ph = g >> 1;
-      f32x4 acc[NB6];
+      uint4 a6[B3Steps<16, 7>::STEPS * 3];
 #pragma unroll
-      for (int j = 0; j < NB6; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      b3q_mac_alds<16, NC6, 7, NB6>(b3q_lane_ptr<16, NC6, 7>(IN6, colb, lane), A6 + lane, acc);
+      for (int i = 0; i < B3Steps<16, 7>::STEPS * 3; ++i) a6[i] = A6[i * 64 + lane];
       const int lo = 6 - t0;
       // t = 2 colb + 32 j + (2 n + p): t % 16 is the lane's, t / 16 = colb / 8 + 2 j + n / 8
       uint2* q = OUT6 + (g & 1) * OUT_QS + ((2 * n + ph) & 15) * HSB + (n >> 3) + colb / 8;
-#pragma unroll
-      for (int j = 0; j < NB6; ++j) {
+      b3c_mac_tiles<16, NC6, 7, NB6>(b3c_lane_ptr<16, NC6, 7>(IN6, colb, lane), a6, [&](const int j, const f32x4 acc) {
         const int t = 2 * (colb + j * 16 + n) + ph;
         float v[4];
-        t3_finish(acc[j], bias6, (unsigned)(t - lo) < (unsigned)T_OUT, v);
+        t3_finish(acc, bias6, (unsigned)(t - lo) < (unsigned)T_OUT, v);
         const unsigned h0 = pack_bf16x2(v[0], v[1]), h1 = pack_bf16x2(v[2], v[3]);
         const float r0 = v[0] - bf16_lo(h0), r1 = v[1] - bf16_hi(h0), r2 = v[2] - bf16_lo(h1), r3 = v[3] - bf16_hi(h1);
         const unsigned m0 = pack_bf16x2(r0, r1), m1 = pack_bf16x2(r2, r3);
@@ -214,7 +217,8 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
         q[2 * j] = make_uint2(h0, h1);
         q[2 * j + OUT_PS] = make_uint2(m0, m1);
         q[2 * j + 2 * OUT_PS] = make_uint2(l0, l1);
-      }
+      });
+      T3_STAMP2(29)
     }
     __syncthreads();
     T3_STAMP(4)
@@ -270,6 +274,7 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
   }
   if (clk) clk[31] = __builtin_amdgcn_s_memrealtime();
 #undef T3_STAMP
+#undef T3_STAMP2
 }
 
 }  // namespace
