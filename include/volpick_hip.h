@@ -69,8 +69,10 @@ typedef struct {
                                       per-row fused kernel, bit2 = encoder stages 0-2 as three launches instead of the
                                       time-tiled fused kernel, bit3 = encoder stages 3-6 as four launches instead of one
                                       per-window fused kernel (all bit-identical; layer tests, A/B timing),
-                                      bit4 = the fused ResCNN kernel on the fp32 MFMA instead of the bf16 matrix cores
-                                      with exact three-piece operands (the two agree to fp32 rounding, not bitwise) */
+                                      bit4 = the fused ResCNN kernel, bit5 = stages 1 and 2 of the fused decoder 0-3
+                                      kernel, bit6 = the fused decoder tail (stages 4-6 + heads) on the fp32 MFMA
+                                      instead of the bf16 matrix cores with exact three-piece operands (the two
+                                      forms agree to fp32 rounding, not bitwise) */
 } vp_config;
 
 /* Fills cfg with the defaults for model_kind. */

@@ -9,21 +9,30 @@
 //     stage 4 columns n4 = t0/8 - 3 + [0, 156 / 192)  reads stage-3 samples [n4 - 2, n4 + 2]  (K = 7 folded to 5 taps)
 //   (needed / computed: every wave takes one block of 3 / 5 / 5 n-tiles of one m-tile per stage)
 //
-// LDS (154 KB).  Three-piece images [piece][column][C + 8 channels] take 1.5 x the bytes of fp32 rows (and the padding that
-// keeps the 16-byte fragment reads off each other's banks is 8 channels of 16 or 32), so a 2000-sample tile no longer
-// fits: 1200-sample tiles, and two regions used twice per tile --
-//     R0 (93 KB): the stage-3 image (32 ch x 196 columns), then the stage-5 output = stage-6 input (16 ch x 648 columns)
-//     R1 (62 KB): the stage-4 output = stage-5 input (16 ch x 328 columns), then the stage-6 output staged for the heads
+// LDS (157 KB).  Three-piece images take 6 bytes per value against the 4 of fp32 rows, so a 2000-sample tile no longer
+// fits beside its staging: 1200-sample tiles, chunk-plane images [piece][8-channel chunk][column][8 channels] (conv_b3.h), and
+// two regions used twice per tile --
+//     R0 (63 KB): the stage-3 image (32 ch x 208 columns), then the stage-5 output = stage-6 input (16 ch x 656 columns)
+//     R1 (62 KB): the stage-4 output = stage-5 input (16 ch x 384 columns), then the stage-6 output staged for the heads
+//     + the operands of stages 5 and 6 (18 + 12 KB) and the heads' tap table (2 KB)
 // Nothing is zero-filled per tile: everything LDS ever holds is a bfloat16 piece of a finite number (or the zeros of the
 // one fill at kernel start), a column a stage reads beyond what its producer wrote meets a zero weight (the padded taps)
 // or feeds an output nobody keeps, and samples outside a row's signal are WRITTEN as zeros by the producing stage.
 //
-// Weights.  16-channel layers pack two taps into the K = 32 of one instruction (conv_b3.h: B3Steps); the operands of
-// the three stages are 15 + 9 + 12 16-byte registers per lane and stay resident over all tiles of a workgroup (reloaded
-// when the decoder changes: twice per workgroup at most).  The heads (8 -> 1, k = 11) are the Toeplitz product of
-// eqt_tail.hip with K ordered (tap, channel): a B fragment = the 8 channels of one staged sample (one 16-byte read, staging
-// [sample % 16][sample / 16] so that 16 lanes read 256 consecutive bytes), an A fragment = w[.][tap - m] or zero: a 43-entry
-// table per piece in LDS, read with a per-lane offset.
+// Weights.  16-channel layers pack two taps into the K = 32 of one instruction (conv_b3.h: B3Steps).  The stage-4 operand
+// (15 16-byte registers per lane) stays in registers over all tiles of a workgroup, those of stages 5 and 6 rest in
+// LDS and are read into registers at the start of their stage (all three in registers spilled: the reloads, counted
+// by vmcnt behind the next tile's stage-3 loads, exposed the latency of those); everything is reloaded when the decoder
+// changes (twice per workgroup at most).  The heads (8 -> 1, k = 11) are the Toeplitz product of eqt_tail.hip with K
+// ordered (tap, channel): a B fragment = the 8 channels of one staged sample (two 8-byte reads: staging [channel quad]
+// [sample % 16][sample / 16], odd row pitch: the stores of stage 6 are conflict-free, the reads 2-way), an A fragment =
+// w[.][tap - m] or zero: a 43-entry table per piece in LDS, read with a per-lane offset.
+//
+// Where the time goes (tools/tail_clock.py; 15 tiles of 19.6 k cycles per workgroup at 256 windows): stage 4 / 5 / 6
+// 4.3 / 5.2 / 6.6 k cycles for 2.9 / 2.9 / 3.8 k of MFMA issue per SIMD, heads 2.4 k, conversion of the next tile's stage-3
+// rows 1.1 k.  The older wave of a SIMD runs its chain of MFMAs first; what the younger one adds behind it, and every
+// epilogue (bias, ReLU, split into pieces, stores: 40 vector instructions per n-tile, an MFMA leaves 8 of its 16 cycles to
+// them), is what a stage costs beyond its MFMAs.  Bank conflicts are not: three image layouts measured the same (conv_b3.h).
 //
 // Plan flag reserved[7] & 64 keeps the fp32-MFMA kernel of eqt_tail.hip (bit-identical to the layer launches); this one
 // agrees with it to fp32 rounding (tests/test_gpu_eqt.py).
@@ -40,7 +49,7 @@ constexpr int T3_NTH = 512, T3_WAVES = 8;
 constexpr int NB4 = 3, NB5 = 5, NB6 = 5;                                         // n-tiles per wave and stage
 constexpr int C4 = 4 * NB4 * 16, C5 = 4 * NB5 * 16, C6 = T3_WAVES * NB6 * 16;    // columns computed: 192, 320, 640
 constexpr int PARK_COLS = 160;                                                   // stage-3 samples a tile needs
-constexpr int NC4 = 208, NC5 = C5 + 16, NC6 = C6 + 16;                            // image columns (every one a stage may read), 8 mod 16
+constexpr int NC4 = 208, NC5 = 2 * C4, NC6 = C6 + 16;  // (a place for every column stage 4 / 5 writes: no range tests)                            // image columns (every one a stage may read), 8 mod 16
 using Q4 = B3Chunk<32, NC4>;                                                      // quad-plane images (conv_b3.h)
 using Q5 = B3Chunk<16, NC5>;
 using Q6 = B3Chunk<16, NC6>;
@@ -53,7 +62,8 @@ constexpr int T3_LDS_BYTES = OFF_A6 + A6_N * 16;
 static_assert(OFF_A5 % 16 == 0, "16-byte fragments");
 static_assert(3 * Q4::PS * 2 <= R0_BYTES && 3 * Q5::PS * 2 <= R1_BYTES && T3_LDS_BYTES <= 160 * 1024 && OFF_R1 % 16 == 0 && OFF_HT % 16 == 0,
               "LDS budget");
-static_assert(NC4 >= C4 + 4 && NC5 >= C5 + 6 && NC6 >= C6 + 8 && HSB % 2 == 1, "every column a stage reads has a place");
+static_assert(NC4 >= C4 + 4 && NC5 >= C5 + 6 && NC6 >= C6 + 8 && NC5 >= 2 * C4 && NC6 >= 2 * C5 && HSB % 2 == 1,
+              "every column a stage reads or writes has a place");
 static_assert(TILES_PER_ROW * TW == T_OUT && TW % 16 == 0 && TW % 8 == 0, "tile grid");
 // what a tile needs (file comment) is computed, and what is computed has a place
 static_assert(TW + 11 <= 2 * C6 && C6 / 8 <= HSB - 1 && (TW / 16 + 15) / 16 <= T3_WAVES, "stage 6 / heads");
@@ -108,10 +118,6 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
   int n_done = 0;
 #define T3_STAMP(k) \
   if (clk && n_done < 4) clk[n_done * 6 + (k)] = __builtin_readcyclecounter();
-  unsigned long long* clk2 =  // lane 0 of wave (workgroup % 8)
-      (a.clk && lane == 0 && w == ((int)blockIdx.x & 7) && (int)blockIdx.x < a.B) ? a.clk + (long)blockIdx.x * 32 : nullptr;
-#define T3_STAMP2(k) /* second tile only: end of a stage's MFMAs / of its epilogue (slots 24 .. 29), of wave (workgroup % 8) */ \
-  if (clk2 && n_done == 1) clk2[k] = __builtin_readcyclecounter();
   if (clk) clk[30] = __builtin_amdgcn_s_memrealtime();
 
   // stage-3 samples of a tile: image column x <-> sample t0/8 - 5 + x of the row; an item = four channels of one sample
@@ -174,9 +180,8 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
         const int t = 2 * (colb + j * 16 + n) + ph;
         float v[4];
         t3_finish(acc, bias4, (unsigned)(t - lo) < 1500u, v);
-        if (t < NC5) b3c_store4<16, NC5>(IN5, t, g, v);
+        b3c_store4<16, NC5>(IN5, t, g, v);
       });
-      T3_STAMP2(25)
     }
     __syncthreads();
     T3_STAMP(2)
@@ -190,15 +195,14 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
         const int t = 2 * (colb + j * 16 + n) + ph;
         float v[4];
         t3_finish(acc, bias5, (unsigned)(t - lo) < 3000u, v);
-        if (t < NC6) b3c_store4<16, NC6>(IN6, t, g, v);
+        b3c_store4<16, NC6>(IN6, t, g, v);
       });
-      T3_STAMP2(27)
     }
     __syncthreads();
     T3_STAMP(3)
     if (more) request(nid);  // travels under stage 6 and the heads
     {  // stage 6: column c reads the image columns c + tap; one m-tile: lane group g holds phase g / 2, channels 4 (g % 2) ..;
-       // output t = 2 c + p = sample t0 - 6 + t of the row -> 16-byte chunk (t % 16) * HSB + t / 16 of the staging
+       // output t = 2 c + p = sample t0 - 6 + t of the row -> 8-byte unit (t % 16) * HSB + t / 16 of its quad's staging plane
       const int colb = w * (NB6 * 16), ph = g >> 1;
       uint4 a6[B3Steps<16, 7>::STEPS * 3];
 #pragma unroll
@@ -218,7 +222,6 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
         q[2 * j + OUT_PS] = make_uint2(m0, m1);
         q[2 * j + 2 * OUT_PS] = make_uint2(l0, l1);
       });
-      T3_STAMP2(29)
     }
     __syncthreads();
     T3_STAMP(4)
@@ -274,7 +277,6 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
   }
   if (clk) clk[31] = __builtin_amdgcn_s_memrealtime();
 #undef T3_STAMP
-#undef T3_STAMP2
 }
 
 }  // namespace
