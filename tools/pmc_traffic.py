@@ -34,6 +34,7 @@ NAMES = {
                       ("eqt_res3_kernel", "fused.rescnn (7 residual blocks)"), ("eqt_res_kernel", "fused.rescnn (7 residual blocks)"),
                       ("eqt_mid_kernel", "fused.mid (3 BiLSTM + 2 transformer blocks + pick branches)"),
                       ("eqt_dec03_kernel", "fused.dec03 (decoder.0-3, one row per workgroup)"),
+                      ("eqt_tail3_kernel", "fused.tail (decoder.4-6 + heads, time-tiled)"),
                       ("eqt_tail_kernel", "fused.tail (decoder.4-6 + heads, time-tiled)")],
 }
 

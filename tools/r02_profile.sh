@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 artifact set, on the GPU box: gpurun --timeout 1200 -- 'bash tools/r02_profile.sh TAG'
 # -> gpurun_out/r02_TAG/: GPU suite, the default bench line (both models), rocprofv3 --kernel-trace --stats of the same
-# command, bench --strong at N = 1, phase clocks of eqt_tail_kernel / pn_window_kernel, the same-box A/B of the fused
+# command, bench --strong at N = 1, phase clocks of eqt_tail3_kernel / pn_window_kernel, the same-box A/B of the fused
 # EQTransformer plan against the layer launches.  PMC traffic: tools/pmc_traffic.sh (separate call).
 export TMPDIR=/tmp
 T=${1:-a}; R=$PWD; O=$R/gpurun_out/r02_$T; mkdir -p $O
@@ -29,5 +29,11 @@ chk
 tools/ab_e2e.sh 3 0 0,0,0,0,0,0,0,15 > $O/eqt_fused_vs_layer_launches_e2e.txt 2>&1
 chk
 timeout -k 10 200 python tools/ab_steps.py eqtransformer "0" "0,0,0,0,0,0,0,15" > $O/eqt_fused_vs_layer_launches_steps.txt 2>&1
+chk
+ls -la $O
+# the bf16-piece kernels (ResCNN, decoder 0-3 stages 1-2, decoder tail) against their fp32-MFMA forms, same box
+timeout -k 10 200 python tools/ab_steps.py eqtransformer "0" "0,0,0,0,0,0,0,112" > $O/eqt_bf16_pieces_vs_fp32_mfma_steps.txt 2>&1
+chk
+tools/ab_e2e.sh 2 0 0,0,0,0,0,0,0,112 > $O/eqt_bf16_pieces_vs_fp32_mfma_e2e.txt 2>&1
 chk
 ls -la $O
