@@ -37,16 +37,20 @@ static_assert(S0 % 32 == 16 && S1 % 32 == 16 && S2 % 32 == 16 && S3 % 32 == 16, 
 constexpr int OFF0 = 0, OFF1 = OFF0 + 16 * S0, OFF2 = OFF1 + 64 * S1, OFF3 = OFF2 + 64 * S2, D03_LDS_FLOATS = OFF3 + 32 * S3;
 static_assert(D03_LDS_FLOATS * 4 <= 160 * 1024 && OFF1 % 4 == 0 && OFF2 % 4 == 0 && OFF3 % 4 == 0, "LDS budget");
 
-// B3 instantiation: stages 1 and 2 (64 -> 64 and 64 -> 32 channels, 53 % of the row's MFMA issue) on the bf16 matrix cores with
-// exact three-piece operands (conv_b3.h).  Stage 0 (fp32 MFMA, its GEMM rows regrouped (phase, channel)) writes its output as
-// a three-piece image, stage 1 reads and writes piece images, stage 2 reads one and writes the fp32 image of stage 3 as
-// before.  LDS: the stage-2 input image (85 KB), and behind it the stage-3 fp32 image, which takes the place of the
-// (dead) stage-0 input and stage-1 input images -- one more barrier per row, 136 KB in all.
+// B3 instantiation: stages 1, 2 and 3 (97 % of the row's MFMA issue) on the bf16 matrix cores with exact three-piece
+// operands (conv_b3.h).  Stage 0 (fp32 MFMA, its GEMM rows regrouped (phase, channel)) writes its output as a three-piece
+// image, stages 1 and 2 read and write piece images, stage 3 reads one and writes the row to memory.  LDS: the stage-2
+// input image (85 KB, [column][64 + 8 channels]), and behind it the stage-3 input image (77 KB, chunk planes, unpadded),
+// which takes the place of the (dead) stage-0 input and stage-1 input images -- one more barrier per row, 158 KB in all.
 constexpr int B3_X1_NC = 100, B3_X2_NC = 196;                          // columns: sample t at column t + 1
 constexpr int B3_X1_PS = B3_X1_NC * 72, B3_X2_PS = B3_X2_NC * 72;      // bf16 elements per piece
 constexpr int B3_OFF_X2 = 0, B3_OFF_R = 3 * B3_X2_PS * 2;              // bytes
 constexpr int B3_OFF_X0 = B3_OFF_R, B3_OFF_X1 = B3_OFF_X0 + 16 * S0 * 4, B3_OFF_X3 = B3_OFF_R;
-constexpr int B3_LDS_BYTES = B3_OFF_X3 + 32 * S3 * 4;
+// stage-3 input as a chunk-plane three-piece image (conv_b3.h): sample t at column t + 2, 400 columns, no padding channels
+constexpr int B3_X3_NC = 400, B3_X3_C0 = 2;
+using QX3 = B3Chunk<32, B3_X3_NC>;
+constexpr int B3_LDS_BYTES = B3_OFF_X3 + 3 * QX3::PS * 2;
+static_assert(B3_X3_NC >= C3 + 4 + 0 && B3_X3_NC >= L3 + B3_X3_C0, "every column stage 3 reads has a place");
 static_assert(B3_OFF_X1 + 3 * B3_X1_PS * 2 <= B3_LDS_BYTES && B3_LDS_BYTES <= 160 * 1024 && B3_OFF_R % 16 == 0 && B3_OFF_X1 % 16 == 0,
               "LDS budget of the bf16-piece variant");
 
@@ -60,8 +64,8 @@ struct Dec03Args {
   const float* af[4];  // A fragments regrouped for 16-byte loads [set][MT][CB * TAPS / 4][64][4]
   const float* bs[4];  // bias [set][COUT]
   long af_stride[4];
-  const uint4* af3[2];  // B3: three-piece operands of stages 1 and 2 [set][MT][TAPS * 2][piece][64] (conv_b3.h)
-  long af3_stride[2];   // uint4 per set
+  const uint4* af3[3];  // B3: three-piece operands of stages 1, 2 (rows (phase, channel)) and 3 (rows (channel, phase)): [set][MT][steps][piece][64]
+  long af3_stride[3];   // uint4 per set
   const float* edge_w;  // [3][64][64][3] pre-summed taps of the two edge outputs of stage 2 (eqt.hip)
   const float* edge_b;  // [3][32]
   int B, n_rows;
@@ -128,15 +132,12 @@ struct Stage0Pieces : B3Store<64> {
     }
   }
 };
-// B3, stage 2 -> the fp32 image of stage 3; samples from `hi` on are the edge fix's / padding (ClipStore)
+// B3, stage 2 -> the three-piece image of stage 3; samples from `hi` on are the edge fix's / padding (ClipStore)
 struct ClipQuad {
-  float* img;  // image + BI
+  bf16_t* img;
   int hi;
   __device__ __forceinline__ void quad(const int co, const int t, const float (&v)[4]) const {
-    if (t < hi) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) img[(co + r) * S3 + t] = v[r];
-    }
+    if (t < hi) b3c_store4<32, B3_X3_NC>(img, t + B3_X3_C0, co >> 2, v);
   }
 };
 
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
     int o_r = B3_OFF_R / 16;  // opaque: keeps the fp32 images' addresses inside the DS immediates (as below)
     asm volatile("" : "+v"(o_r));
     float* X0 = reinterpret_cast<float*>(base + 16 * o_r);
-    float* X3 = X0;
+    bf16_t* X3 = reinterpret_cast<bf16_t*>(base + 16 * o_r);
     const B3Image<64> iX1{reinterpret_cast<bf16_t*>(base + B3_OFF_X1), B3_X1_PS, 1}, iX2{reinterpret_cast<bf16_t*>(base + B3_OFF_X2), B3_X2_PS, 1};
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -194,49 +195,74 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
         st.zero_rest(1, 1 + 2 * C0, tid, D03_NTH);
         conv_lds_areg<D_0, S0, BI, S0, BI>(X0, X0, areg0, bias0, wave_u, C0, st, 0, 1, lane);
       }
-      float areg3[D_3::CB * D_3::TAPS], bias3[4];
-      load_areg4<D_3>(a.af[3] + d * a.af_stride[3], mt23, lane, areg3);
-      load_biasreg<D_3>(a.bs[3] + d * 32, mt23, lane, bias3);
       __syncthreads();
       {  // stage 1: 64 x 94 -> 64 x 188 on the bf16 matrix cores
         const B3Store<64> st{iX2.img, iX2.ps, iX2.c0, L2, B3_X2_NC};
         conv_b3<D_1, true, 64, 64>(iX1, iX1, a.af3[0] + d * a.af3_stride[0], a.bs[1] + d * 64, C1, st, wave_u, D03_WAVES, lane);
       }
       __syncthreads();
-      {  // stage 2: 64 x 188 -> 32 x 375 (fp32 image in the place of the dead stage-0 / stage-1 inputs: its padding
+      {  // stage 2: 64 x 188 -> 32 x 375 (three-piece image in the place of the dead stage-0 / stage-1 inputs: its padding
          // columns are cleared here, every row) + the two samples at the cropped edge from the definition
-        constexpr int W = S3 - L3;  // BI columns on the left, the rest behind sample 374
-        for (int i = tid; i < 32 * W; i += D03_NTH) {
-          const int c = i / W, k = i - c * W;
-          X3[c * S3 + (k < BI ? k : L3 + k)] = 0.f;
+        constexpr int PADC = B3_X3_C0 + (B3_X3_NC - L3 - B3_X3_C0);  // columns 0, 1 and 377 .. 399
+        if (tid < PADC * 12) {
+          const int k = tid % PADC, cp = tid / PADC;  // cp = piece * 4 + chunk
+          const int col = k < B3_X3_C0 ? k : L3 + k;
+          *reinterpret_cast<uint4*>(X3 + (cp >> 2) * QX3::PS + (cp & 3) * QX3::CHS + col * 8) = make_uint4(0u, 0u, 0u, 0u);
         }
-        const ClipQuad st{X3 + BI, L3 - 2};
+        const ClipQuad st{X3, L3 - 2};
         conv_b3<D_2, true, 64, 64>(iX2, iX2, a.af3[1] + d * a.af3_stride[1], a.bs[2] + d * 32, C2, st, wave_u, D03_WAVES, lane);
         if (wave_u == D03_WAVES - 1) {
           constexpr int n0 = (L3 - 2 - 2) >> 1;
           const float* e = a.edge_w + ((long)d * 64 * 64 + lane) * 3;
           float acc = a.edge_b[d * 32 + (lane >> 1)];
-#pragma unroll 8
-          for (int ci = 0; ci < 64; ++ci) {
-            const float* ec = e + (long)ci * 64 * 3;
-            const bf16_t* xs = iX2.img + (n0 + iX2.c0) * 72 + ci;
+          for (int ci0 = 0; ci0 < 64; ci0 += 16) {  // the weights of 16 input channels requested together, then used
+            float wv[16][3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-              const float x = (from_bf16(xs[k * 72]) + from_bf16(xs[k * 72 + iX2.ps])) + from_bf16(xs[k * 72 + 2 * iX2.ps]);  // exact
-              acc = fmaf(ec[k], x, acc);
+            for (int u = 0; u < 16; ++u)
+#pragma unroll
+              for (int k = 0; k < 3; ++k) wv[u][k] = e[(long)(ci0 + u) * 64 * 3 + k];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+              const bf16_t* xs = iX2.img + (n0 + iX2.c0) * 72 + ci0 + u;
+#pragma unroll
+              for (int k = 0; k < 3; ++k) {
+                const float x = (from_bf16(xs[k * 72]) + from_bf16(xs[k * 72 + iX2.ps])) + from_bf16(xs[k * 72 + 2 * iX2.ps]);  // exact
+                acc = fmaf(wv[u][k], x, acc);
+              }
             }
           }
-          X3[(lane >> 1) * S3 + BI + L3 - 2 + (lane & 1)] = fmaxf(acc, 0.f);
+          unsigned short h, m, l;
+          b3_split(fmaxf(acc, 0.f), h, m, l);
+          const int ch = lane >> 1;
+          bf16_t* q = X3 + (ch >> 3) * QX3::CHS + (L3 - 2 + (lane & 1) + B3_X3_C0) * 8 + (ch & 7);
+          q[0] = h, q[QX3::PS] = m, q[2 * QX3::PS] = l;
         }
       }
+      // stage 3's operand (m-tile mt23 = channels 8 mt23 .. + 7, both phases): 60 registers, so only now that stage 2's are free
+      uint4 a3[B3Steps<32, 5>::STEPS * 3];
+      float bias3[4];
+      b3_load_a<32, 5>(a.af3[2] + d * a.af3_stride[2], mt23, lane, a3);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias3[r] = a.bs[3][d * 32 + mt23 * 8 + 2 * g + (r >> 1)];
       if (more) {
         request(next);
         load_stage0(nd);
       }
       __syncthreads();
-      {  // stage 3: 32 x 375 -> 32 x 750, straight to memory
-        RowOut st{a.y + (long)row * a.ws_y + HALO, a.ls_y};
-        conv_lds_areg<D_3, S3, BI, S3, BI>(X3, X3, areg3, bias3, mt23, C3, st, blk23, 2, lane);
+      {  // stage 3: 32 x 375 -> 32 x 750, straight to memory: rows (channel, phase), so a lane's accumulator pairs are
+         // two consecutive samples of one channel (8-byte stores, full 128-byte lines per 16 lanes)
+        float* yrow = a.y + (long)row * a.ws_y + HALO + (long)(mt23 * 8 + 2 * g) * a.ls_y;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int colb = (blk23 + 2 * k) * 96;
+          b3c_mac_tiles<32, B3_X3_NC, 5, 6>(b3c_lane_ptr<32, B3_X3_NC, 5>(X3, colb, lane), a3, [&](const int j, const f32x4 acc) {
+            const int t = 2 * (colb + j * 16 + (lane & 15));
+            if (t < L4) {
+              *reinterpret_cast<float2*>(yrow + t) = make_float2(fmaxf(acc[0] + bias3[0], 0.f), fmaxf(acc[1] + bias3[1], 0.f));
+              *reinterpret_cast<float2*>(yrow + a.ls_y + t) = make_float2(fmaxf(acc[2] + bias3[2], 0.f), fmaxf(acc[3] + bias3[3], 0.f));
+            }
+          });
+        }
       }
       if (!more) break;
       row = next;
@@ -369,10 +395,10 @@ int plan_eqt_fuse_dec03(Net& net, bool b3) {
   }
   HostBlob* q[4];
   for (int i = 0; i < 4; ++i) q[i] = c[i]->afrag_q4 ? c[i]->afrag_q4 : net.add_blob(regroup_afrag4(*c[i]));
-  HostBlob* p3[2] = {nullptr, nullptr};
-  if (b3) {  // stage 0 with its rows regrouped (phase, channel), stages 1 and 2 as three-piece operands
+  HostBlob* p3[3] = {nullptr, nullptr, nullptr};
+  if (b3) {  // stage 0 with its rows regrouped (phase, channel), stages 1-3 as three-piece operands
     q[0] = net.add_blob(regroup_afrag4_phase_major(*c[0]));
-    for (int i = 0; i < 2; ++i) p3[i] = net.add_blob(b3_operand(*c[1 + i], true));
+    for (int i = 0; i < 3; ++i) p3[i] = net.add_blob(b3_operand(*c[1 + i], i < 2));
   }
   const int x_in = c[0]->src1, y_out = c[3]->dst;
   for (int i = 0; i < 3; ++i) net.tensor_sets[c[i]->dst] = 0;  // stages 0-2 live in LDS under this plan
@@ -402,7 +428,7 @@ int plan_eqt_fuse_dec03(Net& net, bool b3) {
     a.n_rows = 3 * B;
     const int grid = a.n_rows < 256 ? a.n_rows : 256;
     if (b3) {
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < 3; ++i) {
         a.af3[i] = reinterpret_cast<const uint4*>(p3[i]->d);
         a.af3_stride[i] = (long)(p3[i]->h.size() / 3 / 4);
       }
