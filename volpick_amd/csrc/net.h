@@ -64,6 +64,8 @@ struct Net {
   float* arena = nullptr;  // one device allocation for tensors + constants
   size_t arena_floats = 0;
   double flops_per_window = 0;
+  int warm_launches = 1;  // launches of the fused PhaseNet kernels that still pre-touch the weights (first launch of a plan:
+                          // cold L2); in steady state the weights are L2-resident and the touch only delays 8 workgroups
   HostBlob* debug_clock = nullptr;  // fused PhaseNet core: per-layer shader-clock stamps (debug plan flag)
   HostBlob* win_flags = nullptr;    // [max_batch]: 1 where annotate_batch_pre met a non-finite window (its predictions become NaN, as the reference's)
   bool fused_pre = false;           // the plan's first launch can gather + normalise its windows itself (pn_window_kernel)

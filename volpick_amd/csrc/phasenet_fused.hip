@@ -126,7 +126,8 @@ struct CoreArgs {
   int dbg_ls[12];
   long dbg_ws[12];
   unsigned long long* clk;  // optional [B][32]: [0..14] shader-clock stamps (start, load, 13 layers), [16],[17] 100 MHz wall clock
-  int warm;                 // 1 (default): the first workgroup of each XCD pre-touches the weights
+  int warm;                 // 1: the first workgroup of each XCD pre-touches the weights (pn_core_kernel: every launch -- the
+                            // level-0 launches of the three-launch plan run in between; pn_window_kernel: a plan's first launch)
 };
 
 template <int C, int S, int B = IB>
@@ -988,7 +989,11 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   if (clk && tid == 0) clk[(long)win * 32 + (slot)] = __builtin_readcyclecounter();
   WIN_STAMP(0)
   WIN_STAMP(18)
-  if (win < 8 && a.c.warm) {  // first workgroup of each XCD: touch one word per 128-byte line of the core weights (pn_core_kernel)
+  // first workgroup of each XCD: touch one word per 128-byte line of the core weights (pn_core_kernel) -- on the FIRST launch of a
+  // plan only (Net::warm_launches): from then on the weights are L2-resident from launch to launch (nothing but this kernel
+  // runs on the chip), and pulling 2 MB through one CU's L1 made those eight workgroups, hence the launch, 9 us longer
+  // (107.4 -> 97.8 us back to back, tools/ab_steps.py phasenet "0" "0,0,0,0,1")
+  if (win < 8 && a.c.warm) {
     float sink = 0.f;
 #define CORE_WARM(IDX, LAYER)                                                                          \
   for (int l = tid; l < LAYER::MT * LAYER::CB * LAYER::TAPS * 2; l += NTH) sink += a.c.af[IDX][l * 32];
@@ -1638,7 +1643,8 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         a.c.bs[i] = n.convs[3 + i]->bias.d;
       }
       a.c.clk = clk ? reinterpret_cast<unsigned long long*>(clk->d) : nullptr;
-      a.c.warm = n.cfg.reserved[4] != 1;
+      a.c.warm = n.cfg.reserved[4] != 1 && n.warm_launches > 0;
+      if (n.warm_launches > 0) --n.warm_launches;
       a.x = tx.p;
       a.ls_x = tx.ls;
       a.ws_x = (long)tx.win_stride();
