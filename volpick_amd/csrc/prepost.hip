@@ -160,40 +160,41 @@ int launch_gather_normalize(const PreArgs& a, int n_windows, hipStream_t stream)
 // a (L, n_out, coverage) NaN buffer and takes nanmean / nanmax; the gather form reads each
 // prediction once, writes each output once, and needs no coverage-deep buffer.
 // ---------------------------------------------------------------------------------------
+// I = int when the stream is shorter than 2^31 - T samples (launch_stack): the two divisions per sample are then
+// 32-bit (a 64-bit division is ~60 instructions on this target; they were a third of the kernel's time)
+template <class I>
 __global__ __launch_bounds__(256) void stack_kernel(const StackArgs a) {
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long tl = (long)blockIdx.x * 256 + threadIdx.x;
   const int c = blockIdx.y;
-  if (t >= a.N) return;
-  const int T = a.T;
-  const long last_start = a.N - T;
+  if (tl >= a.N) return;
+  const I t = (I)tl, T = (I)a.T, step = (I)a.step, blind_l = (I)a.blind_l, blind_r = (I)a.blind_r;
+  const I last_start = (I)(a.N - a.T);
   // regular windows i*step, i in [lo, hi]
-  long hi = (t - a.blind_l >= 0) ? (t - a.blind_l) / a.step : -1;
-  long lo_num = t - T + a.blind_r;  // need i*step > lo_num
-  long lo = (lo_num < 0) ? 0 : lo_num / a.step + 1;
-  if (hi > a.n_regular - 1) hi = a.n_regular - 1;
+  I hi = (t - blind_l >= 0) ? (t - blind_l) / step : -1;
+  const I lo_num = t - T + blind_r;  // need i*step > lo_num
+  const I lo = (lo_num < 0) ? 0 : lo_num / step + 1;
+  if (hi > (I)a.n_regular - 1) hi = (I)a.n_regular - 1;
   float acc = (a.mode == VP_STACK_AVG) ? 0.f : -INFINITY;
   int cnt = 0;
-  bool nan_seen = false;
-  for (long i = lo; i <= hi; ++i) {
-    const float v = a.pred[((long)i * a.n_out + c) * T + (t - i * a.step)];
+  for (I i = lo; i <= hi; ++i) {
+    const float v = a.pred[((long)i * a.n_out + c) * a.T + (long)(t - i * step)];
     if (v != v) continue;  // nanmean / nanmax skip NaN predictions
     acc = (a.mode == VP_STACK_AVG) ? acc + v : fmaxf(acc, v);
     ++cnt;
   }
   if (a.has_tail) {
-    const long j = t - last_start;
-    if (j >= a.blind_l && j < T - a.blind_r) {
-      const float v = a.pred[((long)a.n_regular * a.n_out + c) * T + j];
+    const I j = t - last_start;
+    if (j >= blind_l && j < T - blind_r) {
+      const float v = a.pred[((long)a.n_regular * a.n_out + c) * a.T + (long)j];
       if (v == v) {
         acc = (a.mode == VP_STACK_AVG) ? acc + v : fmaxf(acc, v);
         ++cnt;
       }
     }
   }
-  (void)nan_seen;
   float r = NAN;
   if (cnt > 0) r = (a.mode == VP_STACK_AVG) ? acc / (float)cnt : acc;
-  a.out[(long)c * a.N + t] = r;
+  a.out[(long)c * a.N + tl] = r;
 }
 
 // One thread per (sample of any block, channel): the block is found by bisection over the cumulative lengths.
@@ -251,7 +252,10 @@ int launch_stack_multi(const StackMultiArgs& a, hipStream_t stream) {
 
 int launch_stack(const StackArgs& a, hipStream_t stream) {
   dim3 grid((unsigned)((a.N + 255) / 256), a.n_out, 1);
-  hipLaunchKernelGGL(stack_kernel, grid, dim3(256), 0, stream, a);
+  if (a.N + a.T < (1L << 31) && a.step > 0 && (long)a.n_regular * a.step < (1L << 31))
+    hipLaunchKernelGGL(stack_kernel<int>, grid, dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(stack_kernel<long>, grid, dim3(256), 0, stream, a);
   return 0;
 }
 
@@ -277,10 +281,18 @@ __device__ __forceinline__ void trigger_scan_body(const PickArgs& a) {
   if (c0 >= a.n) return;
   if (tid == 0) n_ends = 0;
   __syncthreads();
-  for (int i = tid; i < SCAN_CHUNK; i += 256) {
-    const long t = c0 + i;
-    if (t < a.n && a.trace[t] > a.thr_off && !(t + 1 < a.n && a.trace[t + 1] > a.thr_off))
-      ends[atomicAdd(&n_ends, 1)] = i;
+  {  // all samples of the chunk requested before the first is looked at: one memory round trip instead of eight
+    constexpr int PER = SCAN_CHUNK / 256;
+    float v[PER], nx[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const long t = c0 + tid + 256 * k;
+      v[k] = t < a.n ? a.trace[t] : -INFINITY;
+      nx[k] = t + 1 < a.n ? a.trace[t + 1] : -INFINITY;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+      if (v[k] > a.thr_off && !(nx[k] > a.thr_off)) ends[atomicAdd(&n_ends, 1)] = tid + 256 * k;
   }
   __syncthreads();
   const int ne = n_ends;
