@@ -47,6 +47,28 @@ def test_nonfinite_windows_come_out_as_nan(cls, name, flags):
     assert np.isnan(out[2]).all() and not np.isnan(out[[0, 1, 3, 4, 5]]).any()
 
 
+def test_nonfinite_windows_do_not_leak_into_their_neighbours_in_a_wrapped_grid():
+    """300 EQTransformer windows: the persistent fused kernels run several rows / tiles per workgroup, their LDS images
+    are reused from tile to tile without clearing, and the bf16-piece stages read one zero-weight tap beyond the
+    filter -- whatever a non-finite window leaves behind must not reach a kept sample of the next one (0 x NaN)."""
+    model = EQTransformer.from_pretrained("volpick").cuda()
+    T = model.in_samples
+    base = synthetic_windows(7, T, seed=77)
+    x = base[np.arange(300) % 7].copy()
+    clean = np.asarray(model._forward_raw(x, preprocess=True))
+    bad = x.copy()
+    lost = [0, 1, 85, 86, 150, 255, 256, 299]
+    for k, w in enumerate(lost):
+        bad[w, k % 3, (k * 977) % T] = [np.nan, np.inf, -np.inf][k % 3]
+    bad[150] = 3e38  # finite input whose activations overflow on the way
+    got = np.asarray(model._forward_raw(bad, preprocess=True))
+    keep = np.setdiff1d(np.arange(300), lost)
+    assert np.array_equal(got[keep], clean[keep])
+    for w in lost:
+        if w != 150:
+            assert np.isnan(got[w]).all(), w
+
+
 def test_annotate_ignores_poisoned_windows_like_the_oracle():
     model = PhaseNet.from_pretrained("volpick").cuda()
     net = load_pretrained("phasenet")

@@ -15,9 +15,11 @@
 //     R0 (63 KB): the stage-3 image (32 ch x 208 columns), then the stage-5 output = stage-6 input (16 ch x 656 columns)
 //     R1 (62 KB): the stage-4 output = stage-5 input (16 ch x 384 columns), then the stage-6 output staged for the heads
 //     + the operands of stages 5 and 6 (18 + 12 KB) and the heads' tap table (2 KB)
-// Nothing is zero-filled per tile: everything LDS ever holds is a bfloat16 piece of a finite number (or the zeros of the
-// one fill at kernel start), a column a stage reads beyond what its producer wrote meets a zero weight (the padded taps)
-// or feeds an output nobody keeps, and samples outside a row's signal are WRITTEN as zeros by the producing stage.
+// Nothing is zero-filled per tile.  Samples outside a row's signal are WRITTEN as zeros by the producing stage; a column
+// a stage reads beyond what its producer wrote this tile (left-overs of the image that lay there before) only ever feeds
+// outputs nobody keeps: everything a KEPT output touches -- the zero-weight padded taps of stages 5 / 6 and of the heads
+// included, 0 x NaN being NaN -- is computed from this tile's own stage-3 samples (static_assert below; a non-finite
+// window must not reach its neighbour: tests/test_gpu_nonfinite.py).
 //
 // Weights.  16-channel layers pack two taps into the K = 32 of one instruction (conv_b3.h: B3Steps).  The stage-4 operand
 // (15 16-byte registers per lane) stays in registers over all tiles of a workgroup, those of stages 5 and 6 rest in
@@ -48,7 +50,8 @@ constexpr int TW = 1200, TILES_PER_ROW = 5, T_OUT = 6000;
 constexpr int T3_NTH = 512, T3_WAVES = 8;
 constexpr int NB4 = 3, NB5 = 5, NB6 = 5;                                         // n-tiles per wave and stage
 constexpr int C4 = 4 * NB4 * 16, C5 = 4 * NB5 * 16, C6 = T3_WAVES * NB6 * 16;    // columns computed: 192, 320, 640
-constexpr int PARK_COLS = 160;                                                   // stage-3 samples a tile needs
+constexpr int PARK_COLS = 168;  // stage-3 samples a tile parks: the 160 its kept outputs need + the one more (161) that reaches them
+                                // through the zero-weight padded taps of stages 5 / 6 and the heads (0 x stale non-finite = NaN)
 constexpr int NC4 = 208, NC5 = 2 * C4, NC6 = C6 + 16;  // (a place for every column stage 4 / 5 writes: no range tests)                            // image columns (every one a stage may read), 8 mod 16
 using Q4 = B3Chunk<32, NC4>;                                                      // quad-plane images (conv_b3.h)
 using Q5 = B3Chunk<16, NC5>;
@@ -68,6 +71,9 @@ static_assert(TILES_PER_ROW * TW == T_OUT && TW % 16 == 0 && TW % 8 == 0, "tile 
 // what a tile needs (file comment) is computed, and what is computed has a place
 static_assert(TW + 11 <= 2 * C6 && C6 / 8 <= HSB - 1 && (TW / 16 + 15) / 16 <= T3_WAVES, "stage 6 / heads");
 static_assert(TW / 2 + 6 + 6 <= 2 * C5 && TW / 4 + 6 + 5 <= 2 * C4 && TW / 8 + 6 + 4 <= PARK_COLS && PARK_COLS <= NC4, "halo chain");
+// ... and everything a kept output touches, zero-weight taps included, is this tile's data: heads staged t <= TW + 12 -> stage-6
+// column <= (TW + 12) / 2 -> stage-5 sample + 7 -> stage-5 column -> stage-4 sample + 1 + 5 -> stage-4 column -> image column + 4
+static_assert(((((TW + 12) / 2 + 7) / 2 + 1 + 5) / 2 + 4) < PARK_COLS, "closure of the kept outputs under the padded taps");
 static_assert(PARK_COLS * 8 <= 3 * T3_NTH, "three (four channels x one sample) items per thread");
 
 struct Tail3Args {
