@@ -38,6 +38,10 @@ for n, c in zip(names, med):
 wall = (clk[:, 17] - clk[:, 16]).astype(np.float64) / 100e6
 cyc = (clk[:, 14] - clk[:, 0]).astype(np.float64)
 print("in-kernel wall us (median)", np.median(wall) * 1e6, " shader clock GHz (median)", np.median(cyc / wall) / 1e9)
+t_s = (clk[:, 16] - clk[:, 16].min()).astype(np.float64) / 100.0  # us after the first workgroup's start
+t_e = (clk[:, 17] - clk[:, 16].min()).astype(np.float64) / 100.0
+print("workgroup starts after the first (us): median %.2f  p90 %.2f  max %.2f;  ends: min %.2f  median %.2f  max %.2f;  wall min / max %.2f / %.2f"
+      % (np.median(t_s), np.percentile(t_s, 90), t_s.max(), t_e.min(), np.median(t_e), t_e.max(), wall.min() * 1e6, wall.max() * 1e6))
 if n_steps == 1:  # whole-network kernel: slot 1 - slot 0 is the level-0 down phase; 18..22 and 23..28 detail the two level-0 phases
     dphase = np.diff(clk[:, 18:23].astype(np.int64), axis=1)
     print("level-0 down phase median cycles: load x %d  inc %d  down0.same (two passes) %d  down0.down (MFMA) %d" % tuple(np.median(dphase, axis=0)))

@@ -49,7 +49,8 @@ constexpr int B3_OFF_X0 = B3_OFF_R, B3_OFF_X1 = B3_OFF_X0 + 16 * S0 * 4, B3_OFF_
 // stage-3 input as a chunk-plane three-piece image (conv_b3.h): sample t at column t + 2, 400 columns, no padding channels
 constexpr int B3_X3_NC = 400, B3_X3_C0 = 2;
 using QX3 = B3Chunk<32, B3_X3_NC>;
-constexpr int B3_LDS_BYTES = B3_OFF_X3 + 3 * QX3::PS * 2;
+constexpr int B3_OFF_EDGE = B3_OFF_X3 + 3 * QX3::PS * 2;  // [8 waves][64] partial sums of the two edge samples
+constexpr int B3_LDS_BYTES = B3_OFF_EDGE + D03_WAVES * 64 * 4;
 static_assert(B3_X3_NC >= C3 + 4 + 0 && B3_X3_NC >= L3 + B3_X3_C0, "every column stage 3 reads has a place");
 static_assert(B3_OFF_X1 + 3 * B3_X1_PS * 2 <= B3_LDS_BYTES && B3_LDS_BYTES <= 160 * 1024 && B3_OFF_R % 16 == 0 && B3_OFF_X1 % 16 == 0,
               "LDS budget of the bf16-piece variant");
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
     asm volatile("" : "+v"(o_r));
     float* X0 = reinterpret_cast<float*>(base + 16 * o_r);
     bf16_t* X3 = reinterpret_cast<bf16_t*>(base + 16 * o_r);
+    float* EDGE = reinterpret_cast<float*>(base + B3_OFF_EDGE);
     const B3Image<64> iX1{reinterpret_cast<bf16_t*>(base + B3_OFF_X1), B3_X1_PS, 1}, iX2{reinterpret_cast<bf16_t*>(base + B3_OFF_X2), B3_X2_PS, 1};
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -209,34 +211,31 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
           const int col = k < B3_X3_C0 ? k : L3 + k;
           *reinterpret_cast<uint4*>(X3 + (cp >> 2) * QX3::PS + (cp & 3) * QX3::CHS + col * 8) = make_uint4(0u, 0u, 0u, 0u);
         }
+        // The two samples at the cropped edge (decoder2_edge_kernel, eqt.hip): lane = (channel, which sample), 64 input channels x
+        // 3 pre-summed taps.  Every wave takes eight input channels -- weights requested here, used behind the conv -- and leaves
+        // its partial sum in LDS (one wave doing all 64 kept the other seven at the barrier for 10 k cycles per row).
+        constexpr int n0 = (L3 - 2 - 2) >> 1;
+        float ew[8][3];
+        {
+          const float* e = a.edge_w + ((long)d * 64 * 64 + lane) * 3 + (long)(8 * wave_u) * 64 * 3;
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ew[u][k] = e[u * 64 * 3 + k];
+        }
         const ClipQuad st{X3, L3 - 2};
         conv_b3<D_2, true, 64, 64>(iX2, iX2, a.af3[1] + d * a.af3_stride[1], a.bs[2] + d * 32, C2, st, wave_u, D03_WAVES, lane);
-        if (wave_u == D03_WAVES - 1) {
-          constexpr int n0 = (L3 - 2 - 2) >> 1;
-          const float* e = a.edge_w + ((long)d * 64 * 64 + lane) * 3;
-          float acc = a.edge_b[d * 32 + (lane >> 1)];
-          for (int ci0 = 0; ci0 < 64; ci0 += 16) {  // the weights of 16 input channels requested together, then used
-            float wv[16][3];
+        float pacc = 0.f;
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
+        for (int u = 0; u < 8; ++u) {
+          const bf16_t* xs = iX2.img + (n0 + iX2.c0) * 72 + 8 * wave_u + u;
 #pragma unroll
-              for (int k = 0; k < 3; ++k) wv[u][k] = e[(long)(ci0 + u) * 64 * 3 + k];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-              const bf16_t* xs = iX2.img + (n0 + iX2.c0) * 72 + ci0 + u;
-#pragma unroll
-              for (int k = 0; k < 3; ++k) {
-                const float x = (from_bf16(xs[k * 72]) + from_bf16(xs[k * 72 + iX2.ps])) + from_bf16(xs[k * 72 + 2 * iX2.ps]);  // exact
-                acc = fmaf(wv[u][k], x, acc);
-              }
-            }
+          for (int k = 0; k < 3; ++k) {
+            const float x = (from_bf16(xs[k * 72]) + from_bf16(xs[k * 72 + iX2.ps])) + from_bf16(xs[k * 72 + 2 * iX2.ps]);  // exact
+            pacc = fmaf(ew[u][k], x, pacc);
           }
-          unsigned short h, m, l;
-          b3_split(fmaxf(acc, 0.f), h, m, l);
-          const int ch = lane >> 1;
-          bf16_t* q = X3 + (ch >> 3) * QX3::CHS + (L3 - 2 + (lane & 1) + B3_X3_C0) * 8 + (ch & 7);
-          q[0] = h, q[QX3::PS] = m, q[2 * QX3::PS] = l;
         }
+        EDGE[wave_u * 64 + lane] = pacc;
       }
       // stage 3's operand (m-tile mt23 = channels 8 mt23 .. + 7, both phases): 60 registers, so only now that stage 2's are free
       uint4 a3[B3Steps<32, 5>::STEPS * 3];
@@ -249,6 +248,16 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
         load_stage0(nd);
       }
       __syncthreads();
+      if (blk23 == 1) {  // the four waves whose last n-tiles read the edge samples finish them, each for itself (same values)
+        float acc = a.edge_b[d * 32 + (lane >> 1)];
+#pragma unroll
+        for (int w8 = 0; w8 < D03_WAVES; ++w8) acc += EDGE[w8 * 64 + lane];
+        unsigned short h, m, l;
+        b3_split(fmaxf(acc, 0.f), h, m, l);
+        const int ch = lane >> 1;
+        bf16_t* q = X3 + (ch >> 3) * QX3::CHS + (L3 - 2 + (lane & 1) + B3_X3_C0) * 8 + (ch & 7);
+        q[0] = h, q[QX3::PS] = m, q[2 * QX3::PS] = l;
+      }
       {  // stage 3: 32 x 375 -> 32 x 750, straight to memory: rows (channel, phase), so a lane's accumulator pairs are
          // two consecutive samples of one channel (8-byte stores, full 128-byte lines per 16 lanes)
         float* yrow = a.y + (long)row * a.ws_y + HALO + (long)(mt23 * 8 + 2 * g) * a.ls_y;
