@@ -69,11 +69,11 @@ def _oracle_stages(net, x):
 
 # vp_config.reserved[7]: bit 0 = decoder.4 / .5 / .6+heads as three launches, bit 1 = decoder.0 .. .3 as five launches,
 # bit 2 = encoder.0 .. .2 as three launches, bit 3 = encoder.3 .. .6 as four launches; bit 4 = ResCNN on the fp32 MFMA,
-# bit 5 = every stage of the fused decoder.0 .. .3 on the fp32 MFMA, bit 6 = the fused decoder tail on the fp32 MFMA (the
-# default runs decoder stages 1, 2, 4, 5, 6, the heads and the ResCNN on the bf16 matrix cores with exact three-piece
-# operands: fp32-accurate, different rounding)
+# bit 5 = every stage of the fused decoder.0 .. .3 on the fp32 MFMA, bit 6 = the fused decoder tail, bit 7 = the fused encoder
+# 3-6 kernel on the fp32 MFMA (the default runs encoder stages 3-6, decoder stages 1-6, the heads and the ResCNN on the
+# bf16 matrix cores with exact three-piece operands: fp32-accurate, different rounding)
 UNFUSED = (0, 0, 0, 0, 0, 0, 0, 15)
-FP32_MFMA = 32 | 64
+FP32_MFMA = 32 | 64 | 128
 
 
 @pytest.fixture(scope="module")
@@ -131,8 +131,8 @@ def test_fused_decoder_kernels_are_bitwise_the_layer_launches(model_fp32_mfma, B
 
 
 @pytest.mark.parametrize("B", [1, 2, 5, 86, 256, 300])
-def test_bf16_piece_decoder_stages_agree_with_the_fp32_mfma_form(model, model_fp32_mfma, B):
-    """The default eqt_dec03_kernel runs stages 1 and 2 as six bf16 MFMAs per K-step over exact three-piece operands
+def test_bf16_piece_kernels_agree_with_the_fp32_mfma_forms(model, model_fp32_mfma, B):
+    """The default eqt_enc36_b3_kernel runs its four stages, eqt_dec03_kernel its stages 1-3 as six bf16 MFMAs per K-step over exact three-piece operands
     (conv_b3.h), eqt_tail3_kernel its three stages and the heads: what they drop is below the rounding of one fp32 product, so the two forms differ by fp32 rounding
     only -- for every row of batches that leave the persistent grid partly filled, filled, and wrapped (the fp32 image
     of stage 3 is rebuilt in the place of the stage-0 / stage-1 images every row)."""
@@ -140,7 +140,9 @@ def test_bf16_piece_decoder_stages_agree_with_the_fp32_mfma_form(model, model_fp
     xd = torch.from_numpy(x).cuda()
     got = model._forward_raw(xd, preprocess=True)
     want = model_fp32_mfma._forward_raw(xd, preprocess=True)
-    assert (got - want).abs().max().item() < 2e-6
+    # (2e-6 while only the decoder differed; rounding differences of the encoder pass through the BiLSTM / attention
+    # stages on their way out -- the distance of either form to the oracle is 6.5e-6, tools/err_check.py)
+    assert (got - want).abs().max().item() < 1e-5
     assert (got > 0).all() and (got < 1).all()
     again = model._forward_raw(xd, preprocess=True)
     assert torch.equal(got.view(torch.int32), again.view(torch.int32))

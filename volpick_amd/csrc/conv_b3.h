@@ -246,13 +246,13 @@ template <int C, int NC, int TAPS, int NB, class Finish>
 __device__ __forceinline__ void b3c_mac_tiles(const bf16_t* p, const uint4 (&a)[B3Steps<C, TAPS>::STEPS * 3], Finish finish) {
   using G = B3Steps<C, TAPS>;
   using Q = B3Chunk<C, NC>;
-  static_assert(G::KS == 1, "one 32-channel step per tap");
   constexpr int STEPS = G::STEPS;
   constexpr int AHEAD = 2, NBUF = AHEAD + 1, PAIRS = STEPS * NB;
   uint4 b[NBUF][3];
   auto load_b = [&](const int i) {
     const int s = i % STEPS, j = i / STEPS;
-    const int off = (s * G::TPK + j * 16) * 8;
+    // C >= 32: step = (tap, 32-channel step ks): four chunk planes further per ks; C < 32: TPK taps per step
+    const int off = ((C >= 32 ? s / G::KS : s * G::TPK) + j * 16) * 8 + (C >= 32 ? (s % G::KS) * 4 * Q::CHS : 0);
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) b[i % NBUF][pc] = *reinterpret_cast<const uint4*>(p + pc * Q::PS + off);
   };

@@ -505,7 +505,7 @@ int plan_eqt(Net& net, const ParamView& pv) {
   }
   // bit 3 keeps encoder.3 .. .6 as four launches
   if (!(net.cfg.reserved[7] & 8)) {
-    int rc = plan_eqt_fuse_enc36(net);
+    int rc = (net.cfg.reserved[7] & 128) ? plan_eqt_fuse_enc36(net) : plan_eqt_fuse_enc36_b3(net);  // bit 7: the fp32-MFMA kernel
     if (rc != VP_OK) return rc;
   }
   // bit 1 keeps decoder.0 .. .3 (+ the stage-2 edge fix) as five launches

@@ -7,8 +7,7 @@
 //     stage 6 columns n6 = t0/2 - 3 + [0, 606 / 640)  reads stage-5 samples [n6 - 3, n6 + 3]  (K = 11 folded to 7 taps)
 //     stage 5 columns n5 = t0/4 - 3 + [0, 306 / 320)  reads stage-4 samples [n5 - 2, n5 + 2]  (K = 9 folded to 5 taps)
 //     stage 4 columns n4 = t0/8 - 3 + [0, 156 / 160)  reads stage-3 samples [n4 - 2, n4 + 2]  (K = 7 folded to 5 taps)
-//   (needed / computed: every wave takes one block of n-tiles of one m-tile per stage: 3 / 6 / 6 the older, 2 / 4 / 4 the
-//   younger wave of a SIMD)
+//   (needed / computed: every wave takes one block of n-tiles of one m-tile per stage: 3 or 2 / 5 / 5)
 //
 // LDS (157 KB).  Three-piece images take 6 bytes per value against the 4 of fp32 rows, so a 2000-sample tile no longer
 // fits beside its staging: 1200-sample tiles, chunk-plane images [piece][8-channel chunk][column][8 channels] (conv_b3.h), and
@@ -51,9 +50,10 @@ constexpr int TW = 1200, TILES_PER_ROW = 5, T_OUT = 6000;
 constexpr int T3_NTH = 512, T3_WAVES = 8;
 // n-tiles per wave and stage: the first four waves of a workgroup (one per SIMD) are the OLDER wave of their SIMD, whose MFMAs
 // issue first; with equal shares the younger wave was still a quarter of a stage behind when the older one was through
-// (tools/tail_clock.py), so the older wave takes the larger share: 3 + 2, 6 + 4, 6 + 4 n-tiles per SIMD
-constexpr int NB4O = 3, NB4Y = 2, NB5O = 5, NB5Y = 5, NB6O = 5, NB6Y = 5;
-constexpr int C4 = 2 * (NB4O + NB4Y) * 16, C5 = 2 * (NB5O + NB5Y) * 16, C6 = 4 * (NB6O + NB6Y) * 16;  // columns computed: 160, 320, 640
+// (tools/tail_clock.py).  Stage 4 needs 10 n-tiles per phase: 3 to the older, 2 to the younger wave; stages 5 and 6 measured
+// no faster with 6 + 4 than with 5 + 5
+constexpr int NB4O = 3, NB4Y = 2, NB5 = 5, NB6 = 5;
+constexpr int C4 = 2 * (NB4O + NB4Y) * 16, C5 = 4 * NB5 * 16, C6 = T3_WAVES * NB6 * 16;  // columns computed: 160, 320, 640
 constexpr int PARK_COLS = 168;  // stage-3 samples a tile parks: the 160 its kept outputs need + the one more (161) that reaches them
                                 // through the zero-weight padded taps of stages 5 / 6 and the heads (0 x stale non-finite = NaN)
 constexpr int NC4 = 208, NC5 = C5 + 16, NC6 = C6 + 16;  // (a place for every column a stage writes or reads: no range tests)                            // image columns (every one a stage may read), 8 mod 16
@@ -199,8 +199,7 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
     __syncthreads();
     T3_STAMP(2)
     {  // stage 5: column c reads the image columns c + 1 + tap; output t = 2 c + p -> column t of the stage-6 input image
-      const bool older = w < 4;
-      const int ph = w & 1, colb = older ? (w >> 1) * (NB5O * 16) : 2 * NB5O * 16 + ((w - 4) >> 1) * (NB5Y * 16);
+      const int ph = w & 1, colb = (w >> 1) * (NB5 * 16);
       uint4 a5[B3Steps<16, 5>::STEPS * 3];  // this wave's operand: LDS -> registers for the stage
 #pragma unroll
       for (int i = 0; i < B3Steps<16, 5>::STEPS * 3; ++i) a5[i] = A5[ph * (A5_N / 2) + i * 64 + lane];
@@ -211,16 +210,14 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
         t3_finish(acc, bias5, (unsigned)(t - lo) < 3000u, v);
         b3c_store4<16, NC6>(IN6, t, g, v);
       };
-      if (older) b3c_mac_tiles<16, NC5, 5, NB5O>(b3c_lane_ptr<16, NC5, 5>(IN5, colb + 1, lane), a5, finish);
-      else b3c_mac_tiles<16, NC5, 5, NB5Y>(b3c_lane_ptr<16, NC5, 5>(IN5, colb + 1, lane), a5, finish);
+      b3c_mac_tiles<16, NC5, 5, NB5>(b3c_lane_ptr<16, NC5, 5>(IN5, colb + 1, lane), a5, finish);
     }
     __syncthreads();
     T3_STAMP(3)
     if (more) request(nid);  // travels under stage 6 and the heads
     {  // stage 6: column c reads the image columns c + tap; one m-tile: lane group g holds phase g / 2, channels 4 (g % 2) ..;
        // output t = 2 c + p = sample t0 - 6 + t of the row -> 8-byte unit (t % 16) * HSB + t / 16 of its quad's staging plane
-      const bool older = w < 4;
-      const int colb = older ? w * (NB6O * 16) : 4 * NB6O * 16 + (w - 4) * (NB6Y * 16), ph = g >> 1;
+      const int colb = w * (NB6 * 16), ph = g >> 1;
       uint4 a6[B3Steps<16, 7>::STEPS * 3];
 #pragma unroll
       for (int i = 0; i < B3Steps<16, 7>::STEPS * 3; ++i) a6[i] = A6[i * 64 + lane];
@@ -239,8 +236,7 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
         q[2 * j + OUT_PS] = make_uint2(m0, m1);
         q[2 * j + 2 * OUT_PS] = make_uint2(l0, l1);
       };
-      if (older) b3c_mac_tiles<16, NC6, 7, NB6O>(b3c_lane_ptr<16, NC6, 7>(IN6, colb, lane), a6, finish);
-      else b3c_mac_tiles<16, NC6, 7, NB6Y>(b3c_lane_ptr<16, NC6, 7>(IN6, colb, lane), a6, finish);
+      b3c_mac_tiles<16, NC6, 7, NB6>(b3c_lane_ptr<16, NC6, 7>(IN6, colb, lane), a6, finish);
     }
     __syncthreads();
     T3_STAMP(4)
@@ -362,7 +358,7 @@ int plan_eqt_fuse_tail_b3(Net& net) {
   st.flops_per_window = 0;
   for (int i = 0; i < 3; ++i) st.flops_per_window += net.steps[first + i].flops_per_window;
   {  // matrix work issued per tile, as fp32-equivalent FLOP: one group of six bf16 MFMAs = one 16 x 16 x 32 fp32-accurate product
-    const double groups = 4.0 * (NB4O + NB4Y) * 5 + 4.0 * (NB5O + NB5Y) * 3 + 4.0 * (NB6O + NB6Y) * 4 + 5.0 * 7;
+    const double groups = 4.0 * (NB4O + NB4Y) * 5 + 8.0 * NB5 * 3 + 8.0 * NB6 * 4 + 5.0 * 7;
     st.issued_flops_per_window = 3.0 * TILES_PER_ROW * groups * 16384.0;
   }
   st.run = [=](Net& n, int B, hipStream_t s) -> int {
