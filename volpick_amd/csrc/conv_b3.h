@@ -38,13 +38,15 @@ __device__ __forceinline__ void b3_split(const float v, unsigned short& h, unsig
 }
 // four consecutive channels ch .. ch + 3 of column col: one 8-byte store per piece
 __device__ __forceinline__ void b3_store4(bf16_t* img, const int ps, const int cs, const int col, const int ch, const float (&v)[4]) {
-  unsigned short h[4], m[4], l[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) b3_split(v[i], h[i], m[i], l[i]);
+  // pairs at a time: one v_cvt_pk_bf16_f32 rounds two values and leaves them packed (the same pieces as b3_split's)
+  const unsigned h0 = pack_bf16x2(v[0], v[1]), h1 = pack_bf16x2(v[2], v[3]);
+  const float r0 = v[0] - bf16_lo(h0), r1 = v[1] - bf16_hi(h0), r2 = v[2] - bf16_lo(h1), r3 = v[3] - bf16_hi(h1);
+  const unsigned m0 = pack_bf16x2(r0, r1), m1 = pack_bf16x2(r2, r3);
+  const unsigned l0 = pack_bf16x2(r0 - bf16_lo(m0), r1 - bf16_hi(m0)), l1 = pack_bf16x2(r2 - bf16_lo(m1), r3 - bf16_hi(m1));
   bf16_t* p = img + col * cs + ch;
-  *reinterpret_cast<uint2*>(p) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-  *reinterpret_cast<uint2*>(p + ps) = make_uint2((unsigned)m[0] | ((unsigned)m[1] << 16), (unsigned)m[2] | ((unsigned)m[3] << 16));
-  *reinterpret_cast<uint2*>(p + 2 * ps) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+  *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(p + ps) = make_uint2(m0, m1);
+  *reinterpret_cast<uint2*>(p + 2 * ps) = make_uint2(l0, l1);
 }
 
 // Output side of a layer: a three-piece image.  Columns [col_lo, col_hi) are the ones the layer's tiles write (zeros
