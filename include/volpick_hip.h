@@ -70,7 +70,7 @@ typedef struct {
                                       time-tiled fused kernel, bit3 = encoder stages 3-6 as four launches instead of one
                                       per-window fused kernel (all bit-identical; layer tests, A/B timing),
                                       bit4 = the fused ResCNN kernel, bit5 = stages 1 and 2 of the fused decoder 0-3
-                                      kernel, bit6 = the fused decoder tail (stages 4-6 + heads), bit7 = the fused encoder 3-6 kernel on the fp32 MFMA
+                                      kernel, bit6 = the fused decoder tail (stages 4-6 + heads), bit7 = the fused encoder 3-6 kernel, bit8 = stages 1 and 2 of the fused encoder 0-2 kernel on the fp32 MFMA
                                       instead of the bf16 matrix cores with exact three-piece operands (the two
                                       forms agree to fp32 rounding, not bitwise) */
 } vp_config;

@@ -70,10 +70,10 @@ def _oracle_stages(net, x):
 # vp_config.reserved[7]: bit 0 = decoder.4 / .5 / .6+heads as three launches, bit 1 = decoder.0 .. .3 as five launches,
 # bit 2 = encoder.0 .. .2 as three launches, bit 3 = encoder.3 .. .6 as four launches; bit 4 = ResCNN on the fp32 MFMA,
 # bit 5 = every stage of the fused decoder.0 .. .3 on the fp32 MFMA, bit 6 = the fused decoder tail, bit 7 = the fused encoder
-# 3-6 kernel on the fp32 MFMA (the default runs encoder stages 3-6, decoder stages 1-6, the heads and the ResCNN on the
+# 3-6 kernel, bit 8 = stages 1 and 2 of the fused encoder 0-2 kernel on the fp32 MFMA (the default runs encoder stages 1-6, decoder stages 1-6, the heads and the ResCNN on the
 # bf16 matrix cores with exact three-piece operands: fp32-accurate, different rounding)
 UNFUSED = (0, 0, 0, 0, 0, 0, 0, 15)
-FP32_MFMA = 32 | 64 | 128
+FP32_MFMA = 32 | 64 | 128 | 256
 
 
 @pytest.fixture(scope="module")

@@ -14,7 +14,7 @@ with torch.no_grad():
     orc64 = load_pretrained("eqtransformer").double()
     w64 = torch.stack(orc64(xn.double()), 1).numpy()
 print("oracle fp32 vs fp64: max %.2e mean %.2e" % (np.abs(w32 - w64).max(), np.abs(w32 - w64).mean()))
-for name, flags in [("default (bf16 pieces)", (0,)), ("all fp32 MFMA", (0, 0, 0, 0, 0, 0, 0, 240)), ("only encoder 3-6 bf16", (0, 0, 0, 0, 0, 0, 0, 112)), ("layer plan", (1, 0, 0, 0, 0, 0, 0, 15))]:
+for name, flags in [("default (bf16 pieces)", (0,)), ("all fp32 MFMA", (0, 0, 0, 0, 0, 0, 0, 496)), ("only encoder 3-6 bf16", (0, 0, 0, 0, 0, 0, 0, 368)), ("only encoder 1-2 bf16", (0, 0, 0, 0, 0, 0, 0, 240)), ("layer plan", (1, 0, 0, 0, 0, 0, 0, 15))]:
     m = EQTransformer.from_pretrained("volpick"); m._plan_flags = flags; m.cuda()
     got = torch.stack(list(m(xn.cuda())), 1).double().cpu().numpy()
     e64 = np.abs(got - w64); e32 = np.abs(got - w32)

@@ -31,9 +31,9 @@ chk
 timeout -k 10 200 python tools/ab_steps.py eqtransformer "0" "0,0,0,0,0,0,0,15" > $O/eqt_fused_vs_layer_launches_steps.txt 2>&1
 chk
 ls -la $O
-# the bf16-piece kernels (encoder 3-6, ResCNN, decoder 0-3 stages 1-3, decoder tail) against their fp32-MFMA forms, same box
-timeout -k 10 200 python tools/ab_steps.py eqtransformer "0" "0,0,0,0,0,0,0,240" > $O/eqt_bf16_pieces_vs_fp32_mfma_steps.txt 2>&1
+# the bf16-piece kernels (encoder 1-6, ResCNN, decoder 0-3 stages 1-3, decoder tail) against their fp32-MFMA forms, same box
+timeout -k 10 200 python tools/ab_steps.py eqtransformer "0" "0,0,0,0,0,0,0,496" > $O/eqt_bf16_pieces_vs_fp32_mfma_steps.txt 2>&1
 chk
-tools/ab_e2e.sh 2 0 0,0,0,0,0,0,0,240 > $O/eqt_bf16_pieces_vs_fp32_mfma_e2e.txt 2>&1
+tools/ab_e2e.sh 2 0 0,0,0,0,0,0,0,496 > $O/eqt_bf16_pieces_vs_fp32_mfma_e2e.txt 2>&1
 chk
 ls -la $O

@@ -500,7 +500,7 @@ int plan_eqt(Net& net, const ParamView& pv) {
   }
   // bit 2 keeps encoder.0 .. .2 as three launches
   if (!(net.cfg.reserved[7] & 4)) {
-    int rc = plan_eqt_fuse_front(net);
+    int rc = plan_eqt_fuse_front(net, !(net.cfg.reserved[7] & 256));  // bit 8: stages 1 and 2 on the fp32 MFMA too
     if (rc != VP_OK) return rc;
   }
   // bit 3 keeps encoder.3 .. .6 as four launches

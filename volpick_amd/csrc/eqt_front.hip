@@ -21,6 +21,7 @@
 // pool neighbouring columns = neighbouring lanes (one DPP move) and the even lane stores.
 // Same packed fragments, same K order, same max / ReLU arithmetic: bit-identical to the launches it replaces
 // (plan flag reserved[7] & 4 keeps them).
+#include "conv_b3.h"
 #include "conv_lds.h"
 #include "eqt_kernels.h"
 #include "net.h"
@@ -47,6 +48,21 @@ static_assert(SI >= BII + 2 * (C0 - 1) + 12 - 5 && S0P >= BI + C1 + 4 && S0P >= 
 constexpr int OFFI = 0, OFF0P = 4 * SI + 4 - (4 * SI) % 4, OFF1P = OFF0P + 8 * S0P, FR_LDS_FLOATS = OFF1P + 16 * S1P;
 static_assert(FR_LDS_FLOATS * 4 <= 160 * 1024 && OFF0P % 4 == 0 && OFF1P % 4 == 0, "LDS budget");
 constexpr int PRE = (3 * SI + FR_NTH - 1) / FR_NTH;  // input samples a thread carries for the next tile
+// B3 instantiation (default): stages 1 and 2 (73 % of the tile's MFMA issue) on the bf16 matrix cores with exact three-piece
+// operands (conv_b3.h).  Stage 0 (fp32 MFMA: 3 input channels) writes its pooled output as a chunk-plane piece image
+// [piece][column][8 channels] (column = its MFMA column), stage 1 packs four taps of its 8 channels into a K = 32 step
+// (9 taps -> 3 steps) and writes [piece][2 chunks][column][8 channels] (column = pooled index), stage 2 packs two taps of
+// 16 channels (7 -> 4 steps) and writes the pooled row to memory.  The columns behind what a stage writes stay zero from
+// the one fill at kernel start (nothing is aliased); every column a kept output touches, padded taps included, is written
+// in the same tile.
+constexpr int NC0 = 1040, NC1 = 528;
+using QE0 = B3Chunk<8, NC0>;
+using QE1 = B3Chunk<16, NC1>;
+static_assert(NC0 >= C1 + 12 && NC1 >= C2 + 8, "every column stages 1 / 2 read has a place");
+static_assert(1012 + 11 <= C0 && 500 + 7 <= C1 / 2, "kept outputs touch only columns written in the same tile");
+constexpr int FB_OFF_E0 = (4 * SI + 4) * 4 + 16 - ((4 * SI + 4) * 4) % 16, FB_OFF_E1 = FB_OFF_E0 + 3 * QE0::PS * 2;
+constexpr int FB_LDS_BYTES = FB_OFF_E1 + 3 * QE1::PS * 2;
+static_assert(FB_LDS_BYTES <= 160 * 1024 && FB_OFF_E0 % 16 == 0 && FB_OFF_E1 % 16 == 0, "LDS budget of the bf16-piece variant");
 
 struct FrontArgs {
   const float* x;  // input rows [B][3][ls]
@@ -57,6 +73,7 @@ struct FrontArgs {
   long ws_y;
   const float* af[3];  // packed A fragments [CB][TAPS][64]
   const float* bs[3];
+  const uint4* af3[2];  // B3: three-piece operands of stages 1 and 2 [steps][piece][64] (net.hip: b3_operand)
   int n_tiles;
 };
 
@@ -82,6 +99,34 @@ struct Pool0Store {
         if (!fast) v = ((unsigned)(s_lo + colb + j * 16 + n) < (unsigned)L0P) ? v : 0.f;
         row[j * 16] = v;
       }
+    }
+  }
+};
+
+// B3, stage 0: the same pooling, the pooled sample of column c of channels 2 g, 2 g + 1 as a pair of bfloat16 per piece
+struct Pool0Pieces {
+  static constexpr bool custom_block_epilogue = true;
+  bf16_t* img;
+  int s_lo;
+  template <class L>
+  __device__ __forceinline__ void block_epilogue(const f32x4 (&acc)[L::NB], const float (&biasv)[4], const int mt, const int colb,
+                                                 const int g, const int n) const {
+    static_assert(L::P == 2 && L::MT == 1 && L::RELU == 1, "stage 0 of the encoder");
+    (void)mt;
+    const bool fast = (unsigned)(s_lo + colb) < (unsigned)L0P && (unsigned)(s_lo + colb + L::NB * 16 - 1) < (unsigned)L0P;
+    bf16_t* q = img + (colb + n) * 8 + 2 * g;
+#pragma unroll
+    for (int j = 0; j < L::NB; ++j) {
+      float v0 = fmaxf(fmaxf(acc[j][0] + biasv[0], 0.f), fmaxf(acc[j][1] + biasv[1], 0.f));
+      float v1 = fmaxf(fmaxf(acc[j][2] + biasv[2], 0.f), fmaxf(acc[j][3] + biasv[3], 0.f));
+      if (!fast && !((unsigned)(s_lo + colb + j * 16 + n) < (unsigned)L0P)) v0 = v1 = 0.f;
+      const unsigned h = pack_bf16x2(v0, v1);
+      const float r0 = v0 - bf16_lo(h), r1 = v1 - bf16_hi(h);
+      const unsigned m = pack_bf16x2(r0, r1);
+      const unsigned l = pack_bf16x2(r0 - bf16_lo(m), r1 - bf16_hi(m));
+      *reinterpret_cast<unsigned*>(q + j * 128) = h;
+      *reinterpret_cast<unsigned*>(q + j * 128 + QE0::PS) = m;
+      *reinterpret_cast<unsigned*>(q + j * 128 + 2 * QE0::PS) = l;
     }
   }
 };
@@ -116,6 +161,7 @@ struct Pool1Store {
   }
 };
 
+template <bool B3>
 __global__ __launch_bounds__(FR_NTH) void eqt_front_kernel(const FrontArgs a) {
   extern __shared__ float4 fr_lds_raw[];
   float* lds = reinterpret_cast<float*>(fr_lds_raw);
@@ -124,12 +170,18 @@ __global__ __launch_bounds__(FR_NTH) void eqt_front_kernel(const FrontArgs a) {
   float* XI = lds + OFFI;
   float* E0P = lds + 4 * off0;
   float* E1P = lds + 4 * off1;
+  bf16_t* E0 = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(fr_lds_raw) + FB_OFF_E0);  // B3
+  bf16_t* E1 = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(fr_lds_raw) + FB_OFF_E1);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   int tile = blockIdx.x;
   if (tile >= a.n_tiles) return;
   // the fourth channel row of the input image pads K to the 4-channel MFMA step: zero, once
   for (int i = tid; i < SI + 4; i += FR_NTH) XI[3 * SI + i] = 0.f;
+  if constexpr (B3) {  // the piece images: the columns no stage writes are read (zero weights, unkept outputs) and must be finite
+    uint4* z = reinterpret_cast<uint4*>(reinterpret_cast<char*>(fr_lds_raw) + FB_OFF_E0);
+    for (int i = tid; i < (FB_LDS_BYTES - FB_OFF_E0) / 16; i += FR_NTH) z[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
 
   // input samples of a tile: 3 rows x the SI physical columns of the image; column p <-> sample 8 j0 - 28 + p of the row,
   // zero outside [0, 6000)
@@ -162,6 +214,15 @@ __global__ __launch_bounds__(FR_NTH) void eqt_front_kernel(const FrontArgs a) {
   load_biasreg<F_e0>(a.bs[0], 0, lane, bias0);
   load_biasreg<F_e1>(a.bs[1], 0, lane, bias1);
   load_biasreg<F_e2>(a.bs[2], 0, lane, bias2);
+  uint4 a1[B3Steps<8, 9>::STEPS * 3], a2[B3Steps<16, 7>::STEPS * 3];  // B3: the operands of stages 1 and 2, for the whole kernel
+  float b1v[4], b2v[4];
+  if constexpr (B3) {
+    b3_load_a<8, 9>(a.af3[0], 0, lane, a1);
+    b3_load_a<16, 7>(a.af3[1], 0, lane, a2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b1v[r] = a.bs[1][4 * (lane >> 4) + r], b2v[r] = a.bs[2][4 * (lane >> 4) + r];
+    __syncthreads();  // the zero fill of the piece images
+  }
 
   while (true) {
     const int next = tile + gridDim.x;
@@ -169,6 +230,45 @@ __global__ __launch_bounds__(FR_NTH) void eqt_front_kernel(const FrontArgs a) {
     const int win = tile / FR_TILES, j0 = (tile - win * FR_TILES) * FW;
     park();
     __syncthreads();
+    if constexpr (B3) {
+      const int n = lane & 15, g = lane >> 4;
+      {  // stage 0 (fp32 MFMA): column c <-> pooled sample 4 j0 - 10 + c -> column c of the stage-1 piece image
+        Pool0Pieces st{E0, 4 * j0 - 10};
+        conv_lds_areg<F_e0, SI, BII, SI, BII>(XI, XI, areg0, bias0, 0, C0, st, wave_u, FR_WAVES, lane);
+      }
+      __syncthreads();
+      if (more) request(next);  // travels under stages 1 and 2
+      __builtin_amdgcn_sched_barrier(0);
+      {  // stage 1: column c <-> conv sample 4 j0 - 6 + c reads image columns c .. c + 8; pooled -> column c / 2 of the stage-2 image
+        const int colb = wave_u * 128, s_lo = 4 * j0 - 6;
+        b3c_mac_tiles<8, NC0, 9, 8>(b3c_lane_ptr<8, NC0, 9>(E0, colb, lane), a1, [&](const int j, const f32x4 acc) {
+          const int c = colb + j * 16 + n;
+          const bool in = (unsigned)(s_lo + c) < (unsigned)L0P;
+          float m[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = in ? fmaxf(acc[r] + b1v[r], 0.f) : 0.f;
+            m[r] = fmaxf(v, lane_xor1(v));
+          }
+          if (!(n & 1)) b3c_store4<16, NC1>(E1, c >> 1, g, m);
+        });
+      }
+      __syncthreads();
+      {  // stage 2: column c <-> conv sample 2 j0 + c reads image columns c .. c + 6; pooled sample j0 + c / 2 of the encoder.2 row
+        const int colb = wave_u * 64;
+        float* y = a.y + (long)win * a.ws_y + HALO + j0 + (long)(4 * g) * a.ls_y;
+        b3c_mac_tiles<16, NC1, 7, 4>(b3c_lane_ptr<16, NC1, 7>(E1, colb, lane), a2, [&](const int j, const f32x4 acc) {
+          const int c = colb + j * 16 + n;
+          const bool in = (unsigned)(2 * j0 + c) < (unsigned)L1P;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = in ? fmaxf(acc[r] + b2v[r], 0.f) : 0.f;
+            const float m = fmaxf(v, lane_xor1(v));
+            if (!(n & 1) && c < 2 * FW) y[(long)r * a.ls_y + (c >> 1)] = m;
+          }
+        });
+      }
+    } else {
     {  // stage 0: column c <-> pooled sample 4 j0 - 10 + c = stage-1 logical column c - 4
       Pool0Store st{E0P + BI - 4, 4 * j0 - 10};
       conv_lds_areg<F_e0, SI, BII, SI, BII>(XI, XI, areg0, bias0, 0, C0, st, wave_u, FR_WAVES, lane);
@@ -185,6 +285,7 @@ __global__ __launch_bounds__(FR_NTH) void eqt_front_kernel(const FrontArgs a) {
       Pool1Store<true> st{a.y + (long)win * a.ws_y + HALO + j0, a.ls_y, 2 * j0, (unsigned)L1P, 2 * FW};
       conv_lds_areg<F_e2, S1P, BI, S1P, BI>(E1P, E1P, areg2, bias2, 0, C2, st, wave_u, FR_WAVES, lane);
     }
+    }
     if (!more) break;
     tile = next;
     // no barrier: the next park writes the input image, whose last readers (stage 0) are two barriers back
@@ -194,7 +295,7 @@ __global__ __launch_bounds__(FR_NTH) void eqt_front_kernel(const FrontArgs a) {
 }  // namespace
 
 // Replaces the steps "encoder.0", "encoder.1", "encoder.2" of the plan by one fused step.
-int plan_eqt_fuse_front(Net& net) {
+int plan_eqt_fuse_front(Net& net, bool b3) {
   int first = -1;
   for (size_t i = 0; i < net.steps.size(); ++i)
     if (net.steps[i].name == "encoder.0") first = (int)i;
@@ -209,6 +310,14 @@ int plan_eqt_fuse_front(Net& net) {
   if (!c[0] || !c[1] || !c[2]) {
     set_error("fused encoder front: conv layers missing");
     return VP_ERR_INVALID;
+  }
+  HostBlob* p3[2] = {nullptr, nullptr};
+  if (b3) {
+    if (c[1]->g.cinp() != 8 || c[1]->g.taps != 9 || c[1]->g.M() != 16 || c[2]->g.cinp() != 16 || c[2]->g.taps != 7 || c[2]->g.M() != 16) {
+      set_error("fused encoder front: unexpected layer shape");
+      return VP_ERR_INVALID;
+    }
+    for (int i = 0; i < 2; ++i) p3[i] = net.add_blob(b3_operand(*c[1 + i], false));
   }
   const int x_in = c[0]->src1, y_out = c[2]->dst;
   net.tensor_sets[c[0]->dst] = 0;  // encoder.0 / .1 live in LDS under this plan
@@ -233,10 +342,18 @@ int plan_eqt_fuse_front(Net& net) {
     }
     a.n_tiles = B * FR_TILES;
     const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
-    hipLaunchKernelGGL(eqt_front_kernel, dim3(grid), dim3(FR_NTH), FR_LDS_FLOATS * sizeof(float), s, a);
+    if (b3) {
+      for (int i = 0; i < 2; ++i) a.af3[i] = reinterpret_cast<const uint4*>(p3[i]->d);
+      hipLaunchKernelGGL(eqt_front_kernel<true>, dim3(grid), dim3(FR_NTH), FB_LDS_BYTES, s, a);
+    } else {
+      hipLaunchKernelGGL(eqt_front_kernel<false>, dim3(grid), dim3(FR_NTH), FR_LDS_FLOATS * sizeof(float), s, a);
+    }
     return 0;
   };
-  net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_front_kernel), FR_LDS_FLOATS * sizeof(float)});
+  if (b3)
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_front_kernel<true>), (size_t)FB_LDS_BYTES});
+  else
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_front_kernel<false>), FR_LDS_FLOATS * sizeof(float)});
   net.steps.erase(net.steps.begin() + first, net.steps.begin() + first + 3);
   net.steps.insert(net.steps.begin() + first, std::move(st));
   return VP_OK;

@@ -116,7 +116,7 @@ int plan_eqt(Net& net, const ParamView& pv);
 int plan_eqt_fuse_res(Net& net);  // swaps the 14 ResCNN conv steps for one fused launch
 int plan_eqt_fuse_tail_b3(Net& net);  // the same on the bf16 matrix cores, exact three-piece operands (eqt_tail_b3.hip)
 int plan_eqt_fuse_tail(Net& net);  // swaps decoder.4 / .5 / .6+heads for one time-tiled fused launch (eqt_tail.hip)
-int plan_eqt_fuse_front(Net& net);  // swaps encoder.0 / .1 / .2 for one time-tiled fused launch (eqt_front.hip)
+int plan_eqt_fuse_front(Net& net, bool b3);  // swaps encoder.0 / .1 / .2 for one time-tiled fused launch (eqt_front.hip)
 int plan_eqt_fuse_enc36_b3(Net& net);  // the same on the bf16 matrix cores, exact three-piece operands (eqt_enc36_b3.hip)
 int plan_eqt_fuse_enc36(Net& net);  // swaps encoder.3 .. .6 for one launch per window (eqt_enc36.hip)
 int plan_eqt_fuse_dec03(Net& net, bool b3);  // swaps decoder.0 / .1 / .2 / .2.edge / .3 for one launch per (decoder, window) row (eqt_dec03.hip)
