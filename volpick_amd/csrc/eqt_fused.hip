@@ -185,6 +185,7 @@ struct Res3Args {
   const float* s_next[7];
   const float* b_next[7];
   long af_bytes_k3, af_bytes_k2;  // size of one conv's operand (L2 warm-up)
+  int warm;                       // 0: no pre-touch of the weights (plan flag reserved[4] = 1)
 };
 
 __device__ __forceinline__ void split3(const float v, unsigned short& h, unsigned short& m, unsigned short& l) {
@@ -273,16 +274,23 @@ __global__ __launch_bounds__(256) void eqt_res3_kernel(const Res3Args a) {
   __shared__ __attribute__((aligned(16))) bf16_t MID[3 * R3_PS];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), win = blockIdx.x;
   const int g = lane >> 4, n = lane & 15;
-  if (win < 8) {  // one workgroup per XCD touches every line of the weights up front (see eqt_res_kernel)
+  if (a.warm) {
+    // The weights (1 MB) have left L2 since the last launch (the other kernels of the step move 0.3 GB): every XCD's L2 is
+    // warmed up front, one word per 128-byte line (see eqt_res_kernel) -- by ALL workgroups of the XCD, each a slice of the
+    // lines (consecutive workgroups go to consecutive XCDs): as the job of the first workgroup of each XCD, pulling 2 MB
+    // through one CU made those eight workgroups, hence the launch, 4 us longer.
+    const int nx = gridDim.x >= 8 ? gridDim.x >> 3 : 1, xw = win >> 3;  // workgroups per XCD that take part; this one's index
     constexpr int kers_pf[7] = {3, 3, 3, 3, 2, 3, 2};
-    float sink = 0.f;
+    unsigned sink = 0u;
+    if (xw < nx) {
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int lines = (int)((kers_pf[i] == 3 ? a.af_bytes_k3 : a.af_bytes_k2) / 128);
-      for (int l = tid; l < lines; l += 256)
-        sink += __uint_as_float(reinterpret_cast<const unsigned*>(a.af1[i])[l * 32] ^ reinterpret_cast<const unsigned*>(a.af2[i])[l * 32]);
+      for (int i = 0; i < 7; ++i) {
+        const int lines = (int)((kers_pf[i] == 3 ? a.af_bytes_k3 : a.af_bytes_k2) / 128);
+        for (int l = xw * 256 + tid; l < lines; l += nx * 256)
+          sink ^= reinterpret_cast<const unsigned*>(a.af1[i])[l * 32] ^ reinterpret_cast<const unsigned*>(a.af2[i])[l * 32];
+      }
     }
-    if (sink == 1.2345678e-30f) a.out[0] = sink;  // never true: keeps the loads alive
+    if (sink == 0x12345678u && a.ls_x == -1) a.out[0] = __uint_as_float(sink);  // never true: keeps the loads alive
   }
   for (int i = tid; i < 3 * R3_PS / 8; i += 256) {  // zero halo columns (and everything else once)
     reinterpret_cast<uint4*>(ACT)[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -474,6 +482,7 @@ int plan_eqt_fuse_res(Net& net) {
       }
       a.af_bytes_k3 = 4L * 3 * 2 * 3 * 64 * 16;
       a.af_bytes_k2 = 4L * 2 * 2 * 3 * 64 * 16;
+      a.warm = n.cfg.reserved[4] != 1;
       hipLaunchKernelGGL(eqt_res3_kernel, dim3(B), dim3(256), 0, s, a);
       return 0;
     };
