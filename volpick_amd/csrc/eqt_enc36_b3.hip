@@ -59,17 +59,27 @@ struct Enc36B3Args {
   int B;
 };
 
-// b3_load_a with the pointer made opaque at every use: inside the window loop the per-lane 64-bit addresses of the 12-18
-// loads are loop invariants, and hipcc hoists them out of the loop and spills them (89 registers; every reload sits in front
-// of the load that needs it)
+// b3_load_a with a uniform base and an opaque 32-bit lane offset: inside the window loop the per-lane 64-bit addresses of
+// the 12-18 loads are loop invariants, and hipcc hoists them out of the loop and spills them (89 registers; every reload
+// sits in front of the load that needs it).  (Making the POINTER opaque loses its address space: flat loads, which
+// count in vmcnt and lgkmcnt and return out of order, so that every stage waited for the operand of the next.)
 template <int C, int TAPS>
 __device__ __forceinline__ void e3_load_a(const uint4* __restrict__ af3, const int mt, const int lane,
                                           uint4 (&a)[B3Steps<C, TAPS>::STEPS * 3]) {
   constexpr int N = B3Steps<C, TAPS>::STEPS * 3;
-  const uint4* p = af3 + (long)mt * (N * 64) + lane;
-  asm volatile("" : "+v"(p));
+  const uint4* p = af3 + (long)mt * (N * 64);  // uniform
+  unsigned off = (unsigned)lane;
+  asm volatile("" : "+v"(off));
 #pragma unroll
-  for (int i = 0; i < N; ++i) a[i] = p[i * 64];
+  for (int i = 0; i < N; ++i) a[i] = p[i * 64 + off];
+}
+
+// the lane's four consecutive values of a per-channel vector (uniform base, opaque 32-bit lane offset: see e3_load_a)
+__device__ __forceinline__ void e3_load4(const float* __restrict__ base, const int lane, float (&v)[4]) {
+  unsigned go = (unsigned)(lane >> 4);
+  asm volatile("" : "+v"(go));
+  const float4 q = reinterpret_cast<const float4*>(base)[go];
+  v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
 }
 
 __device__ __forceinline__ float lane_xor1(float v) { return dpp_move<0xB1, 0xF>(v); }  // quad_perm [1,0,3,2]
@@ -111,24 +121,32 @@ __global__ __launch_bounds__(E3_NTH) void eqt_enc36_b3_kernel(const Enc36B3Args 
     uint4 a3[B3Steps<16, 7>::STEPS * 3];
     float bias3[4];
     e3_load_a<16, 7>(a.af3[0], mt2, lane, a3);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bias3[r] = a.bs[0][mt2 * 16 + 4 * g + r];
-    {  // the window's 16 x 750 input -> the whole stage-3 image (zeros outside the row): an item = four channels of one column
+    e3_load4(a.bs[0] + mt2 * 16, lane, bias3);
+    {  // the window's 16 x 750 input -> the whole stage-3 image [0, 784) <-> samples -3 .. 780 (the tensor's margins are zero):
+       // an item = four channels of one column; all of a thread's items requested before the first is split
       const float* src = a.x + (long)win * a.ws_x + (HALO - K3);
-      for (int i = tid; i < 4 * NC3; i += E3_NTH) {
-        const int cq = i / NC3, col = i - cq * NC3;
-        float v[4];
+      constexpr int ITEMS = (4 * NC3 + E3_NTH - 1) / E3_NTH;
+      float v[ITEMS][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (unsigned)(col - K3) < (unsigned)N3 ? src[(long)(4 * cq + r) * a.ls_x + col] : 0.f;
-        b3c_store4<16, NC3>(X3, col, cq, v);
+      for (int r = 0; r < 4; ++r) {
+        const float* row = src + (long)r * a.ls_x;  // uniform base per channel-in-quad; 32-bit per-lane offsets
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+          const int i = tid + k * E3_NTH, cq = i / NC3, col = i - cq * NC3;
+          v[k][r] = i < 4 * NC3 ? row[(unsigned)(4 * cq * a.ls_x + col)] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < ITEMS; ++k) {
+        const int i = tid + k * E3_NTH, cq = i / NC3, col = i - cq * NC3;
+        if (i < 4 * NC3) b3c_store4<16, NC3>(X3, col, cq, v[k]);
       }
     }
     __syncthreads();  // also: every wave is through with stage 6 of the window before (region B)
     uint4 a4[B3Steps<32, 5>::STEPS * 3];
     float bias4[4];
     e3_load_a<32, 5>(a.af3[1], mt2, lane, a4);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bias4[r] = a.bs[1][mt2 * 16 + 4 * g + r];
+    e3_load4(a.bs[1] + mt2 * 16, lane, bias4);
     {  // stage 3: 16 x 750 -> 32 x 375
       zero_pads<Q4, 4, K4, NC4>(X4, N4, tid);
       const int colb = blk2 * (NB3 * 16);
@@ -143,8 +161,7 @@ __global__ __launch_bounds__(E3_NTH) void eqt_enc36_b3_kernel(const Enc36B3Args 
     uint4 a5[B3Steps<32, 5>::STEPS * 3];
     float bias5[4];
     e3_load_a<32, 5>(a.af3[2], mt4, lane, a5);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bias5[r] = a.bs[2][mt4 * 16 + 4 * g + r];
+    e3_load4(a.bs[2] + mt4 * 16, lane, bias5);
     {  // stage 4: 32 x 375 -> 32 x 188 (odd tail pooled alone)
       zero_pads<Q5, 4, K5, NC5>(X5, N5, tid);
       const int colb = blk2 * (NB4 * 16);
@@ -159,8 +176,7 @@ __global__ __launch_bounds__(E3_NTH) void eqt_enc36_b3_kernel(const Enc36B3Args 
     uint4 a6[B3Steps<64, 3>::STEPS * 3];
     float bias6[4];
     e3_load_a<64, 3>(a.af3[3], mt4, lane, a6);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bias6[r] = a.bs[3][mt4 * 16 + 4 * g + r];
+    e3_load4(a.bs[3] + mt4 * 16, lane, bias6);
     {  // stage 5: 32 x 188 -> 64 x 94
       zero_pads<Q6, 8, K6, NC6>(X6, N6, tid);
       const int colb = blk4 * (NB5 * 16);
@@ -176,8 +192,8 @@ __global__ __launch_bounds__(E3_NTH) void eqt_enc36_b3_kernel(const Enc36B3Args 
       float* y = a.y + (long)win * a.ws_y + HALO;
       float* act = a.act + (long)win * a.ws_a + HALO;
       float sc[4], sh[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sc[r] = a.bn_s[mt4 * 16 + 4 * g + r], sh[r] = a.bn_b[mt4 * 16 + 4 * g + r];
+      e3_load4(a.bn_s + mt4 * 16, lane, sc);
+      e3_load4(a.bn_b + mt4 * 16, lane, sh);
       const int colb = blk4 * (NB6 * 16);
       b3c_mac_tiles<64, NC6, 3, NB6>(b3c_lane_ptr<64, NC6, 3>(X6, colb, lane), a6, [&](const int j, const f32x4 acc) {
         const int c = colb + j * 16 + n;
