@@ -203,6 +203,7 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
         conv_b3<D_1, true, 64, 64>(iX1, iX1, a.af3[0] + d * a.af3_stride[0], a.bs[1] + d * 64, C1, st, wave_u, D03_WAVES, lane);
       }
       __syncthreads();
+      float eb;
       {  // stage 2: 64 x 188 -> 32 x 375 (three-piece image in the place of the dead stage-0 / stage-1 inputs: its padding
          // columns are cleared here, every row) + the two samples at the cropped edge from the definition
         constexpr int PADC = B3_X3_C0 + (B3_X3_NC - L3 - B3_X3_C0);  // columns 0, 1 and 377 .. 399
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
         // its partial sum in LDS (one wave doing all 64 kept the other seven at the barrier for 10 k cycles per row).
         constexpr int n0 = (L3 - 2 - 2) >> 1;
         float ew[8][3];
+        eb = a.edge_b[d * 32 + (lane >> 1)];  // used behind the next barrier: requested here, or its wait there covers the operand loads too
         {
           const float* e = a.edge_w + ((long)d * 64 * 64 + lane) * 3 + (long)(8 * wave_u) * 64 * 3;
 #pragma unroll
@@ -243,13 +245,13 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
       b3_load_a<32, 5>(a.af3[2] + d * a.af3_stride[2], mt23, lane, a3);
 #pragma unroll
       for (int r = 0; r < 4; ++r) bias3[r] = a.bs[3][d * 32 + mt23 * 8 + 2 * g + (r >> 1)];
-      if (more) {
-        request(next);
-        load_stage0(nd);
-      }
+      // the next row's input and stage-0 operand: requested unconditionally (the last row asks for its own again) -- behind a
+      // branch the number of loads in flight is unknown, and the wait for stage 3's operand would have to be for everything
+      request(more ? next : row);
+      load_stage0(nd);
       __syncthreads();
       if (blk23 == 1) {  // the four waves whose last n-tiles read the edge samples finish them, each for itself (same values)
-        float acc = a.edge_b[d * 32 + (lane >> 1)];
+        float acc = eb;
 #pragma unroll
         for (int w8 = 0; w8 < D03_WAVES; ++w8) acc += EDGE[w8 * 64 + lane];
         unsigned short h, m, l;
@@ -261,6 +263,9 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
       {  // stage 3: 32 x 375 -> 32 x 750, straight to memory: rows (channel, phase), so a lane's accumulator pairs are
          // two consecutive samples of one channel (8-byte stores, full 128-byte lines per 16 lanes)
         float* yrow = a.y + (long)row * a.ws_y + HALO + (long)(mt23 * 8 + 2 * g) * a.ls_y;
+        // one wait for the bias here, where every path passes: met first inside the stores' exec-masked blocks, it is waited
+        // for again at the top of every such block -- together with the stores of the n-tile before
+        asm volatile("" ::"v"(bias3[0]), "v"(bias3[1]), "v"(bias3[2]), "v"(bias3[3]));
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const int colb = (blk23 + 2 * k) * 96;
