@@ -159,15 +159,19 @@ __global__ __launch_bounds__(256) void eqt_res_kernel(const ResArgs a) {
 // time.  (Activations cut to two pieces would need five products and move the probabilities by up to 4e-5,
 // tools/split_bf16_study.py: not done -- parity first.)
 //   K of an instruction = 32 input channels at ONE tap (a lane supplies 8 consecutive channels), so the conv inputs
-//   rest in LDS as three bf16 images [piece][column][64 channels]: a B fragment is one 16-byte read per piece, and a
+//   rest in LDS as three bf16 images (layout below): a B fragment is one 16-byte read per piece, and a
 //   lane's four accumulator rows (four consecutive output channels of one column) are one 8-byte store per piece.
-//   Column stride 72 elements (144 bytes): the 16 columns of a read fall on disjoint banks.  The residual stream stays
-//   fp32.  The A operand: [m-tile][tap * 2 + channel half][piece][lane][8], 72 / 48 registers per conv and lane,
+//   The residual stream stays fp32.  The A operand: [m-tile][tap * 2 + channel half][piece][lane][8], 72 / 48 registers per conv and lane,
 //   requested one conv ahead.
 typedef __bf16 bf16x8_res __attribute__((ext_vector_type(8)));
-constexpr int R3_CS = 72;                    // elements per column of a piece image
-constexpr int R3_NC = 50;                    // columns: logical t = column - 1, t in [-1, 48]
-constexpr int R3_PS = R3_NC * R3_CS;         // elements per piece
+// piece images as chunk planes [piece][8 chunks of 8 channels][64 columns][8 channels] (the layout of conv_b3.h's B3Chunk<64, 64>):
+// a fragment piece = one ds_read_b128, 16 lanes reading 256 consecutive bytes, the planes 1 KB apart -- conflict-free.
+// (As [column][64 + 8 channels] the reads ran 2-way conflicted, and the four waves of a window read the SAME fragments:
+// 36 KB per K-step at 128 B/clk = the 288 cycles of the step's MFMAs, one wave per SIMD to hide nothing behind:
+// 3.9 k cycles per k = 3 conv for 1.7 k of MFMA issue, tools stamps of a diagnostic build.)
+constexpr int R3_NC = 64;                    // columns: logical t at column t + 1
+constexpr int R3_CHS = R3_NC * 8;            // elements per chunk plane
+constexpr int R3_PS = 8 * R3_CHS;            // elements per piece
 constexpr int R3_XS = 49;                    // fp32 residual rows
 
 struct Res3Args {
@@ -201,7 +205,7 @@ __device__ __forceinline__ void store3(bf16_t* img, const int col, const int ch,
   const float r0 = v[0] - bf16_lo(h0), r1 = v[1] - bf16_hi(h0), r2 = v[2] - bf16_lo(h1), r3 = v[3] - bf16_hi(h1);
   const unsigned m0 = pack_bf16x2(r0, r1), m1 = pack_bf16x2(r2, r3);
   const unsigned l0 = pack_bf16x2(r0 - bf16_lo(m0), r1 - bf16_hi(m0)), l1 = pack_bf16x2(r2 - bf16_lo(m1), r3 - bf16_hi(m1));
-  bf16_t* p = img + col * R3_CS + ch;
+  bf16_t* p = img + (ch >> 3) * R3_CHS + col * 8 + (ch & 7);
   *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
   *reinterpret_cast<uint2*>(p + R3_PS) = make_uint2(m0, m1);
   *reinterpret_cast<uint2*>(p + 2 * R3_PS) = make_uint2(l0, l1);
@@ -235,7 +239,7 @@ __device__ __forceinline__ void res3_mac(const bf16_t* src, const Res3A<TAPS>& A
   const int g = lane >> 4, n = lane & 15;
 #pragma unroll
   for (int j = 0; j < 3; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bf16_t* bp = src + (n + IN_OFF + 1) * R3_CS + 8 * g;  // column of logical t = n + IN_OFF, channels 8 g ..
+  const bf16_t* bp = src + g * R3_CHS + (n + IN_OFF + 1) * 8;  // chunk g (channels 8 g ..), column of logical t = n + IN_OFF
   uint4 bA[3][3], bB[3][3];  // [n-tile][piece], two sets: the reads of step s + 1 are issued before the MFMAs of step s
   auto load_b = [&](uint4 (&b)[3][3], const int s) {
     const int tap = s >> 1, ks = s & 1;
@@ -243,7 +247,7 @@ __device__ __forceinline__ void res3_mac(const bf16_t* src, const Res3A<TAPS>& A
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc)
-        b[j][pc] = *reinterpret_cast<const uint4*>(bp + pc * R3_PS + (j * 16 + tap) * R3_CS + ks * 32);
+        b[j][pc] = *reinterpret_cast<const uint4*>(bp + pc * R3_PS + (j * 16 + tap) * 8 + ks * 4 * R3_CHS);
   };
   load_b(bA, 0);
 #pragma unroll
