@@ -72,7 +72,8 @@ typedef struct {
                                       bit4 = the fused ResCNN kernel, bit5 = stages 1 and 2 of the fused decoder 0-3
                                       kernel, bit6 = the fused decoder tail (stages 4-6 + heads), bit7 = the fused encoder 3-6 kernel, bit8 = stages 1 and 2 of the fused encoder 0-2 kernel on the fp32 MFMA
                                       instead of the bf16 matrix cores with exact three-piece operands (the two
-                                      forms agree to fp32 rounding, not bitwise) */
+                                      forms agree to fp32 rounding, not bitwise), bit9 = the bf16-piece ResCNN kernel with
+                                      four waves per window (one per SIMD) instead of eight (K split over wave pairs) */
 } vp_config;
 
 /* Fills cfg with the defaults for model_kind. */
