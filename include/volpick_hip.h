@@ -52,7 +52,8 @@ typedef struct {
   float layernorm_eps;        /* EQT LayerNormalization eps */
   float norm_eps;             /* x / (amp + norm_eps) */
   int32_t taper_samples;      /* EQT half-cosine taper length (0 for PhaseNet) */
-  int32_t reserved[8];        /* [0]: 1 = PhaseNet layer-by-layer plan instead of the fused kernels (debug / A-B);
+  int32_t plan_flags[8];      /* plan selectors (debug plans, A/B timing; all 0 = the default plan):
+                                 [0]: 1 = PhaseNet layer-by-layer plan instead of the fused kernels (debug / A-B);
                                  [1]: bit0 = fused kernels also dump their LDS intermediates to the debug tensors
                                       (selects the three-launch plan), bit1 = per-layer clock stamps;
                                  [2]: 1 = hand-pipelined K loop in the PhaseNet MFMA layers (A/B);
@@ -74,6 +75,7 @@ typedef struct {
                                       instead of the bf16 matrix cores with exact three-piece operands (the two
                                       forms agree to fp32 rounding, not bitwise), bit9 = the bf16-piece ResCNN kernel with
                                       four waves per window (one per SIMD) instead of eight (K split over wave pairs) */
+  int32_t reserved[4];        /* must be 0 */
 } vp_config;
 
 /* Fills cfg with the defaults for model_kind. */
@@ -244,7 +246,7 @@ int vp_debug_tensor_read(vp_handle* h, int index, int B, float* host_out);  /* V
  * one stray word in a margin of tensor k - 1 for the duration of the scan (the checker checking itself: expect 1). */
 int vp_debug_check_halos(vp_handle* h, int self_test, int64_t* n_bad, const char** first_bad_tensor);
 
-/* Debug (handles created with reserved[1] & 2): B x 32 words per window of the fused PhaseNet core
+/* Debug (handles created with plan_flags[1] & 2): B x 32 words per window of the fused PhaseNet core
  * kernel: [0..14] shader-clock stamps (kernel start, input loaded, after each of the 13 layers),
  * [16],[17] the 100 MHz wall clock at kernel start / end, [18..22] phase stamps of pn_up3p_kernel. */
 int vp_debug_core_clock(vp_handle* h, int B, unsigned long long* out32);
@@ -346,8 +348,13 @@ void* vp_train_stream(const vp_trainer* t);
  * vp_rccl_unique_id: the root fills 128 bytes that every rank must receive out of band (a file, a socket,
  *   torch.distributed's store ...).  vp_rccl_comm_init: collective over the n_ranks processes, binds the communicator
  *   to device_id.  vp_bcast_weights: in place -- the root sends weights_dev, every other rank receives into it;
- *   returns when the data has arrived.  vp_rccl_comm_destroy releases the communicator. */
+ *   returns when the data has arrived.  vp_rccl_comm_destroy releases the communicator.
+ *
+ * vp_rccl_available: 1 if RCCL could be bound in this process, 0 otherwise (vp_last_error says why).  A binder checks it
+ *   on EVERY rank and agrees on the outcome (e.g. an all-reduce MIN over its own transport) before anyone enters the
+ *   collective vp_rccl_comm_init: a rank that cannot take part must not leave the others waiting inside it. */
 #define VP_RCCL_UNIQUE_ID_BYTES 128
+int vp_rccl_available(void);
 int vp_rccl_unique_id(void* id128);
 int vp_rccl_comm_init(int device_id, int n_ranks, const void* id128, int rank, void** comm);
 int vp_rccl_comm_destroy(void* comm);

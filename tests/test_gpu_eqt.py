@@ -67,7 +67,7 @@ def _oracle_stages(net, x):
     return {k: v.numpy() for k, v in out.items()}, [f.numpy() for f in final]
 
 
-# vp_config.reserved[7]: bit 0 = decoder.4 / .5 / .6+heads as three launches, bit 1 = decoder.0 .. .3 as five launches,
+# vp_config.plan_flags[7]: bit 0 = decoder.4 / .5 / .6+heads as three launches, bit 1 = decoder.0 .. .3 as five launches,
 # bit 2 = encoder.0 .. .2 as three launches, bit 3 = encoder.3 .. .6 as four launches; bit 4 = ResCNN on the fp32 MFMA,
 # bit 5 = every stage of the fused decoder.0 .. .3 on the fp32 MFMA, bit 6 = the fused decoder tail, bit 7 = the fused encoder
 # 3-6 kernel, bit 8 = stages 1 and 2 of the fused encoder 0-2 kernel on the fp32 MFMA (the default runs encoder stages 1-6, decoder stages 1-6, the heads and the ResCNN on the
@@ -116,7 +116,7 @@ def test_fused_decoder_kernels_are_bitwise_the_layer_launches(model_fp32_mfma, B
     product on the matrix cores) use the same packed fragments and the same K order as the conv_mfma_kernel launches
     they replace: identical bits, for every tile of every row (left edge, interior, right edge of the signal), for
     batch sizes that leave the persistent grids partly filled, exactly filled, and wrapped several times.  `keep`
-    (vp_config.reserved[7]) un-fuses the tail, the decoder stages 0-3, the encoder front, the encoder stages 3-6, or all of them.
+    (vp_config.plan_flags[7]) un-fuses the tail, the decoder stages 0-3, the encoder front, the encoder stages 3-6, or all of them.
     The fused side is the plan with eqt_dec03_kernel's stages all on the fp32 MFMA (the next test covers the default)."""
     model = model_fp32_mfma
     other = EQTransformer.from_pretrained("volpick")
@@ -164,7 +164,7 @@ def test_forward_parity(model, oracle, B):
 
 
 def test_six_launch_plan_matches_fused_middle_kernel(model, oracle):
-    """reserved[2] = 1 keeps the BiLSTM / transformer / pick-branch launches that eqt_mid_kernel replaces (scalar FMA
+    """plan_flags[2] = 1 keeps the BiLSTM / transformer / pick-branch launches that eqt_mid_kernel replaces (scalar FMA
     chains instead of matrix-core tiles, same algorithm): both plans within the oracle tolerance, and of each other."""
     B = 5
     x = synthetic_windows(B, 6000, seed=77)

@@ -70,7 +70,7 @@ def test_layers_match_oracle(oracle, flags):
 
 
 def test_fused_equals_layerwise_bitwise(oracle):
-    """Same packed weights, same k-order of every MFMA chain: the all-MFMA fused plan (reserved[5] = 1) and the
+    """Same packed weights, same k-order of every MFMA chain: the all-MFMA fused plan (plan_flags[5] = 1) and the
     layer plan must agree exactly; the default plan runs the level-0 layers on the VALU (another summation
     order) and agrees to rounding."""
     x = synthetic_windows(9, 3001, seed=77)
@@ -124,7 +124,7 @@ def test_preprocess_matches_annotate_batch_pre(oracle):
 
 def test_in_kernel_preprocessing_is_bitwise_gather_normalize(model):
     """The default plan runs annotate_batch_pre inside its forward kernel with the arithmetic and reduction order of
-    gather_normalize_kernel: same bits as the plan that goes through the input tensor (reserved[6] = 1)."""
+    gather_normalize_kernel: same bits as the plan that goes through the input tensor (plan_flags[6] = 1)."""
     data, _, _ = synthetic_stream_array(40_000, seed=77, n_events=4)
     data[1] += 321.0
     via_tensor = PhaseNet.from_pretrained("volpick")

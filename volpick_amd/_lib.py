@@ -30,7 +30,8 @@ class VpConfig(C.Structure):
         ("layernorm_eps", C.c_float),
         ("norm_eps", C.c_float),
         ("taper_samples", C.c_int32),
-        ("reserved", C.c_int32 * 8),
+        ("plan_flags", C.c_int32 * 8),
+        ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -142,6 +143,7 @@ SIGNATURES = {
          C.c_void_p, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     ),
     "vp_debug_check_halos": (C.c_int, [_H, C.c_int, _I64P, C.POINTER(C.c_char_p)]),
+    "vp_rccl_available": (C.c_int, []),
     "vp_rccl_unique_id": (C.c_int, [C.c_void_p]),
     "vp_rccl_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "vp_rccl_comm_destroy": (C.c_int, [C.c_void_p]),
@@ -211,3 +213,8 @@ def check(rc: int, what: str = "volpick_hip"):
         msg = load().vp_last_error().decode(errors="replace")
         raise VolpickHipError(f"{what} failed ({rc}): {msg}")
     return rc
+
+
+def last_error() -> str:
+    """The calling thread's last error message of the library."""
+    return load().vp_last_error().decode(errors="replace")

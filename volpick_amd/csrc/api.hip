@@ -166,6 +166,7 @@ int vp_create(int device_id, int model_kind, const float* weights, size_t n_floa
     vp_default_config(model_kind, &c);
   }
   VP_REQUIRE(c.max_batch > 0 && c.max_batch <= 65535, "max_batch %d out of range", c.max_batch);
+  for (int v : c.reserved) VP_REQUIRE(v == 0, "vp_config.reserved must be zero (plan selectors live in plan_flags)");
   VP_HIP(hipSetDevice(device_id));
 
   std::vector<float> host;
@@ -1030,10 +1031,10 @@ int vp_debug_check_halos(vp_handle* h, int self_test, int64_t* n_bad, const char
   return VP_OK;
 }
 
-// Debug: per-window shader-clock stamps of the fused PhaseNet core kernel (plan flag reserved[1]).
+// Debug: per-window shader-clock stamps of the fused PhaseNet core kernel (plan flag plan_flags[1]).
 // Debug: 8 stamps per conv launch (workgroup tile 1 / window 7): start, loaded, mfma done, staged, stored.
 int vp_debug_conv_clock(vp_handle* h, unsigned long long* out, int max_layers) {
-  VP_REQUIRE(h && out && h->net.debug_clock && h->net.debug_clock->d, "no clock stamps (create with reserved[1] & 2)");
+  VP_REQUIRE(h && out && h->net.debug_clock && h->net.debug_clock->d, "no clock stamps (create with plan_flags[1] & 2)");
   VP_HIP(hipSetDevice(h->device));
   VP_HIP(hipStreamSynchronize(h->stream));
   const int n = std::min<int>(max_layers, 64);
@@ -1044,7 +1045,7 @@ int vp_debug_conv_clock(vp_handle* h, unsigned long long* out, int max_layers) {
 }
 
 int vp_debug_core_clock(vp_handle* h, int B, unsigned long long* out32) {
-  VP_REQUIRE(h && out32 && h->net.debug_clock && h->net.debug_clock->d, "no clock stamps (create with reserved[1]=1)");
+  VP_REQUIRE(h && out32 && h->net.debug_clock && h->net.debug_clock->d, "no clock stamps (create with plan_flags[1]=1)");
   VP_HIP(hipSetDevice(h->device));
   VP_HIP(hipStreamSynchronize(h->stream));
   VP_HIP(hipMemcpy(out32, h->net.debug_clock->d, (size_t)B * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1053,7 +1054,7 @@ int vp_debug_core_clock(vp_handle* h, int B, unsigned long long* out32) {
 
 // Debug: the stamps of eqt_tail_kernel (third region of the EQTransformer debug clock buffer, eqt.hip).
 int vp_debug_tail_clock(vp_handle* h, int B, unsigned long long* out32) {
-  VP_REQUIRE(h && out32 && h->net.debug_clock && h->net.debug_clock->d, "no clock stamps (create with reserved[1] & 2)");
+  VP_REQUIRE(h && out32 && h->net.debug_clock && h->net.debug_clock->d, "no clock stamps (create with plan_flags[1] & 2)");
   VP_REQUIRE(h->net.model_kind == VP_MODEL_EQTRANSFORMER && B > 0 && B <= h->net.max_batch, "EQTransformer handles only");
   VP_HIP(hipSetDevice(h->device));
   VP_HIP(hipStreamSynchronize(h->stream));

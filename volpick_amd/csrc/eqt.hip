@@ -51,7 +51,7 @@ using EQ_d5 = ConvCfg<16, 0, 16, 2, 5, 1, -2, 0, 2, 2, 6, 1, EPI_STORE, 0, 1>;
 // NW = 6 (376-column steps): 8 tiles x 768 rows = 6144 workgroups at 6 per CU = exactly four residencies of the chip
 // (NW = 8: 4608 workgroups at 4 per CU = 4.5, the last one half empty); 96.6 -> 95 us.
 using EQ_d6 = ConvCfg<16, 0, 8, 2, 7, 1, -3, 0, 1, 4, 6, 1, EPI_HEAD, 1>;  // + Conv1d(8,1,11) + sigmoid head
-// A/B tile variants (plan flag reserved[3] = 1): half-width tiles, twice the workgroups per CU
+// A/B tile variants (plan flag plan_flags[3] = 1): half-width tiles, twice the workgroups per CU
 using EQ_d3b = ConvCfg<32, 0, 32, 2, 5, 1, -2, 0, 2, 2, 3, 1, EPI_STORE>;
 using EQ_d4b = ConvCfg<32, 0, 16, 2, 5, 1, -2, 0, 2, 2, 3, 1, EPI_STORE>;
 using EQ_d5b = ConvCfg<16, 0, 16, 2, 5, 1, -2, 0, 2, 2, 3, 1, EPI_STORE>;
@@ -362,8 +362,8 @@ int plan_eqt(Net& net, const ParamView& pv) {
     st.run = [=](Net& n, int B, hipStream_t s_) -> int { return launch_pick_branch(mk_pick(n, B), s_); };
     mid_flops += st.flops_per_window;
     net.steps.push_back(std::move(st));
-    // reserved[2] = 1 keeps the six separate launches (A/B timing); default: one launch for the whole latency-bound chain
-    if (net.cfg.reserved[2] != 1 && mid_first >= 0 && (int)net.steps.size() == mid_first + 6) {
+    // plan_flags[2] = 1 keeps the six separate launches (A/B timing); default: one launch for the whole latency-bound chain
+    if (net.cfg.plan_flags[2] != 1 && mid_first >= 0 && (int)net.steps.size() == mid_first + 6) {
       Step fused;
       fused.name = "fused.mid (3 BiLSTM + 2 transformer blocks + pick branches)";
       fused.flops_per_window = mid_flops;
@@ -388,7 +388,7 @@ int plan_eqt(Net& net, const ParamView& pv) {
   const int dk[7] = {3, 5, 5, 7, 7, 9, 11};
   const char* dec_prefix[3] = {"decoder_d", "pick_decoders.0", "pick_decoders.1"};
   int dsrc = dec_in;
-  const bool alt = net.cfg.reserved[3] == 1;
+  const bool alt = net.cfg.plan_flags[3] == 1;
   for (int i = 0; i < 7; ++i) {
     const bool polyphase = true;
     const int dst_len = dout[i];
@@ -485,32 +485,32 @@ int plan_eqt(Net& net, const ParamView& pv) {
 
   net.flops_per_window = 0;
   for (auto& s : net.steps) net.flops_per_window += s.flops_per_window;
-  if (net.cfg.reserved[1] & 2)  // debug clock stamps of every conv launch (tools/conv_clock.py)
+  if (net.cfg.plan_flags[1] & 2)  // debug clock stamps of every conv launch (tools/conv_clock.py)
     // [max_batch][32] eqt_mid_kernel | [64][8] conv launches | [max_batch][32] eqt_tail_kernel  (64-bit words)
     net.debug_clock = net.add_blob(std::vector<float>(((size_t)net.max_batch * 64 + 64 * 8) * 2, 0.f));
-  // reserved[0] = 1 keeps the 14 ResCNN conv launches (layer-by-layer debug / A-B plan)
-  if (net.cfg.reserved[0] != 1) {
+  // plan_flags[0] = 1 keeps the 14 ResCNN conv launches (layer-by-layer debug / A-B plan)
+  if (net.cfg.plan_flags[0] != 1) {
     int rc = plan_eqt_fuse_res(net);
     if (rc != VP_OK) return rc;
   }
-  // reserved[7] bit 0 keeps decoder.4 / .5 / .6+heads as three launches (layer tests, A/B timing)
-  if (!(net.cfg.reserved[7] & 1) && !alt) {
-    int rc = (net.cfg.reserved[7] & 64) ? plan_eqt_fuse_tail(net) : plan_eqt_fuse_tail_b3(net);  // bit 6: the fp32-MFMA kernel
+  // plan_flags[7] bit 0 keeps decoder.4 / .5 / .6+heads as three launches (layer tests, A/B timing)
+  if (!(net.cfg.plan_flags[7] & 1) && !alt) {
+    int rc = (net.cfg.plan_flags[7] & 64) ? plan_eqt_fuse_tail(net) : plan_eqt_fuse_tail_b3(net);  // bit 6: the fp32-MFMA kernel
     if (rc != VP_OK) return rc;
   }
   // bit 2 keeps encoder.0 .. .2 as three launches
-  if (!(net.cfg.reserved[7] & 4)) {
-    int rc = plan_eqt_fuse_front(net, !(net.cfg.reserved[7] & 256));  // bit 8: stages 1 and 2 on the fp32 MFMA too
+  if (!(net.cfg.plan_flags[7] & 4)) {
+    int rc = plan_eqt_fuse_front(net, !(net.cfg.plan_flags[7] & 256));  // bit 8: stages 1 and 2 on the fp32 MFMA too
     if (rc != VP_OK) return rc;
   }
   // bit 3 keeps encoder.3 .. .6 as four launches
-  if (!(net.cfg.reserved[7] & 8)) {
-    int rc = (net.cfg.reserved[7] & 128) ? plan_eqt_fuse_enc36(net) : plan_eqt_fuse_enc36_b3(net);  // bit 7: the fp32-MFMA kernel
+  if (!(net.cfg.plan_flags[7] & 8)) {
+    int rc = (net.cfg.plan_flags[7] & 128) ? plan_eqt_fuse_enc36(net) : plan_eqt_fuse_enc36_b3(net);  // bit 7: the fp32-MFMA kernel
     if (rc != VP_OK) return rc;
   }
   // bit 1 keeps decoder.0 .. .3 (+ the stage-2 edge fix) as five launches
-  if (!(net.cfg.reserved[7] & 2)) {
-    int rc = plan_eqt_fuse_dec03(net, !(net.cfg.reserved[7] & 32));  // bit 5: every stage on the fp32 MFMA
+  if (!(net.cfg.plan_flags[7] & 2)) {
+    int rc = plan_eqt_fuse_dec03(net, !(net.cfg.plan_flags[7] & 32));  // bit 5: every stage on the fp32 MFMA
     if (rc != VP_OK) return rc;
   }
   return VP_OK;

@@ -10,7 +10,7 @@
 // wave keeps one m-tile) in registers, fetched as 16-byte loads while the stage before runs, B fragments out of LDS one
 // K-step ahead (conv_lds_areg).  The two outputs at the cropped right edge of stage 2 (eqt.hip: decoder2_edge_kernel)
 // are computed by one wave beside the stage itself, from the definition, with the same pre-summed taps.
-// Same packed fragments, same K order: bit-identical to the launches it replaces (plan flag reserved[7] & 2 keeps them).
+// Same packed fragments, same K order: bit-identical to the launches it replaces (plan flag plan_flags[7] & 2 keeps them).
 #include "conv_b3.h"
 #include "conv_lds.h"
 #include "eqt_kernels.h"

@@ -9,7 +9,7 @@
 // neighbouring columns = neighbouring lanes (one DPP move), conv outputs beyond the row counted as zero (ReLU outputs are
 // >= 0: that is MaxPool's -1e10 pad for the odd tail of stage 4 and the next stage's zero padding at once).  Stage 6
 // writes the bottleneck row and, as the launch it replaces, relu(bn1(row)) for the first residual block.
-// Same packed fragments, same K order, same arithmetic: bit-identical (plan flag reserved[7] & 8 keeps the launches).
+// Same packed fragments, same K order, same arithmetic: bit-identical (plan flag plan_flags[7] & 8 keeps the launches).
 #include "conv_lds.h"
 #include "eqt_kernels.h"
 #include "net.h"

@@ -13,7 +13,7 @@
 // row count as zero (ReLU outputs are >= 0: MaxPool's -1e10 pad for the odd tail of stage 4 and the next stage's zero
 // padding at once).  Stage 6 writes the bottleneck row and relu(bn1(row)) for the first residual block to memory.
 //
-// Plan flag reserved[7] & 128 keeps the fp32-MFMA kernel (bit-identical to the layer launches); this one agrees with it
+// Plan flag plan_flags[7] & 128 keeps the fp32-MFMA kernel (bit-identical to the layer launches); this one agrees with it
 // to fp32 rounding (tests/test_gpu_eqt.py).
 #include "conv_b3.h"
 #include "eqt_kernels.h"

@@ -20,7 +20,7 @@
 // n-tiles per stage.  MaxPool: stage 0 pools the two output phases of a column (two registers of a lane); stages 1 and 2
 // pool neighbouring columns = neighbouring lanes (one DPP move) and the even lane stores.
 // Same packed fragments, same K order, same max / ReLU arithmetic: bit-identical to the launches it replaces
-// (plan flag reserved[7] & 4 keeps them).
+// (plan flag plan_flags[7] & 4 keeps them).
 #include "conv_b3.h"
 #include "conv_lds.h"
 #include "eqt_kernels.h"

@@ -2,7 +2,7 @@
 // run back to back inside one workgroup per window with the residual stream, the BN-ReLU'd conv
 // input and the mid activation in LDS (60 KB); only the packed weights stream in from L2.
 // Same arithmetic and the same packed A-fragments as the 14 conv_mfma_kernel launches it replaces
-// (plan flag reserved[0] = 1 keeps those for A/B timing and the layer-by-layer parity test).
+// (plan flag plan_flags[0] = 1 keeps those for A/B timing and the layer-by-layer parity test).
 #include "bf16.h"
 #include "conv_lds.h"
 #include "eqt_kernels.h"
@@ -189,7 +189,7 @@ struct Res3Args {
   const float* s_next[7];
   const float* b_next[7];
   long af_bytes_k3, af_bytes_k2;  // size of one conv's operand (L2 warm-up)
-  int warm;                       // 0: no pre-touch of the weights (plan flag reserved[4] = 1)
+  int warm;                       // 0: no pre-touch of the weights (plan flag plan_flags[4] = 1)
 };
 
 __device__ __forceinline__ void split3(const float v, unsigned short& h, unsigned short& m, unsigned short& l) {
@@ -647,9 +647,9 @@ int plan_eqt_fuse_res(Net& net) {
     q1[i] = net.add_blob(regroup_afrag4(*c1[i]));
     q2[i] = net.add_blob(regroup_afrag4(*c2[i]));
   }
-  // default: the 14 convs on the bf16 matrix cores with exact three-piece operands (eqt_res3_kernel); reserved[7] bit 4
+  // default: the 14 convs on the bf16 matrix cores with exact three-piece operands (eqt_res3_kernel); plan_flags[7] bit 4
   // keeps the fp32-MFMA kernel (A/B timing; the two agree to fp32 rounding, not bitwise)
-  const bool bf3 = !(net.cfg.reserved[7] & 16);
+  const bool bf3 = !(net.cfg.plan_flags[7] & 16);
   std::vector<HostBlob*> b1(7, nullptr), b2(7, nullptr);
   if (bf3)
     for (int i = 0; i < 7; ++i) {
@@ -684,8 +684,8 @@ int plan_eqt_fuse_res(Net& net) {
       }
       a.af_bytes_k3 = 4L * 3 * 2 * 3 * 64 * 16;
       a.af_bytes_k2 = 4L * 2 * 2 * 3 * 64 * 16;
-      a.warm = n.cfg.reserved[4] != 1;
-      if (n.cfg.reserved[7] & 512)  // bit 9: the one-wave-per-SIMD form (four waves per window)
+      a.warm = n.cfg.plan_flags[4] != 1;
+      if (n.cfg.plan_flags[7] & 512)  // bit 9: the one-wave-per-SIMD form (four waves per window)
         hipLaunchKernelGGL(eqt_res3_kernel, dim3(B), dim3(256), 0, s, a);
       else
         hipLaunchKernelGGL(eqt_res3k_kernel, dim3(B), dim3(R3K_NTH), R3K_LDS_BYTES, s, a);

@@ -476,7 +476,7 @@ int launch_bilstm(const BiLstmArgs& a, int cin, int B, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------
-constexpr int TR_NTH = 512;  // threads per window (1024 ran the kernel itself 3 us faster and the pipeline 1 % slower: tools/sweep_pick.sh)
+constexpr int TR_NTH = 512;  // threads per window (1024 ran the kernel itself 3 us faster and the pipeline 1 % slower: a round-1 workgroup-size sweep, LOG.md)
 __global__ __launch_bounds__(TR_NTH) void transformer_kernel(const TransformerArgs a) {
   constexpr int NTH = TR_NTH;
   __shared__ float xs[T][EQT_H];
@@ -584,7 +584,7 @@ int launch_pick_branch(const PickBranchArgs& a, hipStream_t s) {
 // One workgroup (8 wavefronts) per window walks bilstm.0-2 -> transformer_d0 -> transformer_d -> pick branches.
 // The current activation travels through LDS as [16 channels][48] rows (`cur`; column 47 is the zero K-padding of the
 // a.x products); every stage still writes its tensor to memory (decoder inputs; the others for the layer tests).
-// Against the separate kernels above (kept as the six-launch plan, reserved[2] = 1):
+// Against the separate kernels above (kept as the six-launch plan, plan_flags[2] = 1):
 //   * every dense product is a set of 16x16x4 fp32 matrix-core tiles with the time steps as columns (mfma_tile):
 //     LSTM input projections, Conv1d(32,16,1), q / k projections, a.x, both feed-forward layers; LayerNorm runs in the
 //     epilogues of a.x and of the second feed-forward product (layer_norm_mfma);

@@ -32,7 +32,7 @@
 // words.  Zero products leave an fp32 FMA chain unchanged and the non-zero ones come in the order ci, k of the
 // VALU loop: bit-identical to it.
 // Same packed fragments, same K order and same head arithmetic as the launches it replaces: bit-identical results
-// (plan flag reserved[7] & 1 keeps the three launches; tests/test_gpu_eqt.py compares the two).
+// (plan flag plan_flags[7] & 1 keeps the three launches; tests/test_gpu_eqt.py compares the two).
 #include "conv_lds.h"
 #include "eqt_kernels.h"
 #include "net.h"
@@ -80,7 +80,7 @@ struct TailArgs {
   const float* head_a;  // Toeplitz A fragments of the heads [3][HEAD_KS / 4][64][4]
   const float* head_b;  // [3]
   int B, n_tiles;
-  unsigned long long* clk;  // debug (plan flag reserved[1] & 2): 32 words per workgroup: six shader-clock stamps for each of
+  unsigned long long* clk;  // debug (plan flag plan_flags[1] & 2): 32 words per workgroup: six shader-clock stamps for each of
                             // its first four tiles (tile start, image parked, after stages 4 / 5 / 6, heads done);
                             // [30], [31] the 100 MHz wall clock at kernel start / end
 };

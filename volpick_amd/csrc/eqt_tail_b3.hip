@@ -36,7 +36,7 @@
 // epilogue (bias, ReLU, split into pieces, stores: 40 vector instructions per n-tile, an MFMA leaves 8 of its 16 cycles to
 // them), is what a stage costs beyond its MFMAs.  Bank conflicts are not: three image layouts measured the same (conv_b3.h).
 //
-// Plan flag reserved[7] & 64 keeps the fp32-MFMA kernel of eqt_tail.hip (bit-identical to the layer launches); this one
+// Plan flag plan_flags[7] & 64 keeps the fp32-MFMA kernel of eqt_tail.hip (bit-identical to the layer launches); this one
 // agrees with it to fp32 rounding (tests/test_gpu_eqt.py).
 #include "conv_b3.h"
 #include "eqt_kernels.h"
@@ -91,7 +91,7 @@ struct Tail3Args {
   const uint4* head_t;           // [3][piece][HT_N]: the 8 channels' w[.][k] as bf16 pieces, k = entry - 15 (zero outside 0 .. 10)
   const float* head_b;           // [3]
   int B, n_tiles;
-  unsigned long long* clk;  // debug (plan flag reserved[1] & 2): the stamps of eqt_tail.hip's TailArgs::clk, same slots
+  unsigned long long* clk;  // debug (plan flag plan_flags[1] & 2): the stamps of eqt_tail.hip's TailArgs::clk, same slots
 };
 
 struct Tile3 {

@@ -133,8 +133,8 @@ int plan_phasenet(Net& net, const ParamView& pv) {
 
   net.flops_per_window = 0;
   for (auto& s : net.steps) net.flops_per_window += s.flops_per_window;
-  // reserved[0] = 1 keeps the layer-by-layer plan (debug / A-B timing); default is the fused plan.
-  if (net.cfg.reserved[0] != 1) return plan_phasenet_fused(net, pv, net.cfg.reserved[1]);
+  // plan_flags[0] = 1 keeps the layer-by-layer plan (debug / A-B timing); default is the fused plan.
+  if (net.cfg.plan_flags[0] != 1) return plan_phasenet_fused(net, pv, net.cfg.plan_flags[1]);
   return VP_OK;
 }
 

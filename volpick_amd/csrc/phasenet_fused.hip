@@ -1418,17 +1418,17 @@ std::vector<float> pack_valu(const float* W, int cin, bool transposed, const std
 
 int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
   const bool debug_dumps = (debug_flags & 1) != 0, debug_clock = (debug_flags & 2) != 0;
-  // reserved[2] = 1 selects the hand-pipelined K loop (sched_barrier) for A/B timing; the compiler's own
+  // plan_flags[2] = 1 selects the hand-pipelined K loop (sched_barrier) for A/B timing; the compiler's own
   // schedule measured 0-5 % faster on every layer (tools/micro/micro_layers.hip), so it is the default.
-  const bool pipe = net.cfg.reserved[2] == 1;
-  const bool persistent = net.cfg.reserved[3] != 1;  // reserved[3] = 1: one workgroup per tile for up3 too (A/B timing)
-  const bool down0_persistent = net.cfg.reserved[3] == 2;
-  // reserved[5] = 1 keeps the MFMA forms of the two level-0 kernels (A/B timing; bit-identical to the layer plan),
+  const bool pipe = net.cfg.plan_flags[2] == 1;
+  const bool persistent = net.cfg.plan_flags[3] != 1;  // plan_flags[3] = 1: one workgroup per tile for up3 too (A/B timing)
+  const bool down0_persistent = net.cfg.plan_flags[3] == 2;
+  // plan_flags[5] = 1 keeps the MFMA forms of the two level-0 kernels (A/B timing; bit-identical to the layer plan),
   // 2 the three-launch plan with the VALU level-0 kernels; default: the whole network in one launch (pn_window_kernel).
   // The debug dumps of the intermediates exist in the three-launch plans only.
-  const bool valu = net.cfg.reserved[5] != 1;
-  const bool whole = valu && net.cfg.reserved[5] != 2 && !debug_dumps;
-  const bool b3 = whole && net.cfg.reserved[5] != 3;  // reserved[5] = 3: the one-launch kernel with all core layers on the fp32 MFMA
+  const bool valu = net.cfg.plan_flags[5] != 1;
+  const bool whole = valu && net.cfg.plan_flags[5] != 2 && !debug_dumps;
+  const bool b3 = whole && net.cfg.plan_flags[5] != 3;  // plan_flags[5] = 3: the one-launch kernel with all core layers on the fp32 MFMA
   HostBlob *vw[5] = {}, *vb[5] = {};
   if (valu) {
     const float eps = net.cfg.bn_eps;
@@ -1501,7 +1501,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
       a.af_down = n.convs[2]->afrag.d;
       a.bs_down = n.convs[2]->bias.d;
       // measured (tools/ab_steps.py, one process): the persistent form is 4-15 % SLOWER here (its 46
-      // A registers cost occupancy and one-tile workgroups already stagger well); reserved[3] = 2 selects it
+      // A registers cost occupancy and one-tile workgroups already stagger well); plan_flags[3] = 2 selects it
       if (valu) {
         Down0VArgs v{};
         v.t = a;
@@ -1556,7 +1556,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         }
       }
       a.clk = clk ? reinterpret_cast<unsigned long long*>(clk->d) : nullptr;
-      a.warm = n.cfg.reserved[4] != 1;
+      a.warm = n.cfg.plan_flags[4] != 1;
       if (pipe) {
         hipLaunchKernelGGL(pn_core_kernel<true>, dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
       } else {
@@ -1643,7 +1643,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         a.c.bs[i] = n.convs[3 + i]->bias.d;
       }
       a.c.clk = clk ? reinterpret_cast<unsigned long long*>(clk->d) : nullptr;
-      a.c.warm = n.cfg.reserved[4] != 1 && n.warm_launches > 0;
+      a.c.warm = n.cfg.plan_flags[4] != 1 && n.warm_launches > 0;
       if (n.warm_launches > 0) --n.warm_launches;
       a.x = tx.p;
       a.ls_x = tx.ls;
@@ -1679,7 +1679,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     };
     steps.clear();
     steps.push_back(std::move(st));
-    net.fused_pre = net.cfg.reserved[6] != 1;  // reserved[6] = 1: gather_normalize_kernel fills the input tensor as in the other plans
+    net.fused_pre = net.cfg.plan_flags[6] != 1;  // plan_flags[6] = 1: gather_normalize_kernel fills the input tensor as in the other plans
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<true, false>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, false>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true>), CORE_LDS_FLOATS * sizeof(float)});

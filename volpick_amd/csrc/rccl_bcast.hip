@@ -8,6 +8,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <mutex>
+#include <string>
+
 #include "vp_common.h"
 
 namespace {
@@ -21,28 +24,36 @@ struct Rccl {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
+std::string g_load_error;  // why the binding failed (first dlopen message / missing symbol), set once
+
+// Binds RCCL once (std::call_once: the first callers may come from several threads).
 Rccl* rccl() {
   static Rccl r;
-  static bool tried = false;
-  if (tried) return r.so ? &r : nullptr;
-  tried = true;
-  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-    r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-    if (r.so) break;
-  }
-  if (!r.so) return nullptr;
-  r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.so, "ncclGetUniqueId"));
-  r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.so, "ncclCommInitRank"));
-  r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.so, "ncclCommDestroy"));
-  r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(dlsym(r.so, "ncclBroadcast"));
-  r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.so, "ncclGetErrorString"));
-  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Broadcast || !r.GetErrorString) {
-    dlclose(r.so);
-    r.so = nullptr;
-    return nullptr;
-  }
-  return &r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.so) break;
+      const char* e = dlerror();  // read once: dlerror() clears the message
+      if (g_load_error.empty()) g_load_error = e ? e : "dlopen failed";
+    }
+    if (!r.so) return;
+    g_load_error.clear();
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.so, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.so, "ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.so, "ncclCommDestroy"));
+    r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(dlsym(r.so, "ncclBroadcast"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.so, "ncclGetErrorString"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Broadcast || !r.GetErrorString) {
+      g_load_error = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclBroadcast / ncclGetErrorString";
+      dlclose(r.so);
+      r.so = nullptr;
+    }
+  });
+  return r.so ? &r : nullptr;
 }
+
+#define VP_NEED_RCCL(r) VP_REQUIRE((r) != nullptr, "RCCL not available: %s", g_load_error.c_str())
 
 #define VP_RCCL(R, call)                                                                \
   do {                                                                                  \
@@ -57,10 +68,16 @@ Rccl* rccl() {
 
 extern "C" {
 
+int vp_rccl_available(void) {
+  if (rccl() != nullptr) return 1;
+  vp::set_error("RCCL not available: %s", g_load_error.c_str());
+  return 0;
+}
+
 int vp_rccl_unique_id(void* id128) {
   VP_REQUIRE(id128 != nullptr, "null id buffer");
   Rccl* r = rccl();
-  VP_REQUIRE(r != nullptr, "librccl.so.1 not found (dlopen): %s", dlerror() ? dlerror() : "?");
+  VP_NEED_RCCL(r);
   ncclUniqueId id;
   VP_RCCL(r, r->GetUniqueId(&id));
   static_assert(sizeof(id) == VP_RCCL_UNIQUE_ID_BYTES, "ncclUniqueId size");
@@ -72,7 +89,7 @@ int vp_rccl_comm_init(int device_id, int n_ranks, const void* id128, int rank, v
   VP_REQUIRE(id128 && comm, "null argument");
   VP_REQUIRE(n_ranks > 0 && rank >= 0 && rank < n_ranks, "rank %d outside [0, %d)", rank, n_ranks);
   Rccl* r = rccl();
-  VP_REQUIRE(r != nullptr, "librccl.so.1 not found (dlopen)");
+  VP_NEED_RCCL(r);
   VP_HIP(hipSetDevice(device_id));
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
@@ -85,7 +102,7 @@ int vp_rccl_comm_init(int device_id, int n_ranks, const void* id128, int rank, v
 int vp_rccl_comm_destroy(void* comm) {
   if (!comm) return VP_OK;
   Rccl* r = rccl();
-  VP_REQUIRE(r != nullptr, "librccl.so.1 not found (dlopen)");
+  VP_NEED_RCCL(r);
   VP_RCCL(r, r->CommDestroy(static_cast<ncclComm_t>(comm)));
   return VP_OK;
 }
@@ -95,7 +112,7 @@ int vp_rccl_comm_destroy(void* comm) {
 int vp_bcast_weights(void* rccl_comm, float* weights_dev, size_t n_floats, int root) {
   VP_REQUIRE(rccl_comm && weights_dev && n_floats > 0, "null / empty argument");
   Rccl* r = rccl();
-  VP_REQUIRE(r != nullptr, "librccl.so.1 not found (dlopen)");
+  VP_NEED_RCCL(r);
   hipStream_t s = nullptr;
   VP_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   ncclResult_t e = r->Broadcast(weights_dev, weights_dev, n_floats, ncclFloat32, root, static_cast<ncclComm_t>(rccl_comm), s);

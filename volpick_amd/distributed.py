@@ -21,30 +21,69 @@ def shard_range(n_items: int, rank: int, world_size: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _global_rank(group, group_rank: int) -> int:
+    """torch.distributed's object / tensor collectives take the GLOBAL rank of the source; this module's ``src`` /
+    ``root`` arguments are ranks WITHIN ``group`` (what RCCL's communicator numbers its members by)."""
+    import torch.distributed as dist
+
+    return group_rank if group is None else dist.get_global_rank(group, group_rank)
+
+
+def _all_agree(ok: bool, group, device) -> bool:
+    """True iff ``ok`` on every rank of the group (all-reduce MIN): the ranks decide TOGETHER which way to go, so a
+    local failure never leaves one rank in a different collective than the others."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
 class RcclCommunicator:
     """An RCCL communicator owned by libvolpick_hip (``vp_rccl_comm_init``), spanning the ranks of a
     ``torch.distributed`` group.  torch.distributed only carries the 128-byte unique id to the other ranks (the
-    out-of-band step any binder has to provide); the collective itself is the library's ``ncclBroadcast``."""
+    out-of-band step any binder has to provide); the collective itself is the library's ``ncclBroadcast``.
+
+    ``src`` / ``root`` are ranks within ``group``.  Construction is collective and every step that can fail on one rank
+    alone is followed by an agreement over the torch group: either every rank ends up with a communicator, or every
+    rank raises ``RcclUnavailable`` at the same point (and may fall back together)."""
 
     def __init__(self, device_index: int, src: int = 0, group=None):
         import ctypes as C
 
+        import torch
         import torch.distributed as dist
 
         from . import _lib
 
         lib = _lib.load()
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        ident = C.create_string_buffer(128)
-        if rank == src:
-            _lib.check(lib.vp_rccl_unique_id(ident), "vp_rccl_unique_id")
-        box = [ident.raw if rank == src else None]
-        dist.broadcast_object_list(box, src=src, group=group)
+        dev = torch.device("cuda", int(device_index))
         self._comm = C.c_void_p()
-        _lib.check(lib.vp_rccl_comm_init(int(device_index), world, box[0], rank, C.byref(self._comm)), "vp_rccl_comm_init")
+        # 1. can every rank bind RCCL at all?  (a rank that cannot must not leave the others inside ncclCommInitRank)
+        have = bool(lib.vp_rccl_available())
+        why = "" if have else _lib.last_error()
+        if not _all_agree(have, group, dev):
+            raise RcclUnavailable("RCCL could not be bound on every rank" + (f" (this rank: {why})" if why else ""))
+        # 2. the unique id: the source ALWAYS enters the object broadcast, with None if it could not make one
+        ident = C.create_string_buffer(128)
+        box = [None]
+        if rank == src:
+            box = [ident.raw if lib.vp_rccl_unique_id(ident) == 0 else None]
+            why = "" if box[0] is not None else _lib.last_error()
+        dist.broadcast_object_list(box, src=_global_rank(group, src), group=group)
+        if box[0] is None:  # the same value on every rank
+            raise RcclUnavailable("vp_rccl_unique_id failed on the source rank" + (f": {why}" if why else ""))
+        # 3. the communicator itself (collective inside RCCL), then agreement on its outcome
+        rc = lib.vp_rccl_comm_init(int(device_index), world, box[0], rank, C.byref(self._comm))
+        why = "" if rc == 0 else _lib.last_error()
+        if not _all_agree(rc == 0, group, dev):
+            self.close()
+            raise RcclUnavailable("vp_rccl_comm_init failed on some rank" + (f" (this rank: {why})" if why else ""))
 
     def broadcast(self, tensor, root: int = 0):
-        """In-place broadcast of a contiguous fp32 CUDA tensor (``vp_bcast_weights``)."""
+        """In-place broadcast of a contiguous fp32 CUDA tensor (``vp_bcast_weights``); ``root`` = rank within the group."""
         import ctypes as C
 
         from . import _lib
@@ -68,17 +107,23 @@ class RcclCommunicator:
         self.close()
 
 
+class RcclUnavailable(RuntimeError):
+    """Raised by ``RcclCommunicator`` on EVERY rank alike when the library's communicator cannot be set up."""
+
+
 LAST_BROADCAST_PATH = None  # which collective the last "nccl" broadcast_weights used (bench.py reports it)
 
 
 def broadcast_weights(model, src: int = 0, group=None, create_handle: bool = True):
-    """Broadcast ``model``'s flat weight blob from ``src`` and (on GPU) build the device plan
+    """Broadcast ``model``'s flat weight blob from ``src`` (a rank within ``group``) and (on GPU) build the device plan
     straight from the broadcast buffer.  Every rank must hold a model of the same class; ranks
     other than ``src`` may hold arbitrary (e.g. zero) weights of the right size.
 
     Backend "nccl": the collective is the library's own ``vp_bcast_weights`` (one ``ncclBroadcast`` over RCCL,
-    include/volpick_hip.h) and ``vp_create(VP_MEM_DEVICE)`` plans from the received device buffer.  Backend "gloo"
-    (CPU tests): a host broadcast of the same blob."""
+    include/volpick_hip.h) and ``vp_create(VP_MEM_DEVICE)`` plans from the received device buffer.  If the library's
+    communicator cannot be brought up, ALL ranks learn so together (``RcclCommunicator``) and ALL of them broadcast
+    through the group's own communicator instead -- never one rank alone.  Backend "gloo" (CPU tests): a host broadcast
+    of the same blob."""
     import torch
     import torch.distributed as dist
 
@@ -86,22 +131,36 @@ def broadcast_weights(model, src: int = 0, group=None, create_handle: bool = Tru
         raise RuntimeError("torch.distributed is not initialised")
     backend = dist.get_backend(group)
     n = int(model._weights.size)
+    src_global = _global_rank(group, src)
     if backend == "nccl":
         dev = torch.device("cuda", torch.cuda.current_device())
         buf = torch.from_numpy(model._weights).to(dev) if dist.get_rank(group) == src else torch.zeros(
             n, dtype=torch.float32, device=dev)
         torch.cuda.current_stream(dev).synchronize()  # the upload is done before RCCL touches the buffer
         global LAST_BROADCAST_PATH
+        comm, why = None, ""
         try:
-            with RcclCommunicator(dev.index, src=src, group=group) as comm:
+            comm = RcclCommunicator(dev.index, src=src, group=group)
+        except RcclUnavailable as e:  # raised on every rank at the same point
+            why = str(e)
+        done = False
+        if comm is not None:
+            try:
                 comm.broadcast(buf, root=src)
+                done = True
+            except Exception as e:
+                why = str(e)
+            comm.close()
+            done = _all_agree(done, group, dev)  # a failed ncclBroadcast on one rank sends everybody to the fallback
+        if done:
             LAST_BROADCAST_PATH = "vp_bcast_weights (ncclBroadcast through the C ABI)"
-        except Exception as e:  # the library's communicator did not come up (on every rank alike): the group's own RCCL one still works
+        else:
             import sys
 
-            print(f"volpick_amd: vp_bcast_weights failed ({e}); broadcasting through torch.distributed", file=sys.stderr)
-            dist.broadcast(buf, src=src, group=group)
-            LAST_BROADCAST_PATH = "torch.distributed.broadcast (RCCL), after vp_bcast_weights failed: " + str(e)[:200]
+            print(f"volpick_amd: vp_bcast_weights unavailable ({why}); all ranks broadcast through torch.distributed",
+                  file=sys.stderr)
+            dist.broadcast(buf, src=src_global, group=group)
+            LAST_BROADCAST_PATH = "torch.distributed.broadcast (RCCL), after vp_bcast_weights failed: " + why[:200]
         model._weights = buf.cpu().numpy()
         if create_handle:
             model._release()
@@ -109,7 +168,7 @@ def broadcast_weights(model, src: int = 0, group=None, create_handle: bool = Tru
             model._ensure_handle(weights_device_ptr=buf.data_ptr())
         return buf
     buf = torch.from_numpy(np.ascontiguousarray(model._weights).copy())
-    dist.broadcast(buf, src=src, group=group)
+    dist.broadcast(buf, src=src_global, group=group)
     model._weights = buf.numpy().copy()
     model._release()
     return buf

@@ -83,7 +83,7 @@ class WaveformModel:
         self.n_contexts = self.default_contexts
         self._device_index = None
         self._max_batch = 256
-        self._plan_flags = (0, 0)  # vp_config.reserved[0:2]: (layer-by-layer plan, dump fused intermediates)
+        self._plan_flags = (0, 0)  # vp_config.plan_flags[0:2]: (layer-by-layer plan, dump fused intermediates)
         self._training = False
         if norm not in ("peak", "std"):
             raise ValueError("norm must be 'peak' or 'std'")
@@ -240,7 +240,7 @@ class WaveformModel:
         if os.environ.get("VOLPICK_PLAN_FLAGS"):  # A/B timing of plan variants through bench.py (debug)
             flags = tuple(int(v) for v in os.environ["VOLPICK_PLAN_FLAGS"].split(","))
         for i, v in enumerate(flags):
-            cfg.reserved[i] = int(v)
+            cfg.plan_flags[i] = int(v)
         return cfg
 
     def _ensure_handle(self, weights_device_ptr=None):

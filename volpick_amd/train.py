@@ -100,13 +100,21 @@ class PhaseNetTrainer:
         if xm != ym:
             raise ValueError("x and y must both be host arrays or both be device tensors")
         if xm == _lib.VP_MEM_DEVICE:
-            # the trainer runs on its own stream: x / y (or their fp32 copies made above) must be complete first
-            _torch().cuda.current_stream(xk.device).synchronize()
+            # the trainer runs on its own stream: x / y (or their fp32 copies made above) must be complete first.  An
+            # event recorded on torch's stream that the trainer's stream waits for (hipStreamWaitEvent): the host does
+            # not block, so a data loader filling the next batch on torch's stream keeps running
+            torch = _torch()
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(xk.device))
+            if getattr(self, "_ext_stream", None) is None:
+                self._ext_stream = torch.cuda.ExternalStream(int(self._lib.vp_train_stream(self._h)), device=xk.device)
+            self._ext_stream.wait_event(ev)
         loss = C.c_double(float("nan"))
         _lib.check(self._lib.vp_train_step(self._h, xp, yp, xm, int(x.shape[0]), float(lr), int(bool(update)),
                                            C.byref(loss) if want_loss else None), "vp_train_step")
         if xm == _lib.VP_MEM_DEVICE and not want_loss:
             self._inputs_in_flight = (xk, yk)  # kept alive until the next step / synchronize(): the kernels still read them
+        self.forward_count = getattr(self, "forward_count", 0) + 1  # every step moves the BatchNorm running statistics
         if update:
             self.global_step += 1
         return loss.value if want_loss else None
@@ -223,9 +231,12 @@ class PhaseNetLit:
         ones validated, as the reference's EMA callback does with ``validate_original_weights=False``
         (volpick/model/ema.py)."""
         tr = self._ensure()
-        if getattr(self, "_validated_at", None) != tr.global_step:
+        # what the exported model depends on: the weights (global_step), the BatchNorm running statistics (every
+        # step(), update or not, moves them) and which weights are validated (EMA on / off)
+        key = (tr.global_step, getattr(tr, "forward_count", 0), self._ema)
+        if getattr(self, "_validated_at", None) != key:
             model = tr.export(ema=self._ema)
-            self._validated_at = tr.global_step
+            self._validated_at = key
         else:
             model = self.model
         if model._device_index is None:
