@@ -213,10 +213,17 @@ int vp_synchronize(vp_handle* h);
 int vp_step_count(const vp_handle* h);
 int vp_step_info(const vp_handle* h, int index, const char** name, double* flops_per_window);
 double vp_flops_per_window(const vp_handle* h);
-/* The MFMA work a conv launch actually issues per window (whole 16-column tiles, channels padded to 4, the folded
- * taps of the polyphase forms) -- the denominator of "fraction of the matrix pipes' time"; 0 for launches that are
- * not a single MFMA convolution (fused kernels, recurrences). */
+/* The work a launch actually issues per window (whole 16-column tiles, channels padded to 4, recomputed halos, the
+ * folded taps of the polyphase forms), as fp32-equivalent FLOP. */
 int vp_step_issued_flops(const vp_handle* h, int index, double* issued_flops_per_window);
+/* The same work by the pipe it is issued to -- what a roofline of the launch has to be priced with: FLOP per window as
+ * fp32 MFMAs (v_mfma_f32_16x16x4_f32), as bf16 MFMAs (v_mfma_f32_16x16x32_bf16; an exact three-piece product is SIX of
+ * them, all counted) and on the vector ALUs (direct convolutions, recurrences, attention scores).  Filled for every
+ * launch of every plan; vp_step_issued_flops = mfma_f32 + mfma_bf16 / 6 + valu (its fp32 equivalent). */
+typedef struct {
+  double mfma_f32_flop, mfma_bf16_flop, valu_flop;
+} vp_issued_work;
+int vp_step_issued_work(const vp_handle* h, int index, vp_issued_work* out);
 int vp_profile_steps(vp_handle* h, int B, int iters, float* step_ms, int cap);
 /* One step timed IN the pipeline: the whole list runs in order `iters` times, only step `index` is bracketed by
  * events (its inputs come from the preceding kernel, as under rocprofv3). */
@@ -254,8 +261,8 @@ int vp_debug_core_clock(vp_handle* h, int B, unsigned long long* out32);
  * workgroup: start, input staged, MFMA loop done, output staged, stored.  Returns the layer count. */
 int vp_debug_conv_clock(vp_handle* h, unsigned long long* out, int max_layers);
 /* Same flag, EQTransformer: B x 32 words of eqt_tail_kernel, one row per workgroup: six stamps for each of its first
- * four tiles (tile start, image parked, after stage 4 / 5 / 6, heads done); [30], [31] the 100 MHz wall clock at kernel
- * start / end. */
+ * four tiles (tile start, image parked, after stage 4 / 5 / 6, heads done); [24], [25] the shader clock and [30], [31] the
+ * 100 MHz wall clock at kernel start / end. */
 int vp_debug_tail_clock(vp_handle* h, int B, unsigned long long* out32);
 
 /* ---------------------------------------------------------------------------------------------
@@ -357,6 +364,7 @@ void* vp_train_stream(const vp_trainer* t);
 int vp_rccl_available(void);
 int vp_rccl_unique_id(void* id128);
 int vp_rccl_comm_init(int device_id, int n_ranks, const void* id128, int rank, void** comm);
+int vp_rccl_comm_info(void* comm, int* n_ranks, int* rank); /* ncclCommCount / ncclCommUserRank of the communicator */
 int vp_rccl_comm_destroy(void* comm);
 int vp_bcast_weights(void* rccl_comm, float* weights_dev, size_t n_floats, int root);
 

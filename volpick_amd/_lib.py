@@ -35,6 +35,10 @@ class VpConfig(C.Structure):
     ]
 
 
+class VpIssuedWork(C.Structure):
+    _fields_ = [("mfma_f32_flop", C.c_double), ("mfma_bf16_flop", C.c_double), ("valu_flop", C.c_double)]
+
+
 class VpTriggerSpec(C.Structure):
     _fields_ = [("row", C.c_int32), ("thr_on", C.c_float), ("thr_off", C.c_float)]
 
@@ -130,6 +134,7 @@ SIGNATURES = {
     "vp_step_count": (C.c_int, [_H]),
     "vp_step_info": (C.c_int, [_H, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double)]),
     "vp_flops_per_window": (C.c_double, [_H]),
+    "vp_step_issued_work": (C.c_int, [_H, C.c_int, C.POINTER(VpIssuedWork)]),
     "vp_step_issued_flops": (C.c_int, [_H, C.c_int, C.POINTER(C.c_double)]),
     "vp_profile_steps": (C.c_int, [_H, C.c_int, C.c_int, _FP, C.c_int]),
     "vp_profile_step_in_pipeline": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, _FP]),
@@ -146,6 +151,7 @@ SIGNATURES = {
     "vp_rccl_available": (C.c_int, []),
     "vp_rccl_unique_id": (C.c_int, [C.c_void_p]),
     "vp_rccl_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "vp_rccl_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vp_rccl_comm_destroy": (C.c_int, [C.c_void_p]),
     "vp_bcast_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "vp_debug_core_clock": (C.c_int, [_H, C.c_int, C.c_void_p]),

@@ -884,6 +884,14 @@ int vp_step_issued_flops(const vp_handle* h, int index, double* issued_flops_per
   return VP_OK;
 }
 
+int vp_step_issued_work(const vp_handle* h, int index, vp_issued_work* out) {
+  VP_REQUIRE(h && out && index >= 0 && index < (int)h->net.steps.size(), "bad step index");
+  const vp::Step& s = h->net.steps[index];
+  out->mfma_f32_flop = s.issued_f32;
+  out->mfma_bf16_flop = s.issued_bf16;
+  out->valu_flop = s.issued_valu;
+  return VP_OK;
+}
 double vp_flops_per_window(const vp_handle* h) { return h ? h->net.flops_per_window : 0.0; }
 
 // Runs every launch of the forward pass `iters` times on B windows (whatever the input

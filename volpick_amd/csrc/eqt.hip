@@ -367,6 +367,12 @@ int plan_eqt(Net& net, const ParamView& pv) {
       Step fused;
       fused.name = "fused.mid (3 BiLSTM + 2 transformer blocks + pick branches)";
       fused.flops_per_window = mid_flops;
+      // issued per window (eqt_kernels.hip): 16 x 16 x 4 fp32 tiles of the dense products -- BiLSTM input projections 8 waves x 3
+      // n-tiles x CIN / 4 K-steps (CIN 64, 16, 16) + Conv1d(32,16,1) 3 x 8; per transformer q / k 12 x 4, a.x 3 x 12, the two
+      // feed-forward layers 24 x 4 and 6 x 16; pick branches 24 x 4 + 2 x (12 x 4 + 3 x 12) -- and, on the vector ALUs, the
+      // eight 47-step recurrences (64 gate rows x 16 units) and the four 47 x 47 x 32 score loops (two packed FMAs per pair)
+      fused.set_issued((24.0 * 16 + 24 + 2 * (24.0 * 4 + 24) + 2 * (48.0 + 36 + 96 + 96) + 96 + 2 * (48.0 + 36)) * 2048.0, 0.0,
+                       8 * 47 * 2.0 * 64 * 16 + 4 * 47.0 * 47 * 32 * 4);
       fused.run = [=](Net& n, int B, hipStream_t s_) -> int {
         MidArgs m{};
         for (int i = 0; i < 3; ++i) m.lstm[i] = mk_lstm[i](n);

@@ -421,7 +421,11 @@ int plan_eqt_fuse_dec03(Net& net, bool b3) {
   st.flops_per_window = 0;
   for (int i = 0; i < 5; ++i) st.flops_per_window += net.steps[first + i].flops_per_window;
   // issued MFMA work per row: 8 m-tiles x 3 n-tiles x 12 K-steps, 8 x 6 x 48, 4 x 12 x 48, 4 x 24 x 40 (2048 FLOP each)
-  st.issued_flops_per_window = 3.0 * (8.0 * 3 * 12 + 8.0 * 6 * 48 + 4.0 * 12 * 48 + 4.0 * 24 * 40) * 2048.0;
+  // (B3: stages 1-3 as six-MFMA groups over K = 32: an eighth of the fp32 K-steps; the two edge samples of stage 2: VALU, not counted)
+  if (b3)
+    st.set_issued(3.0 * 8.0 * 3 * 12 * 2048.0, 3.0 * (8.0 * 6 * 6 + 4.0 * 12 * 6 + 4.0 * 24 * 5) * 6 * 16384.0, 0.0);
+  else
+    st.set_issued(3.0 * (8.0 * 3 * 12 + 8.0 * 6 * 48 + 4.0 * 12 * 48 + 4.0 * 24 * 40) * 2048.0, 0.0, 0.0);
   st.run = [=](Net& n, int B, hipStream_t s) -> int {
     Dec03Args a{};
     const Tensor &tx = n.tensors[x_in], &ty = n.tensors[y_out];

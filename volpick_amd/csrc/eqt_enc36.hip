@@ -208,7 +208,7 @@ int plan_eqt_fuse_enc36(Net& net) {
   st.flops_per_window = 0;
   for (int i = 0; i < 4; ++i) st.flops_per_window += net.steps[first + i].flops_per_window;
   // issued MFMA work: 2 m-tiles x 48 n-tiles x 28 K-steps, 2 x 24 x 40, 4 x 12 x 40, 4 x 6 x 48 (2048 FLOP each)
-  st.issued_flops_per_window = (2.0 * 48 * 28 + 2.0 * 24 * 40 + 4.0 * 12 * 40 + 4.0 * 6 * 48) * 2048.0;
+  st.set_issued((2.0 * 48 * 28 + 2.0 * 24 * 40 + 4.0 * 12 * 40 + 4.0 * 6 * 48) * 2048.0, 0.0, 0.0);
   st.run = [=](Net& n, int B, hipStream_t s) -> int {
     Enc36Args a{};
     const Tensor &tx = n.tensors[x_in], &ty = n.tensors[y_out], &ta = n.tensors[act_out];

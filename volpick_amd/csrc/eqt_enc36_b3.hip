@@ -251,7 +251,7 @@ int plan_eqt_fuse_enc36_b3(Net& net) {
   st.flops_per_window = 0;
   for (int i = 0; i < 4; ++i) st.flops_per_window += net.steps[first + i].flops_per_window;
   // matrix work issued, as fp32-equivalent FLOP: one group of six bf16 MFMAs = one 16 x 16 x 32 fp32-accurate product
-  st.issued_flops_per_window = (2.0 * 48 * 4 + 2.0 * 24 * 5 + 4.0 * 12 * 5 + 4.0 * 6 * 6) * 16384.0;  // 1008 groups = 6048 MFMAs
+  st.set_issued(0.0, (2.0 * 48 * 4 + 2.0 * 24 * 5 + 4.0 * 12 * 5 + 4.0 * 6 * 6) * 6 * 16384.0, 0.0);  // 1008 groups = 6048 MFMAs
   st.run = [=](Net& n, int B, hipStream_t s) -> int {
     Enc36B3Args a{};
     const Tensor &tx = n.tensors[x_in], &ty = n.tensors[y_out], &ta = n.tensors[act_out];

@@ -326,7 +326,12 @@ int plan_eqt_fuse_front(Net& net, bool b3) {
   st.name = "fused.front (encoder.0-2, time-tiled)";
   st.flops_per_window = 0;
   for (int i = 0; i < 3; ++i) st.flops_per_window += net.steps[first + i].flops_per_window;
-  st.issued_flops_per_window = FR_TILES * (64.0 * 12 + 64.0 * 18 + 32.0 * 28) * 2048.0;
+  // per tile: stage 0 64 n-tiles x 12 K-steps of fp32 MFMAs; stages 1 / 2 64 x 18 and 32 x 28 fp32 MFMAs, or (bf16 pieces) 64 n-tiles x
+  // 3 K-steps and 32 x 4 K-steps of six-MFMA groups
+  if (b3)
+    st.set_issued(FR_TILES * 64.0 * 12 * 2048.0, FR_TILES * (64.0 * B3Steps<8, 9>::STEPS + 32.0 * B3Steps<16, 7>::STEPS) * 6 * 16384.0, 0.0);
+  else
+    st.set_issued(FR_TILES * (64.0 * 12 + 64.0 * 18 + 32.0 * 28) * 2048.0, 0.0, 0.0);
   st.run = [=](Net& n, int B, hipStream_t s) -> int {
     FrontArgs a{};
     const Tensor &tx = n.tensors[x_in], &ty = n.tensors[y_out];

@@ -661,6 +661,14 @@ int plan_eqt_fuse_res(Net& net) {
   st.name = "fused.rescnn (7 residual blocks)";
   st.flops_per_window = 0;
   for (int i = 0; i < 14; ++i) st.flops_per_window += net.steps[first + i].flops_per_window;
+  {  // 4 m-tiles x 3 n-tiles per conv; K = 64 channels x taps: 16 x taps fp32 K-steps, or 2 x taps six-MFMA groups
+    double taps = 0;
+    for (int i = 0; i < 7; ++i) taps += c1[i]->g.taps + c2[i]->g.taps;
+    if (bf3)
+      st.set_issued(0.0, 12.0 * 2 * taps * 6 * 16384.0, 0.0);
+    else
+      st.set_issued(12.0 * 16 * taps * 2048.0, 0.0, 0.0);
+  }
   if (bf3) {
     st.run = [=](Net& n, int B, hipStream_t s) -> int {
       Res3Args a{};

@@ -347,7 +347,7 @@ int plan_eqt_fuse_tail(Net& net) {
   for (int i = 0; i < 3; ++i) st.flops_per_window += net.steps[first + i].flops_per_window;
   {  // issued MFMA work per tile: 2 m-tiles x 16 n-tiles x 40 K-steps, 2 x 32 x 20, 1 x 64 x 28, heads 8 x 56 (2048 FLOP each)
     const double mfma = 2.0 * (C4 / 16) * 40 + 2.0 * (C5 / 16) * 20 + 1.0 * (C6 / 16) * 28 + 8.0 * HEAD_KS;
-    st.issued_flops_per_window = 3.0 * TILES_PER_ROW * mfma * 2048.0;
+    st.set_issued(3.0 * TILES_PER_ROW * mfma * 2048.0, 0.0, 0.0);
   }
   st.run = [=](Net& n, int B, hipStream_t s) -> int {
     TailArgs a{};

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
 #define T3_STAMP(k) \
   if (clk && n_done < 4) clk[n_done * 6 + (k)] = __builtin_readcyclecounter();
   if (clk) clk[30] = __builtin_amdgcn_s_memrealtime();
+  if (clk) clk[24] = __builtin_readcyclecounter();  // [24], [25]: shader clock at the kernel's two ends ([30], [31]: the 100 MHz clock)
 
   // stage-3 samples of a tile: image column x <-> sample t0/8 - 5 + x of the row; an item = four channels of one sample
   float pre[3][4];
@@ -290,6 +291,7 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
     id = nid;
     // no barrier here: the next tile's stage-3 image lands in R0, which nobody has read since the barrier behind stage 6
   }
+  if (clk) clk[25] = __builtin_readcyclecounter();
   if (clk) clk[31] = __builtin_amdgcn_s_memrealtime();
 #undef T3_STAMP
 }
@@ -357,9 +359,9 @@ int plan_eqt_fuse_tail_b3(Net& net) {
   st.name = "fused.tail (decoder.4-6 + heads, time-tiled)";
   st.flops_per_window = 0;
   for (int i = 0; i < 3; ++i) st.flops_per_window += net.steps[first + i].flops_per_window;
-  {  // matrix work issued per tile, as fp32-equivalent FLOP: one group of six bf16 MFMAs = one 16 x 16 x 32 fp32-accurate product
+  {  // matrix work issued per tile: groups of six bf16 MFMAs (one 16 x 16 x 32 fp32-accurate product each)
     const double groups = 4.0 * (NB4O + NB4Y) * 5 + 8.0 * NB5 * 3 + 8.0 * NB6 * 4 + 5.0 * 7;
-    st.issued_flops_per_window = 3.0 * TILES_PER_ROW * groups * 16384.0;
+    st.set_issued(0.0, 3.0 * TILES_PER_ROW * groups * 6 * 16384.0, 0.0);
   }
   st.run = [=](Net& n, int B, hipStream_t s) -> int {
     Tail3Args a{};

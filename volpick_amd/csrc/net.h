@@ -34,7 +34,15 @@ struct Step {
   std::string name;
   std::function<int(Net&, int /*B*/, hipStream_t)> run;
   double flops_per_window = 0;
-  double issued_flops_per_window = 0;  // MFMA work actually issued (padded tiles, folded taps); 0 = not an MFMA conv step
+  // Work the launch ISSUES per window (whole tiles, padded channels, recomputed halos, folded taps), by the pipe it runs on:
+  double issued_f32 = 0;   // FLOP as v_mfma_f32_16x16x4_f32 (2,048 each)
+  double issued_bf16 = 0;  // FLOP as v_mfma_f32_16x16x32_bf16 (16,384 each; an exact three-piece product group is SIX of them)
+  double issued_valu = 0;  // FLOP on the vector ALUs (direct convolutions, recurrences, attention scores)
+  double issued_flops_per_window = 0;  // fp32-equivalent of the three: issued_f32 + issued_bf16 / 6 + issued_valu (set_issued)
+  void set_issued(double f32, double bf16, double valu) {
+    issued_f32 = f32, issued_bf16 = bf16, issued_valu = valu;
+    issued_flops_per_window = f32 + bf16 / 6.0 + valu;
+  }
 };
 
 constexpr int kDenseOut = -2;

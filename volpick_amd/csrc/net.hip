@@ -224,7 +224,7 @@ void Net::add_conv_step(ConvLayer* L) {
   {  // what the matrix cores are asked to do: whole 16-column tiles, channels padded to 4, folded / polyphase taps
     const int step_cols = L->g.tn() - (L->g.epi == EPI_HEAD ? 8 : 0);
     const double tiles = (L->cols + step_cols - 1) / step_cols;
-    s.issued_flops_per_window = 2.0 * tiles * L->g.M() * L->g.tn() * L->g.cinp() * L->g.taps * L->n_sets;
+    s.set_issued(2.0 * tiles * L->g.M() * L->g.tn() * L->g.cinp() * L->g.taps * L->n_sets, 0.0, 0.0);
   }
   steps.push_back(std::move(s));
 }

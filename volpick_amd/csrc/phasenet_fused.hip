@@ -1618,6 +1618,20 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     Step st;
     st.name = "fused.window (whole PhaseNet, one workgroup per window)";
     st.flops_per_window = flops(0, 17);
+    {  // issued: inc, down0.same, both halves of up3.same and the 1x1 head on the vector ALUs (direct convolutions: no padding);
+       // every other layer as whole 16-column tiles of M x (padded channels x taps) on the matrix cores -- the five deepest
+       // (convs 7 .. 11) as six-MFMA groups over bf16 pieces when b3
+      auto padded = [&](int i) {
+        const ConvLayer& L = *net.convs[i];
+        return 2.0 * L.g.M() * ((L.cols + 15) / 16 * 16) * L.g.cinp() * L.g.taps;
+      };
+      double f32 = 0, bf16 = 0;
+      for (int i = 2; i <= 16; ++i) {
+        if (b3 && i >= 7 && i <= 11) bf16 += 6.0 * padded(i);
+        else f32 += padded(i);
+      }
+      st.set_issued(f32, bf16, flops(0, 1) + flops(17, 17));
+    }
     HostBlob* e0 = &net.convs[17]->e0;
     HostBlob* e1 = &net.convs[17]->e1;
     HostBlob* clk = debug_clock ? net.debug_clock : nullptr;

@@ -20,6 +20,8 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -43,9 +45,12 @@ Rccl* rccl() {
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.so, "ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.so, "ncclCommDestroy"));
     r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(dlsym(r.so, "ncclBroadcast"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.so, "ncclCommCount"));
+    r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.so, "ncclCommUserRank"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.so, "ncclGetErrorString"));
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Broadcast || !r.GetErrorString) {
-      g_load_error = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclBroadcast / ncclGetErrorString";
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Broadcast || !r.GetErrorString || !r.CommCount || !r.CommUserRank) {
+      g_load_error = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclBroadcast / ncclGetErrorString / "
+                     "ncclCommCount / ncclCommUserRank";
       dlclose(r.so);
       r.so = nullptr;
     }
@@ -96,6 +101,16 @@ int vp_rccl_comm_init(int device_id, int n_ranks, const void* id128, int rank, v
   ncclComm_t c = nullptr;
   VP_RCCL(r, r->CommInitRank(&c, n_ranks, id, rank));
   *comm = c;
+  return VP_OK;
+}
+
+// What RCCL itself says about the communicator: the number of ranks it spans and this process's rank in it.
+int vp_rccl_comm_info(void* comm, int* n_ranks, int* rank) {
+  VP_REQUIRE(comm && n_ranks && rank, "null argument");
+  Rccl* r = rccl();
+  VP_NEED_RCCL(r);
+  VP_RCCL(r, r->CommCount(static_cast<ncclComm_t>(comm), n_ranks));
+  VP_RCCL(r, r->CommUserRank(static_cast<ncclComm_t>(comm), rank));
   return VP_OK;
 }
 

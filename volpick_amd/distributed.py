@@ -81,6 +81,11 @@ class RcclCommunicator:
         if not _all_agree(rc == 0, group, dev):
             self.close()
             raise RcclUnavailable("vp_rccl_comm_init failed on some rank" + (f" (this rank: {why})" if why else ""))
+        n, r = C.c_int(), C.c_int()
+        _lib.check(lib.vp_rccl_comm_info(self._comm, C.byref(n), C.byref(r)), "vp_rccl_comm_info")
+        self.n_ranks, self.rank = n.value, r.value  # what RCCL itself reports (ncclCommCount / ncclCommUserRank)
+        if (self.n_ranks, self.rank) != (world, rank):
+            raise RuntimeError(f"RCCL communicator spans {self.n_ranks} ranks (this one {self.rank}); expected {world} / {rank}")
 
     def broadcast(self, tensor, root: int = 0):
         """In-place broadcast of a contiguous fp32 CUDA tensor (``vp_bcast_weights``); ``root`` = rank within the group."""
@@ -112,6 +117,7 @@ class RcclUnavailable(RuntimeError):
 
 
 LAST_BROADCAST_PATH = None  # which collective the last "nccl" broadcast_weights used (bench.py reports it)
+LAST_RCCL_RANKS = None      # ncclCommCount of the library's communicator in that broadcast (None: fallback path)
 
 
 def broadcast_weights(model, src: int = 0, group=None, create_handle: bool = True):
@@ -137,7 +143,8 @@ def broadcast_weights(model, src: int = 0, group=None, create_handle: bool = Tru
         buf = torch.from_numpy(model._weights).to(dev) if dist.get_rank(group) == src else torch.zeros(
             n, dtype=torch.float32, device=dev)
         torch.cuda.current_stream(dev).synchronize()  # the upload is done before RCCL touches the buffer
-        global LAST_BROADCAST_PATH
+        global LAST_BROADCAST_PATH, LAST_RCCL_RANKS
+        LAST_RCCL_RANKS = None
         comm, why = None, ""
         try:
             comm = RcclCommunicator(dev.index, src=src, group=group)
@@ -147,6 +154,7 @@ def broadcast_weights(model, src: int = 0, group=None, create_handle: bool = Tru
         if comm is not None:
             try:
                 comm.broadcast(buf, root=src)
+                LAST_RCCL_RANKS = comm.n_ranks
                 done = True
             except Exception as e:
                 why = str(e)

@@ -21,6 +21,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
+import time
 import warnings
 from pathlib import Path
 
@@ -84,6 +85,7 @@ class WaveformModel:
         self._device_index = None
         self._max_batch = 256
         self._plan_flags = (0, 0)  # vp_config.plan_flags[0:2]: (layer-by-layer plan, dump fused intermediates)
+        self._timing = None        # dict: classify() records its phases there, SERIALISED by device synchronisations (bench.py `api`)
         self._training = False
         if norm not in ("peak", "std"):
             raise ValueError("norm must be 'peak' or 'std'")
@@ -409,8 +411,9 @@ class WaveformModel:
             return self._annotate_block(data, args)
         stacking = _lib.VP_STACK_AVG if args["stacking"] == "avg" else _lib.VP_STACK_MAX
         batch = max(1, min(int(args["batch_size"]), self._max_batch))
-        jobs = []
-        for r, sg in enumerate(segs):
+        tm = self._timing
+
+        def upload(sg):
             lo, hi = sg["lo"], sg["hi"]
             if torch.is_tensor(data):
                 x = data[:, lo:hi].to(dev, torch.float32).contiguous()
@@ -420,11 +423,27 @@ class WaveformModel:
                 x = torch.from_numpy(np.ascontiguousarray(data[:, lo:hi], dtype=np.float32)).to(dev)
             y = torch.empty((3, hi - lo), dtype=torch.float32, device=dev)
             torch.cuda.current_stream(dev).synchronize()
-            _lib.check(lib.vp_classify_submit(self._context(r), 0, C.c_void_p(x.data_ptr()), _lib.VP_MEM_DEVICE, hi - lo,
-                                              args["overlap"], args["blinding"][0], args["blinding"][1], stacking, batch,
-                                              None, 0, C.c_void_p(y.data_ptr()), _lib.VP_MEM_DEVICE, 0),
+            return x, y
+
+        def submit(r, sg, x, y):
+            _lib.check(lib.vp_classify_submit(self._context(r), 0, C.c_void_p(x.data_ptr()), _lib.VP_MEM_DEVICE,
+                                              sg["hi"] - sg["lo"], args["overlap"], args["blinding"][0], args["blinding"][1],
+                                              stacking, batch, None, 0, C.c_void_p(y.data_ptr()), _lib.VP_MEM_DEVICE, 0),
                        "vp_classify_submit")
-            jobs.append((x, y))
+
+        jobs = []
+        if tm is None:  # segment r + 1 is uploaded while segment r computes
+            for r, sg in enumerate(segs):
+                x, y = upload(sg)
+                submit(r, sg, x, y)
+                jobs.append((x, y))
+        else:  # profiled: all uploads, then all compute (the two phases separated; their sum exceeds the pipelined wall time)
+            t0 = time.perf_counter()
+            jobs = [upload(sg) for sg in segs]
+            tm["h2d_ms"] = tm.get("h2d_ms", 0.0) + (time.perf_counter() - t0) * 1e3
+            t0 = time.perf_counter()
+            for r, (sg, (x, y)) in enumerate(zip(segs, jobs)):
+                submit(r, sg, x, y)
         out = torch.empty((3, n), dtype=torch.float32, device=dev)
         fv = lv = -1
         found = C.c_int()
@@ -438,6 +457,9 @@ class WaveformModel:
             lv = l.value + sg["lo"]
         n_windows = int(lib.vp_window_starts(n, self.in_samples, args["overlap"], None, 0))
         torch.cuda.current_stream(dev).synchronize()
+        if tm is not None:
+            tm["gpu_ms"] = tm.get("gpu_ms", 0.0) + (time.perf_counter() - t0) * 1e3
+            tm["windows"] = tm.get("windows", 0) + n_windows
         return out, fv, lv, n_windows
 
     def _pick_rows(self, dev_out, specs, cap=8192):
@@ -604,13 +626,25 @@ class WaveformModel:
                     emit(g0, triggers)
             chunk.clear()
 
+        tm = self._timing
+        t_mark = time.perf_counter()
         for grp in _group_stream(stream, self.component_order, sr, copy, self.in_samples):
             if self._is_long(grp["data"].shape[1], args):  # a day-long block: its segments occupy all contexts
                 for g0, job in pending:
                     emit(g0, self._collect_block(job, args, specs)[0])
                 pending = []
+                if tm is not None:
+                    tm["host_assembly_ms"] = tm.get("host_assembly_ms", 0.0) + (time.perf_counter() - t_mark) * 1e3
                 dev_out, fv, lv, nw = self._annotate_segments(grp["data"], args)
-                emit(grp, self._pick_rows(dev_out, specs))
+                t_mark = time.perf_counter()
+                found = self._pick_rows(dev_out, specs)
+                if tm is not None:
+                    tm["pick_scan_d2h_ms"] = tm.get("pick_scan_d2h_ms", 0.0) + (time.perf_counter() - t_mark) * 1e3
+                    t_mark = time.perf_counter()
+                emit(grp, found)
+                if tm is not None:
+                    tm["emit_records_ms"] = tm.get("emit_records_ms", 0.0) + (time.perf_counter() - t_mark) * 1e3
+                t_mark = time.perf_counter()
                 continue
             if self.batch_across_blocks and torch.is_tensor(grp["data"]):
                 nw = (grp["data"].shape[1] - self.in_samples) // step + 2
