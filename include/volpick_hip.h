@@ -63,8 +63,9 @@ typedef struct {
                                       bf16 matrix cores with exact three-piece operands (default), 1 = three launches,
                                       all MFMA (bit-identical to the layer plan), 2 = three launches, level-0
                                       stride-1 convs on the VALU, 3 = one launch, every core layer on the fp32 MFMA;
-                                 [6]: 1 = the one-launch plan reads the input tensor filled by gather_normalize
-                                      instead of cutting and normalising its windows itself;
+                                 [6]: PhaseNet: 1 = the one-launch plan reads the input tensor filled by gather_normalize
+                                      instead of cutting and normalising its windows itself; EQTransformer: 2 = the fused
+                                      encoder front cuts and normalises its windows itself (A/B: slower end to end);
                                  [7]: EQTransformer: bit0 = decoder stages 4-6 + heads as three launches instead of the
                                       time-tiled fused kernel, bit1 = decoder stages 0-3 as five launches instead of one
                                       per-row fused kernel, bit2 = encoder stages 0-2 as three launches instead of the

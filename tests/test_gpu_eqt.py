@@ -233,6 +233,33 @@ def test_preprocess_matches_annotate_batch_pre(oracle, per_comp):
         oracle.norm_amp_per_comp = False
 
 
+@pytest.mark.parametrize("norm,per_comp", [("peak", False), ("peak", True), ("std", False)])
+def test_in_kernel_preprocessing_is_bitwise_gather_normalize(norm, per_comp):
+    """plan_flags[6] = 2 runs annotate_batch_pre inside eqt_front_kernel (window cut from the raw stream, statistics in
+    the reduction order of gather_normalize_kernel, normalisation + taper while a tile is parked): same bits as the default
+    plan, which goes through gather_normalize_kernel and the input tensor -- on a stream with a tail window, on dense
+    windows, with non-finite windows (the tail kernel writes their NaN in both plans)."""
+    def make(flags):
+        m = EQTransformer.from_pretrained("volpick")
+        m.norm, m.norm_amp_per_comp, m._plan_flags = norm, per_comp, flags
+        return m.cuda()
+
+    fused, via_tensor = make((0, 0, 0, 0, 0, 0, 2)), make((0, 0))
+    data, _, _ = synthetic_stream_array(6000 + 500 * 21 + 137, seed=78, n_events=3)
+    data[1] += 321.0
+    args = fused._argdict(dict(overlap=5500, blinding=(500, 500), stacking="avg"))
+    a = fused._annotate_block(data, args)[0].cpu().numpy()
+    b = via_tensor._annotate_block(data, args)[0].cpu().numpy()
+    assert np.array_equal(a, b, equal_nan=True)
+    x = synthetic_windows(7, 6000, seed=3)
+    x[2, 1, 4000] = np.inf
+    x[5, 0, 17] = np.nan
+    ya, yb = fused._forward_raw(x, preprocess=True), via_tensor._forward_raw(x, preprocess=True)
+    assert np.isnan(ya[2]).all() and np.isnan(ya[5]).all() and np.isfinite(ya[[0, 1, 3, 4, 6]]).all()
+    assert np.array_equal(ya, yb, equal_nan=True)
+    fused._release(), via_tensor._release()
+
+
 @pytest.mark.parametrize("overlap,blinding,stacking", [(5500, (500, 500), "avg"), (1800, (500, 500), "avg"),
                                                        (3000, (1000, 1000), "max")])
 def test_annotate_parity(model, oracle, overlap, blinding, stacking):

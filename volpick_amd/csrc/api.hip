@@ -18,6 +18,10 @@ struct vp_handle {
   float total_ms = 0.f;
   bool timing = false;  // stage events cost ~5 us of stream bubble each: off unless vp_set_timing(h, 1)
   float stage_ms[4] = {0.f, 0.f, 0.f, 0.f};
+  // the window description of the latest preprocessing batch: the vp_profile_* calls replay it through plans whose first
+  // launch cuts its windows itself (the caller keeps that stream buffer alive while profiling)
+  vp::PreArgs last_pre{};
+  int last_pre_windows = 0;
   // growable device scratch
   float* d_in = nullptr;    // staged host input (stream or windows)
   size_t d_in_cap = 0;
@@ -95,15 +99,22 @@ vp::PreArgs pre_args(const vp_handle* h, const float* src, int dense, long N, lo
 // windows itself take the window description with them; otherwise gather_normalize fills the input tensor first.
 int run_batch(vp_handle* h, const vp::PreArgs& pa, int nb) {
   vp::Net& net = h->net;
+  if (pa.preprocess) {
+    h->last_pre = pa;
+    h->last_pre_windows = nb;
+  }
   if (net.fused_pre && pa.preprocess) {
     net.pre = &pa;
     const int rc = net.run(nb, h->stream);
     net.pre = nullptr;
+    if (rc == VP_OK && pa.flags && !net.fused_pre_poisons && !net.poison_in_plan)
+      vp::launch_poison(net.y, pa.flags, nb, (long)net.n_out * net.in_samples, h->stream);
     return rc;
   }
   vp::launch_gather_normalize(pa, nb, h->stream);
   const int rc = net.run(nb, h->stream);
-  if (rc == VP_OK && pa.flags) vp::launch_poison(net.y, pa.flags, nb, (long)net.n_out * net.in_samples, h->stream);
+  if (rc == VP_OK && pa.flags && !net.poison_in_plan)
+    vp::launch_poison(net.y, pa.flags, nb, (long)net.n_out * net.in_samples, h->stream);
   return rc;
 }
 
@@ -894,6 +905,16 @@ int vp_step_issued_work(const vp_handle* h, int index, vp_issued_work* out) {
 }
 double vp_flops_per_window(const vp_handle* h) { return h ? h->net.flops_per_window : 0.0; }
 
+// Plans whose first launch cuts and normalises its windows itself are profiled the way they run: on the windows of the
+// handle's latest preprocessing batch (when it had at least B of them); otherwise on the input tensor.
+struct ProfilePre {
+  vp::Net& net;
+  ProfilePre(vp_handle* h, int B) : net(h->net) {
+    if (net.fused_pre && h->last_pre_windows >= B && h->last_pre.src) net.pre = &h->last_pre;
+  }
+  ~ProfilePre() { net.pre = nullptr; }
+};
+
 // Runs every launch of the forward pass `iters` times on B windows (whatever the input
 // tensor currently holds) and reports the mean duration of each launch in milliseconds,
 // measured with HIP events on the handle's stream.
@@ -902,6 +923,7 @@ int vp_profile_steps(vp_handle* h, int B, int iters, float* step_ms, int cap) {
   vp::Net& net = h->net;
   VP_REQUIRE(B > 0 && B <= net.max_batch, "B outside (0, max_batch]");
   VP_HIP(hipSetDevice(h->device));
+  ProfilePre pre_scope(h, B);
   const int n = (int)net.steps.size();
   for (int s = 0; s < n && s < cap; ++s) {
     int rc = net.steps[s].run(net, B, h->stream);  // warm
@@ -925,6 +947,7 @@ int vp_profile_one_step(vp_handle* h, int B, int iters, int index, float* ms) {
   VP_REQUIRE(B > 0 && B <= net.max_batch, "B outside (0, max_batch]");
   VP_REQUIRE(index >= 0 && index < (int)net.steps.size(), "step index %d outside [0, %d)", index, (int)net.steps.size());
   VP_HIP(hipSetDevice(h->device));
+  ProfilePre pre_scope(h, B);
   int rc = net.steps[index].run(net, B, h->stream);  // warm
   if (rc != 0) return rc;
   VP_HIP(hipEventRecord(h->ev[0], h->stream));
@@ -946,6 +969,7 @@ int vp_profile_step_in_pipeline(vp_handle* h, int B, int iters, int index, float
   const int n = (int)net.steps.size();
   VP_REQUIRE(index >= 0 && index < n, "step index %d outside [0, %d)", index, n);
   VP_HIP(hipSetDevice(h->device));
+  ProfilePre pre_scope(h, B);
   int rc = net.run(B, h->stream);  // warm
   if (rc != VP_OK) return rc;
   // every pass is enqueued before the first one is waited for: the launch is timed the way it runs in a busy

@@ -75,7 +75,165 @@ struct FrontArgs {
   const float* bs[3];
   const uint4* af3[2];  // B3: three-piece operands of stages 1 and 2 [steps][piece][64] (net.hip: b3_operand)
   int n_tiles;
+  PreArgs pre;  // has_pre: the kernel cuts its windows out of the raw stream and normalises them itself (annotate_batch_pre,
+  int has_pre;  // arithmetic and reduction order of gather_normalize_kernel: bitwise the same rows); x is then unused
+  int B;
 };
+
+// annotate_batch_pre statistics of one window by a 512-thread workgroup, in the arithmetic AND reduction order of
+// gather_normalize_kernel (prepost.hip; 1024 threads, thread t sums samples t, t + 1024, ...; one partial per wavefront,
+// the 16 partials added in order): a thread stands in for the "virtual" threads tid and tid + 512, its wavefront w for the
+// virtual wavefronts w and w + 8.  -> mean[c], den[c] = amplitude + eps, bad = a non-finite sample in the window.
+// Results in LDS: out[0..2] = mean, out[3..5] = den, out[6] = 1.0 if bad (read back by the threads that park a tile).
+__device__ __forceinline__ void front_window_stats(const PreArgs& p, const float* src, const long cs, float* red, float* out) {
+  constexpr int VT = 1024, NWV = 16, MAXE = 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, T = p.T;
+  float* stat = red + 3 * NWV;
+  if (p.norm == VP_NORM_PEAK) {
+    // ONE pass: max_k |v_k - mean| = max(vmax - mean, mean - vmin) bit for bit (rounding is monotonic and symmetric), so
+    // the sums, maxima and minima are gathered together.  (A NaN / Inf sample makes the mean non-finite: the window is
+    // flagged and its predictions become NaN whatever the amplitude says.)
+    float s[2][3], hi[3] = {-INFINITY, -INFINITY, -INFINITY}, lo[3] = {INFINITY, INFINITY, INFINITY};
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float v[MAXE];
+#pragma unroll
+        for (int k = 0; k < MAXE; ++k) {
+          const int t = tid + 512 * h + k * VT;
+          v[k] = t < T ? src[c * cs + t] : 0.f;
+        }
+        s[h][c] = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXE; ++k) {
+          s[h][c] += v[k];
+          if (tid + 512 * h + k * VT < T) hi[c] = fmaxf(hi[c], v[k]), lo[c] = fminf(lo[c], v[k]);
+        }
+      }
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float r = wave_sum(s[h][c]);
+        if (lane == 0) red[c * NWV + wave + 8 * h] = r;
+      }
+      const float rh = wave_max(hi[c]), rl = -wave_max(-lo[c]);
+      if (lane == 0) red[3 * NWV + 8 + c * 16 + wave] = rh, red[3 * NWV + 8 + c * 16 + 8 + wave] = rl;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      bool bad = false;
+      float amp[3], mean[3];
+      for (int c = 0; c < 3; ++c) {
+        float acc = 0.f;
+        for (int i = 0; i < NWV; ++i) acc += red[c * NWV + i];
+        mean[c] = acc / (float)T;
+        float vh = red[3 * NWV + 8 + c * 16], vl = red[3 * NWV + 8 + c * 16 + 8];
+        for (int i = 1; i < 8; ++i) vh = fmaxf(vh, red[3 * NWV + 8 + c * 16 + i]), vl = fminf(vl, red[3 * NWV + 8 + c * 16 + 8 + i]);
+        amp[c] = fmaxf(vh - mean[c], mean[c] - vl);
+        bad |= !isfinite(mean[c]) || !isfinite(amp[c]);
+      }
+      if (!p.per_comp) amp[0] = amp[1] = amp[2] = fmaxf(amp[0], fmaxf(amp[1], amp[2]));
+      for (int c = 0; c < 3; ++c) {
+        out[c] = mean[c];
+        out[3 + c] = amp[c] + p.norm_eps;
+      }
+      out[6] = bad ? 1.f : 0.f;
+    }
+    __syncthreads();
+    return;
+  }
+  // norm = std: the window is read twice, for the mean and for the sum of squares (36 samples per thread held across the
+  // barriers would not fit beside the kernel's resident weights; the second read hits L2)
+  float s[2][3];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v[MAXE];
+#pragma unroll
+      for (int k = 0; k < MAXE; ++k) {
+        const int t = tid + 512 * h + k * VT;
+        v[k] = t < T ? src[c * cs + t] : 0.f;
+      }
+      s[h][c] = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXE; ++k) s[h][c] += v[k];
+    }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    for (int c = 0; c < 3; ++c) {
+      const float r = wave_sum(s[h][c]);
+      if (lane == 0) red[c * NWV + wave + 8 * h] = r;
+    }
+  __syncthreads();
+  if (tid < 3) {
+    float acc = 0.f;
+    for (int i = 0; i < NWV; ++i) acc += red[tid * NWV + i];
+    stat[tid * 2] = acc / (float)T;
+  }
+  __syncthreads();
+  const float mean[3] = {stat[0], stat[2], stat[4]};
+  float m[2][3];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      m[h][c] = 0.f;
+      float v[MAXE];
+#pragma unroll
+      for (int k = 0; k < MAXE; ++k) {
+        const int t = tid + 512 * h + k * VT;
+        v[k] = t < T ? src[c * cs + t] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < MAXE; ++k) {
+        const int t = tid + 512 * h + k * VT;
+        if (t < T) {
+          const float d = v[k] - mean[c];
+          if (p.norm == VP_NORM_PEAK) {
+            m[h][c] = fmaxf(m[h][c], fabsf(d));
+            if (d != d) m[h][c] = d;  // propagate NaN like torch.max
+          } else {
+            m[h][c] += d * d;
+          }
+        }
+      }
+    }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    for (int c = 0; c < 3; ++c) {
+      const float r = (p.norm == VP_NORM_PEAK) ? wave_max(m[h][c]) : wave_sum(m[h][c]);
+      if (lane == 0) red[c * NWV + wave + 8 * h] = r;
+    }
+  __syncthreads();
+  if (tid < 3) {
+    const float* r = red + tid * NWV;
+    float acc = r[0];
+    for (int i = 1; i < NWV; ++i) acc = (p.norm == VP_NORM_PEAK) ? fmaxf(acc, r[i]) : acc + r[i];
+    stat[tid * 2 + 1] = acc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    bool bad = false;
+    for (int c = 0; c < 3; ++c) bad |= !isfinite(stat[2 * c]) || !isfinite(stat[2 * c + 1]);
+    float amp[3];
+    if (p.per_comp) {
+      for (int c = 0; c < 3; ++c) amp[c] = (p.norm == VP_NORM_PEAK) ? stat[2 * c + 1] : sqrtf(stat[2 * c + 1] / (float)(T - 1));
+    } else {
+      const float g = (p.norm == VP_NORM_PEAK) ? fmaxf(stat[1], fmaxf(stat[3], stat[5]))
+                                               : sqrtf((stat[1] + stat[3] + stat[5]) / (float)(3 * T - 1));
+      amp[0] = amp[1] = amp[2] = g;
+    }
+    for (int c = 0; c < 3; ++c) {
+      out[c] = mean[c];
+      out[3 + c] = amp[c] + p.norm_eps;
+    }
+    out[6] = bad ? 1.f : 0.f;
+  }
+  __syncthreads();  // the statistics are visible; `red` is free for the next window
+}
 
 __device__ __forceinline__ float lane_xor1(float v) { return dpp_move<0xB1, 0xF>(v); }  // quad_perm [1,0,3,2]
 
@@ -161,7 +319,8 @@ struct Pool1Store {
   }
 };
 
-template <bool B3>
+// CUT: the kernel cuts its windows out of the raw stream and normalises them itself (FrontArgs::pre).
+template <bool B3, bool CUT>
 __global__ __launch_bounds__(FR_NTH) void eqt_front_kernel(const FrontArgs a) {
   extern __shared__ float4 fr_lds_raw[];
   float* lds = reinterpret_cast<float*>(fr_lds_raw);
@@ -172,9 +331,19 @@ __global__ __launch_bounds__(FR_NTH) void eqt_front_kernel(const FrontArgs a) {
   float* E1P = lds + 4 * off1;
   bf16_t* E0 = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(fr_lds_raw) + FB_OFF_E0);  // B3
   bf16_t* E1 = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(fr_lds_raw) + FB_OFF_E1);
+  __shared__ float fr_red[3 * 16 + 8 + 3 * 16];  // CUT: partial sums (+ maxima / minima) of front_window_stats
+  __shared__ float fr_stat[8];          //      the window's mean[3], den[3], non-finite flag
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int tile = blockIdx.x;
+  // Tile order.  Reading the input tensor: tiles blockIdx.x, + gridDim.x, ... (any tile to any workgroup).  Cutting the
+  // windows itself (has_pre): window-major -- workgroup b takes the FR_TILES tiles of windows b, b + gridDim.x, ... and
+  // computes a window's statistics once, in front of its first tile.
+  constexpr bool has_pre = CUT;
+  int seq = 0;
+  auto tile_at = [&](const int q) {
+    return has_pre ? ((int)blockIdx.x + (q / FR_TILES) * (int)gridDim.x) * FR_TILES + q % FR_TILES : (int)blockIdx.x + q * (int)gridDim.x;
+  };
+  int tile = tile_at(0);
   if (tile >= a.n_tiles) return;
   // the fourth channel row of the input image pads K to the 4-channel MFMA step: zero, once
   for (int i = tid; i < SI + 4; i += FR_NTH) XI[3 * SI + i] = 0.f;
@@ -186,17 +355,59 @@ __global__ __launch_bounds__(FR_NTH) void eqt_front_kernel(const FrontArgs a) {
   // input samples of a tile: 3 rows x the SI physical columns of the image; column p <-> sample 8 j0 - 28 + p of the row,
   // zero outside [0, 6000)
   float pre[PRE];
+  // has_pre: where window `win` of this launch starts in the raw stream (PreArgs, as gather_normalize_kernel) and its row stride
+  auto raw_window = [&](const int win, long& cs) -> const float* {
+    const PreArgs& p = a.pre;
+    long start = p.dense ? 0 : (long)(p.first_window + win) * p.step;
+    if (!p.dense && start > p.N - T_IN) start = p.N - T_IN;  // tail window flush with the end
+    const float* src = p.src + (p.dense ? (long)win * 3 * T_IN : start);
+    cs = p.dense ? T_IN : p.N;
+    if (p.table) {
+      const long* e = p.table + 3 * (p.first_window + win);
+      src = p.src + e[0] + e[2];
+      cs = e[1];
+    }
+    return src;
+  };
   auto request = [&](int t) {
     const int win = t / FR_TILES, j0 = (t - win * FR_TILES) * FW;
+    long cs = a.ls_x;
     const float* src = a.x + (long)win * a.ws_x + HALO;
+    if constexpr (has_pre) src = raw_window(win, cs);
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
       const int idx = tid + k * FR_NTH, c = idx / SI, p = idx - c * SI;
       const int smp = 8 * j0 - 28 + p;
-      pre[k] = (idx < 3 * SI && (unsigned)smp < (unsigned)T_IN) ? src[(long)c * a.ls_x + smp] : 0.f;
+      pre[k] = (idx < 3 * SI && (unsigned)smp < (unsigned)T_IN) ? src[(long)c * cs + smp] : 0.f;
     }
   };
-  auto park = [&]() {
+  auto park = [&](const int j0) {
+    if constexpr (has_pre) {  // (v - mean) / (amp + eps), tapered: the expression of gather_normalize_kernel, sample by sample
+      const int taper = a.pre.taper;
+      const float m0 = fr_stat[0], m1 = fr_stat[1], m2 = fr_stat[2], d0 = fr_stat[3], d1 = fr_stat[4], d2 = fr_stat[5];
+#pragma unroll
+      for (int k = 0; k < PRE; ++k) {
+        const int idx = tid + k * FR_NTH, c = idx / SI, p = idx - c * SI;
+        const int t = 8 * j0 - 28 + p;
+        if (idx < 3 * SI) {
+          float o = 0.f;
+          if ((unsigned)t < (unsigned)T_IN) {
+            const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+            const float den = c == 0 ? d0 : (c == 1 ? d1 : d2);
+            o = (pre[k] - mean) / den;
+            if (taper > 0) {
+              const int e = (t < taper) ? t : ((T_IN - 1 - t < taper) ? T_IN - 1 - t : -1);
+              if (e >= 0) {  // 0.5 * (1 + cos(linspace(pi, 2 pi, taper)[e]))
+                const float ang = 3.14159265358979323846f * (1.f + (float)e / (float)(taper - 1));
+                o *= 0.5f * (1.f + cosf(ang));
+              }
+            }
+          }
+          XI[idx] = o;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < PRE; ++k) {
       const int idx = tid + k * FR_NTH;
@@ -225,10 +436,16 @@ __global__ __launch_bounds__(FR_NTH) void eqt_front_kernel(const FrontArgs a) {
   }
 
   while (true) {
-    const int next = tile + gridDim.x;
+    const int next = tile_at(++seq);
     const bool more = next < a.n_tiles;
     const int win = tile / FR_TILES, j0 = (tile - win * FR_TILES) * FW;
-    park();
+    if (has_pre && j0 == 0) {  // (CUT) first tile of a window: its statistics (uniform branch; ends with a barrier)
+      long cs;
+      const float* src = raw_window(win, cs);
+      front_window_stats(a.pre, src, cs, fr_red, fr_stat);
+      if (tid == 0 && a.pre.flags) a.pre.flags[win] = fr_stat[6];  // the tail kernel turns the window's predictions into NaN
+    }
+    park(j0);
     __syncthreads();
     if constexpr (B3) {
       const int n = lane & 15, g = lane >> 4;
@@ -346,21 +563,42 @@ int plan_eqt_fuse_front(Net& net, bool b3) {
       a.bs[i] = c[i]->bias.d;
     }
     a.n_tiles = B * FR_TILES;
-    const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
+    a.B = B;
+    if (n.pre) {
+      a.pre = *n.pre;
+      a.has_pre = 1;
+    }
+    const int grid = a.has_pre ? (B < 256 ? B : 256) : (a.n_tiles < 256 ? a.n_tiles : 256);
     if (b3) {
       for (int i = 0; i < 2; ++i) a.af3[i] = reinterpret_cast<const uint4*>(p3[i]->d);
-      hipLaunchKernelGGL(eqt_front_kernel<true>, dim3(grid), dim3(FR_NTH), FB_LDS_BYTES, s, a);
+      if (a.has_pre)
+        hipLaunchKernelGGL((eqt_front_kernel<true, true>), dim3(grid), dim3(FR_NTH), FB_LDS_BYTES, s, a);
+      else
+        hipLaunchKernelGGL((eqt_front_kernel<true, false>), dim3(grid), dim3(FR_NTH), FB_LDS_BYTES, s, a);
     } else {
-      hipLaunchKernelGGL(eqt_front_kernel<false>, dim3(grid), dim3(FR_NTH), FR_LDS_FLOATS * sizeof(float), s, a);
+      if (a.has_pre)
+        hipLaunchKernelGGL((eqt_front_kernel<false, true>), dim3(grid), dim3(FR_NTH), FR_LDS_FLOATS * sizeof(float), s, a);
+      else
+        hipLaunchKernelGGL((eqt_front_kernel<false, false>), dim3(grid), dim3(FR_NTH), FR_LDS_FLOATS * sizeof(float), s, a);
     }
     return 0;
   };
-  if (b3)
-    net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_front_kernel<true>), (size_t)FB_LDS_BYTES});
-  else
-    net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_front_kernel<false>), FR_LDS_FLOATS * sizeof(float)});
+  if (b3) {
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_front_kernel<true, true>), (size_t)FB_LDS_BYTES});
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_front_kernel<true, false>), (size_t)FB_LDS_BYTES});
+  } else {
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_front_kernel<false, true>), FR_LDS_FLOATS * sizeof(float)});
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_front_kernel<false, false>), FR_LDS_FLOATS * sizeof(float)});
+  }
   net.steps.erase(net.steps.begin() + first, net.steps.begin() + first + 3);
   net.steps.insert(net.steps.begin() + first, std::move(st));
+  // plan_flags[6] = 2: the kernel cuts its windows out of the raw stream and normalises them itself (no gather_normalize launch,
+  // no input tensor: -13 us of small kernels and 37 MB per step).  NOT the default: the statistics of a window (one pass over
+  // its 72 KB, two barriers) and the 13 divisions per thread and tile stand in front of the first MFMA of every workgroup and
+  // cost the kernel 8.6 us (34.3 -> 42.9), while the small launches they replace mostly hide in the tails of the big
+  // kernels: 728 k against 736 k windows/s end to end (profiles/r03_eqt_front_cuts_its_windows_ab.txt).  Kept for that A/B
+  // and for the bitwise test of the in-kernel arithmetic.
+  net.fused_pre = first == 0 && net.cfg.plan_flags[6] == 2;
   return VP_OK;
 }
 

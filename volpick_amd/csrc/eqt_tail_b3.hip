@@ -90,6 +90,7 @@ struct Tail3Args {
   const float *bs4, *bs5, *bs6;  // bias [set][COUT]
   const uint4* head_t;           // [3][piece][HT_N]: the 8 channels' w[.][k] as bf16 pieces, k = entry - 15 (zero outside 0 .. 10)
   const float* head_b;           // [3]
+  const float* flags;            // optional [B]: != 0 where the window held a non-finite sample: its predictions are written as NaN
   int B, n_tiles;
   unsigned long long* clk;  // debug (plan flag plan_flags[1] & 2): the stamps of eqt_tail.hip's TailArgs::clk, same slots
 };
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
         r.y = 1.f / (1.f + expf(-acc[1]));
         r.z = 1.f / (1.f + expf(-acc[2]));
         r.w = 1.f / (1.f + expf(-acc[3]));
+        if (a.flags && a.flags[b] != 0.f) r.x = r.y = r.z = r.w = __builtin_nanf("");  // what launch_poison writes (prepost.h)
         *reinterpret_cast<float4*>(a.y + ((long)b * 3 + id.d) * T_OUT + t0 + 16 * blk + 4 * g) = r;
       }
     }
@@ -379,6 +381,7 @@ int plan_eqt_fuse_tail_b3(Net& net) {
     a.bs4 = c4->bias.d, a.bs5 = c5->bias.d, a.bs6 = c6->bias.d;
     a.head_t = reinterpret_cast<const uint4*>(head_t->d);
     a.head_b = c6->e1.d;
+    a.flags = n.win_flags ? n.win_flags->d : nullptr;  // set by gather_normalize_kernel (or by eqt_front_kernel when it cuts the windows itself)
     a.B = B;
     a.n_tiles = 3 * B * TILES_PER_ROW;
     a.clk = (n.debug_clock && n.debug_clock->d)
@@ -391,6 +394,7 @@ int plan_eqt_fuse_tail_b3(Net& net) {
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_tail3_kernel), (size_t)T3_LDS_BYTES});
   net.steps.erase(net.steps.begin() + first, net.steps.begin() + first + 3);
   net.steps.push_back(std::move(st));
+  net.poison_in_plan = true;  // no poison_kernel launch behind this plan
   return VP_OK;
 }
 

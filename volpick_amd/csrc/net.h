@@ -76,7 +76,10 @@ struct Net {
                           // cold L2); in steady state the weights are L2-resident and the touch only delays 8 workgroups
   HostBlob* debug_clock = nullptr;  // fused PhaseNet core: per-layer shader-clock stamps (debug plan flag)
   HostBlob* win_flags = nullptr;    // [max_batch]: 1 where annotate_batch_pre met a non-finite window (its predictions become NaN, as the reference's)
-  bool fused_pre = false;           // the plan's first launch can gather + normalise its windows itself (pn_window_kernel)
+  bool fused_pre = false;           // the plan's first launch can gather + normalise its windows itself (pn_window_kernel, eqt_front_kernel)
+  bool fused_pre_poisons = false;   // ... and that launch writes the NaN predictions of a non-finite window itself (pn_window_kernel)
+  bool poison_in_plan = false;      // the plan's LAST launch reads win_flags and writes NaN for flagged windows, whoever set the
+                                    // flags (eqt_tail3_kernel): poison_kernel is never launched
   const PreArgs* pre = nullptr;     // set by the caller around run() when fused_pre: where the windows of this batch come from
 
   int add_tensor(const std::string& name, int C, int L, int sets = 1);

@@ -1694,6 +1694,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     steps.clear();
     steps.push_back(std::move(st));
     net.fused_pre = net.cfg.plan_flags[6] != 1;  // plan_flags[6] = 1: gather_normalize_kernel fills the input tensor as in the other plans
+    net.fused_pre_poisons = true;                // ... and then writes the NaN predictions of a non-finite window itself
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<true, false>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, false>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true>), CORE_LDS_FLOATS * sizeof(float)});
