@@ -148,6 +148,12 @@ int vp_classify(vp_handle* h, const float* stream, int stream_mem, int64_t N, in
                 int out_mem, int64_t* first_valid, int64_t* last_valid, int64_t* n_windows, int64_t* on,
                 int64_t* off, int64_t* peak, float* value, int32_t* spec_of, int cap, int* n_found);
 
+/* The trigger scan of vp_classify alone: `rows_dev` is a device (n_out, N) array of stacked rows (what vp_annotate left
+ * there); every spec's row is scanned in one launch, one synchronisation, one result copy.  Same result layout and cap
+ * rule as vp_classify. */
+int vp_pick_rows(vp_handle* h, const float* rows_dev, int64_t N, const vp_trigger_spec* specs, int n_specs, int64_t* on,
+                 int64_t* off, int64_t* peak, float* value, int32_t* spec_of, int cap, int* n_found);
+
 /* Asynchronous form of vp_classify for callers that keep the GPU fed (several station blocks
  * or bench steps in flight): vp_classify_submit enqueues the whole path on the handle's stream
  * and returns without synchronising; vp_classify_collect(slot) waits for that submit and returns

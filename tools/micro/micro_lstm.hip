@@ -203,6 +203,85 @@ __device__ __forceinline__ void recur1(const float* gx, const f32x2 (&whh)[H / 2
 // h[u] is kept in lane (gate, u) of ALL four rows, so `row_newbcast:u` hands unit u's h to every lane of a row.  The four
 // gates of a unit sit in four different rows: v_permlane32_swap + 2 x v_permlane16_swap bring (i, f, g, o) of unit u to every
 // lane (*, u), and all four rows then update c and h redundantly.  gx here: [t][GS] indexed 16 * gate + unit.
+#define LSTM5_MATVEC \
+  "v_fmac_f32_dpp %[g0], %[h], %[w0] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_mul_f32_dpp %[acc1], %[h], %[w1] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_mul_f32_dpp %[acc2], %[h], %[w2] row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_mul_f32_dpp %[acc3], %[h], %[w3] row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[g0], %[h], %[w4] row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc1], %[h], %[w5] row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc2], %[h], %[w6] row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc3], %[h], %[w7] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[g0], %[h], %[w8] row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc1], %[h], %[w9] row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc2], %[h], %[w10] row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc3], %[h], %[w11] row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[g0], %[h], %[w12] row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc1], %[h], %[w13] row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc2], %[h], %[w14] row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc3], %[h], %[w15] row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+#define LSTM5_MATVEC2 \
+  "v_fmac_f32_dpp %[g0], %[h], %[w0] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc1], %[h], %[w1] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc2], %[h], %[w2] row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc3], %[h], %[w3] row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[g0], %[h], %[w4] row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc1], %[h], %[w5] row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc2], %[h], %[w6] row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc3], %[h], %[w7] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[g0], %[h], %[w8] row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc1], %[h], %[w9] row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc2], %[h], %[w10] row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc3], %[h], %[w11] row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[g0], %[h], %[w12] row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc1], %[h], %[w13] row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc2], %[h], %[w14] row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" \
+  "v_fmac_f32_dpp %[acc3], %[h], %[w15] row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+#define LSTM5_NOMAT "v_mov_b32 %[acc1], 0\n\tv_mov_b32 %[acc2], 0\n\tv_mov_b32 %[acc3], 0\n\t"
+#define LSTM5_STEP(MV) \
+    asm volatile( \
+        "ds_read_b32 %[gn], %[gaddr]\n\t" \
+        "s_nop 0\n\t" \
+        MV \
+        "v_add_u32 %[gaddr], %[gstep], %[gaddr]\n\t" \
+        "v_add_f32 %[g0], %[g0], %[acc1]\n\t" \
+        "v_add_f32 %[acc2], %[acc2], %[acc3]\n\t" \
+        "v_add_f32 %[t0], %[g0], %[acc2]\n\t" \
+        "v_exp_f32 %[t0], %[t0]\n\t" \
+        "s_nop 0\n\t" \
+        "v_add_f32 %[t0], 1.0, %[t0]\n\t" \
+        "v_rcp_f32 %[t0], %[t0]\n\t" \
+        "s_nop 0\n\t" \
+        "v_fma_f32 %[b], %[t0], %[A], %[B]\n\t" \
+        "v_fma_f32 %[t0], %[t0], %[A], %[B]\n\t" \
+        "s_nop 1\n\t" \
+        "v_permlane32_swap_b32 %[t0], %[b]\n\t" \
+        "v_mov_b32 %[a2], %[t0]\n\t" \
+        "v_mov_b32 %[b2], %[b]\n\t" \
+        "s_nop 0\n\t" \
+        "v_permlane16_swap_b32 %[t0], %[a2]\n\t" \
+        "v_permlane16_swap_b32 %[b], %[b2]\n\t" \
+        "v_mul_f32 %[t1], %[t0], %[b]\n\t" \
+        "v_fmac_f32 %[t1], %[a2], %[C]\n\t" \
+        "v_mul_f32 %[a2], -2.0, %[b2]\n\t" \
+        "v_exp_f32 %[t0], %[t1]\n\t" \
+        "v_mov_b32 %[C], %[t1]\n\t" \
+        "v_add_f32 %[t0], 1.0, %[t0]\n\t" \
+        "v_rcp_f32 %[t0], %[t0]\n\t" \
+        "s_nop 0\n\t" \
+        "v_fma_f32 %[h], %[t0], %[a2], %[b2]\n\t" \
+        "s_mov_b64 exec, %[row0]\n\t" \
+        "ds_write_b32 %[haddr], %[h]\n\t" \
+        "s_mov_b64 exec, -1\n\t" \
+        "v_add_u32 %[haddr], 4, %[haddr]\n\t" \
+        "s_waitcnt lgkmcnt(1)" \
+        : [h] "+v"(h), [C] "+v"(C), [g0] "+v"(g0), [acc1] "=&v"(acc1), [acc2] "=&v"(acc2), [acc3] "=&v"(acc3), [t0] "=&v"(t0), \
+          [t1] "=&v"(t1), [a2] "=&v"(a2), [b] "=&v"(b), [b2] "=&v"(b2), [gn] "=&v"(gn), [gaddr] "+v"(gaddr), [haddr] "+v"(haddr) \
+        : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), [w5] "v"(w[5]), [w6] "v"(w[6]), \
+          [w7] "v"(w[7]), [w8] "v"(w[8]), [w9] "v"(w[9]), [w10] "v"(w[10]), [w11] "v"(w[11]), [w12] "v"(w[12]), [w13] "v"(w[13]), \
+          [w14] "v"(w[14]), [w15] "v"(w[15]), [A] "v"(A), [B] "v"(Bc), [gstep] "s"(GS * 4), [row0] "s"(row0) \
+        : "memory");
+template <int DIAG>
 __device__ __forceinline__ void recur5(const float* gx, const float (&w)[H], float* hout, const int hs) {
   const int lane = threadIdx.x & 63;
   const bool is_g = (lane >> 4) == 2;
@@ -215,70 +294,19 @@ __device__ __forceinline__ void recur5(const float* gx, const float (&w)[H], flo
   const unsigned long long row0 = 0xffffull;
   for (int s = 0; s < T; ++s) {
     float acc1, acc2, acc3, t0, t1, a2, b, b2, gn;
-    asm volatile(
-        "ds_read_b32 %[gn], %[gaddr]\n\t"
-        "v_fmac_f32_dpp %[g0], %[h], %[w0] row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %[acc1], %[h], %[w1] row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %[acc2], %[h], %[w2] row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %[acc3], %[h], %[w3] row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %[g0], %[h], %[w4] row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %[acc1], %[h], %[w5] row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %[acc2], %[h], %[w6] row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %[acc3], %[h], %[w7] row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %[g0], %[h], %[w8] row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %[acc1], %[h], %[w9] row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %[acc2], %[h], %[w10] row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %[acc3], %[h], %[w11] row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %[g0], %[h], %[w12] row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %[acc1], %[h], %[w13] row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %[acc2], %[h], %[w14] row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %[acc3], %[h], %[w15] row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_u32 %[gaddr], %[gstep], %[gaddr]\n\t"
-        "v_add_f32 %[g0], %[g0], %[acc1]\n\t"
-        "v_add_f32 %[acc2], %[acc2], %[acc3]\n\t"
-        "v_add_f32 %[t0], %[g0], %[acc2]\n\t"
-        "v_exp_f32 %[t0], %[t0]\n\t"
-        "s_nop 0\n\t"
-        "v_add_f32 %[t0], 1.0, %[t0]\n\t"
-        "v_rcp_f32 %[t0], %[t0]\n\t"
-        "s_nop 0\n\t"
-        "v_fma_f32 %[t0], %[t0], %[A], %[B]\n\t"       // t0 = act: rows (i, f, g, o)
-        "v_mov_b32 %[b], %[t0]\n\t"
-        "s_nop 1\n\t"
-        "v_permlane32_swap_b32 %[t0], %[b]\n\t"         // t0 = (i, f, i, f), b = (g, o, g, o)
-        "s_nop 1\n\t"
-        "v_mov_b32 %[a2], %[t0]\n\t"
-        "v_mov_b32 %[b2], %[b]\n\t"
-        "s_nop 1\n\t"
-        "v_permlane16_swap_b32 %[t0], %[a2]\n\t"        // t0 = i everywhere, a2 = f
-        "v_permlane16_swap_b32 %[b], %[b2]\n\t"         // b = g, b2 = o
-        "s_nop 1\n\t"
-        "v_mul_f32 %[t1], %[t0], %[b]\n\t"              // i * G
-        "v_fmac_f32 %[t1], %[a2], %[C]\n\t"             // + f * C
-        "v_mul_f32 %[a2], -2.0, %[b2]\n\t"              // -2 o
-        "v_exp_f32 %[t0], %[t1]\n\t"
-        "v_mov_b32 %[C], %[t1]\n\t"
-        "v_add_f32 %[t0], 1.0, %[t0]\n\t"
-        "v_rcp_f32 %[t0], %[t0]\n\t"
-        "s_nop 0\n\t"
-        "v_fma_f32 %[h], %[t0], %[a2], %[b2]\n\t"
-        "s_mov_b64 exec, %[row0]\n\t"
-        "ds_write_b32 %[haddr], %[h]\n\t"
-        "s_mov_b64 exec, -1\n\t"
-        "v_add_u32 %[haddr], 4, %[haddr]\n\t"
-        "s_waitcnt lgkmcnt(1)"
-        : [h] "+v"(h), [C] "+v"(C), [g0] "+v"(g0), [acc1] "=&v"(acc1), [acc2] "=&v"(acc2), [acc3] "=&v"(acc3), [t0] "=&v"(t0),
-          [t1] "=&v"(t1), [a2] "=&v"(a2), [b] "=&v"(b), [b2] "=&v"(b2), [gn] "=&v"(gn), [gaddr] "+v"(gaddr), [haddr] "+v"(haddr)
-        : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), [w5] "v"(w[5]), [w6] "v"(w[6]),
-          [w7] "v"(w[7]), [w8] "v"(w[8]), [w9] "v"(w[9]), [w10] "v"(w[10]), [w11] "v"(w[11]), [w12] "v"(w[12]), [w13] "v"(w[13]),
-          [w14] "v"(w[14]), [w15] "v"(w[15]), [A] "v"(A), [B] "v"(Bc), [gstep] "s"(GS * 4), [row0] "s"(row0)
-        : "memory");
+    if constexpr (DIAG == 0) {
+      LSTM5_STEP(LSTM5_MATVEC)
+    } else if constexpr (DIAG == 1) {
+      LSTM5_STEP(LSTM5_NOMAT)
+    } else {
+      LSTM5_STEP(LSTM5_MATVEC LSTM5_MATVEC2)
+    }
     g0 = gn;
   }
 }
 
 
-template <int FORM>
+template <int FORM, int DIAG5 = 0>
 __global__ __launch_bounds__(64) void k(const float* __restrict__ gx_g, const float* __restrict__ whh_g, float* out, int reps,
                                         unsigned long long* clk) {
   __shared__ float gx[T * GS + 64];
@@ -298,7 +326,7 @@ __global__ __launch_bounds__(64) void k(const float* __restrict__ gx_g, const fl
     for (int j = 0; j < H; ++j) w[j] = whh_g[r5 * H + j] * sc5;
     const unsigned long long c0 = __builtin_readcyclecounter();
     for (int r = 0; r < reps; ++r) {
-      recur5(gx, w, hout, 48);
+      recur5<DIAG5>(gx, w, hout, 48);
       __syncthreads();
     }
     const unsigned long long c1 = __builtin_readcyclecounter();
@@ -362,14 +390,16 @@ int main() {
   hipMemcpy(d_gx, gx.data(), gx.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(d_whh, whh.data(), whh.size() * 4, hipMemcpyHostToDevice);
   const int reps = 400;
-  for (int form = 0; form < 6; ++form) {
+  for (int form = 0; form < 8; ++form) {
     for (int rep = 0; rep < 2; ++rep) {
       if (form == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(64), 0, 0, d_gx, d_whh, d_out, reps, d_clk);
       else if (form == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(64), 0, 0, d_gx, d_whh, d_out, reps, d_clk);
       else if (form == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(64), 0, 0, d_gx, d_whh, d_out, reps, d_clk);
       else if (form == 3) hipLaunchKernelGGL(k<3>, dim3(256), dim3(64), 0, 0, d_gx, d_whh, d_out, reps, d_clk);
       else if (form == 4) hipLaunchKernelGGL(k<4>, dim3(256), dim3(64), 0, 0, d_gx, d_whh, d_out, reps, d_clk);
-      else hipLaunchKernelGGL(k<5>, dim3(256), dim3(64), 0, 0, d_gx, d_whh, d_out, reps, d_clk);
+      else if (form == 5) hipLaunchKernelGGL((k<5, 0>), dim3(256), dim3(64), 0, 0, d_gx, d_whh, d_out, reps, d_clk);
+      else if (form == 6) hipLaunchKernelGGL((k<5, 1>), dim3(256), dim3(64), 0, 0, d_gx, d_whh, d_out, reps, d_clk);
+      else hipLaunchKernelGGL((k<5, 2>), dim3(256), dim3(64), 0, 0, d_gx, d_whh, d_out, reps, d_clk);
       hipDeviceSynchronize();
     }
     std::vector<float> out(H * 48);

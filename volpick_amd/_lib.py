@@ -101,6 +101,8 @@ SIGNATURES = {
          C.c_int, C.c_void_p, C.c_int, _I64P, _I64P, _I64P, _I64P, _I64P, _I64P, _FP, C.POINTER(C.c_int32), C.c_int,
          C.POINTER(C.c_int)],
     ),
+    "vp_pick_rows": (C.c_int, [_H, C.c_void_p, C.c_int64, C.POINTER(VpTriggerSpec), C.c_int, _I64P, _I64P, _I64P, _FP,
+                               C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int)]),
     "vp_classify_submit": (
         C.c_int,
         [_H, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -568,6 +568,39 @@ int vp_classify(vp_handle* h, const float* stream, int stream_mem, int64_t N, in
   return VP_OK;
 }
 
+// The trigger scan alone, over several rows of one device array in ONE launch and ONE synchronisation (what classify() runs
+// on the stacked rows of a day-long block that annotate has left on the device).
+int vp_pick_rows(vp_handle* h, const float* rows_dev, int64_t N, const vp_trigger_spec* specs, int n_specs, int64_t* on,
+                 int64_t* off, int64_t* peak, float* value, int32_t* spec_of, int cap, int* n_found) {
+  VP_REQUIRE(h && rows_dev && n_found && N > 0, "null / empty argument");
+  VP_REQUIRE(n_specs > 0 && n_specs <= 16 && specs, "bad trigger specs");
+  VP_REQUIRE(cap >= 0 && (cap == 0 || (on && off && peak && value)), "null output arrays");
+  VP_HIP(hipSetDevice(h->device));
+  int slot = -1;
+  for (int i = 0; i < VP_MAX_INFLIGHT; ++i)
+    if (!h->slot[i].busy) {
+      slot = i;
+      break;
+    }
+  VP_REQUIRE(slot >= 0, "all %d in-flight slots are busy", VP_MAX_INFLIGHT);
+  const float* rows[16];
+  int64_t lens[16];
+  float t_on[16], t_off[16];
+  for (int i = 0; i < n_specs; ++i) {
+    VP_REQUIRE(specs[i].row >= 0 && specs[i].row < h->net.n_out, "spec %d: row %d out of range", i, specs[i].row);
+    VP_REQUIRE(specs[i].thr_off <= specs[i].thr_on, "spec %d: thr_off must not exceed thr_on", i);
+    rows[i] = rows_dev + (size_t)specs[i].row * N;
+    lens[i] = N;
+    t_on[i] = specs[i].thr_on;
+    t_off[i] = specs[i].thr_off;
+  }
+  vp_handle::Slot& sl = h->slot[slot];
+  int rc = scan_submit(h, sl, rows, lens, t_on, t_off, n_specs, cap);
+  if (rc != VP_OK) return rc;
+  VP_HIP(hipStreamSynchronize(h->stream));
+  return scan_collect(sl, on, off, peak, value, spec_of, cap, n_found);
+}
+
 // K stream blocks in one call: the windows of ALL blocks fill the forward batches together, as the
 // reference's batch_size spans every fragment of the stream it is given (README.md:54-66); stacking and
 // the trigger scan of all blocks are one launch each.
