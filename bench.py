@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU budget of the baseline legs, all models together")
     ap.add_argument("--contexts", type=int, default=0,
                     help="device contexts (stream + workspace) steps alternate over; 0 = the model's default (PhaseNet 3, EQTransformer 4)")
+    ap.add_argument("--depth", type=int, default=0, help="submits in flight per device context (0 = the model's default)")
     ap.add_argument("--strong", action="store_true", help="time configs[3]: one 24 h stream sharded over the ranks")
     ap.add_argument("--sustain-seconds", type=float, default=5.2,
                     help="length of the one long timed region per model reported as `sustained` (0 = skip)")
@@ -309,7 +310,7 @@ def bench_model(model_name, env, cpu_budget_s):
     # submits in flight per context: the host enqueues ahead of the GPU, and one context's latency-bound stages
     # (LSTM/attention, small tail kernels) overlap the other's MFMA-bound ones.  Every step is still one full pass
     # over one batch, and every step is collected inside the timed region.
-    NCTX, DEPTH = (args.contexts if args.contexts > 0 else model.n_contexts), 2
+    NCTX, DEPTH = (args.contexts if args.contexts > 0 else model.n_contexts), (args.depth if args.depth > 0 else 2)
     ctxs = [model._context(k) for k in range(NCTX)]
     outs = [out] + [torch.empty_like(out) for _ in range(NCTX - 1)]
 
