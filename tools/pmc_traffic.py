@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""HBM bytes per launch from two rocprofv3 counter passes -> profiles/r02_traffic.json.
+"""HBM bytes per launch from two rocprofv3 counter passes -> profiles/r03_traffic.json (or the name given as the second argument).
 
     tools/pmc_traffic.sh            (on the GPU box: four --pmc runs of tools/run_forward.py, counters only)
     python tools/pmc_traffic.py gpurun_out/pmc
@@ -15,7 +15,7 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-OUT = ROOT / "profiles" / "r02_traffic.json"
+OUT = ROOT / "profiles" / (sys.argv[2] if len(sys.argv) > 2 else "r03_traffic.json")
 
 
 def per_kernel(path, counter):
