@@ -604,6 +604,14 @@ def bench_strong(env):
         "weight_broadcast_s": t_bcast,
         "weight_broadcast_path": _bcast_path(),
     }
+    if use_dist:  # what every rank saw (its own segment, its own median), so that a multi-GPU line checks itself
+        info = {"rank": rank, "device": torch.cuda.current_device(), "segment": [sg["lo"], sg["hi"]] if sg else None,
+                "keeps": [sg["keep_lo"], sg["keep_hi"]] if sg else None,
+                "ms_per_step_own_median": statistics.median(OWN_TIMES) / steps * 1e3 if OWN_TIMES else None,
+                "weight_broadcast_s": t_bcast, "rccl_comm_ranks": _rccl_ranks()}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, info)
+        out["ranks"] = gathered
     if rank == 0:
         out["picks"] = len(res[0].picks)
         out["detections"] = len(res[0].detections)
