@@ -1032,8 +1032,8 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
       // (prepost.hip): window cut from the stream, per-channel mean, peak / std amplitude, scale — the window is read
       // once into registers and the normalised rows go straight into the x image (no input tensor in memory).
       const PreArgs& p = a.pre;
-      float* red = lds + 11 * W0_S;  // [3][NWV] partials, then stat[3][2] (free arena space behind the x rows)
-      float* stat = red + 3 * NWV;
+      float* red = lds + 11 * W0_S;  // [9][NWV] partials (sums, maxima, minima), then stat[3][2] (free arena space behind the x rows)
+      float* stat = red + 9 * NWV;
       long start = p.dense ? 0 : (long)(p.first_window + win) * p.step;
       if (!p.dense && start > p.N - T0) start = p.N - T0;  // tail window flush with the end
       const float* src = p.src + (p.dense ? (long)win * 3 * T0 : start);
@@ -1053,9 +1053,26 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
           v[c][k] = t < T0 ? src[c * cs + t] : 0.f;
           sum[c] += v[c][k];
         }
+      const bool one_pass = p.norm == VP_NORM_PEAK;  // uniform
+      // norm = peak in ONE reduction round: max_k |v_k - mean| = max(vmax - mean, mean - vmin) bit for bit (rounding is
+      // monotonic and symmetric), so the maxima and minima travel with the sums (two barriers and one reduction round
+      // fewer in front of every window's first convolution; a NaN / Inf sample makes the mean non-finite: the window is
+      // flagged and its predictions become NaN whatever the amplitude says)
+      float vhi[3] = {-INFINITY, -INFINITY, -INFINITY}, vlo[3] = {INFINITY, INFINITY, INFINITY};
+      if (one_pass) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int k = 0; k < MAXE; ++k)
+            if (tid + k * NTH < T0) vhi[c] = fmaxf(vhi[c], v[c][k]), vlo[c] = fminf(vlo[c], v[c][k]);
+      }
       for (int c = 0; c < 3; ++c) {
         const float r = wave_sum(sum[c]);
         if (lane == 0) red[c * NWV + wave] = r;
+        if (one_pass) {
+          const float rh = wave_max(vhi[c]), rl = -wave_max(-vlo[c]);
+          if (lane == 0) red[(3 + c) * NWV + wave] = rh, red[(6 + c) * NWV + wave] = rl;
+        }
       }
       for (int i = tid; i < 3 * (W0_S - T0); i += NTH) {  // zero margins of the x rows: samples -4 .. -1 and T0 .. 3019
         const int c = i / (W0_S - T0), k = i - c * (W0_S - T0);
@@ -1065,10 +1082,17 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
       if (tid < 3) {
         float acc = 0.f;
         for (int i = 0; i < NWV; ++i) acc += red[tid * NWV + i];
-        stat[tid * 2] = acc / (float)T0;
+        const float mu = acc / (float)T0;
+        stat[tid * 2] = mu;
+        if (one_pass) {
+          float h = red[(3 + tid) * NWV], l = red[(6 + tid) * NWV];
+          for (int i = 1; i < NWV; ++i) h = fmaxf(h, red[(3 + tid) * NWV + i]), l = fminf(l, red[(6 + tid) * NWV + i]);
+          stat[tid * 2 + 1] = fmaxf(h - mu, mu - l);
+        }
       }
       __syncthreads();
       const float mean[3] = {stat[0], stat[2], stat[4]};
+      if (!one_pass) {
       float m[3] = {0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < 3; ++c)
@@ -1077,27 +1101,23 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
           const int t = tid + k * NTH;
           if (t < T0) {
             const float d = v[c][k] - mean[c];
-            if (p.norm == VP_NORM_PEAK) {
-              m[c] = fmaxf(m[c], fabsf(d));
-              if (d != d) m[c] = d;  // propagate NaN like torch.max
-            } else {
-              m[c] += d * d;
-            }
+            m[c] += d * d;
           }
         }
       __syncthreads();
       for (int c = 0; c < 3; ++c) {
-        const float r = (p.norm == VP_NORM_PEAK) ? wave_max(m[c]) : wave_sum(m[c]);
+        const float r = wave_sum(m[c]);
         if (lane == 0) red[c * NWV + wave] = r;
       }
       __syncthreads();
       if (tid < 3) {
         const float* r = red + tid * NWV;
         float acc = r[0];
-        for (int i = 1; i < NWV; ++i) acc = (p.norm == VP_NORM_PEAK) ? fmaxf(acc, r[i]) : acc + r[i];
+        for (int i = 1; i < NWV; ++i) acc = acc + r[i];
         stat[tid * 2 + 1] = acc;
       }
       __syncthreads();
+      }
       for (int c = 0; c < 3; ++c) poisoned |= !isfinite(stat[2 * c]) || !isfinite(stat[2 * c + 1]);
       float amp[3];
       if (p.per_comp) {
