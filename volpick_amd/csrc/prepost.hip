@@ -56,6 +56,23 @@ __global__ __launch_bounds__(1024) void gather_normalize_kernel(const PreArgs a)
       v[c][k] = t < T ? src[c * cs + t] : 0.f;
       s[c] += v[c][k];
     }
+  // norm = peak in ONE reduction round: max_k |v_k - mean| = max(vmax - mean, mean - vmin) bit for bit (rounding is monotonic and
+  // symmetric), so the maxima and minima travel with the sums.  A NaN / Inf sample makes the mean non-finite: the window is
+  // flagged and its predictions become NaN whatever the amplitude says.
+  const bool one_pass = a.norm == VP_NORM_PEAK;  // uniform
+  __shared__ float red_hi[3][NWV], red_lo[3][NWV];
+  if (one_pass) {
+    float vhi[3] = {-INFINITY, -INFINITY, -INFINITY}, vlo[3] = {INFINITY, INFINITY, INFINITY};
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int k = 0; k < MAXE; ++k)
+        if (tid + k * NTH < T) vhi[c] = fmaxf(vhi[c], v[c][k]), vlo[c] = fminf(vlo[c], v[c][k]);
+    for (int c = 0; c < 3; ++c) {
+      const float rh = wave_max(vhi[c]), rl = -wave_max(-vlo[c]);
+      if (lane == 0) red_hi[c][wave] = rh, red_lo[c][wave] = rl;
+    }
+  }
   for (int c = 0; c < 3; ++c) {
     const float r = wave_sum(s[c]);
     if (lane == 0) red[c][wave] = r;
@@ -64,39 +81,42 @@ __global__ __launch_bounds__(1024) void gather_normalize_kernel(const PreArgs a)
   if (tid < 3) {
     float acc = 0.f;
     for (int i = 0; i < NWV; ++i) acc += red[tid][i];
-    stat[tid][0] = acc / (float)T;
+    const float mu = acc / (float)T;
+    stat[tid][0] = mu;
+    if (one_pass) {
+      float h = red_hi[tid][0], l = red_lo[tid][0];
+      for (int i = 1; i < NWV; ++i) h = fmaxf(h, red_hi[tid][i]), l = fminf(l, red_lo[tid][i]);
+      stat[tid][1] = fmaxf(h - mu, mu - l);
+    }
   }
   __syncthreads();
   const float mean[3] = {stat[0][0], stat[1][0], stat[2][0]};
-  float m[3] = {0.f, 0.f, 0.f};
+  if (!one_pass) {  // norm = std: the sum of squares needs the mean first
+    float m[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int k = 0; k < MAXE; ++k) {
-      const int t = tid + k * NTH;
-      if (t < T) {
-        const float d = v[c][k] - mean[c];
-        if (a.norm == VP_NORM_PEAK) {
-          m[c] = fmaxf(m[c], fabsf(d));
-          if (d != d) m[c] = d;  // propagate NaN like torch.max
-        } else {
+      for (int k = 0; k < MAXE; ++k) {
+        const int t = tid + k * NTH;
+        if (t < T) {
+          const float d = v[c][k] - mean[c];
           m[c] += d * d;
         }
       }
+    __syncthreads();
+    for (int c = 0; c < 3; ++c) {
+      const float r = wave_sum(m[c]);
+      if (lane == 0) red[c][wave] = r;
     }
-  __syncthreads();
-  for (int c = 0; c < 3; ++c) {
-    const float r = (a.norm == VP_NORM_PEAK) ? wave_max(m[c]) : wave_sum(m[c]);
-    if (lane == 0) red[c][wave] = r;
+    __syncthreads();
+    if (tid < 3) {
+      const float* r = red[tid];
+      float acc = r[0];
+      for (int i = 1; i < NWV; ++i) acc = acc + r[i];
+      stat[tid][1] = acc;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (tid < 3) {
-    const float* r = red[tid];
-    float acc = r[0];
-    for (int i = 1; i < NWV; ++i) acc = (a.norm == VP_NORM_PEAK) ? fmaxf(acc, r[i]) : acc + r[i];
-    stat[tid][1] = acc;
-  }
-  __syncthreads();
   if (a.flags && tid == 0) {  // a non-finite sample shows in the statistics of its channel
     bool bad = false;
     for (int c = 0; c < 3; ++c) bad |= !isfinite(stat[c][0]) || !isfinite(stat[c][1]);
@@ -299,25 +319,48 @@ __device__ __forceinline__ void trigger_scan_body(const PickArgs& a) {
   for (int r = wave; r < ne; r += 4) {
     const long off = c0 + ends[r];
     long on = -1;
-    for (long pos = off; pos >= 0; pos -= 64) {
-      const long idx = pos - lane;
-      const float v = (idx >= 0) ? a.trace[idx] : -INFINITY;
-      const bool above = (idx >= 0) && (v > a.thr_off);
-      const unsigned long long broken = __ballot(!above);
-      const int k = broken ? __ffsll((long long)broken) - 1 : 64;  // lanes [0, k) lie inside the run
-      const unsigned long long hit = __ballot(lane < k && v > a.thr_on);
-      if (hit) on = pos - (63 - __clzll((long long)hit));
-      if (k < 64) break;
+    // four 64-sample blocks per trip, their reads in flight together: a Detection run (thr_off = thr / 2) is thousands of
+    // samples long, and with one dependent 64-sample read per trip the kernel took 22 us on an EQTransformer step (14 now;
+    // requesting the next trip ahead of the test changed nothing more)
+    bool done = false;
+    for (long pos = off; pos >= 0 && !done; pos -= 256) {
+      float vv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long idx = pos - 64 * u - lane;
+        vv[u] = (idx >= 0) ? a.trace[idx] : -INFINITY;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (done) continue;
+        const long p0 = pos - 64 * u;
+        if (p0 < 0) {
+          done = true;
+          continue;
+        }
+        const long idx = p0 - lane;
+        const float v = vv[u];
+        const bool above = (idx >= 0) && (v > a.thr_off);
+        const unsigned long long broken = __ballot(!above);
+        const int k = broken ? __ffsll((long long)broken) - 1 : 64;  // lanes [0, k) lie inside the run
+        const unsigned long long hit = __ballot(lane < k && v > a.thr_on);
+        if (hit) on = p0 - (63 - __clzll((long long)hit));
+        if (k < 64) done = true;
+      }
     }
     if (on < 0) continue;
     float best = -INFINITY;
     long arg = off;
-    for (long i = on + lane; i <= off; i += 64) {
-      const float v = a.trace[i];
-      if (v > best) {
-        best = v;
-        arg = i;
-      }
+    for (long i0 = on + lane; i0 <= off; i0 += 256) {  // first argmax: a lane meets its samples in increasing order
+      float vv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) vv[u] = (i0 + 64 * u <= off) ? a.trace[i0 + 64 * u] : -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (vv[u] > best) {
+          best = vv[u];
+          arg = i0 + 64 * u;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
