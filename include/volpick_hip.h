@@ -75,7 +75,9 @@ typedef struct {
                                       kernel, bit6 = the fused decoder tail (stages 4-6 + heads), bit7 = the fused encoder 3-6 kernel, bit8 = stages 1 and 2 of the fused encoder 0-2 kernel on the fp32 MFMA
                                       instead of the bf16 matrix cores with exact three-piece operands (the two
                                       forms agree to fp32 rounding, not bitwise), bit9 = the bf16-piece ResCNN kernel with
-                                      four waves per window (one per SIMD) instead of eight (K split over wave pairs) */
+                                      four waves per window (one per SIMD) instead of eight (K split over wave pairs),
+                                      bit10 = the decoder tail computes every tile of a row even where annotate / classify
+                                      blind the output (default: only the tiles that hold kept samples) */
   int32_t reserved[4];        /* must be 0 */
 } vp_config;
 

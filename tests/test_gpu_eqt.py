@@ -260,6 +260,26 @@ def test_in_kernel_preprocessing_is_bitwise_gather_normalize(norm, per_comp):
     fused._release(), via_tensor._release()
 
 
+@pytest.mark.parametrize("blinding", [(500, 500), (1000, 1000), (250, 777), (0, 0), (496, 1), (17, 0), (2999, 2999)])
+def test_decoder_tail_skips_only_blinded_tiles(model, blinding):
+    """annotate / classify blind the first and last samples of every window; eqt_tail3_kernel computes only the time tiles that
+    hold kept samples (four tiles of 1264 instead of five of 1200 for blinding (500, 500)).  The stacked rows are bit for bit
+    those of the plan that computes every tile (plan_flags[7] bit 10), for avg and max stacking, with a tail window."""
+    full = EQTransformer.from_pretrained("volpick")
+    full._plan_flags = (0, 0, 0, 0, 0, 0, 0, 1024)
+    full.cuda()
+    data, _, _ = synthetic_stream_array(6000 + 500 * 17 + 233, seed=431, n_events=4)
+    for stacking in ("avg", "max"):
+        args = model._argdict(dict(overlap=5500, blinding=blinding, stacking=stacking))
+        a, fva, lva, nwa = model._annotate_block(data, args)
+        b, fvb, lvb, nwb = full._annotate_block(data, args)
+        assert (fva, lva, nwa) == (fvb, lvb, nwb) and nwa == 19
+        assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True)
+    x = synthetic_windows(3, 6000, seed=12)  # model(x): the whole row, unchanged
+    assert np.array_equal(model._forward_raw(x, preprocess=True), full._forward_raw(x, preprocess=True))
+    full._release()
+
+
 @pytest.mark.parametrize("overlap,blinding,stacking", [(5500, (500, 500), "avg"), (1800, (500, 500), "avg"),
                                                        (3000, (1000, 1000), "max")])
 def test_annotate_parity(model, oracle, overlap, blinding, stacking):

@@ -22,6 +22,7 @@ struct vp_handle {
   // launch cuts its windows itself (the caller keeps that stream buffer alive while profiling)
   vp::PreArgs last_pre{};
   int last_pre_windows = 0;
+  int last_out_lo = 0, last_out_hi = 0;  // ... and the kept output range of that batch (Net::out_lo / out_hi)
   // growable device scratch
   float* d_in = nullptr;    // staged host input (stream or windows)
   size_t d_in_cap = 0;
@@ -102,6 +103,7 @@ int run_batch(vp_handle* h, const vp::PreArgs& pa, int nb) {
   if (pa.preprocess) {
     h->last_pre = pa;
     h->last_pre_windows = nb;
+    h->last_out_lo = net.out_lo, h->last_out_hi = net.out_hi;
   }
   if (net.fused_pre && pa.preprocess) {
     net.pre = &pa;
@@ -335,7 +337,9 @@ static int annotate_device(vp_handle* h, const float* stream, int stream_mem, in
     for (int64_t w0 = 0; w0 < nwin; w0 += batch) {
       const int nb = (int)std::min<int64_t>(batch, nwin - w0);
       net.y = h->d_pred + (size_t)w0 * out_w;
+      net.out_lo = blind_l, net.out_hi = T - blind_r;  // what stacking will read of every window
       rc = run_batch(h, pre_args(h, d_stream, 0, N, step, w0, 1), nb);
+      net.out_lo = net.out_hi = 0;
       net.y = y_saved;
       if (rc != VP_OK) return rc;
     }
@@ -944,8 +948,12 @@ struct ProfilePre {
   vp::Net& net;
   ProfilePre(vp_handle* h, int B) : net(h->net) {
     if (net.fused_pre && h->last_pre_windows >= B && h->last_pre.src) net.pre = &h->last_pre;
+    net.out_lo = h->last_out_lo, net.out_hi = h->last_out_hi;  // the launches are profiled over the range the last call kept
   }
-  ~ProfilePre() { net.pre = nullptr; }
+  ~ProfilePre() {
+    net.pre = nullptr;
+    net.out_lo = net.out_hi = 0;
+  }
 };
 
 // Runs every launch of the forward pass `iters` times on B windows (whatever the input

@@ -46,39 +46,54 @@ namespace vp {
 
 namespace {
 
-constexpr int TW = 1200, TILES_PER_ROW = 5, T_OUT = 6000;
+constexpr int T_OUT = 6000;
 constexpr int T3_NTH = 512, T3_WAVES = 8;
-// n-tiles per wave and stage: the first four waves of a workgroup (one per SIMD) are the OLDER wave of their SIMD, whose MFMAs
-// issue first; with equal shares the younger wave was still a quarter of a stage behind when the older one was through
-// (tools/tail_clock.py).  Stage 4 needs 10 n-tiles per phase: 3 to the older, 2 to the younger wave; stages 5 and 6 measured
-// no faster with 6 + 4 than with 5 + 5
-constexpr int NB4O = 3, NB4Y = 2, NB5 = 5, NB6 = 5;
-constexpr int C4 = 2 * (NB4O + NB4Y) * 16, C5 = 4 * NB5 * 16, C6 = T3_WAVES * NB6 * 16;  // columns computed: 160, 320, 640
-constexpr int PARK_COLS = 168;  // stage-3 samples a tile parks: the 160 its kept outputs need + the one more (161) that reaches them
-                                // through the zero-weight padded taps of stages 5 / 6 and the heads (0 x stale non-finite = NaN)
-constexpr int NC4 = 208, NC5 = C5 + 16, NC6 = C6 + 16;  // (a place for every column a stage writes or reads: no range tests)                            // image columns (every one a stage may read), 8 mod 16
-using Q4 = B3Chunk<32, NC4>;                                                      // quad-plane images (conv_b3.h)
-using Q5 = B3Chunk<16, NC5>;
-using Q6 = B3Chunk<16, NC6>;
-constexpr int HSB = 81, OUT_QS = 16 * HSB, OUT_PS = 2 * OUT_QS;                  // heads' staging: 8-byte units per row / quad plane / piece
-constexpr int HT_N = 43;                                                         // head table entries: k = -15 .. 27
-constexpr int R0_BYTES = 3 * Q6::PS * 2, R1_BYTES = 3 * OUT_PS * 8;
-constexpr int A5_N = 2 * B3Steps<16, 5>::STEPS * 3 * 64, A6_N = B3Steps<16, 7>::STEPS * 3 * 64;  // uint4: operands of stages 5 and 6
-constexpr int OFF_R1 = R0_BYTES, OFF_HT = OFF_R1 + R1_BYTES, OFF_A5 = OFF_HT + 3 * HT_N * 16 + 48, OFF_A6 = OFF_A5 + A5_N * 16;
-constexpr int T3_LDS_BYTES = OFF_A6 + A6_N * 16;
-static_assert(OFF_A5 % 16 == 0, "16-byte fragments");
-static_assert(3 * Q4::PS * 2 <= R0_BYTES && 3 * Q5::PS * 2 <= R1_BYTES && T3_LDS_BYTES <= 160 * 1024 && OFF_R1 % 16 == 0 && OFF_HT % 16 == 0,
-              "LDS budget");
-static_assert(NC4 >= C4 + 4 && NC5 >= C5 + 6 && NC6 >= C6 + 8 && NC5 >= 2 * C4 && NC6 >= 2 * C5 && HSB % 2 == 1,
-              "every column a stage reads or writes has a place");
-static_assert(TILES_PER_ROW * TW == T_OUT && TW % 16 == 0 && TW % 8 == 0, "tile grid");
-// what a tile needs (file comment) is computed, and what is computed has a place
-static_assert(TW + 11 <= 2 * C6 && C6 / 8 <= HSB - 1 && (TW / 16 + 15) / 16 <= T3_WAVES, "stage 6 / heads");
-static_assert(TW / 2 + 6 + 6 <= 2 * C5 && TW / 4 + 6 + 5 <= 2 * C4 && TW / 8 + 6 + 4 <= PARK_COLS && PARK_COLS <= NC4, "halo chain");
-// ... and everything a kept output touches, zero-weight taps included, is this tile's data: heads staged t <= TW + 12 -> stage-6
-// column <= (TW + 12) / 2 -> stage-5 sample + 7 -> stage-5 column -> stage-4 sample + 1 + 5 -> stage-4 column -> image column + 4
-static_assert(((((TW + 12) / 2 + 7) / 2 + 1 + 5) / 2 + 4) < PARK_COLS, "closure of the kept outputs under the padded taps");
-static_assert(PARK_COLS * 8 <= 3 * T3_NTH, "three (four channels x one sample) items per thread");
+constexpr int HSB = 81, OUT_QS = 16 * HSB, OUT_PS = 2 * OUT_QS;  // heads' staging: 8-byte units per row / quad plane / piece
+constexpr int HT_N = 43;                                         // head table entries: k = -15 .. 27
+// Two tilings of a row.  TW = 1200: five tiles cover the 6000 samples (the form of round 2).  TW = 1264: FOUR tiles cover the
+// 5008 samples [496, 5504) that are left when the caller blinds 500 samples at either end of every window (README.md:58,
+// BASELINE configs[2]) -- the blinded samples are never stacked, so their tiles are not computed: the launch walks the
+// output range [t_lo, t_hi) it is given, in whichever tiling needs fewer tiles (plan_eqt_fuse_tail_b3).  The wider tile
+// fits the same 157 KB: stage 6 still computes 640 columns (needs 638), stages 4 and 5 one n-tile more per wave (192 / 384
+// columns for 164 / 322 needed), whose surplus outputs beyond the stage-6 image are not stored.
+template <int TW_>
+struct T3 {
+  static constexpr int TW = TW_;
+  // n-tiles per wave and stage: the first four waves of a workgroup (one per SIMD) are the OLDER wave of their SIMD, whose MFMAs
+  // issue first; with equal shares the younger wave was still a quarter of a stage behind when the older one was through
+  // (tools/tail_clock.py).  TW = 1200: stage 4 needs 10 n-tiles per phase: 3 to the older, 2 to the younger wave; stages 5 and 6
+  // measured no faster with 6 + 4 than with 5 + 5
+  static constexpr int NB4O = 3, NB4Y = TW_ > 1200 ? 3 : 2, NB5 = TW_ > 1200 ? 6 : 5, NB6 = 5;
+  static constexpr int C4 = 2 * (NB4O + NB4Y) * 16, C5 = 4 * NB5 * 16, C6 = T3_WAVES * NB6 * 16;  // columns computed per stage
+  // stage-3 samples a tile parks: what its kept outputs need + the one more that reaches them through the zero-weight padded
+  // taps of stages 5 / 6 and the heads (0 x stale non-finite = NaN)
+  static constexpr int PARK_COLS = TW_ > 1200 ? 176 : 168;
+  static constexpr int NC4 = 208, NC5 = C5 + 16, NC6 = C6 + 16;  // image columns (a place for every column a stage reads)
+  using Q4 = B3Chunk<32, NC4>;                                    // chunk-plane images (conv_b3.h)
+  using Q5 = B3Chunk<16, NC5>;
+  using Q6 = B3Chunk<16, NC6>;
+  static constexpr bool GUARD5 = 2 * C5 > NC6;  // stage 5 computes columns beyond the stage-6 image: those stores are skipped
+  static constexpr int R0_BYTES = 3 * Q6::PS * 2, R1_BYTES = 3 * OUT_PS * 8;
+  static constexpr int A5_N = 2 * B3Steps<16, 5>::STEPS * 3 * 64, A6_N = B3Steps<16, 7>::STEPS * 3 * 64;  // uint4: operands of stages 5 and 6
+  static constexpr int OFF_R1 = R0_BYTES, OFF_HT = OFF_R1 + R1_BYTES, OFF_A5 = OFF_HT + 3 * HT_N * 16 + 48, OFF_A6 = OFF_A5 + A5_N * 16;
+  static constexpr int LDS_BYTES = OFF_A6 + A6_N * 16;
+  static_assert(OFF_A5 % 16 == 0, "16-byte fragments");
+  static_assert(3 * Q4::PS * 2 <= R0_BYTES && 3 * Q5::PS * 2 <= R1_BYTES && LDS_BYTES <= 160 * 1024 && OFF_R1 % 16 == 0 && OFF_HT % 16 == 0,
+                "LDS budget");
+  static_assert(NC4 >= PARK_COLS && NC5 >= C5 + 6 && NC6 >= C6 + 8 && NC5 >= 2 * C4 && (GUARD5 || NC6 >= 2 * C5) && HSB % 2 == 1,
+                "every column a stage reads or writes has a place");
+  static_assert(TW % 16 == 0 && TW % 8 == 0, "tile grid");
+  // what a tile needs (file comment) is computed, and what is computed has a place
+  static_assert(TW + 11 <= 2 * C6 && C6 / 8 <= HSB - 1 && (TW / 16 + 15) / 16 <= T3_WAVES, "stage 6 / heads");
+  static_assert(TW / 2 + 6 + 6 <= 2 * C5 && TW / 2 + 6 + 6 <= NC6 && TW / 4 + 6 + 5 <= 2 * C4 && TW / 8 + 6 + 4 <= PARK_COLS, "halo chain");
+  // ... and everything a kept output touches, zero-weight taps included, is this tile's data: heads staged t <= TW + 12 -> stage-6
+  // column <= (TW + 12) / 2 -> stage-5 sample + 7 -> stage-5 column -> stage-4 sample + 1 + 5 -> stage-4 column -> image column + 4
+  static_assert(((((TW + 12) / 2 + 7) / 2 + 1 + 5) / 2 + 4) < PARK_COLS, "closure of the kept outputs under the padded taps");
+  static_assert(PARK_COLS * 8 <= 3 * T3_NTH && PARK_COLS * 8 > 2 * T3_NTH, "three (four channels x one sample) items per thread");
+  // six-MFMA groups a tile issues
+  static constexpr double GROUPS = 4.0 * (NB4O + NB4Y) * 5 + 8.0 * NB5 * 3 + 8.0 * NB6 * 4 + 5.0 * 7;
+};
+constexpr int T3_LDS_MAX = T3<1264>::LDS_BYTES > T3<1200>::LDS_BYTES ? T3<1264>::LDS_BYTES : T3<1200>::LDS_BYTES;
 
 struct Tail3Args {
   const float* x3;  // stage-3 rows [3 B][32][ls]
@@ -92,15 +107,17 @@ struct Tail3Args {
   const float* head_b;           // [3]
   const float* flags;            // optional [B]: != 0 where the window held a non-finite sample: its predictions are written as NaN
   int B, n_tiles;
+  int t_lo, tiles_per_row;       // tile j of a row = outputs [t_lo + j TW, t_lo + (j + 1) TW): t_lo a multiple of 16, the tiles cover what the caller keeps
   unsigned long long* clk;  // debug (plan flag plan_flags[1] & 2): the stamps of eqt_tail.hip's TailArgs::clk, same slots
 };
 
 struct Tile3 {
   int d, win, t0;
 };
-__device__ __forceinline__ Tile3 tile3_id(const int tile, const int B) {
-  const int row = tile / TILES_PER_ROW, j = tile - row * TILES_PER_ROW;  // row = d * B + b
-  return Tile3{row / B, row, j * TW};
+template <int TW>
+__device__ __forceinline__ Tile3 tile3_id(const int tile, const Tail3Args& a) {
+  const int row = tile / a.tiles_per_row, j = tile - row * a.tiles_per_row;  // row = d * B + b
+  return Tile3{row / a.B, row, a.t_lo + j * TW};
 }
 
 // relu(acc + bias) of the lane's four rows; zero outside the row's signal
@@ -109,7 +126,15 @@ __device__ __forceinline__ void t3_finish(const f32x4 acc, const float (&bias)[4
   for (int r = 0; r < 4; ++r) v[r] = in ? fmaxf(acc[r] + bias[r], 0.f) : 0.f;
 }
 
+template <int TW_>
 __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
+  using K = T3<TW_>;
+  using Q5 = typename K::Q5;
+  using Q6 = typename K::Q6;
+  constexpr int TW = K::TW, NB4O = K::NB4O, NB4Y = K::NB4Y, NB5 = K::NB5, NB6 = K::NB6, PARK_COLS = K::PARK_COLS, NC4 = K::NC4,
+                NC5 = K::NC5, NC6 = K::NC6, OFF_R1 = K::OFF_R1, OFF_HT = K::OFF_HT, OFF_A5 = K::OFF_A5, OFF_A6 = K::OFF_A6,
+                A5_N = K::A5_N, A6_N = K::A6_N, T3_LDS_BYTES = K::LDS_BYTES;
+  (void)sizeof(Q5), (void)sizeof(Q6);
   extern __shared__ uint4 t3_lds[];
   char* base = reinterpret_cast<char*>(t3_lds);
   bf16_t* IN4 = reinterpret_cast<bf16_t*>(base);            // R0
@@ -124,7 +149,7 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
   int tile = blockIdx.x;
   if (tile >= a.n_tiles) return;
   for (int i = tid; i < T3_LDS_BYTES / 16; i += T3_NTH) t3_lds[i] = make_uint4(0u, 0u, 0u, 0u);
-  Tile3 id = tile3_id(tile, a.B);
+  Tile3 id = tile3_id<TW>(tile, a);
   unsigned long long* clk = (a.clk && tid == 0 && (int)blockIdx.x < a.B) ? a.clk + (long)blockIdx.x * 32 : nullptr;
   int n_done = 0;
 #define T3_STAMP(k) \
@@ -179,7 +204,7 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
   while (true) {
     const int next = tile + gridDim.x;
     const bool more = next < a.n_tiles;
-    const Tile3 nid = more ? tile3_id(next, a.B) : id;
+    const Tile3 nid = more ? tile3_id<TW>(next, a) : id;
     const int t0 = id.t0;
     T3_STAMP(0)
     park();
@@ -210,7 +235,7 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
         const int t = 2 * (colb + j * 16 + n) + ph;
         float v[4];
         t3_finish(acc, bias5, (unsigned)(t - lo) < 3000u, v);
-        b3c_store4<16, NC6>(IN6, t, g, v);
+        if (!K::GUARD5 || t < NC6) b3c_store4<16, NC6>(IN6, t, g, v);  // (TW = 1264: columns beyond the stage-6 image are nobody's input)
       };
       b3c_mac_tiles<16, NC5, 5, NB5>(b3c_lane_ptr<16, NC5, 5>(IN5, colb + 1, lane), a5, finish);
     }
@@ -271,7 +296,7 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       const int blk = 16 * w + n;
-      if (blk < TW / 16) {
+      if (blk < TW / 16 && t0 + 16 * blk < T_OUT) {  // (the last tile of a row may reach past it)
         const int b = id.win - id.d * a.B;
         float4 r;
         r.x = 1.f / (1.f + expf(-acc[0]));
@@ -321,7 +346,7 @@ int plan_eqt_fuse_tail_b3(Net& net) {
     return VP_ERR_INVALID;
   }
   const int x3 = c4->src1;
-  net.need(x3, HALO - 5 + (TILES_PER_ROW - 1) * TW / 8 + PARK_COLS);  // the last tile reads past the row: zero margin
+  net.need(x3, HALO - 5 + T_OUT / 8 + T3<1264>::PARK_COLS);  // the last tile of a row may read past it: zero margin
   net.tensor_sets[c4->dst] = 0;  // stages 4 and 5 are never materialised by this plan
   net.tensor_sets[c5->dst] = 0;
   HostBlob* p4 = net.add_blob(b3_operand(*c4, true));
@@ -362,8 +387,7 @@ int plan_eqt_fuse_tail_b3(Net& net) {
   st.flops_per_window = 0;
   for (int i = 0; i < 3; ++i) st.flops_per_window += net.steps[first + i].flops_per_window;
   {  // matrix work issued per tile: groups of six bf16 MFMAs (one 16 x 16 x 32 fp32-accurate product each)
-    const double groups = 4.0 * (NB4O + NB4Y) * 5 + 8.0 * NB5 * 3 + 8.0 * NB6 * 4 + 5.0 * 7;
-    st.set_issued(0.0, 3.0 * TILES_PER_ROW * groups * 6 * 16384.0, 0.0);
+    st.set_issued(0.0, 3.0 * 5 * T3<1200>::GROUPS * 6 * 16384.0, 0.0);  // the whole row; a launch over a blinded range sets its own (below)
   }
   st.run = [=](Net& n, int B, hipStream_t s) -> int {
     Tail3Args a{};
@@ -383,15 +407,29 @@ int plan_eqt_fuse_tail_b3(Net& net) {
     a.head_b = c6->e1.d;
     a.flags = n.win_flags ? n.win_flags->d : nullptr;  // set by gather_normalize_kernel (or by eqt_front_kernel when it cuts the windows itself)
     a.B = B;
-    a.n_tiles = 3 * B * TILES_PER_ROW;
+    // the outputs the caller keeps (annotate / classify: [blind_l, T - blind_r); model(x): the whole row), in the tiling that
+    // needs fewer tiles; plan_flags[7] bit 10 computes the whole row whatever the blinding (A/B, tests)
+    const bool whole = (n.cfg.plan_flags[7] & 1024) || n.out_hi <= 0;
+    const int t_lo = whole ? 0 : (n.out_lo / 16) * 16, t_hi = whole ? T_OUT : n.out_hi;
+    const int tiles_a = (t_hi - t_lo + 1199) / 1200, tiles_b = (t_hi - t_lo + 1263) / 1264;
+    const bool wide = tiles_b < tiles_a;
+    a.t_lo = t_lo;
+    a.tiles_per_row = wide ? tiles_b : tiles_a;
+    a.n_tiles = 3 * B * a.tiles_per_row;
+    if (!n.steps.empty() && n.steps.back().name.rfind("fused.tail", 0) == 0)  // what THIS launch issues (vp_step_issued_work)
+      n.steps.back().set_issued(0.0, 3.0 * a.tiles_per_row * (wide ? T3<1264>::GROUPS : T3<1200>::GROUPS) * 6 * 16384.0, 0.0);
     a.clk = (n.debug_clock && n.debug_clock->d)
                 ? reinterpret_cast<unsigned long long*>(n.debug_clock->d) + (size_t)n.max_batch * 32 + 64 * 8
                 : nullptr;
     const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
-    hipLaunchKernelGGL(eqt_tail3_kernel, dim3(grid), dim3(T3_NTH), T3_LDS_BYTES, s, a);
+    if (wide)
+      hipLaunchKernelGGL(eqt_tail3_kernel<1264>, dim3(grid), dim3(T3_NTH), T3<1264>::LDS_BYTES, s, a);
+    else
+      hipLaunchKernelGGL(eqt_tail3_kernel<1200>, dim3(grid), dim3(T3_NTH), T3<1200>::LDS_BYTES, s, a);
     return 0;
   };
-  net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_tail3_kernel), (size_t)T3_LDS_BYTES});
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_tail3_kernel<1200>), (size_t)T3<1200>::LDS_BYTES});
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_tail3_kernel<1264>), (size_t)T3<1264>::LDS_BYTES});
   net.steps.erase(net.steps.begin() + first, net.steps.begin() + first + 3);
   net.steps.push_back(std::move(st));
   net.poison_in_plan = true;  // no poison_kernel launch behind this plan

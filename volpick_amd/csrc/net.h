@@ -77,6 +77,9 @@ struct Net {
   HostBlob* debug_clock = nullptr;  // fused PhaseNet core: per-layer shader-clock stamps (debug plan flag)
   HostBlob* win_flags = nullptr;    // [max_batch]: 1 where annotate_batch_pre met a non-finite window (its predictions become NaN, as the reference's)
   bool fused_pre = false;           // the plan's first launch can gather + normalise its windows itself (pn_window_kernel, eqt_front_kernel)
+  int out_lo = 0, out_hi = 0;       // set by the caller around run(): the output samples [out_lo, out_hi) of every window that it keeps
+                                    // (annotate / classify blind the rest); 0, 0 = all.  A last launch that tiles the time axis skips the
+                                    // tiles outside (eqt_tail3_kernel)
   bool fused_pre_poisons = false;   // ... and that launch writes the NaN predictions of a non-finite window itself (pn_window_kernel)
   bool poison_in_plan = false;      // the plan's LAST launch reads win_flags and writes NaN for flagged windows, whoever set the
                                     // flags (eqt_tail3_kernel): poison_kernel is never launched
