@@ -70,6 +70,7 @@ struct Dec03Args {
   const float* edge_w;  // [3][64][64][3] pre-summed taps of the two edge outputs of stage 2 (eqt.hip)
   const float* edge_b;  // [3][32]
   int B, n_rows;
+  int even_split;  // plan_flags[7] bit 11: stage 3's n-tiles 12 + 12 over the two waves of a SIMD instead of 14 + 10
 };
 
 // Stage output t = 2 * column + phase at img[co * S + t]; [0, len) is the row, beyond it the next stage's zero padding.
@@ -266,16 +267,28 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
         // one wait for the bias here, where every path passes: met first inside the stores' exec-masked blocks, it is waited
         // for again at the top of every such block -- together with the stores of the n-tile before
         asm volatile("" ::"v"(bias3[0]), "v"(bias3[1]), "v"(bias3[2]), "v"(bias3[3]));
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int colb = (blk23 + 2 * k) * 96;
-          b3c_mac_tiles<32, B3_X3_NC, 5, 6>(b3c_lane_ptr<32, B3_X3_NC, 5>(X3, colb, lane), a3, [&](const int j, const f32x4 acc) {
+        // The 24 n-tiles of an m-tile: 14 to the older wave of the SIMD (waves 0-3, whose MFMAs issue first), 10 to the younger
+        // one, which also finishes the edge samples: with 12 + 12 the younger waves were 5 k cycles behind at the end of a row.
+        // plan_flags[7] bit 11: the even split (A/B).
+        auto stage3 = [&](const int colb, auto nb_tag) {
+          constexpr int NB = decltype(nb_tag)::value;
+          b3c_mac_tiles<32, B3_X3_NC, 5, NB>(b3c_lane_ptr<32, B3_X3_NC, 5>(X3, colb, lane), a3, [&](const int j, const f32x4 acc) {
             const int t = 2 * (colb + j * 16 + (lane & 15));
             if (t < L4) {
               *reinterpret_cast<float2*>(yrow + t) = make_float2(fmaxf(acc[0] + bias3[0], 0.f), fmaxf(acc[1] + bias3[1], 0.f));
               *reinterpret_cast<float2*>(yrow + a.ls_y + t) = make_float2(fmaxf(acc[2] + bias3[2], 0.f), fmaxf(acc[3] + bias3[3], 0.f));
             }
           });
+        };
+        if (a.even_split) {
+          stage3(blk23 * 96, std::integral_constant<int, 6>{});
+          stage3((blk23 + 2) * 96, std::integral_constant<int, 6>{});
+        } else if (blk23 == 0) {
+          stage3(0, std::integral_constant<int, 7>{});
+          stage3(112, std::integral_constant<int, 7>{});
+        } else {
+          stage3(224, std::integral_constant<int, 5>{});
+          stage3(304, std::integral_constant<int, 5>{});
         }
       }
       if (!more) break;
@@ -444,6 +457,7 @@ int plan_eqt_fuse_dec03(Net& net, bool b3) {
     a.edge_b = eb->d;
     a.B = B;
     a.n_rows = 3 * B;
+    a.even_split = (n.cfg.plan_flags[7] >> 11) & 1;
     const int grid = a.n_rows < 256 ? a.n_rows : 256;
     if (b3) {
       for (int i = 0; i < 3; ++i) {
