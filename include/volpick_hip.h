@@ -275,32 +275,40 @@ int vp_debug_conv_clock(vp_handle* h, unsigned long long* out, int max_layers);
 int vp_debug_tail_clock(vp_handle* h, int B, unsigned long long* out32);
 
 /* ---------------------------------------------------------------------------------------------
- * Waveform-file ingestion: miniSEED 2 records -> sample arrays, the step the
- * reference performs with obspy.read() (libmseed) before stream_to_array
+ * Waveform-file ingestion: miniSEED 2 and miniSEED 3 records -> sample arrays,
+ * the step the reference performs with obspy.read() (libmseed) before stream_to_array
  * (/root/reference volpick/data/convert.py:7,26-70).
  *
  * vp_mseed_scan (host only, no GPU) walks a miniSEED byte string and fills one vp_mseed_record per
- * data record: fixed header, blockette 1000 (encoding, word order, record length) and blockette
- * 1001 (microseconds); the header time correction is applied unless activity flag bit 1 says it
- * already was.  Writes at most `cap` records and always reports the total in *n_found.
+ * data record; the two formats may be mixed in one buffer.  miniSEED 2: fixed header, blockette 1000
+ * (encoding, word order, record length) and blockette 1001 (microseconds); the header time
+ * correction is applied unless activity flag bit 1 says it already was.  miniSEED 3 (FDSN 2020:
+ * "MS" 3, 40-byte little-endian fixed header, source identifier "FDSN:NET_STA_LOC_B_S_SS", extra
+ * headers, payload): the CRC-32C of every record is verified (VP_ERR_INVALID on a mismatch), start
+ * times are truncated from nanoseconds to microseconds, a negative rate field is a period in
+ * seconds, the channel is BAND SOURCE SUBSOURCE joined when each is one character; identifiers whose
+ * codes do not fit the fields below are VP_ERR_UNSUPPORTED.  Writes at most `cap` records and always
+ * reports the total in *n_found.
  *
  * vp_mseed_decode (HIP, one wavefront per record) decodes records into `out`: record r's samples go
  * to out[out_index[r] .. out_index[r] + min(nsamples, out_count[r])), clipped to [0, out_len);
- * out_index[r] < 0 skips the record, out_count may be NULL.  Encodings: 1 int16, 3 int32, 4 float32,
- * 5 float64, 10 Steim-1, 11 Steim-2, either byte order.  out_kind VP_SAMPLES_INT32 (integer
+ * out_index[r] < 0 skips the record, out_count may be NULL.  Encodings: 0 text (one sample per byte,
+ * its unsigned value), 1 int16, 2 int24, 3 int32, 4 float32, 5 float64, 10 Steim-1, 11 Steim-2,
+ * either byte order.  out_kind VP_SAMPLES_INT32 (integer
  * encodings only, exact) or VP_SAMPLES_FLOAT32.  zero_fill != 0 clears `out` first (the zero fill of
  * gaps in stream_to_array).  `status` (host, may be NULL) receives per record 0 = ok,
  * 1 = Steim reverse-integration constant mismatch, 2 = payload shorter than the header's count.
  * buf / out may be host or device memory (buf_mem / out_mem); recs, out_index, out_count, status
- * are host arrays.  Record payloads must start 4-byte aligned within buf. */
+ * are host arrays.  buf itself must be 4-byte aligned; payloads may start at any byte (miniSEED 3
+ * headers have no fixed length). */
 enum { VP_SAMPLES_INT32 = 0, VP_SAMPLES_FLOAT32 = 1 };
 typedef struct {
   int64_t offset;      /* byte offset of the record */
   int64_t start_us;    /* first sample, microseconds since 1970-01-01T00:00:00 UTC */
   double sample_rate;  /* Hz */
   int32_t reclen, data_offset, nsamples, encoding;
-  int32_t big_endian;  /* word order of header and payload */
-  int32_t quality;     /* data quality indicator character */
+  int32_t big_endian;  /* word order of the payload (and of a miniSEED 2 header) */
+  int32_t quality;     /* miniSEED 2: data quality indicator character; miniSEED 3: 0x300 | publication version */
   char network[4], station[8], location[4], channel[4]; /* NUL terminated, blanks stripped */
 } vp_mseed_record;
 int vp_mseed_scan(const uint8_t* buf, size_t nbytes, vp_mseed_record* recs, int64_t cap, int64_t* n_found);

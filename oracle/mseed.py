@@ -7,7 +7,10 @@ turns the resulting Stream into a (3, N) array with ``stream_to_array``
 reference repository holds no waveform file, so this module restates the published formats
 from the SEED 2.4 manual (fixed section of data header, blockettes 1000/1001, data
 encodings 1/3/4/5/10/11 with the Steim-1/Steim-2 frame layout) and the SAC binary header
-layout; nothing here has been checked against a libmseed-written file.
+layout; nothing here has been checked against a libmseed-written file.  miniSEED 3 follows the
+FDSN specification of 2020 ("miniSEED 3", fixed 40-byte little-endian header, source identifier
+``FDSN:NET_STA_LOC_B_S_SS``, CRC-32C over the record with its CRC field zeroed); the CRC routine is
+pinned by the standard check value (CRC-32C of b"123456789" = 0xE3069283, tests/test_mseed3.py).
 
 Besides the decoder it holds a small *encoder* (Steim-1/2 packing and record writing) used
 only to manufacture test inputs, and ``stream_to_array`` -- the in-repo array assembly rule.
@@ -22,6 +25,7 @@ from datetime import datetime, timedelta, timezone
 import numpy as np
 
 ENC_INT16, ENC_INT32, ENC_FLOAT32, ENC_FLOAT64, ENC_STEIM1, ENC_STEIM2 = 1, 3, 4, 5, 10, 11
+ENC_TEXT, ENC_INT24 = 0, 2
 _EPOCH = datetime(1970, 1, 1, tzinfo=timezone.utc)
 
 
@@ -97,6 +101,116 @@ def steim_encode(samples, version: int, nframes: int, prev: int = 0, byteorder: 
 
 
 # ----------------------------------------------------------------------------- record writer (test inputs)
+def pack_plain(values, encoding, byteorder):
+    """Payload bytes of the uncompressed encodings (0 text: one byte per sample; 2: 24-bit two's complement)."""
+    v = np.asarray(values)
+    if encoding == ENC_TEXT:
+        return v.astype(np.uint8).tobytes()
+    if encoding == ENC_INT24:
+        b = (v.astype(np.int64) & 0xFFFFFF).astype("<u4").view(np.uint8).reshape(-1, 4)[:, :3]
+        return (b[:, ::-1] if byteorder == ">" else b).tobytes()
+    dt = {ENC_INT16: "i2", ENC_INT32: "i4", ENC_FLOAT32: "f4", ENC_FLOAT64: "f8"}[encoding]
+    return v.astype(byteorder + dt).tobytes()
+
+
+# ----------------------------------------------------------------------------- miniSEED 3
+def crc32c(data: bytes, crc: int = 0) -> int:
+    """CRC-32C (Castagnoli polynomial 0x1EDC6F41, reflected), bit by bit: the slow textbook form."""
+    crc ^= 0xFFFFFFFF
+    for byte in data:
+        crc ^= byte
+        for _ in range(8):
+            crc = (crc >> 1) ^ (0x82F63B78 if crc & 1 else 0)
+    return crc ^ 0xFFFFFFFF
+
+
+_CRC_TABLE = None
+
+
+def crc32c_fast(data: bytes) -> int:
+    """Table form of ``crc32c`` (the encoder below writes day-long files)."""
+    global _CRC_TABLE
+    if _CRC_TABLE is None:
+        t = []
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ (0x82F63B78 if c & 1 else 0)
+            t.append(c)
+        _CRC_TABLE = t
+    crc = 0xFFFFFFFF
+    t = _CRC_TABLE
+    for byte in data:
+        crc = (crc >> 8) ^ t[(crc ^ byte) & 0xFF]
+    return crc ^ 0xFFFFFFFF
+
+
+def write_mseed3(traces, encoding=ENC_STEIM2, max_payload=448, extra_headers=b"", pubversion=1, flags=0, sid=None,
+                 period_rate=False, nanosecond=0):
+    """miniSEED 3 records of ``traces`` (same dicts as ``write_mseed``): header fields little-endian, Steim frames
+    big-endian, every other payload little-endian, variable record length (no padding but whole Steim frames)."""
+    out = bytearray()
+    for tr in traces:
+        data = np.asarray(tr["data"])
+        rate = float(tr["rate"])
+        ident = sid if sid is not None else "FDSN:{}_{}_{}_{}".format(
+            tr["network"], tr["station"], tr["location"], "_".join(tr["channel"].ljust(3)[:3]).replace(" ", ""))
+        ident = ident.encode()
+        pos, prev, n = 0, 0, len(data)
+        while pos < n:
+            if encoding in (ENC_STEIM1, ENC_STEIM2):
+                payload, cnt = steim_encode(data[pos:], 1 if encoding == ENC_STEIM1 else 2, max_payload // 64, prev, ">")
+                used = 0  # drop the unused frames at the end of the last record
+                w = np.frombuffer(payload, ">u4").reshape(-1, 16)
+                for f in range(w.shape[0]):
+                    if w[f, 0] != 0 or f == 0:
+                        used = f + 1
+                payload = payload[: 64 * used]
+            else:
+                width = {ENC_TEXT: 1, ENC_INT16: 2, ENC_INT24: 3, ENC_INT32: 4, ENC_FLOAT32: 4, ENC_FLOAT64: 8}[encoding]
+                cnt = min(n - pos, max_payload // width)
+                payload = pack_plain(data[pos:pos + cnt], encoding, "<")
+            us = tr["start_us"] + int(round(pos * 1e6 / rate))
+            d = _EPOCH + timedelta(microseconds=us)
+            hdr = bytearray(40)
+            hdr[0:3] = b"MS\x03"
+            struct.pack_into("<BIHHBBBBdIIBBHI", hdr, 3, flags, d.microsecond * 1000 + nanosecond, d.year,
+                             d.timetuple().tm_yday, d.hour, d.minute, d.second, encoding,
+                             -1.0 / rate if period_rate else rate, cnt, 0, pubversion, len(ident), len(extra_headers),
+                             len(payload))
+            rec = bytearray(hdr + ident + extra_headers + payload)
+            struct.pack_into("<I", rec, 28, crc32c_fast(bytes(rec)))
+            out += rec
+            if encoding in (ENC_STEIM1, ENC_STEIM2):
+                prev = int(data[pos + cnt - 1])
+            pos += cnt
+    return bytes(out)
+
+
+def scan_record3(buf: bytes, off: int):
+    """One miniSEED 3 record at ``off`` -> (record dict, record length); the CRC is verified."""
+    (flags, nsec, year, doy, hh, mm, ss, enc, rate, ns, crc, pubversion, sid_len, extra_len,
+     payload_len) = struct.unpack_from("<BIHHBBBBdIIBBHI", buf, off + 3)
+    reclen = 40 + sid_len + extra_len + payload_len
+    if off + reclen > len(buf):
+        raise ValueError(f"miniSEED 3 record at byte {off} runs past the end of the buffer")
+    rec = bytearray(buf[off:off + reclen])
+    rec[28:32] = b"\0\0\0\0"
+    if crc32c_fast(bytes(rec)) != crc:
+        raise ValueError(f"miniSEED 3 record at byte {off}: CRC-32C mismatch")
+    sid = buf[off + 40: off + 40 + sid_len].decode()
+    if not sid.startswith("FDSN:") or sid.count("_") != 5:
+        raise ValueError(f"source identifier {sid!r} is not FDSN:NET_STA_LOC_B_S_SS")
+    net, sta, loc, band, source, sub = sid[5:].split("_")
+    if max(len(band), len(source), len(sub)) > 1:
+        raise ValueError(f"source identifier {sid!r}: channel codes longer than one character")
+    start = btime_to_us(year, doy, hh, mm, ss, 0) + nsec // 1000
+    return dict(offset=off, reclen=reclen, nsamples=ns, encoding=enc, big_endian=enc in (ENC_STEIM1, ENC_STEIM2),
+                data_offset=40 + sid_len + extra_len, start_us=start,
+                rate=rate if rate > 0 else (-1.0 / rate if rate < 0 else 0.0), network=net, station=sta, location=loc,
+                channel=band + source + sub, format_version=3, pubversion=pubversion), reclen
+
+
 def write_mseed(traces, reclen=512, encoding=ENC_STEIM2, byteorder=">", with_b1001=False, seq0=1,
                 time_correction=0, activity_flags=0):
     """``traces``: list of dicts {network, station, location, channel, start_us, rate, data}.
@@ -122,6 +236,10 @@ def write_mseed(traces, reclen=512, encoding=ENC_STEIM2, byteorder=">", with_b10
             if encoding in (ENC_STEIM1, ENC_STEIM2):
                 payload, cnt = steim_encode(data[pos:], 1 if encoding == ENC_STEIM1 else 2, payload_bytes // 64, prev,
                                             byteorder)
+            elif encoding in (ENC_TEXT, ENC_INT24):
+                cnt = min(n - pos, payload_bytes // (1 if encoding == ENC_TEXT else 3))
+                payload = pack_plain(data[pos:pos + cnt], encoding, byteorder)
+                payload += b"\0" * (payload_bytes - len(payload))
             else:
                 dt = {ENC_INT16: "i2", ENC_INT32: "i4", ENC_FLOAT32: "f4", ENC_FLOAT64: "f8"}[encoding]
                 cnt = min(n - pos, payload_bytes // np.dtype(dt).itemsize)
@@ -154,11 +272,18 @@ def write_mseed(traces, reclen=512, encoding=ENC_STEIM2, byteorder=">", with_b10
 
 # ----------------------------------------------------------------------------- decoder (the restatement)
 def scan_records(buf: bytes):
-    """Walk a miniSEED 2 byte string; returns one dict per data record."""
+    """Walk a miniSEED 2 / 3 byte string; returns one dict per data record."""
     recs = []
     off = 0
     n = len(buf)
-    while off + 48 <= n:
+    while off + 40 <= n:
+        if buf[off:off + 3] == b"MS\x03":
+            rec, reclen = scan_record3(buf, off)
+            recs.append(rec)
+            off += reclen
+            continue
+        if off + 48 > n:
+            break
         h = buf[off:off + 48]
         if not (h[0:6].replace(b" ", b"0").isdigit() and h[6:7] in b"DRQM"):
             off += 64  # not a data record header: resynchronise on the smallest record unit
@@ -246,6 +371,14 @@ def decode_record(buf: bytes, rec: dict):
     enc, n, bo = rec["encoding"], rec["nsamples"], ">" if rec["big_endian"] else "<"
     if enc in (ENC_STEIM1, ENC_STEIM2):
         return decode_steim(p, n, 1 if enc == ENC_STEIM1 else 2, rec["big_endian"])
+    if enc == ENC_TEXT:
+        return np.frombuffer(p, dtype=np.uint8, count=n).astype(np.int32)
+    if enc == ENC_INT24:
+        b = np.frombuffer(p, dtype=np.uint8, count=3 * n).reshape(-1, 3).astype(np.int32)
+        if rec["big_endian"]:
+            b = b[:, ::-1]
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        return np.where(v >= 1 << 23, v - (1 << 24), v).astype(np.int32)
     dt = {ENC_INT16: "i2", ENC_INT32: "i4", ENC_FLOAT32: "f4", ENC_FLOAT64: "f8"}.get(enc)
     if dt is None:
         raise ValueError(f"unsupported encoding {enc}")

@@ -93,7 +93,6 @@ struct T3 {
   // six-MFMA groups a tile issues
   static constexpr double GROUPS = 4.0 * (NB4O + NB4Y) * 5 + 8.0 * NB5 * 3 + 8.0 * NB6 * 4 + 5.0 * 7;
 };
-constexpr int T3_LDS_MAX = T3<1264>::LDS_BYTES > T3<1200>::LDS_BYTES ? T3<1264>::LDS_BYTES : T3<1200>::LDS_BYTES;
 
 struct Tail3Args {
   const float* x3;  // stage-3 rows [3 B][32][ls]

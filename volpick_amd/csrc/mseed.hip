@@ -1,4 +1,4 @@
-// miniSEED 2 ingestion: host record scanner and a one-wavefront-per-record
+// miniSEED 2 / miniSEED 3 ingestion: host record scanner and a one-wavefront-per-record
 // decoder.  Replaces obspy.read()'s libmseed unpacking ahead of stream_to_array
 // (/root/reference volpick/data/convert.py:7,26-70).
 //
@@ -22,6 +22,18 @@ struct DevRec {
   int enc;              // encoding | big_endian << 8
 };
 
+// 32-bit word of a payload that may start at any byte (miniSEED 3): two aligned loads and v_alignbyte_b32.  The second
+// load is skipped when none of its bytes lies inside the buffer; when some do, the aligned word holding them cannot cross a
+// page, so reading its last bytes beyond `nbytes` touches no other allocation's page.
+__device__ __forceinline__ unsigned load_word(const uint8_t* __restrict__ buf, const long long byte, const long long nbytes) {
+  const int sh = static_cast<int>(byte & 3);
+  const unsigned* a = reinterpret_cast<const unsigned*>(buf + (byte - sh));
+  const unsigned lo = a[0];
+  if (sh == 0) return lo;
+  const unsigned hi = byte - sh + 4 < nbytes ? a[1] : 0u;
+  return __builtin_amdgcn_alignbyte(hi, lo, sh);
+}
+
 // Inclusive prefix sum over the 64 lanes in seven DPP adds (no LDS traffic): three row_shr steps
 // inside each group of four lanes, two bank-masked row_shr steps inside each row of 16, then
 // row_bcast:15 / row_bcast:31 carry the row totals across rows.  Masked-off lanes add `old` = 0.
@@ -44,7 +56,7 @@ __global__ __launch_bounds__(64 * REC_PER_WG) void mseed_decode_kernel(const uin
                                                                        const DevRec* __restrict__ recs,
                                                                        const long long n_recs, OutT* __restrict__ out,
                                                                        const long long out_len,
-                                                                       int* __restrict__ status) {
+                                                                       int* __restrict__ status, const long long nbytes) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long r = (long long)blockIdx.x * REC_PER_WG + wave;
   if (r >= n_recs) return;  // no workgroup barrier below: waves are independent
@@ -59,7 +71,6 @@ __global__ __launch_bounds__(64 * REC_PER_WG) void mseed_decode_kernel(const uin
     }
   };
   if (enc == 10 || enc == 11) {
-    const unsigned* w = reinterpret_cast<const unsigned*>(buf + rec.payload);
     const int nwords = (rec.nbytes >> 6) << 4;  // whole 64-byte frames
     int produced = 0, carry = 0;
     unsigned x0 = 0, xn = 0;
@@ -69,7 +80,7 @@ __global__ __launch_bounds__(64 * REC_PER_WG) void mseed_decode_kernel(const uin
       const int g = base + lane;
       unsigned word = 0;
       if (g < nwords) {
-        word = w[g];
+        word = load_word(buf, rec.payload + 4ll * g, nbytes);
         if (be) word = __builtin_bswap32(word);
       }
       const int idx = lane & 15;
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(64 * REC_PER_WG) void mseed_decode_kernel(const uin
     if (produced < ns && lane == 0 && status) status[r] = 2;
     return;
   }
-  const int width = enc == 1 ? 2 : enc == 5 ? 8 : 4;
+  const int width = enc == 0 ? 1 : enc == 1 ? 2 : enc == 2 ? 3 : enc == 5 ? 8 : 4;
   int n = rec.nbytes / width;
   if (n < ns) {
     if (lane == 0 && status) status[r] = 2;
@@ -146,20 +157,31 @@ __global__ __launch_bounds__(64 * REC_PER_WG) void mseed_decode_kernel(const uin
   }
   const uint8_t* p = buf + rec.payload;
   for (int i = lane; i < n; i += 64) {
-    if (enc == 1) {
-      unsigned short h = reinterpret_cast<const unsigned short*>(p)[i];
-      if (be) h = __builtin_bswap16(h);
+    if (enc == 0) {  // text: the byte's value
+      store(i, static_cast<int>(p[i]));
+    } else if (enc == 1) {
+      unsigned h;
+      if ((rec.payload & 1) == 0) {
+        h = reinterpret_cast<const unsigned short*>(p)[i];
+        if (be) h = __builtin_bswap16(static_cast<unsigned short>(h));
+      } else {
+        h = be ? (p[2 * i] << 8) | p[2 * i + 1] : (p[2 * i + 1] << 8) | p[2 * i];
+      }
       store(i, static_cast<int>(static_cast<short>(h)));
+    } else if (enc == 2) {  // 24-bit two's complement
+      const unsigned b0 = p[3 * i], b1 = p[3 * i + 1], b2 = p[3 * i + 2];
+      const unsigned u = be ? (b0 << 16) | (b1 << 8) | b2 : (b2 << 16) | (b1 << 8) | b0;
+      store(i, __builtin_amdgcn_sbfe(static_cast<int>(u), 0, 24));
     } else if (enc == 3) {
-      unsigned u = reinterpret_cast<const unsigned*>(p)[i];
+      unsigned u = load_word(buf, rec.payload + 4ll * i, nbytes);
       if (be) u = __builtin_bswap32(u);
       store(i, static_cast<int>(u));
     } else if (enc == 4) {
-      unsigned u = reinterpret_cast<const unsigned*>(p)[i];
+      unsigned u = load_word(buf, rec.payload + 4ll * i, nbytes);
       if (be) u = __builtin_bswap32(u);
       store(i, __uint_as_float(u));
-    } else {  // float64, as two words (payloads are only guaranteed 4-byte aligned)
-      unsigned a = reinterpret_cast<const unsigned*>(p)[2 * i], b = reinterpret_cast<const unsigned*>(p)[2 * i + 1];
+    } else {  // float64, as two words
+      unsigned a = load_word(buf, rec.payload + 8ll * i, nbytes), b = load_word(buf, rec.payload + 8ll * i + 4, nbytes);
       unsigned long long u = be ? ((unsigned long long)__builtin_bswap32(a) << 32) | __builtin_bswap32(b)
                                 : ((unsigned long long)b << 32) | a;
       store(i, __longlong_as_double(static_cast<long long>(u)));
@@ -197,6 +219,118 @@ double seed_rate(int factor, int mult) {
   return r;
 }
 
+// CRC-32C (Castagnoli, reflected 0x82F63B78) as miniSEED 3 defines it over the record with its CRC field zeroed:
+// slicing-by-8 tables built once.
+struct Crc32cTables {
+  uint32_t t[8][256];
+  Crc32cTables() {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u)));
+      t[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int s = 1; s < 8; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xff];
+  }
+};
+uint32_t crc32c_update(uint32_t crc, const uint8_t* p, size_t n) {
+  static const Crc32cTables T;
+  while (n >= 8) {
+    uint32_t lo, hi;
+    std::memcpy(&lo, p, 4);
+    std::memcpy(&hi, p + 4, 4);
+    lo ^= crc;
+    crc = T.t[7][lo & 0xff] ^ T.t[6][(lo >> 8) & 0xff] ^ T.t[5][(lo >> 16) & 0xff] ^ T.t[4][lo >> 24] ^ T.t[3][hi & 0xff] ^
+          T.t[2][(hi >> 8) & 0xff] ^ T.t[1][(hi >> 16) & 0xff] ^ T.t[0][hi >> 24];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) crc = (crc >> 8) ^ T.t[0][(crc ^ *p++) & 0xff];
+  return crc;
+}
+uint32_t mseed3_crc(const uint8_t* rec, size_t reclen) {  // bytes 28..31 count as zero
+  static const uint8_t zero[4] = {0, 0, 0, 0};
+  uint32_t c = 0xffffffffu;
+  c = crc32c_update(c, rec, 28);
+  c = crc32c_update(c, zero, 4);
+  c = crc32c_update(c, rec + 32, reclen - 32);
+  return ~c;
+}
+
+// "FDSN:NET_STA_LOC_BAND_SOURCE_SUBSOURCE" -> the four codes of a record; false when the identifier has another shape or a
+// code does not fit its field
+bool split_sid(const uint8_t* sid, int n, vp_mseed_record* m) {
+  if (n < 5 || std::memcmp(sid, "FDSN:", 5) != 0) return false;
+  const uint8_t* f[6];
+  int len[6], k = 0;
+  f[0] = sid + 5;
+  for (int i = 5; i < n; ++i) {
+    if (sid[i] == '_') {
+      if (k == 5) return false;
+      len[k] = (int)(sid + i - f[k]);
+      f[++k] = sid + i + 1;
+    }
+  }
+  if (k != 5) return false;
+  len[5] = (int)(sid + n - f[5]);
+  if (len[0] > 3 || len[1] > 7 || len[2] > 3) return false;
+  copy_code(m->network, 4, f[0], len[0]);
+  copy_code(m->station, 8, f[1], len[1]);
+  copy_code(m->location, 4, f[2], len[2]);
+  if (len[3] > 1 || len[4] > 1 || len[5] > 1) return false;  // the joined form would be B_S_SS: longer than the field
+  uint8_t cha[3];
+  int c = 0;
+  for (int j = 3; j < 6; ++j)
+    if (len[j]) cha[c++] = f[j][0];
+  copy_code(m->channel, 4, cha, c);
+  return true;
+}
+
+// One miniSEED 3 record at `off`.  Returns VP_OK and the record length, or an error with its message set.
+int scan_mseed3(const uint8_t* buf, size_t nbytes, size_t off, vp_mseed_record* m, size_t* reclen) {
+  const uint8_t* h = buf + off;
+  const unsigned nsec = rd32(h + 4, false);
+  const int year = (int)rd16(h + 8, false), doy = (int)rd16(h + 10, false);
+  const int hh = h[12], mm = h[13], ss = h[14], enc = h[15];
+  uint64_t rbits = 0;
+  for (int i = 7; i >= 0; --i) rbits = (rbits << 8) | h[16 + i];
+  double rate;
+  std::memcpy(&rate, &rbits, 8);
+  const unsigned ns = rd32(h + 24, false), crc = rd32(h + 28, false);
+  const int sid_len = h[33], extra_len = (int)rd16(h + 34, false);
+  const unsigned payload = rd32(h + 36, false);
+  const size_t len = 40 + (size_t)sid_len + extra_len + payload;
+  if (payload > (1u << 30) || off + len > nbytes) {
+    set_error("miniSEED 3 record at byte %zu runs past the end of the buffer", off);
+    return VP_ERR_INVALID;
+  }
+  if (year < 1900 || year > 2100 || doy < 1 || doy > 366 || nsec > 999999999u || ns > 0x7fffffffu) {
+    set_error("miniSEED 3 record at byte %zu: implausible start time or sample count", off);
+    return VP_ERR_INVALID;
+  }
+  if (mseed3_crc(h, len) != crc) {
+    set_error("miniSEED 3 record at byte %zu: CRC-32C mismatch", off);
+    return VP_ERR_INVALID;
+  }
+  *reclen = len;
+  if (!m) return VP_OK;
+  if (!split_sid(h + 40, sid_len, m)) {
+    set_error("miniSEED 3 record at byte %zu: source identifier '%.*s' is not FDSN:NET_STA_LOC_B_S_SS with codes that fit "
+              "vp_mseed_record", off, sid_len, (const char*)(h + 40));
+    return VP_ERR_UNSUPPORTED;
+  }
+  m->offset = (int64_t)off;
+  m->start_us = ((days_to_year(year) + doy - 1) * 86400LL + hh * 3600 + mm * 60 + ss) * 1000000LL + nsec / 1000;
+  m->sample_rate = rate > 0 ? rate : rate < 0 ? -1.0 / rate : 0.0;
+  m->reclen = (int32_t)len;
+  m->data_offset = 40 + sid_len + extra_len;
+  m->nsamples = (int32_t)ns;
+  m->encoding = enc;
+  m->big_endian = enc == 10 || enc == 11 || enc == 19;  // Steim frames are big-endian words; everything else little-endian
+  m->quality = 0x300 | h[32];
+  return VP_OK;
+}
+
 bool is_data_header(const uint8_t* h) {
   for (int i = 0; i < 6; ++i)
     if (!((h[i] >= '0' && h[i] <= '9') || h[i] == ' ')) return false;
@@ -208,12 +342,11 @@ int build_dev_recs(const vp_mseed_record* recs, const int64_t* out_index, const 
   for (int64_t r = 0; r < n_recs; ++r) {
     const vp_mseed_record& m = recs[r];
     if (out_index[r] < 0 || m.nsamples <= 0) continue;
-    VP_REQUIRE(m.offset >= 0 && m.data_offset >= 48 && m.data_offset <= m.reclen &&
+    VP_REQUIRE(m.offset >= 0 && m.data_offset >= 40 && m.data_offset <= m.reclen &&
                    (size_t)(m.offset + m.reclen) <= nbytes,
                "mseed record %lld lies outside the buffer", (long long)r);
-    VP_REQUIRE(((m.offset + m.data_offset) & 3) == 0, "mseed record %lld: payload is not 4-byte aligned", (long long)r);
     const int e = m.encoding;
-    if (!(e == 1 || e == 3 || e == 4 || e == 5 || e == 10 || e == 11)) {
+    if (!(e == 0 || e == 1 || e == 2 || e == 3 || e == 4 || e == 5 || e == 10 || e == 11)) {
       set_error("mseed record %lld: unsupported encoding %d", (long long)r, e);
       return VP_ERR_UNSUPPORTED;
     }
@@ -233,13 +366,13 @@ int build_dev_recs(const vp_mseed_record* recs, const int64_t* out_index, const 
   return VP_OK;
 }
 
-void launch_decode(const uint8_t* buf, const DevRec* recs, long long n, int out_kind, void* out, long long out_len,
-                   int* status, hipStream_t s) {
+void launch_decode(const uint8_t* buf, long long nbytes, const DevRec* recs, long long n, int out_kind, void* out,
+                   long long out_len, int* status, hipStream_t s) {
   const dim3 grid((unsigned)((n + REC_PER_WG - 1) / REC_PER_WG)), block(64 * REC_PER_WG);
   if (out_kind == VP_SAMPLES_INT32) {
-    hipLaunchKernelGGL(mseed_decode_kernel<int>, grid, block, 0, s, buf, recs, n, (int*)out, out_len, status);
+    hipLaunchKernelGGL(mseed_decode_kernel<int>, grid, block, 0, s, buf, recs, n, (int*)out, out_len, status, nbytes);
   } else {
-    hipLaunchKernelGGL(mseed_decode_kernel<float>, grid, block, 0, s, buf, recs, n, (float*)out, out_len, status);
+    hipLaunchKernelGGL(mseed_decode_kernel<float>, grid, block, 0, s, buf, recs, n, (float*)out, out_len, status, nbytes);
   }
 }
 
@@ -260,8 +393,18 @@ extern "C" int vp_mseed_scan(const uint8_t* buf, size_t nbytes, vp_mseed_record*
   VP_REQUIRE(buf && n_found && (recs || cap == 0), "vp_mseed_scan: null argument");
   int64_t n = 0;
   size_t off = 0;
-  while (off + 48 <= nbytes) {
+  while (off + 40 <= nbytes) {
     const uint8_t* h = buf + off;
+    if (h[0] == 'M' && h[1] == 'S' && h[2] == 3) {
+      size_t len = 0;
+      vp_mseed_record scratch;
+      const int rc = scan_mseed3(buf, nbytes, off, n < cap ? &recs[n] : &scratch, &len);
+      if (rc != VP_OK) return rc;
+      ++n;
+      off += len;
+      continue;
+    }
+    if (off + 48 > nbytes) break;
     if (!is_data_header(h)) {
       off += 64;
       continue;
@@ -361,7 +504,7 @@ extern "C" int vp_mseed_decode(int device_id, const uint8_t* buf, int buf_mem, s
       VP_HIP(hipMalloc(&dstat.p, dev.size() * sizeof(int)));
       VP_HIP(hipMemsetAsync(dstat.p, 0, dev.size() * sizeof(int), s));
     }
-    launch_decode(bufp, (const DevRec*)drec.p, (long long)dev.size(), out_kind, outp, out_len, (int*)dstat.p, s);
+    launch_decode(bufp, (long long)nbytes, (const DevRec*)drec.p, (long long)dev.size(), out_kind, outp, out_len, (int*)dstat.p, s);
     VP_HIP(hipGetLastError());
   }
   if (out_mem == VP_MEM_HOST) VP_HIP(hipMemcpyAsync(out, outp, out_bytes, hipMemcpyDeviceToHost, s));
@@ -393,10 +536,10 @@ extern "C" int vp_mseed_decode_bench(int device_id, const uint8_t* buf_dev, size
   VP_HIP(hipEventCreate(&e0));
   VP_HIP(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i)
-    launch_decode(buf_dev, (const DevRec*)drec.p, (long long)dev.size(), out_kind, out_dev, out_len, nullptr, s);
+    launch_decode(buf_dev, (long long)nbytes, (const DevRec*)drec.p, (long long)dev.size(), out_kind, out_dev, out_len, nullptr, s);
   VP_HIP(hipEventRecord(e0, s));
   for (int i = 0; i < iters; ++i)
-    launch_decode(buf_dev, (const DevRec*)drec.p, (long long)dev.size(), out_kind, out_dev, out_len, nullptr, s);
+    launch_decode(buf_dev, (long long)nbytes, (const DevRec*)drec.p, (long long)dev.size(), out_kind, out_dev, out_len, nullptr, s);
   VP_HIP(hipEventRecord(e1, s));
   VP_HIP(hipEventSynchronize(e1));
   float t = 0.f;

@@ -3,9 +3,10 @@
 ``read()`` stands where the reference calls ``obspy.read`` ahead of the picker
 (/root/reference volpick/data/convert.py:7 and the ``read(...)`` call sites of
 ``convert_mseed_to_seisbench``; Final_models/demo.ipynb:249-266 builds the same kind of Stream
-from an FDSN download) and returns this package's ``Stream``.  miniSEED records are found by
-the library's host scanner (``vp_mseed_scan``) and unpacked on the GPU (``vp_mseed_decode``:
-one wavefront per record, Steim-1/2 and the plain integer / float encodings); there is no CPU
+from an FDSN download) and returns this package's ``Stream``.  miniSEED 2 and miniSEED 3 records
+(also mixed in one file) are found by the library's host scanner (``vp_mseed_scan``, which checks
+the CRC-32C of miniSEED 3 records) and unpacked on the GPU (``vp_mseed_decode``: one wavefront per
+record, Steim-1/2, the plain 16 / 24 / 32-bit integer and float encodings, text); there is no CPU
 decoder in the product -- without a GPU ``read`` of a miniSEED file raises.  SAC files are a
 header plus raw float32 samples and need no kernel.
 
@@ -43,6 +44,8 @@ def _as_bytes(source):
 
 def _looks_like_mseed(buf):
     h = buf[:8]
+    if h[:3] == b"MS\x03":
+        return True
     return len(h) >= 8 and all(48 <= c <= 57 or c == 32 for c in h[:6]) and h[6:7] in (b"D", b"R", b"Q", b"M")
 
 
@@ -85,8 +88,9 @@ def _segments(recs):
 def read_mseed(source, device=0, dtype=None, device_resident=False):
     """miniSEED -> Stream (one Trace per continuous segment, sorted by id and time).
 
-    Integer encodings decode to int32 exactly; float32/float64 records to float32.  ``dtype``
-    forces the sample type of every trace (``np.float32`` decodes integers straight to fp32).
+    Integer encodings decode to int32 exactly; float32/float64 records to float32; text records
+    (encoding 0: log channels) to ObsPy's ``|S1`` characters.  ``dtype`` forces the sample type of
+    every trace (``np.float32`` decodes integers straight to fp32).
     ``device_resident=True`` leaves the decoded samples on the GPU: the traces are backed by CUDA
     tensors, ``classify`` / ``annotate`` assemble and consume them there, and ``trace.data`` copies
     to the host only when somebody reads it.
@@ -139,12 +143,16 @@ def read_mseed(source, device=0, dtype=None, device_resident=False):
         else:
             if dtype is not None and data.dtype != np.dtype(dtype):
                 data = data.astype(dtype)
+            elif int(r["encoding"][a]) == 0 and dtype is None:
+                data = data.astype(np.uint8).view("S1")
             tr_args = dict(data=data)
         tr = Trace(header=dict(network=r["network"][a].decode(), station=r["station"][a].decode(),
                               location=r["location"][a].decode(), channel=r["channel"][a].decode(),
                               starttime=UTCDateTime._from_us(int(r["start_us"][a])),
                               sampling_rate=float(r["sample_rate"][a])), **tr_args)
-        tr.stats["mseed"] = dict(dataquality=chr(int(r["quality"][a])), number_of_records=int(b - a),
+        q = int(r["quality"][a])
+        tr.stats["mseed"] = dict(dataquality=chr(q) if q < 256 else "", format_version=2 if q < 256 else 3,
+                                 publication_version=q & 255 if q >= 256 else None, number_of_records=int(b - a),
                                  encoding=int(r["encoding"][a]), byteorder=">" if r["big_endian"][a] else "<",
                                  record_length=int(r["reclen"][a]),
                                  steim_integrity_errors=int((status[a:b] == 1).sum()))
