@@ -389,6 +389,10 @@ def bench_model(model_name, env, cpu_budget_s):
                                         "valu": iss.valu_flop}}
         k["pipe_time_ms"] = pipe_time_s(k["issued_flop_per_window"], args.batch) * 1e3
         k["frac_of_pipe_peaks"] = k["pipe_time_ms"] / k["ms"] if k["ms"] > 0 else None
+        if k["name"].startswith("fused.mid"):
+            k["note"] = ("two windows per 1024-thread workgroup: a 256-window launch holds 128 of the 256 CUs (the other contexts' "
+                         "kernels run on the rest); one window per workgroup took 66 us on all 256; frac_of_pipe_peaks is against "
+                         "the whole chip")
         kernels.append(k)
     fwd_ms = sum(k["ms"] for k in kernels)
     # Roofline candidates are the launches that hold >= 5 % of the forward FLOPs (the MFMA / packed-FMA bound ones).

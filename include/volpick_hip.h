@@ -56,7 +56,11 @@ typedef struct {
                                  [0]: 1 = PhaseNet layer-by-layer plan instead of the fused kernels (debug / A-B);
                                  [1]: bit0 = fused kernels also dump their LDS intermediates to the debug tensors
                                       (selects the three-launch plan), bit1 = per-layer clock stamps;
-                                 [2]: 1 = hand-pipelined K loop in the PhaseNet MFMA layers (A/B);
+                                 [2]: PhaseNet: 1 = hand-pipelined K loop in the MFMA layers (A/B); EQTransformer: 1 = the three
+                                      BiLSTM blocks, two transformer blocks and the pick branches as six launches instead
+                                      of eqt_mid_kernel, 2 = eqt_mid_kernel with one window per 512-thread workgroup
+                                      (default: two windows per 1024-thread workgroup, so that a batch leaves half the
+                                      CUs to the kernels of the other device contexts);
                                  [3]: tiled level-0 kernel variants of the all-MFMA plan (A/B);
                                  [4]: 1 = no L2 warm-up of the weight streams;
                                  [5]: PhaseNet plan: 0 = the whole network in one launch, its five deepest layers on the
@@ -77,7 +81,9 @@ typedef struct {
                                       forms agree to fp32 rounding, not bitwise), bit9 = the bf16-piece ResCNN kernel with
                                       four waves per window (one per SIMD) instead of eight (K split over wave pairs),
                                       bit10 = the decoder tail computes every tile of a row even where annotate / classify
-                                      blind the output (default: only the tiles that hold kept samples) */
+                                      blind the output (default: only the tiles that hold kept samples),
+                                      bit11 = stage 3 of the fused decoder 0-3 kernel shares its n-tiles evenly between
+                                      the two waves of a SIMD (default: 14 + 10) */
   int32_t reserved[4];        /* must be 0 */
 } vp_config;
 

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 for v in A B; do
   if [ $v = A ]; then f="$1"; else f="$2"; fi
-  VOLPICK_PLAN_FLAGS="$f" timeout -k 10 200 python bench.py --model eqtransformer --no-cpu-baseline > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err
+  VOLPICK_PLAN_FLAGS="$f" timeout -k 10 200 python bench.py --model eqtransformer --no-cpu-baseline --sustain-seconds 0 --no-api > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err
 done
 python - "$1" "$2" <<'PY'
 import json, sys

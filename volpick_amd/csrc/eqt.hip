@@ -362,7 +362,8 @@ int plan_eqt(Net& net, const ParamView& pv) {
     st.run = [=](Net& n, int B, hipStream_t s_) -> int { return launch_pick_branch(mk_pick(n, B), s_); };
     mid_flops += st.flops_per_window;
     net.steps.push_back(std::move(st));
-    // plan_flags[2] = 1 keeps the six separate launches (A/B timing); default: one launch for the whole latency-bound chain
+    // plan_flags[2] = 1 keeps the six separate launches (A/B timing); default: one launch for the whole latency-bound chain,
+    // two windows per workgroup; plan_flags[2] = 2: that launch with one window per workgroup (the form of rounds 1-2)
     if (net.cfg.plan_flags[2] != 1 && mid_first >= 0 && (int)net.steps.size() == mid_first + 6) {
       Step fused;
       fused.name = "fused.mid (3 BiLSTM + 2 transformer blocks + pick branches)";
@@ -379,7 +380,8 @@ int plan_eqt(Net& net, const ParamView& pv) {
         for (int i = 0; i < 2; ++i) m.tr[i] = mk_tr[i](n);
         m.pick = mk_pick(n, B);
         m.clk = n.debug_clock ? reinterpret_cast<unsigned long long*>(n.debug_clock->d) : nullptr;  // slots [B][8] (tools/mid_clock.py)
-        return launch_eqt_mid(m, B, s_);
+        m.B = B;
+        return launch_eqt_mid(m, B, s_, n.cfg.plan_flags[2] == 2);
       };
       net.steps.erase(net.steps.begin() + mid_first, net.steps.end());
       net.steps.push_back(std::move(fused));

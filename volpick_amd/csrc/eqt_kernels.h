@@ -81,8 +81,10 @@ struct MidArgs {
   TransformerArgs tr[2];
   PickBranchArgs pick;
   unsigned long long* clk;  // optional debug: 8 shader-clock stamps per window (start, after each of the six stages, end)
+  int B;                    // windows (the two-window workgroups clamp their last window to it)
 };
-int launch_eqt_mid(const MidArgs& a, int B, hipStream_t s);
+// default: two windows per 1024-thread workgroup (128 CUs for a batch of 256); one_window_per_workgroup: the 512-thread form
+int launch_eqt_mid(const MidArgs& a, int B, hipStream_t s, bool one_window_per_workgroup);
 
 int launch_bilstm(const BiLstmArgs& a, int cin, int B, hipStream_t s);
 int launch_transformer(const TransformerArgs& a, int B, hipStream_t s);

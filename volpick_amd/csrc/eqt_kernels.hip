@@ -3,6 +3,13 @@
 #include "prepost.h"
 #include "conv_valu.h"
 
+// Thread index within a window's 512-thread team.  Every kernel of this file has at most 512 threads per workgroup except the
+// two-window form of eqt_mid_kernel (1024 threads: waves 0-7 take one window, waves 8-15 the next).
+// The second team's roles are rotated by two waves: the two recurrence waves of a window (roles 0 and 1) then sit on SIMDs 0, 1
+// for the first team and on SIMDs 2, 3 for the second (hardware wave h runs on SIMD h % 4).
+#define MID_TID ((threadIdx.x + ((threadIdx.x >> 9) << 7)) & 511)
+#define MID_NT (blockDim.x > 512u ? 512u : blockDim.x)  // threads of a window's team
+
 namespace vp {
 
 namespace {
@@ -44,7 +51,7 @@ __device__ inline float quad_bcast(float v) {  // value of lane SEL of the quad,
 // Input projection of one direction for the time steps t0, t0 + tstep, ... (any number of waves may share it).
 template <int CIN>
 __device__ void lstm_project(const float* xs, float* gx, const LstmWeights w, const int t0, const int tstep) {
-  const int lane = threadIdx.x & 63, row = lstm_row(lane);
+  const int lane = MID_TID & 63, row = lstm_row(lane);
   float wih[CIN];
 #pragma unroll
   for (int c = 0; c < CIN; ++c) wih[c] = w.w_ih[row * CIN + c];
@@ -68,7 +75,7 @@ __device__ void lstm_project(const float* xs, float* gx, const LstmWeights w, co
 // the registers of the 16-byte loads are used as they arrive.  (As sixteen scalars hipcc re-paired them with v_mov
 // right behind the loads, i.e. waited for them at the point of issue -- which defeats requesting them a stage ahead.)
 __device__ inline void lstm_load_whh(f32x2 (&whh)[EQT_H / 2], const LstmWeights w) {
-  const int row = lstm_row(threadIdx.x & 63);
+  const int row = lstm_row(MID_TID & 63);
   const f32x2* p = reinterpret_cast<const f32x2*>(w.w_hh + row * EQT_H);
 #pragma unroll
   for (int j = 0; j < EQT_H / 2; ++j) whh[j] = p[j];
@@ -82,7 +89,7 @@ __device__ __forceinline__ float lstm_gate_scale(const int gate) { return gate =
 // instructions (v_mul_f32_dpp / v_fmac_f32_dpp read the quad's i and f gates in place).
 template <int GS = 64, bool SCALED = false>
 __device__ void lstm_recur(const float* gx, const f32x2 (&whh)[EQT_H / 2], const bool reverse, float* hout, const int hs) {
-  const int lane = threadIdx.x & 63;
+  const int lane = MID_TID & 63;
   const bool is_g = (lane & 3) == 2;
   float h = 0.f, c = 0.f;
   float gnext = gx[(reverse ? T - 1 : 0) * GS + lane];
@@ -149,7 +156,7 @@ __device__ void lstm_direction(const float* xs, float* gx, const LstmWeights w, 
 template <int KS>
 __device__ __forceinline__ void mfma_load_a(float (&a)[KS], const float* w, const int row_stride) {  // K contiguous
   static_assert(KS % 4 == 0, "16-byte loads");
-  const int lane = threadIdx.x & 63;
+  const int lane = MID_TID & 63;
   const float4* p = reinterpret_cast<const float4*>(w + (lane & 15) * row_stride + (lane >> 4) * KS);
 #pragma unroll
   for (int i = 0; i < KS / 4; ++i) {
@@ -159,7 +166,7 @@ __device__ __forceinline__ void mfma_load_a(float (&a)[KS], const float* w, cons
 }
 template <int KS>
 __device__ __forceinline__ void mfma_load_a_t(float (&a)[KS], const float* w, const int k_stride) {  // rows contiguous
-  const int lane = threadIdx.x & 63;
+  const int lane = MID_TID & 63;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) a[ks] = w[(lane & 15) + ((lane >> 4) * KS + ks) * k_stride];
 }
@@ -169,7 +176,7 @@ __device__ __forceinline__ void load4(float (&v)[4], const float* p) {  // p 16-
 }
 template <int KS>
 __device__ __forceinline__ f32x4 mfma_tile(const float (&a)[KS], const float* b, const int bs, const int n0, f32x4 acc) {
-  const int lane = threadIdx.x & 63;
+  const int lane = MID_TID & 63;
   const float* bp = b + (lane >> 4) * KS * bs + n0 + (lane & 15);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bp[ks * bs], acc, 0, 0, 0);
@@ -186,13 +193,13 @@ struct ProjFrag {
 };
 template <int CIN>
 __device__ __forceinline__ void lstm_project_load(ProjFrag<CIN>& f, const LstmWeights w, const int q) {
-  const int lane = threadIdx.x & 63;
+  const int lane = MID_TID & 63;
   mfma_load_a<CIN / 4>(f.a, w.w_ih + q * 16 * CIN, CIN);
   load4(f.bias, w.b + q * 16 + 4 * (lane >> 4));  // lstm_project_mfma applies lstm_gate_scale(q) to the result
 }
 template <int CIN>
 __device__ __forceinline__ void lstm_project_mfma(const ProjFrag<CIN>& f, const float* xs, float* gx, const int q) {
-  const int lane = threadIdx.x & 63;
+  const int lane = MID_TID & 63;
 #pragma unroll
   for (int nt = 0; nt < 3; ++nt) {
     f32x4 acc = {f.bias[0], f.bias[1], f.bias[2], f.bias[3]};
@@ -221,7 +228,7 @@ __device__ __forceinline__ void attn_wa(float (&wa)[32], const float wa_lane) {
 // were 60 % of its cycles), and the constant sum_u Wa[u] drops out.  plain = true: q, k hold the raw projections.
 template <int ES>
 __device__ __forceinline__ void attn_scores(const float (*q)[KP], const float (*k)[KP], float* e, const float (&wa)[32], const bool plain) {
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = MID_TID, nt = MID_NT;
   if (plain) {
     for (int idx = tid; idx < T * T; idx += nt) {
       const int i = idx / T, j = idx - i * T;
@@ -257,7 +264,7 @@ __device__ __forceinline__ void attn_scores(const float (*q)[KP], const float (*
 template <int ES, bool ZERO_PAD>
 __device__ __forceinline__ void attn_softmax(float* e, const float eps, const int width) {
   // three rows per trip (wave_max3 / wave_sum3)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  const int tid = MID_TID, lane = tid & 63, wave = tid >> 6, nw = MID_NT >> 6;
   constexpr int R = 3;
   const int lower = lane - width / 2;  // mask[i][j] = lower_j <= i < lower_j + width
   for (int i0 = wave; i0 < T; i0 += R * nw) {
@@ -287,7 +294,7 @@ __device__ __forceinline__ void attn_softmax(float* e, const float eps, const in
 
 __device__ void attention_core(const float (*xs)[EQT_H], float (*q)[KP], float (*k)[KP], float (*e)[48],
                                float (*v)[EQT_H], const AttnWeights w, const float eps, const int width) {
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = MID_TID, nt = MID_NT;
   const float wa_lane = w.Wa[tid & 31];
   // Guard of the E_q E_k form: |q|, |k| <= 30 (E within 1e+-26, no inf x 0); a window beyond that takes the plain form.
   bool big = false;
@@ -338,7 +345,7 @@ struct AttnFrag {
 };
 // fragments of the q / k projection of this wave: m-tile mt = wave & 3 (q rows 0-15, 16-31, k rows 0-15, 16-31)
 __device__ __forceinline__ void attn_load(AttnFrag& f, const AttnWeights w) {
-  const int lane = threadIdx.x & 63, mt = (threadIdx.x >> 6) & 3;
+  const int lane = MID_TID & 63, mt = (MID_TID >> 6) & 3;
   mfma_load_a_t<4>(f.a, (mt < 2 ? w.Wt : w.Wx) + 16 * (mt & 1), 32);
   // loaded unconditionally (q rows ignore it at use): a select on a loaded value would make the wave wait for the
   // load right here, at the point that exists to leave it in flight
@@ -355,8 +362,8 @@ __device__ void mid_attention(const AttnFrag& f, const float wa_lane, const floa
                               float* e, const float eps, const int width, Prefetch&& prefetch, Finish&& finish,
                               unsigned long long* sub) {
 #define ATT_SUB(slot) \
-  if (sub && threadIdx.x == 0) sub[slot] = __builtin_readcyclecounter();
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (sub && MID_TID == 0) sub[slot] = __builtin_readcyclecounter();
+  const int tid = MID_TID, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   {  // q / k projection: waves 0-3 take the column tiles 0 and 1 of their m-tile, waves 4-7 tile 2
     const int mt = wave & 3;
     float(*dstp)[KP] = mt < 2 ? q : k;
@@ -414,7 +421,7 @@ __device__ void mid_attention(const AttnFrag& f, const float wa_lane, const floa
 }
 
 __device__ inline void load_window_transposed(const float* src, int ls, float (*xs)[EQT_H]) {
-  for (int idx = threadIdx.x; idx < EQT_H * T; idx += blockDim.x) {
+  for (int idx = MID_TID; idx < EQT_H * T; idx += MID_NT) {
     const int c = idx / T, t = idx - c * T;
     xs[t][c] = src[(long)c * ls + HALO + t];
   }
@@ -443,7 +450,7 @@ __global__ __launch_bounds__(128) void bilstm_kernel(const BiLstmArgs a) {
   __shared__ __attribute__((aligned(16))) float xs[T * CIN];
   __shared__ float gx[2][T * 64];
   __shared__ float hc[32][48];
-  const int tid = threadIdx.x, b = blockIdx.x;
+  const int tid = MID_TID, b = blockIdx.x;
   const float* src = a.src + (long)b * a.ws_src;
   for (int idx = tid; idx < CIN * T; idx += 128) {
     const int c = idx / T, t = idx - c * T;
@@ -493,7 +500,7 @@ __global__ __launch_bounds__(TR_NTH) void transformer_kernel(const TransformerAr
   __shared__ float v[T][EQT_H];
   __shared__ float y1[T][EQT_H];
   __shared__ float h1[T][128];
-  const int tid = threadIdx.x, b = blockIdx.x;
+  const int tid = MID_TID, b = blockIdx.x;
   load_window_transposed(a.src + (long)b * a.ws_src, a.ls_src, xs);
   __syncthreads();
   attention_core(xs, q, k, e, v, a.att, a.attn_eps, 0);  // ends with a barrier: q / k / e are dead now
@@ -556,7 +563,7 @@ __global__ __launch_bounds__(PICK_NTH) void pick_branch_kernel(const PickBranchA
   __shared__ __attribute__((aligned(8))) float q[T][KP], k[T][KP];
   __shared__ float e[T][48];
   __shared__ float v[T][EQT_H];
-  const int tid = threadIdx.x, b = blockIdx.x, br = blockIdx.y;
+  const int tid = MID_TID, b = blockIdx.x, br = blockIdx.y;
   load_window_transposed(a.src + (long)b * a.ws_src, a.ls_src, xs);
   __syncthreads();
   if (tid < 64) lstm_direction<EQT_H>(&xs[0][0], gx, a.lstm[br], false, &hl[0][0], 48);
@@ -598,7 +605,7 @@ constexpr int MID_POOL = 16000;  // floats; the stages carve it up in turn
 
 // Debug clock stamps inside the stages (slots 8.. of the window's 32; the last caller of a stage wins).
 #define MID_SUB(slot) \
-  if (sub && threadIdx.x == 0) sub[slot] = __builtin_readcyclecounter();
+  if (sub && MID_TID == 0) sub[slot] = __builtin_readcyclecounter();
 
 // The operands a stage reads from memory, as registers: requested one stage ahead (under the 47 sequential LSTM steps
 // or the attention score loop of the stage before), so that no stage but the first waits for memory.
@@ -610,7 +617,7 @@ struct BiFrags {
 };
 template <int CIN>
 __device__ __forceinline__ void bi_load(BiFrags<CIN>& g, const BiLstmArgs& a) {
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = MID_TID & 63, wave = __builtin_amdgcn_readfirstlane(MID_TID >> 6);
   // no branches (waves that do not need an operand fetch it anyway): in one basic block the reads of the argument
   // block cluster into a single wait; behind wave-dependent branches they serialised, ~1 k cycles apiece
   lstm_project_load<CIN>(g.f, (wave >> 2) ? a.bwd : a.fwd, wave & 3);
@@ -622,7 +629,7 @@ __device__ __forceinline__ void bi_load(BiFrags<CIN>& g, const BiLstmArgs& a) {
 template <int CIN, class Prefetch>
 __device__ void mid_bilstm(const BiLstmArgs& a, BiFrags<CIN>& g, const int b, float* P, float* cur,
                            const bool from_memory, Prefetch&& prefetch, unsigned long long* sub) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = MID_TID, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* gx = P;                    // [2][T * GXS]
   float* hc = P + 2 * T * GXS;      // [32][48]
   float* xs = hc + 32 * 48;         // [CIN][48], first stage only (later stages read `cur`)
@@ -694,14 +701,14 @@ struct TrFrags {
 // late: the operands of its last phases, requested by the stage itself at the start of its score loop -- fewer
 // registers are live across that loop than with everything fetched a stage ahead.
 __device__ __forceinline__ void tr_load_early(TrFrags& g, const TransformerArgs& a) {
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = MID_TID & 63, wave = __builtin_amdgcn_readfirstlane(MID_TID >> 6);
   attn_load(g.af, a.att);
   g.wa_lane = a.att.Wa[lane & 31];
   mfma_load_a<4>(g.a1, a.w1 + wave * 16 * EQT_H, EQT_H);
   load4(g.b1v, a.bb1 + 16 * wave + 4 * (lane >> 4));
 }
 __device__ __forceinline__ void tr_load_late(TrFrags& g, const TransformerArgs& a) {
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = MID_TID & 63, wave = __builtin_amdgcn_readfirstlane(MID_TID >> 6);
   g.ln_par = a.g1[lane];  // g1 | b1 | g2 | b2 are one blob (eqt_kernels.h)
   const int half = wave >= 3;
   mfma_load_a<16>(g.a2, a.w2 + 64 * half, 128);  // waves 6, 7 too: no branch, see bi_load
@@ -712,7 +719,7 @@ __device__ __forceinline__ void tr_load_late(TrFrags& g, const TransformerArgs& 
 // l ^ 48 (the result layout of the matrix-core products); gamma at lane G0 + c of `par`, beta at G0 + 16 + c.
 template <int G0>
 __device__ __forceinline__ void layer_norm_mfma(float (&z)[4], const float par, const float eps) {
-  const int g = (threadIdx.x & 63) >> 4;
+  const int g = (MID_TID & 63) >> 4;
   float s = (z[0] + z[1]) + (z[2] + z[3]);
   s += __shfl_xor(s, 16);
   s += __shfl_xor(s, 32);
@@ -730,7 +737,7 @@ __device__ __forceinline__ void layer_norm_mfma(float (&z)[4], const float par, 
 template <class Prefetch>
 __device__ void mid_transformer(const TransformerArgs& a, TrFrags& g, const int b, float* P, float* cur,
                                 Prefetch&& prefetch, unsigned long long* sub) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = MID_TID, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float(*q)[KP] = reinterpret_cast<float(*)[KP]>(P);
   float(*k)[KP] = q + T;
   float* e = P + 2 * T * KP;        // [48][AES]
@@ -807,7 +814,7 @@ struct PickFrags {
   float wa_lane[2];
 };
 __device__ __forceinline__ void pick_load(PickFrags& g, const PickBranchArgs& a) {
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = MID_TID & 63, wave = __builtin_amdgcn_readfirstlane(MID_TID >> 6);
   // static offsets into the argument block + selects (a wave-dependent index would be a second, dependent read)
   lstm_project_load<EQT_H>(g.f, (wave >> 2) ? a.lstm[1] : a.lstm[0], wave & 3);
   lstm_load_whh(g.whh, (wave & 1) ? a.lstm[1] : a.lstm[0]);  // every wave: no branch, see bi_load
@@ -817,7 +824,7 @@ __device__ __forceinline__ void pick_load(PickFrags& g, const PickBranchArgs& a)
 
 __device__ void mid_pick(const PickBranchArgs& a, PickFrags& g, const int b, float* P, const float* cur,
                          unsigned long long* sub) {
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = MID_TID, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* gx = P;                                   // [2][T * GXS]
   float* hl = gx + 2 * T * GXS;                    // [2][16][48] LSTM outputs of the P and the S branch
   float(*q)[KP] = reinterpret_cast<float(*)[KP]>(hl + 2 * 16 * 48);
@@ -868,13 +875,22 @@ __device__ void mid_pick(const PickBranchArgs& a, PickFrags& g, const int b, flo
   }
 }
 
-__global__ __launch_bounds__(MID_NTH) void eqt_mid_kernel(const MidArgs a) {
-  __shared__ __attribute__((aligned(16))) float P[MID_POOL];
-  __shared__ float cur[16 * 48];
-  const int b = blockIdx.x;
+// WPB windows per workgroup.  The stages are latency-bound (two of a window's eight waves run its recurrences, the chip's other
+// wave slots idle) and a window needs 67 KB of LDS and 127 registers: two windows fit a CU.  With WPB = 2 the 256 windows of a
+// batch take 128 CUs instead of 256 for the same 66 us, and the other device contexts' kernels run on the CUs left free.
+// The two teams execute the same barriers in the same order (same code, same trip counts); an odd batch's last workgroup
+// computes its last window twice (identical stores).
+template <int WPB>
+__global__ __launch_bounds__(WPB * MID_NTH) void eqt_mid_kernel(const MidArgs a) {
+  __shared__ __attribute__((aligned(16))) float P_all[WPB * MID_POOL];
+  __shared__ float cur_all[WPB * 16 * 48];
+  const int team = WPB > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 9) : 0;
+  float* P = P_all + team * MID_POOL;
+  float* cur = cur_all + team * 16 * 48;
+  const int b = min((int)blockIdx.x * WPB + team, a.B - 1);
   int stamp = 0;
   unsigned long long* sub = a.clk ? a.clk + (long)b * 32 : nullptr;
-  if (threadIdx.x < 16) cur[threadIdx.x * 48 + 47] = 0.f;  // K padding of the a.x products; no stage writes column 47
+  if (MID_TID < 16) cur[MID_TID * 48 + 47] = 0.f;  // K padding of the a.x products; no stage writes column 47
   {  // The argument block is 13 cache lines and every stage reads its own part of it when it starts: a cold line
      // costs ~3.5 k cycles (measured: the stage that first touched another stage's arguments grew by that much).
      // All lines are requested here at once, so the later reads hit the scalar cache.
@@ -886,7 +902,7 @@ __global__ __launch_bounds__(MID_NTH) void eqt_mid_kernel(const MidArgs a) {
     asm volatile("" ::"s"(acc));
   }
 #define MID_STAMP()                                                                                   \
-  if (a.clk && threadIdx.x == 0) a.clk[(long)b * 32 + stamp] = __builtin_readcyclecounter();         \
+  if (a.clk && MID_TID == 0) a.clk[(long)b * 32 + stamp] = __builtin_readcyclecounter();         \
   ++stamp;
   MID_STAMP()
   // each stage requests the next one's weights under its own longest arithmetic phase (see BiFrags)
@@ -909,8 +925,12 @@ __global__ __launch_bounds__(MID_NTH) void eqt_mid_kernel(const MidArgs a) {
 #undef MID_STAMP
 }
 
-int launch_eqt_mid(const MidArgs& a, int B, hipStream_t s) {
-  hipLaunchKernelGGL(eqt_mid_kernel, dim3(B), dim3(MID_NTH), 0, s, a);
+int launch_eqt_mid(const MidArgs& a, int B, hipStream_t s, bool one_window_per_workgroup) {
+  if (one_window_per_workgroup) {
+    hipLaunchKernelGGL(eqt_mid_kernel<1>, dim3(B), dim3(MID_NTH), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(eqt_mid_kernel<2>, dim3((B + 1) / 2), dim3(2 * MID_NTH), 0, s, a);
+  }
   return 0;
 }
 
