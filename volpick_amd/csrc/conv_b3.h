@@ -185,6 +185,97 @@ __device__ __forceinline__ void conv_b3(const B3Image<C1> i1, const B3Image<C2> 
   }
 }
 
+// ---- a concat layer whose two inputs cannot rest in LDS as piece images at the same time (PhaseNet up1.same) ------------------
+// One item (m-tile mt, NB n-tiles from column colb) per wave, its accumulators carried across calls: the K-steps of ONE
+// 32-channel step `KSTEP` of the concatenated input (all taps) from the image `im` that holds those channels.
+template <class L, int KSTEP, int NB>
+__device__ __forceinline__ void conv_b3_part(const B3Image<32> im, const uint4* __restrict__ af3, const int mt, const int colb,
+                                             const int lane, f32x4 (&acc)[NB]) {
+  static_assert(L::P == 1 && L::SN == 1 && (L::CIN1 + L::CIN2) % 32 == 0, "plain unit-stride conv, 32-channel K-steps");
+  constexpr int KS = (L::CIN1 + L::CIN2) / 32, STEPS = L::TAPS * KS, PF = 3;
+  static_assert(KSTEP < KS, "channel step of the concat");
+  const int g = lane >> 4, n = lane & 15;
+  const uint4* ap = af3 + (long)mt * (STEPS * 3 * 64) + lane;
+  uint4 q[PF + 1][3];
+  auto load_a = [&](const int tap) {
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) q[tap % (PF + 1)][pc] = ap[((tap * KS + KSTEP) * 3 + pc) * 64];
+  };
+#pragma unroll
+  for (int tap = 0; tap < PF && tap < L::TAPS; ++tap) load_a(tap);
+  uint4 b[2][3];
+  auto load_b = [&](uint4 (&bv)[3], const int tap, const int j) {
+    const bf16_t* p = im.img + (colb + j * 16 + n + tap + L::IN_OFF + im.c0) * 40 + 8 * g;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) bv[pc] = *reinterpret_cast<const uint4*>(p + pc * im.ps);
+  };
+  load_b(b[0], 0, 0);
+#pragma unroll
+  for (int tap = 0; tap < L::TAPS; ++tap) {
+    if (tap + PF < L::TAPS) load_a(tap + PF);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int i = tap * NB + j;
+      if (i + 1 < L::TAPS * NB) load_b(b[(i + 1) & 1], (i + 1) / NB, (i + 1) % NB);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int WP[6] = {2, 1, 0, 1, 0, 0}, XP[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, q[tap % (PF + 1)][WP[t]]),
+                                                        __builtin_bit_cast(bf16x8_b3, b[i & 1][XP[t]]), acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// lds_epilogue hook (conv_lds.h) of a FOUR-PHASE fp32-MFMA layer (transposed conv, rows (channel, phase)) whose output feeds
+// the bf16 chain: a lane's four values are four consecutive samples of ONE channel, so the pieces leave as 2-byte stores.
+// Only samples [0, L) are written: zero the other columns first (B3Store::zero_rest with the written range).
+template <int C>
+struct B3PhaseStore {
+  static constexpr bool custom_block_epilogue = true;
+  bf16_t* img;
+  int ps, c0, L;
+  template <class LY>
+  __device__ __forceinline__ void block_epilogue(const f32x4 (&acc)[LY::NB], const float (&biasv)[4], const int mt, const int colb,
+                                                 const int g, const int n) const {
+    static_assert(LY::P == 4, "four phases per channel");
+    const int co = mt * 4 + g;
+#pragma unroll
+    for (int j = 0; j < LY::NB; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[j][r] + biasv[r];
+        if (LY::RELU) v = fmaxf(v, 0.f);
+        const int t = 4 * (colb + j * 16 + n) + r + LY::OUT_OFF;
+        if ((unsigned)t < (unsigned)L) {
+          unsigned short h, m, l;
+          b3_split(v, h, m, l);
+          bf16_t* p = img + (t + c0) * (C + 8) + co;
+          p[0] = h;
+          p[ps] = m;
+          p[2 * ps] = l;
+        }
+      }
+    }
+  }
+};
+
+// an fp32 image [32 channels][S], sample t at column B + t, -> the three-piece image (samples [t_lo, t_hi): whatever the fp32
+// image holds there, its zero margins included)
+template <int S, int B>
+__device__ __forceinline__ void b3_from_f32(const float* src, const B3Image<32> im, const int t_lo, const int t_hi, const int tid,
+                                            const int nth) {
+  const int n = t_hi - t_lo;
+  for (int i = tid; i < 8 * n; i += nth) {
+    const int cq = i / n, t = t_lo + (i - cq * n);
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = src[(4 * cq + r) * S + B + t];
+    b3_store4(im.img, im.ps, 40, t + im.c0, 4 * cq, v);
+  }
+}
+
 // ---- one item per wave, the operand in registers (time-tiled kernels whose weights do not change from tile to tile) --------
 // K-steps of a layer with C input channels: C >= 32: (tap, 32-channel step); C = 16 / 8: all channels of 2 / 4 consecutive
 // taps per step (net.hip: b3_operand pads the filter with zero taps), lane group g = lane / 16 supplies tap `tap_of_lane`,

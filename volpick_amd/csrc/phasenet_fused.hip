@@ -925,8 +925,8 @@ using W_upT = LdsLayer<16, 0, 8, 4, 2, 1, -1, -2, 3, 1>;    // out sample 4m + p
 struct WindowArgs {
   CoreArgs c;       // d0 / u2s unused (they live in LDS)
   const float* af4[13];  // weights of the core layers regrouped for 16-byte loads (conv_lds_q4), null where unused
-  const uint4* af3[5];   // down3.same .. up0.same as three-piece bf16 operands (conv_b3.h), B3 instantiation
-  int af3_lines[5];      // their sizes in 128-byte lines (L2 warm-up)
+  const uint4* af3[6];   // down3.same .. up0.same (+ up1.same, U1B) as three-piece bf16 operands (conv_b3.h), B3 instantiation
+  int af3_lines[6];      // their sizes in 128-byte lines (L2 warm-up)
   const float* x;   // [B][3][ls] normalised input
   int ls_x;
   long ws_x;
@@ -975,7 +975,13 @@ constexpr int B3_SK3_OFF = CORE_LDS_FLOATS * 2 - 3 * B3_SK3_PS;  // bf16 element
 static_assert(B3_SK3_OFF % 8 == 0 && (A_R * 2) % 8 == 0 && (A_Q * 2) % 8 == 0, "16-byte aligned images");
 static_assert(A_R * 2 + 3 * B3_U0T_PS <= B3_SK3_OFF && A_R * 2 + 3 * B3_D2_PS <= B3_SK3_OFF && 3 * B3_BOT_PS <= (A_R - A_Q) * 2,
               "three-piece images of the deep layers fit their slots");
-template <bool PIPE, bool B3>
+// U1B (with B3): up1.same on the bf16 matrix cores as well.  Its two inputs (skip 2, up1.convT's output: 32 channels x 188 each)
+// do not fit the arena as piece images side by side, so it runs in two K halves over ONE 48 KB image at the end of the arena
+// (up2.convT's output slot): up1.convT writes its output there as pieces, eight waves (m-tile x four blocks of three n-tiles)
+// take its taps, the image is refilled from the fp32 skip-2 rows, the same waves add the other half and store.
+constexpr int B3_U1_NC = 200, B3_U1_PS = B3_U1_NC * 40;  // columns (sample t at column t + 3) / elements per piece
+static_assert(A_U2T * 4 % 16 == 0 && A_U2T * 2 + 3 * B3_U1_PS <= CORE_LDS_FLOATS * 2 && B3_U1_NC >= 192 + 6, "up1.same piece image");
+template <bool PIPE, bool B3, bool U1B = false>
 __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   extern __shared__ float4 lds_raw[];
   float* lds = reinterpret_cast<float*>(lds_raw);
@@ -1000,7 +1006,7 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
     CORE_WARM(0, C_d1same) CORE_WARM(1, C_d1down) CORE_WARM(2, C_d2same) CORE_WARM(3, C_d2down)
     if constexpr (B3) {
 #pragma unroll
-      for (int i = 0; i < 5; ++i)
+      for (int i = 0; i < 6; ++i)
         for (int l = tid; l < a.af3_lines[i]; l += NTH) sink += __uint_as_float(reinterpret_cast<const unsigned*>(a.af3[i])[l * 32]);
     } else {
       CORE_WARM(4, C_d3same) CORE_WARM(5, C_d3down) CORE_WARM(6, C_d4same) CORE_WARM(7, C_u0T) CORE_WARM(8, C_u0same)
@@ -1305,8 +1311,52 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   CORE_LAYER(7, C_u0T, A_BOT, S4_, A_BOT, S4_, IB, A_U0T, S3_, TB, RangeStoreV, 64, T4 + 1, T3)
   CORE_LAYER(8, C_u0same, A_SKIP3, S3_, A_U0T, S3_, TB, A_U0S, S3_, IB, RangeStoreS, 64, T3, T3)
   }
+  if constexpr (B3 && U1B) {
+    const B3Image<32> iP{reinterpret_cast<bf16_t*>(lds) + A_U2T * 2, B3_U1_PS, 3};
+    {  // up1.convT (fp32 MFMA, 8 m-tiles x 1 block) -> three-piece image
+      const B3PhaseStore<32> st{iP.img, iP.ps, iP.c0, T2};
+      (B3Store<32>{iP.img, iP.ps, iP.c0, T2, B3_U1_NC}).zero_rest(3, 3 + T2, tid, NTH);
+      if (wave < C_u1T::MT) {
+        float ar[C_u1T::CB * C_u1T::TAPS], br[4];
+        load_areg4<C_u1T>(a.af4[9], wave, lane, ar);
+        load_biasreg<C_u1T>(a.c.bs[9], wave, lane, br);
+        conv_lds_areg<C_u1T, S3_, IB, S3_, IB>(lds + X_U0S, lds + X_U0S, ar, br, wave, T3 + 1, st, 0, 1, lane);
+      }
+      __syncthreads();
+      WIN_STAMP(stamp)
+      ++stamp;
+    }
+    {  // up1.same: K half of up1.convT's channels, then the half of skip 2
+      const F32QuadStore<S2_, IB> st{lds + A_U1S, T2};
+      zero_halo<32, S2_, T2, IB>(lds + A_U1S, tid, NTH);
+      const int mt = wave & 1, colb = (wave >> 1) * 48;
+      f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      if (wave < 8) conv_b3_part<C_u1same, 1, 3>(iP, a.af3[5], mt, colb, lane, acc);
+      __syncthreads();  // every wave is through with up1.convT's pieces
+      b3_from_f32<S2_, IB>(lds + A_SKIP2, iP, -3, B3_U1_NC - 3, tid, NTH);
+      __syncthreads();
+      if (wave < 8) {
+        conv_b3_part<C_u1same, 0, 3>(iP, a.af3[5], mt, colb, lane, acc);
+        const int co0 = mt * 16 + 4 * (lane >> 4);
+        float biasv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) biasv[r] = a.c.bs[10][co0 + r];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = C_u1same::RELU ? fmaxf(acc[j][r] + biasv[r], 0.f) : acc[j][r] + biasv[r];
+          st.quad(co0, colb + j * 16 + (lane & 15), v);
+        }
+      }
+      __syncthreads();
+      WIN_STAMP(stamp)
+      ++stamp;
+    }
+  } else {
   CORE_LAYER_AREG(9, C_u1T, X_U0S, S3_, X_U1T, S2_, TB, RangeStoreV, 32, T3 + 1, T2, wave, 0, 1)        // 8 m-tiles x 1 block (pn_core_kernel)
   CORE_LAYER(10, C_u1same, A_SKIP2, S2_, X_U1T, S2_, TB, A_U1S, S2_, IB, RangeStoreS, 32, T2, T2)
+  }
   CORE_LAYER_AREG(11, C_u2T, A_U1S, S2_, A_U2T, S1_, TB, RangeStoreV, 16, T2 + 1, T1, wave & 3, wave >> 2, 4)  // 4 m-tiles x 4 blocks
 #undef CORE_LAYER_AREG
   // up2.same has eight items: waves 0-7 run it, waves 8-15 meanwhile fetch the eight skip rows of the up phase into
@@ -1449,6 +1499,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
   const bool valu = net.cfg.plan_flags[5] != 1;
   const bool whole = valu && net.cfg.plan_flags[5] != 2 && !debug_dumps;
   const bool b3 = whole && net.cfg.plan_flags[5] != 3;  // plan_flags[5] = 3: the one-launch kernel with all core layers on the fp32 MFMA
+  const bool u1b = b3 && net.cfg.plan_flags[5] != 4;    // plan_flags[5] = 4: up1.same stays on the fp32 MFMA (the form of round 2)
   HostBlob *vw[5] = {}, *vb[5] = {};
   if (valu) {
     const float eps = net.cfg.bn_eps;
@@ -1648,6 +1699,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
       double f32 = 0, bf16 = 0;
       for (int i = 2; i <= 16; ++i) {
         if (b3 && i >= 7 && i <= 11) bf16 += 6.0 * padded(i);
+        else if (u1b && i == 13) bf16 += 6.0 * 2.0 * 32 * 192 * 64 * 7;  // up1.same: 2 m-tiles x 12 n-tiles x 14 K-steps
         else f32 += padded(i);
       }
       st.set_issued(f32, bf16, flops(0, 1) + flops(17, 17));
@@ -1661,13 +1713,14 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
       std::vector<float> v = regroup_afrag4(*net.convs[3 + i]);
       q4[i] = net.add_blob(std::move(v));
     }
-    HostBlob* p3[5] = {};
+    HostBlob* p3[6] = {};
     if (b3)
       for (int i = 0; i < 5; ++i) p3[i] = net.add_blob(b3_operand(*net.convs[3 + 4 + i], i == 3));
+    if (u1b) p3[5] = net.add_blob(b3_operand(*net.convs[3 + 10], false));
     st.run = [=](Net& n, int B, hipStream_t s) -> int {
       WindowArgs a{};
       for (int i = 0; i < 13; ++i) a.af4[i] = q4[i] ? q4[i]->d : nullptr;
-      for (int i = 0; i < 5; ++i) {
+      for (int i = 0; i < 6; ++i) {
         a.af3[i] = p3[i] ? reinterpret_cast<const uint4*>(p3[i]->d) : nullptr;
         a.af3_lines[i] = p3[i] ? (int)(p3[i]->h.size() * 4 / 128) : 0;
       }
@@ -1702,7 +1755,9 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         a.pre = *n.pre;
         a.has_pre = 1;
       }
-      if (b3) {
+      if (u1b) {
+        hipLaunchKernelGGL((pn_window_kernel<false, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
+      } else if (b3) {
         hipLaunchKernelGGL((pn_window_kernel<false, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
       } else if (pipe) {
         hipLaunchKernelGGL((pn_window_kernel<true, false>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
@@ -1718,6 +1773,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<true, false>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, false>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true>), CORE_LDS_FLOATS * sizeof(float)});
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true>), CORE_LDS_FLOATS * sizeof(float)});
   }
   net.steps = std::move(steps);
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_core_kernel<true>), CORE_LDS_FLOATS * sizeof(float)});
