@@ -67,8 +67,9 @@ typedef struct {
                                       bf16 matrix cores with exact three-piece operands (default), 1 = three launches,
                                       all MFMA (bit-identical to the layer plan), 2 = three launches, level-0
                                       stride-1 convs on the VALU, 3 = one launch, every core layer on the fp32 MFMA,
-                                      4 = one launch with up1.same on the fp32 MFMA (default: on the bf16 matrix cores too,
-                                      in two K halves);
+                                      4 = one launch with up1.same and up2.same on the fp32 MFMA, 5 = with up2.same only
+                                      (default: both on the bf16 matrix cores too, each in two K halves over one piece
+                                      image that is refilled in between);
                                  [6]: PhaseNet: 1 = the one-launch plan reads the input tensor filled by gather_normalize
                                       instead of cutting and normalising its windows itself; EQTransformer: 2 = the fused
                                       encoder front cuts and normalises its windows itself (A/B: slower end to end);

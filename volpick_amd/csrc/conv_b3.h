@@ -228,8 +228,23 @@ __device__ __forceinline__ void conv_b3_part(const B3Image<32> im, const uint4* 
   }
 }
 
+// 4 x 4 transpose between a lane's four registers and the four 16-lane rows of the wavefront: afterwards v[k] of row g holds what
+// v[g] of row k held (v_permlane32_swap: upper half of the first operand <-> lower half of the second; v_permlane16_swap: odd
+// rows of the first <-> even rows of the second).
+__device__ __forceinline__ void b3_transpose_rows(float (&v)[4]) {
+  const auto p02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[0]), __float_as_uint(v[2]), false, false);
+  const auto p13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[1]), __float_as_uint(v[3]), false, false);
+  const auto q01 = __builtin_amdgcn_permlane16_swap(p02[0], p13[0], false, false);
+  const auto q23 = __builtin_amdgcn_permlane16_swap(p02[1], p13[1], false, false);
+  v[0] = __uint_as_float(q01[0]);
+  v[1] = __uint_as_float(q01[1]);
+  v[2] = __uint_as_float(q23[0]);
+  v[3] = __uint_as_float(q23[1]);
+}
+
 // lds_epilogue hook (conv_lds.h) of a FOUR-PHASE fp32-MFMA layer (transposed conv, rows (channel, phase)) whose output feeds
-// the bf16 chain: a lane's four values are four consecutive samples of ONE channel, so the pieces leave as 2-byte stores.
+// the bf16 chain: a lane's four values are four consecutive samples of ONE channel (channel 4 mt + row g of the lane); the
+// transpose above turns them into the m-tile's four channels at ONE sample (phase g), which leave as one 8-byte store per piece.
 // Only samples [0, L) are written: zero the other columns first (B3Store::zero_rest with the written range).
 template <int C>
 struct B3PhaseStore {
@@ -240,23 +255,17 @@ struct B3PhaseStore {
   __device__ __forceinline__ void block_epilogue(const f32x4 (&acc)[LY::NB], const float (&biasv)[4], const int mt, const int colb,
                                                  const int g, const int n) const {
     static_assert(LY::P == 4, "four phases per channel");
-    const int co = mt * 4 + g;
 #pragma unroll
     for (int j = 0; j < LY::NB; ++j) {
+      float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = acc[j][r] + biasv[r];
-        if (LY::RELU) v = fmaxf(v, 0.f);
-        const int t = 4 * (colb + j * 16 + n) + r + LY::OUT_OFF;
-        if ((unsigned)t < (unsigned)L) {
-          unsigned short h, m, l;
-          b3_split(v, h, m, l);
-          bf16_t* p = img + (t + c0) * (C + 8) + co;
-          p[0] = h;
-          p[ps] = m;
-          p[2 * ps] = l;
-        }
+        v[r] = acc[j][r] + biasv[r];  // biasv: the lane's channel, the same for its four phases
+        if (LY::RELU) v[r] = fmaxf(v[r], 0.f);
       }
+      b3_transpose_rows(v);  // v[k] = channel 4 mt + k at phase g
+      const int t = 4 * (colb + j * 16 + n) + g + LY::OUT_OFF;
+      if ((unsigned)t < (unsigned)L) b3_store4(img, ps, C + 8, t + c0, 4 * mt, v);
     }
   }
 };
@@ -371,6 +380,85 @@ __device__ __forceinline__ void b3c_mac_tiles(const bf16_t* p, const uint4 (&a)[
     prev = acc;
   }
   finish(NB - 1, prev);
+}
+
+// The same with the accumulators of all NB n-tiles kept: acc[j] += operand x fragments of n-tile j.  For a layer whose K is walked
+// in two passes over ONE image that is refilled in between (PhaseNet up2.same).
+template <int C, int NC, int TAPS, int NB>
+__device__ __forceinline__ void b3c_mac_tiles_acc(const bf16_t* p, const uint4 (&a)[B3Steps<C, TAPS>::STEPS * 3], f32x4 (&acc)[NB]) {
+  using G = B3Steps<C, TAPS>;
+  using Q = B3Chunk<C, NC>;
+  constexpr int STEPS = G::STEPS;
+  constexpr int AHEAD = 1, NBUF = AHEAD + 1, PAIRS = STEPS * NB;
+  uint4 b[NBUF][3];
+  auto load_b = [&](const int i) {
+    const int s = i % STEPS, j = i / STEPS;
+    const int off = ((C >= 32 ? s / G::KS : s * G::TPK) + j * 16) * 8 + (C >= 32 ? (s % G::KS) * 4 * Q::CHS : 0);
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) b[i % NBUF][pc] = *reinterpret_cast<const uint4*>(p + pc * Q::PS + off);
+  };
+  load_b(0);
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      const int i = j * STEPS + s;
+      if (i + AHEAD < PAIRS) load_b(i + AHEAD);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int WP[6] = {2, 1, 0, 1, 0, 0}, XP[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, a[s * 3 + WP[t]]),
+                                                        __builtin_bit_cast(bf16x8_b3, b[i % NBUF][XP[t]]), acc[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// B3PhaseStore for a chunk-plane image (C = 16: two chunks of eight channels)
+template <int C, int NC>
+struct B3PhaseStoreC {
+  static constexpr bool custom_block_epilogue = true;
+  bf16_t* img;
+  int c0, L;
+  template <class LY>
+  __device__ __forceinline__ void block_epilogue(const f32x4 (&acc)[LY::NB], const float (&biasv)[4], const int mt, const int colb,
+                                                 const int g, const int n) const {
+    static_assert(LY::P == 4, "four phases per channel");
+#pragma unroll
+    for (int j = 0; j < LY::NB; ++j) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[j][r] + biasv[r];
+        if (LY::RELU) v[r] = fmaxf(v[r], 0.f);
+      }
+      b3_transpose_rows(v);  // v[k] = channel 4 mt + k at phase g
+      const int t = 4 * (colb + j * 16 + n) + g + LY::OUT_OFF;
+      if ((unsigned)t < (unsigned)L) b3c_store4<C, NC>(img, t + c0, mt, v);
+    }
+  }
+};
+// zero the columns of a chunk-plane image outside [col_lo, col_hi)
+template <int C, int NC>
+__device__ __forceinline__ void b3c_zero_rest(bf16_t* img, const int col_lo, const int col_hi, const int tid, const int nth) {
+  using Q = B3Chunk<C, NC>;
+  const int nz = NC - (col_hi - col_lo);
+  for (int i = tid; i < 3 * (C / 8) * nz; i += nth) {
+    const int cp = i / nz, k = i - cp * nz, col = k < col_lo ? k : col_hi + (k - col_lo);
+    *reinterpret_cast<uint4*>(img + (cp / (C / 8)) * Q::PS + (cp % (C / 8)) * Q::CHS + col * 8) = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+// an fp32 image [C channels][S], sample t at column B + t, -> the chunk-plane image, columns [0, NC) <-> samples [-c0, NC - c0)
+template <int C, int NC, int S, int B>
+__device__ __forceinline__ void b3c_from_f32(const float* src, bf16_t* img, const int c0, const int tid, const int nth) {
+  for (int i = tid; i < (C / 4) * NC; i += nth) {
+    const int cq = i / NC, col = i - cq * NC;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (B + col - c0 < S) ? src[(4 * cq + r) * S + B + col - c0] : 0.f;
+    b3c_store4<C, NC>(img, col, cq, v);
+  }
 }
 
 }  // namespace vp

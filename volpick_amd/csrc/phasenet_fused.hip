@@ -927,6 +927,7 @@ struct WindowArgs {
   const float* af4[13];  // weights of the core layers regrouped for 16-byte loads (conv_lds_q4), null where unused
   const uint4* af3[6];   // down3.same .. up0.same (+ up1.same, U1B) as three-piece bf16 operands (conv_b3.h), B3 instantiation
   int af3_lines[6];      // their sizes in 128-byte lines (L2 warm-up)
+  const uint4* af3_u2[2];  // U2B: up2.same's operand per input half (skip 1 | up2.convT), 16-channel K-steps (B3Steps<16, 7>)
   const float* x;   // [B][3][ls] normalised input
   int ls_x;
   long ws_x;
@@ -981,8 +982,22 @@ static_assert(A_R * 2 + 3 * B3_U0T_PS <= B3_SK3_OFF && A_R * 2 + 3 * B3_D2_PS <=
 // take its taps, the image is refilled from the fp32 skip-2 rows, the same waves add the other half and store.
 constexpr int B3_U1_NC = 200, B3_U1_PS = B3_U1_NC * 40;  // columns (sample t at column t + 3) / elements per piece
 static_assert(A_U2T * 4 % 16 == 0 && A_U2T * 2 + 3 * B3_U1_PS <= CORE_LDS_FLOATS * 2 && B3_U1_NC >= 192 + 6, "up1.same piece image");
-template <bool PIPE, bool B3, bool U1B = false>
+// U2B (with U1B): up2.same the same way.  Its inputs are 16 channels x 751 each: 74 KB as a chunk-plane piece image, one at a
+// time.  up1.same's output moves to the skip-2 slot (dead once its pieces are made), up2.convT writes pieces into the 74 KB behind
+// it, waves 0-7 (six n-tiles each, accumulators kept) take that half, the image is refilled from the fp32 skip-1 rows, the
+// same waves add the other half and store into the skip-1 slot -- the up phase then finds up2.same at the start of the arena
+// and its two groups of level-0 rows behind it.
+constexpr int B3_U2_NC = 784, B3_U2_OFF = A_Q;  // columns (sample t at column t + 3) / float offset of the image
+static_assert(B3_U2_OFF % 4 == 0 && B3_U2_OFF * 4 + 3 * B3Chunk<16, B3_U2_NC>::PS * 2 <= CORE_LDS_FLOATS * 4 &&
+                  B3_U2_NC >= 48 * 16 + 8 && B3_U2_OFF >= A_SKIP2 + 32 * S2_,
+              "up2.same piece image: behind up1.same's relocated output, inside the arena");
+template <bool PIPE, bool B3, bool U1B = false, bool U2B = false>
 __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
+  static_assert(!U2B || U1B, "U2B relocates up1.same's output: needs the U1B form");
+  // up phase: up2.same | level-0 rows 0-3 | level-0 rows 4-7
+  constexpr int XU_U = U2B ? A_SKIP1 : WU_U, XU_G0 = U2B ? A_SKIP2 : WU_G0, XU_G1 = U2B ? A_SKIP2 + 4 * W0_S : WU_G1;
+  static_assert(XU_G1 + 4 * W0_S <= CORE_LDS_FLOATS && XU_U + 16 * S1_ <= (U2B ? XU_G0 : A_U2T), "up-phase regions");
+  constexpr int X_U1S = U2B ? A_SKIP2 : A_U1S;  // up1.same's output
   extern __shared__ float4 lds_raw[];
   float* lds = reinterpret_cast<float*>(lds_raw);
   // (the wave index as a scalar: item loops, block indices and the epilogues' "whole block in range" tests become
@@ -1327,8 +1342,8 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
       ++stamp;
     }
     {  // up1.same: K half of up1.convT's channels, then the half of skip 2
-      const F32QuadStore<S2_, IB> st{lds + A_U1S, T2};
-      zero_halo<32, S2_, T2, IB>(lds + A_U1S, tid, NTH);
+      const F32QuadStore<S2_, IB> st{lds + X_U1S, T2};  // (U2B: skip 2's own slot -- its halo columns are zero already, and the
+      zero_halo<32, S2_, T2, IB>(lds + X_U1S, tid, NTH);  //  stores come after the rows have been turned into pieces)
       const int mt = wave & 1, colb = (wave >> 1) * 48;
       f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
       if (wave < 8) conv_b3_part<C_u1same, 1, 3>(iP, a.af3[5], mt, colb, lane, acc);
@@ -1357,15 +1372,30 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   CORE_LAYER_AREG(9, C_u1T, X_U0S, S3_, X_U1T, S2_, TB, RangeStoreV, 32, T3 + 1, T2, wave, 0, 1)        // 8 m-tiles x 1 block (pn_core_kernel)
   CORE_LAYER(10, C_u1same, A_SKIP2, S2_, X_U1T, S2_, TB, A_U1S, S2_, IB, RangeStoreS, 32, T2, T2)
   }
-  CORE_LAYER_AREG(11, C_u2T, A_U1S, S2_, A_U2T, S1_, TB, RangeStoreV, 16, T2 + 1, T1, wave & 3, wave >> 2, 4)  // 4 m-tiles x 4 blocks
+  [[maybe_unused]] bf16_t* const P2 = reinterpret_cast<bf16_t*>(lds) + B3_U2_OFF * 2;
+  if constexpr (U2B) {  // up2.convT (fp32 MFMA, 4 m-tiles x 4 blocks) -> chunk-plane piece image
+    const B3PhaseStoreC<16, B3_U2_NC> st{P2, 3, T1};
+    b3c_zero_rest<16, B3_U2_NC>(P2, 3, 3 + T1, tid, NTH);
+    {
+      float ar[C_u2T::CB * C_u2T::TAPS], br[4];
+      load_areg4<C_u2T>(a.af4[11], wave & 3, lane, ar);
+      load_biasreg<C_u2T>(a.c.bs[11], wave & 3, lane, br);
+      conv_lds_areg<C_u2T, S2_, IB, S2_, IB>(lds + X_U1S, lds + X_U1S, ar, br, wave & 3, T2 + 1, st, wave >> 2, 4, lane);
+    }
+    __syncthreads();
+    WIN_STAMP(stamp)
+    ++stamp;
+  } else {
+  CORE_LAYER_AREG(11, C_u2T, X_U1S, S2_, A_U2T, S1_, TB, RangeStoreV, 16, T2 + 1, T1, wave & 3, wave >> 2, 4)  // 4 m-tiles x 4 blocks
+  }
 #undef CORE_LAYER_AREG
   // up2.same has eight items: waves 0-7 run it, waves 8-15 meanwhile fetch the eight skip rows of the up phase into
   // registers (their LDS destination is still in use by this layer) and park them in LDS right after the barrier —
   // the read-back of the skip tensor costs the up phase nothing (it was 8 k cycles of exposed memory latency).
   constexpr int NSKQ = (8 * W0_Q + 511) / 512;
   {
-    RangeStoreS<S1_, IB> st{{lds + WU_U, T1}};
-    zero_halo<16, S1_, T1, IB>(lds + WU_U, tid, NTH);
+    RangeStoreS<S1_, IB> st{{lds + XU_U, T1}};
+    if constexpr (!U2B) zero_halo<16, S1_, T1, IB>(lds + XU_U, tid, NTH);
     if (wave >= 8) {
       float4 skq[NSKQ];
       const float* src = a.skip0 + (long)win * a.ws_s;
@@ -1377,13 +1407,46 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
         if (i < 8 * W0_Q && p + 3 < a.ls_s) skq[k] = *reinterpret_cast<const float4*>(src + (long)c * a.ls_s + p);
       }
       WIN_WARM_SCALAR(a.w_up, 16 * 7 * 8)
+      if constexpr (U2B) {
+        __syncthreads();  // waves 0-7 are through with up2.convT's pieces
+        b3c_from_f32<16, B3_U2_NC, S1_, IB>(lds + A_SKIP1, P2, 3, tid, NTH);
+        __syncthreads();  // skip 1 rests in the image: its fp32 rows give way to up2.same's output
+        zero_halo<16, S1_, T1, IB>(lds + XU_U, tid - 512, NTH - 512);
+      }
       __syncthreads();  // up2.same done: its inputs give way to the level-0 rows (0-3 -> G0, 4-7 -> G1)
 #pragma unroll
       for (int k = 0; k < NSKQ; ++k) {
         const int i = tid - 512 + k * 512, c = i / W0_Q, q = i - c * W0_Q;
         if (i < 8 * W0_Q)
-          *reinterpret_cast<float4*>(((c < 4) ? lds + WU_G0 + c * W0_S : lds + WU_G1 + (c - 4) * W0_S) + 4 * q) = skq[k];
+          *reinterpret_cast<float4*>(((c < 4) ? lds + XU_G0 + c * W0_S : lds + XU_G1 + (c - 4) * W0_S) + 4 * q) = skq[k];
       }
+    } else if constexpr (U2B) {
+      // wave w: n-tiles 6 w .. 6 w + 5 (48 for the 47 that hold samples), K = 2 halves x 4 steps of two taps x 16 channels
+      const bf16_t* bp = b3c_lane_ptr<16, B3_U2_NC, 7>(P2, wave * 96, lane);
+      f32x4 acc[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      uint4 aw[B3Steps<16, 7>::STEPS * 3];
+      b3_load_a<16, 7>(a.af3_u2[1], 0, lane, aw);
+      b3c_mac_tiles_acc<16, B3_U2_NC, 7, 6>(bp, aw, acc);
+      b3_load_a<16, 7>(a.af3_u2[0], 0, lane, aw);  // on its way under the refill
+      __syncthreads();
+      b3c_from_f32<16, B3_U2_NC, S1_, IB>(lds + A_SKIP1, P2, 3, tid, NTH);
+      __syncthreads();
+      b3c_mac_tiles_acc<16, B3_U2_NC, 7, 6>(bp, aw, acc);
+      {
+        const int co0 = 4 * (lane >> 4);
+        float biasv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) biasv[r] = a.c.bs[12][co0 + r];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int t = wave * 96 + j * 16 + (lane & 15);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st(co0 + r, t, C_u2same::RELU ? fmaxf(acc[j][r] + biasv[r], 0.f) : acc[j][r] + biasv[r]);
+        }
+      }
+      __syncthreads();
     } else {
       conv_lds<C_u2same, S1_, IB, S1_, TB, PIPE, (C_u2same::NB < BDB_MAX_NB), ADEEP_LAYER(C_u2same)>(lds + A_SKIP1, lds + A_U2T, a.c.af[12], a.c.bs[12], T1, st, wave, NWV, lane);
       __syncthreads();
@@ -1395,7 +1458,7 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
 
   // ================= level-0 up path: up3.convT -> cat(skip0, .) -> up3.same -> 1x1 -> softmax =================
   {
-    float *G0 = lds + WU_G0, *G1 = lds + WU_G1, *U = lds + WU_U;
+    float *G0 = lds + XU_G0, *G1 = lds + XU_G1, *U = lds + XU_U;
     WIN_STAMP(23)
     __syncthreads();
     WIN_STAMP(24)
@@ -1499,7 +1562,8 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
   const bool valu = net.cfg.plan_flags[5] != 1;
   const bool whole = valu && net.cfg.plan_flags[5] != 2 && !debug_dumps;
   const bool b3 = whole && net.cfg.plan_flags[5] != 3;  // plan_flags[5] = 3: the one-launch kernel with all core layers on the fp32 MFMA
-  const bool u1b = b3 && net.cfg.plan_flags[5] != 4;    // plan_flags[5] = 4: up1.same stays on the fp32 MFMA (the form of round 2)
+  const bool u1b = b3 && net.cfg.plan_flags[5] != 4;    // plan_flags[5] = 4: up1.same and up2.same stay on the fp32 MFMA (the form of round 2)
+  const bool u2b = u1b && net.cfg.plan_flags[5] != 5;   // plan_flags[5] = 5: only up2.same does
   HostBlob *vw[5] = {}, *vb[5] = {};
   if (valu) {
     const float eps = net.cfg.bn_eps;
@@ -1700,6 +1764,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
       for (int i = 2; i <= 16; ++i) {
         if (b3 && i >= 7 && i <= 11) bf16 += 6.0 * padded(i);
         else if (u1b && i == 13) bf16 += 6.0 * 2.0 * 32 * 192 * 64 * 7;  // up1.same: 2 m-tiles x 12 n-tiles x 14 K-steps
+        else if (u2b && i == 15) bf16 += 6.0 * 2.0 * 16 * 768 * 32 * 8;  // up2.same: 48 n-tiles x 2 halves x 4 K-steps
         else f32 += padded(i);
       }
       st.set_issued(f32, bf16, flops(0, 1) + flops(17, 17));
@@ -1717,9 +1782,48 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     if (b3)
       for (int i = 0; i < 5; ++i) p3[i] = net.add_blob(b3_operand(*net.convs[3 + 4 + i], i == 3));
     if (u1b) p3[5] = net.add_blob(b3_operand(*net.convs[3 + 10], false));
+    HostBlob* p3u2[2] = {};
+    if (u2b) {  // up2.same per input half as 16-channel K-steps (B3Steps<16, 7>: two taps per step, tap 7 = zero weights):
+                // [step][piece][lane][8], lane = 16 g + row, tap = 2 step + g / 2, channels 16 half + 8 (g % 2) ..
+      const ConvLayer& L = *net.convs[3 + 12];
+      const int taps = L.g.taps, CB = L.g.cinp() / 4;
+      auto rne = [](float x) -> uint16_t {
+        uint32_t u;
+        memcpy(&u, &x, 4);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+      };
+      auto widen = [](uint16_t h) -> float {
+        const uint32_t u = (uint32_t)h << 16;
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+      };
+      for (int half = 0; half < 2; ++half) {
+        std::vector<uint16_t> o((size_t)4 * 3 * 64 * 8);
+        for (int st = 0; st < 4; ++st)
+          for (int l = 0; l < 64; ++l)
+            for (int i = 0; i < 8; ++i) {
+              const int m = l & 15, g = l >> 4, tap = 2 * st + g / 2, ci = 16 * half + 8 * (g % 2) + i;
+              const float w = tap < taps ? L.afrag.h[(((size_t)(ci / 4)) * taps + tap) * 64 + (ci % 4) * 16 + m] : 0.f;
+              (void)CB;
+              const uint16_t h = rne(w);
+              const float r1 = w - widen(h);
+              const uint16_t md = rne(r1);
+              const size_t base = (((size_t)st * 3) * 64 + l) * 8 + i;
+              o[base] = h;
+              o[base + 64 * 8] = md;
+              o[base + 2 * 64 * 8] = rne(r1 - widen(md));
+            }
+        std::vector<float> f(o.size() / 2);
+        memcpy(f.data(), o.data(), o.size() * 2);
+        p3u2[half] = net.add_blob(std::move(f));
+      }
+    }
     st.run = [=](Net& n, int B, hipStream_t s) -> int {
       WindowArgs a{};
       for (int i = 0; i < 13; ++i) a.af4[i] = q4[i] ? q4[i]->d : nullptr;
+      for (int i = 0; i < 2; ++i) a.af3_u2[i] = p3u2[i] ? reinterpret_cast<const uint4*>(p3u2[i]->d) : nullptr;
       for (int i = 0; i < 6; ++i) {
         a.af3[i] = p3[i] ? reinterpret_cast<const uint4*>(p3[i]->d) : nullptr;
         a.af3_lines[i] = p3[i] ? (int)(p3[i]->h.size() * 4 / 128) : 0;
@@ -1755,7 +1859,9 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         a.pre = *n.pre;
         a.has_pre = 1;
       }
-      if (u1b) {
+      if (u2b) {
+        hipLaunchKernelGGL((pn_window_kernel<false, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
+      } else if (u1b) {
         hipLaunchKernelGGL((pn_window_kernel<false, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
       } else if (b3) {
         hipLaunchKernelGGL((pn_window_kernel<false, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
@@ -1774,6 +1880,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, false>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true>), CORE_LDS_FLOATS * sizeof(float)});
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
   }
   net.steps = std::move(steps);
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_core_kernel<true>), CORE_LDS_FLOATS * sizeof(float)});
