@@ -163,6 +163,18 @@ def test_forward_parity(model, oracle, B):
         assert (g > 0).all() and (g < 1).all()
 
 
+@pytest.mark.parametrize("B", [1, 2, 5, 256, 257])
+def test_middle_kernel_with_two_windows_per_workgroup_is_bitwise_the_one_window_form(model, B):
+    """Default: eqt_mid_kernel<2> -- 1024 threads, waves 0-7 one window, waves 8-15 the next (roles rotated by two waves), an
+    odd batch's last workgroup computing its last window twice; plan_flags[2] = 2: one window per 512-thread workgroup.
+    Same arithmetic per window: every output bit-identical."""
+    x = torch.from_numpy(synthetic_windows(B, 6000, seed=500 + B)).cuda()
+    one = EQTransformer.from_pretrained("volpick")
+    one._plan_flags = (0, 0, 2)
+    one.cuda()
+    assert torch.equal(model._forward_raw(x, preprocess=True), one._forward_raw(x, preprocess=True))
+
+
 def test_six_launch_plan_matches_fused_middle_kernel(model, oracle):
     """plan_flags[2] = 1 keeps the BiLSTM / transformer / pick-branch launches that eqt_mid_kernel replaces (scalar FMA
     chains instead of matrix-core tiles, same algorithm): both plans within the oracle tolerance, and of each other."""

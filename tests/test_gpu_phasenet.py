@@ -97,6 +97,32 @@ def test_fused_equals_layerwise_bitwise(oracle):
     assert np.abs(three(xn).numpy() - want).max() < 5e-6
 
 
+@pytest.mark.parametrize("B", [1, 7, 256])
+def test_up_path_on_the_bf16_matrix_cores_agrees_with_the_fp32_mfma_forms(oracle, B):
+    """Default plan: up1.same and up2.same run on the bf16 matrix cores in two K halves (pn_window_kernel U1B / U2B);
+    plan_flags[5] = 5 keeps up2.same, 4 both on the fp32 MFMA (round 2's kernel): the three agree to fp32 rounding, each
+    within the regression bar of the oracle, and an input with a non-finite window poisons that window only."""
+    x = synthetic_windows(B, 3001, seed=300 + B)
+    xn = OP.batch_pre(oracle, torch.from_numpy(x))
+    with torch.no_grad():
+        want = oracle(xn).numpy()
+    outs = []
+    for flags in ((0,), (0, 0, 0, 0, 0, 5), (0, 0, 0, 0, 0, 4)):
+        m = PhaseNet.from_pretrained("volpick")
+        m._plan_flags = flags
+        m.cuda()
+        outs.append(m(xn).numpy())
+        assert np.abs(outs[-1] - want).max() < 3e-5, flags
+    assert np.abs(outs[0] - outs[2]).max() < 1e-5 and np.abs(outs[1] - outs[2]).max() < 1e-5
+    if B > 1:
+        bad = xn.clone()
+        bad[B // 2, 1, 1500] = float("nan")
+        got = PhaseNet.from_pretrained("volpick").cuda()(bad).numpy()
+        assert np.isnan(got[B // 2]).all()
+        keep = [b for b in range(B) if b != B // 2]
+        assert np.array_equal(got[keep], outs[0][keep])
+
+
 @pytest.mark.parametrize("B", [1, 5, 256, 300])
 def test_forward_parity(model, oracle, B):
     x = synthetic_windows(B, 3001, seed=100 + B)
