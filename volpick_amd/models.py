@@ -238,9 +238,11 @@ class WaveformModel:
         _lib.check(lib.vp_default_config(self._kind, C.byref(cfg)))
         cfg.norm = _lib.VP_NORM_PEAK if self.norm == "peak" else _lib.VP_NORM_STD
         cfg.max_batch = int(self._max_batch)
-        flags = self._plan_flags
-        if os.environ.get("VOLPICK_PLAN_FLAGS"):  # A/B timing of plan variants through bench.py (debug)
-            flags = tuple(int(v) for v in os.environ["VOLPICK_PLAN_FLAGS"].split(","))
+        flags = list(self._plan_flags)
+        if os.environ.get("VOLPICK_PLAN_FLAGS"):  # A/B timing of plan variants through bench.py (debug): the entries the model
+            env = [int(v) for v in os.environ["VOLPICK_PLAN_FLAGS"].split(",")]  # itself left at 0 come from the environment
+            flags += [0] * (len(env) - len(flags))
+            flags = [f if f != 0 or i >= len(env) else env[i] for i, f in enumerate(flags)]
         for i, v in enumerate(flags):
             cfg.plan_flags[i] = int(v)
         return cfg
