@@ -479,6 +479,10 @@ def bench_model(model_name, env, cpu_budget_s):
                      "peak, sum_i issued_i / (sum_i issued_i / peak_i) with fp32 MFMA 157.3, bf16 MFMA 2500 and packed fp32 "
                      "FMA 157.3 TFLOP/s (MI355X_MICROARCH.md) -- the pipes share the SIMD's issue, so their times add; "
                      "frac = pipe time / kernel duration <= 1 by construction",
+            "frac_note": ("the fraction moves with the instruction mix as well as with the duration: moving a layer from the fp32 "
+                          "to the bf16 matrix cores cuts its pipe time to 6/16, so a kernel can get faster while frac falls "
+                          "(pn_window_kernel, round 2 -> 3: pipe time 56 -> 46 us per 256 windows with up1.same / up2.same on the "
+                          "bf16 pipes, duration 102 -> 94-98 us at the same clock); read it beside kernel_ms"),
             "issued_flop_per_window": dom["issued_flop_per_window"],
             "pipe_time_ms": dom_pipe_s * 1e3,
             "kernel_ms": dom_ms.value,
