@@ -174,6 +174,39 @@ def _scaled_state(model_name, sd, s):
     return sd
 
 
+def _scaled_up_path(sd, s):
+    """PhaseNet: both inputs of up1.same and of up2.same (the skip rows and the transposed conv's output: the layers that run
+    in two K halves over one refilled piece image) at s times their size; every consumer of those tensors divides by s."""
+    sd = {k: (v.clone() if torch.is_tensor(v) else np.array(v, copy=True)) for k, v in sd.items()}
+    for level, up in ((2, 1), (1, 2)):  # up1.same reads skip 2, up2.same skip 1
+        for k in ("weight", "bias"):
+            sd[f"down_branch.{level}.1.{k}"] = sd[f"down_branch.{level}.1.{k}"] * s  # BatchNorm of down{level}.same (the skip)
+            sd[f"up_branch.{up}.1.{k}"] = sd[f"up_branch.{up}.1.{k}"] * s            # BatchNorm of up{up}.convT
+        sd[f"down_branch.{level}.2.weight"] = sd[f"down_branch.{level}.2.weight"] / s  # down{level}.down reads the skip too
+        sd[f"up_branch.{up}.2.weight"] = sd[f"up_branch.{up}.2.weight"] / s            # up{up}.same
+    return sd
+
+
+@pytest.mark.parametrize("scale", [1e15, 1e-15])
+def test_activations_far_from_unity_in_the_up_path_piece_layers(scale):
+    oracle = load_pretrained("phasenet", "volpick")
+    m = va.PhaseNet.from_pretrained("volpick")
+    big = copy.deepcopy(oracle)
+    big.load_state_dict(_scaled_up_path(big.state_dict(), scale), strict=True)
+    m.load_state_dict({k: (v.numpy() if torch.is_tensor(v) else v) for k, v in _scaled_up_path(m.state_dict(), scale).items()})
+    m.cuda()
+    try:
+        x = synthetic_windows(4, m.in_samples, seed=4600)
+        xn = OP.batch_pre(oracle, torch.from_numpy(x))
+        with torch.no_grad():
+            want = _as_array(big(xn))
+            plain = _as_array(oracle(xn))
+        assert np.abs(want - plain).max() < 1e-5, "the scaling must be neutral for the oracle itself"
+        _check(_as_array(m(xn.cuda())), want, f"phasenet up path x {scale:g}")
+    finally:
+        m._release()
+
+
 @pytest.mark.parametrize("scale", [1e20, 1e-20, 1e30, 1e-30])
 def test_activations_far_from_unity_in_piece_layers(default_pair, scale):
     name, model, oracle = default_pair
