@@ -318,7 +318,7 @@ __device__ __forceinline__ void b3_load_a(const uint4* __restrict__ af3, const i
 // about 40 VALU instructions) and the fragment reads themselves, not their bank conflicts.
 template <int C, int NC>
 struct B3Chunk {
-  static_assert(NC % 16 == 0, "chunk plane stride = 0 mod 256 bytes");
+  static_assert(NC % 2 == 0, "16-byte columns; the bank property above holds for NC % 16 == 0 (PhaseNet's up1.same output: 194)");
   static constexpr int CHS = NC * 8, PS = (C / 8) * CHS;  // bf16 per chunk plane / per piece
 };
 // four consecutive channels 4 quad .. 4 quad + 3 of column col, split into the three pieces (pairs at a time: v_cvt_pk_bf16_f32)

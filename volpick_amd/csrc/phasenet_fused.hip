@@ -928,6 +928,7 @@ struct WindowArgs {
   const uint4* af3[6];   // down3.same .. up0.same (+ up1.same, U1B) as three-piece bf16 operands (conv_b3.h), B3 instantiation
   int af3_lines[6];      // their sizes in 128-byte lines (L2 warm-up)
   const uint4* af3_u2[2];  // U2B: up2.same's operand per input half (skip 1 | up2.convT), 16-channel K-steps (B3Steps<16, 7>)
+  const uint4* af3_uT[2];  // U3B: up1.convT / up2.convT, rows (phase, channel)
   const float* x;   // [B][3][ls] normalised input
   int ls_x;
   long ws_x;
@@ -991,9 +992,26 @@ constexpr int B3_U2_NC = 784, B3_U2_OFF = A_Q;  // columns (sample t at column t
 static_assert(B3_U2_OFF % 4 == 0 && B3_U2_OFF * 4 + 3 * B3Chunk<16, B3_U2_NC>::PS * 2 <= CORE_LDS_FLOATS * 4 &&
                   B3_U2_NC >= 48 * 16 + 8 && B3_U2_OFF >= A_SKIP2 + 32 * S2_,
               "up2.same piece image: behind up1.same's relocated output, inside the arena");
-template <bool PIPE, bool B3, bool U1B = false, bool U2B = false>
+// U3B (with U2B): the two transposed convs in front of them on the bf16 matrix cores as well.  up0.same then writes ITS output
+// as pieces (21.6 KB in the old skip-3 slot; up0.convT's image moves 1.1 KB up to make room), up1.convT reads them and
+// writes up1.same's first image as before; up1.same writes its output as a chunk-plane piece image into the skip-2 slot
+// (37 KB: it reaches 6.4 KB into the slot behind), up2.convT reads that and writes up2.same's first image, which therefore
+// starts 6.4 KB later and has 768 columns instead of 784 (the 48th n-tile of up2.same, whose outputs nobody keeps, then reads a
+// few columns of the neighbouring plane).
+constexpr int B3_U0S_NC = 50, B3_U0S_PS = B3_U0S_NC * 72;                    // up0.same's output: sample t at column t + 1
+constexpr int B3_U0T_SHIFT = ((A_Q * 2 + 3 * B3_U0S_PS - A_R * 2 + 7) / 8) * 8;  // bf16 elements: up0.convT's image starts this much later
+constexpr int B3_U1S_NC = 194;                                                // up1.same's output (chunk planes): sample t at column t + 1
+constexpr int B3_U2_NC3 = 768, B3_U2_OFF3 = (A_SKIP2 * 4 + 3 * B3Chunk<32, B3_U1S_NC>::PS * 2 + 15) / 16 * 4;  // floats
+static_assert(B3_U0T_SHIFT >= 0 && A_R * 2 + B3_U0T_SHIFT + 3 * B3_U0T_PS <= B3_SK3_OFF && (A_R * 2 + B3_U0T_SHIFT) % 8 == 0,
+              "up0.convT's image between up0.same's output pieces and the skip-3 image");
+static_assert(B3_U2_OFF3 * 4 + 3 * B3Chunk<16, B3_U2_NC3>::PS * 2 <= CORE_LDS_FLOATS * 4 && B3_U2_NC3 >= 47 * 16 + 8 + 3 &&
+                  B3_U1S_NC >= 192 + 2,
+              "up1.same's output pieces and up2.same's image behind them fit the arena");
+template <bool PIPE, bool B3, bool U1B = false, bool U2B = false, bool U3B = false>
 __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   static_assert(!U2B || U1B, "U2B relocates up1.same's output: needs the U1B form");
+  static_assert(!U3B || U2B, "U3B builds on the U2B layout");
+  constexpr int U2_NC = U3B ? B3_U2_NC3 : B3_U2_NC, U2_OFF = U3B ? B3_U2_OFF3 : B3_U2_OFF;
   // up phase: up2.same | level-0 rows 0-3 | level-0 rows 4-7
   constexpr int XU_U = U2B ? A_SKIP1 : WU_U, XU_G0 = U2B ? A_SKIP2 : WU_G0, XU_G1 = U2B ? A_SKIP2 + 4 * W0_S : WU_G1;
   static_assert(XU_G1 + 4 * W0_S <= CORE_LDS_FLOATS && XU_U + 16 * S1_ <= (U2B ? XU_G0 : A_U2T), "up-phase regions");
@@ -1275,7 +1293,7 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   if constexpr (B3) {
     bf16_t* l16 = reinterpret_cast<bf16_t*>(lds);
     const B3Image<32> iD2{l16 + A_R * 2, B3_D2_PS, 3};
-    const B3Image<64> iSK3{l16 + B3_SK3_OFF, B3_SK3_PS, 3}, iD3{l16 + A_R * 2, B3_D3_PS, 3}, iU0T{l16 + A_R * 2, B3_U0T_PS, 3};
+    const B3Image<64> iSK3{l16 + B3_SK3_OFF, B3_SK3_PS, 3}, iD3{l16 + A_R * 2, B3_D3_PS, 3}, iU0T{l16 + A_R * 2 + (U3B ? B3_U0T_SHIFT : 0), B3_U0T_PS, 3};
     const B3Image<128> iBOT{l16 + A_Q * 2, B3_BOT_PS, 1};
 #define B3_END          \
   __syncthreads();      \
@@ -1311,7 +1329,12 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
       conv_b3<C_u0T, true, 128, 128>(iBOT, iBOT, a.af3[3], a.c.bs[7], T4 + 1, st, wave, NWV, lane);
       B3_END
     }
-    {  // up0.same: cat(skip 3, up0.convT) -> fp32 image for up1.convT
+    if constexpr (U3B) {  // up0.same: cat(skip 3, up0.convT) -> three-piece image for up1.convT
+      B3Store<64> st{l16 + A_Q * 2, B3_U0S_PS, 1, T3, B3_U0S_NC};
+      st.zero_rest(1, 1 + 48, tid, NTH);
+      conv_b3<C_u0same, false, 64, 64>(iSK3, iU0T, a.af3[4], a.c.bs[8], T3, st, wave, NWV, lane);
+      B3_END
+    } else {  // up0.same: cat(skip 3, up0.convT) -> fp32 image for up1.convT
       F32QuadStore<S3_, IB> st{lds + X_U0S, T3};
       zero_halo<64, S3_, T3, IB>(lds + X_U0S, tid, NTH);
       conv_b3<C_u0same, false, 64, 64>(iSK3, iU0T, a.af3[4], a.c.bs[8], T3, st, wave, NWV, lane);
@@ -1328,7 +1351,15 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   }
   if constexpr (B3 && U1B) {
     const B3Image<32> iP{reinterpret_cast<bf16_t*>(lds) + A_U2T * 2, B3_U1_PS, 3};
-    {  // up1.convT (fp32 MFMA, 8 m-tiles x 1 block) -> three-piece image
+    if constexpr (U3B) {  // up1.convT on the bf16 matrix cores: rows (phase, channel), samples 4 c + phase - 1, columns c in [0, 48)
+      const B3Image<64> iU0S{reinterpret_cast<bf16_t*>(lds) + A_Q * 2, B3_U0S_PS, 1};
+      B3Store<32> st{iP.img, iP.ps, iP.c0, T2, B3_U1_NC};
+      st.zero_rest(2, 2 + 192, tid, NTH);
+      conv_b3<C_u1T, true, 64, 64>(iU0S, iU0S, a.af3_uT[0], a.c.bs[9], T3 + 1, st, wave, NWV, lane);
+      __syncthreads();
+      WIN_STAMP(stamp)
+      ++stamp;
+    } else {  // up1.convT (fp32 MFMA, 8 m-tiles x 1 block) -> three-piece image
       const B3PhaseStore<32> st{iP.img, iP.ps, iP.c0, T2};
       (B3Store<32>{iP.img, iP.ps, iP.c0, T2, B3_U1_NC}).zero_rest(3, 3 + T2, tid, NTH);
       if (wave < C_u1T::MT) {
@@ -1343,13 +1374,17 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
     }
     {  // up1.same: K half of up1.convT's channels, then the half of skip 2
       const F32QuadStore<S2_, IB> st{lds + X_U1S, T2};  // (U2B: skip 2's own slot -- its halo columns are zero already, and the
-      zero_halo<32, S2_, T2, IB>(lds + X_U1S, tid, NTH);  //  stores come after the rows have been turned into pieces)
+      if constexpr (!U3B) zero_halo<32, S2_, T2, IB>(lds + X_U1S, tid, NTH);  //  stores come after the rows have been turned into pieces)
+      [[maybe_unused]] bf16_t* const iU1S = reinterpret_cast<bf16_t*>(lds) + A_SKIP2 * 2;  // U3B: the output as chunk-plane pieces
       const int mt = wave & 1, colb = (wave >> 1) * 48;
       f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
       if (wave < 8) conv_b3_part<C_u1same, 1, 3>(iP, a.af3[5], mt, colb, lane, acc);
       __syncthreads();  // every wave is through with up1.convT's pieces
       b3_from_f32<S2_, IB>(lds + A_SKIP2, iP, -3, B3_U1_NC - 3, tid, NTH);
       __syncthreads();
+      if constexpr (U3B) {
+        if (wave >= 8) b3c_zero_rest<32, B3_U1S_NC>(iU1S, 1, 193, tid - 512, NTH - 512);
+      }
       if (wave < 8) {
         conv_b3_part<C_u1same, 0, 3>(iP, a.af3[5], mt, colb, lane, acc);
         const int co0 = mt * 16 + 4 * (lane >> 4);
@@ -1361,7 +1396,13 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
           float v[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = C_u1same::RELU ? fmaxf(acc[j][r] + biasv[r], 0.f) : acc[j][r] + biasv[r];
-          st.quad(co0, colb + j * 16 + (lane & 15), v);
+          const int t = colb + j * 16 + (lane & 15);
+          if constexpr (U3B) {
+            if (t >= T2) v[0] = v[1] = v[2] = v[3] = 0.f;
+            b3c_store4<32, B3_U1S_NC>(iU1S, t + 1, co0 >> 2, v);
+          } else {
+            st.quad(co0, t, v);
+          }
         }
       }
       __syncthreads();
@@ -1372,10 +1413,29 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   CORE_LAYER_AREG(9, C_u1T, X_U0S, S3_, X_U1T, S2_, TB, RangeStoreV, 32, T3 + 1, T2, wave, 0, 1)        // 8 m-tiles x 1 block (pn_core_kernel)
   CORE_LAYER(10, C_u1same, A_SKIP2, S2_, X_U1T, S2_, TB, A_U1S, S2_, IB, RangeStoreS, 32, T2, T2)
   }
-  [[maybe_unused]] bf16_t* const P2 = reinterpret_cast<bf16_t*>(lds) + B3_U2_OFF * 2;
-  if constexpr (U2B) {  // up2.convT (fp32 MFMA, 4 m-tiles x 4 blocks) -> chunk-plane piece image
-    const B3PhaseStoreC<16, B3_U2_NC> st{P2, 3, T1};
-    b3c_zero_rest<16, B3_U2_NC>(P2, 3, 3 + T1, tid, NTH);
+  [[maybe_unused]] bf16_t* const P2 = reinterpret_cast<bf16_t*>(lds) + U2_OFF * 2;
+  if constexpr (U3B) {  // up2.convT on the bf16 matrix cores: wave = (phase m-tile, block of three n-tiles), samples 4 c + phase - 1
+    const bf16_t* iU1S = reinterpret_cast<const bf16_t*>(lds) + A_SKIP2 * 2;
+    b3c_zero_rest<16, U2_NC>(P2, 3, 3 + T1, tid, NTH);
+    const int mt = wave & 3, colb = (wave >> 2) * 48, g = lane >> 4, n = lane & 15;
+    uint4 aT[B3Steps<32, 2>::STEPS * 3];
+    b3_load_a<32, 2>(a.af3_uT[1], mt, lane, aT);
+    float biasv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) biasv[r] = a.c.bs[11][4 * g + r];
+    b3c_mac_tiles<32, B3_U1S_NC, 2, 3>(b3c_lane_ptr<32, B3_U1S_NC, 2>(iU1S, colb, lane), aT, [&](const int j, const f32x4 acc) {
+      const int t = 4 * (colb + j * 16 + n) + mt - 1;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = C_u2T::RELU ? fmaxf(acc[r] + biasv[r], 0.f) : acc[r] + biasv[r];
+      if ((unsigned)t < (unsigned)T1) b3c_store4<16, U2_NC>(P2, t + 3, g, v);
+    });
+    __syncthreads();
+    WIN_STAMP(stamp)
+    ++stamp;
+  } else if constexpr (U2B) {  // up2.convT (fp32 MFMA, 4 m-tiles x 4 blocks) -> chunk-plane piece image
+    const B3PhaseStoreC<16, U2_NC> st{P2, 3, T1};
+    b3c_zero_rest<16, U2_NC>(P2, 3, 3 + T1, tid, NTH);
     {
       float ar[C_u2T::CB * C_u2T::TAPS], br[4];
       load_areg4<C_u2T>(a.af4[11], wave & 3, lane, ar);
@@ -1409,7 +1469,7 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
       WIN_WARM_SCALAR(a.w_up, 16 * 7 * 8)
       if constexpr (U2B) {
         __syncthreads();  // waves 0-7 are through with up2.convT's pieces
-        b3c_from_f32<16, B3_U2_NC, S1_, IB>(lds + A_SKIP1, P2, 3, tid, NTH);
+        b3c_from_f32<16, U2_NC, S1_, IB>(lds + A_SKIP1, P2, 3, tid, NTH);
         __syncthreads();  // skip 1 rests in the image: its fp32 rows give way to up2.same's output
         zero_halo<16, S1_, T1, IB>(lds + XU_U, tid - 512, NTH - 512);
       }
@@ -1422,18 +1482,18 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
       }
     } else if constexpr (U2B) {
       // wave w: n-tiles 6 w .. 6 w + 5 (48 for the 47 that hold samples), K = 2 halves x 4 steps of two taps x 16 channels
-      const bf16_t* bp = b3c_lane_ptr<16, B3_U2_NC, 7>(P2, wave * 96, lane);
+      const bf16_t* bp = b3c_lane_ptr<16, U2_NC, 7>(P2, wave * 96, lane);
       f32x4 acc[6];
 #pragma unroll
       for (int j = 0; j < 6; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       uint4 aw[B3Steps<16, 7>::STEPS * 3];
       b3_load_a<16, 7>(a.af3_u2[1], 0, lane, aw);
-      b3c_mac_tiles_acc<16, B3_U2_NC, 7, 6>(bp, aw, acc);
+      b3c_mac_tiles_acc<16, U2_NC, 7, 6>(bp, aw, acc);
       b3_load_a<16, 7>(a.af3_u2[0], 0, lane, aw);  // on its way under the refill
       __syncthreads();
-      b3c_from_f32<16, B3_U2_NC, S1_, IB>(lds + A_SKIP1, P2, 3, tid, NTH);
+      b3c_from_f32<16, U2_NC, S1_, IB>(lds + A_SKIP1, P2, 3, tid, NTH);
       __syncthreads();
-      b3c_mac_tiles_acc<16, B3_U2_NC, 7, 6>(bp, aw, acc);
+      b3c_mac_tiles_acc<16, U2_NC, 7, 6>(bp, aw, acc);
       {
         const int co0 = 4 * (lane >> 4);
         float biasv[4];
@@ -1564,6 +1624,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
   const bool b3 = whole && net.cfg.plan_flags[5] != 3;  // plan_flags[5] = 3: the one-launch kernel with all core layers on the fp32 MFMA
   const bool u1b = b3 && net.cfg.plan_flags[5] != 4;    // plan_flags[5] = 4: up1.same and up2.same stay on the fp32 MFMA (the form of round 2)
   const bool u2b = u1b && net.cfg.plan_flags[5] != 5;   // plan_flags[5] = 5: only up2.same does
+  const bool u3b = u2b && net.cfg.plan_flags[5] != 6;   // plan_flags[5] = 6: up1.convT / up2.convT stay on the fp32 MFMA
   HostBlob *vw[5] = {}, *vb[5] = {};
   if (valu) {
     const float eps = net.cfg.bn_eps;
@@ -1765,6 +1826,8 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         if (b3 && i >= 7 && i <= 11) bf16 += 6.0 * padded(i);
         else if (u1b && i == 13) bf16 += 6.0 * 2.0 * 32 * 192 * 64 * 7;  // up1.same: 2 m-tiles x 12 n-tiles x 14 K-steps
         else if (u2b && i == 15) bf16 += 6.0 * 2.0 * 16 * 768 * 32 * 8;  // up2.same: 48 n-tiles x 2 halves x 4 K-steps
+        else if (u3b && i == 12) bf16 += 8.0 * 3 * 4 * 6 * 16384.0;       // up1.convT: 8 m-tiles x 3 n-tiles x 4 K-steps
+        else if (u3b && i == 14) bf16 += 4.0 * 12 * 2 * 6 * 16384.0;      // up2.convT: 4 m-tiles x 12 n-tiles x 2 K-steps
         else f32 += padded(i);
       }
       st.set_issued(f32, bf16, flops(0, 1) + flops(17, 17));
@@ -1782,6 +1845,11 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     if (b3)
       for (int i = 0; i < 5; ++i) p3[i] = net.add_blob(b3_operand(*net.convs[3 + 4 + i], i == 3));
     if (u1b) p3[5] = net.add_blob(b3_operand(*net.convs[3 + 10], false));
+    HostBlob* p3uT[2] = {};
+    if (u3b) {
+      p3uT[0] = net.add_blob(b3_operand(*net.convs[3 + 9], true));
+      p3uT[1] = net.add_blob(b3_operand(*net.convs[3 + 11], true));
+    }
     HostBlob* p3u2[2] = {};
     if (u2b) {  // up2.same per input half as 16-channel K-steps (B3Steps<16, 7>: two taps per step, tap 7 = zero weights):
                 // [step][piece][lane][8], lane = 16 g + row, tap = 2 step + g / 2, channels 16 half + 8 (g % 2) ..
@@ -1823,6 +1891,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     st.run = [=](Net& n, int B, hipStream_t s) -> int {
       WindowArgs a{};
       for (int i = 0; i < 13; ++i) a.af4[i] = q4[i] ? q4[i]->d : nullptr;
+      for (int i = 0; i < 2; ++i) a.af3_uT[i] = p3uT[i] ? reinterpret_cast<const uint4*>(p3uT[i]->d) : nullptr;
       for (int i = 0; i < 2; ++i) a.af3_u2[i] = p3u2[i] ? reinterpret_cast<const uint4*>(p3u2[i]->d) : nullptr;
       for (int i = 0; i < 6; ++i) {
         a.af3[i] = p3[i] ? reinterpret_cast<const uint4*>(p3[i]->d) : nullptr;
@@ -1859,7 +1928,9 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         a.pre = *n.pre;
         a.has_pre = 1;
       }
-      if (u2b) {
+      if (u3b) {
+        hipLaunchKernelGGL((pn_window_kernel<false, true, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
+      } else if (u2b) {
         hipLaunchKernelGGL((pn_window_kernel<false, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
       } else if (u1b) {
         hipLaunchKernelGGL((pn_window_kernel<false, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
@@ -1881,6 +1952,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
   }
   net.steps = std::move(steps);
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_core_kernel<true>), CORE_LDS_FLOATS * sizeof(float)});
