@@ -68,9 +68,9 @@ typedef struct {
                                       all MFMA (bit-identical to the layer plan), 2 = three launches, level-0
                                       stride-1 convs on the VALU, 3 = one launch, every core layer on the fp32 MFMA,
                                       4 = one launch with up1.same and up2.same on the fp32 MFMA, 5 = with up2.same only,
-                                      6 = with up1.convT and up2.convT on the fp32 MFMA (default: all four on the bf16
-                                      matrix cores too, the two convs in two K halves over one piece image that is
-                                      refilled in between);
+                                      6 = with up1.convT and up2.convT on the fp32 MFMA, 7 = with down1.same and down2.same
+                                      on the fp32 MFMA (default: all six on the bf16 matrix cores too, up1.same / up2.same
+                                      in two K halves over one piece image that is refilled in between);
                                  [6]: PhaseNet: 1 = the one-launch plan reads the input tensor filled by gather_normalize
                                       instead of cutting and normalising its windows itself; EQTransformer: 2 = the fused
                                       encoder front cuts and normalises its windows itself (A/B: slower end to end);

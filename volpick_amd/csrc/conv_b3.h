@@ -439,6 +439,62 @@ struct B3PhaseStoreC {
     }
   }
 };
+// lds_epilogue hooks (conv_lds.h) of fp32-MFMA layers whose output feeds a bf16 layer with 8 or 16 input channels: chunk-plane
+// image, sample t at column t + c0; every computed column inside the image is written (zeros outside [0, L)).
+// P = 1: a lane's four rows are four consecutive channels.
+template <int C, int NC>
+struct B3BlockStoreC {
+  static constexpr bool custom_block_epilogue = true;
+  bf16_t* img;
+  int c0, L;
+  template <class LY>
+  __device__ __forceinline__ void block_epilogue(const f32x4 (&acc)[LY::NB], const float (&biasv)[4], const int mt, const int colb,
+                                                 const int g, const int n) const {
+    static_assert(LY::P == 1 && LY::OUT_OFF == 0, "plain conv");
+#pragma unroll
+    for (int j = 0; j < LY::NB; ++j) {
+      const int t = colb + j * 16 + n;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[j][r] + biasv[r];
+        if (LY::RELU) v[r] = fmaxf(v[r], 0.f);
+        if (t >= L) v[r] = 0.f;
+      }
+      if (t + c0 < NC) b3c_store4<C, NC>(img, t + c0, (mt * 16 + 4 * g) >> 2, v);
+    }
+  }
+};
+// P = 2, rows (channel, phase): a lane holds (channel 2 g, phases 0 1), (channel 2 g + 1, phases 0 1); two v_permlane16_swap
+// (odd rows of the first operand <-> even rows of the second) leave rows 0 / 1 with channels 0-3 at phase 0 / 1 and rows
+// 2 / 3 with channels 4-7.
+template <int C, int NC>
+struct B3PairStoreC {
+  static constexpr bool custom_block_epilogue = true;
+  bf16_t* img;
+  int c0, L;
+  template <class LY>
+  __device__ __forceinline__ void block_epilogue(const f32x4 (&acc)[LY::NB], const float (&biasv)[4], const int mt, const int colb,
+                                                 const int g, const int n) const {
+    static_assert(LY::P == 2 && LY::M == 16, "two phases x eight channels = one m-tile");
+#pragma unroll
+    for (int j = 0; j < LY::NB; ++j) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[j][r] + biasv[r];
+        if (LY::RELU) v[r] = fmaxf(v[r], 0.f);
+      }
+      const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
+      const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[2]), __float_as_uint(v[3]), false, false);
+      float w[4] = {__uint_as_float(a[0]), __uint_as_float(b[0]), __uint_as_float(a[1]), __uint_as_float(b[1])};
+      const int t = 2 * (colb + j * 16 + n) + (g & 1) + LY::OUT_OFF;
+      if ((unsigned)t >= (unsigned)L) w[0] = w[1] = w[2] = w[3] = 0.f;
+      if ((unsigned)(t + c0) < (unsigned)NC) b3c_store4<C, NC>(img, t + c0, g >> 1, w);
+    }
+  }
+};
+
 // zero the columns of a chunk-plane image outside [col_lo, col_hi)
 template <int C, int NC>
 __device__ __forceinline__ void b3c_zero_rest(bf16_t* img, const int col_lo, const int col_hi, const int tid, const int nth) {

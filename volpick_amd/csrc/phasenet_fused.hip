@@ -929,6 +929,7 @@ struct WindowArgs {
   int af3_lines[6];      // their sizes in 128-byte lines (L2 warm-up)
   const uint4* af3_u2[2];  // U2B: up2.same's operand per input half (skip 1 | up2.convT), 16-channel K-steps (B3Steps<16, 7>)
   const uint4* af3_uT[2];  // U3B: up1.convT / up2.convT, rows (phase, channel)
+  const uint4* af3_d12[2]; // D12B: down1.same (B3Steps<8, 7>), down2.same (B3Steps<16, 7>)
   const float* x;   // [B][3][ls] normalised input
   int ls_x;
   long ws_x;
@@ -1007,8 +1008,16 @@ static_assert(B3_U0T_SHIFT >= 0 && A_R * 2 + B3_U0T_SHIFT + 3 * B3_U0T_PS <= B3_
 static_assert(B3_U2_OFF3 * 4 + 3 * B3Chunk<16, B3_U2_NC3>::PS * 2 <= CORE_LDS_FLOATS * 4 && B3_U2_NC3 >= 47 * 16 + 8 + 3 &&
                   B3_U1S_NC >= 192 + 2,
               "up1.same's output pieces and up2.same's image behind them fit the arena");
-template <bool PIPE, bool B3, bool U1B = false, bool U2B = false, bool U3B = false>
+// D12B: down1.same and down2.same on the bf16 matrix cores (8 / 16 input channels: K-steps of four / two taps).  Their inputs
+// arrive as chunk-plane piece images written by the fp32-MFMA strided convs in front of them (down0.down: two phases per
+// m-tile, two v_permlane16_swap bring four channels of one sample to a lane; down1.down: plain), their outputs are the fp32
+// skip rows as before.
+constexpr int B3_D0_NC = 760, B3_D1_NC = 200;  // sample t at column t + 3
+static_assert(A_D0 * 4 + 3 * B3Chunk<8, B3_D0_NC>::PS * 2 <= CORE_LDS_FLOATS * 4 && B3_D0_NC >= 47 * 16 + 7 && B3_D1_NC >= 192 + 7,
+              "down0.down / down1.down as piece images");
+template <bool PIPE, bool B3, bool U1B = false, bool U2B = false, bool U3B = false, bool D12B = false>
 __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
+  static_assert(!D12B || B3, "D12B is a form of the B3 kernel");
   static_assert(!U2B || U1B, "U2B relocates up1.same's output: needs the U1B form");
   static_assert(!U3B || U2B, "U3B builds on the U2B layout");
   constexpr int U2_NC = U3B ? B3_U2_NC3 : B3_U2_NC, U2_OFF = U3B ? B3_U2_OFF3 : B3_U2_OFF;
@@ -1237,7 +1246,11 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
           }
         }
       }
-      zero_halo<8, S1_, T1>(lds + A_D0, tid, NTH);  // the x rows are dead: down0.down takes their place
+      if constexpr (D12B) {  // the x rows are dead: down0.down takes their place (D12B: as a piece image)
+        b3c_zero_rest<8, B3_D0_NC>(reinterpret_cast<bf16_t*>(lds) + A_D0 * 2, 3, B3_D0_NC, tid, NTH);
+      } else {
+        zero_halo<8, S1_, T1>(lds + A_D0, tid, NTH);
+      }
       lds_barrier();
       if (own) {  // the float4 holding sample T0 - 1 also rewrites up to three zeros of the row's right margin
         float* d = a.skip0 + (long)win * a.ws_s + HALO + t0;
@@ -1249,8 +1262,13 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
       }
       WIN_STAMP(21)
       // down0.down: Conv1d(8, 8, 7, stride 4, pad 3) + BN + ReLU on the MFMA, straight into the core's input image
-      RangeStore<S1_, IB> st{lds + A_D0, T1};
-      conv_lds_areg<W_down, W0_S, 4, W0_S, 4>(H, H, aD, bD, 0, (T1 + 1) / 2, st, wave, NWV, lane);
+      if constexpr (D12B) {
+        const B3PairStoreC<8, B3_D0_NC> st{reinterpret_cast<bf16_t*>(lds) + A_D0 * 2, 3, T1};
+        conv_lds_areg<W_down, W0_S, 4, W0_S, 4>(H, H, aD, bD, 0, (T1 + 1) / 2, st, wave, NWV, lane);
+      } else {
+        RangeStore<S1_, IB> st{lds + A_D0, T1};
+        conv_lds_areg<W_down, W0_S, 4, W0_S, 4>(H, H, aD, bD, 0, (T1 + 1) / 2, st, wave, NWV, lane);
+      }
     }
     lds_barrier();  // not __syncthreads(): the skip rows drain to memory under the first core layers
     WIN_STAMP(22)
@@ -1286,9 +1304,67 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
     WIN_STAMP(stamp)                                                                                               \
     ++stamp;                                                                                                       \
   }
+  if constexpr (D12B) {
+    bf16_t* const iD0 = reinterpret_cast<bf16_t*>(lds) + A_D0 * 2;  // written by down0.down
+    bf16_t* const iD1 = reinterpret_cast<bf16_t*>(lds) + A_D1 * 2;
+    const int g = lane >> 4, n = lane & 15;
+    {  // down1.same: one m-tile, 47 n-tiles: three per wave
+      zero_halo<16, S1_, T1, IB>(lds + A_SKIP1, tid, NTH);
+      uint4 aw[B3Steps<8, 7>::STEPS * 3];
+      b3_load_a<8, 7>(a.af3_d12[0], 0, lane, aw);
+      float biasv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) biasv[r] = a.c.bs[0][4 * g + r];
+      const int colb = wave * 48;
+      b3c_mac_tiles<8, B3_D0_NC, 7, 3>(b3c_lane_ptr<8, B3_D0_NC, 7>(iD0, colb, lane), aw, [&](const int j, const f32x4 acc) {
+        const int t = colb + j * 16 + n;
+        if (t < T1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) lds[A_SKIP1 + (4 * g + r) * S1_ + IB + t] = fmaxf(acc[r] + biasv[r], 0.f);
+        }
+      });
+      __syncthreads();
+      WIN_STAMP(stamp)
+      ++stamp;
+    }
+    {  // down1.down (fp32 MFMA, strided) -> piece image
+      const B3BlockStoreC<16, B3_D1_NC> st{iD1, 3, T2};
+      b3c_zero_rest<16, B3_D1_NC>(iD1, 3, 3 + 192, tid, NTH);
+      if constexpr (Q4_LAYER(C_d1down)) {
+        conv_lds_q4<C_d1down, S1_, IB, S1_, IB>(lds + A_SKIP1, lds + A_SKIP1, a.af4[1], a.c.bs[1], T2, st, wave, NWV, lane);
+      } else {
+        conv_lds<C_d1down, S1_, IB, S1_, IB, PIPE, (C_d1down::NB < BDB_MAX_NB), ADEEP_LAYER(C_d1down)>(lds + A_SKIP1, lds + A_SKIP1, a.c.af[1], a.c.bs[1], T2, st, wave, NWV, lane);
+      }
+      __syncthreads();
+      WIN_STAMP(stamp)
+      ++stamp;
+    }
+    {  // down2.same: wave = (m-tile, block of three n-tiles), eight waves
+      zero_halo<32, S2_, T2, IB>(lds + A_SKIP2, tid, NTH);
+      if (wave < 8) {
+        const int mt = wave & 1, colb = (wave >> 1) * 48;
+        uint4 aw[B3Steps<16, 7>::STEPS * 3];
+        b3_load_a<16, 7>(a.af3_d12[1], mt, lane, aw);
+        float biasv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) biasv[r] = a.c.bs[2][mt * 16 + 4 * g + r];
+        b3c_mac_tiles<16, B3_D1_NC, 7, 3>(b3c_lane_ptr<16, B3_D1_NC, 7>(iD1, colb, lane), aw, [&](const int j, const f32x4 acc) {
+          const int t = colb + j * 16 + n;
+          if (t < T2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[A_SKIP2 + (mt * 16 + 4 * g + r) * S2_ + IB + t] = fmaxf(acc[r] + biasv[r], 0.f);
+          }
+        });
+      }
+      __syncthreads();
+      WIN_STAMP(stamp)
+      ++stamp;
+    }
+  } else {
   CORE_LAYER(0, C_d1same, A_D0, S1_, A_D0, S1_, IB, A_SKIP1, S1_, IB, RangeStoreS, 16, T1, T1)
   CORE_LAYER(1, C_d1down, A_SKIP1, S1_, A_SKIP1, S1_, IB, A_D1, S2_, IB, RangeStoreS, 16, T2, T2)
   CORE_LAYER(2, C_d2same, A_D1, S2_, A_D1, S2_, IB, A_SKIP2, S2_, IB, RangeStoreS, 32, T2, T2)
+  }
   constexpr int X_U0S = B3 ? A_Q : A_U0S, X_U1T = A_U1T;  // B3: up0.same lands in the old skip-3 slot (up1.same's output slot later on)
   if constexpr (B3) {
     bf16_t* l16 = reinterpret_cast<bf16_t*>(lds);
@@ -1625,6 +1701,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
   const bool u1b = b3 && net.cfg.plan_flags[5] != 4;    // plan_flags[5] = 4: up1.same and up2.same stay on the fp32 MFMA (the form of round 2)
   const bool u2b = u1b && net.cfg.plan_flags[5] != 5;   // plan_flags[5] = 5: only up2.same does
   const bool u3b = u2b && net.cfg.plan_flags[5] != 6;   // plan_flags[5] = 6: up1.convT / up2.convT stay on the fp32 MFMA
+  const bool d12b = u3b && net.cfg.plan_flags[5] != 7;  // plan_flags[5] = 7: down1.same / down2.same stay on the fp32 MFMA
   HostBlob *vw[5] = {}, *vb[5] = {};
   if (valu) {
     const float eps = net.cfg.bn_eps;
@@ -1826,6 +1903,8 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         if (b3 && i >= 7 && i <= 11) bf16 += 6.0 * padded(i);
         else if (u1b && i == 13) bf16 += 6.0 * 2.0 * 32 * 192 * 64 * 7;  // up1.same: 2 m-tiles x 12 n-tiles x 14 K-steps
         else if (u2b && i == 15) bf16 += 6.0 * 2.0 * 16 * 768 * 32 * 8;  // up2.same: 48 n-tiles x 2 halves x 4 K-steps
+        else if (d12b && i == 3) bf16 += 48.0 * 2 * 6 * 16384.0;          // down1.same: 48 n-tiles x 2 K-steps
+        else if (d12b && i == 5) bf16 += 2.0 * 12 * 4 * 6 * 16384.0;      // down2.same: 2 m-tiles x 12 n-tiles x 4 K-steps
         else if (u3b && i == 12) bf16 += 8.0 * 3 * 4 * 6 * 16384.0;       // up1.convT: 8 m-tiles x 3 n-tiles x 4 K-steps
         else if (u3b && i == 14) bf16 += 4.0 * 12 * 2 * 6 * 16384.0;      // up2.convT: 4 m-tiles x 12 n-tiles x 2 K-steps
         else f32 += padded(i);
@@ -1845,6 +1924,11 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     if (b3)
       for (int i = 0; i < 5; ++i) p3[i] = net.add_blob(b3_operand(*net.convs[3 + 4 + i], i == 3));
     if (u1b) p3[5] = net.add_blob(b3_operand(*net.convs[3 + 10], false));
+    HostBlob* p3d12[2] = {};
+    if (d12b) {
+      p3d12[0] = net.add_blob(b3_operand(*net.convs[3 + 0], false));
+      p3d12[1] = net.add_blob(b3_operand(*net.convs[3 + 2], false));
+    }
     HostBlob* p3uT[2] = {};
     if (u3b) {
       p3uT[0] = net.add_blob(b3_operand(*net.convs[3 + 9], true));
@@ -1891,6 +1975,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     st.run = [=](Net& n, int B, hipStream_t s) -> int {
       WindowArgs a{};
       for (int i = 0; i < 13; ++i) a.af4[i] = q4[i] ? q4[i]->d : nullptr;
+      for (int i = 0; i < 2; ++i) a.af3_d12[i] = p3d12[i] ? reinterpret_cast<const uint4*>(p3d12[i]->d) : nullptr;
       for (int i = 0; i < 2; ++i) a.af3_uT[i] = p3uT[i] ? reinterpret_cast<const uint4*>(p3uT[i]->d) : nullptr;
       for (int i = 0; i < 2; ++i) a.af3_u2[i] = p3u2[i] ? reinterpret_cast<const uint4*>(p3u2[i]->d) : nullptr;
       for (int i = 0; i < 6; ++i) {
@@ -1928,7 +2013,9 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         a.pre = *n.pre;
         a.has_pre = 1;
       }
-      if (u3b) {
+      if (d12b) {
+        hipLaunchKernelGGL((pn_window_kernel<false, true, true, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
+      } else if (u3b) {
         hipLaunchKernelGGL((pn_window_kernel<false, true, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
       } else if (u2b) {
         hipLaunchKernelGGL((pn_window_kernel<false, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
@@ -1953,6 +2040,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
   }
   net.steps = std::move(steps);
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_core_kernel<true>), CORE_LDS_FLOATS * sizeof(float)});
