@@ -238,3 +238,32 @@ def test_regression_bar_full_batch(default_pair):
     got = _as_array(model(xn.cuda()))
     err = _check(got, want, f"{name} 256 windows")
     assert float(np.abs(got - want).mean()) < 2e-7, err
+
+
+# ---- (e) every documented plan selector (include/volpick_hip.h: vp_config.plan_flags) still produces oracle-grade outputs --------
+PLAN_SELECTORS = {
+    "phasenet": [(1,), (0, 1), (0, 0, 1), (0, 0, 0, 1), (0, 0, 0, 2), (0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 2),
+                 (0, 0, 0, 0, 0, 3), (0, 0, 0, 0, 0, 4), (0, 0, 0, 0, 0, 5), (0, 0, 0, 0, 0, 6), (0, 0, 0, 0, 0, 7),
+                 (0, 0, 0, 0, 0, 0, 1)],
+    "eqtransformer": [(1,), (0, 0, 1), (0, 0, 2), (0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 0, 2)] +
+                     [(0, 0, 0, 0, 0, 0, 0, 1 << b) for b in range(12)] + [(0, 0, 0, 0, 0, 0, 0, 0x1F0), (0, 0, 0, 0, 0, 0, 0, 0xF)],
+}
+
+
+@pytest.mark.parametrize("name,flags", [(n, f) for n, fl in PLAN_SELECTORS.items() for f in fl],
+                         ids=[f"{n}-{'.'.join(map(str, f))}" for n, fl in PLAN_SELECTORS.items() for f in fl])
+def test_every_plan_selector_is_oracle_grade(name, flags):
+    oracle = load_pretrained(name, "volpick")
+    m = MODELS[name].from_pretrained("volpick")
+    m._plan_flags = flags
+    m.cuda()
+    try:
+        x = synthetic_windows(3, m.in_samples, seed=4700)
+        xn = OP.batch_pre(oracle, torch.from_numpy(x))
+        with torch.no_grad():
+            want = _as_array(oracle(xn))
+        _check(_as_array(m(xn.cuda())), want, f"{name} plan_flags {flags}")
+        got = _as_array(m._forward_raw(torch.from_numpy(x).cuda(), preprocess=True))  # the in-kernel / gather_normalize front end
+        _check(got, want, f"{name} plan_flags {flags}, preprocessing on the device")
+    finally:
+        m._release()
