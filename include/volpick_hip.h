@@ -87,7 +87,9 @@ typedef struct {
                                       bit10 = the decoder tail computes every tile of a row even where annotate / classify
                                       blind the output (default: only the tiles that hold kept samples),
                                       bit11 = stage 3 of the fused decoder 0-3 kernel shares its n-tiles evenly between
-                                      the two waves of a SIMD (default: 14 + 10) */
+                                      the two waves of a SIMD (default: 14 + 10),
+                                      bit12 = the bf16-piece ResCNN kernel with eight waves per window (K split over wave
+                                      pairs; default: four waves per window and TWO windows per workgroup, bit9: one) */
   int32_t reserved[4];        /* must be 0 */
 } vp_config;
 

@@ -190,6 +190,7 @@ struct Res3Args {
   const float* b_next[7];
   long af_bytes_k3, af_bytes_k2;  // size of one conv's operand (L2 warm-up)
   int warm;                       // 0: no pre-touch of the weights (plan flag plan_flags[4] = 1)
+  int n_windows;                  // eqt_res3_kernel<2>: the last workgroup of an odd batch clamps its second window to it
 };
 
 __device__ __forceinline__ void split3(const float v, unsigned short& h, unsigned short& m, unsigned short& l) {
@@ -272,18 +273,28 @@ __device__ __forceinline__ void res3_mac(const bf16_t* src, const Res3A<TAPS>& A
   }
 }
 
-__global__ __launch_bounds__(256) void eqt_res3_kernel(const Res3Args a) {
-  __shared__ __attribute__((aligned(16))) float X[64 * R3_XS];
-  __shared__ __attribute__((aligned(16))) bf16_t ACT[3 * R3_PS];
-  __shared__ __attribute__((aligned(16))) bf16_t MID[3 * R3_PS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), win = blockIdx.x;
+// WPB windows per workgroup: team = threadIdx.x / 256 takes window WPB blockIdx.x + team with its own images; the teams run the
+// same barriers in lock step.  WPB = 2: one wave of each team per SIMD -- the two-waves-per-SIMD issue rate of eqt_res3k_kernel
+// without its partial-sum exchange -- and a batch of 256 windows holds 128 CUs (the other contexts' kernels run on the rest,
+// as beside eqt_mid_kernel<2>).  An odd batch's last workgroup computes its last window twice (identical stores).
+template <int WPB>
+__global__ __launch_bounds__(256 * WPB) void eqt_res3_kernel(const Res3Args a) {
+  __shared__ __attribute__((aligned(16))) float X_all[WPB * 64 * R3_XS];
+  __shared__ __attribute__((aligned(16))) bf16_t ACT_all[WPB * 3 * R3_PS];
+  __shared__ __attribute__((aligned(16))) bf16_t MID_all[WPB * 3 * R3_PS];
+  const int team = WPB > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
+  float* X = X_all + team * 64 * R3_XS;
+  bf16_t* ACT = ACT_all + team * 3 * R3_PS;
+  bf16_t* MID = MID_all + team * 3 * R3_PS;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int win = min((int)blockIdx.x * WPB + team, a.n_windows - 1);
   const int g = lane >> 4, n = lane & 15;
-  if (a.warm) {
+  if (a.warm && team == 0) {
     // The weights (1 MB) have left L2 since the last launch (the other kernels of the step move 0.3 GB): every XCD's L2 is
     // warmed up front, one word per 128-byte line (see eqt_res_kernel) -- by ALL workgroups of the XCD, each a slice of the
     // lines (consecutive workgroups go to consecutive XCDs): as the job of the first workgroup of each XCD, pulling 2 MB
     // through one CU made those eight workgroups, hence the launch, 4 us longer.
-    const int nx = gridDim.x >= 8 ? gridDim.x >> 3 : 1, xw = win >> 3;  // workgroups per XCD that take part; this one's index
+    const int nx = gridDim.x >= 8 ? gridDim.x >> 3 : 1, xw = (int)blockIdx.x >> 3;  // workgroups per XCD that take part; this one's index
     constexpr int kers_pf[7] = {3, 3, 3, 3, 2, 3, 2};
     unsigned sink = 0u;
     if (xw < nx) {
@@ -693,10 +704,13 @@ int plan_eqt_fuse_res(Net& net) {
       a.af_bytes_k3 = 4L * 3 * 2 * 3 * 64 * 16;
       a.af_bytes_k2 = 4L * 2 * 2 * 3 * 64 * 16;
       a.warm = n.cfg.plan_flags[4] != 1;
-      if (n.cfg.plan_flags[7] & 512)  // bit 9: the one-wave-per-SIMD form (four waves per window)
-        hipLaunchKernelGGL(eqt_res3_kernel, dim3(B), dim3(256), 0, s, a);
-      else
+      a.n_windows = B;
+      if (n.cfg.plan_flags[7] & 4096)  // bit 12: eight waves per window, K split over wave pairs (round 2's default: 31.5 us on 256 CUs)
         hipLaunchKernelGGL(eqt_res3k_kernel, dim3(B), dim3(R3K_NTH), R3K_LDS_BYTES, s, a);
+      else if (n.cfg.plan_flags[7] & 512)  // bit 9: four waves per window, one window per workgroup
+        hipLaunchKernelGGL(eqt_res3_kernel<1>, dim3(B), dim3(256), 0, s, a);
+      else  // four waves per window, two windows per workgroup: 44.5 us on 128 CUs
+        hipLaunchKernelGGL(eqt_res3_kernel<2>, dim3((B + 1) / 2), dim3(512), 0, s, a);
       return 0;
     };
   } else
