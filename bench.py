@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--sustain-seconds", type=float, default=5.2,
                     help="length of the one long timed region per model reported as `sustained` (0 = skip)")
     ap.add_argument("--no-api", action="store_true", help="skip the `api` object (classify() on a host 24 h stream)")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="rehearsal of the N > 1 plumbing on a ONE-GPU box: process group over gloo, every rank on cuda:0, weights "
+                         "through the host broadcast (no RCCL); the line it prints is not a measurement")
     args = ap.parse_args()
 
     import torch
@@ -89,8 +92,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", str(world))
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_gloo:
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     env = dict(args=args, world=world, rank=rank, use_dist=use_dist, dev=torch.device("cuda", torch.cuda.current_device()))
@@ -250,7 +257,7 @@ def timed_repeats(run_once, sync_all, repeats, use_dist, dev):
         sync_all()
     OWN_TIMES[:] = times
     if use_dist:
-        tt = torch.tensor(times, dtype=torch.float64, device=dev)
+        tt = torch.tensor(times, dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         times = [float(v) for v in tt.tolist()]
     return times
@@ -281,6 +288,8 @@ def bench_model(model_name, env, cpu_budget_s):
         dist.barrier()
         t0 = time.perf_counter()
         broadcast_weights(model, src=0)
+        if model._handle is None:  # --rehearse-gloo: the host broadcast leaves the plan to be built
+            model.cuda(dev)
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
     else:
