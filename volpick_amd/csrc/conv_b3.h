@@ -382,6 +382,55 @@ __device__ __forceinline__ void b3c_mac_tiles(const bf16_t* p, const uint4 (&a)[
   finish(NB - 1, prev);
 }
 
+// The same with the n-tiles taken in PAIRS whose MFMAs alternate: consecutive instructions never share an accumulator, so one
+// wave issues them back to back (a chain into one accumulator issues every 20-26 cycles from one wave, LOG.md).  NB even.
+template <int C, int NC, int TAPS, int NB, class Finish>
+__device__ __forceinline__ void b3c_mac_tile_pairs(const bf16_t* p, const uint4 (&a)[B3Steps<C, TAPS>::STEPS * 3], Finish finish) {
+  using G = B3Steps<C, TAPS>;
+  using Q = B3Chunk<C, NC>;
+  static_assert(NB % 2 == 0, "pairs of n-tiles");
+  constexpr int STEPS = G::STEPS, PAIRS = STEPS * (NB / 2);
+  uint4 b[2][2][3];  // [buffer][tile of the pair][piece]
+  auto load_b = [&](const int i) {  // i = pair index * STEPS + step
+    const int s = i % STEPS, jp = i / STEPS;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int off = ((C >= 32 ? s / G::KS : s * G::TPK) + (2 * jp + h) * 16) * 8 + (C >= 32 ? (s % G::KS) * 4 * Q::CHS : 0);
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) b[i & 1][h][pc] = *reinterpret_cast<const uint4*>(p + pc * Q::PS + off);
+    }
+  };
+  load_b(0);
+  f32x4 prev0 = {0.f, 0.f, 0.f, 0.f}, prev1 = prev0;
+#pragma unroll
+  for (int jp = 0; jp < NB / 2; ++jp) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    __builtin_amdgcn_sched_barrier(0);
+    if (jp > 0) {
+      finish(2 * jp - 2, prev0);
+      finish(2 * jp - 1, prev1);
+    }
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      const int i = jp * STEPS + s;
+      if (i + 1 < PAIRS) load_b(i + 1);
+      constexpr int WP[6] = {2, 1, 0, 1, 0, 0}, XP[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, a[s * 3 + WP[t]]),
+                                                      __builtin_bit_cast(bf16x8_b3, b[i & 1][0][XP[t]]), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, a[s * 3 + WP[t]]),
+                                                      __builtin_bit_cast(bf16x8_b3, b[i & 1][1][XP[t]]), acc1, 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    prev0 = acc0;
+    prev1 = acc1;
+  }
+  finish(NB - 2, prev0);
+  finish(NB - 1, prev1);
+}
+
 // The same with the accumulators of all NB n-tiles kept: acc[j] += operand x fragments of n-tile j.  For a layer whose K is walked
 // in two passes over ONE image that is refilled in between (PhaseNet up2.same).
 template <int C, int NC, int TAPS, int NB>

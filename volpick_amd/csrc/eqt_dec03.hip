@@ -42,8 +42,11 @@ static_assert(D03_LDS_FLOATS * 4 <= 160 * 1024 && OFF1 % 4 == 0 && OFF2 % 4 == 0
 // image, stages 1 and 2 read and write piece images, stage 3 reads one and writes the row to memory.  LDS: the stage-2
 // input image (85 KB, [column][64 + 8 channels]), and behind it the stage-3 input image (77 KB, chunk planes, unpadded),
 // which takes the place of the (dead) stage-0 input and stage-1 input images -- one more barrier per row, 158 KB in all.
-constexpr int B3_X1_NC = 100, B3_X2_NC = 196;                          // columns: sample t at column t + 1
-constexpr int B3_X1_PS = B3_X1_NC * 72, B3_X2_PS = B3_X2_NC * 72;      // bf16 elements per piece
+constexpr int B3_X1_NC = 112, B3_X2_NC = 208;                          // columns: sample t at column t + 1
+using QX1 = B3Chunk<64, B3_X1_NC>;                                     // chunk-plane images (conv_b3.h): no padding channels
+using QX2 = B3Chunk<64, B3_X2_NC>;
+constexpr int B3_X1_PS = QX1::PS, B3_X2_PS = QX2::PS;                  // bf16 elements per piece
+static_assert(B3_X1_NC >= C1 + 3 && B3_X2_NC >= C2 + 3, "every column stages 1 / 2 read has a place");
 constexpr int B3_OFF_X2 = 0, B3_OFF_R = 3 * B3_X2_PS * 2;              // bytes
 constexpr int B3_OFF_X0 = B3_OFF_R, B3_OFF_X1 = B3_OFF_X0 + 16 * S0 * 4, B3_OFF_X3 = B3_OFF_R;
 // stage-3 input as a chunk-plane three-piece image (conv_b3.h): sample t at column t + 2, 400 columns, no padding channels
@@ -118,9 +121,14 @@ struct RowOut {
   }
 };
 
-// B3, stage 0: rows (phase, channel): m-tile mt holds phase mt / 4, channels (mt % 4) * 16 ..; -> three-piece image
-struct Stage0Pieces : B3Store<64> {
+// B3, stage 0: rows (phase, channel): m-tile mt holds phase mt / 4, channels (mt % 4) * 16 ..; -> chunk-plane three-piece image
+struct Stage0Pieces {
   static constexpr bool custom_block_epilogue = true;
+  bf16_t* img;
+  __device__ __forceinline__ void quad(const int co, const int t, const float (&v)[4]) const {
+    const float z[4] = {t < L1 ? v[0] : 0.f, t < L1 ? v[1] : 0.f, t < L1 ? v[2] : 0.f, t < L1 ? v[3] : 0.f};
+    b3c_store4<64, B3_X1_NC>(img, t + 1, co >> 2, z);
+  }
   template <class L>
   __device__ __forceinline__ void block_epilogue(const f32x4 (&acc)[L::NB], const float (&biasv)[4], const int mt, const int colb,
                                                  const int g, const int n) const {
@@ -154,7 +162,8 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
     float* X0 = reinterpret_cast<float*>(base + 16 * o_r);
     bf16_t* X3 = reinterpret_cast<bf16_t*>(base + 16 * o_r);
     float* EDGE = reinterpret_cast<float*>(base + B3_OFF_EDGE);
-    const B3Image<64> iX1{reinterpret_cast<bf16_t*>(base + B3_OFF_X1), B3_X1_PS, 1}, iX2{reinterpret_cast<bf16_t*>(base + B3_OFF_X2), B3_X2_PS, 1};
+    bf16_t* const X1 = reinterpret_cast<bf16_t*>(base + B3_OFF_X1);
+    bf16_t* const X2 = reinterpret_cast<bf16_t*>(base + B3_OFF_X2);
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     int row = blockIdx.x;
@@ -193,16 +202,31 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
       const int nd = more ? next / a.B : d;
       park();
       __syncthreads();
+      uint4 a1[B3Steps<64, 3>::STEPS * 3];  // stage 1's operand: on its way under stage 0
+      b3_load_a<64, 3>(a.af3[0] + d * a.af3_stride[0], wave_u, lane, a1);
       {  // stage 0: 16 x 47 -> 64 x 94, three pieces
-        Stage0Pieces st{{iX1.img, iX1.ps, iX1.c0, L1, B3_X1_NC}};
-        st.zero_rest(1, 1 + 2 * C0, tid, D03_NTH);
+        Stage0Pieces st{X1};
+        b3c_zero_rest<64, B3_X1_NC>(X1, 1, 1 + 2 * C0, tid, D03_NTH);
         conv_lds_areg<D_0, S0, BI, S0, BI>(X0, X0, areg0, bias0, wave_u, C0, st, 0, 1, lane);
       }
-      __syncthreads();
-      {  // stage 1: 64 x 94 -> 64 x 188 on the bf16 matrix cores
-        const B3Store<64> st{iX2.img, iX2.ps, iX2.c0, L2, B3_X2_NC};
-        conv_b3<D_1, true, 64, 64>(iX1, iX1, a.af3[0] + d * a.af3_stride[0], a.bs[1] + d * 64, C1, st, wave_u, D03_WAVES, lane);
+      const int n = lane & 15;
+      {  // stage 1: 64 x 94 -> 64 x 188 on the bf16 matrix cores: wave = m-tile (phase w / 4, channels 16 (w % 4) ..), six n-tiles,
+         // its operand in registers (requested ahead of the barrier)
+        const int ph = wave_u >> 2, co0 = (wave_u & 3) * 16 + 4 * g;
+        float bias1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias1[r] = a.bs[1][d * 64 + co0 + r];
+        __syncthreads();
+        b3c_mac_tile_pairs<64, B3_X1_NC, 3, 6>(b3c_lane_ptr<64, B3_X1_NC, 3>(X1, 0, lane), a1, [&](const int j, const f32x4 acc) {
+          const int t = 2 * (j * 16 + n) + ph;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = t < L2 ? fmaxf(acc[r] + bias1[r], 0.f) : 0.f;
+          b3c_store4<64, B3_X2_NC>(X2, t + 1, co0 >> 2, v);
+        });
       }
+      uint4 a2[B3Steps<64, 3>::STEPS * 3];  // stage 2's operand: requested before the barrier, stage 1's registers are free
+      b3_load_a<64, 3>(a.af3[1] + d * a.af3_stride[1], wave_u & 3, lane, a2);
       __syncthreads();
       float eb;
       {  // stage 2: 64 x 188 -> 32 x 375 (three-piece image in the place of the dead stage-0 / stage-1 inputs: its padding
@@ -227,14 +251,25 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
             for (int k = 0; k < 3; ++k) ew[u][k] = e[u * 64 * 3 + k];
         }
         const ClipQuad st{X3, L3 - 2};
-        conv_b3<D_2, true, 64, 64>(iX2, iX2, a.af3[1] + d * a.af3_stride[1], a.bs[2] + d * 32, C2, st, wave_u, D03_WAVES, lane);
+        {  // wave = (m-tile w % 4: phase mt / 2, channels 16 (mt % 2) ..; block w / 4 of six n-tiles), operand in registers
+          const int mt2 = wave_u & 3, ph = mt2 >> 1, co0 = (mt2 & 1) * 16 + 4 * g, colb = (wave_u >> 2) * 96;
+          float bias2[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bias2[r] = a.bs[2][d * 32 + co0 + r];
+          b3c_mac_tile_pairs<64, B3_X2_NC, 3, 6>(b3c_lane_ptr<64, B3_X2_NC, 3>(X2, colb, lane), a2, [&](const int j, const f32x4 acc) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[r] + bias2[r], 0.f);
+            st.quad(co0, 2 * (colb + j * 16 + n) + ph, v);
+          });
+        }
         float pacc = 0.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const bf16_t* xs = iX2.img + (n0 + iX2.c0) * 72 + 8 * wave_u + u;
+          const bf16_t* xs = X2 + wave_u * QX2::CHS + (n0 + 1) * 8 + u;  // channel 8 w + u = chunk w
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
-            const float x = (from_bf16(xs[k * 72]) + from_bf16(xs[k * 72 + iX2.ps])) + from_bf16(xs[k * 72 + 2 * iX2.ps]);  // exact
+            const float x = (from_bf16(xs[k * 8]) + from_bf16(xs[k * 8 + QX2::PS])) + from_bf16(xs[k * 8 + 2 * QX2::PS]);  // exact
             pacc = fmaf(ew[u][k], x, pacc);
           }
         }
