@@ -82,6 +82,7 @@ class WaveformModel:
         # device contexts classify() pipelines station blocks over (tools/ctx_sweep.sh: PhaseNet 3, EQTransformer 4 with
         # >= 5 hardware queues -- volpick_amd/__init__.py; more contexts than that only add queueing)
         self.n_contexts = self.default_contexts
+        self._seg_per_context = 2  # segments of a long block per device context (<= VP_MAX_INFLIGHT submit slots)
         self._device_index = None
         self._max_batch = 256
         self._plan_flags = (0, 0)  # vp_config.plan_flags[0:2]: (layer-by-layer plan, dump fused intermediates)
@@ -408,7 +409,10 @@ class WaveformModel:
         lib = _lib.load()
         dev = torch.device("cuda", self._device_index)
         n = data.shape[1]
-        segs = plan_segments(n, self.in_samples, args["overlap"], args["blinding"], self.n_contexts)
+        # _seg_per_context segments per device context (one submit slot each): the first upload, which nothing overlaps, is that
+        # much shorter
+        nc = self.n_contexts
+        segs = plan_segments(n, self.in_samples, args["overlap"], args["blinding"], nc * self._seg_per_context)
         if len(segs) == 1:
             return self._annotate_block(data, args)
         stacking = _lib.VP_STACK_AVG if args["stacking"] == "avg" else _lib.VP_STACK_MAX
@@ -428,7 +432,7 @@ class WaveformModel:
             return x, y
 
         def submit(r, sg, x, y):
-            _lib.check(lib.vp_classify_submit(self._context(r), 0, C.c_void_p(x.data_ptr()), _lib.VP_MEM_DEVICE,
+            _lib.check(lib.vp_classify_submit(self._context(r % nc), r // nc, C.c_void_p(x.data_ptr()), _lib.VP_MEM_DEVICE,
                                               sg["hi"] - sg["lo"], args["overlap"], args["blinding"][0], args["blinding"][1],
                                               stacking, batch, None, 0, C.c_void_p(y.data_ptr()), _lib.VP_MEM_DEVICE, 0),
                        "vp_classify_submit")
@@ -451,7 +455,7 @@ class WaveformModel:
         found = C.c_int()
         for r, (sg, (x, y)) in enumerate(zip(segs, jobs)):
             f, l, w = C.c_int64(), C.c_int64(), C.c_int64()
-            _lib.check(lib.vp_classify_collect(self._context(r), 0, C.byref(f), C.byref(l), C.byref(w), None, None, None,
+            _lib.check(lib.vp_classify_collect(self._context(r % nc), r // nc, C.byref(f), C.byref(l), C.byref(w), None, None, None,
                                                None, None, 0, C.byref(found)), "vp_classify_collect")
             out[:, sg["keep_lo"]:sg["keep_hi"]] = y[:, sg["keep_lo"] - sg["lo"]:sg["keep_hi"] - sg["lo"]]
             if r == 0:
