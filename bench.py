@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
 """Headline benchmark: waveform-windows/s of the volpick picking path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N=1: run directly)
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Both forms work for any N.  Run directly with N > 1 (no RANK in the environment), this script is the LAUNCHER: without
+importing torch or touching HIP it starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on itself as a
+child process (127.0.0.1 rendezvous on a free port), relays rank 0's one JSON line and exits with the child's code.
+Under an external torch.distributed.run, WORLD_SIZE must equal --gpus (else exit 2: a line that says n_gpus = 8 is
+never produced by fewer ranks).
 
 A "step" is one pass of the whole hot path over one batch of 256
 windows cut from a device-resident synthetic 3-component stream: window gather +
@@ -55,6 +61,68 @@ def pipe_time_s(issued, batch):
                     issued["valu"] / (PEAK_FP32_TFLOPS * 1e12))
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment: start the N ranks as ONE child process
+    group (torch.distributed.run on this file), pass everything but the JSON line through to stderr, print the JSON line,
+    return the child's exit code.  The parent never imports torch and never touches HIP (a process that has initialised
+    the GPU must not replace itself, and does not need to: it only waits)."""
+    import signal
+    import socket
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))  # torch.distributed.run would pin it to 1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", port, str(Path(__file__).resolve())] + list(argv)
+
+    def die_with_parent():  # the rank group must not outlive a launcher that is killed outright (SIGKILL cannot be relayed)
+        try:
+            C.CDLL(None, use_errno=True).prctl(1, signal.SIGTERM)  # PR_SET_PDEATHSIG
+        except (OSError, AttributeError):
+            pass
+
+    # The child stays in the launcher's process group: whoever started the launcher in a session / group of its own
+    # (the driver's timeout, tests/test_gpu_bench_rehearsal.py) takes every rank with one killpg.
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, preexec_fn=die_with_parent)
+
+    def forward(signum, _frame):  # SIGTERM / Ctrl-C of the launcher alone: the elastic agent ends its workers on SIGTERM
+        try:
+            child.send_signal(signum)
+        except ProcessLookupError:
+            pass
+
+    old = {sg: signal.signal(sg, forward) for sg in (signal.SIGTERM, signal.SIGINT)}
+    lines = []
+    try:
+        for ln in child.stdout:
+            if ln.startswith("{") and ln.rstrip().endswith("}"):
+                lines.append(ln.rstrip())
+            else:
+                sys.stderr.write(ln)
+        rc = child.wait()
+    finally:
+        if child.poll() is None:
+            child.terminate()
+            try:
+                child.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                child.kill()
+                child.wait()
+        for sg, h in old.items():
+            signal.signal(sg, h)
+    if rc == 0 and len(lines) != 1:
+        sys.stderr.write(f"bench.py launcher: expected ONE JSON line from rank 0, got {len(lines)}\n")
+        rc = 3
+    for ln in lines[-1:]:
+        print(ln, flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +146,15 @@ def main():
                     help="rehearsal of the N > 1 plumbing on a ONE-GPU box: process group over gloo, every rank on cuda:0, weights "
                          "through the host broadcast (no RCCL); the line it prints is not a measurement")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "RANK" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    elif int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')} in the environment: "
+                         "the launcher and the flag must agree\n")
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
@@ -85,6 +162,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "RANK" in os.environ and not args.rehearse_gloo and local_rank >= torch.cuda.device_count():
+        sys.stderr.write(f"bench.py: rank {rank} wants cuda:{local_rank}, this node shows {torch.cuda.device_count()} GPU(s)\n")
+        sys.exit(2)
     # under torch.distributed.run (RANK set) the RCCL path is exercised even for one rank
     use_dist = world > 1 or "RANK" in os.environ
     if use_dist:
@@ -131,6 +211,24 @@ def _rccl_ranks():
     from volpick_amd import distributed
 
     return distributed.LAST_RCCL_RANKS
+
+
+def _rccl_libraries():
+    """The librccl the C ABI bound by dlopen, and every librccl this process has mapped (torch's bundled copy carries
+    the same SONAME, so the two must be ONE object: `one_copy`)."""
+    from volpick_amd import distributed
+
+    mapped = set()
+    try:
+        for ln in Path("/proc/self/maps").read_text().splitlines():
+            f = ln.split()[-1]
+            if "librccl" in f:
+                mapped.add(os.path.realpath(f))
+    except OSError:
+        pass
+    bound = distributed.LAST_RCCL_LIBRARY
+    return {"bound_by_vp": bound, "mapped": sorted(mapped),
+            "one_copy": (len(mapped) == 1 and bound is not None and os.path.realpath(bound) in mapped) if mapped else None}
 
 
 def clock_probe_create(cls, batch, dev):
@@ -523,7 +621,8 @@ def bench_model(model_name, env, cpu_budget_s):
     }
     if use_dist:  # what every rank saw, so that a multi-GPU line checks itself
         info = {"rank": rank, "device": torch.cuda.current_device(), "ms_per_step_own_median": None,
-                "weight_broadcast_s": t_bcast, "rccl_comm_ranks": _rccl_ranks(), "windows_per_step": args.batch}
+                "weight_broadcast_s": t_bcast, "weight_broadcast_path": _bcast_path(), "rccl_comm_ranks": _rccl_ranks(),
+                "librccl": _rccl_libraries(), "windows_per_step": args.batch}
         info["ms_per_step_own_median"] = statistics.median(env.get("own_times", [dt])) / args.steps * 1e3
         gathered = [None] * world
         dist.all_gather_object(gathered, info)
@@ -625,7 +724,8 @@ def bench_strong(env):
         info = {"rank": rank, "device": torch.cuda.current_device(), "segment": [sg["lo"], sg["hi"]] if sg else None,
                 "keeps": [sg["keep_lo"], sg["keep_hi"]] if sg else None,
                 "ms_per_step_own_median": statistics.median(OWN_TIMES) / steps * 1e3 if OWN_TIMES else None,
-                "weight_broadcast_s": t_bcast, "rccl_comm_ranks": _rccl_ranks()}
+                "weight_broadcast_s": t_bcast, "weight_broadcast_path": _bcast_path(), "rccl_comm_ranks": _rccl_ranks(),
+                "librccl": _rccl_libraries()}
         gathered = [None] * world
         dist.all_gather_object(gathered, info)
         out["ranks"] = gathered

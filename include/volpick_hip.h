@@ -396,9 +396,24 @@ int vp_rccl_comm_init(int device_id, int n_ranks, const void* id128, int rank, v
 int vp_rccl_comm_info(void* comm, int* n_ranks, int* rank); /* ncclCommCount / ncclCommUserRank of the communicator */
 int vp_rccl_comm_destroy(void* comm);
 int vp_bcast_weights(void* rccl_comm, float* weights_dev, size_t n_floats, int root);
+/* Absolute path of the shared object the RCCL entry points above were bound from (dladdr of ncclBroadcast), so that a
+ * multi-GPU run can show that the process carries ONE RCCL: PyTorch-ROCm bundles a librccl with the same SONAME
+ * (librccl.so.1), and dlopen by SONAME hands back the copy that is already mapped.  Writes a NUL-terminated string of at
+ * most cap bytes; VP_ERR_UNSUPPORTED if RCCL could not be bound. */
+int vp_rccl_library_path(char* buf, size_t cap);
 
 const char* vp_last_error(void);
 const char* vp_version(void);
+
+/* ABI revision of this header.  It changes whenever a struct a caller fills (vp_config, vp_trigger_spec,
+ * vp_mseed_record) changes size or layout, or an entry point changes its signature; added entry points do not bump it.
+ * A binder compiled against this header checks vp_abi_version() == VP_ABI_VERSION and vp_config_size() ==
+ * sizeof(vp_config) once, before vp_create reads its struct.  History: 1 = round 1 (vp_config with reserved[8]),
+ * 2 = round 3 (plan_flags[8] + reserved[4]: the struct grew by 16 bytes), 3 = this header (layout of 2, the two
+ * checks added). */
+#define VP_ABI_VERSION 3
+int vp_abi_version(void);
+size_t vp_config_size(void);
 
 #ifdef __cplusplus
 }

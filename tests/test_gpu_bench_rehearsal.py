@@ -1,40 +1,66 @@
-"""bench.py's N > 1 plumbing on a ONE-GPU box: two ranks under torch.distributed.run over gloo, both on cuda:0
-(`--rehearse-gloo`: no RCCL, weights through the host broadcast).  What is checked is the contract of the line -- one JSON
-object from rank 0, whole-job value over the max-over-ranks span, `ranks` with what every rank saw -- not the numbers."""
+"""bench.py's N > 1 plumbing on a ONE-GPU box: `python bench.py --gpus 2 --rehearse-gloo` called DIRECTLY, the way the driver
+calls it (no RANK in the environment): the script launches its two ranks itself (torch.distributed.run as a child process),
+both on cuda:0, process group over gloo, weights through the host broadcast (no RCCL).  What is checked is the contract of
+the line -- ONE JSON object on stdout, n_gpus = 2, whole-job value over the max-over-ranks span, `ranks` with what every
+rank saw -- not the numbers; and that nothing of the rank group is left behind."""
 import json
 import os
+import signal
 import subprocess
 import sys
+import time
 from pathlib import Path
 
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def _run(extra, port):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--rehearse-gloo"] + extra
-    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, "rank 0 prints ONE JSON line, the other ranks nothing"
+def _run(extra, timeout=420):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--rehearse-gloo"] + extra
+    # a session of its own: launcher, elastic agent and ranks share ONE process group that a timeout can kill whole
+    p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        p.communicate()
+        pytest.fail(f"bench.py --gpus 2 did not finish within {timeout} s; its process group was killed")
+    finally:
+        _reap_group(p.pid)
+    assert p.returncode == 0, err[-2000:]
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), "stdout carries ONE JSON line from rank 0 and nothing else"
     return json.loads(lines[0])
 
 
+def _reap_group(pgid):
+    """No process of the launcher's group may be left (a rank that survives holds the GPU for the steps after this one)."""
+    for _ in range(50):
+        try:
+            os.killpg(pgid, 0)
+        except ProcessLookupError:
+            return
+        time.sleep(0.1)
+    os.killpg(pgid, signal.SIGKILL)
+    pytest.fail("bench.py left processes of its rank group behind")
+
+
 def test_weak_line_of_two_ranks():
-    d = _run(["--steps", "5", "--warmup", "2", "--model", "phasenet", "--no-cpu-baseline", "--no-api", "--sustain-seconds", "0"], 29541)
+    d = _run(["--steps", "5", "--warmup", "2", "--model", "phasenet", "--no-cpu-baseline", "--no-api", "--sustain-seconds", "0"])
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["value"] == pytest.approx(2 * 256 / (d["ms_per_step"] * 1e-3), rel=1e-6)  # whole job over the slowest rank's span
     assert [r["rank"] for r in d["ranks"]] == [0, 1] and all(r["windows_per_step"] == 256 for r in d["ranks"])
+    assert all(r["device"] == 0 and "weight_broadcast_path" in r and "librccl" in r for r in d["ranks"])
     assert max(r["ms_per_step_own_median"] for r in d["ranks"]) <= d["ms_per_step"] * 1.25
     assert d["roofline"]["frac"] <= 1.0
 
 
 def test_strong_line_of_two_ranks():
-    d = _run(["--strong", "--steps", "2", "--warmup", "1"], 29542)
+    d = _run(["--strong", "--steps", "2", "--warmup", "1"])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     segs = [r["segment"] for r in d["ranks"]]
     keeps = [r["keeps"] for r in d["ranks"]]

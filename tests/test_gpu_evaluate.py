@@ -51,6 +51,7 @@ def test_evaluate_windows_matches_reference_protocol(name, T):
     assert len(got) == 4 and all(len(g) == n for g in got)
 
 
+@pytest.mark.slow
 def test_evaluation_protocol_at_its_real_size():
     """model_training/test.ipynb:624 of the reference evaluates 35,120 windows at batch 1024.  Same size here (PhaseNet):
     1,024 distinct synthetic windows tiled to 35,120, so the answer is known without an oracle run of that length -- window

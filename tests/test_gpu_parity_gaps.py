@@ -193,8 +193,14 @@ def test_rccl_broadcast_then_create_from_device_weights(pn):
         assert np.array_equal(w.cpu().numpy(), ref)
         assert lib.vp_bcast_weights(comm, None, 0, 0) < 0 and lib.vp_rccl_comm_init(0, 1, ident, 3, C.byref(comm)) < 0
         _lib.check(lib.vp_rccl_comm_destroy(comm))
+        path = C.create_string_buffer(4096)
+        _lib.check(lib.vp_rccl_library_path(path, len(path)))
+        mapped = {os.path.realpath(ln.split()[-1]) for ln in open("/proc/self/maps") if "librccl" in ln}
+        assert mapped == {os.path.realpath(path.value.decode())}, "ONE RCCL in the process: the copy torch mapped is the one dlopen bound"
     finally:
+        torch.cuda.synchronize()
         dist.destroy_process_group()
+        torch.cuda.synchronize()
 
 
 # ------------------------------------------------------------------------------------------- (c)

@@ -18,6 +18,7 @@ VP_NORM_PEAK, VP_NORM_STD = 0, 1
 VP_STACK_AVG, VP_STACK_MAX = 0, 1
 VP_MEM_HOST, VP_MEM_DEVICE = 0, 1
 VP_MAX_INFLIGHT = 4
+VP_ABI_VERSION = 3  # include/volpick_hip.h
 
 
 class VpConfig(C.Structure):
@@ -156,6 +157,9 @@ SIGNATURES = {
     "vp_rccl_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vp_rccl_comm_destroy": (C.c_int, [C.c_void_p]),
     "vp_bcast_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "vp_rccl_library_path": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "vp_abi_version": (C.c_int, []),
+    "vp_config_size": (C.c_size_t, []),
     "vp_debug_core_clock": (C.c_int, [_H, C.c_int, C.c_void_p]),
     "vp_debug_conv_clock": (C.c_int, [_H, C.c_void_p, C.c_int]),
     "vp_debug_tail_clock": (C.c_int, [_H, C.c_int, C.c_void_p]),
@@ -212,6 +216,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
+    if lib.vp_abi_version() != VP_ABI_VERSION or lib.vp_config_size() != C.sizeof(VpConfig):
+        raise VolpickHipError(f"{LIB_PATH}: ABI {lib.vp_abi_version()} / sizeof(vp_config) {lib.vp_config_size()}, this binding "
+                              f"was written for ABI {VP_ABI_VERSION} / {C.sizeof(VpConfig)}: rebuild the library")
     _lib = lib
     return lib
 

@@ -125,7 +125,9 @@ int run_batch(vp_handle* h, const vp::PreArgs& pa, int nb) {
 extern "C" {
 
 const char* vp_last_error(void) { return vp::last_error(); }
-const char* vp_version(void) { return "volpick_hip 0.1 (gfx950)"; }
+const char* vp_version(void) { return "volpick_hip 0.4 (gfx950)"; }
+int vp_abi_version(void) { return VP_ABI_VERSION; }
+size_t vp_config_size(void) { return sizeof(vp_config); }
 
 int vp_default_config(int model_kind, vp_config* cfg) {
   VP_REQUIRE(cfg != nullptr, "cfg is null");

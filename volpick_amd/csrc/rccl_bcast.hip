@@ -122,6 +122,23 @@ int vp_rccl_comm_destroy(void* comm) {
   return VP_OK;
 }
 
+int vp_rccl_library_path(char* buf, size_t cap) {
+  VP_REQUIRE(buf != nullptr && cap > 0, "null / empty buffer");
+  buf[0] = 0;
+  Rccl* r = rccl();
+  if (!r) {
+    vp::set_error("RCCL not available: %s", g_load_error.c_str());
+    return VP_ERR_UNSUPPORTED;
+  }
+  Dl_info info;
+  if (!dladdr(reinterpret_cast<void*>(r->Broadcast), &info) || !info.dli_fname) {
+    vp::set_error("dladdr(ncclBroadcast) found no object");
+    return VP_ERR_UNSUPPORTED;
+  }
+  snprintf(buf, cap, "%s", info.dli_fname);
+  return VP_OK;
+}
+
 // In place on every rank: the root sends weights_dev, the others receive into it.  Runs on a stream of its own on the
 // calling thread's current device and returns when the data has arrived (start-up path, once per model).
 int vp_bcast_weights(void* rccl_comm, float* weights_dev, size_t n_floats, int root) {

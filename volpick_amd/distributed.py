@@ -81,11 +81,19 @@ class RcclCommunicator:
         if not _all_agree(rc == 0, group, dev):
             self.close()
             raise RcclUnavailable("vp_rccl_comm_init failed on some rank" + (f" (this rank: {why})" if why else ""))
-        n, r = C.c_int(), C.c_int()
-        _lib.check(lib.vp_rccl_comm_info(self._comm, C.byref(n), C.byref(r)), "vp_rccl_comm_info")
-        self.n_ranks, self.rank = n.value, r.value  # what RCCL itself reports (ncclCommCount / ncclCommUserRank)
-        if (self.n_ranks, self.rank) != (world, rank):
-            raise RuntimeError(f"RCCL communicator spans {self.n_ranks} ranks (this one {self.rank}); expected {world} / {rank}")
+        # 4. what RCCL itself reports (ncclCommCount / ncclCommUserRank) is part of the agreed outcome: a rank whose
+        #    communicator came up with another shape must not leave alone while the others enter ncclBroadcast
+        n, r = C.c_int(-1), C.c_int(-1)
+        rc = lib.vp_rccl_comm_info(self._comm, C.byref(n), C.byref(r))
+        self.n_ranks, self.rank = n.value, r.value
+        mine = rc == 0 and (self.n_ranks, self.rank) == (world, rank)
+        why = "" if mine else (_lib.last_error() if rc != 0 else
+                               f"communicator spans {self.n_ranks} ranks (this one {self.rank}); expected {world} / {rank}")
+        if not _all_agree(mine, group, dev):
+            self.close()
+            raise RcclUnavailable("vp_rccl_comm_info disagrees with the group on some rank" + (f" (this rank: {why})" if why else ""))
+        path = C.create_string_buffer(4096)
+        self.library_path = path.value.decode() if lib.vp_rccl_library_path(path, len(path)) == 0 else None
 
     def broadcast(self, tensor, root: int = 0):
         """In-place broadcast of a contiguous fp32 CUDA tensor (``vp_bcast_weights``); ``root`` = rank within the group."""
@@ -99,11 +107,15 @@ class RcclCommunicator:
         return tensor
 
     def close(self):
+        """Never raises (every rank has to reach the agreement that follows a close)."""
         from . import _lib
 
-        if self._comm:
-            _lib.load().vp_rccl_comm_destroy(self._comm)
-            self._comm = None
+        comm, self._comm = self._comm, None
+        if comm:
+            try:
+                _lib.load().vp_rccl_comm_destroy(comm)
+            except Exception:  # noqa: BLE001
+                pass
 
     def __enter__(self):
         return self
@@ -118,6 +130,7 @@ class RcclUnavailable(RuntimeError):
 
 LAST_BROADCAST_PATH = None  # which collective the last "nccl" broadcast_weights used (bench.py reports it)
 LAST_RCCL_RANKS = None      # ncclCommCount of the library's communicator in that broadcast (None: fallback path)
+LAST_RCCL_LIBRARY = None    # the shared object vp_bcast_weights' RCCL entry points were bound from (vp_rccl_library_path)
 
 
 def broadcast_weights(model, src: int = 0, group=None, create_handle: bool = True):
@@ -143,8 +156,8 @@ def broadcast_weights(model, src: int = 0, group=None, create_handle: bool = Tru
         buf = torch.from_numpy(model._weights).to(dev) if dist.get_rank(group) == src else torch.zeros(
             n, dtype=torch.float32, device=dev)
         torch.cuda.current_stream(dev).synchronize()  # the upload is done before RCCL touches the buffer
-        global LAST_BROADCAST_PATH, LAST_RCCL_RANKS
-        LAST_RCCL_RANKS = None
+        global LAST_BROADCAST_PATH, LAST_RCCL_RANKS, LAST_RCCL_LIBRARY
+        LAST_RCCL_RANKS = LAST_RCCL_LIBRARY = None
         comm, why = None, ""
         try:
             comm = RcclCommunicator(dev.index, src=src, group=group)
@@ -154,11 +167,11 @@ def broadcast_weights(model, src: int = 0, group=None, create_handle: bool = Tru
         if comm is not None:
             try:
                 comm.broadcast(buf, root=src)
-                LAST_RCCL_RANKS = comm.n_ranks
+                LAST_RCCL_RANKS, LAST_RCCL_LIBRARY = comm.n_ranks, comm.library_path
                 done = True
-            except Exception as e:
+            except Exception as e:  # noqa: BLE001 -- whatever went wrong here, the agreement below must be reached
                 why = str(e)
-            comm.close()
+            comm.close()  # never raises
             done = _all_agree(done, group, dev)  # a failed ncclBroadcast on one rank sends everybody to the fallback
         if done:
             LAST_BROADCAST_PATH = "vp_bcast_weights (ncclBroadcast through the C ABI)"
