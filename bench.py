@@ -228,7 +228,7 @@ def _rccl_libraries():
         pass
     bound = distributed.LAST_RCCL_LIBRARY
     return {"bound_by_vp": bound, "mapped": sorted(mapped),
-            "one_copy": (len(mapped) == 1 and bound is not None and os.path.realpath(bound) in mapped) if mapped else None}
+            "one_copy": (len(mapped) == 1 and os.path.realpath(bound) in mapped) if (mapped and bound) else None}
 
 
 def clock_probe_create(cls, batch, dev):
@@ -270,7 +270,7 @@ def clock_probe_read(probe, model_name, batch):
     return ghz
 
 
-def bench_api(model_name, model, batch):
+def bench_api(model_name, model, batch, oracle_threads=None):
     """The drop-in call itself, as /root/reference README.md:54-66 writes it: `picker.classify(stream, batch_size=256,
     overlap=..., blinding=..., stacking="avg", ...)` on a HOST Stream of one 24 h three-component station (BASELINE
     configs[3]'s workload on one GPU): wall time of the whole call (stream grouping, upload, forward passes, stacking,
@@ -294,13 +294,26 @@ def bench_api(model_name, model, batch):
     st = va.Stream([va.Trace(data[i], dict(network="XX", station="DAY", location="", channel=f"HH{c}", starttime=t0,
                                            sampling_rate=100.0)) for i, c in enumerate("ZNE")])
     n_windows = int(OP.window_starts(n, T, kw["overlap"]).shape[0])
+    import gc
+
     res = model.classify(st, **kw)  # warm-up: contexts, buffers
-    walls = []
-    for _ in range(5):
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        res = model.classify(st, **kw)
-        walls.append(time.perf_counter() - t)
+    walls, pauses, t_gc = [], [], [0.0]
+
+    def gc_watch(phase, info):  # full collections of CPython's cyclic collector inside the timed calls (round 3's 65 ms call)
+        if phase == "start":
+            t_gc[0] = time.perf_counter()
+        elif info["generation"] == 2:
+            pauses.append((len(walls), (time.perf_counter() - t_gc[0]) * 1e3))
+
+    gc.callbacks.append(gc_watch)
+    try:
+        for _ in range(9):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            res = model.classify(st, **kw)
+            walls.append(time.perf_counter() - t)
+    finally:
+        gc.callbacks.remove(gc_watch)
     model._timing = {}
     model.classify(st, **kw)
     phases, model._timing = model._timing, None
@@ -308,9 +321,15 @@ def bench_api(model_name, model, batch):
     # the oracle on a 10-minute slice of the same stream (60,000 samples), and the HIP path on the same slice
     net = load_pretrained(model_name)
     ten = data[:, :60_000]
+    threads_before = torch.get_num_threads()
+    if oracle_threads:  # the thread count of cpu_baseline's fastest leg, not torch's default (all logical CPUs: 3x slower)
+        torch.set_num_threads(int(oracle_threads))
+    OP.classify_array(net, ten[:, :30_000], overlap=kw["overlap"], blinding=kw["blinding"], batch_size=batch)  # warm-up
     t = time.perf_counter()
     want = OP.classify_array(net, ten, overlap=kw["overlap"], blinding=kw["blinding"], batch_size=batch)
     t_cpu = time.perf_counter() - t
+    oracle_threads_used = torch.get_num_threads()
+    torch.set_num_threads(threads_before)
     st10 = va.Stream([va.Trace(ten[i], dict(network="XX", station="DAY", location="", channel=f"HH{c}", starttime=t0,
                                             sampling_rate=100.0)) for i, c in enumerate("ZNE")])
     got = model.classify(st10, **kw)
@@ -323,6 +342,11 @@ def bench_api(model_name, model, batch):
         "windows": n_windows,
         "wall_ms": wall * 1e3,
         "wall_ms_all": [w * 1e3 for w in walls],
+        "wall_statistic": f"median of {len(walls)} calls",
+        "full_gc_collections_in_timed_calls": [{"call": i, "pause_ms": ms} for i, ms in pauses],
+        "gc_note": "round 3's 65 ms call among 24-27 ms ones was a full (generation 2) collection of CPython's cyclic collector "
+                   "(30-37 ms in a process that has torch imported), driven by the ~10 k record objects each call built; classify() "
+                   "now keeps triggers as columns and builds Pick / Detection objects on first access (tools/api_outlier.py)",
         "value": n_windows / wall,
         "unit": "windows/s",
         "picks": len(res.picks),
@@ -333,7 +357,7 @@ def bench_api(model_name, model, batch):
                        "h2d with gpu segment by segment",
         "cpu_oracle_10min": {"windows": w10, "wall_ms": t_cpu * 1e3, "windows_per_s": w10 / t_cpu,
                              "picks_oracle": len(want_p), "picks_hip_same_slice": len(got_p), "picks_identical": want_p == got_p,
-                             "threads": torch.get_num_threads()},
+                             "threads": oracle_threads_used},
     }
 
 
@@ -627,11 +651,11 @@ def bench_model(model_name, env, cpu_budget_s):
         gathered = [None] * world
         dist.all_gather_object(gathered, info)
         result["ranks"] = gathered
-    if cpu_budget_s > 0 and not args.no_api:
-        result["api"] = bench_api(model_name, model, args.batch)
     if cpu_budget_s > 0:
         result["cpu_baseline"] = cpu_baseline(model_name, data, overlap, blinding, args.batch, cpu_budget_s)
         result["pick_parity"] = pick_parity(model, model_name, data, overlap, blinding, args.batch)
+    if cpu_budget_s > 0 and not args.no_api:
+        result["api"] = bench_api(model_name, model, args.batch, oracle_threads=result["cpu_baseline"]["cores"])
     model._release()
     return result
 
@@ -801,6 +825,17 @@ def host_cpu():
     return model, n_phys, logical
 
 
+def cpu_quota():
+    """CPUs' worth of time the cgroup grants this job (cgroup v2 cpu.max), or None: a one-GPU box hands out 16 of the
+    host's 256 logical CPUs that way -- affinity and /proc/cpuinfo still show them all, and threads beyond the quota are
+    throttled, not run."""
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        return None if quota == "max" else max(1, int(quota) // int(period))
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(model_name, data, overlap, blinding, batch, budget_s):
     """The CPU oracle (torch-CPU restatement of the reference path, kind "port": the stand-in for SeisBench on
     the CPU, which cannot be installed here) timed on this host over whole `batch`-window chunks of the bench
@@ -819,7 +854,8 @@ def cpu_baseline(model_name, data, overlap, blinding, batch, budget_s):
     step = T - overlap
     seg = data[:, : T + step * (batch - 1)]
     threads_before = torch.get_num_threads()
-    counts = sorted({1, min(8, n_phys), min(32, n_phys), n_phys})
+    quota = cpu_quota()
+    counts = sorted({1, min(8, n_phys), min(quota or 16, n_phys), min(32, n_phys), n_phys})
     share = budget_s / len(counts)
     legs = []
     for threads in counts:
@@ -851,6 +887,7 @@ def cpu_baseline(model_name, data, overlap, blinding, batch, budget_s):
         "cpu_model": cpu_model,
         "physical_cores": n_phys,
         "logical_cpus": n_logical,
+        "cgroup_cpu_quota": quota,
         "one_thread": {"value": one["value"], "cores": 1},
         "all_physical_cores": {"value": legs[-1]["value"], "cores": legs[-1]["threads"]},
         "legs": legs,

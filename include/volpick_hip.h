@@ -245,6 +245,11 @@ typedef struct {
   double mfma_f32_flop, mfma_bf16_flop, valu_flop;
 } vp_issued_work;
 int vp_step_issued_work(const vp_handle* h, int index, vp_issued_work* out);
+/* A launch whose tiling follows the output range the caller keeps (eqt_tail3_kernel: only the tiles that hold un-blinded
+ * samples) issues different work for different ranges.  vp_step_issued_work answers for the range the vp_profile_* calls
+ * time (the one the handle's latest preprocessing batch kept); this one for any [out_lo, out_hi) (out_hi <= 0: the whole
+ * row, what model(x) computes).  Pure: no launch changes what either reports. */
+int vp_step_issued_work_for_range(const vp_handle* h, int index, int out_lo, int out_hi, vp_issued_work* out);
 int vp_profile_steps(vp_handle* h, int B, int iters, float* step_ms, int cap);
 /* One step timed IN the pipeline: the whole list runs in order `iters` times, only step `index` is bracketed by
  * events (its inputs come from the preceding kernel, as under rocprofv3). */

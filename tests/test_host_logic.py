@@ -262,3 +262,41 @@ def test_resampling_rule_and_numerics():
     assert len(c) == 1250 and np.abs(c - 2.5).max() < 1e-9
     with pytest.raises(NotImplementedError):
         resample_array(np.ma.masked_array(x, mask=x > 2), 50.0, 100.0)
+
+
+def test_records_from_columns_sort_like_the_records_and_are_built_on_first_touch():
+    """classify() keeps triggers as columns and defers the Pick / Detection objects: the lists must equal what sorting the
+    records themselves gives (Pick order: start_time, trace_id, phase; stable), times rounded as UTCDateTime.__add__ rounds."""
+    from volpick_amd.models import _records_from_columns
+    from volpick_amd.picks import Detection, Pick
+
+    rng = np.random.default_rng(5)
+    labels = ["Detection", "P", "S"]
+    tids = ["XX.B.", "XX.A.", "XX.B."]  # two blocks of one station + another station
+    t0s = [va.UTCDateTime("2021-01-01T00:00:00")._us, va.UTCDateTime("2021-01-01T00:00:00.005")._us, va.UTCDateTime("2021-01-01T01:00:00")._us]
+    cols, want_p, want_d = [], [], []
+    for g in range(3):
+        m = 40
+        spec = rng.integers(0, 3, m).astype(np.int32)
+        on = rng.integers(0, 50, m).astype(np.int64)  # many ties in the start time
+        off, peak = on + rng.integers(1, 30, m), on + rng.integers(0, 5, m)
+        val = rng.random(m).astype(np.float32)
+        cols.append((g, spec, on, off, peak, val))
+        t0 = va.UTCDateTime._from_us(t0s[g])
+        for i in range(m):
+            if labels[spec[i]] == "Detection":
+                want_d.append(Detection(tids[g], t0 + int(on[i]) / 100.0, t0 + int(off[i]) / 100.0, float(val[i])))
+            else:
+                want_p.append(Pick(tids[g], t0 + int(on[i]) / 100.0, t0 + int(off[i]) / 100.0, t0 + int(peak[i]) / 100.0, float(val[i]),
+                                   labels[spec[i]]))
+    picks, dets = _records_from_columns(cols, tids, t0s, labels, 100.0)
+    assert picks._lazy is not None and len(picks) == len(want_p) and picks._lazy is not None  # len() builds nothing
+    assert list(picks) == sorted(want_p) and picks._lazy is None
+    assert list(dets) == sorted(want_d)
+    assert isinstance(picks.select(phase="P"), va.PickList) and {p.phase for p in picks.select(phase="P")} == {"P"}
+    both = va.PickList()
+    both += picks
+    both.append(want_p[0])
+    assert len(both) == len(want_p) + 1 and str(both).startswith(f"PickList with {len(want_p) + 1} entries")
+    empty_p, empty_d = _records_from_columns([], [], [], labels, 100.0)
+    assert len(empty_p) == 0 and list(empty_d) == []

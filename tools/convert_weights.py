@@ -15,7 +15,12 @@ repository, see volpick_amd/weights/LICENSE.weights); no reference source code
 is copied.  Run once in the build container:
 
     python tools/convert_weights.py [/root/reference]
+
+It also writes tests/golden/weights.sha256: one SHA-256 per tensor and per metadata JSON, computed FROM THE REFERENCE'S
+FILES (not from the converted copies).  tests/test_weights_pinned.py recomputes them from what the package ships, so the
+only hot-path data the reference pins stays pinned.
 """
+import hashlib
 import json
 import shutil
 import sys
@@ -35,7 +40,29 @@ SETS = {
 }
 
 
+def tensor_digest(name, a):
+    """SHA-256 over name, dtype, shape and the little-endian bytes of one tensor."""
+    a = np.ascontiguousarray(a)
+    h = hashlib.sha256()
+    h.update(f"{name}|{a.dtype.newbyteorder('<').str}|{','.join(map(str, a.shape))}|".encode())
+    h.update(a.astype(a.dtype.newbyteorder("<"), copy=False).tobytes())
+    return h.hexdigest()
+
+
+def json_digest(meta):
+    """SHA-256 of the metadata in canonical form (sorted keys, no insignificant white space)."""
+    return hashlib.sha256(json.dumps(meta, sort_keys=True, separators=(",", ":"), ensure_ascii=True).encode()).hexdigest()
+
+
+def digest_lines(model, name, arrays, meta):
+    lines = [f"{json_digest(meta)}  {model}/{name}.json"]
+    lines += [f"{tensor_digest(k, arrays[k])}  {model}/{name}.npz:{k}" for k in arrays]
+    return lines
+
+
 def main(ref_root="/root/reference"):
+    digests = ["# SHA-256 of every tensor and metadata JSON of the four released weight sets, computed by tools/convert_weights.py",
+               "# from /root/reference/Final_models/**/*.{pt,json}.v1 (tensor: name|dtype|shape|little-endian bytes; JSON: canonical form)"]
     ref = Path(ref_root) / "Final_models"
     for model, entries in SETS.items():
         out_dir = REPO / "volpick_amd" / "weights" / model
@@ -46,8 +73,10 @@ def main(ref_root="/root/reference"):
             np.savez(out_dir / f"{name}.npz", **arrays)
             meta = json.loads((ref / sub / f"{name}.json.v1").read_text())
             (out_dir / f"{name}.json").write_text(json.dumps(meta, indent=4) + "\n")
+            digests += digest_lines(model, name, arrays, meta)
             n = sum(a.size for a in arrays.values() if a.dtype == np.float32)
             print(f"{model}/{name}: {len(arrays)} tensors, {n} floats")
+    (REPO / "tests" / "golden" / "weights.sha256").write_text("\n".join(digests) + "\n")
     lic = Path(ref_root) / "LICENSE"
     if lic.exists():
         shutil.copy(lic, REPO / "volpick_amd" / "weights" / "LICENSE.weights")

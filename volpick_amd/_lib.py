@@ -138,6 +138,7 @@ SIGNATURES = {
     "vp_step_info": (C.c_int, [_H, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double)]),
     "vp_flops_per_window": (C.c_double, [_H]),
     "vp_step_issued_work": (C.c_int, [_H, C.c_int, C.POINTER(VpIssuedWork)]),
+    "vp_step_issued_work_for_range": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.POINTER(VpIssuedWork)]),
     "vp_step_issued_flops": (C.c_int, [_H, C.c_int, C.POINTER(C.c_double)]),
     "vp_profile_steps": (C.c_int, [_H, C.c_int, C.c_int, _FP, C.c_int]),
     "vp_profile_step_in_pipeline": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, _FP]),

@@ -19,7 +19,7 @@ struct vp_handle {
   bool timing = false;  // stage events cost ~5 us of stream bubble each: off unless vp_set_timing(h, 1)
   float stage_ms[4] = {0.f, 0.f, 0.f, 0.f};
   // the window description of the latest preprocessing batch: the vp_profile_* calls replay it through plans whose first
-  // launch cuts its windows itself (the caller keeps that stream buffer alive while profiling)
+  // launch cuts its windows itself -- after checking that what it points to is still allocated (pre_is_replayable)
   vp::PreArgs last_pre{};
   int last_pre_windows = 0;
   int last_out_lo = 0, last_out_hi = 0;  // ... and the kept output range of that batch (Net::out_lo / out_hi)
@@ -930,7 +930,10 @@ int vp_step_info(const vp_handle* h, int index, const char** name, double* flops
 
 int vp_step_issued_flops(const vp_handle* h, int index, double* issued_flops_per_window) {
   VP_REQUIRE(h && issued_flops_per_window && index >= 0 && index < (int)h->net.steps.size(), "bad step index");
-  *issued_flops_per_window = h->net.steps[index].issued_flops_per_window;
+  vp_issued_work w;
+  const int rc = vp_step_issued_work(h, index, &w);
+  if (rc != VP_OK) return rc;
+  *issued_flops_per_window = w.mfma_f32_flop + w.mfma_bf16_flop / 6.0 + w.valu_flop;
   return VP_OK;
 }
 
@@ -940,16 +943,66 @@ int vp_step_issued_work(const vp_handle* h, int index, vp_issued_work* out) {
   out->mfma_f32_flop = s.issued_f32;
   out->mfma_bf16_flop = s.issued_bf16;
   out->valu_flop = s.issued_valu;
+  if (s.issued_for_range) {  // the tiling the vp_profile_* calls time: the output range the latest preprocessing batch kept
+    double w[3];
+    s.issued_for_range(h->net, h->last_out_lo, h->last_out_hi, w);
+    out->mfma_f32_flop = w[0], out->mfma_bf16_flop = w[1], out->valu_flop = w[2];
+  }
+  return VP_OK;
+}
+
+int vp_step_issued_work_for_range(const vp_handle* h, int index, int out_lo, int out_hi, vp_issued_work* out) {
+  VP_REQUIRE(h && out && index >= 0 && index < (int)h->net.steps.size(), "bad step index");
+  const vp::Step& s = h->net.steps[index];
+  double w[3] = {s.issued_f32, s.issued_bf16, s.issued_valu};
+  if (s.issued_for_range) s.issued_for_range(h->net, out_lo, out_hi, w);
+  out->mfma_f32_flop = w[0], out->mfma_bf16_flop = w[1], out->valu_flop = w[2];
   return VP_OK;
 }
 double vp_flops_per_window(const vp_handle* h) { return h ? h->net.flops_per_window : 0.0; }
 
 // Plans whose first launch cuts and normalises its windows itself are profiled the way they run: on the windows of the
 // handle's latest preprocessing batch (when it had at least B of them); otherwise on the input tensor.
+// The description is only a description: its src / table pointers may be the caller's device stream, the handle's staging
+// buffer or the window table of a vp_classify_multi call, any of which may have been freed or regrown since.  It is
+// replayed only if every byte the first B windows would read still lies inside a live device allocation
+// (hipMemGetAddressRange fails for a pointer that has been freed); otherwise the launches read the input tensor.
+static bool range_is_live(const void* p, size_t bytes) {
+  if (!p) return false;
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  if (hipMemGetAddressRange(&base, &size, const_cast<void*>(p)) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  const char* lo = static_cast<const char*>(base);
+  const char* q = static_cast<const char*>(p);
+  return q >= lo && bytes <= size && (size_t)(q - lo) <= size - bytes;
+}
+
+static bool pre_is_replayable(const vp::PreArgs& pa, int B) {
+  if (!pa.src || B <= 0) return false;
+  if (pa.dense) return range_is_live(pa.src, (size_t)B * 3 * pa.T * sizeof(float));
+  if (!pa.table) return pa.N >= pa.T && range_is_live(pa.src, (size_t)3 * pa.N * sizeof(float));
+  const size_t n = (size_t)(pa.first_window + B) * 3;
+  if (!range_is_live(pa.table, n * sizeof(long))) return false;
+  std::vector<long> tab(n);
+  if (hipMemcpy(tab.data(), pa.table, n * sizeof(long), hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  for (long w = pa.first_window; w < pa.first_window + B; ++w) {  // (block offset in src, block length, window start)
+    const long off = tab[3 * w], len = tab[3 * w + 1], start = tab[3 * w + 2];
+    if (off < 0 || len < pa.T || start < 0 || start + pa.T > len) return false;
+    if (!range_is_live(pa.src + off, (size_t)3 * len * sizeof(float))) return false;
+  }
+  return true;
+}
+
 struct ProfilePre {
   vp::Net& net;
   ProfilePre(vp_handle* h, int B) : net(h->net) {
-    if (net.fused_pre && h->last_pre_windows >= B && h->last_pre.src) net.pre = &h->last_pre;
+    if (net.fused_pre && h->last_pre_windows >= B && pre_is_replayable(h->last_pre, B)) net.pre = &h->last_pre;
     net.out_lo = h->last_out_lo, net.out_hi = h->last_out_hi;  // the launches are profiled over the range the last call kept
   }
   ~ProfilePre() {

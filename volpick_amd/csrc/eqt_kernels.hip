@@ -9,6 +9,14 @@
 // for the first team and on SIMDs 2, 3 for the second (hardware wave h runs on SIMD h % 4).
 #define MID_TID ((threadIdx.x + ((threadIdx.x >> 9) << 7)) & 511)
 #define MID_NT (blockDim.x > 512u ? 512u : blockDim.x)  // threads of a window's team
+// The two-window form shares its barriers, not its decisions: a vote (which form a window's attention scores take) is ONE
+// workgroup-wide OR reduction in which every team sets its own bit and reads only that bit back, so what a window computes
+// never depends on the window it shares a workgroup with (same barrier count on both teams, no extra LDS).
+#define MID_TEAM (threadIdx.x >> 9)
+__device__ __forceinline__ bool team_vote_or(bool mine) {
+  const int team = __builtin_amdgcn_readfirstlane(MID_TEAM);  // wave-uniform: the result steers scalar branches
+  return __builtin_amdgcn_readfirstlane((__ockl_wgred_or_i32(mine ? (1 << team) : 0) >> team) & 1) != 0;
+}
 
 namespace vp {
 
@@ -310,7 +318,7 @@ __device__ void attention_core(const float (*xs)[EQT_H], float (*q)[KP], float (
     k[t][u] = ak;
     big |= !(fabsf(aq) <= 30.f) || !(fabsf(ak) <= 30.f);  // also catches NaN
   }
-  const bool plain = __syncthreads_or(big);  // barrier: q / k complete
+  const bool plain = team_vote_or(big);  // barrier: q / k complete
   if (!plain) {
     for (int idx = tid; idx < T * 32; idx += nt) {
       const int t = idx >> 5, u = idx & 31;
@@ -379,7 +387,7 @@ __device__ void mid_attention(const AttnFrag& f, const float wa_lane, const floa
         for (int r = 0; r < 4; ++r) big |= !(fabsf(acc[n][r]) <= 30.f) && (16 * (nt0 + n) + (lane & 15) < T);
       }
     }
-    const bool plain = __syncthreads_or(big);  // only the vote: nothing has been written yet
+    const bool plain = team_vote_or(big);  // only the vote: nothing has been written yet
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
       const int t = 16 * (nt0 + n) + (lane & 15);

@@ -322,6 +322,27 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
 #undef T3_STAMP
 }
 
+// The tiling of one launch, a pure function of the output range the caller keeps (annotate / classify: [blind_l, T - blind_r);
+// model(x): the whole row, out_hi <= 0) -- the form that needs fewer tiles; plan_flags[7] bit 10 computes the whole row
+// whatever the blinding (A/B, tests).  issued_bf16: matrix work per WINDOW, groups of six bf16 MFMAs (one 16 x 16 x 32
+// fp32-accurate product each) over the three decoders' tiles.
+struct Tail3Tiling {
+  int t_lo, tiles_per_row;
+  bool wide;
+  double issued_bf16;
+};
+Tail3Tiling tail3_tiling(const vp_config& cfg, int out_lo, int out_hi) {
+  const bool whole = (cfg.plan_flags[7] & 1024) || out_hi <= 0;
+  const int t_lo = whole ? 0 : (out_lo / 16) * 16, t_hi = whole ? T_OUT : out_hi;
+  const int tiles_a = (t_hi - t_lo + 1199) / 1200, tiles_b = (t_hi - t_lo + 1263) / 1264;
+  Tail3Tiling t;
+  t.wide = tiles_b < tiles_a;
+  t.t_lo = t_lo;
+  t.tiles_per_row = t.wide ? tiles_b : tiles_a;
+  t.issued_bf16 = 3.0 * t.tiles_per_row * (t.wide ? T3<1264>::GROUPS : T3<1200>::GROUPS) * 6 * 16384.0;
+  return t;
+}
+
 }  // namespace
 
 // Replaces the steps "decoder.4", "decoder.5", "decoder.6+heads" of the plan by one fused step (bf16-piece form).
@@ -385,9 +406,6 @@ int plan_eqt_fuse_tail_b3(Net& net) {
   st.name = "fused.tail (decoder.4-6 + heads, time-tiled)";
   st.flops_per_window = 0;
   for (int i = 0; i < 3; ++i) st.flops_per_window += net.steps[first + i].flops_per_window;
-  {  // matrix work issued per tile: groups of six bf16 MFMAs (one 16 x 16 x 32 fp32-accurate product each)
-    st.set_issued(0.0, 3.0 * 5 * T3<1200>::GROUPS * 6 * 16384.0, 0.0);  // the whole row; a launch over a blinded range sets its own (below)
-  }
   st.run = [=](Net& n, int B, hipStream_t s) -> int {
     Tail3Args a{};
     const Tensor& t3 = n.tensors[x3];
@@ -408,15 +426,11 @@ int plan_eqt_fuse_tail_b3(Net& net) {
     a.B = B;
     // the outputs the caller keeps (annotate / classify: [blind_l, T - blind_r); model(x): the whole row), in the tiling that
     // needs fewer tiles; plan_flags[7] bit 10 computes the whole row whatever the blinding (A/B, tests)
-    const bool whole = (n.cfg.plan_flags[7] & 1024) || n.out_hi <= 0;
-    const int t_lo = whole ? 0 : (n.out_lo / 16) * 16, t_hi = whole ? T_OUT : n.out_hi;
-    const int tiles_a = (t_hi - t_lo + 1199) / 1200, tiles_b = (t_hi - t_lo + 1263) / 1264;
-    const bool wide = tiles_b < tiles_a;
-    a.t_lo = t_lo;
-    a.tiles_per_row = wide ? tiles_b : tiles_a;
+    const Tail3Tiling tl = tail3_tiling(n.cfg, n.out_lo, n.out_hi);
+    const bool wide = tl.wide;
+    a.t_lo = tl.t_lo;
+    a.tiles_per_row = tl.tiles_per_row;
     a.n_tiles = 3 * B * a.tiles_per_row;
-    if (!n.steps.empty() && n.steps.back().name.rfind("fused.tail", 0) == 0)  // what THIS launch issues (vp_step_issued_work)
-      n.steps.back().set_issued(0.0, 3.0 * a.tiles_per_row * (wide ? T3<1264>::GROUPS : T3<1200>::GROUPS) * 6 * 16384.0, 0.0);
     a.clk = (n.debug_clock && n.debug_clock->d)
                 ? reinterpret_cast<unsigned long long*>(n.debug_clock->d) + (size_t)n.max_batch * 32 + 64 * 8
                 : nullptr;
@@ -429,6 +443,10 @@ int plan_eqt_fuse_tail_b3(Net& net) {
   };
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_tail3_kernel<1200>), (size_t)T3<1200>::LDS_BYTES});
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_tail3_kernel<1264>), (size_t)T3<1264>::LDS_BYTES});
+  st.issued_for_range = [](const Net& n, int lo, int hi, double* w) {
+    w[0] = 0.0, w[1] = tail3_tiling(n.cfg, lo, hi).issued_bf16, w[2] = 0.0;
+  };
+  st.set_issued(0.0, tail3_tiling(net.cfg, 0, 0).issued_bf16, 0.0);  // the whole row
   net.steps.erase(net.steps.begin() + first, net.steps.begin() + first + 3);
   net.steps.push_back(std::move(st));
   net.poison_in_plan = true;  // no poison_kernel launch behind this plan

@@ -43,6 +43,9 @@ struct Step {
     issued_f32 = f32, issued_bf16 = bf16, issued_valu = valu;
     issued_flops_per_window = f32 + bf16 / 6.0 + valu;
   }
+  // A launch whose tiling depends on the output range the caller keeps (Net::out_lo / out_hi) says what it issues for a
+  // given range through this pure function; the fields above then hold the whole-row figure and run() never touches them.
+  std::function<void(const Net&, int /*out_lo*/, int /*out_hi*/, double* /*f32, bf16, valu*/)> issued_for_range;
 };
 
 constexpr int kDenseOut = -2;

@@ -47,6 +47,38 @@ def OrderedDictTensors(arrays, torch):
     return OrderedDict((k, torch.from_numpy(np.array(v, order="C"))) for k, v in arrays.items())
 
 
+def _no_triggers():
+    return (np.empty(0, np.int32), np.empty(0, np.int64), np.empty(0, np.int64), np.empty(0, np.int64), np.empty(0, np.float32))
+
+
+def _records_from_columns(cols, tids, t0s, labels, sr):
+    """Trigger columns of all station blocks -> (PickList, DetectionList), sorted as the records sort ((start_time,
+    trace_id, phase) / (start_time, trace_id), stable), the records deferred.  Times: t0 + k / sr in integer microseconds,
+    rounded as stream.UTCDateTime.__add__ rounds (float64 k / sr * 1e6, half to even)."""
+    if not cols:
+        return PickList(), DetectionList()
+    grp = np.concatenate([np.full(len(c[1]), c[0], np.int64) for c in cols])
+    spec, on, off, peak, val = (np.concatenate([c[i] for c in cols]) for i in range(1, 6))
+    t0 = np.asarray(t0s, np.int64)[grp]
+    us = lambda k: t0 + np.rint(k / float(sr) * 1e6).astype(np.int64)
+    start, end, top = us(on), us(off), us(peak)
+    order = {t: i for i, t in enumerate(sorted(set(tids)))}  # equal ids (two blocks of one station) compare equal
+    tid_rank = np.asarray([order[t] for t in tids], np.int64)[grp]
+    lab_rank = np.asarray([sorted(set(labels)).index(l) for l in labels], np.int64)[spec] if labels else spec
+    is_det = np.asarray([l == "Detection" for l in labels], bool)[spec]
+    U = UTCDateTime._from_us
+
+    def build(mask, keys, make_one):
+        idx = np.flatnonzero(mask)
+        idx = idx[np.lexsort(tuple(k[idx] for k in keys))]
+        g, s_, a, b, c, v = grp[idx].tolist(), spec[idx].tolist(), start[idx].tolist(), end[idx].tolist(), top[idx].tolist(), val[idx].tolist()
+        return len(idx), (lambda: [make_one(tids[g[i]], a[i], b[i], c[i], v[i], labels[s_[i]]) for i in range(len(g))])
+
+    n_p, make_p = build(~is_det, (lab_rank, tid_rank, start), lambda tid, a, b, c, v, ph: Pick(tid, U(a), U(b), U(c), v, ph))
+    n_d, make_d = build(is_det, (tid_rank, start), lambda tid, a, b, c, v, ph: Detection(tid, U(a), U(b), v))
+    return PickList._deferred(n_p, make_p), DetectionList._deferred(n_d, make_d)
+
+
 class WaveformModel:
     """Common host logic: weight registry, device handle, stream handling, annotate/classify."""
 
@@ -468,13 +500,14 @@ class WaveformModel:
             tm["windows"] = tm.get("windows", 0) + n_windows
         return out, fv, lv, n_windows
 
-    def _pick_rows(self, dev_out, specs, cap=8192):
-        """Trigger scan of the rows of a device (n_out, N) array -> [(spec_index, on, off, peak, value)]."""
+    def _pick_rows(self, dev_out, specs, cap=8192, columns=False):
+        """Trigger scan of the rows of a device (n_out, N) array -> [(spec_index, on, off, peak, value)]
+        (``columns=True``: the same as five arrays)."""
         lib = _lib.load()
         h = self._ensure_handle()
         n = dev_out.shape[1]
         if not specs:
-            return []
+            return _no_triggers() if columns else []
         dev_out = dev_out.contiguous()  # (a column slice of the stacked rows is a strided view)
         self._torch_sync(dev_out)
         c_specs = (_lib.VpTriggerSpec * len(specs))(*[_lib.VpTriggerSpec(r, on, off) for r, _, on, off in specs])
@@ -490,6 +523,8 @@ class WaveformModel:
                 break
             cap = found.value
         m = found.value  # grouped by spec, sorted by onset inside each group
+        if columns:
+            return spec_of[:m], on[:m], off[:m], peak[:m], val[:m]
         return list(zip(spec_of[:m].tolist(), on[:m].tolist(), off[:m].tolist(), peak[:m].tolist(), val[:m].tolist()))
 
     @staticmethod
@@ -533,8 +568,9 @@ class WaveformModel:
                                           len(specs), None, _lib.VP_MEM_DEVICE, cap), "vp_classify_submit")
         return {"ctx": ctx, "x": x, "cap": cap, "data": data}  # x must outlive the submit
 
-    def _collect_block(self, job, args, specs):
-        """Wait for a submitted block -> ([(spec_index, on, off, peak, value)], n_windows)."""
+    def _collect_block(self, job, args, specs, columns=False):
+        """Wait for a submitted block -> ([(spec_index, on, off, peak, value)], n_windows)
+        (``columns=True``: the triggers as five arrays)."""
         lib = _lib.load()
         h = self._context(job["ctx"])
         cap = job["cap"]
@@ -545,8 +581,12 @@ class WaveformModel:
                                            cap, C.byref(found)), "vp_classify_collect")
         if found.value > cap:  # rare: more triggers than the result block holds -> redo this block with room
             job2 = self._submit_block(job["ctx"], job["data"], args, specs, found.value)
-            return self._collect_block(job2, args, specs)
-        return [(spec_of[i], on[i], off[i], peak[i], val[i]) for i in range(found.value)], nw.value
+            return self._collect_block(job2, args, specs, columns)
+        m = found.value
+        if columns:
+            col = lambda a, dt: np.frombuffer(a, dtype=dt, count=m).copy() if m else np.empty(0, dt)
+            return (col(spec_of, np.int32), col(on, np.int64), col(off, np.int64), col(peak, np.int64), col(val, np.float32)), nw.value
+        return [(spec_of[i], on[i], off[i], peak[i], val[i]) for i in range(m)], nw.value
 
     def _classify_blocks(self, groups, args, specs, cap_per_row=256):
         """Blocks of several stations in ONE library call -> one trigger list per block."""
@@ -611,20 +651,23 @@ class WaveformModel:
         args = self._argdict(kwargs)
         specs = self._trigger_specs(args)
         sr = self.sampling_rate
-        # Triggers are gathered as plain tuples keyed like Pick / Detection sort (start time in integer microseconds, trace
-        # id, phase) and turned into records after ONE sort of those tuples: sorting the dataclass objects themselves
-        # builds a key tuple of UTCDateTime objects per comparison (a station-day: ~5 ms of a 28 ms call).
-        raw_p, raw_d = [], []
-        us = lambda t0, k: t0._us + int(round(float(k / sr) * 1e6))  # == (t0 + k / sr)._us (stream.UTCDateTime.__add__)
+        # Triggers stay COLUMNS (numpy) from the library's result arrays to the sorted record lists: times in integer
+        # microseconds, one stable lexsort by Pick / Detection order (start time, trace id, phase), and the records
+        # themselves are built when the caller first touches the list (picks._PrintableList._deferred).
+        cols = []  # (group index, spec indices, on, off, peak, value) per emitted trigger list
+        tids, t0s = [], []
 
         def emit(grp, triggers):
-            t0, tid = grp["starttime"], grp["trace_id"]
-            for si, on, off, pk, v in triggers:
-                label = specs[si][1]
-                if label == "Detection":
-                    raw_d.append((us(t0, on), tid, us(t0, off), v))
-                else:
-                    raw_p.append((us(t0, on), tid, label, us(t0, off), us(t0, pk), v))
+            if not isinstance(triggers, tuple):  # [(spec, on, off, peak, value)] of the multi-block call
+                if not triggers:
+                    return
+                z = list(zip(*triggers))
+                triggers = (np.asarray(z[0], np.int32), np.asarray(z[1], np.int64), np.asarray(z[2], np.int64),
+                            np.asarray(z[3], np.int64), np.asarray(z[4], np.float32))
+            if len(triggers[0]):
+                cols.append((len(tids),) + triggers)
+                tids.append(grp["trace_id"])
+                t0s.append(grp["starttime"]._us)
 
         # Blocks already on the device (read(..., device_resident=True)) are classified several at a time: their
         # windows share the forward batches (SeisBench's batch_size spans the whole stream) and stacking / trigger
@@ -638,7 +681,7 @@ class WaveformModel:
 
         def flush_chunk():
             if len(chunk) == 1:
-                emit(chunk[0], self._classify_block(chunk[0]["data"], args, specs)[0])
+                emit(chunk[0], self._collect_block(self._submit_block(0, chunk[0]["data"], args, specs, 8192), args, specs, True)[0])
             elif chunk:
                 for g0, triggers in zip(chunk, self._classify_blocks(chunk, args, specs)):
                     emit(g0, triggers)
@@ -649,13 +692,13 @@ class WaveformModel:
         for grp in _group_stream(stream, self.component_order, sr, copy, self.in_samples):
             if self._is_long(grp["data"].shape[1], args):  # a day-long block: its segments occupy all contexts
                 for g0, job in pending:
-                    emit(g0, self._collect_block(job, args, specs)[0])
+                    emit(g0, self._collect_block(job, args, specs, True)[0])
                 pending = []
                 if tm is not None:
                     tm["host_assembly_ms"] = tm.get("host_assembly_ms", 0.0) + (time.perf_counter() - t_mark) * 1e3
                 dev_out, fv, lv, nw = self._annotate_segments(grp["data"], args)
                 t_mark = time.perf_counter()
-                found = self._pick_rows(dev_out, specs)
+                found = self._pick_rows(dev_out, specs, columns=True)
                 if tm is not None:
                     tm["pick_scan_d2h_ms"] = tm.get("pick_scan_d2h_ms", 0.0) + (time.perf_counter() - t_mark) * 1e3
                     t_mark = time.perf_counter()
@@ -674,18 +717,14 @@ class WaveformModel:
                 continue
             if len(pending) == max(1, self.n_contexts):
                 g0, job = pending.pop(0)
-                emit(g0, self._collect_block(job, args, specs)[0])
+                emit(g0, self._collect_block(job, args, specs, True)[0])
             pending.append((grp, self._submit_block(n_host % max(1, self.n_contexts), grp["data"], args, specs, 8192)))
             n_host += 1  # host blocks only: device-resident blocks take the chunk path and must not advance the context
         for g0, job in pending:
-            emit(g0, self._collect_block(job, args, specs)[0])
+            emit(g0, self._collect_block(job, args, specs, True)[0])
         flush_chunk()
         t_mark = time.perf_counter()
-        U = UTCDateTime._from_us
-        raw_p.sort(key=lambda r: r[:3])  # stable, like sorted() on the records: (start_time, trace_id, phase)
-        raw_d.sort(key=lambda r: r[:2])
-        picks = PickList(Pick(tid, U(a), U(b), U(c), v, ph) for a, tid, ph, b, c, v in raw_p)
-        detections = DetectionList(Detection(tid, U(a), U(b), v) for a, tid, b, v in raw_d)
+        picks, detections = _records_from_columns(cols, tids, t0s, [sp[1] for sp in specs], sr)
         if tm is not None:
             tm["emit_records_ms"] = tm.get("emit_records_ms", 0.0) + (time.perf_counter() - t_mark) * 1e3
         return ClassifyOutput(self.name, picks=picks, detections=detections)
