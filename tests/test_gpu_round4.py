@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 def _scaled_attention(scale, flags=()):
     m = EQTransformer.from_pretrained("volpick")
     sd = m.state_dict()
-    for key in ("transformer_d0.attention.Wt", "transformer_d0.attention.Wx", "transformer_d.attention.Wt", "transformer_d.attention.Wx"):
+    for key in ("transformer_d0.attention.Wt", "transformer_d0.attention.Wx"):  # the first attention layer only: its input does not move
         sd[key] = sd[key] * np.float32(scale)
     m.load_state_dict(sd)
     m._plan_flags = flags
@@ -36,34 +36,32 @@ def test_a_windows_attention_form_does_not_depend_on_its_workgroup_partner():
     oracle = load_pretrained("eqtransformer")
     seen = {}
     hooks = [getattr(oracle, name).attention.register_forward_hook(lambda mod, inp, out, name=name: seen.__setitem__(name, inp[0].detach()))
-             for name in ("transformer_d0", "transformer_d")]
+             for name in ("transformer_d0",)]
     import oracle.pipeline as OP
 
     with torch.no_grad():
         oracle(OP.batch_pre(oracle, torch.from_numpy(x)))
     for hk in hooks:
         hk.remove()
-    # per window: max |x Wt|, |x Wx + bh| over both attention layers, per unit of scale (bh is small against the products)
-    amp = np.zeros(B)
-    for name, xin in seen.items():
-        att = getattr(oracle, name).attention
-        xin = xin if xin.shape[-1] == att.Wt.shape[0] else xin.transpose(1, 2)
-        q, k = (xin @ att.Wt).abs().amax(dim=(1, 2)), (xin @ att.Wx).abs().amax(dim=(1, 2))
-        amp = np.maximum(amp, torch.maximum(q, k).numpy())
-    scale = 30.0 / np.median(amp)  # about half of the windows beyond the guard
-    big = amp * scale > 33.0
-    small = amp * scale < 27.0
+    # per window: max |x Wt|, |x Wx + bh| of the first attention layer, per unit of scale
+    att, xin = oracle.transformer_d0.attention, seen["transformer_d0"]
+    xin = xin if xin.shape[-1] == att.Wt.shape[0] else xin.transpose(1, 2)  # (B, T, 16)
+    with torch.no_grad():
+        top = lambda t: t.abs().amax(dim=(1, 2)).numpy()
+        scale = 30.0 / np.median(np.maximum(top(xin @ att.Wt), top(xin @ att.Wx)))  # about half of the windows beyond the guard
+        worst = np.maximum(top(xin @ (att.Wt * scale)), top(xin @ (att.Wx * scale) + att.bh))
+    big, small = worst > 30.0 * 1.02, worst < 30.0 * 0.98
     mixed_pairs = int(sum((big[2 * i] and small[2 * i + 1]) or (small[2 * i] and big[2 * i + 1]) for i in range(B // 2)))
-    assert mixed_pairs >= 4, (mixed_pairs, np.sort(amp * scale))
+    assert mixed_pairs >= 4, (mixed_pairs, np.sort(worst))
     two, _ = _scaled_attention(scale)
     one, _ = _scaled_attention(scale, (0, 0, 2))
     xt = torch.from_numpy(x).cuda()
     a, b = two._forward_raw(xt, preprocess=True), one._forward_raw(xt, preprocess=True)
     assert torch.isfinite(a).all()
     assert torch.equal(a, b)
-    # ... and whatever a window is paired with: the same windows in reversed order
-    c = two._forward_raw(torch.flip(xt, dims=[0]).contiguous(), preprocess=True)
-    assert torch.equal(torch.flip(c, dims=[0]), a)
+    # ... and whatever a window is paired with: the same windows shifted by one (every window gets another partner)
+    c = two._forward_raw(torch.roll(xt, 1, 0).contiguous(), preprocess=True)
+    assert torch.equal(torch.roll(c, -1, 0), a)
     two._release(), one._release()
 
 
