@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--sustain-seconds", type=float, default=5.2,
                     help="length of the one long timed region per model reported as `sustained` (0 = skip)")
     ap.add_argument("--no-api", action="store_true", help="skip the `api` object (classify() on a host 24 h stream)")
+    ap.add_argument("--no-train", action="store_true", help="skip the `train` object (BASELINE configs[4]: bf16 training step, B = 512)")
+    ap.add_argument("--no-mseed", action="store_true", help="skip the `mseed` object (SURVEY 8f-1: Steim-2 station-day decode)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the N > 1 plumbing on a ONE-GPU box: process group over gloo, every rank on cuda:0, weights "
                          "through the host broadcast (no RCCL); the line it prints is not a measurement")
@@ -194,6 +196,16 @@ def main():
             result["eqtransformer"] = {k: eq[k] for k in ("value", "unit", "ms_per_step", "timing", "sustained", "config",
                                                           "roofline", "forward", "api", "ranks", "cpu_baseline",
                                                           "pick_parity") if k in eq}
+    # the two widened rows that have a throughput of their own (N = 1, the default run only): each a few seconds
+    if world == 1 and not args.strong and args.model == "both" and not args.no_cpu_baseline:
+        for key, skip, fn in (("train", args.no_train, bench_train), ("mseed", args.no_mseed, bench_mseed)):
+            if not skip:
+                t0 = time.perf_counter()
+                try:
+                    result[key] = fn()
+                except Exception as e:  # noqa: BLE001 -- a widened row must not cost the headline line
+                    result[key] = {"error": repr(e)[:400]}
+                result[key]["bench_seconds"] = time.perf_counter() - t0
     if rank == 0:
         print(json.dumps(result))
     if use_dist:
@@ -359,6 +371,165 @@ def bench_api(model_name, model, batch, oracle_threads=None):
                              "picks_oracle": len(want_p), "picks_hip_same_slice": len(got_p), "picks_identical": want_p == got_p,
                              "threads": oracle_threads_used},
     }
+
+
+def bench_train(batch=512, steps=30, warmup=5, torch_steps=6):
+    """BASELINE configs[4]: one PhaseNet training step (forward in training mode, vector cross-entropy, backward, Adam;
+    /root/reference volpick/model/models.py:34-51,160-185) on VCSEIS-shaped synthetic batches resident in HBM, activation /
+    gradient rows stored as bfloat16 with fp32 accumulation (vp_train_create_dtype(VP_TRAIN_BF16)).  Beside it, as the
+    stated baseline, the same step through stock PyTorch-ROCm autograd (eager, bf16 autocast) on the same GPU."""
+    import torch
+
+    import volpick_amd as va
+    from volpick_amd.synthetic import synthetic_windows
+    from volpick_amd.train import PhaseNetTrainer, gaussian_labels
+
+    rng = np.random.default_rng(1005)
+    x = synthetic_windows(batch, 3001, seed=1005)
+    x = x - x.mean(-1, keepdims=True)
+    x = (x / (np.abs(x).max(-1, keepdims=True) + 1e-10)).astype(np.float32)
+    p = rng.integers(300, 1500, batch).astype(float)
+    y = gaussian_labels(p, p + rng.integers(200, 1200, batch))
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    tr = PhaseNetTrainer(va.PhaseNet.from_pretrained("volpick"), max_batch=batch, dtype="bf16")
+    for _ in range(warmup):
+        tr.step(xd, yd, 1e-4, want_loss=False)
+    tr.synchronize()
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.step(xd, yd, 1e-4, want_loss=False)
+        tr.synchronize()
+        times.append((time.perf_counter() - t0) / steps)
+    dt = statistics.median(times)
+    loss = tr.step(xd, yd, 1e-4)
+    launches = int(tr._lib.vp_train_launch_count(tr._h))
+    flop = 3 * 38.93e6  # SURVEY 8d: forward FLOP per 3x3001 window; backward = input gradient + weight gradient = 2x
+    out = {
+        "metric": "PhaseNet training windows/sec (fwd + loss + bwd + Adam)", "value": batch / dt, "unit": "windows/s",
+        "ms_per_step": dt * 1e3, "ms_per_step_all": [t * 1e3 for t in times], "batch": batch, "steps": steps, "warmup": warmup,
+        "dtype": "bf16 storage / f32 accumulate", "data": "synthetic (VCSEIS-shaped: 3 x 3001, Gaussian P/S labels sigma 20)",
+        "launches_per_step": launches, "loss_after": loss,
+        "roofline": {"bound": "mfma", "achieved": flop * batch / dt / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": flop * batch / dt / (PEAK_FP32_TFLOPS * 1e12),
+                     "basis": "algorithmic 3 x forward FLOP of the whole step (all launches) / step time, against the dense fp32 "
+                              "rate the reference arithmetic is priced in; the convs run the fp32 MFMA on widened operands, the "
+                              "weight gradients the bf16 MFMA (exact on bf16-stored rows)"},
+    }
+    tr.close()
+    # the same step through stock PyTorch-ROCm (MIOpen / rocBLAS kernels, eager autograd) on this GPU
+    try:
+        from oracle.models import load_pretrained
+
+        t_setup = time.perf_counter()
+        net = load_pretrained("phasenet").cuda().train()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+
+        def torch_step():
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                pred = net(xd)
+            l = -(yd * torch.log(pred.float() + 1e-5)).mean(-1).sum(-1).mean()
+            l.backward()
+            opt.step()
+
+        for _ in range(2):
+            torch_step()
+        torch.cuda.synchronize()
+        t_setup = time.perf_counter() - t_setup
+        t0 = time.perf_counter()
+        for _ in range(torch_steps):
+            torch_step()
+        torch.cuda.synchronize()
+        gt = (time.perf_counter() - t0) / torch_steps
+        out["torch_rocm_same_gpu"] = {"value": batch / gt, "unit": "windows/s", "ms_per_step": gt * 1e3, "first_steps_s": t_setup,
+                                      "note": f"torch {torch.__version__} eager autograd + torch.optim.Adam, bf16 autocast, batch {batch}: the "
+                                              "stated baseline of this row (the reference trains through PyTorch Lightning on one GPU)"}
+        out["vs_torch_rocm"] = gt / dt
+        del net, opt
+    except Exception as e:  # noqa: BLE001 -- the baseline is context, its failure must not cost the line
+        out["torch_rocm_same_gpu"] = {"error": repr(e)[:300]}
+    return out
+
+
+def bench_mseed(hours=24, iters=30):
+    """SURVEY 8f-1 (what feeds A1; /root/reference volpick/data/convert.py:7 reads through obspy): Steim-2 decode of one
+    three-component station-day (100 Hz, 4096-byte records) with the file resident in HBM -- vp_mseed_decode, HIP events
+    around `iters` launches (vp_mseed_decode_bench).  Input: the committed six-minute fixture tests/golden/
+    bench_steim2_6min.mseed tiled to 24 h by patching the records' start times (records then arrive out of time order,
+    as archives deliver them).  Checked against the fixture's own samples; the CPU decoder of oracle/mseed.py beside it."""
+    import struct
+    from datetime import datetime, timedelta, timezone
+
+    import torch
+
+    import volpick_amd as va
+    import volpick_amd.io as vio
+    from volpick_amd import _lib
+
+    lib = _lib.load()
+    blob0 = (ROOT / "tests" / "golden" / "bench_steim2_6min.mseed").read_bytes()
+    want = np.load(ROOT / "tests" / "golden" / "bench_steim2_6min_samples.npz")
+    recs0 = vio.scan_mseed(blob0)
+    tiles = hours * 10
+    epoch = datetime(1970, 1, 1, tzinfo=timezone.utc)
+    parts = []
+    for k in range(tiles):
+        b = bytearray(blob0)
+        for r in recs0:
+            t = epoch + timedelta(microseconds=int(r["start_us"]) + k * 360_000_000)
+            # the BTIME carries 100 us units; a blockette 1001 of the record keeps its microsecond offset
+            struct.pack_into(">HHBBBBH", b, int(r["offset"]) + 20, t.year, t.timetuple().tm_yday, t.hour, t.minute, t.second, 0,
+                             t.microsecond // 100)
+        parts.append(bytes(b))
+    buf = b"".join(parts)
+    t0 = time.perf_counter()
+    recs = vio.scan_mseed(buf)
+    t_scan = time.perf_counter() - t0
+    ns = recs["nsamples"].astype(np.int64)
+    index = (np.cumsum(ns) - ns).astype(np.int64)
+    total = int(ns.sum())
+    dbuf = torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
+    dout = torch.empty(total, dtype=torch.int32, device="cuda")
+    recs_c = (_lib.VpMseedRecord * len(recs)).from_buffer_copy(np.ascontiguousarray(recs).tobytes())
+    ms = C.c_float(0)
+    _lib.check(lib.vp_mseed_decode_bench(0, dbuf.data_ptr(), len(buf), recs_c, index.ctypes.data_as(C.POINTER(C.c_int64)),
+                                         len(recs), _lib.VP_SAMPLES_INT32, dout.data_ptr(), total, iters, C.byref(ms)),
+               "vp_mseed_decode_bench")
+    got = dout.cpu().numpy()
+    first_tile = np.concatenate([want[c] for c in ("HHZ", "HHN", "HHE")])
+    exact = bool(np.array_equal(got[: first_tile.size], first_tile) and np.array_equal(got[-first_tile.size:], first_tile))
+    payload = int((recs["reclen"] - recs["data_offset"]).sum())
+    algo = payload + 4 * total  # every payload byte read once, every int32 sample written once
+    va.read(buf[: len(blob0)])
+    t0 = time.perf_counter()
+    st = va.read(buf)
+    t_read = time.perf_counter() - t0
+    day_ok = len(st) == 3 and all(tr.stats.npts == total // 3 for tr in st)
+    out = {
+        "metric": "miniSEED samples decoded per second (Steim-2, one 3-component station-day, file resident in HBM)",
+        "value": total / (ms.value * 1e-3), "unit": "samples/s", "kernel_ms": ms.value, "records": int(len(recs)), "samples": total,
+        "file_bytes": len(buf), "bytes_per_sample": len(buf) / total, "bit_exact_vs_fixture_samples": exact,
+        "read_gives_three_day_long_traces": day_ok,
+        "roofline": {"bound": "hbm", "achieved": algo / (ms.value * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": algo / (ms.value * 1e-3) / (PEAK_HBM_GBS * 1e9), "algorithmic_bytes": algo,
+                     "basis": "payload bytes read + 4 B per decoded sample written, per launch / its duration (HIP events, "
+                              f"{iters} launches back to back); 36 MB file + 104 MB of samples: latency of the serial Steim "
+                              "difference chain inside a record, not bandwidth, bounds it"},
+        "read_wall_ms_host_file_to_host_stream": t_read * 1e3, "scan_ms": t_scan * 1e3,
+    }
+    from oracle import mseed as OM
+
+    orecs = OM.scan_records(blob0)
+    n_cpu, reps, t0 = 0, 0, time.perf_counter()
+    while time.perf_counter() - t0 < 2.0:
+        n_cpu += sum(len(OM.decode_record(blob0, r)) for r in orecs)
+        reps += 1
+    t_cpu = time.perf_counter() - t0
+    out["cpu_baseline"] = {"value": n_cpu / t_cpu, "unit": "samples/s", "cores": 1, "kind": "port",
+                           "sample": f"{reps} x the fixture's {len(orecs)} records ({n_cpu} samples) through oracle/mseed.py (numpy / Python)"}
+    return out
 
 
 def timed_repeats(run_once, sync_all, repeats, use_dist, dev):

@@ -379,6 +379,7 @@ int vp_train_tensor_count(const vp_trainer* t);
 int vp_train_tensor_info(const vp_trainer* t, int index, const char** name, int* channels, int* length);
 int vp_train_tensor_read(vp_trainer* t, int index, int B, float* out);
 void* vp_train_stream(const vp_trainer* t);
+int vp_train_launch_count(const vp_trainer* t); /* kernel launches the latest vp_train_step enqueued */
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU bring-up.  The reference is single-GPU; windows are independent given the

@@ -190,6 +190,7 @@ SIGNATURES = {
     "vp_train_tensor_info": (C.c_int, [_H, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "vp_train_tensor_read": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
     "vp_train_stream": (C.c_void_p, [_H]),
+    "vp_train_launch_count": (C.c_int, [_H]),
     "vp_last_error": (C.c_char_p, []),
     "vp_version": (C.c_char_p, []),
 }

@@ -170,8 +170,16 @@ __global__ __launch_bounds__(256) void load_rows_bf16_kernel(const float* __rest
 
 }  // namespace
 
+thread_local int g_launches = 0;  // kernel launches of the step being enqueued (vp_train_launch_count)
+#define TRL(...)                      \
+  do {                                \
+    ++g_launches;                     \
+    hipLaunchKernelGGL(__VA_ARGS__);  \
+  } while (0)
+
 struct Trainer {
   int device = 0, max_batch = 0;
+  int launches_last_step = 0;
   bool bf16 = false;  // activation / gradient rows stored as bfloat16 (weights, gradients, statistics, Adam: fp32)
   int esize = 4;      // bytes per row element
   hipStream_t stream = nullptr;
@@ -530,6 +538,7 @@ int upload(Trainer& tr, const float* weights) {
 }
 
 void run_conv(Trainer& tr, const ConvOp& op, int B) {
+  ++g_launches;
   ConvArgs a{};
   const Tensor& s1 = tr.tensors[op.src1];
   a.src1 = s1.p;
@@ -592,17 +601,17 @@ BnArgs bn_args(Trainer& tr, const BnOp& b, int B) {
 #define BN_CROP_LAUNCH(KERNEL, GRID, NTH)                                              \
   do {                                                                                 \
     if (a.crop == 0) {                                                                 \
-      hipLaunchKernelGGL((KERNEL<T, 0>), GRID, dim3(NTH), 0, s, a);                     \
+      TRL((KERNEL<T, 0>), GRID, dim3(NTH), 0, s, a);                     \
     } else if (a.crop == 1) {                                                          \
-      hipLaunchKernelGGL((KERNEL<T, 1>), GRID, dim3(NTH), 0, s, a);                     \
+      TRL((KERNEL<T, 1>), GRID, dim3(NTH), 0, s, a);                     \
     } else {                                                                           \
-      hipLaunchKernelGGL((KERNEL<T, 2>), GRID, dim3(NTH), 0, s, a);                     \
+      TRL((KERNEL<T, 2>), GRID, dim3(NTH), 0, s, a);                     \
     }                                                                                  \
   } while (0)
 template <class T>
 void bn_forward_v(const BnArgs& a, hipStream_t s) {
   const dim3 grid(a.C, a.GB);
-  hipLaunchKernelGGL(bnv_stats_partial_kernel<T>, grid, dim3(256), 0, s, a);
+  TRL(bnv_stats_partial_kernel<T>, grid, dim3(256), 0, s, a);
   BN_CROP_LAUNCH(bnv_apply_kernel, grid, 256);
 }
 template <class T>
@@ -615,12 +624,13 @@ void bn_backward_v(const BnArgs& a, hipStream_t s) {
 
 int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B, bool update, float lr) {
   hipStream_t s = tr.stream;
-  hipLaunchKernelGGL(gather_pack_kernel, dim3((unsigned)((tr.frag_n + 255) / 256)), dim3(256), 0, s, tr.frag_idx, tr.w,
+  g_launches = 0;
+  TRL(gather_pack_kernel, dim3((unsigned)((tr.frag_n + 255) / 256)), dim3(256), 0, s, tr.frag_idx, tr.w,
                      tr.frag, (long)tr.frag_n);
   if (tr.bf16) {
-    hipLaunchKernelGGL(load_rows_bf16_kernel, dim3((T0 + 511) / 512, 3, B), dim3(256), 0, s, x_dev, tr.rows(tr.t_x), 3, T0);
+    TRL(load_rows_bf16_kernel, dim3((T0 + 511) / 512, 3, B), dim3(256), 0, s, x_dev, tr.rows(tr.t_x), 3, T0);
   } else {
-    hipLaunchKernelGGL(load_rows_kernel, dim3((T0 + 255) / 256, 3, B), dim3(256), 0, s, x_dev, tr.rows(tr.t_x), 3, T0);
+    TRL(load_rows_kernel, dim3((T0 + 255) / 256, 3, B), dim3(256), 0, s, x_dev, tr.rows(tr.t_x), 3, T0);
   }
   for (Layer& L : tr.layers) {
     run_conv(tr, L.fwd, B);
@@ -646,16 +656,16 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     int gx = (T0 + 255) / 256;
     if (tr.bf16) {
       gx = (T0 + 511) / 512;
-      hipLaunchKernelGGL(head_fwd_bwd_pair_kernel<bf16_t>, dim3(gx, B), dim3(256), 0, s, h);
+      TRL(head_fwd_bwd_pair_kernel<bf16_t>, dim3(gx, B), dim3(256), 0, s, h);
     } else {
-      hipLaunchKernelGGL(head_fwd_bwd_kernel, dim3(gx, B), dim3(256), 0, s, h);
+      TRL(head_fwd_bwd_kernel, dim3(gx, B), dim3(256), 0, s, h);
     }
     // two stages: 64 row groups, then the 64 group sums
-    hipLaunchKernelGGL((sum_rows_kernel<double, double>), dim3(1, 64), dim3(256), 0, s, tr.head_partial, gx * B, 28,
+    TRL((sum_rows_kernel<double, double>), dim3(1, 64), dim3(256), 0, s, tr.head_partial, gx * B, 28,
                        tr.head_stage);
-    hipLaunchKernelGGL((sum_rows_kernel<double, double>), dim3(1, 1), dim3(256), 0, s, tr.head_stage, 64, 28,
+    TRL((sum_rows_kernel<double, double>), dim3(1, 1), dim3(256), 0, s, tr.head_stage, 64, 28,
                        tr.head_sums);
-    hipLaunchKernelGGL(head_final_kernel, dim3(1), dim3(32), 0, s, tr.head_sums, tr.head_sums + 28,
+    TRL(head_final_kernel, dim3(1), dim3(32), 0, s, tr.head_sums, tr.head_sums + 28,
                        tr.grad + tr.poff.at("out.bias"), tr.grad + tr.poff.at("out.weight"));
   }
   SumJobs jobs{};
@@ -687,6 +697,7 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
       const int items = ((B + w.WB - 1) / w.WB) * g.chunks;
       const int cap = w.out_n > 10000 ? 256 : 512;  // one partial result per workgroup: fewer, longer-lived workgroups for the big weight tensors
       const int grid = items < cap ? items : cap;
+      ++g_launches;
       w.launch(g, grid, s);
       SumJob& jb = jobs.job[jobs.count++];
       jb.partial = g.partial;
@@ -699,26 +710,27 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     if (li == 0) {  // conv bias of `inc`: sum of gz per channel (zero up to rounding: BatchNorm removes the mean)
       const int GB = B < 64 ? B : 64;
       if (tr.bf16) {
-        hipLaunchKernelGGL(channel_sum_partial_v_kernel<bf16_t>, dim3(8, GB), dim3(256), 0, s, tr.rows(L.bn.gz), B, T0, GB,
+        TRL(channel_sum_partial_v_kernel<bf16_t>, dim3(8, GB), dim3(256), 0, s, tr.rows(L.bn.gz), B, T0, GB,
                            tr.bn_partial);
       } else {
-        hipLaunchKernelGGL(channel_sum_partial_v_kernel<float>, dim3(8, GB), dim3(256), 0, s, tr.rows(L.bn.gz), B, T0, GB,
+        TRL(channel_sum_partial_v_kernel<float>, dim3(8, GB), dim3(256), 0, s, tr.rows(L.bn.gz), B, T0, GB,
                            tr.bn_partial);
       }
-      hipLaunchKernelGGL((sum_rows_kernel<double, float>), dim3(1, 1), dim3(256), 0, s, tr.bn_partial, GB, 8,
+      TRL((sum_rows_kernel<double, float>), dim3(1, 1), dim3(256), 0, s, tr.bn_partial, GB, 8,
                          tr.grad + tr.poff.at("inc.bias"));
     }
     if (L.dgrad.used) run_conv(tr, L.dgrad, B);
   }
-  hipLaunchKernelGGL(sum_rows_multi_kernel, dim3(sum_blocks), dim3(256), 0, s, jobs);
+  TRL(sum_rows_multi_kernel, dim3(sum_blocks), dim3(256), 0, s, jobs);
   if (update) {
     tr.step += 1;
     const float bc1 = 1.f - powf(tr.beta1, (float)tr.step);
     const float bc2 = 1.f - powf(tr.beta2, (float)tr.step);
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((tr.n_params + 255) / 256)), dim3(256), 0, s, tr.w, tr.grad,
+    TRL(adam_kernel, dim3((unsigned)((tr.n_params + 255) / 256)), dim3(256), 0, s, tr.w, tr.grad,
                        tr.adam_m, tr.adam_v, tr.mask, tr.ema, (int)tr.n_params, lr, tr.beta1, tr.beta2, tr.adam_eps, bc1,
                        sqrtf(bc2), tr.ema_decay);
   }
+  tr.launches_last_step = g_launches;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("training step: kernel launch failed: %s", hipGetErrorString(e));
@@ -890,6 +902,8 @@ int vp_train_tensor_read(vp_trainer* h, int index, int B, float* out) {
                      (size_t)B * t.C, hipMemcpyDeviceToHost));
   return VP_OK;
 }
+int vp_train_launch_count(const vp_trainer* h) { return h ? reinterpret_cast<const Trainer*>(h)->launches_last_step : 0; }
+
 void* vp_train_stream(const vp_trainer* h) { return h ? reinterpret_cast<const Trainer*>(h)->stream : nullptr; }
 
 }  // extern "C"
