@@ -42,6 +42,9 @@ from pathlib import Path
 # hardware queues for the device contexts' streams (volpick_amd/__init__.py sets the same default; here it is set before
 # anything can start the HIP runtime)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+# the stock PyTorch-ROCm training step timed beside `train` goes through MIOpen: its default exhaustive find takes ~35 s on a
+# fresh box (no kernel cache), the fast find 2 s, for the same 12.5 ms step
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 
 import numpy as np  # noqa: E402
 

@@ -533,7 +533,12 @@ int upload(Trainer& tr, const float* weights) {
     for (ConvOp* op : {&L.fwd, &L.dgrad})
       if (op->used && op->lds_bytes > 48 * 1024)
         TR_HIP(hipFuncSetAttribute(op->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)op->lds_bytes));
-  TR_HIP(hipStreamCreate(&tr.stream));
+  // Non-blocking: a blocking stream synchronises implicitly with the legacy default stream, so every event a binder
+  // records there for the step's inputs (volpick_amd/train.py: torch's current stream) serialised the step against its
+  // predecessor on the device -- 2.75 instead of 1.72 ms per 512-window step (tools/train_probe.py).  The uploads above ran
+  // on the default stream: they are complete before the first step can be enqueued.
+  TR_HIP(hipDeviceSynchronize());
+  TR_HIP(hipStreamCreateWithFlags(&tr.stream, hipStreamNonBlocking));
   return VP_OK;
 }
 
