@@ -45,6 +45,10 @@ print("workgroup starts after the first (us): median %.2f  p90 %.2f  max %.2f;  
 if n_steps == 1:  # whole-network kernel: slot 1 - slot 0 is the level-0 down phase; 18..22 and 23..28 detail the two level-0 phases
     dphase = np.diff(clk[:, 18:23].astype(np.int64), axis=1)
     print("level-0 down phase median cycles: load x %d  inc %d  down0.same (two passes) %d  down0.down (MFMA) %d" % tuple(np.median(dphase, axis=0)))
+    sub = clk[:, [18, 29, 30, 31, 19]].astype(np.int64)
+    if (sub[:, 1:4] > 0).all():
+        print("load x in detail (wave 0's stamps): window read + partial reductions %d  barrier + 3-lane finish + barrier %d  "
+              "normalise + store x image %d  closing barrier %d" % tuple(np.median(np.diff(sub, axis=1), axis=0)))
     uphase = np.diff(clk[:, 23:29].astype(np.int64), axis=1)
     print("level-0 up phase median cycles: load skip rows %d  up3.same(skip) %d  up3.convT (MFMA) %d  up3.same(convT) %d  1x1+softmax+store %d"
           % tuple(np.median(uphase, axis=0)))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run N forward passes of one model (for rocprofv3 counter collection). usage: run_forward.py phasenet|eqtransformer [n]"""
+"""Run N forward passes of one model (for rocprofv3 counter collection). usage: run_forward.py phasenet|eqtransformer [n] [plan flags, e.g. 0,0,0,0,0,3]"""
 import sys
 from pathlib import Path
 
@@ -12,7 +12,10 @@ from volpick_amd.synthetic import synthetic_windows  # noqa: E402
 name = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 cls = va.PhaseNet if name == "phasenet" else va.EQTransformer
-m = cls.from_pretrained("volpick").cuda()
+m = cls.from_pretrained("volpick")
+if len(sys.argv) > 3:
+    m._plan_flags = tuple(int(v) for v in sys.argv[3].split(","))
+m.cuda()
 x = torch.from_numpy(synthetic_windows(256, cls.in_samples, seed=1)).cuda()
 for _ in range(n):
     y = m._forward_raw(x, preprocess=True)

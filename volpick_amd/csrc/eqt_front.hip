@@ -384,7 +384,8 @@ __global__ __launch_bounds__(FR_NTH) void eqt_front_kernel(const FrontArgs a) {
   auto park = [&](const int j0) {
     if constexpr (has_pre) {  // (v - mean) / (amp + eps), tapered: the expression of gather_normalize_kernel, sample by sample
       const int taper = a.pre.taper;
-      const float m0 = fr_stat[0], m1 = fr_stat[1], m2 = fr_stat[2], d0 = fr_stat[3], d1 = fr_stat[4], d2 = fr_stat[5];
+      const float m0 = fr_stat[0], m1 = fr_stat[1], m2 = fr_stat[2];
+      const NormDiv n0 = norm_div_prepare(fr_stat[3]), n1 = norm_div_prepare(fr_stat[4]), n2 = norm_div_prepare(fr_stat[5]);
 #pragma unroll
       for (int k = 0; k < PRE; ++k) {
         const int idx = tid + k * FR_NTH, c = idx / SI, p = idx - c * SI;
@@ -393,8 +394,8 @@ __global__ __launch_bounds__(FR_NTH) void eqt_front_kernel(const FrontArgs a) {
           float o = 0.f;
           if ((unsigned)t < (unsigned)T_IN) {
             const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
-            const float den = c == 0 ? d0 : (c == 1 ? d1 : d2);
-            o = (pre[k] - mean) / den;
+            const NormDiv den = c == 0 ? n0 : (c == 1 ? n1 : n2);
+            o = norm_div(pre[k] - mean, den);
             if (taper > 0) {
               const int e = (t < taper) ? t : ((T_IN - 1 - t < taper) ? T_IN - 1 - t : -1);
               if (e >= 0) {  // 0.5 * (1 + cos(linspace(pi, 2 pi, taper)[e]))

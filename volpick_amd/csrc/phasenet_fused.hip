@@ -1114,14 +1114,17 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
           for (int k = 0; k < MAXE; ++k)
             if (tid + k * NTH < T0) vhi[c] = fmaxf(vhi[c], v[c][k]), vlo[c] = fminf(vlo[c], v[c][k]);
       }
-      for (int c = 0; c < 3; ++c) {
-        const float r = wave_sum(sum[c]);
-        if (lane == 0) red[c * NWV + wave] = r;
-        if (one_pass) {
-          const float rh = wave_max(vhi[c]), rl = -wave_max(-vlo[c]);
-          if (lane == 0) red[(3 + c) * NWV + wave] = rh, red[(6 + c) * NWV + wave] = rl;
-        }
+      wave_sum3(sum[0], sum[1], sum[2]);  // (the DPP tree of wave_sum, three rows interleaved by hand: prepost.h)
+      if (one_pass) {
+        float nlo[3] = {-vlo[0], -vlo[1], -vlo[2]};
+        wave_max3(vhi[0], vhi[1], vhi[2]);
+        wave_max3(nlo[0], nlo[1], nlo[2]);
+        if (lane == 0)
+          for (int c = 0; c < 3; ++c) red[(3 + c) * NWV + wave] = vhi[c], red[(6 + c) * NWV + wave] = -nlo[c];
       }
+      if (lane == 0)
+        for (int c = 0; c < 3; ++c) red[c * NWV + wave] = sum[c];
+      WIN_STAMP(29)
       for (int i = tid; i < 3 * (W0_S - T0); i += NTH) {  // zero margins of the x rows: samples -4 .. -1 and T0 .. 3019
         const int c = i / (W0_S - T0), k = i - c * (W0_S - T0);
         X[c * W0_S + (k < 4 ? k : T0 + k)] = 0.f;
@@ -1139,6 +1142,7 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
         }
       }
       __syncthreads();
+      WIN_STAMP(30)
       const float mean[3] = {stat[0], stat[2], stat[4]};
       if (!one_pass) {
       float m[3] = {0.f, 0.f, 0.f};
@@ -1175,21 +1179,29 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
                                                  : sqrtf((stat[1] + stat[3] + stat[5]) / (float)(3 * T0 - 1));
         amp[0] = amp[1] = amp[2] = g;
       }
+      const NormDiv den[3] = {norm_div_prepare(amp[0] + p.norm_eps), norm_div_prepare(amp[1] + p.norm_eps),
+                              norm_div_prepare(amp[2] + p.norm_eps)};
+      if (p.taper > 0) {  // (uniform; PhaseNet's default is no taper: the plain loop below then carries no branch per sample)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float den = amp[c] + p.norm_eps;
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int k = 0; k < MAXE; ++k) {
-          const int t = tid + k * NTH;
-          if (t < T0) {
-            float o = (v[c][k] - mean[c]) / den;
-            if (p.taper > 0) {
+          for (int k = 0; k < MAXE; ++k) {
+            const int t = tid + k * NTH;
+            if (t < T0) {
+              float o = norm_div(v[c][k] - mean[c], den[c]);
               const int e = (t < p.taper) ? t : ((T0 - 1 - t < p.taper) ? T0 - 1 - t : -1);
               if (e >= 0) o *= 0.5f * (1.f + cosf(3.14159265358979323846f * (1.f + (float)e / (float)(p.taper - 1))));
+              X[c * W0_S + 4 + t] = o;
             }
-            X[c * W0_S + 4 + t] = o;
           }
-        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int k = 0; k < MAXE; ++k) {
+            const int t = tid + k * NTH;
+            if (k + 1 < MAXE || t < T0) X[c * W0_S + 4 + t] = norm_div(v[c][k] - mean[c], den[c]);
+          }
       }
     } else {  // x rows: sample 4q - 4 .. 4q - 1 at float4 q; physical index HALO + 4q - 4 (16-byte aligned)
       const float* src = a.x + (long)win * a.ws_x;
@@ -1204,6 +1216,7 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
     {
       if (tid < 8) *reinterpret_cast<float4*>(H + tid * W0_S) = make_float4(0.f, 0.f, 0.f, 0.f);  // samples -4 .. -1: left padding
     }
+    WIN_STAMP(31)
     __syncthreads();
     WIN_STAMP(19)
     if (vconv) {  // inc: Conv1d(3, 8, 7, same, bias) + BN + ReLU

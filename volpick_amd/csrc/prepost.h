@@ -81,6 +81,25 @@ __device__ __forceinline__ void wave_sum3(float& a, float& b, float& c) { VP_RED
 #undef VP_DPP3
 
 
+// n / den for many n and ONE den (the amplitude of a window channel): the compiler's own division sequence -- v_rcp_f32, one
+// Newton step on the reciprocal, quotient, two residual corrections -- with the part that depends on den alone done once.
+// Bit for bit the quotient `n / den` yields wherever that sequence does not rescale its operands (v_div_scale: exponents
+// near the ends of the range; a window whose amplitude is 0, Inf or NaN is flagged and poisoned whatever comes out here).
+// 5 vector instructions per sample instead of 12 (annotate_batch_pre inside pn_window_kernel: 9 divisions per lane).
+struct NormDiv {
+  float den, r;
+};
+__device__ __forceinline__ NormDiv norm_div_prepare(const float den) {
+  float r = __builtin_amdgcn_rcpf(den);
+  r = fmaf(fmaf(-den, r, 1.f), r, r);
+  return NormDiv{den, r};
+}
+__device__ __forceinline__ float norm_div(const float n, const NormDiv d) {
+  float q = n * d.r;
+  q = fmaf(fmaf(-d.den, q, n), d.r, q);
+  return fmaf(fmaf(-d.den, q, n), d.r, q);
+}
+
 struct StackArgs {
   const float* pred;  // [n_windows][n_out][T]
   float* out;         // [n_out][N]

@@ -68,15 +68,16 @@ __global__ __launch_bounds__(1024) void gather_normalize_kernel(const PreArgs a)
 #pragma unroll
       for (int k = 0; k < MAXE; ++k)
         if (tid + k * NTH < T) vhi[c] = fmaxf(vhi[c], v[c][k]), vlo[c] = fminf(vlo[c], v[c][k]);
-    for (int c = 0; c < 3; ++c) {
-      const float rh = wave_max(vhi[c]), rl = -wave_max(-vlo[c]);
-      if (lane == 0) red_hi[c][wave] = rh, red_lo[c][wave] = rl;
-    }
+    // (three reductions interleaved by hand: the same DPP tree as wave_max / wave_sum, bit for bit, a third of the time)
+    float nlo[3] = {-vlo[0], -vlo[1], -vlo[2]};
+    wave_max3(vhi[0], vhi[1], vhi[2]);
+    wave_max3(nlo[0], nlo[1], nlo[2]);
+    if (lane == 0)
+      for (int c = 0; c < 3; ++c) red_hi[c][wave] = vhi[c], red_lo[c][wave] = -nlo[c];
   }
-  for (int c = 0; c < 3; ++c) {
-    const float r = wave_sum(s[c]);
-    if (lane == 0) red[c][wave] = r;
-  }
+  wave_sum3(s[0], s[1], s[2]);
+  if (lane == 0)
+    for (int c = 0; c < 3; ++c) red[c][wave] = s[c];
   __syncthreads();
   if (tid < 3) {
     float acc = 0.f;
@@ -133,12 +134,12 @@ __global__ __launch_bounds__(1024) void gather_normalize_kernel(const PreArgs a)
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const float den = amp[c] + a.norm_eps;
+    const NormDiv den = norm_div_prepare(amp[c] + a.norm_eps);
 #pragma unroll
     for (int k = 0; k < MAXE; ++k) {
       const int t = tid + k * NTH;
       if (t < T) {
-        float o = (v[c][k] - mean[c]) / den;
+        float o = norm_div(v[c][k] - mean[c], den);
         if (a.taper > 0) {
           const int e = (t < a.taper) ? t : ((T - 1 - t < a.taper) ? T - 1 - t : -1);
           if (e >= 0) {  // 0.5 * (1 + cos(linspace(pi, 2 pi, taper)[e]))
