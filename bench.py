@@ -42,9 +42,6 @@ from pathlib import Path
 # hardware queues for the device contexts' streams (volpick_amd/__init__.py sets the same default; here it is set before
 # anything can start the HIP runtime)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
-# the stock PyTorch-ROCm training step timed beside `train` goes through MIOpen: its default exhaustive find takes ~35 s on a
-# fresh box (no kernel cache), the fast find 2 s, for the same 12.5 ms step
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 
 import numpy as np  # noqa: E402
 
@@ -146,6 +143,8 @@ def main():
                     help="length of the one long timed region per model reported as `sustained` (0 = skip)")
     ap.add_argument("--no-api", action="store_true", help="skip the `api` object (classify() on a host 24 h stream)")
     ap.add_argument("--no-train", action="store_true", help="skip the `train` object (BASELINE configs[4]: bf16 training step, B = 512)")
+    ap.add_argument("--no-train-torch", action="store_true",
+                    help="`train` without the stock PyTorch-ROCm step beside it (MIOpen's first-use find costs ~35 s on a fresh box)")
     ap.add_argument("--no-mseed", action="store_true", help="skip the `mseed` object (SURVEY 8f-1: Steim-2 station-day decode)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the N > 1 plumbing on a ONE-GPU box: process group over gloo, every rank on cuda:0, weights "
@@ -201,7 +200,8 @@ def main():
                                                           "pick_parity") if k in eq}
     # the two widened rows that have a throughput of their own (N = 1, the default run only): each a few seconds
     if world == 1 and not args.strong and args.model == "both" and not args.no_cpu_baseline:
-        for key, skip, fn in (("train", args.no_train, bench_train), ("mseed", args.no_mseed, bench_mseed)):
+        for key, skip, fn in (("train", args.no_train, lambda: bench_train(torch_baseline=not args.no_train_torch)),
+                              ("mseed", args.no_mseed, bench_mseed)):
             if not skip:
                 t0 = time.perf_counter()
                 try:
@@ -376,7 +376,7 @@ def bench_api(model_name, model, batch, oracle_threads=None):
     }
 
 
-def bench_train(batch=512, steps=30, warmup=5, torch_steps=6):
+def bench_train(batch=512, steps=30, warmup=5, torch_steps=6, torch_baseline=True):
     """BASELINE configs[4]: one PhaseNet training step (forward in training mode, vector cross-entropy, backward, Adam;
     /root/reference volpick/model/models.py:34-51,160-185) on VCSEIS-shaped synthetic batches resident in HBM, activation /
     gradient rows stored as bfloat16 with fp32 accumulation (vp_train_create_dtype(VP_TRAIN_BF16)).  Beside it, as the
@@ -421,7 +421,12 @@ def bench_train(batch=512, steps=30, warmup=5, torch_steps=6):
                               "weight gradients the bf16 MFMA (exact on bf16-stored rows)"},
     }
     tr.close()
-    # the same step through stock PyTorch-ROCm (MIOpen / rocBLAS kernels, eager autograd) on this GPU
+    # the same step through stock PyTorch-ROCm (MIOpen / rocBLAS kernels, eager autograd) on this GPU.  On a fresh box MIOpen
+    # has no kernel cache: its find + compile of the 19 conv layers' forward / backward kernels takes ~35 s before the first
+    # step (MIOPEN_FIND_MODE=FAST takes 7 s and then runs the step at 573 ms instead of 12.5: not a baseline); --no-train-torch
+    # skips the leg
+    if not torch_baseline:
+        return out
     try:
         from oracle.models import load_pretrained
 

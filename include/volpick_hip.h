@@ -61,7 +61,9 @@ typedef struct {
                                       of eqt_mid_kernel, 2 = eqt_mid_kernel with one window per 512-thread workgroup
                                       (default: two windows per 1024-thread workgroup, so that a batch leaves half the
                                       CUs to the kernels of the other device contexts);
-                                 [3]: tiled level-0 kernel variants of the all-MFMA plan (A/B);
+                                 [3]: tiled level-0 kernel variants of the all-MFMA plan (A/B); 64 = PhaseNet's one-launch plan
+                                      WITHOUT the first-come-first-served gate between the device contexts' forward
+                                      launches (A/B: csrc/api.hip ForwardGate);
                                  [4]: 1 = no L2 warm-up of the weight streams;
                                  [5]: PhaseNet plan: 0 = the whole network in one launch, its five deepest layers on the
                                       bf16 matrix cores with exact three-piece operands (default), 1 = three launches,

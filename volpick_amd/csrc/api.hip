@@ -1,6 +1,7 @@
 // C ABI of libvolpick_hip.so (include/volpick_hip.h).
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <numeric>
 
 #include "net.h"
@@ -96,6 +97,53 @@ vp::PreArgs pre_args(const vp_handle* h, const float* src, int dense, long N, lo
   return a;
 }
 
+// ---- first come, first served between the device contexts of one GPU (PhaseNet) ----------------------------------------------
+// A PhaseNet forward pass is ONE launch that fills the chip: 256 workgroups of 1024 threads, each owning its CU's LDS and
+// register file.  Three device contexts keep three such launches pending, and the hardware shares the CUs that a finishing
+// launch frees between ALL pending launches, workgroup by workgroup: three launches then progress together, end together,
+// their post-processing and the host's turn-around come in one burst, and the chip idles ~30 us in every four steps
+// (tools/trace_timeline.py, round 4).  The gate below lets forward launch n + 2 wait for the END of launch n (an event, no
+// host synchronisation): at any time one launch runs and ONE waits for its CUs, so launches run in submission order, each
+// step's stacking / trigger scan / publish run under the NEXT step's forward pass (they fit beside its workgroups: prepost.hip),
+// and the host collects step n while step n + 1 computes.  Distance 2, not 1: the successor's workgroups still move onto
+// CUs as the predecessor's leave them.
+struct ForwardGate {
+  static constexpr int RING = 8, DIST = 2;
+  std::mutex mu;
+  hipEvent_t done[RING] = {};
+  bool made = false;
+  unsigned long long seq = 0;
+};
+ForwardGate& forward_gate(int device) {
+  static ForwardGate gates[16];
+  return gates[(unsigned)device % 16];
+}
+struct ForwardTurn {  // RAII around one forward launch of a gated plan
+  ForwardGate* g = nullptr;
+  hipStream_t s;
+  ForwardTurn(vp_handle* h, bool gated) : s(h->stream) {
+    if (!gated) return;
+    g = &forward_gate(h->device);
+    g->mu.lock();
+    if (!g->made) {
+      for (auto& e : g->done)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+      g->made = true;
+    }
+    if (g->seq >= ForwardGate::DIST) {
+      hipEvent_t e = g->done[(g->seq - ForwardGate::DIST) % ForwardGate::RING];
+      if (e) (void)hipStreamWaitEvent(s, e, 0);
+    }
+  }
+  ~ForwardTurn() {
+    if (!g) return;
+    hipEvent_t e = g->done[g->seq % ForwardGate::RING];
+    if (e) (void)hipEventRecord(e, s);
+    ++g->seq;
+    g->mu.unlock();
+  }
+};
+
 // One batch through annotate_batch_pre + the forward pass.  Plans whose first launch gathers and normalises the
 // windows itself take the window description with them; otherwise gather_normalize fills the input tensor first.
 int run_batch(vp_handle* h, const vp::PreArgs& pa, int nb) {
@@ -105,6 +153,8 @@ int run_batch(vp_handle* h, const vp::PreArgs& pa, int nb) {
     h->last_pre_windows = nb;
     h->last_out_lo = net.out_lo, h->last_out_hi = net.out_hi;
   }
+  // (one-launch plans only: a plan of several launches gains from the contexts' launches interleaving)
+  const ForwardTurn turn(h, net.model_kind == VP_MODEL_PHASENET && net.steps.size() == 1 && net.cfg.plan_flags[3] != 64);
   if (net.fused_pre && pa.preprocess) {
     net.pre = &pa;
     const int rc = net.run(nb, h->stream);

@@ -109,14 +109,14 @@ struct B3BlockStore : B3Store<C> {
 
 // The conv.  L = LdsLayer (conv_lds.h) with CIN1, CIN2 multiples of 32; MPERM: GEMM rows ordered (phase, channel).
 // Items = (m-tile, block of NB n-tiles); wave w takes items w, w + nwaves, ...
-template <class L, bool MPERM, int C1, int C2, class Store>
+template <class L, bool MPERM, int C1, int C2, class Store, int PF_ = 3>
 __device__ __forceinline__ void conv_b3(const B3Image<C1> i1, const B3Image<C2> i2, const uint4* __restrict__ af3,
                                         const float* __restrict__ bias, const int cols, const Store store, const int wave,
                                         const int nwaves, const int lane) {
   static_assert(L::CIN1 % 32 == 0 && L::CIN2 % 32 == 0 && L::CIN1 == C1 && (L::CIN2 == 0 || L::CIN2 == C2), "32-channel K-steps");
   static_assert(MPERM || L::P == 1, "multi-phase layers order their rows (phase, channel)");
   constexpr int KS1 = L::CIN1 / 32, KS = (L::CIN1 + L::CIN2) / 32, STEPS = L::TAPS * KS, NB = L::NB;
-  constexpr int PF = 3;  // K-steps of A in flight ahead of the MFMAs (4 and 5 measured the same: the layers with one n-tile per
+  constexpr int PF = PF_;  // K-steps of A in flight ahead of the MFMAs (4 and 5 measured the same: the layers with one n-tile per
                          // item run at the rate the weights stream out of L2, 34-44 B/clk/CU)
   constexpr int MT = L::M / 16, MT_PER_PHASE = L::COUT / 16;
   const int NT = (cols + 15) >> 4, NBLK = (NT + NB - 1) / NB, items = MT * NBLK;

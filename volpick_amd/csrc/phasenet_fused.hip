@@ -1421,12 +1421,12 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
     if constexpr (U3B) {  // up0.same: cat(skip 3, up0.convT) -> three-piece image for up1.convT
       B3Store<64> st{l16 + A_Q * 2, B3_U0S_PS, 1, T3, B3_U0S_NC};
       st.zero_rest(1, 1 + 48, tid, NTH);
-      conv_b3<C_u0same, false, 64, 64>(iSK3, iU0T, a.af3[4], a.c.bs[8], T3, st, wave, NWV, lane);
+      conv_b3<C_u0same, false, 64, 64, decltype(st), 2>(iSK3, iU0T, a.af3[4], a.c.bs[8], T3, st, wave, NWV, lane);
       B3_END
     } else {  // up0.same: cat(skip 3, up0.convT) -> fp32 image for up1.convT
       F32QuadStore<S3_, IB> st{lds + X_U0S, T3};
       zero_halo<64, S3_, T3, IB>(lds + X_U0S, tid, NTH);
-      conv_b3<C_u0same, false, 64, 64>(iSK3, iU0T, a.af3[4], a.c.bs[8], T3, st, wave, NWV, lane);
+      conv_b3<C_u0same, false, 64, 64, decltype(st), 2>(iSK3, iU0T, a.af3[4], a.c.bs[8], T3, st, wave, NWV, lane);
       B3_END
     }
 #undef B3_END

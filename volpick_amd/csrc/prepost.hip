@@ -289,17 +289,24 @@ int launch_stack(const StackArgs& a, hipStream_t stream) {
 // > thr_on), then takes a strided max/argmax over [on, off] with a wave reduction.
 // Triggers are appended with one atomic each and sorted on the host.
 // ---------------------------------------------------------------------------------------
-constexpr int SCAN_CHUNK = 2048;  // samples per workgroup
+// 1024 samples per workgroup, their run ends as 16-bit offsets: 1 KB of LDS and <= 32 registers per lane, so that the scan's
+// waves find room on a CU that a 1024-thread forward workgroup of another device context fills (pn_window_kernel leaves 2 KB
+// of LDS and 32 registers per SIMD lane): the post-processing of step k then runs UNDER the forward pass of step k + 1
+// instead of holding its CUs for itself at the boundary between two launches
+constexpr int SCAN_CHUNK = 1024;  // samples per workgroup
 
 // One launch: every workgroup lists the run ENDS inside its 2048-sample chunk in LDS (phase 1,
 // one thread per 8 samples), then its four wavefronts walk those runs backwards through memory
 // (phase 2) -- a run may start in an earlier chunk, only its end decides who owns it.
+// I = int when every row is shorter than 2^31 - 2048 samples (launch_pick): 32-bit positions keep the kernel within 32 registers
+template <class I>
 __device__ __forceinline__ void trigger_scan_body(const PickArgs& a) {
   __shared__ int n_ends;
-  __shared__ int ends[SCAN_CHUNK / 2 + 1];
+  __shared__ unsigned short ends[SCAN_CHUNK / 2 + 2];  // a run end needs a sample above and a next sample below: at most every other one
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long c0 = (long)blockIdx.x * SCAN_CHUNK;
-  if (c0 >= a.n) return;
+  const I n = (I)a.n;
+  const I c0 = (I)blockIdx.x * SCAN_CHUNK;
+  if ((long)blockIdx.x * SCAN_CHUNK >= a.n) return;
   if (tid == 0) n_ends = 0;
   __syncthreads();
   {  // all samples of the chunk requested before the first is looked at: one memory round trip instead of eight
@@ -307,39 +314,39 @@ __device__ __forceinline__ void trigger_scan_body(const PickArgs& a) {
     float v[PER], nx[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      const long t = c0 + tid + 256 * k;
-      v[k] = t < a.n ? a.trace[t] : -INFINITY;
-      nx[k] = t + 1 < a.n ? a.trace[t + 1] : -INFINITY;
+      const I t = c0 + tid + 256 * k;
+      v[k] = t < n ? a.trace[t] : -INFINITY;
+      nx[k] = t + 1 < n ? a.trace[t + 1] : -INFINITY;
     }
 #pragma unroll
     for (int k = 0; k < PER; ++k)
-      if (v[k] > a.thr_off && !(nx[k] > a.thr_off)) ends[atomicAdd(&n_ends, 1)] = tid + 256 * k;
+      if (v[k] > a.thr_off && !(nx[k] > a.thr_off)) ends[atomicAdd(&n_ends, 1)] = (unsigned short)(tid + 256 * k);
   }
   __syncthreads();
   const int ne = n_ends;
   for (int r = wave; r < ne; r += 4) {
-    const long off = c0 + ends[r];
-    long on = -1;
+    const I off = c0 + (int)ends[r];
+    I on = -1;
     // four 64-sample blocks per trip, their reads in flight together: a Detection run (thr_off = thr / 2) is thousands of
     // samples long, and with one dependent 64-sample read per trip the kernel took 22 us on an EQTransformer step (14 now;
     // requesting the next trip ahead of the test changed nothing more)
     bool done = false;
-    for (long pos = off; pos >= 0 && !done; pos -= 256) {
+    for (I pos = off; pos >= 0 && !done; pos -= 256) {
       float vv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const long idx = pos - 64 * u - lane;
+        const I idx = pos - 64 * u - lane;
         vv[u] = (idx >= 0) ? a.trace[idx] : -INFINITY;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (done) continue;
-        const long p0 = pos - 64 * u;
+        const I p0 = pos - 64 * u;
         if (p0 < 0) {
           done = true;
           continue;
         }
-        const long idx = p0 - lane;
+        const I idx = p0 - lane;
         const float v = vv[u];
         const bool above = (idx >= 0) && (v > a.thr_off);
         const unsigned long long broken = __ballot(!above);
@@ -351,8 +358,8 @@ __device__ __forceinline__ void trigger_scan_body(const PickArgs& a) {
     }
     if (on < 0) continue;
     float best = -INFINITY;
-    long arg = off;
-    for (long i0 = on + lane; i0 <= off; i0 += 256) {  // first argmax: a lane meets its samples in increasing order
+    I arg = off;
+    for (I i0 = on + lane; i0 <= off; i0 += 256) {  // first argmax: a lane meets its samples in increasing order
       float vv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) vv[u] = (i0 + 64 * u <= off) ? a.trace[i0 + 64 * u] : -INFINITY;
@@ -366,7 +373,7 @@ __device__ __forceinline__ void trigger_scan_body(const PickArgs& a) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ob = __shfl_xor(best, o, 64);
-      const long oa = __shfl_xor(arg, o, 64);
+      const I oa = __shfl_xor(arg, o, 64);
       if (ob > best || (ob == best && oa < arg)) {
         best = ob;
         arg = oa;
@@ -384,13 +391,20 @@ __device__ __forceinline__ void trigger_scan_body(const PickArgs& a) {
   }
 }
 
-__global__ __launch_bounds__(256) void trigger_scan_kernel(const PickBatch batch) { trigger_scan_body(batch.a[blockIdx.y]); }
-__global__ __launch_bounds__(256) void trigger_scan_table_kernel(const PickArgs* rows) { trigger_scan_body(rows[blockIdx.y]); }
+template <class I>
+__global__ __launch_bounds__(256) void trigger_scan_kernel(const PickBatch batch) { trigger_scan_body<I>(batch.a[blockIdx.y]); }
+template <class I>
+__global__ __launch_bounds__(256) void trigger_scan_table_kernel(const PickArgs* rows) { trigger_scan_body<I>(rows[blockIdx.y]); }
+constexpr long SCAN_INT_MAX = 2147483647L - 4096;  // rows up to here are scanned with 32-bit positions
 
 int launch_pick_table(const PickArgs* rows, int n_rows, long n_max, hipStream_t stream) {
   if (n_rows <= 0 || n_max <= 0) return 0;
-  hipLaunchKernelGGL(trigger_scan_table_kernel, dim3((unsigned)((n_max + SCAN_CHUNK - 1) / SCAN_CHUNK), n_rows), dim3(256),
-                     0, stream, rows);
+  const dim3 grid((unsigned)((n_max + SCAN_CHUNK - 1) / SCAN_CHUNK), n_rows);
+  if (n_max <= SCAN_INT_MAX) {
+    hipLaunchKernelGGL(trigger_scan_table_kernel<int>, grid, dim3(256), 0, stream, rows);
+  } else {
+    hipLaunchKernelGGL(trigger_scan_table_kernel<long>, grid, dim3(256), 0, stream, rows);
+  }
   return 0;
 }
 
@@ -399,8 +413,12 @@ int launch_pick(const PickBatch& b, hipStream_t stream) {
   long n_max = 0;
   for (int i = 0; i < b.n; ++i) n_max = (b.a[i].n > n_max) ? b.a[i].n : n_max;
   if (b.n <= 0 || n_max <= 0) return 0;
-  hipLaunchKernelGGL(trigger_scan_kernel, dim3((unsigned)((n_max + SCAN_CHUNK - 1) / SCAN_CHUNK), b.n), dim3(256), 0,
-                     stream, b);
+  const dim3 grid((unsigned)((n_max + SCAN_CHUNK - 1) / SCAN_CHUNK), b.n);
+  if (n_max <= SCAN_INT_MAX) {
+    hipLaunchKernelGGL(trigger_scan_kernel<int>, grid, dim3(256), 0, stream, b);
+  } else {
+    hipLaunchKernelGGL(trigger_scan_kernel<long>, grid, dim3(256), 0, stream, b);
+  }
   return 0;
 }
 
@@ -413,17 +431,18 @@ __global__ __launch_bounds__(256) void publish_kernel(char* dev, char* host, int
   int* cnt = reinterpret_cast<int*>(dev);
   int* hcnt = reinterpret_cast<int*>(host);
   const int tid = threadIdx.x;
+  const long L = cap > 0 ? cap : 1;
+  // a result block of a spec is [on | off | peak : int64 x L each][value : float x L]: the first m entries of each of the four
+  // arrays as 4-byte words, one flat index space (few registers: this workgroup, too, runs beside a forward workgroup)
   for (int i = 0; i < n_specs; ++i) {
     const int found = cnt[2 * i];
     const int m = found < cap ? found : cap;
-    const int64_t* s_on = reinterpret_cast<const int64_t*>(dev + header + per_spec * i);
-    int64_t* d_on = reinterpret_cast<int64_t*>(host + header + per_spec * i);
-    const long L = cap > 0 ? cap : 1;
-    for (int k = tid; k < m; k += 256) {
-      d_on[k] = s_on[k];
-      d_on[L + k] = s_on[L + k];
-      d_on[2 * L + k] = s_on[2 * L + k];
-      reinterpret_cast<float*>(d_on + 3 * L)[k] = reinterpret_cast<const float*>(s_on + 3 * L)[k];
+    const unsigned* src = reinterpret_cast<const unsigned*>(dev + header + per_spec * i);
+    unsigned* dst = reinterpret_cast<unsigned*>(host + header + per_spec * i);
+    for (int w = tid; w < 7 * m; w += 256) {
+      const int arr = w / (2 * m);                                       // 0, 1, 2: the int64 arrays (2 m words each); 3: the values
+      const long o = arr < 3 ? 2 * L * arr + (w - 2 * m * arr) : 6 * L + (w - 6 * m);
+      dst[o] = src[o];
     }
     if (tid == 0) {
       hcnt[2 * i] = found;
