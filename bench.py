@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--repeats", type=int, default=21,
                     help="the K steps are timed this many times, each between two synchronisations; value = median "
                          "(the first ~6 regions after an idle GPU run at ramping clocks: timing.windows_per_s_first)")
+    ap.add_argument("--settle-seconds", type=float, default=0.4,
+                    help="untimed steps run for this long between the W warm-up steps and the timed regions, so that the shader "
+                         "clock has climbed to what it holds under the load (0 = none)")
     ap.add_argument("--model", default="both", choices=["both", "phasenet", "eqtransformer"])
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -657,6 +660,16 @@ def bench_model(model_name, env, cpu_budget_s):
 
     n_picks = run_steps(args.warmup)
     assert nw.value == args.batch, (nw.value, args.batch)
+    # Clock settling, untimed: after an idle GPU the shader clock climbs for tens of milliseconds (round 4: the 21 regions of
+    # 20 PhaseNet steps ran 100.3, 103.8, 99.9 ... 87.3 us per step in order, still falling at the end, against 84.9 us in the
+    # 5 s region behind them), so W warm-up steps of 0.09 ms leave the timed regions on the ramp.  More warm-up steps of the same
+    # kind run until --settle-seconds have passed; the timed regions are K steps each, exactly as before.
+    settle_steps, t_settle = 0, time.perf_counter()
+    while args.settle_seconds > 0 and time.perf_counter() - t_settle < args.settle_seconds:
+        run_steps(max(args.steps, 20))
+        settle_steps += max(args.steps, 20)
+    torch.cuda.synchronize()
+    t_settle = time.perf_counter() - t_settle
     times = timed_repeats(lambda: run_steps(args.steps), sync_all, args.repeats, use_dist, dev)
     env["own_times"] = list(OWN_TIMES)
     n_picks = found.value
@@ -762,6 +775,8 @@ def bench_model(model_name, env, cpu_budget_s):
             "windows_per_s_min": windows / max(times),
             "windows_per_s_max": windows / min(times),
             "windows_per_s_first": windows / times[0],
+            "settle": {"seconds": t_settle, "steps": settle_steps,
+                       "note": "untimed steps between the W warm-up steps and the timed regions (clock settling, --settle-seconds)"},
             "ms_per_step_all": [t / args.steps * 1e3 for t in times],
         },
         "config": {
