@@ -111,12 +111,13 @@ struct ForwardGate {
   static constexpr int RING = 8, DIST = 2;
   std::mutex mu;
   hipEvent_t done[RING] = {};
+  hipStream_t by[RING] = {};  // the stream launch (seq % RING) went to
   bool made = false;
   unsigned long long seq = 0;
 };
 ForwardGate& forward_gate(int device) {
-  static ForwardGate gates[16];
-  return gates[(unsigned)device % 16];
+  static ForwardGate gates[64];
+  return gates[(unsigned)device % 64];
 }
 struct ForwardTurn {  // RAII around one forward launch of a gated plan
   ForwardGate* g = nullptr;
@@ -131,14 +132,15 @@ struct ForwardTurn {  // RAII around one forward launch of a gated plan
       g->made = true;
     }
     if (g->seq >= ForwardGate::DIST) {
-      hipEvent_t e = g->done[(g->seq - ForwardGate::DIST) % ForwardGate::RING];
-      if (e) (void)hipStreamWaitEvent(s, e, 0);
+      const int k = (int)((g->seq - ForwardGate::DIST) % ForwardGate::RING);
+      if (g->done[k] && g->by[k] != s) (void)hipStreamWaitEvent(s, g->done[k], 0);  // (its own stream is in order anyway)
     }
   }
   ~ForwardTurn() {
     if (!g) return;
-    hipEvent_t e = g->done[g->seq % ForwardGate::RING];
-    if (e) (void)hipEventRecord(e, s);
+    const int k = (int)(g->seq % ForwardGate::RING);
+    if (g->done[k]) (void)hipEventRecord(g->done[k], s);
+    g->by[k] = s;
     ++g->seq;
     g->mu.unlock();
   }
