@@ -132,3 +132,32 @@ def test_profile_after_the_source_stream_is_gone_reads_no_freed_memory(cls_name)
     x = synthetic_windows(2, T, seed=1)
     assert torch.isfinite(m._forward_raw(torch.from_numpy(x).cuda(), preprocess=True)).all()  # the handle is still good
     m._release()
+
+
+def test_first_come_first_served_forward_launches_change_no_result():
+    """PhaseNet's device contexts queue their forward launches first come, first served (csrc/api.hip ForwardGate: launch n + 2
+    waits for the end of launch n); plan_flags[3] = 64 switches the gate off.  Same numbers either way: a day-long block over
+    all contexts (the stacked rows, bitwise) and many station blocks pipelined over the contexts (the picks)."""
+    import volpick_amd as va
+
+    gated = va.PhaseNet.from_pretrained("volpick").cuda()
+    free = va.PhaseNet.from_pretrained("volpick")
+    free._plan_flags = (0, 0, 0, 64)
+    free.cuda()
+    data, _, _ = synthetic_stream_array(3001 + 1501 * 2300, seed=21, n_events=120)
+    args = gated._argdict(dict(overlap=1500, blinding=(0, 0), stacking="avg", batch_size=256))
+    assert gated._is_long(data.shape[1], args)
+    a, fva, lva, nwa = gated._annotate_segments(data, args)
+    b, fvb, lvb, nwb = free._annotate_segments(data, args)
+    assert (fva, lva, nwa) == (fvb, lvb, nwb) and nwa == 2301
+    assert torch.equal(a, b)
+    t0 = va.UTCDateTime("2021-01-01T00:00:00")
+    st = va.Stream()
+    for k in range(9):
+        d, _, _ = synthetic_stream_array(60_000, seed=300 + k, n_events=5)
+        for i, c in enumerate("ZNE"):
+            st.append(va.Trace(d[i], dict(network="XX", station=f"S{k:02d}", location="", channel=f"HH{c}", starttime=t0, sampling_rate=100.0)))
+    key = lambda res: [(p.trace_id, p.phase, p.peak_time.timestamp, p.peak_value) for p in res.picks]
+    pa, pb = key(gated.classify(st)), key(free.classify(st))
+    assert len(pa) > 20 and pa == pb
+    gated._release(), free._release()
