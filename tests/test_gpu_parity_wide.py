@@ -3,7 +3,7 @@ north-star bar, and inputs / weights far from the O(1) activations of volpick_am
 (the bf16-piece kernels) against the CPU oracle.
 
 Two bars.  CONTRACT = 1e-4 absolute on probabilities (BASELINE.json north_star).  REGRESSION = 3e-5: the measured
-distance to the oracle is 1.1e-5 at most (profiles/r02_err_check_vs_oracle.txt), so a change that quintuples it -- one
+distance to the oracle is 1.1e-5 at most (profiles/archive/r02_err_check_vs_oracle.txt), so a change that quintuples it -- one
 dropped piece product, one wrong rounding mode -- fails here long before it reaches the contract bar."""
 import copy
 
