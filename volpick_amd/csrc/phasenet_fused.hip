@@ -930,8 +930,6 @@ struct WindowArgs {
   const uint4* af3_u2[2];  // U2B: up2.same's operand per input half (skip 1 | up2.convT), 16-channel K-steps (B3Steps<16, 7>)
   const uint4* af3_uT[2];  // U3B: up1.convT / up2.convT, rows (phase, channel)
   const uint4* af3_d12[2]; // D12B: down1.same (B3Steps<8, 7>), down2.same (B3Steps<16, 7>)
-  const uint4* af3_d0s;    // D0B: down0.same, rows (phase, channel), K-steps of four taps x 8 channels (B3Steps<8, 8>)
-  const float* bs_d0s;     // D0B: its bias [8] (BatchNorm folded)
   const float* x;   // [B][3][ls] normalised input
   int ls_x;
   long ws_x;
@@ -1017,23 +1015,9 @@ static_assert(B3_U2_OFF3 * 4 + 3 * B3Chunk<16, B3_U2_NC3>::PS * 2 <= CORE_LDS_FL
 constexpr int B3_D0_NC = 760, B3_D1_NC = 200;  // sample t at column t + 3
 static_assert(A_D0 * 4 + 3 * B3Chunk<8, B3_D0_NC>::PS * 2 <= CORE_LDS_FLOATS * 4 && B3_D0_NC >= 47 * 16 + 7 && B3_D1_NC >= 192 + 7,
               "down0.down / down1.down as piece images");
-// D0B (with D12B): down0.same on the bf16 matrix cores as well, SLICE BY SLICE.  The layer's input (inc's output, 8 channels x
-// 3001 samples) takes 144 KB as a piece image and cannot rest in LDS beside its fp32 form, but a slice of it can: the GEMM is
-// M = 16 rows (output phase p, channel), N = 1501 columns n <-> samples 2 n + p, K = 8 taps j x 8 channels (rows of phase 1 carry
-// the filter shifted by one tap, tap 7 / tap 0 zero), B[(j, ci)][n] = x[ci][2 n + j - 3].  A slice is 256 columns = one
-// n-tile per wave: every thread converts one (sample, channel quad) of the NEXT slice's 520 input samples into the other of
-// two 25 KB piece images (chunk planes, in the 65 KB behind the fp32 rows that x leaves free) while its wave's twelve MFMAs of
-// THIS slice run, one barrier, then the slice's outputs overwrite inc in place (the next slice's input -- their ranges overlap
-// by three samples -- is already converted).  Six slices: 1128 MFMAs + ~40 vector instructions of splitting per thread and
-// slice instead of 896 packed FMAs per lane (17.1 k -> see DESIGN.md cycles).  plan_flags[5] = 8 keeps the VALU form.
-constexpr int D0B_NS = 256, D0B_NC = 528, D0B_SLICES = (T0 / 2 + 1 + D0B_NS - 1) / D0B_NS, D0B_NT = (T0 / 2 + 1 + 15) / 16;
-constexpr int D0B_PS = B3Chunk<8, D0B_NC>::PS;  // bf16 per piece of a slice image
-static_assert(D0B_SLICES == 6 && D0B_NT == 94 && D0B_NC >= 2 * D0B_NS + 8 && WD_X * 4 + 2 * 3 * D0B_PS * 2 <= CORE_LDS_FLOATS * 4,
-              "down0.same slices: two piece images behind the eight fp32 rows");
-template <bool PIPE, bool B3, bool U1B = false, bool U2B = false, bool U3B = false, bool D12B = false, bool D0B = false>
+template <bool PIPE, bool B3, bool U1B = false, bool U2B = false, bool U3B = false, bool D12B = false>
 __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   static_assert(!D12B || B3, "D12B is a form of the B3 kernel");
-  static_assert(!D0B || D12B, "D0B is a form of the D12B kernel");
   static_assert(!U2B || U1B, "U2B relocates up1.same's output: needs the U1B form");
   static_assert(!U3B || U2B, "U3B builds on the U2B layout");
   constexpr int U2_NC = U3B ? B3_U2_NC3 : B3_U2_NC, U2_OFF = U3B ? B3_U2_OFF3 : B3_U2_OFF;
@@ -1258,69 +1242,6 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
       float aD[W_down::CB * W_down::TAPS], bD[4];  // A fragments of down0.down: fetched under the FMAs of down0.same
       load_areg<W_down>(a.af_down, 0, lane, aD);
       load_biasreg<W_down>(a.bs_down, 0, lane, bD);
-      if constexpr (D0B) {
-        bf16_t* const P0 = reinterpret_cast<bf16_t*>(lds) + WD_X * 2;
-        uint4 aw[B3Steps<8, 8>::STEPS * 3];
-        b3_load_a<8, 8>(a.af3_d0s, 0, lane, aw);
-        const int g = lane >> 4, n = lane & 15;
-        float biasv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) biasv[r] = a.bs_d0s[(4 * g + r) & 7];  // GEMM row 4 g + r = (phase, channel)
-        // one (sample, channel quad) of slice k per thread (+ 16 left over): sample 512 k - 3 + col -> column col
-        auto convert = [&](const int k) {
-          bf16_t* const P = P0 + (k & 1) * 3 * D0B_PS;
-          for (int item = tid; item < 2 * (2 * D0B_NS + 8); item += NTH) {
-            const int col = item >> 1, quad = item & 1, hc = 512 * k + 1 + col;  // H column of the sample: 4 + t
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = hc < W0_S ? H[(4 * quad + r) * W0_S + hc] : 0.f;
-            b3c_store4<8, D0B_NC>(P, col, quad, v);
-          }
-        };
-        convert(0);
-        lds_barrier();
-#pragma unroll 1
-        for (int k = 0; k < D0B_SLICES; ++k) {
-          const int nt = 16 * k + wave;  // this wave's n-tile of the slice
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          if (nt < D0B_NT) {
-            const bf16_t* p = P0 + (k & 1) * 3 * D0B_PS + (2 * (16 * wave + n) + g) * 8;
-            uint4 b[2][3];
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-              for (int pc = 0; pc < 3; ++pc) b[st][pc] = *reinterpret_cast<const uint4*>(p + pc * D0B_PS + 4 * st * 8);
-            if (k + 1 < D0B_SLICES) convert(k + 1);
-            constexpr int WP[6] = {2, 1, 0, 1, 0, 0}, XP[6] = {0, 1, 2, 0, 1, 0};  // (w piece, x piece), smallest products first
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-              for (int t6 = 0; t6 < 6; ++t6)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, aw[st * 3 + WP[t6]]),
-                                                             __builtin_bit_cast(bf16x8_b3, b[st][XP[t6]]), acc, 0, 0, 0);
-          } else if (k + 1 < D0B_SLICES) {
-            convert(k + 1);
-          }
-          lds_barrier();  // every wave is through with this slice's image and with its share of the next one's input
-          if (nt < D0B_NT) {
-            const int t = 2 * (16 * nt + n) + (g >> 1);
-            if (t < W0_S - 4) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-                H[((4 * g + r) & 7) * W0_S + 4 + t] = t < T0 ? fmaxf(acc[r] + biasv[r], 0.f) : 0.f;
-            }
-          }
-        }
-        lds_barrier();  // down0.same complete in H
-        b3c_zero_rest<8, B3_D0_NC>(reinterpret_cast<bf16_t*>(lds) + A_D0 * 2, 3, B3_D0_NC, tid, NTH);  // (the slice images are dead)
-        if (own) {  // the skip tensor: this lane's four samples of every channel, from the finished rows
-          float* d = a.skip0 + (long)win * a.ws_s + HALO + t0;
-#pragma unroll
-          for (int c = 0; c < 8; ++c)
-            *reinterpret_cast<f32x4*>(d + (long)c * a.ls_s) = *reinterpret_cast<const f32x4*>(H + c * W0_S + 4 + t0);
-        }
-        lds_barrier();
-      } else {
       f32x2 acc[4][4];
       if (vconv) {
         valu_bias(acc, a.b_same);
@@ -1351,7 +1272,6 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
           *reinterpret_cast<f32x4*>(d + (long)(2 * c) * a.ls_s) = lo[c];
           *reinterpret_cast<f32x4*>(d + (long)(2 * c + 1) * a.ls_s) = hi[c];
         }
-      }
       }
       WIN_STAMP(21)
       // down0.down: Conv1d(8, 8, 7, stride 4, pad 3) + BN + ReLU on the MFMA, straight into the core's input image
@@ -1795,7 +1715,6 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
   const bool u2b = u1b && net.cfg.plan_flags[5] != 5;   // plan_flags[5] = 5: only up2.same does
   const bool u3b = u2b && net.cfg.plan_flags[5] != 6;   // plan_flags[5] = 6: up1.convT / up2.convT stay on the fp32 MFMA
   const bool d12b = u3b && net.cfg.plan_flags[5] != 7;  // plan_flags[5] = 7: down1.same / down2.same stay on the fp32 MFMA
-  const bool d0b = d12b && net.cfg.plan_flags[5] != 8;  // plan_flags[5] = 8: down0.same stays on the vector ALUs
   HostBlob *vw[5] = {}, *vb[5] = {};
   if (valu) {
     const float eps = net.cfg.bn_eps;
@@ -2003,8 +1922,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         else if (u3b && i == 14) bf16 += 4.0 * 12 * 2 * 6 * 16384.0;      // up2.convT: 4 m-tiles x 12 n-tiles x 2 K-steps
         else f32 += padded(i);
       }
-      if (d0b) bf16 += (double)D0B_NT * 2 * 6 * 16384.0;  // down0.same: 94 n-tiles x 2 K-steps of six MFMAs
-      st.set_issued(f32, bf16, (d0b ? flops(0, 0) : flops(0, 1)) + flops(17, 17));
+      st.set_issued(f32, bf16, flops(0, 1) + flops(17, 17));
     }
     HostBlob* e0 = &net.convs[17]->e0;
     HostBlob* e1 = &net.convs[17]->e1;
@@ -2024,7 +1942,6 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
       p3d12[0] = net.add_blob(b3_operand(*net.convs[3 + 0], false));
       p3d12[1] = net.add_blob(b3_operand(*net.convs[3 + 2], false));
     }
-    HostBlob* p3d0s = d0b ? net.add_blob(b3_operand(*net.convs[1], true)) : nullptr;
     HostBlob* p3uT[2] = {};
     if (u3b) {
       p3uT[0] = net.add_blob(b3_operand(*net.convs[3 + 9], true));
@@ -2073,8 +1990,6 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
       for (int i = 0; i < 13; ++i) a.af4[i] = q4[i] ? q4[i]->d : nullptr;
       for (int i = 0; i < 2; ++i) a.af3_d12[i] = p3d12[i] ? reinterpret_cast<const uint4*>(p3d12[i]->d) : nullptr;
       for (int i = 0; i < 2; ++i) a.af3_uT[i] = p3uT[i] ? reinterpret_cast<const uint4*>(p3uT[i]->d) : nullptr;
-      a.af3_d0s = p3d0s ? reinterpret_cast<const uint4*>(p3d0s->d) : nullptr;
-      a.bs_d0s = n.convs[1]->bias.d;
       for (int i = 0; i < 2; ++i) a.af3_u2[i] = p3u2[i] ? reinterpret_cast<const uint4*>(p3u2[i]->d) : nullptr;
       for (int i = 0; i < 6; ++i) {
         a.af3[i] = p3[i] ? reinterpret_cast<const uint4*>(p3[i]->d) : nullptr;
@@ -2111,9 +2026,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         a.pre = *n.pre;
         a.has_pre = 1;
       }
-      if (d0b) {
-        hipLaunchKernelGGL((pn_window_kernel<false, true, true, true, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
-      } else if (d12b) {
+      if (d12b) {
         hipLaunchKernelGGL((pn_window_kernel<false, true, true, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
       } else if (u3b) {
         hipLaunchKernelGGL((pn_window_kernel<false, true, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
@@ -2141,7 +2054,6 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
-    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
   }
   net.steps = std::move(steps);
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_core_kernel<true>), CORE_LDS_FLOATS * sizeof(float)});
