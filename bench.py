@@ -812,6 +812,13 @@ def bench_model(model_name, env, cpu_budget_s):
             "pipe_time_ms": dom_pipe_s * 1e3,
             "kernel_ms": dom_ms.value,
             "kernel_ms_back_to_back": dom["ms"],
+            "kernel_ms_note": "HIP events around the launch, 200 passes on ONE stream: every pass pays the event records and the "
+                              "drain / refill of the chip between two launches of one queue (what rocprofv3's AverageNs of the same "
+                              "command shows, profiles/); in the timed loop the device contexts' launches follow each other without "
+                              "that gap, so a whole STEP there can be shorter than this figure (step_bound)",
+            "step_bound": ({"ms": sustained["ms_per_step"] * (len(kernels) == 1), "frac": dom_pipe_s * 1e3 / sustained["ms_per_step"],
+                            "note": "one-launch plan: the launch cannot take longer than a whole step of the sustained region"}
+                           if sustained and len(kernels) == 1 and world == 1 else None),
             "algorithmic": {
                 "tflops": dom_algorithmic,
                 "flop_over_fp32_peak": dom_algorithmic / PEAK_FP32_TFLOPS,
