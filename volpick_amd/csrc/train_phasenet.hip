@@ -183,6 +183,12 @@ struct Trainer {
   bool bf16 = false;  // activation / gradient rows stored as bfloat16 (weights, gradients, statistics, Adam: fp32)
   int esize = 4;      // bytes per row element
   hipStream_t stream = nullptr;
+  // The weight gradients run on a stream of their own: wgrad of layer L needs gz of L and the activations below it, nothing
+  // downstream needs its result before the fold at the end of the step, and the backward chain (BatchNorm backward -> input
+  // gradient -> next layer's BatchNorm backward) is a string of short launches that leave most of the chip idle in the deep
+  // layers.  Events order the two: ev_gz[L] (gz of L complete) -> wgrad of L; ev_wg (all weight gradients) -> fold + Adam.
+  hipStream_t stream_wg = nullptr;
+  hipEvent_t ev_gz[32] = {}, ev_wg = nullptr;
   std::vector<Tensor> tensors;
   std::vector<Layer> layers;
   std::map<std::string, long> poff;  // parameter name -> offset in the flat blob
@@ -240,6 +246,10 @@ struct Trainer {
                     (void*)head_sums, (void*)head_stage, (void*)x_dev, (void*)y_dev, (void*)p_dev})
       if (p) (void)hipFree(p);
     if (stream) (void)hipStreamDestroy(stream);
+    if (stream_wg) (void)hipStreamDestroy(stream_wg);
+    for (hipEvent_t e : ev_gz)
+      if (e) (void)hipEventDestroy(e);
+    if (ev_wg) (void)hipEventDestroy(ev_wg);
   }
 };
 
@@ -539,6 +549,9 @@ int upload(Trainer& tr, const float* weights) {
   // on the default stream: they are complete before the first step can be enqueued.
   TR_HIP(hipDeviceSynchronize());
   TR_HIP(hipStreamCreateWithFlags(&tr.stream, hipStreamNonBlocking));
+  TR_HIP(hipStreamCreateWithFlags(&tr.stream_wg, hipStreamNonBlocking));
+  for (int i = 0; i < NLAYER; ++i) TR_HIP(hipEventCreateWithFlags(&tr.ev_gz[i], hipEventDisableTiming));
+  TR_HIP(hipEventCreateWithFlags(&tr.ev_wg, hipEventDisableTiming));
   return VP_OK;
 }
 
@@ -703,7 +716,9 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
       const int cap = w.out_n > 10000 ? 256 : 512;  // one partial result per workgroup: fewer, longer-lived workgroups for the big weight tensors
       const int grid = items < cap ? items : cap;
       ++g_launches;
-      w.launch(g, grid, s);
+      (void)hipEventRecord(tr.ev_gz[li], s);  // gz of this layer is complete (bn_backward_v above)
+      (void)hipStreamWaitEvent(tr.stream_wg, tr.ev_gz[li], 0);
+      w.launch(g, grid, tr.stream_wg);
       SumJob& jb = jobs.job[jobs.count++];
       jb.partial = g.partial;
       jb.out = tr.grad + w.grad_off;
@@ -726,6 +741,8 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     }
     if (L.dgrad.used) run_conv(tr, L.dgrad, B);
   }
+  (void)hipEventRecord(tr.ev_wg, tr.stream_wg);
+  (void)hipStreamWaitEvent(s, tr.ev_wg, 0);  // every weight gradient's partial rows are written
   TRL(sum_rows_multi_kernel, dim3(sum_blocks), dim3(256), 0, s, jobs);
   if (update) {
     tr.step += 1;
