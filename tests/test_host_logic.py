@@ -298,5 +298,13 @@ def test_records_from_columns_sort_like_the_records_and_are_built_on_first_touch
     both += picks
     both.append(want_p[0])
     assert len(both) == len(want_p) + 1 and str(both).startswith(f"PickList with {len(want_p) + 1} entries")
+    import copy
+    import pickle
+
+    again, _ = _records_from_columns(cols, tids, t0s, labels, 100.0)
+    assert again._lazy is not None
+    clone = pickle.loads(pickle.dumps(again))  # a deferred list travels as its records (multiprocessing, dist.gather_object)
+    assert isinstance(clone, va.PickList) and list(clone) == sorted(want_p) and list(copy.deepcopy(again)) == sorted(want_p)
+    assert list(again.copy()) == sorted(want_p) and list(again[:3]) == sorted(want_p)[:3]
     empty_p, empty_d = _records_from_columns([], [], [], labels, 100.0)
     assert len(empty_p) == 0 and list(empty_d) == []

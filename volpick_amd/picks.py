@@ -82,6 +82,16 @@ class _PrintableList(UserList):
     def __len__(self):
         return self._lazy[0] if self._lazy is not None else len(self._data)
 
+    def __getstate__(self):  # pickling / copying hands over the records, never the deferred builder
+        return {"_data": self.data, "_lazy": None}
+
+    def __setstate__(self, state):
+        self._lazy = None
+        self._data = list(state["_data"])
+
+    def copy(self):
+        return self.__class__(self.data)
+
     def __str__(self):
         head = f"{self._name} with {len(self)} entries:\n\n"
         if len(self) <= 20:
