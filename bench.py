@@ -60,6 +60,131 @@ def pipe_time_s(issued, batch):
     return batch * (issued["mfma_f32"] / (PEAK_FP32_TFLOPS * 1e12) + issued["mfma_bf16"] / (PEAK_BF16_TFLOPS * 1e12) +
                     issued["valu"] / (PEAK_FP32_TFLOPS * 1e12))
 
+COMPACT_LIMIT = 8000  # bytes: the driver keeps the last 8 KB of stdout and parses the last line (round 4's 20 KB line was cut)
+
+
+def _r(v, sig=6):
+    """Round floats to `sig` significant digits (bytes matter in the compact line); NaN / inf -> None (strict JSON)."""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float(f"{v:.{sig}g}")
+    if isinstance(v, dict):
+        return {k: _r(x, sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, sig) for x in v]
+    return v
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _compact_model(m):
+    """The short form of one model's result (the top-level PhaseNet line or the `eqtransformer` object)."""
+    out = _pick(m, "value", "unit", "ms_per_step")
+    if isinstance(m.get("config"), dict):
+        out["config"] = _pick(m["config"], "workload", "batch", "parallelism")
+    t = m.get("timing") or {}
+    if t:
+        out["timing"] = _pick(t, "repeats", "windows_per_s_min", "windows_per_s_max")
+        if isinstance(t.get("settle"), dict):
+            out["timing"]["settle"] = _pick(t["settle"], "steps", "seconds")
+    if m.get("sustained"):
+        out["sustained"] = _pick(m["sustained"], "value", "ms_per_step", "seconds", "shader_clock_ghz")
+    r = m.get("roofline")
+    if r:
+        rr = _pick(r, "bound", "kernel", "achieved", "peak", "unit", "frac", "kernel_ms", "pipe_time_ms", "traffic")
+        if isinstance(rr.get("kernel"), str):
+            rr["kernel"] = rr["kernel"][:72]
+        if r.get("step_bound"):
+            rr["step_bound"] = _pick(r["step_bound"], "ms", "frac")
+        if r.get("algorithmic"):
+            rr["algorithmic"] = _pick(r["algorithmic"], "tflops", "flop_over_fp32_peak")
+        out["roofline"] = rr
+    c = m.get("cpu_baseline")
+    if c:
+        out["cpu_baseline"] = _pick(c, "value", "unit", "cores", "kind", "cpu_model", "physical_cores", "cgroup_cpu_quota")
+        if isinstance(c.get("sample"), str):
+            out["cpu_baseline"]["sample"] = c["sample"][:110]
+    if m.get("pick_parity"):
+        out["pick_parity"] = _pick(m["pick_parity"], "picks_hip", "picks_oracle", "max_abs_dt_samples", "max_abs_dvalue")
+    a = m.get("api")
+    if a:
+        out["api"] = _pick(a, "windows", "wall_ms", "wall_ms_records_built", "value", "picks")
+        if isinstance(a.get("cpu_oracle_10min"), dict):
+            out["api"]["picks_identical_10min"] = a["cpu_oracle_10min"].get("picks_identical")
+    if m.get("ranks"):
+        out["ranks"] = [_pick(x, "rank", "device", "ms_per_step_own_median", "weight_broadcast_path", "rccl_comm_ranks", "segment")
+                        for x in m["ranks"]]
+    return out
+
+
+def compact_line(result, detail_path=None):
+    """The ONE line the driver parses: the contract's keys plus the short form of every object of the full result
+    (which goes to `detail_path` and to stderr).  Strict JSON (no NaN), < COMPACT_LIMIT bytes -- asserted."""
+    out = _pick(result, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data")
+    body = _compact_model(result)
+    for k in ("value", "unit", "ms_per_step"):
+        body.pop(k, None)
+    out.update(body)
+    for k in ("weight_broadcast_path", "weight_broadcast_s", "picks", "detections"):
+        if k in result:
+            out[k] = result[k]
+    if result.get("ranks"):
+        out["rccl_comm_ranks"] = result["ranks"][0].get("rccl_comm_ranks")
+    if isinstance(result.get("eqtransformer"), dict):
+        out["eqtransformer"] = _compact_model(result["eqtransformer"])
+    tr = result.get("train")
+    if isinstance(tr, dict):
+        out["train"] = _pick(tr, "value", "unit", "ms_per_step", "batch", "dtype", "launches_per_step", "loss_after",
+                             "loss_torch_same_batch", "vs_torch_rocm", "error")
+        if isinstance(tr.get("roofline"), dict):
+            out["train"]["roofline"] = _pick(tr["roofline"], "bound", "achieved", "peak", "unit", "frac")
+    ms = result.get("mseed")
+    if isinstance(ms, dict):
+        out["mseed"] = _pick(ms, "value", "unit", "kernel_ms", "bit_exact_vs_fixture_samples", "file_to_picks_ms", "error")
+        if "read_wall_ms_host_file_to_host_stream" in ms:
+            out["mseed"]["read_wall_ms"] = ms["read_wall_ms_host_file_to_host_stream"]
+        if isinstance(ms.get("roofline"), dict):
+            out["mseed"]["roofline"] = _pick(ms["roofline"], "bound", "achieved", "peak", "unit", "frac")
+        if isinstance(ms.get("cpu_baseline"), dict):
+            out["mseed"]["cpu_baseline"] = _pick(ms["cpu_baseline"], "value", "unit", "cores", "kind")
+    if detail_path:
+        out["detail"] = str(detail_path)
+    out = _r(out)
+    line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    if len(line) >= COMPACT_LIMIT and "ranks" in out:  # many ranks: the per-rank objects are in the detail file
+        out["ranks"] = [_pick(x, "rank", "ms_per_step_own_median") for x in out["ranks"]]
+        line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    assert len(line) < COMPACT_LIMIT, f"compact bench line is {len(line)} bytes (limit {COMPACT_LIMIT})"
+    return line
+
+
+def emit(result, detail_file):
+    """Full result -> `detail_file` (+ stderr); compact line -> the LAST line of stdout."""
+    full = json.dumps(_r(result, 9), allow_nan=False)
+    path = None
+    if detail_file:
+        try:
+            Path(detail_file).parent.mkdir(parents=True, exist_ok=True)
+            Path(detail_file).write_text(full + "\n")
+            path = detail_file
+        except OSError as e:
+            sys.stderr.write(f"bench.py: cannot write {detail_file}: {e}\n")
+    sys.stderr.write("bench.py detail: " + full + "\n")
+    sys.stderr.flush()
+    rel = None
+    if path:
+        try:
+            rel = str(Path(path).resolve().relative_to(ROOT))
+        except ValueError:
+            rel = str(path)
+    print(compact_line(result, rel), flush=True)
+
 
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` with N > 1 and no RANK in the environment: start the N ranks as ONE child process
@@ -149,6 +274,8 @@ def main():
     ap.add_argument("--no-train-torch", action="store_true",
                     help="`train` without the stock PyTorch-ROCm step beside it (MIOpen's first-use find costs ~35 s on a fresh box)")
     ap.add_argument("--no-mseed", action="store_true", help="skip the `mseed` object (SURVEY 8f-1: Steim-2 station-day decode)")
+    ap.add_argument("--detail-file", default=str(ROOT / "bench_detail.json"),
+                    help="the full result object goes here (and to stderr); stdout's last line is the compact (< 8 KB) form of it")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="rehearsal of the N > 1 plumbing on a ONE-GPU box: process group over gloo, every rank on cuda:0, weights "
                          "through the host broadcast (no RCCL); the line it prints is not a measurement")
@@ -213,7 +340,7 @@ def main():
                     result[key] = {"error": repr(e)[:400]}
                 result[key]["bench_seconds"] = time.perf_counter() - t0
     if rank == 0:
-        print(json.dumps(result))
+        emit(result, args.detail_file)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -330,6 +457,13 @@ def bench_api(model_name, model, batch, oracle_threads=None):
             t = time.perf_counter()
             res = model.classify(st, **kw)
             walls.append(time.perf_counter() - t)
+        walls_built = []  # the same call with every Pick / Detection record materialised inside the timed region (what the
+        for _ in range(5):  # reference's classify() hands back: plain lists of records)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r2 = model.classify(st, **kw)
+            n_built = len(list(r2.picks)) + len(list(getattr(r2, "detections", []) or []))
+            walls_built.append(time.perf_counter() - t)
     finally:
         gc.callbacks.remove(gc_watch)
     model._timing = {}
@@ -361,6 +495,9 @@ def bench_api(model_name, model, batch, oracle_threads=None):
         "wall_ms": wall * 1e3,
         "wall_ms_all": [w * 1e3 for w in walls],
         "wall_statistic": f"median of {len(walls)} calls",
+        "wall_ms_records_built": statistics.median(walls_built) * 1e3,
+        "records_built": n_built,
+        "value_records_built": n_windows / statistics.median(walls_built),
         "full_gc_collections_in_timed_calls": [{"call": i, "pause_ms": ms} for i, ms in pauses],
         "gc_note": "round 3's 65 ms call among 24-27 ms ones was a full (generation 2) collection of CPython's cyclic collector "
                    "(30-37 ms in a process that has torch imported), driven by the ~10 k record objects each call built; classify() "
@@ -409,14 +546,38 @@ def bench_train(batch=512, steps=30, warmup=5, torch_steps=6, torch_baseline=Tru
         tr.synchronize()
         times.append((time.perf_counter() - t0) / steps)
     dt = statistics.median(times)
-    loss = tr.step(xd, yd, 1e-4)
+    # loss of the batch at the weights the timed steps arrived at (no update), and -- the comparator -- the same batch through
+    # torch autograd's forward on the oracle module carrying THE SAME weights and the same bf16 storage points
+    w_now = tr.weights()
+    loss = tr.step(xd, yd, 0.0, update=False)
+    launches_fwd_bwd = int(tr._lib.vp_train_launch_count(tr._h))
+    tr.step(xd, yd, 1e-4, want_loss=False)
+    tr.synchronize()
     launches = int(tr._lib.vp_train_launch_count(tr._h))
+    loss_torch = None
+    try:
+        from oracle.bf16_emulation import bf16_storage
+        from oracle.models import load_pretrained as _lp
+
+        chk = _lp("phasenet")
+        chk.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in w_now.items()}, strict=False)
+        chk = chk.cuda().train()
+        with torch.no_grad(), bf16_storage(chk) as cn:
+            pr = cn(xd)
+            loss_torch = float(-(yd * torch.log(pr + 1e-5)).mean(-1).sum(-1).mean())
+        del chk, pr
+    except Exception as e:  # noqa: BLE001 -- the comparator must not cost the line
+        loss_torch = repr(e)[:200]
     flop = 3 * 38.93e6  # forward FLOP per 3x3001 window; backward = input gradient + weight gradient = 2x
     out = {
         "metric": "PhaseNet training windows/sec (fwd + loss + bwd + Adam)", "value": batch / dt, "unit": "windows/s",
         "ms_per_step": dt * 1e3, "ms_per_step_all": [t * 1e3 for t in times], "batch": batch, "steps": steps, "warmup": warmup,
         "dtype": "bf16 storage / f32 accumulate", "data": "synthetic (VCSEIS-shaped: 3 x 3001, Gaussian P/S labels sigma 20)",
-        "launches_per_step": launches, "loss_after": loss,
+        "launches_per_step": launches, "launches_without_update": launches_fwd_bwd, "loss_after": loss,
+        "loss_torch_same_batch": loss_torch,
+        "loss_note": "loss_after: the batch at the weights the timed steps arrived at (vp_train_step, update = 0); "
+                     "loss_torch_same_batch: the same batch and weights through the torch module (training-mode BatchNorm, "
+                     "bf16 storage points of oracle/bf16_emulation.py) on this GPU",
         "roofline": {"bound": "mfma", "achieved": flop * batch / dt / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": flop * batch / dt / (PEAK_FP32_TFLOPS * 1e12),
                      "basis": "algorithmic 3 x forward FLOP of the whole step (all launches) / step time, against the dense fp32 "

@@ -373,6 +373,12 @@ int vp_train_set_hyper(vp_trainer* t, float beta1, float beta2, float adam_eps, 
 int vp_train_set_ema(vp_trainer* t, float decay);
 int vp_train_step(vp_trainer* t, const float* x, const float* y, int mem, int B, float lr, int update, double* loss);
 int vp_train_synchronize(vp_trainer* t);
+/* The trainer runs on its own non-blocking stream (vp_train_stream).  A caller that hands vp_train_step DEVICE x / y
+ * produced on another stream (a) makes the trainer's stream wait for them before the call (an event of its stream that
+ * vp_train_stream waits for) and (b) calls this afterwards: `stream` (hipStream_t, NULL = legacy default stream) then
+ * waits, on the device, for the point behind the step's last read of x / y -- so refilling or freeing them on `stream`
+ * cannot overtake a queued step.  Host x / y are staged inside vp_train_step and need neither. */
+int vp_train_wait_inputs_consumed(vp_trainer* t, void* stream);
 int vp_train_read(vp_trainer* t, int which, float* out, size_t n_floats);
 int vp_train_write_weights(vp_trainer* t, const float* weights, size_t n_floats);
 int vp_train_predictions(vp_trainer* t, float* out, int B);

@@ -91,3 +91,64 @@ def test_launch_ranks_relays_the_one_json_line(tmp_path, monkeypatch):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and "--nproc-per-node 2" in d["argv"] and "--master-addr 127.0.0.1" in d["argv"] and d["argv"].endswith("--gpus 2 --steps 3")
     assert "noise from a rank" in out.stderr
+
+
+# ---- the compact line: what the driver parses (round 4's 20 KB line crossed its 16 KiB limit and was recorded as null) ----
+def _required(d, path):
+    cur = d
+    for k in path.split("."):
+        assert isinstance(cur, dict) and k in cur, f"compact line lacks {path}"
+        cur = cur[k]
+    return cur
+
+
+def test_compact_line_from_round_4_detail_is_small_strict_and_complete():
+    import json
+
+    full = json.loads((Path(__file__).resolve().parents[1] / "profiles" / "r04_b_bench.json").read_text())
+    assert len(json.dumps(full)) > 16384  # the line that was cut
+    line = bench.compact_line(full, "bench_detail.json")
+    assert "\n" not in line and len(line) < 4096 < bench.COMPACT_LIMIT
+    d = json.loads(line, parse_constant=lambda c: (_ for _ in ()).throw(AssertionError(f"non-strict JSON constant {c}")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config.workload", "config.batch", "timing.repeats", "timing.settle.steps", "sustained.value",
+              "sustained.ms_per_step", "sustained.shader_clock_ghz", "roofline.bound", "roofline.kernel", "roofline.achieved",
+              "roofline.peak", "roofline.unit", "roofline.frac", "roofline.kernel_ms", "roofline.step_bound", "roofline.traffic",
+              "roofline.algorithmic.flop_over_fp32_peak", "cpu_baseline.value", "cpu_baseline.unit", "cpu_baseline.cores",
+              "cpu_baseline.kind", "cpu_baseline.cpu_model", "cpu_baseline.sample", "pick_parity.picks_hip", "pick_parity.picks_oracle",
+              "pick_parity.max_abs_dt_samples", "weight_broadcast_path", "eqtransformer.value", "eqtransformer.ms_per_step",
+              "eqtransformer.config.workload", "eqtransformer.roofline.frac", "eqtransformer.roofline.kernel_ms",
+              "eqtransformer.cpu_baseline.value", "eqtransformer.pick_parity.max_abs_dt_samples", "eqtransformer.sustained.value",
+              "train.value", "train.ms_per_step", "train.batch", "train.dtype", "train.launches_per_step", "train.roofline.frac",
+              "train.vs_torch_rocm", "mseed.value", "mseed.kernel_ms", "mseed.roofline.frac", "mseed.read_wall_ms", "detail"):
+        _required(d, k)
+    assert d["value"] == float(f"{full['value']:.6g}") and d["n_gpus"] == 1 and d["dtype"] == "f32"
+    assert abs(d["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-5
+    assert abs(d["roofline"]["achieved"] / d["roofline"]["peak"] - d["roofline"]["frac"]) < 1e-4
+
+
+def test_compact_line_never_carries_nan_and_shrinks_many_ranks():
+    import json
+
+    ranks = [{"rank": r, "device": r, "ms_per_step_own_median": 0.09, "weight_broadcast_path": "rccl", "rccl_comm_ranks": 8,
+              "librccl": {"bound_by_vp": "/x" * 200, "mapped": ["/y" * 200], "one_copy": True}, "windows_per_step": 256} for r in range(8)]
+    res = {"metric": "waveform-windows/sec", "value": float("nan"), "unit": "windows/s", "n_gpus": 8, "steps": 20, "warmup": 5,
+           "ms_per_step": float("inf"), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "w", "batch": 256, "parallelism": "p"}, "ranks": ranks, "weight_broadcast_path": "rccl"}
+    line = bench.compact_line(res)
+    d = json.loads(line)
+    assert d["value"] is None and d["ms_per_step"] is None and "NaN" not in line and "Infinity" not in line
+    assert len(d["ranks"]) == 8 and d["rccl_comm_ranks"] == 8 and "librccl" not in d["ranks"][0] and len(line) < bench.COMPACT_LIMIT
+
+
+def test_emit_prints_exactly_one_stdout_line_and_writes_the_detail(tmp_path, capsys):
+    import json
+
+    full = json.loads((Path(__file__).resolve().parents[1] / "profiles" / "r04_b_bench.json").read_text())
+    bench.emit(full, str(tmp_path / "d" / "bench_detail.json"))
+    cap = capsys.readouterr()
+    lines = cap.out.splitlines()
+    assert len(lines) == 1 and len(lines[0]) < 4096 and json.loads(lines[0])["metric"] == "waveform-windows/sec"
+    assert cap.err.startswith("bench.py detail: {")
+    det = json.loads((tmp_path / "d" / "bench_detail.json").read_text())
+    assert det["forward"]["kernels"] and det["eqtransformer"]["forward"]["kernels"]

@@ -98,8 +98,13 @@ def _layers(net):
 
 
 def test_every_kernel_against_torch_on_the_inputs_it_read(step):
-    B, x, y, tr, loss, t, g, pred = step
-    net = load_pretrained("phasenet").train()
+    check_every_kernel(*step)
+
+
+def check_every_kernel(B, x, y, tr, loss, t, g, pred, net=None):
+    """Every launch of one step against torch on the inputs that launch read (the trainer's stored tensors `t`, its
+    gradients `g`): shared with tests/test_gpu_train_large_batch.py (B = 128 / 512, the forms the bench times)."""
+    net = (net if net is not None else load_pretrained("phasenet")).train()
     T = {k: torch.from_numpy(v) for k, v in t.items()}
     pname = {id(p): k for k, p in net.named_parameters()}
     # gradient wrt a of every layer = what its consumers wrote (skips: up path + strided conv below)

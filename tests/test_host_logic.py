@@ -306,5 +306,9 @@ def test_records_from_columns_sort_like_the_records_and_are_built_on_first_touch
     clone = pickle.loads(pickle.dumps(again))  # a deferred list travels as its records (multiprocessing, dist.gather_object)
     assert isinstance(clone, va.PickList) and list(clone) == sorted(want_p) and list(copy.deepcopy(again)) == sorted(want_p)
     assert list(again.copy()) == sorted(want_p) and list(again[:3]) == sorted(want_p)[:3]
+    third, _ = _records_from_columns(cols, tids, t0s, labels, 100.0)
+    shallow = copy.copy(third)  # UserList.__copy__ would look for an instance attribute `data` (KeyError in round 4)
+    assert isinstance(shallow, va.PickList) and list(shallow) == sorted(want_p) and shallow.data is not third.data
+    assert list(copy.copy(va.PickList(sorted(want_p)[:4]))) == sorted(want_p)[:4] and len(copy.copy(va.PickList())) == 0
     empty_p, empty_d = _records_from_columns([], [], [], labels, 100.0)
     assert len(empty_p) == 0 and list(empty_d) == []

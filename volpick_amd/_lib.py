@@ -183,6 +183,7 @@ SIGNATURES = {
     "vp_train_set_ema": (C.c_int, [_H, C.c_float]),
     "vp_train_step": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(C.c_double)]),
     "vp_train_synchronize": (C.c_int, [_H]),
+    "vp_train_wait_inputs_consumed": (C.c_int, [_H, C.c_void_p]),
     "vp_train_read": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_size_t]),
     "vp_train_write_weights": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
     "vp_train_predictions": (C.c_int, [_H, C.c_void_p, C.c_int]),

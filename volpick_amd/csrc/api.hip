@@ -107,6 +107,7 @@ vp::PreArgs pre_args(const vp_handle* h, const float* src, int dense, long N, lo
 // step's stacking / trigger scan / publish run under the NEXT step's forward pass (they fit beside its workgroups: prepost.hip),
 // and the host collects step n while step n + 1 computes.  Distance 2, not 1: the successor's workgroups still move onto
 // CUs as the predecessor's leave them.
+constexpr int FORWARD_GATE_MIN_WINDOWS = 192;  // 3/4 of the 256 CUs: below it a launch leaves room for another one
 struct ForwardGate {
   static constexpr int RING = 8, DIST = 2;
   std::mutex mu;
@@ -155,8 +156,11 @@ int run_batch(vp_handle* h, const vp::PreArgs& pa, int nb) {
     h->last_pre_windows = nb;
     h->last_out_lo = net.out_lo, h->last_out_hi = net.out_hi;
   }
-  // (one-launch plans only: a plan of several launches gains from the contexts' launches interleaving)
-  const ForwardTurn turn(h, net.model_kind == VP_MODEL_PHASENET && net.steps.size() == 1 && net.cfg.plan_flags[3] != 64);
+  // (one-launch plans only: a plan of several launches gains from the contexts' launches interleaving; and only launches
+  // that fill the chip -- one workgroup per window, 256 CUs: the few-window launches of a classify() over many short
+  // blocks overlap freely across contexts, as before the gate)
+  const ForwardTurn turn(h, net.model_kind == VP_MODEL_PHASENET && net.steps.size() == 1 && net.cfg.plan_flags[3] != 64 &&
+                                nb >= FORWARD_GATE_MIN_WINDOWS);
   if (net.fused_pre && pa.preprocess) {
     net.pre = &pa;
     const int rc = net.run(nb, h->stream);

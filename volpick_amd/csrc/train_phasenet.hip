@@ -202,6 +202,7 @@ struct Trainer {
   float* adam_v = nullptr;
   float* mask = nullptr;
   float* ema = nullptr;     // EMA of the weights (allocated by vp_train_set_ema)
+  hipEvent_t ev_inputs = nullptr;  // behind the last reader of a step's x / y (the head kernel): vp_train_wait_inputs_consumed
   float ema_decay = 0.f;
   int* frag_idx = nullptr;
   float* frag = nullptr;
@@ -552,6 +553,7 @@ int upload(Trainer& tr, const float* weights) {
   TR_HIP(hipStreamCreateWithFlags(&tr.stream_wg, hipStreamNonBlocking));
   for (int i = 0; i < NLAYER; ++i) TR_HIP(hipEventCreateWithFlags(&tr.ev_gz[i], hipEventDisableTiming));
   TR_HIP(hipEventCreateWithFlags(&tr.ev_wg, hipEventDisableTiming));
+  TR_HIP(hipEventCreateWithFlags(&tr.ev_inputs, hipEventDisableTiming));
   return VP_OK;
 }
 
@@ -678,6 +680,8 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     } else {
       TRL(head_fwd_bwd_kernel, dim3(gx, B), dim3(256), 0, s, h);
     }
+    // load_rows above read x, this launch read y: nothing behind this point touches the caller's buffers
+    (void)hipEventRecord(tr.ev_inputs, s);
     // two stages: 64 row groups, then the 64 group sums
     TRL((sum_rows_kernel<double, double>), dim3(1, 64), dim3(256), 0, s, tr.head_partial, gx * B, 28,
                        tr.head_stage);
@@ -822,7 +826,10 @@ int vp_train_set_ema(vp_trainer* h, float decay) {
   VP_HIP(hipSetDevice(tr.device));
   VP_HIP(hipStreamSynchronize(tr.stream));
   if (!tr.ema) VP_HIP(hipMalloc(&tr.ema, tr.n_params * sizeof(float)));
-  VP_HIP(hipMemcpy(tr.ema, tr.w, tr.n_params * sizeof(float), hipMemcpyDeviceToDevice));  // starts at the current weights
+  // starts at the current weights; on the trainer's (non-blocking) stream, so that the next step's Adam / EMA update is
+  // ordered behind the copy (a null-stream device-to-device copy may return before it has run)
+  VP_HIP(hipMemcpyAsync(tr.ema, tr.w, tr.n_params * sizeof(float), hipMemcpyDeviceToDevice, tr.stream));
+  VP_HIP(hipStreamSynchronize(tr.stream));
   tr.ema_decay = decay;
   return VP_OK;
 }
@@ -846,6 +853,16 @@ int vp_train_step(vp_trainer* h, const float* x, const float* y, int mem, int B,
     VP_HIP(hipMemcpyAsync(loss, tr.head_sums + 28, sizeof(double), hipMemcpyDeviceToHost, tr.stream));
     VP_HIP(hipStreamSynchronize(tr.stream));
   }
+  return VP_OK;
+}
+
+// Makes `stream` (a hipStream_t of the same device; NULL = the legacy default stream) wait until the latest vp_train_step
+// has read its x / y for the last time: work enqueued on `stream` afterwards may overwrite or free them.  No host wait.
+int vp_train_wait_inputs_consumed(vp_trainer* h, void* stream) {
+  VP_REQUIRE(h, "vp_train_wait_inputs_consumed: null handle");
+  Trainer& tr = *reinterpret_cast<Trainer*>(h);
+  VP_HIP(hipSetDevice(tr.device));
+  VP_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), tr.ev_inputs, 0));
   return VP_OK;
 }
 

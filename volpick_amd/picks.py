@@ -82,6 +82,9 @@ class _PrintableList(UserList):
     def __len__(self):
         return self._lazy[0] if self._lazy is not None else len(self._data)
 
+    def __copy__(self):  # UserList.__copy__ reads self.__dict__["data"]; here `data` is a property
+        return self.__class__(self.data)
+
     def __getstate__(self):  # pickling / copying hands over the records, never the deferred builder
         return {"_data": self.data, "_lazy": None}
 

@@ -112,8 +112,16 @@ class PhaseNetTrainer:
         loss = C.c_double(float("nan"))
         _lib.check(self._lib.vp_train_step(self._h, xp, yp, xm, int(x.shape[0]), float(lr), int(bool(update)),
                                            C.byref(loss) if want_loss else None), "vp_train_step")
-        if xm == _lib.VP_MEM_DEVICE and not want_loss:
-            self._inputs_in_flight = (xk, yk)  # kept alive until the next step / synchronize(): the kernels still read them
+        if xm == _lib.VP_MEM_DEVICE:
+            # The step is (or may be) still queued on the trainer's non-blocking stream and reads x / y there:
+            #  * record_stream: the caching allocator will not hand their memory out again before the trainer's stream
+            #    has passed this point (the fp32 copies `_arg` may have made are temporaries that die with this frame);
+            #  * torch's current stream waits -- on the device, the host does not block -- for the event behind the step's
+            #    last read of x / y, so `x.copy_(next_batch)` or any other refill enqueued there cannot overtake the step.
+            cur = torch.cuda.current_stream(xk.device)
+            xk.record_stream(self._ext_stream)
+            yk.record_stream(self._ext_stream)
+            _lib.check(self._lib.vp_train_wait_inputs_consumed(self._h, C.c_void_p(cur.cuda_stream)), "vp_train_wait_inputs_consumed")
         self.forward_count = getattr(self, "forward_count", 0) + 1  # every step moves the BatchNorm running statistics
         if update:
             self.global_step += 1
@@ -121,7 +129,6 @@ class PhaseNetTrainer:
 
     def synchronize(self):
         _lib.check(self._lib.vp_train_synchronize(self._h))
-        self._inputs_in_flight = None
 
     def _read(self, which):
         out = np.empty(self.n_params, dtype=np.float32)
