@@ -117,7 +117,7 @@ def _compact_model(m):
         if isinstance(a.get("cpu_oracle_10min"), dict):
             out["api"]["picks_identical_10min"] = a["cpu_oracle_10min"].get("picks_identical")
     if m.get("ranks"):
-        out["ranks"] = [_pick(x, "rank", "device", "ms_per_step_own_median", "weight_broadcast_path", "rccl_comm_ranks", "segment")
+        out["ranks"] = [_pick(x, "rank", "device", "ms_per_step_own_median", "weight_broadcast_path", "rccl_comm_ranks", "windows_per_step", "segment", "keeps")
                         for x in m["ranks"]]
     return out
 
@@ -625,6 +625,31 @@ def bench_train(batch=512, steps=30, warmup=5, torch_steps=6, torch_baseline=Tru
     return out
 
 
+def station_day_mseed(hours=24):
+    """The committed six-minute Steim-2 fixture (tests/golden/bench_steim2_6min.mseed: 36 records, HHZ/HHN/HHE at 100 Hz)
+    tiled to `hours` by patching the records' start times -> (file bytes, the fixture's bytes, its record table, its samples)."""
+    import struct
+    from datetime import datetime, timedelta, timezone
+
+    import volpick_amd.io as vio
+
+    blob0 = (ROOT / "tests" / "golden" / "bench_steim2_6min.mseed").read_bytes()
+    want = np.load(ROOT / "tests" / "golden" / "bench_steim2_6min_samples.npz")
+    recs0 = vio.scan_mseed(blob0)
+    tiles = hours * 10
+    epoch = datetime(1970, 1, 1, tzinfo=timezone.utc)
+    parts = []
+    for k in range(tiles):
+        b = bytearray(blob0)
+        for r in recs0:
+            t = epoch + timedelta(microseconds=int(r["start_us"]) + k * 360_000_000)
+            # the BTIME carries 100 us units; a blockette 1001 of the record keeps its microsecond offset
+            struct.pack_into(">HHBBBBH", b, int(r["offset"]) + 20, t.year, t.timetuple().tm_yday, t.hour, t.minute, t.second, 0,
+                             t.microsecond // 100)
+        parts.append(bytes(b))
+    return b"".join(parts), blob0, recs0, want
+
+
 def bench_mseed(hours=24, iters=30):
     """SURVEY 8f-1 (what feeds A1; /root/reference volpick/data/convert.py:7 reads through obspy): Steim-2 decode of one
     three-component station-day (100 Hz, 4096-byte records) with the file resident in HBM -- vp_mseed_decode, HIP events
@@ -641,21 +666,7 @@ def bench_mseed(hours=24, iters=30):
     from volpick_amd import _lib
 
     lib = _lib.load()
-    blob0 = (ROOT / "tests" / "golden" / "bench_steim2_6min.mseed").read_bytes()
-    want = np.load(ROOT / "tests" / "golden" / "bench_steim2_6min_samples.npz")
-    recs0 = vio.scan_mseed(blob0)
-    tiles = hours * 10
-    epoch = datetime(1970, 1, 1, tzinfo=timezone.utc)
-    parts = []
-    for k in range(tiles):
-        b = bytearray(blob0)
-        for r in recs0:
-            t = epoch + timedelta(microseconds=int(r["start_us"]) + k * 360_000_000)
-            # the BTIME carries 100 us units; a blockette 1001 of the record keeps its microsecond offset
-            struct.pack_into(">HHBBBBH", b, int(r["offset"]) + 20, t.year, t.timetuple().tm_yday, t.hour, t.minute, t.second, 0,
-                             t.microsecond // 100)
-        parts.append(bytes(b))
-    buf = b"".join(parts)
+    buf, blob0, recs0, want = station_day_mseed(hours)
     t0 = time.perf_counter()
     recs = vio.scan_mseed(buf)
     t_scan = time.perf_counter() - t0

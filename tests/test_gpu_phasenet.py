@@ -123,6 +123,39 @@ def test_up_path_on_the_bf16_matrix_cores_agrees_with_the_fp32_mfma_forms(oracle
         assert np.array_equal(got[keep], outs[0][keep])
 
 
+@pytest.mark.parametrize("B", [1, 9, 256])
+def test_level_0_down_path_on_the_matrix_cores_agrees_with_the_vector_alu_form(oracle, B):
+    """Default plan (round 5, pn_window_kernel D0T): inc and down0.same run time-tiled on the bf16 matrix cores with exact
+    three-piece operands (x pieces from registers, inc's output as a ring of pieces); plan_flags[5] = 8 keeps the packed-FMA
+    forms of round 4.  The two agree to fp32 rounding, each within the regression bar of the oracle -- on windows whose energy
+    sits at the two ENDS (the tiles that meet the zero padding), with a DC offset, on the device front end as well; a
+    non-finite window poisons only itself."""
+    x = synthetic_windows(B, 3001, seed=8800 + B)
+    x[0, :, :40] *= 50.0
+    x[-1, :, -40:] *= 50.0
+    x[B // 2, 1] += 777.0
+    xn = OP.batch_pre(oracle, torch.from_numpy(x))
+    with torch.no_grad():
+        want = oracle(xn).numpy()
+    outs, raws = [], []
+    for flags in ((0,), (0, 0, 0, 0, 0, 8)):
+        m = PhaseNet.from_pretrained("volpick")
+        m._plan_flags = flags
+        m.cuda()
+        outs.append(m(xn).numpy())  # through the input tensor
+        raws.append(m._forward_raw(torch.from_numpy(x).cuda(), preprocess=True).cpu().numpy())  # window cut + normalisation in the kernel
+        assert np.abs(outs[-1] - want).max() < 3e-5 and np.abs(raws[-1] - want).max() < 3e-5, flags
+        m._release()
+    assert np.abs(outs[0] - outs[1]).max() < 1e-5 and np.abs(raws[0] - raws[1]).max() < 1e-5
+    if B > 1:
+        bad = xn.clone()
+        bad[1, 2, 7] = float("inf")
+        got = PhaseNet.from_pretrained("volpick").cuda()(bad).numpy()
+        assert np.isnan(got[1]).all()
+        keep = [b for b in range(B) if b != 1]
+        assert np.array_equal(got[keep], outs[0][keep])
+
+
 @pytest.mark.parametrize("B", [1, 5, 256, 300])
 def test_forward_parity(model, oracle, B):
     x = synthetic_windows(B, 3001, seed=100 + B)

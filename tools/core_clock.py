@@ -15,7 +15,12 @@ from volpick_amd.synthetic import synthetic_windows  # noqa: E402
 
 B = 256
 m = va.PhaseNet.from_pretrained("volpick")
-m._plan_flags = (0, 2)
+# optional argument: plan flags "a,b,c,..." (the clock-stamp bit of [1] is added), e.g. "0,0,0,0,0,8" = level-0 down path on the VALU
+_f = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 0]
+_f += [0] * (2 - len(_f))
+_f[1] |= 2
+m._plan_flags = tuple(_f)
+print("plan flags", m._plan_flags)
 m.cuda()
 x = torch.from_numpy(synthetic_windows(B, 3001, seed=1)).cuda()
 for _ in range(3):

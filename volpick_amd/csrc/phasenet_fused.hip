@@ -930,6 +930,9 @@ struct WindowArgs {
   const uint4* af3_u2[2];  // U2B: up2.same's operand per input half (skip 1 | up2.convT), 16-channel K-steps (B3Steps<16, 7>)
   const uint4* af3_uT[2];  // U3B: up1.convT / up2.convT, rows (phase, channel)
   const uint4* af3_d12[2]; // D12B: down1.same (B3Steps<8, 7>), down2.same (B3Steps<16, 7>)
+  const uint4* af3_inc;    // D0T: inc, rows (phase, channel), ONE K-step of eight taps x four channels (three + a zero one)
+  const uint4* af3_d0s;    // D0T: down0.same, rows (phase, channel), two K-steps of four taps x eight channels (B3Steps<8, 8>)
+  const float *bs_inc8, *bs_d0s;  // D0T: their biases [8] (BatchNorm folded)
   const float* x;   // [B][3][ls] normalised input
   int ls_x;
   long ws_x;
@@ -1015,9 +1018,28 @@ static_assert(B3_U2_OFF3 * 4 + 3 * B3Chunk<16, B3_U2_NC3>::PS * 2 <= CORE_LDS_FL
 constexpr int B3_D0_NC = 760, B3_D1_NC = 200;  // sample t at column t + 3
 static_assert(A_D0 * 4 + 3 * B3Chunk<8, B3_D0_NC>::PS * 2 <= CORE_LDS_FLOATS * 4 && B3_D0_NC >= 47 * 16 + 7 && B3_D1_NC >= 192 + 7,
               "down0.down / down1.down as piece images");
-template <bool PIPE, bool B3, bool U1B = false, bool U2B = false, bool U3B = false, bool D12B = false>
-__global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
+// D0T (with D12B): inc and down0.same on the bf16 matrix cores, TIME-TILED.  Neither layer's input exists in fp32 form: the
+// normalised window goes from the registers it was read into straight into piece images [piece][column][3 + 1 channels] of 520
+// columns (tile j: samples 512 j - 3 ..), inc's epilogue writes PIECES into a 528-column ring [piece][column][8 channels]
+// (sample s at column s mod 528; the 16 columns in front of a tile keep the previous tile's tail, which down0.same's taps reach
+// back into), down0.same reads the ring and writes its fp32 rows (the image of the strided conv behind it and the skip tensor).
+// Both GEMMs are M = 16 rows (output phase, channel), columns = sample pairs: inc K = 8 taps x 4 channels = ONE K-step (B fragment
+// = two adjacent columns of the x tile, one ds_read_b128 per piece), down0.same K = 8 taps x 8 channels = two K-steps.  Six tiles of
+// 512 samples, sixteen n-tiles each = one per wave and layer; down0.same runs eight samples behind inc so that it never needs a
+// sample inc has not produced: 6 x 16 x (6 + 12) = 1,728 MFMAs in place of 1,792 packed FMAs per lane.  plan_flags[5] = 8 keeps the
+// VALU forms.  (Round 4's slice-by-slice attempt converted inc's fp32 rows on the fly and lost to the packed FMAs.)
+constexpr int D0T_TILES = 6, D0T_XNC = 520, D0T_XPS = D0T_XNC * 4, D0T_RING = 528, D0T_HPS = B3Chunk<8, D0T_RING>::PS;
+constexpr int D0T_HP_OFF = 134144 / 2;  // bf16 elements from the arena start (behind the reduction scratch of the normalisation)
+static_assert(D0T_TILES * 512 >= W0_S - 4 + 8 && WD_X * 4 + 2 * 3 * D0T_XPS * 2 <= 11 * W0_S * 4 &&
+                  D0T_HP_OFF * 2 >= (11 * W0_S + 9 * 16 + 8) * 4 && D0T_HP_OFF * 2 + 3 * D0T_HPS * 2 <= CORE_LDS_FLOATS * 4,
+              "level-0 tiles: two x images behind the eight fp32 rows, the ring behind the scratch, inside the arena");
+template <bool PIPE, bool B3, bool U1B = false, bool U2B = false, bool U3B = false, bool D12B = false, bool D0T = false>
+// amdgpu_num_vgpr counts the VGPR half of the unified file on gfx90a+ (LLVM doubles it): 60 -> at most 120 registers per lane, so that
+// four forward waves leave each SIMD the 32 registers the post-processing kernels need to run beside them (prepost.hip; a dozen
+// one-off spills per window in the D0T form, none inside a loop)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_window_kernel(const WindowArgs a) {
   static_assert(!D12B || B3, "D12B is a form of the B3 kernel");
+  static_assert(!D0T || D12B, "D0T is a form of the D12B kernel");
   static_assert(!U2B || U1B, "U2B relocates up1.same's output: needs the U1B form");
   static_assert(!U3B || U2B, "U3B builds on the U2B layout");
   constexpr int U2_NC = U3B ? B3_U2_NC3 : B3_U2_NC, U2_OFF = U3B ? B3_U2_OFF3 : B3_U2_OFF;
@@ -1075,6 +1097,8 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
   // ================= level-0 down path: inc -> down0.same -> down0.down =================
   {
     float *H = lds + WD_H, *X = lds + WD_X;
+    constexpr int MAXE = (T0 + NTH - 1) / NTH;
+    float v[3][MAXE];  // the window: samples tid, tid + 1024, tid + 2048 of the three channels (D0T: the normalised ones, kept)
     if (a.has_pre) {
       // SeisBench annotate_batch_pre inside the kernel, arithmetic and reduction order of gather_normalize_kernel
       // (prepost.hip): window cut from the stream, per-channel mean, peak / std amplitude, scale — the window is read
@@ -1091,8 +1115,7 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
         src = p.src + e[0] + e[2];
         cs = e[1];
       }
-      constexpr int MAXE = (T0 + NTH - 1) / NTH;
-      float v[3][MAXE], sum[3] = {0.f, 0.f, 0.f};
+      float sum[3] = {0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -1125,9 +1148,11 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
       if (lane == 0)
         for (int c = 0; c < 3; ++c) red[c * NWV + wave] = sum[c];
       WIN_STAMP(29)
-      for (int i = tid; i < 3 * (W0_S - T0); i += NTH) {  // zero margins of the x rows: samples -4 .. -1 and T0 .. 3019
-        const int c = i / (W0_S - T0), k = i - c * (W0_S - T0);
-        X[c * W0_S + (k < 4 ? k : T0 + k)] = 0.f;
+      if constexpr (!D0T) {
+        for (int i = tid; i < 3 * (W0_S - T0); i += NTH) {  // zero margins of the x rows: samples -4 .. -1 and T0 .. 3019
+          const int c = i / (W0_S - T0), k = i - c * (W0_S - T0);
+          X[c * W0_S + (k < 4 ? k : T0 + k)] = 0.f;
+        }
       }
       __syncthreads();
       if (tid < 3) {
@@ -1191,7 +1216,8 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
               float o = norm_div(v[c][k] - mean[c], den[c]);
               const int e = (t < p.taper) ? t : ((T0 - 1 - t < p.taper) ? T0 - 1 - t : -1);
               if (e >= 0) o *= 0.5f * (1.f + cosf(3.14159265358979323846f * (1.f + (float)e / (float)(p.taper - 1))));
-              X[c * W0_S + 4 + t] = o;
+              if constexpr (D0T) v[c][k] = o;
+              else X[c * W0_S + 4 + t] = o;
             }
           }
       } else {
@@ -1200,9 +1226,19 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
 #pragma unroll
           for (int k = 0; k < MAXE; ++k) {
             const int t = tid + k * NTH;
-            if (k + 1 < MAXE || t < T0) X[c * W0_S + 4 + t] = norm_div(v[c][k] - mean[c], den[c]);
+            if constexpr (D0T) v[c][k] = norm_div(v[c][k] - mean[c], den[c]);
+            else if (k + 1 < MAXE || t < T0) X[c * W0_S + 4 + t] = norm_div(v[c][k] - mean[c], den[c]);
           }
       }
+    } else if constexpr (D0T) {  // the normalised rows of the input tensor, into the same registers
+      const float* src = a.x + (long)win * a.ws_x + HALO;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < MAXE; ++k) {
+          const int t = tid + k * NTH;
+          v[c][k] = t < T0 ? src[(long)c * a.ls_x + t] : 0.f;
+        }
     } else {  // x rows: sample 4q - 4 .. 4q - 1 at float4 q; physical index HALO + 4q - 4 (16-byte aligned)
       const float* src = a.x + (long)win * a.ws_x;
       for (int i = tid; i < 3 * W0_Q; i += NTH) {
@@ -1216,6 +1252,111 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
     {
       if (tid < 8) *reinterpret_cast<float4*>(H + tid * W0_S) = make_float4(0.f, 0.f, 0.f, 0.f);  // samples -4 .. -1: left padding
     }
+    if constexpr (D0T) {
+      bf16_t* const l16 = reinterpret_cast<bf16_t*>(lds);
+      bf16_t* const XP0 = l16 + WD_X * 2;      // two x tiles
+      bf16_t* const HP = l16 + D0T_HP_OFF;     // inc's output: the ring
+      const int g = lane >> 4, n = lane & 15, ph = g >> 1, quad = g & 1;  // GEMM rows 4 g .. 4 g + 3 = (phase ph, channels 4 quad ..)
+      // x tile j <-> samples [512 j - 3, 512 j + 517): this lane's (up to three) samples that fall into it, all three channels
+      // and the zero fourth of a sample as one 8-byte store per piece; columns outside the signal are zeros (the convolution's padding)
+      auto store_x_tile = [&](const int j) {
+        bf16_t* const XP = XP0 + (j & 1) * 3 * D0T_XPS;
+        const int s0 = 512 * j - 3;
+#pragma unroll
+        for (int k = 0; k < MAXE; ++k) {
+          const int t = tid + k * NTH, col = t - s0;
+          if (t < T0 && (unsigned)col < (unsigned)D0T_XNC) {
+            const float q[4] = {v[0][k], v[1][k], v[2][k], 0.f};
+            b3_store4(XP, D0T_XPS, 4, col, 0, q);
+          }
+        }
+        if (tid < D0T_XNC && (unsigned)(s0 + tid) >= (unsigned)T0) {
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<uint2*>(XP + pc * D0T_XPS + tid * 4) = make_uint2(0u, 0u);
+        }
+      };
+      store_x_tile(0);
+      if (tid < 48)  // ring columns 512 .. 527 <-> samples -16 .. -1: zeros
+        *reinterpret_cast<uint4*>(HP + (tid >> 4) * D0T_HPS + (512 + (tid & 15)) * 8) = make_uint4(0u, 0u, 0u, 0u);
+      uint4 aI[3], aS[B3Steps<8, 8>::STEPS * 3];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) aI[pc] = a.af3_inc[pc * 64 + lane];
+      b3_load_a<8, 8>(a.af3_d0s, 0, lane, aS);
+      float bI[4], bS[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bI[r] = a.bs_inc8[4 * quad + r], bS[r] = a.bs_d0s[4 * quad + r];
+      WIN_STAMP(31)
+      __syncthreads();
+      WIN_STAMP(19)
+      constexpr int WP6[6] = {2, 1, 0, 1, 0, 0}, XP6[6] = {0, 1, 2, 0, 1, 0};  // (w piece, x piece), smallest products first
+#pragma unroll 1
+      for (int i = 0; i < D0T_TILES; ++i) {
+        const int cbase = i == 0 ? 0 : D0T_RING - 16 * i;  // ring column of sample 512 i
+        {  // inc, n-tile `wave` of tile i: samples 512 i + 32 wave + 2 n + ph
+          const bf16_t* xp = XP0 + (i & 1) * 3 * D0T_XPS + (32 * wave + 2 * n + 2 * g) * 4;
+          uint4 b[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) b[pc] = *reinterpret_cast<const uint4*>(xp + pc * D0T_XPS);
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t6 = 0; t6 < 6; ++t6)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, aI[WP6[t6]]), __builtin_bit_cast(bf16x8_b3, b[XP6[t6]]),
+                                                         acc, 0, 0, 0);
+          const int s = 512 * i + 32 * wave + 2 * n + ph;
+          int c = cbase + 32 * wave + 2 * n + ph;
+          c = c >= D0T_RING ? c - D0T_RING : c;
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = s < T0 ? fmaxf(acc[r] + bI[r], 0.f) : 0.f;
+          b3c_store4<8, D0T_RING>(HP, c, quad, o);
+          // the next tile's x image (its last readers were inc's waves of tile i - 1, a barrier ago)
+          if (i + 1 < D0T_TILES) store_x_tile(i + 1);
+        }
+        lds_barrier();
+        if (i == 0) { WIN_STAMP(20) }
+        {  // down0.same, n-tile `wave`: samples 512 i - 8 + 32 wave + 2 n + ph read inc's samples .. - 3 + tap, tap = g + 4 step
+          int c0 = cbase - 11 + 32 * wave + 2 * n + g;
+          c0 = c0 < 0 ? c0 + D0T_RING : c0;
+          int c1 = c0 + 4;
+          c0 = c0 >= D0T_RING ? c0 - D0T_RING : c0;
+          c1 = c1 >= D0T_RING ? c1 - D0T_RING : c1;
+          uint4 b[2][3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) {
+            b[0][pc] = *reinterpret_cast<const uint4*>(HP + pc * D0T_HPS + c0 * 8);
+            b[1][pc] = *reinterpret_cast<const uint4*>(HP + pc * D0T_HPS + c1 * 8);
+          }
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int t6 = 0; t6 < 6; ++t6)
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, aS[st * 3 + WP6[t6]]),
+                                                           __builtin_bit_cast(bf16x8_b3, b[st][XP6[t6]]), acc, 0, 0, 0);
+          const int t = 512 * i - 8 + 32 * wave + 2 * n + ph;
+          if ((unsigned)t < (unsigned)(W0_S - 4)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) H[(4 * quad + r) * W0_S + 4 + t] = t < T0 ? fmaxf(acc[r] + bS[r], 0.f) : 0.f;
+          }
+        }
+        lds_barrier();
+      }
+      // down0.same rests in H (fp32): the skip tensor goes to memory, the tile images give way to down0.down's piece image
+      float aD[W_down::CB * W_down::TAPS], bD[4];
+      load_areg<W_down>(a.af_down, 0, lane, aD);
+      load_biasreg<W_down>(a.bs_down, 0, lane, bD);
+      b3c_zero_rest<8, B3_D0_NC>(l16 + A_D0 * 2, 3, B3_D0_NC, tid, NTH);
+      if (own) {
+        float* d = a.skip0 + (long)win * a.ws_s + HALO + t0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          *reinterpret_cast<f32x4*>(d + (long)c * a.ls_s) = *reinterpret_cast<const f32x4*>(H + c * W0_S + 4 + t0);
+      }
+      lds_barrier();
+      WIN_STAMP(21)
+      const B3PairStoreC<8, B3_D0_NC> st{l16 + A_D0 * 2, 3, T1};
+      conv_lds_areg<W_down, W0_S, 4, W0_S, 4>(H, H, aD, bD, 0, (T1 + 1) / 2, st, wave, NWV, lane);
+    } else {
     WIN_STAMP(31)
     __syncthreads();
     WIN_STAMP(19)
@@ -1282,6 +1423,7 @@ __global__ __launch_bounds__(1024) void pn_window_kernel(const WindowArgs a) {
         RangeStore<S1_, IB> st{lds + A_D0, T1};
         conv_lds_areg<W_down, W0_S, 4, W0_S, 4>(H, H, aD, bD, 0, (T1 + 1) / 2, st, wave, NWV, lane);
       }
+    }
     }
     lds_barrier();  // not __syncthreads(): the skip rows drain to memory under the first core layers
     WIN_STAMP(22)
@@ -1715,6 +1857,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
   const bool u2b = u1b && net.cfg.plan_flags[5] != 5;   // plan_flags[5] = 5: only up2.same does
   const bool u3b = u2b && net.cfg.plan_flags[5] != 6;   // plan_flags[5] = 6: up1.convT / up2.convT stay on the fp32 MFMA
   const bool d12b = u3b && net.cfg.plan_flags[5] != 7;  // plan_flags[5] = 7: down1.same / down2.same stay on the fp32 MFMA
+  const bool d0t = d12b && net.cfg.plan_flags[5] != 8;  // plan_flags[5] = 8: inc / down0.same stay on the vector ALUs
   HostBlob *vw[5] = {}, *vb[5] = {};
   if (valu) {
     const float eps = net.cfg.bn_eps;
@@ -1922,7 +2065,8 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         else if (u3b && i == 14) bf16 += 4.0 * 12 * 2 * 6 * 16384.0;      // up2.convT: 4 m-tiles x 12 n-tiles x 2 K-steps
         else f32 += padded(i);
       }
-      st.set_issued(f32, bf16, flops(0, 1) + flops(17, 17));
+      if (d0t) bf16 += (double)D0T_TILES * 16 * (1 + 2) * 6 * 16384.0;  // inc: 96 n-tiles x 1 K-step; down0.same: 96 x 2; six MFMAs each
+      st.set_issued(f32, bf16, (d0t ? 0.0 : flops(0, 1)) + flops(17, 17));
     }
     HostBlob* e0 = &net.convs[17]->e0;
     HostBlob* e1 = &net.convs[17]->e1;
@@ -1941,6 +2085,11 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     if (d12b) {
       p3d12[0] = net.add_blob(b3_operand(*net.convs[3 + 0], false));
       p3d12[1] = net.add_blob(b3_operand(*net.convs[3 + 2], false));
+    }
+    HostBlob *p3inc = nullptr, *p3d0s = nullptr;
+    if (d0t) {
+      p3inc = net.add_blob(b3_operand(*net.convs[0], true));
+      p3d0s = net.add_blob(b3_operand(*net.convs[1], true));
     }
     HostBlob* p3uT[2] = {};
     if (u3b) {
@@ -1991,6 +2140,10 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
       for (int i = 0; i < 2; ++i) a.af3_d12[i] = p3d12[i] ? reinterpret_cast<const uint4*>(p3d12[i]->d) : nullptr;
       for (int i = 0; i < 2; ++i) a.af3_uT[i] = p3uT[i] ? reinterpret_cast<const uint4*>(p3uT[i]->d) : nullptr;
       for (int i = 0; i < 2; ++i) a.af3_u2[i] = p3u2[i] ? reinterpret_cast<const uint4*>(p3u2[i]->d) : nullptr;
+      a.af3_inc = p3inc ? reinterpret_cast<const uint4*>(p3inc->d) : nullptr;
+      a.af3_d0s = p3d0s ? reinterpret_cast<const uint4*>(p3d0s->d) : nullptr;
+      a.bs_inc8 = n.convs[0]->bias.d;
+      a.bs_d0s = n.convs[1]->bias.d;
       for (int i = 0; i < 6; ++i) {
         a.af3[i] = p3[i] ? reinterpret_cast<const uint4*>(p3[i]->d) : nullptr;
         a.af3_lines[i] = p3[i] ? (int)(p3[i]->h.size() * 4 / 128) : 0;
@@ -2026,7 +2179,9 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         a.pre = *n.pre;
         a.has_pre = 1;
       }
-      if (d12b) {
+      if (d0t) {
+        hipLaunchKernelGGL((pn_window_kernel<false, true, true, true, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
+      } else if (d12b) {
         hipLaunchKernelGGL((pn_window_kernel<false, true, true, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
       } else if (u3b) {
         hipLaunchKernelGGL((pn_window_kernel<false, true, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
@@ -2054,6 +2209,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
   }
   net.steps = std::move(steps);
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_core_kernel<true>), CORE_LDS_FLOATS * sizeof(float)});

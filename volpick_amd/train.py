@@ -14,6 +14,7 @@ part of this package.  Forward (training-mode BatchNorm), loss, backward and Ada
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 
 import numpy as np
@@ -73,9 +74,13 @@ class PhaseNetTrainer:
                                                    self.max_batch, self.DTYPES[str(dtype)], C.byref(self._h)), "vp_train_create")
         _lib.check(self._lib.vp_train_set_hyper(self._h, betas[0], betas[1], eps, bn_momentum, loss_eps))
         self.global_step = 0
+        self._in_flight = collections.deque()  # (event behind a queued step, its x, its y): device inputs kept alive
 
     def close(self):
         if getattr(self, "_h", None):
+            if getattr(self, "_in_flight", None):
+                self._lib.vp_train_synchronize(self._h)
+                self._in_flight.clear()
             self._lib.vp_train_destroy(self._h)
             self._h = None
 
@@ -97,6 +102,8 @@ class PhaseNetTrainer:
             raise ValueError(f"expected x and y of shape (B, 3, {self.in_samples}), got {tuple(x.shape)} / {tuple(y.shape)}")
         xk, xp, xm = self._arg(x)
         yk, yp, ym = self._arg(y)
+        while self._in_flight and self._in_flight[0][0].query():  # steps the trainer's stream has passed: their inputs may go
+            self._in_flight.popleft()
         if xm != ym:
             raise ValueError("x and y must both be host arrays or both be device tensors")
         if xm == _lib.VP_MEM_DEVICE:
@@ -114,13 +121,17 @@ class PhaseNetTrainer:
                                            C.byref(loss) if want_loss else None), "vp_train_step")
         if xm == _lib.VP_MEM_DEVICE:
             # The step is (or may be) still queued on the trainer's non-blocking stream and reads x / y there:
-            #  * record_stream: the caching allocator will not hand their memory out again before the trainer's stream
-            #    has passed this point (the fp32 copies `_arg` may have made are temporaries that die with this frame);
+            #  * this object keeps x / y (or the fp32 copies `_arg` made) alive until an event recorded on the trainer's
+            #    stream behind the step has completed, so the caching allocator cannot hand their memory out while the step
+            #    reads it, whatever the caller does with its own references.  (Not Tensor.record_stream: the allocator would
+            #    then record events on the trainer's stream when the tensors die -- possibly after vp_train_destroy has
+            #    destroyed that stream.)
             #  * torch's current stream waits -- on the device, the host does not block -- for the event behind the step's
             #    last read of x / y, so `x.copy_(next_batch)` or any other refill enqueued there cannot overtake the step.
+            done = torch.cuda.Event()
+            done.record(self._ext_stream)
+            self._in_flight.append((done, xk, yk))
             cur = torch.cuda.current_stream(xk.device)
-            xk.record_stream(self._ext_stream)
-            yk.record_stream(self._ext_stream)
             _lib.check(self._lib.vp_train_wait_inputs_consumed(self._h, C.c_void_p(cur.cuda_stream)), "vp_train_wait_inputs_consumed")
         self.forward_count = getattr(self, "forward_count", 0) + 1  # every step moves the BatchNorm running statistics
         if update:
@@ -129,6 +140,7 @@ class PhaseNetTrainer:
 
     def synchronize(self):
         _lib.check(self._lib.vp_train_synchronize(self._h))
+        self._in_flight.clear()
 
     def _read(self, which):
         out = np.empty(self.n_params, dtype=np.float32)
