@@ -126,7 +126,8 @@ def test_up_path_on_the_bf16_matrix_cores_agrees_with_the_fp32_mfma_forms(oracle
 @pytest.mark.parametrize("B", [1, 9, 256])
 def test_level_0_down_path_on_the_matrix_cores_agrees_with_the_vector_alu_form(oracle, B):
     """Default plan (round 5, pn_window_kernel D0T): inc and down0.same run time-tiled on the bf16 matrix cores with exact
-    three-piece operands (x pieces from registers, inc's output as a ring of pieces); plan_flags[5] = 8 keeps the packed-FMA
+    three-piece operands (x pieces from registers into the rows down0.same fills later, inc's output as a ring of pieces, six
+    tiles of 512 samples); plan_flags[5] = 8 keeps the packed-FMA
     forms of round 4.  The two agree to fp32 rounding, each within the regression bar of the oracle -- on windows whose energy
     sits at the two ENDS (the tiles that meet the zero padding), with a DC offset, on the device front end as well; a
     non-finite window poisons only itself."""

@@ -70,7 +70,8 @@ std::vector<float> b3_operand(const ConvLayer& L, bool mperm) {
   // K of one instruction = 32: cinp >= 32: 32 channels of one tap, steps (tap, channel step); cinp = 16 / 8: all channels of
   // 2 / 4 consecutive taps (taps beyond the filter carry zero weights), a lane's eight values = eight channels of one tap
   // cinp = 4 (PhaseNet's inc, three input channels padded to four): all channels of EIGHT consecutive taps per step, a lane's
-  // eight values = four channels of two taps (lane group g: taps 2 g, 2 g + 1)
+  // eight values = four channels of two taps (lane group g: taps 2 g, 2 g + 1) in the order its two 8-byte reads deliver them:
+  // (tap a: ch 0, 1), (tap b: ch 0, 1), (tap a: ch 2, 3), (tap b: ch 2, 3)
   const int KS = cinp >= 32 ? cinp / 32 : 1, TPK = cinp >= 32 ? 1 : 32 / cinp, LPT = cinp >= 32 ? 4 : (cinp >= 8 ? cinp / 8 : 1);  // lanes groups per tap
   const int steps = cinp >= 32 ? taps * KS : (taps + TPK - 1) / TPK;
   auto rne = [](float x) -> uint16_t {
@@ -96,8 +97,8 @@ std::vector<float> b3_operand(const ConvLayer& L, bool mperm) {
           for (int i = 0; i < 8; ++i) {
             const int mp = mt * 16 + (l & 15), g = l >> 4;
             const int m = mperm ? (mp % cout) * P + mp / cout : mp;  // row of the packed fp32 operand
-            const int tap = cinp >= 32 ? st / KS : cinp == 4 ? st * TPK + 2 * g + i / 4 : st * TPK + g / LPT;
-            const int ci = cinp >= 32 ? (st % KS) * 32 + 8 * g + i : cinp == 4 ? i % 4 : 8 * (g % LPT) + i;
+            const int tap = cinp >= 32 ? st / KS : cinp == 4 ? st * TPK + 2 * g + ((i >> 1) & 1) : st * TPK + g / LPT;
+            const int ci = cinp >= 32 ? (st % KS) * 32 + 8 * g + i : cinp == 4 ? (i & 1) + 2 * (i >> 2) : 8 * (g % LPT) + i;
             const float w = tap < taps ? af[(((size_t)(m / 16) * CB + ci / 4) * taps + tap) * 64 + (ci % 4) * 16 + (m % 16)] : 0.f;
             const uint16_t h = rne(w);
             const float r1 = w - widen(h);

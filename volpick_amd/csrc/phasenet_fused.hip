@@ -1019,20 +1019,20 @@ constexpr int B3_D0_NC = 760, B3_D1_NC = 200;  // sample t at column t + 3
 static_assert(A_D0 * 4 + 3 * B3Chunk<8, B3_D0_NC>::PS * 2 <= CORE_LDS_FLOATS * 4 && B3_D0_NC >= 47 * 16 + 7 && B3_D1_NC >= 192 + 7,
               "down0.down / down1.down as piece images");
 // D0T (with D12B): inc and down0.same on the bf16 matrix cores, TIME-TILED.  Neither layer's input exists in fp32 form: the
-// normalised window goes from the registers it was read into straight into piece images [piece][column][3 + 1 channels] of 520
-// columns (tile j: samples 512 j - 3 ..), inc's epilogue writes PIECES into a 528-column ring [piece][column][8 channels]
-// (sample s at column s mod 528; the 16 columns in front of a tile keep the previous tile's tail, which down0.same's taps reach
-// back into), down0.same reads the ring and writes its fp32 rows (the image of the strided conv behind it and the skip tensor).
-// Both GEMMs are M = 16 rows (output phase, channel), columns = sample pairs: inc K = 8 taps x 4 channels = ONE K-step (B fragment
-// = two adjacent columns of the x tile, one ds_read_b128 per piece), down0.same K = 8 taps x 8 channels = two K-steps.  Six tiles of
-// 512 samples, sixteen n-tiles each = one per wave and layer; down0.same runs eight samples behind inc so that it never needs a
-// sample inc has not produced: 6 x 16 x (6 + 12) = 1,728 MFMAs in place of 1,792 packed FMAs per lane.  plan_flags[5] = 8 keeps the
-// VALU forms.  (Round 4's slice-by-slice attempt converted inc's fp32 rows on the fly and lost to the packed FMAs.)
-constexpr int D0T_TILES = 6, D0T_XNC = 520, D0T_XPS = D0T_XNC * 4, D0T_RING = 528, D0T_HPS = B3Chunk<8, D0T_RING>::PS;
-constexpr int D0T_HP_OFF = 134144 / 2;  // bf16 elements from the arena start (behind the reduction scratch of the normalisation)
-static_assert(D0T_TILES * 512 >= W0_S - 4 + 8 && WD_X * 4 + 2 * 3 * D0T_XPS * 2 <= 11 * W0_S * 4 &&
-                  D0T_HP_OFF * 2 >= (11 * W0_S + 9 * 16 + 8) * 4 && D0T_HP_OFF * 2 + 3 * D0T_HPS * 2 <= CORE_LDS_FLOATS * 4,
-              "level-0 tiles: two x images behind the eight fp32 rows, the ring behind the scratch, inside the arena");
+// normalised window goes from the registers it was read into straight into bf16 pieces that rest inside the rows down0.same fills
+// later (pn_window_kernel), inc's epilogue writes PIECES into a 1040-column ring [piece][parity][column / 2][8 channels] (sample s at
+// column s mod 1040; it keeps the previous tile, whose tail down0.same's taps reach back into), down0.same reads the ring and
+// writes its fp32 rows (the image of the strided conv behind it and the skip tensor).  Both GEMMs are M = 16 rows (output phase,
+// channel), columns = sample pairs: inc K = 8 taps x 4 channels = ONE K-step, down0.same K = 8 taps x 8 channels = two K-steps.
+// Six tiles of 512 samples = sixteen n-tiles per layer; in phase j every wave runs one n-tile of inc on tile j and one of
+// down0.same on tile j - 1, eight samples behind (it never needs a sample inc has not produced), one barrier per phase:
+// 6 x 16 x (6 + 12) = 1,728 MFMAs in place of 1,792 packed FMAs per lane.  plan_flags[5] = 8 keeps the VALU forms.
+// (Round 4's slice-by-slice attempt converted inc's fp32 rows on the fly and lost to the packed FMAs.)
+constexpr int D0T_TS = 512, D0T_TILES = 6, D0T_RING = 1040, D0T_HPS = B3Chunk<8, D0T_RING>::PS;
+constexpr int D0T_RED = CORE_LDS_FLOATS - 256;  // the reduction scratch of the normalisation (floats): behind the ring
+static_assert(D0T_TILES * D0T_TS >= W0_S - 4 + 8 && D0T_RING >= 2 * D0T_TS + 11 + 4 && D0T_RING % 2 == 0 &&
+                  WD_X * 4 + 3 * D0T_HPS * 2 <= D0T_RED * 4 && (9 * 16 + 8) <= 256,
+              "level-0 tiles: the ring behind the eight fp32 rows, the scratch behind the ring, inside the arena");
 template <bool PIPE, bool B3, bool U1B = false, bool U2B = false, bool U3B = false, bool D12B = false, bool D0T = false>
 // amdgpu_num_vgpr counts the VGPR half of the unified file on gfx90a+ (LLVM doubles it): 60 -> at most 120 registers per lane, so that
 // four forward waves leave each SIMD the 32 registers the post-processing kernels need to run beside them (prepost.hip; a dozen
@@ -1057,6 +1057,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
   if (clk && tid == 0) clk[(long)win * 32 + 16] = wall_clock64();
 #define WIN_STAMP(slot) \
   if (clk && tid == 0) clk[(long)win * 32 + (slot)] = __builtin_readcyclecounter();
+// -DD0T_PROBE (investigation builds only): the thirteen phases of the tiled level-0 down path stamp slots 2 .. 14 instead of the core layers
+#ifdef D0T_PROBE
+#define CORE_WIN_STAMP(slot)
+#else
+#define CORE_WIN_STAMP(slot) WIN_STAMP(slot)
+#endif
   WIN_STAMP(0)
   WIN_STAMP(18)
   // first workgroup of each XCD: touch one word per 128-byte line of the core weights (pn_core_kernel) -- on the FIRST launch of a
@@ -1099,12 +1105,23 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
     float *H = lds + WD_H, *X = lds + WD_X;
     constexpr int MAXE = (T0 + NTH - 1) / NTH;
     float v[3][MAXE];  // the window: samples tid, tid + 1024, tid + 2048 of the three channels (D0T: the normalised ones, kept)
+    // D0T: the A operands of inc and down0.same, the same 9 KB for every wave: fetched FIRST, so that their trip through the CU's
+    // L1 (16 waves x 9 KB at 64 B per clock) passes under the window's trip from memory instead of in front of the first tile
+    [[maybe_unused]] uint4 aI[3], aS[B3Steps<8, 8>::STEPS * 3];
+    [[maybe_unused]] f32x4 bI, bS;
+    if constexpr (D0T) {
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) aI[pc] = a.af3_inc[pc * 64 + lane];
+      b3_load_a<8, 8>(a.af3_d0s, 0, lane, aS);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bI[r] = a.bs_inc8[4 * ((lane >> 4) & 1) + r], bS[r] = a.bs_d0s[4 * ((lane >> 4) & 1) + r];
+    }
     if (a.has_pre) {
       // SeisBench annotate_batch_pre inside the kernel, arithmetic and reduction order of gather_normalize_kernel
       // (prepost.hip): window cut from the stream, per-channel mean, peak / std amplitude, scale — the window is read
       // once into registers and the normalised rows go straight into the x image (no input tensor in memory).
       const PreArgs& p = a.pre;
-      float* red = lds + 11 * W0_S;  // [9][NWV] partials (sums, maxima, minima), then stat[3][2] (free arena space behind the x rows)
+      float* red = lds + (D0T ? D0T_RED : 11 * W0_S);  // [9][NWV] partials (sums, maxima, minima), then stat[3][2] (free arena space behind the x rows / the ring)
       float* stat = red + 9 * NWV;
       long start = p.dense ? 0 : (long)(p.first_window + win) * p.step;
       if (!p.dense && start > p.N - T0) start = p.N - T0;  // tail window flush with the end
@@ -1249,109 +1266,161 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
         *reinterpret_cast<float4*>(X + c * W0_S + 4 * q) = v;
       }
     }
-    {
+    if constexpr (!D0T) {
       if (tid < 8) *reinterpret_cast<float4*>(H + tid * W0_S) = make_float4(0.f, 0.f, 0.f, 0.f);  // samples -4 .. -1: left padding
+    } else if (tid < 8) {  // (word 3 of rows 0-5 takes x's first sample below: zeroed behind the tile loop)
+      H[tid * W0_S] = H[tid * W0_S + 1] = H[tid * W0_S + 2] = 0.f;
+      if (tid >= 6) H[tid * W0_S + 3] = 0.f;
     }
     if constexpr (D0T) {
       bf16_t* const l16 = reinterpret_cast<bf16_t*>(lds);
-      bf16_t* const XP0 = l16 + WD_X * 2;      // two x tiles
-      bf16_t* const HP = l16 + D0T_HP_OFF;     // inc's output: the ring
+      bf16_t* const HP = l16 + WD_X * 2;  // inc's output: the ring, behind the eight fp32 rows
+      unsigned* const HU = reinterpret_cast<unsigned*>(H);
       const int g = lane >> 4, n = lane & 15, ph = g >> 1, quad = g & 1;  // GEMM rows 4 g .. 4 g + 3 = (phase ph, channels 4 quad ..)
-      // x tile j <-> samples [512 j - 3, 512 j + 517): this lane's (up to three) samples that fall into it, all three channels
-      // and the zero fourth of a sample as one 8-byte store per piece; columns outside the signal are zeros (the convolution's padding)
-      auto store_x_tile = [&](const int j) {
-        bf16_t* const XP = XP0 + (j & 1) * 3 * D0T_XPS;
-        const int s0 = 512 * j - 3;
+      // The normalised window as bf16 pieces INSIDE the rows that down0.same fills later: piece pc of sample t rests in rows
+      // 2 pc (channels 0, 1) and 2 pc + 1 (channel 2 and a zero) at word 3 + t -- one word below the place of down0.same's sample
+      // t, which is written a tile (512 samples) behind inc's reads.  Stored once, straight from the registers the window was
+      // read into: no fp32 x image, no per-tile copies.
 #pragma unroll
-        for (int k = 0; k < MAXE; ++k) {
-          const int t = tid + k * NTH, col = t - s0;
-          if (t < T0 && (unsigned)col < (unsigned)D0T_XNC) {
-            const float q[4] = {v[0][k], v[1][k], v[2][k], 0.f};
-            b3_store4(XP, D0T_XPS, 4, col, 0, q);
-          }
+      for (int k = 0; k < MAXE; ++k) {
+        const int t = tid + k * NTH;
+        if (k + 1 < MAXE || t < T0) {
+          const float q0 = v[0][k], q1 = v[1][k], q2 = v[2][k];
+          const unsigned h0 = pack_bf16x2(q0, q1), h1 = pack_bf16x2(q2, 0.f);
+          const float r0 = q0 - bf16_lo(h0), r1 = q1 - bf16_hi(h0), r2 = q2 - bf16_lo(h1);
+          const unsigned m0 = pack_bf16x2(r0, r1), m1 = pack_bf16x2(r2, 0.f);
+          unsigned* const xp = HU + 3 + t;
+          xp[0] = h0;
+          xp[W0_S] = h1;
+          xp[2 * W0_S] = m0;
+          xp[3 * W0_S] = m1;
+          xp[4 * W0_S] = pack_bf16x2(r0 - bf16_lo(m0), r1 - bf16_hi(m0));
+          xp[5 * W0_S] = pack_bf16x2(r2 - bf16_lo(m1), 0.f);
         }
-        if (tid < D0T_XNC && (unsigned)(s0 + tid) >= (unsigned)T0) {
-#pragma unroll
-          for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<uint2*>(XP + pc * D0T_XPS + tid * 4) = make_uint2(0u, 0u);
-        }
+      }
+      if (tid < 6 * (W0_S - 3 - T0)) {  // zeros behind the signal: words 3 + T0 .. of the six rows
+        const int r = tid / (W0_S - 3 - T0), c = tid - r * (W0_S - 3 - T0);
+        HU[r * W0_S + 3 + T0 + c] = 0u;
+      }
+      // the ring as two planes per piece, even columns | odd columns (sample s at column s mod 1040): the sixteen lanes of a
+      // fragment step two columns at a time and so read consecutive 16-byte chunks of ONE plane
+      auto ring_at = [](const int c) { return (c & 1) * (D0T_RING / 2 * 8) + (c >> 1) * 8; };
+      if (tid < 48)  // ring columns 1024 .. 1039 <-> samples -16 .. -1: zeros
+        *reinterpret_cast<uint4*>(HP + (tid >> 4) * D0T_HPS + ring_at(D0T_RING - 16 + (tid & 15))) = make_uint4(0u, 0u, 0u, 0u);
+      // Every wave runs one n-tile (32 samples) of inc on tile j AND one of down0.same on tile j - 1 per phase: two independent
+      // MFMA chains and epilogues per wave.  (Measured on the way here, tools/d0t_phase_probe.py: a phase costs the SUM of what
+      // its waves issue -- scalar instructions and branches included, the CU has one scalar unit -- plus the latency of each
+      // wave's one serial chain LDS read -> MFMAs -> epilogue -> barrier; thirteen phases of eight-wave roles with per-tile x
+      // copies took 2.1 k cycles each, 870 of them the copies.)
+      // the skip tensor leaves tile by tile, two phases behind down0.same (one 16-byte store per lane and phase: all 96 KB of a
+      // window behind the last tile made every CU of the chip store at once, 5.3 k cycles)
+      const int skip_ch = tid >> 7, skip_q = tid & 127;
+      float* const skip_row = a.skip0 + (long)win * a.ws_s + HALO + (long)skip_ch * a.ls_s;
+      auto store_skip_tile = [&](const int k) {  // samples 512 k - 8 + 4 q .. + 3
+        const int ts = D0T_TS * k - 8 + 4 * skip_q;
+        if (ts >= 0 && ts < T0)
+          *reinterpret_cast<f32x4*>(skip_row + ts) = *reinterpret_cast<const f32x4*>(H + skip_ch * W0_S + 4 + ts);
       };
-      store_x_tile(0);
-      if (tid < 48)  // ring columns 512 .. 527 <-> samples -16 .. -1: zeros
-        *reinterpret_cast<uint4*>(HP + (tid >> 4) * D0T_HPS + (512 + (tid & 15)) * 8) = make_uint4(0u, 0u, 0u, 0u);
-      uint4 aI[3], aS[B3Steps<8, 8>::STEPS * 3];
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc) aI[pc] = a.af3_inc[pc * 64 + lane];
-      b3_load_a<8, 8>(a.af3_d0s, 0, lane, aS);
-      float bI[4], bS[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bI[r] = a.bs_inc8[4 * quad + r], bS[r] = a.bs_d0s[4 * quad + r];
       WIN_STAMP(31)
       __syncthreads();
       WIN_STAMP(19)
-      constexpr int WP6[6] = {2, 1, 0, 1, 0, 0}, XP6[6] = {0, 1, 2, 0, 1, 0};  // (w piece, x piece), smallest products first
-#pragma unroll 1
-      for (int i = 0; i < D0T_TILES; ++i) {
-        const int cbase = i == 0 ? 0 : D0T_RING - 16 * i;  // ring column of sample 512 i
-        {  // inc, n-tile `wave` of tile i: samples 512 i + 32 wave + 2 n + ph
-          const bf16_t* xp = XP0 + (i & 1) * 3 * D0T_XPS + (32 * wave + 2 * n + 2 * g) * 4;
-          uint4 b[3];
+#define D0T_MFMA(ACC, W, X) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, W), __builtin_bit_cast(bf16x8_b3, X), ACC, 0, 0, 0)
+      float aD[W_down::CB * W_down::TAPS], bD[4];
+      int cinc = 32 * wave + 2 * n + ph;                    // inc: ring column of this lane's sample of tile j
+      int csame = D0T_RING - 11 + 32 * wave + 2 * n + g;     // down0.same: ring column of tap g's sample for tile j - 1
+      csame = csame >= D0T_RING ? csame - D0T_RING : csame;
+      const unsigned* xq = HU + 32 * wave + 2 * n + 2 * g;   // inc: words 3 + (sample - 3 + tap), tap = 2 g, of tile 0
+      float* hq = H + 4 * quad * W0_S + 4 - 8 + 32 * wave + 2 * n + ph;  // down0.same: this lane's sample of tile 0
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) b[pc] = *reinterpret_cast<const uint4*>(xp + pc * D0T_XPS);
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int t6 = 0; t6 < 6; ++t6)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, aI[WP6[t6]]), __builtin_bit_cast(bf16x8_b3, b[XP6[t6]]),
-                                                         acc, 0, 0, 0);
-          const int s = 512 * i + 32 * wave + 2 * n + ph;
-          int c = cbase + 32 * wave + 2 * n + ph;
-          c = c >= D0T_RING ? c - D0T_RING : c;
-          float o[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = s < T0 ? fmaxf(acc[r] + bI[r], 0.f) : 0.f;
-          b3c_store4<8, D0T_RING>(HP, c, quad, o);
-          // the next tile's x image (its last readers were inc's waves of tile i - 1, a barrier ago)
-          if (i + 1 < D0T_TILES) store_x_tile(i + 1);
-        }
-        lds_barrier();
-        if (i == 0) { WIN_STAMP(20) }
-        {  // down0.same, n-tile `wave`: samples 512 i - 8 + 32 wave + 2 n + ph read inc's samples .. - 3 + tap, tap = g + 4 step
-          int c0 = cbase - 11 + 32 * wave + 2 * n + g;
-          c0 = c0 < 0 ? c0 + D0T_RING : c0;
-          int c1 = c0 + 4;
-          c0 = c0 >= D0T_RING ? c0 - D0T_RING : c0;
-          c1 = c1 >= D0T_RING ? c1 - D0T_RING : c1;
-          uint4 b[2][3];
+      for (int j = 0; j <= D0T_TILES; ++j) {
+        uint4 bi[3], bs[2][3];
+        if (j < D0T_TILES) {
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc) {
-            b[0][pc] = *reinterpret_cast<const uint4*>(HP + pc * D0T_HPS + c0 * 8);
-            b[1][pc] = *reinterpret_cast<const uint4*>(HP + pc * D0T_HPS + c1 * 8);
-          }
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int t6 = 0; t6 < 6; ++t6)
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, aS[st * 3 + WP6[t6]]),
-                                                           __builtin_bit_cast(bf16x8_b3, b[st][XP6[t6]]), acc, 0, 0, 0);
-          const int t = 512 * i - 8 + 32 * wave + 2 * n + ph;
-          if ((unsigned)t < (unsigned)(W0_S - 4)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) H[(4 * quad + r) * W0_S + 4 + t] = t < T0 ? fmaxf(acc[r] + bS[r], 0.f) : 0.f;
+            const uint2 lo = *reinterpret_cast<const uint2*>(xq + 2 * pc * W0_S), hi = *reinterpret_cast<const uint2*>(xq + (2 * pc + 1) * W0_S);
+            bi[pc] = make_uint4(lo.x, lo.y, hi.x, hi.y);
           }
         }
-        lds_barrier();
-      }
-      // down0.same rests in H (fp32): the skip tensor goes to memory, the tile images give way to down0.down's piece image
-      float aD[W_down::CB * W_down::TAPS], bD[4];
-      load_areg<W_down>(a.af_down, 0, lane, aD);
-      load_biasreg<W_down>(a.bs_down, 0, lane, bD);
-      b3c_zero_rest<8, B3_D0_NC>(l16 + A_D0 * 2, 3, B3_D0_NC, tid, NTH);
-      if (own) {
-        float* d = a.skip0 + (long)win * a.ws_s + HALO + t0;
+        if (j > 0) {
+          int c1 = csame + 4;
+          c1 = c1 >= D0T_RING ? c1 - D0T_RING : c1;
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-          *reinterpret_cast<f32x4*>(d + (long)c * a.ls_s) = *reinterpret_cast<const f32x4*>(H + c * W0_S + 4 + t0);
+          for (int pc = 0; pc < 3; ++pc) {
+            bs[0][pc] = *reinterpret_cast<const uint4*>(HP + pc * D0T_HPS + ring_at(csame));
+            bs[1][pc] = *reinterpret_cast<const uint4*>(HP + pc * D0T_HPS + ring_at(c1));
+          }
+        }
+        if (j >= 2) store_skip_tile(j - 2);
+        if (j == D0T_TILES) {  // the A operand of down0.down, into the registers inc's operand has left
+          load_areg<W_down>(a.af_down, 0, lane, aD);
+          load_biasreg<W_down>(a.bs_down, 0, lane, bD);
+        }
+        f32x4 ia = bI, sa = {0.f, 0.f, 0.f, 0.f}, sb = bS;
+        if (j < D0T_TILES) {  // inc, n-tile `wave` of tile j: samples 512 j + 32 wave + 2 n + ph; smallest products first, bias as the accumulator input
+          D0T_MFMA(ia, aI[2], bi[0]);
+          D0T_MFMA(ia, aI[1], bi[1]);
+          D0T_MFMA(ia, aI[0], bi[2]);
+          D0T_MFMA(ia, aI[1], bi[0]);
+          D0T_MFMA(ia, aI[0], bi[1]);
+          D0T_MFMA(ia, aI[0], bi[0]);
+        }
+        if (j > 0) {  // down0.same, n-tile `wave` of tile j - 1: samples 512 (j - 1) - 8 + 32 wave + 2 n + ph read inc's samples .. - 3 + tap, tap = g + 4 step
+          D0T_MFMA(sa, aS[2], bs[0][0]);  // one chain per K-step
+          D0T_MFMA(sb, aS[5], bs[1][0]);
+          D0T_MFMA(sa, aS[1], bs[0][1]);
+          D0T_MFMA(sb, aS[4], bs[1][1]);
+          D0T_MFMA(sa, aS[0], bs[0][2]);
+          D0T_MFMA(sb, aS[3], bs[1][2]);
+          D0T_MFMA(sa, aS[1], bs[0][0]);
+          D0T_MFMA(sb, aS[4], bs[1][0]);
+          D0T_MFMA(sa, aS[0], bs[0][1]);
+          D0T_MFMA(sb, aS[3], bs[1][1]);
+          D0T_MFMA(sa, aS[0], bs[0][0]);
+          D0T_MFMA(sb, aS[3], bs[1][0]);
+        }
+        if (j < D0T_TILES) {
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = fmaxf(ia[r], 0.f);
+          if (D0T_TS * (j + 1) > T0) {  // (uniform) the tile that meets the end of the signal: zeros beyond it
+            const int s = D0T_TS * j + 32 * wave + 2 * n + ph;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = s < T0 ? o[r] : 0.f;
+          }
+          b3_store4(HP + ring_at(cinc), D0T_HPS, 0, 0, 4 * quad, o);
+          cinc += D0T_TS;
+          cinc = cinc >= D0T_RING ? cinc - D0T_RING : cinc;
+          xq += D0T_TS;
+        }
+        if (j > 0) {
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = fmaxf(sa[r] + sb[r], 0.f);
+          if (j == 1 || D0T_TS * j > T0) {  // (uniform) the tiles that meet the ends of the signal
+            const int t = D0T_TS * (j - 1) - 8 + 32 * wave + 2 * n + ph;
+            if ((unsigned)t < (unsigned)(W0_S - 4)) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) hq[r * W0_S] = t < T0 ? o[r] : 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hq[r * W0_S] = o[r];
+          }
+          csame += D0T_TS;
+          csame = csame >= D0T_RING ? csame - D0T_RING : csame;
+          hq += D0T_TS;
+        }
+        lds_barrier();
+        if (j == 0) { WIN_STAMP(20) }
+#ifdef D0T_PROBE
+        WIN_STAMP(2 + j)
+#endif
       }
+#undef D0T_MFMA
+      // down0.same rests in H (fp32); the ring gives way to down0.down's piece image
+      b3c_zero_rest<8, B3_D0_NC>(l16 + A_D0 * 2, 3, B3_D0_NC, tid, NTH);
+      if (tid < 6) H[tid * W0_S + 3] = 0.f;  // word 3 = sample -1 of down0.same (padding): x's first sample rested there
+      store_skip_tile(D0T_TILES - 1);
       lds_barrier();
       WIN_STAMP(21)
       const B3PairStoreC<8, B3_D0_NC> st{l16 + A_D0 * 2, 3, T1};
@@ -1442,7 +1511,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
       conv_lds<LAYER, SI1, IB, SI2, B2, PIPE, (LAYER::NB < BDB_MAX_NB), ADEEP_LAYER(LAYER)>(lds + (IN1), lds + (IN2), a.c.af[IDX], a.c.bs[IDX], (COLS), st, wave, NWV, lane); \
     }                                                                                                              \
     __syncthreads();                                                                                               \
-    WIN_STAMP(stamp)                                                                                               \
+    CORE_WIN_STAMP(stamp)                                                                                               \
     ++stamp;                                                                                                       \
   }
 #define CORE_LAYER_AREG(IDX, LAYER, IN1, SI1, OUT, SO, OB, STORE, CO, COLS, LOUT, WMT, WFIRST, WSTEP)                       \
@@ -1456,7 +1525,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
       conv_lds_areg<LAYER, SI1, IB, SI1, IB>(lds + (IN1), lds + (IN1), ar, br, (WMT), (COLS), st, (WFIRST), (WSTEP), lane); \
     }                                                                                                              \
     __syncthreads();                                                                                               \
-    WIN_STAMP(stamp)                                                                                               \
+    CORE_WIN_STAMP(stamp)                                                                                               \
     ++stamp;                                                                                                       \
   }
   if constexpr (D12B) {
@@ -1479,7 +1548,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
         }
       });
       __syncthreads();
-      WIN_STAMP(stamp)
+      CORE_WIN_STAMP(stamp)
       ++stamp;
     }
     {  // down1.down (fp32 MFMA, strided) -> piece image
@@ -1491,7 +1560,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
         conv_lds<C_d1down, S1_, IB, S1_, IB, PIPE, (C_d1down::NB < BDB_MAX_NB), ADEEP_LAYER(C_d1down)>(lds + A_SKIP1, lds + A_SKIP1, a.c.af[1], a.c.bs[1], T2, st, wave, NWV, lane);
       }
       __syncthreads();
-      WIN_STAMP(stamp)
+      CORE_WIN_STAMP(stamp)
       ++stamp;
     }
     {  // down2.same: wave = (m-tile, block of three n-tiles), eight waves
@@ -1512,7 +1581,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
         });
       }
       __syncthreads();
-      WIN_STAMP(stamp)
+      CORE_WIN_STAMP(stamp)
       ++stamp;
     }
   } else {
@@ -1528,7 +1597,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
     const B3Image<128> iBOT{l16 + A_Q * 2, B3_BOT_PS, 1};
 #define B3_END          \
   __syncthreads();      \
-  WIN_STAMP(stamp)      \
+  CORE_WIN_STAMP(stamp)      \
   ++stamp;
     {  // down2.down (fp32 MFMA, strided) -> three-piece image
       B3BlockStore<32> st{{iD2.img, iD2.ps, iD2.c0, T3, B3_D2_NC}};
@@ -1588,7 +1657,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
       st.zero_rest(2, 2 + 192, tid, NTH);
       conv_b3<C_u1T, true, 64, 64>(iU0S, iU0S, a.af3_uT[0], a.c.bs[9], T3 + 1, st, wave, NWV, lane);
       __syncthreads();
-      WIN_STAMP(stamp)
+      CORE_WIN_STAMP(stamp)
       ++stamp;
     } else {  // up1.convT (fp32 MFMA, 8 m-tiles x 1 block) -> three-piece image
       const B3PhaseStore<32> st{iP.img, iP.ps, iP.c0, T2};
@@ -1600,7 +1669,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
         conv_lds_areg<C_u1T, S3_, IB, S3_, IB>(lds + X_U0S, lds + X_U0S, ar, br, wave, T3 + 1, st, 0, 1, lane);
       }
       __syncthreads();
-      WIN_STAMP(stamp)
+      CORE_WIN_STAMP(stamp)
       ++stamp;
     }
     {  // up1.same: K half of up1.convT's channels, then the half of skip 2
@@ -1637,7 +1706,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
         }
       }
       __syncthreads();
-      WIN_STAMP(stamp)
+      CORE_WIN_STAMP(stamp)
       ++stamp;
     }
   } else {
@@ -1662,7 +1731,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
       if ((unsigned)t < (unsigned)T1) b3c_store4<16, U2_NC>(P2, t + 3, g, v);
     });
     __syncthreads();
-    WIN_STAMP(stamp)
+    CORE_WIN_STAMP(stamp)
     ++stamp;
   } else if constexpr (U2B) {  // up2.convT (fp32 MFMA, 4 m-tiles x 4 blocks) -> chunk-plane piece image
     const B3PhaseStoreC<16, U2_NC> st{P2, 3, T1};
@@ -1674,7 +1743,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
       conv_lds_areg<C_u2T, S2_, IB, S2_, IB>(lds + X_U1S, lds + X_U1S, ar, br, wave & 3, T2 + 1, st, wave >> 2, 4, lane);
     }
     __syncthreads();
-    WIN_STAMP(stamp)
+    CORE_WIN_STAMP(stamp)
     ++stamp;
   } else {
   CORE_LAYER_AREG(11, C_u2T, X_U1S, S2_, A_U2T, S1_, TB, RangeStoreV, 16, T2 + 1, T1, wave & 3, wave >> 2, 4)  // 4 m-tiles x 4 blocks
@@ -1742,7 +1811,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
       conv_lds<C_u2same, S1_, IB, S1_, TB, PIPE, (C_u2same::NB < BDB_MAX_NB), ADEEP_LAYER(C_u2same)>(lds + A_SKIP1, lds + A_U2T, a.c.af[12], a.c.bs[12], T1, st, wave, NWV, lane);
       __syncthreads();
     }
-    WIN_STAMP(stamp)
+    CORE_WIN_STAMP(stamp)
     ++stamp;
   }
 #undef CORE_LAYER
@@ -1814,6 +1883,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
   }
   if (clk && tid == 0) clk[(long)win * 32 + 17] = wall_clock64();
 #undef WIN_STAMP
+#undef CORE_WIN_STAMP
 #undef WIN_WARM_SCALAR
 }
 
