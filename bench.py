@@ -131,7 +131,7 @@ def compact_line(result, detail_path=None):
     for k in ("value", "unit", "ms_per_step"):
         body.pop(k, None)
     out.update(body)
-    for k in ("weight_broadcast_path", "weight_broadcast_s", "picks", "detections"):
+    for k in ("weight_broadcast_path", "weight_broadcast_s", "picks", "detections", "picks_digest"):
         if k in result:
             out[k] = result[k]
     if result.get("ranks"):
@@ -147,6 +147,8 @@ def compact_line(result, detail_path=None):
     ms = result.get("mseed")
     if isinstance(ms, dict):
         out["mseed"] = _pick(ms, "value", "unit", "kernel_ms", "bit_exact_vs_fixture_samples", "file_to_picks_ms", "error")
+        if isinstance(ms.get("file_to_picks"), dict):
+            out["mseed"]["file_to_picks_host_stream_ms"] = ms["file_to_picks"].get("host_stream_ms")
         if "read_wall_ms_host_file_to_host_stream" in ms:
             out["mseed"]["read_wall_ms"] = ms["read_wall_ms_host_file_to_host_stream"]
         if isinstance(ms.get("roofline"), dict):
@@ -690,6 +692,32 @@ def bench_mseed(hours=24, iters=30):
     st = va.read(buf)
     t_read = time.perf_counter() - t0
     day_ok = len(st) == 3 and all(tr.stats.npts == total // 3 for tr in st)
+
+    # ---- file -> picks: what a caller of obspy.read + classify waits for (/root/reference volpick/data/convert.py:7,150 ahead of
+    # README.md:54-66): the station-day file in host memory -> read() -> PhaseNet.classify() -> pick list, median of 7 calls;
+    # device-resident read (samples stay in HBM, trace.data copies on demand) and the plain host Stream, phases once
+    def med(fn, n=7):
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r = fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t) * 1e3)
+        return statistics.median(ts), r
+
+    picker = va.PhaseNet.from_pretrained("volpick").cuda()
+    ckw = dict(batch_size=256, overlap=1500, blinding=(0, 0), stacking="avg")
+    picker.classify(va.read(buf, device_resident=True), **ckw)  # warm-up: contexts, scratch
+    f2p_dev, n_picks_dev = med(lambda: len(picker.classify(va.read(buf, device_resident=True), **ckw).picks))
+    f2p_host, n_picks_host = med(lambda: len(picker.classify(va.read(buf), **ckw).picks))
+    t_scan2, recs2 = med(lambda: vio.scan_mseed(buf))
+    t_seg, _ = med(lambda: vio._segments(recs2))
+    t_read_dev, st_dev = med(lambda: va.read(buf, device_resident=True))
+    t_cls_dev, _ = med(lambda: len(picker.classify(st_dev, **ckw).picks))
+    t_read_host, st_host = med(lambda: va.read(buf))
+    t_cls_host, _ = med(lambda: len(picker.classify(st_host, **ckw).picks))
+    picker._release()
     out = {
         "metric": "miniSEED samples decoded per second (Steim-2, one 3-component station-day, file resident in HBM)",
         "value": total / (ms.value * 1e-3), "unit": "samples/s", "kernel_ms": ms.value, "records": int(len(recs)), "samples": total,
@@ -699,8 +727,22 @@ def bench_mseed(hours=24, iters=30):
                      "frac": algo / (ms.value * 1e-3) / (PEAK_HBM_GBS * 1e9), "algorithmic_bytes": algo,
                      "basis": "payload bytes read + 4 B per decoded sample written, per launch / its duration (HIP events, "
                               f"{iters} launches back to back); 36 MB file + 104 MB of samples: latency of the serial Steim "
-                              "difference chain inside a record, not bandwidth, bounds it"},
-        "read_wall_ms_host_file_to_host_stream": t_read * 1e3, "scan_ms": t_scan * 1e3,
+                              "difference chain inside a record, not bandwidth, bounds it.  The input is a 36-record fixture tiled 240x and "
+                              "read by back-to-back launches: its 35 MB sit in the 256 MB Infinity Cache, so the READ side of `achieved` is "
+                              "not an HBM measurement (the 104 MB written per launch are)"},
+        "read_wall_ms_host_file_to_host_stream": t_read_host, "read_wall_ms_first_call": t_read * 1e3, "scan_ms": t_scan * 1e3,
+        "file_to_picks_ms": f2p_dev,
+        "file_to_picks": {
+            "call": "PhaseNet.classify(va.read(file_bytes, device_resident=True), batch_size=256, overlap=1500) on the station-day, host file "
+                    "bytes in, pick list out; median of 7",
+            "device_resident_ms": f2p_dev, "host_stream_ms": f2p_host, "picks": n_picks_dev, "picks_host_stream": n_picks_host,
+            "phases_ms": {"scan": t_scan2, "order_and_chain_records": t_seg, "read_device_resident (scan + upload 35 MB + decode)": t_read_dev,
+                          "classify_device_resident": t_cls_dev, "read_host_stream (+ 104 MB to fresh host memory)": t_read_host,
+                          "classify_host_stream (int32 counts uploaded, cast on the device)": t_cls_host},
+            "note": "the host Stream pays for 104 MB of decoded samples landing in fresh host memory (first-touch page faults: 9 of its "
+                    "13 ms; huge pages / MADV_POPULATE_WRITE measured the same) and for their way back up; the device-resident Stream "
+                    "keeps them in HBM and copies to the host only if trace.data is read",
+        },
     }
     from oracle import mseed as OM
 
@@ -1127,8 +1169,13 @@ def bench_strong(env):
         dist.all_gather_object(gathered, info)
         out["ranks"] = gathered
     if rank == 0:
+        import hashlib
+
         out["picks"] = len(res[0].picks)
         out["detections"] = len(res[0].detections)
+        # what the N ranks stitched together, as one number a second run at another N can be compared with
+        rows = sorted((p.phase, p.trace_id, p.start_time._us, p.end_time._us, p.peak_time._us, float(np.float32(p.peak_value))) for p in res[0].picks)
+        out["picks_digest"] = hashlib.sha1(repr(rows).encode()).hexdigest()[:16]
     return out
 
 

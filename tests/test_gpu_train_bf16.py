@@ -158,8 +158,16 @@ def check_every_kernel(B, x, y, tr, loss, t, g, pred, net=None):
     assert abs(loss - l_ref.item()) < 2e-6 * l_ref.item()
     assert np.abs(pred - p_ref.detach().numpy()).max() < 2e-5
     close_bf16(t["up3.same.ga"], a17.grad.numpy(), "up3.same.ga", abs_frac=1e-4)
+    # the head's weight / bias gradients are sums over B x 3001 terms that nearly cancel (the three classes' bias gradients add up
+    # to zero): the kernel finishes them in fp64, torch's fp32 sums are 1.2e-4 off at B = 512 -- so the reference is taken in fp64
+    import copy
+
+    out64 = copy.deepcopy(net.out).double()
+    for p in out64.parameters():
+        p.grad = None
+    ref_loss(torch.softmax(out64(T["up3.same.a"].double()), dim=1), torch.from_numpy(y).double()).backward()
     for k in ("weight", "bias"):
-        want = getattr(net.out, k).grad.numpy()
+        want = getattr(out64, k).grad.numpy()
         assert np.abs(g["out." + k].reshape(want.shape) - want).max() < 1e-4 * np.abs(want).max(), "out." + k
 
 

@@ -112,7 +112,9 @@ def main():
     m, lo, res = med(lambda: len(model.classify(std, **kw).picks))
     rows.append(("PhaseNet.classify(device-resident stream)", m, lo))
     m, lo, res = med(lambda: len(model.classify(st, **kw).picks))
-    rows.append(("PhaseNet.classify(host stream)", m, lo))
+    rows.append(("PhaseNet.classify(host stream, int32 counts)", m, lo))
+    m, lo, res = med(lambda: len(model.classify(va.read(buf), **kw).picks))
+    rows.append(("file -> picks through a HOST stream (read + classify)", m, lo))
     m, lo, res = med(lambda: len(model.classify(va.read(buf, device_resident=True), **kw).picks))
     rows.append(("file -> picks (read device-resident + classify)", m, lo))
     if hasattr(va, "read_and_classify"):

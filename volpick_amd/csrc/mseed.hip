@@ -8,6 +8,8 @@
 // at a time, and the two serial steps -- where each word's differences start (1..7 per word)
 // and the running sum -- are two DPP prefix scans over the lanes; the <= 7 differences of a
 // word are integrated in registers and stored straight to their place in the output.
+#include <mutex>
+
 #include "vp_common.h"
 
 namespace vp {
@@ -376,12 +378,33 @@ void launch_decode(const uint8_t* buf, long long nbytes, const DevRec* recs, lon
   }
 }
 
-struct DevBuf {  // frees on scope exit
-  void* p = nullptr;
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
+// Device scratch of vp_mseed_decode, per device, grow-only, reused from call to call: the file image, the sample array (host
+// destinations), the record table and the status words.  (hipMalloc + hipFree of 35 + 104 MB around every station-day cost
+// more than the decode itself; a call holds the device's lock from its first use of the scratch to its last.)
+struct MseedScratch {
+  std::mutex mu;
+  void* p[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t cap[4] = {0, 0, 0, 0};
+  int grow(int slot, size_t bytes, void** out) {
+    if (bytes > cap[slot]) {
+      if (p[slot]) (void)hipFree(p[slot]);
+      p[slot] = nullptr;
+      cap[slot] = 0;
+      const size_t want = bytes + bytes / 4 + 4096;
+      if (hipMalloc(&p[slot], want) != hipSuccess) {
+        set_error("vp_mseed_decode: cannot allocate %zu bytes of device scratch", want);
+        return VP_ERR_HIP;
+      }
+      cap[slot] = want;
+    }
+    *out = p[slot];
+    return VP_OK;
   }
 };
+MseedScratch& mseed_scratch(int device) {
+  static MseedScratch pool[64];
+  return pool[(unsigned)device % 64];
+}
 
 }  // namespace
 }  // namespace vp
@@ -481,36 +504,38 @@ extern "C" int vp_mseed_decode(int device_id, const uint8_t* buf, int buf_mem, s
     for (int64_t r = 0; r < n_recs; ++r) status[r] = 0;
   VP_HIP(hipSetDevice(device_id));
   hipStream_t s = nullptr;  // the null stream keeps this call self-contained (no handle, one sync at the end)
-  DevBuf dbuf, dout, drec, dstat;
+  MseedScratch& sc = mseed_scratch(device_id);
+  std::lock_guard<std::mutex> lock(sc.mu);
+  void *dbuf = nullptr, *dout = nullptr, *drec = nullptr, *dstat = nullptr;
   const uint8_t* bufp = buf;
   if (buf_mem == VP_MEM_HOST) {
-    VP_HIP(hipMalloc(&dbuf.p, nbytes ? nbytes : 4));
-    VP_HIP(hipMemcpyAsync(dbuf.p, buf, nbytes, hipMemcpyHostToDevice, s));
-    bufp = (const uint8_t*)dbuf.p;
+    if (const int rc2 = sc.grow(0, nbytes ? nbytes : 4, &dbuf)) return rc2;
+    VP_HIP(hipMemcpyAsync(dbuf, buf, nbytes, hipMemcpyHostToDevice, s));
+    bufp = (const uint8_t*)dbuf;
   }
   VP_REQUIRE(((uintptr_t)bufp & 3) == 0, "vp_mseed_decode: buffer is not 4-byte aligned");
   void* outp = out;
   const size_t out_bytes = (size_t)out_len * 4;
   if (out_mem == VP_MEM_HOST) {
-    VP_HIP(hipMalloc(&dout.p, out_bytes ? out_bytes : 4));
-    outp = dout.p;
+    if (const int rc2 = sc.grow(1, out_bytes ? out_bytes : 4, &dout)) return rc2;
+    outp = dout;
     if (!zero_fill) VP_HIP(hipMemcpyAsync(outp, out, out_bytes, hipMemcpyHostToDevice, s));
   }
   if (zero_fill) VP_HIP(hipMemsetAsync(outp, 0, out_bytes, s));
   if (!dev.empty()) {
-    VP_HIP(hipMalloc(&drec.p, dev.size() * sizeof(DevRec)));
-    VP_HIP(hipMemcpyAsync(drec.p, dev.data(), dev.size() * sizeof(DevRec), hipMemcpyHostToDevice, s));
+    if (const int rc2 = sc.grow(2, dev.size() * sizeof(DevRec), &drec)) return rc2;
+    VP_HIP(hipMemcpyAsync(drec, dev.data(), dev.size() * sizeof(DevRec), hipMemcpyHostToDevice, s));
     if (status) {
-      VP_HIP(hipMalloc(&dstat.p, dev.size() * sizeof(int)));
-      VP_HIP(hipMemsetAsync(dstat.p, 0, dev.size() * sizeof(int), s));
+      if (const int rc2 = sc.grow(3, dev.size() * sizeof(int), &dstat)) return rc2;
+      VP_HIP(hipMemsetAsync(dstat, 0, dev.size() * sizeof(int), s));
     }
-    launch_decode(bufp, (long long)nbytes, (const DevRec*)drec.p, (long long)dev.size(), out_kind, outp, out_len, (int*)dstat.p, s);
+    launch_decode(bufp, (long long)nbytes, (const DevRec*)drec, (long long)dev.size(), out_kind, outp, out_len, (int*)dstat, s);
     VP_HIP(hipGetLastError());
   }
   if (out_mem == VP_MEM_HOST) VP_HIP(hipMemcpyAsync(out, outp, out_bytes, hipMemcpyDeviceToHost, s));
   std::vector<int> hstat(dev.size());
   if (status && !dev.empty())
-    VP_HIP(hipMemcpyAsync(hstat.data(), dstat.p, dev.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    VP_HIP(hipMemcpyAsync(hstat.data(), dstat, dev.size() * sizeof(int), hipMemcpyDeviceToHost, s));
   VP_HIP(hipStreamSynchronize(s));
   if (status)
     for (size_t i = 0; i < dev.size(); ++i) status[origin[i]] = hstat[i];
@@ -527,7 +552,12 @@ extern "C" int vp_mseed_decode_bench(int device_id, const uint8_t* buf_dev, size
   if (rc != VP_OK) return rc;
   VP_REQUIRE(!dev.empty(), "vp_mseed_decode_bench: nothing to decode");
   VP_HIP(hipSetDevice(device_id));
-  DevBuf drec;
+  struct Owned {  // frees on scope exit
+    void* p = nullptr;
+    ~Owned() {
+      if (p) (void)hipFree(p);
+    }
+  } drec;
   VP_HIP(hipMalloc(&drec.p, dev.size() * sizeof(DevRec)));
   VP_HIP(hipMemcpy(drec.p, dev.data(), dev.size() * sizeof(DevRec), hipMemcpyHostToDevice));
   hipStream_t s;

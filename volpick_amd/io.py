@@ -53,7 +53,13 @@ def scan_mseed(buf):
     """Record table of a miniSEED byte string as a numpy structured array (host only)."""
     lib = _lib.load()
     n = C.c_int64(0)
-    cap = max(1, len(buf) // 256)
+    # capacity from the first record's length (miniSEED 2: 2 ** byte 6 of blockette 1000, usually at byte 48 + 6; miniSEED 3
+    # records vary) -- a table sized for 256-byte records is 10 MB of zeroed ctypes memory for a 35 MB station-day of
+    # 4096-byte records; the scanner reports the real count, so a low guess costs one more pass
+    guess = 512
+    if len(buf) >= 56 and buf[:3] != b"MS\x03" and buf[48:50] in (b"\x03\xe8", b"\xe8\x03") and 7 <= buf[54] <= 24:
+        guess = 1 << buf[54]
+    cap = max(16, len(buf) // guess + 16)
     while True:
         recs = (_lib.VpMseedRecord * cap)()
         _lib.check(lib.vp_mseed_scan(buf, len(buf), recs, cap, C.byref(n)), "vp_mseed_scan")

@@ -806,7 +806,10 @@ class _Rows:
     def upload(self, torch, dev):
         x = torch.empty(self.shape, dtype=torch.float32, device=dev)
         for c, p in enumerate(self.parts):
-            x[c].copy_(torch.from_numpy(np.ascontiguousarray(p)))  # casts int / float64 counts to float32
+            h = torch.from_numpy(np.ascontiguousarray(p))
+            # int32 counts (what a miniSEED file decodes to) and float64 rows travel as they are and are cast on the device:
+            # the host-side cast of a day-long row costs 20 ms, 30 x its upload
+            x[c].copy_(h if h.dtype == torch.float32 else h.to(dev))
         return x
 
 
