@@ -139,7 +139,7 @@ def test_level_0_down_path_on_the_matrix_cores_agrees_with_the_vector_alu_form(o
     with torch.no_grad():
         want = oracle(xn).numpy()
     outs, raws = [], []
-    for flags in ((0,), (0, 0, 0, 0, 0, 8)):
+    for flags in ((0,), (0, 0, 0, 0, 0, 8), (0, 0, 0, 0, 0, 9)):  # default (level 0 down AND up on the matrix cores) | neither | down only
         m = PhaseNet.from_pretrained("volpick")
         m._plan_flags = flags
         m.cuda()
@@ -148,6 +148,7 @@ def test_level_0_down_path_on_the_matrix_cores_agrees_with_the_vector_alu_form(o
         assert np.abs(outs[-1] - want).max() < 3e-5 and np.abs(raws[-1] - want).max() < 3e-5, flags
         m._release()
     assert np.abs(outs[0] - outs[1]).max() < 1e-5 and np.abs(raws[0] - raws[1]).max() < 1e-5
+    assert np.abs(outs[2] - outs[1]).max() < 1e-5 and np.abs(raws[2] - raws[1]).max() < 1e-5
     if B > 1:
         bad = xn.clone()
         bad[1, 2, 7] = float("inf")

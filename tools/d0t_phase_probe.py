@@ -18,8 +18,15 @@ _lib.check(lib.vp_profile_steps(m._handle, B, 200, ms, n))
 clk=np.zeros((B,32),np.uint64)
 _lib.check(lib.vp_debug_core_clock(m._handle, B, clk.ctypes.data_as(C.c_void_p)))
 c=clk.astype(np.int64)
-print("start->x loaded(19):", np.median(c[:,19]-c[:,0]))
-prev=c[:,19]
-for j in range(7):
-    print("phase",j, np.median(c[:,2+j]-prev)); prev=c[:,2+j]
-print("after loop -> stamp21:", np.median(c[:,21]-prev), " down0.down:", np.median(c[:,22]-c[:,21]))
+if len(sys.argv) > 1 and sys.argv[1] == "up":  # library built with -DU3T_PROBE: slots 2 .. 14 = the thirteen phases of the up path
+    print("up phase: start(23) -> operands loaded, ring zeroed (24):", np.median(c[:,24]-c[:,23]))
+    prev=c[:,24]
+    for j in range(13):
+        print("phase",j, np.median(c[:,2+j]-prev)); prev=c[:,2+j]
+    print("whole up phase:", np.median(c[:,28]-c[:,23]))
+else:
+    print("start->x loaded(19):", np.median(c[:,19]-c[:,0]))
+    prev=c[:,19]
+    for j in range(7):
+        print("phase",j, np.median(c[:,2+j]-prev)); prev=c[:,2+j]
+    print("after loop -> stamp21:", np.median(c[:,21]-prev), " down0.down:", np.median(c[:,22]-c[:,21]))

@@ -933,6 +933,9 @@ struct WindowArgs {
   const uint4* af3_inc;    // D0T: inc, rows (phase, channel), ONE K-step of eight taps x four channels (three + a zero one)
   const uint4* af3_d0s;    // D0T: down0.same, rows (phase, channel), two K-steps of four taps x eight channels (B3Steps<8, 8>)
   const float *bs_inc8, *bs_d0s;  // D0T: their biases [8] (BatchNorm folded)
+  const uint4* af3_u3t;    // U3T: up3.convT, rows (phase, channel), ONE K-step of two taps x 16 channels (B3Steps<16, 2>), two m-tiles
+  const uint4* af3_u3s;    // U3T: up3.same, rows (phase, channel), four K-steps of two taps x 16 channels (skip 0 | up3.convT) (B3Steps<16, 8>)
+  const float *bs_u3t, *bs_u3s;  // U3T: their biases [8]
   const float* x;   // [B][3][ls] normalised input
   int ls_x;
   long ws_x;
@@ -1033,13 +1036,30 @@ constexpr int D0T_RED = CORE_LDS_FLOATS - 256;  // the reduction scratch of the 
 static_assert(D0T_TILES * D0T_TS >= W0_S - 4 + 8 && D0T_RING >= 2 * D0T_TS + 11 + 4 && D0T_RING % 2 == 0 &&
                   WD_X * 4 + 3 * D0T_HPS * 2 <= D0T_RED * 4 && (9 * 16 + 8) <= 256,
               "level-0 tiles: the ring behind the eight fp32 rows, the scratch behind the ring, inside the arena");
-template <bool PIPE, bool B3, bool U1B = false, bool U2B = false, bool U3B = false, bool D12B = false, bool D0T = false>
+// U3T (with D0T): the level-0 UP path on the bf16 matrix cores, time-tiled the same way.  up2.same writes its output as a piece
+// image (16 channels x 751 samples, chunk planes, at the start of the arena); behind it a 528-column ring holds the 16 input
+// channels of up3.same as pieces -- chunk 0 the skip tensor (read back from memory tile by tile and split), chunk 1 the output of
+// up3.convT (bf16 MFMA: rows (phase, channel) = two m-tiles, K = two taps x 16 channels = ONE K-step; its epilogue writes pieces)
+// -- as even / odd column planes.  Twelve tiles of 256 samples: in phase j waves 8-15 produce tile j (samples 256 j - 2 ..:
+// one (m-tile, n-tile) of the transposed conv and one (sample, channel quad) of the skip tensor per lane), waves 0-7 run up3.same
+// (rows (phase, channel), K = 8 taps x 16 channels = four K-steps) on tile j - 1, eight samples behind, and finish it in
+// registers: the two lanes that hold a sample's eight channels exchange their halves of the 1 x 1 conv (v_permlane16_swap),
+// softmax, store.  No fp32 level-0 row exists in the up path any more.  plan_flags[5] = 9 keeps the VALU / fp32-MFMA form.
+constexpr int U3T_TS = 256, U3T_TILES = 12, U3T_RING = 528, U3T_NCU = 768;
+using U3T_QU = B3Chunk<16, U3T_NCU>;                      // up2.same's output: sample t at column t + 1
+constexpr int U3T_PL = U3T_RING / 2 * 8, U3T_CH = 2 * U3T_PL, U3T_PS = 2 * U3T_CH;  // ring: bf16 per parity plane / chunk / piece
+constexpr int U3T_RING_OFF = 3 * U3T_QU::PS;              // bf16 elements from the arena start: behind the U image
+static_assert(U3T_TILES * U3T_TS >= T0 + 8 && U3T_TILES * U3T_TS < 6 * U3T_RING && U3T_RING >= 2 * U3T_TS + 11 + 4 && U3T_NCU >= T1 + 2 &&
+                  (U3T_RING_OFF + 3 * U3T_PS) * 2 <= CORE_LDS_FLOATS * 4 && U3T_RING_OFF % 8 == 0,
+              "level-0 up tiles: up2.same's piece image and the ring behind it fit the arena");
+template <bool PIPE, bool B3, bool U1B = false, bool U2B = false, bool U3B = false, bool D12B = false, bool D0T = false, bool U3T = false>
 // amdgpu_num_vgpr counts the VGPR half of the unified file on gfx90a+ (LLVM doubles it): 60 -> at most 120 registers per lane, so that
 // four forward waves leave each SIMD the 32 registers the post-processing kernels need to run beside them (prepost.hip; a dozen
 // one-off spills per window in the D0T form, none inside a loop)
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_window_kernel(const WindowArgs a) {
   static_assert(!D12B || B3, "D12B is a form of the B3 kernel");
   static_assert(!D0T || D12B, "D0T is a form of the D12B kernel");
+  static_assert(!U3T || (D0T && U3B), "U3T is a form of the D0T kernel");
   static_assert(!U2B || U1B, "U2B relocates up1.same's output: needs the U1B form");
   static_assert(!U3B || U2B, "U3B builds on the U2B layout");
   constexpr int U2_NC = U3B ? B3_U2_NC3 : B3_U2_NC, U2_OFF = U3B ? B3_U2_OFF3 : B3_U2_OFF;
@@ -1057,8 +1077,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
   if (clk && tid == 0) clk[(long)win * 32 + 16] = wall_clock64();
 #define WIN_STAMP(slot) \
   if (clk && tid == 0) clk[(long)win * 32 + (slot)] = __builtin_readcyclecounter();
-// -DD0T_PROBE (investigation builds only): the thirteen phases of the tiled level-0 down path stamp slots 2 .. 14 instead of the core layers
-#ifdef D0T_PROBE
+// -DD0T_PROBE / -DU3T_PROBE (investigation builds only): the phases of the tiled level-0 down / up path stamp slots 2 .. instead of the core layers
+#if defined(D0T_PROBE) || defined(U3T_PROBE)
 #define CORE_WIN_STAMP(slot)
 #else
 #define CORE_WIN_STAMP(slot) WIN_STAMP(slot)
@@ -1756,7 +1776,22 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
   {
     RangeStoreS<S1_, IB> st{{lds + XU_U, T1}};
     if constexpr (!U2B) zero_halo<16, S1_, T1, IB>(lds + XU_U, tid, NTH);
-    if (wave >= 8) {
+    if (U3T && wave >= 8) {
+      if constexpr (U3T) {  // nothing to fetch here: the skip tensor comes back tile by tile in the up phase
+        __syncthreads();  // waves 0-7 are through with up2.convT's pieces
+        b3c_from_f32<16, U2_NC, S1_, IB>(lds + A_SKIP1, P2, 3, tid, NTH);
+        __syncthreads();  // skip 1 rests in the image: its fp32 rows give way to up2.same's output (pieces, U3T_QU)
+        {  // the columns of that image no sample owns: column 0 (sample -1) and 752 .. 767
+          bf16_t* const UP = reinterpret_cast<bf16_t*>(lds);
+          const int i = tid - 512;
+          if (i < 3 * 2 * (U3T_NCU - T1)) {
+            const int cp = i / (U3T_NCU - T1), k = i - cp * (U3T_NCU - T1), col = k == 0 ? 0 : T1 + k;
+            *reinterpret_cast<uint4*>(UP + (cp >> 1) * U3T_QU::PS + (cp & 1) * U3T_QU::CHS + col * 8) = make_uint4(0u, 0u, 0u, 0u);
+          }
+        }
+        __syncthreads();
+      }
+    } else if (wave >= 8) {
       float4 skq[NSKQ];
       const float* src = a.skip0 + (long)win * a.ws_s;
 #pragma unroll
@@ -1802,8 +1837,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
           const int t = wave * 96 + j * 16 + (lane & 15);
+          if constexpr (U3T) {  // pieces, sample t at column t + 1 (zeros behind the signal)
+            float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) st(co0 + r, t, C_u2same::RELU ? fmaxf(acc[j][r] + biasv[r], 0.f) : acc[j][r] + biasv[r]);
+            for (int r = 0; r < 4; ++r) v[r] = t < T1 ? fmaxf(acc[j][r] + biasv[r], 0.f) : 0.f;
+            if (t + 1 < U3T_NCU) b3c_store4<16, U3T_NCU>(reinterpret_cast<bf16_t*>(lds), t + 1, co0 >> 2, v);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st(co0 + r, t, C_u2same::RELU ? fmaxf(acc[j][r] + biasv[r], 0.f) : acc[j][r] + biasv[r]);
+          }
         }
       }
       __syncthreads();
@@ -1817,7 +1859,140 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
 #undef CORE_LAYER
 
   // ================= level-0 up path: up3.convT -> cat(skip0, .) -> up3.same -> 1x1 -> softmax =================
-  {
+  if constexpr (U3T) {
+    bf16_t* const l16 = reinterpret_cast<bf16_t*>(lds);
+    const bf16_t* const UP = l16;
+    bf16_t* const RU = l16 + U3T_RING_OFF;
+    const int g = lane >> 4, n = lane & 15, ph = g >> 1, quad = g & 1;
+    auto ring_at = [](const int c) { return (c & 1) * U3T_PL + (c >> 1) * 8; };
+    WIN_STAMP(23)
+    const bool producer = wave >= 8;  // (uniform)
+    const int wv = wave & 7;
+    // operands: the consumer's 48 registers (four K-steps x three pieces), the producer's 12
+    uint4 aw[B3Steps<16, 8>::STEPS * 3];
+    f32x4 bv;
+    float w1[3][4], b1[3];  // consumer: its four channels' columns of the 1 x 1 conv
+    const int pl = tid - 512;                       // producer lane 0 .. 511
+    const int sk_q = pl & 1, sk_s = pl >> 1;        // skip tensor: channel quad, sample within the tile
+    const float* const sk_src = a.skip0 + (long)win * a.ws_s + HALO + (long)(4 * sk_q) * a.ls_s;
+    float sk[4] = {0.f, 0.f, 0.f, 0.f};
+    auto fetch_skip = [&](const int j) {  // samples 256 j - 2 + sk_s of channels 4 sk_q ..
+      const int ts = U3T_TS * j - 2 + sk_s;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sk[r] = (unsigned)ts < (unsigned)T0 ? sk_src[(long)r * a.ls_s + ts] : 0.f;
+    };
+    if (producer) {
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) aw[pc] = a.af3_u3t[(long)(wv & 1) * (3 * 64) + pc * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = a.bs_u3t[4 * quad + r];
+      fetch_skip(0);
+    } else {
+      b3_load_a<16, 8>(a.af3_u3s, 0, lane, aw);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = a.bs_u3s[4 * quad + r];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        b1[c] = a.b_out[c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w1[c][r] = a.w_out[c * 8 + 4 * quad + r];
+      }
+    }
+    if (tid < 96) {  // ring columns 512 .. 527 <-> samples -16 .. -1 of both chunks: zeros
+      const int cp = tid >> 4, c = U3T_RING - 16 + (tid & 15);  // cp = piece * 2 + chunk
+      *reinterpret_cast<uint4*>(RU + (cp >> 1) * U3T_PS + (cp & 1) * U3T_CH + ring_at(c)) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    WIN_STAMP(24)
+#define U3T_MFMA(ACC, W, X) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, W), __builtin_bit_cast(bf16x8_b3, X), ACC, 0, 0, 0)
+    // producer: transposed conv item (m-tile wv & 1 = phases 2 (wv & 1) + ph, n-tile wv >> 1 of the tile's 64 level-1 samples)
+    const int mphase = 2 * (wv & 1) + ph;
+    int ct = mphase - 2 + 4 * (16 * (wv >> 1) + n);   // sample of this lane's output in tile 0 (tile j: + 256 j), >= -2
+    ct = ct < 0 ? ct + U3T_RING : ct;                 // its ring column
+    int cs = sk_s - 2;                                // skip sample of tile 0
+    cs = cs < 0 ? cs + U3T_RING : cs;
+    const bf16_t* up = UP + quad * U3T_QU::CHS + (16 * (wv >> 1) + n + ph) * 8;  // U column m + tap (sample m + tap - 1), tap = ph, chunk quad
+    // consumer: n-tile wv of tile j - 1: samples 256 (j - 1) - 8 + 32 wv + 2 n + ph read the ring's samples .. - 3 + tap, tap = 2 step + ph, chunk quad
+    int cc = U3T_RING - 11 + 32 * wv + 2 * n + ph;
+    cc = cc >= U3T_RING ? cc - U3T_RING : cc;
+    float* const yrow = a.y + (long)win * 3 * T0;
+#pragma unroll
+    for (int j = 0; j <= U3T_TILES; ++j) {
+      if (producer) {
+        if (j < U3T_TILES) {
+          uint4 b[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) b[pc] = *reinterpret_cast<const uint4*>(up + pc * U3T_QU::PS);
+          f32x4 acc = bv;
+          U3T_MFMA(acc, aw[2], b[0]);
+          U3T_MFMA(acc, aw[1], b[1]);
+          U3T_MFMA(acc, aw[0], b[2]);
+          U3T_MFMA(acc, aw[1], b[0]);
+          U3T_MFMA(acc, aw[0], b[1]);
+          U3T_MFMA(acc, aw[0], b[0]);
+          // the skip quad fetched a phase ago -> pieces, chunk 0
+          b3_store4(RU + ring_at(cs), U3T_PS, 0, 0, 4 * sk_q, sk);
+          if (j + 1 < U3T_TILES) fetch_skip(j + 1);
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[r], 0.f);
+          if (j == 0 || U3T_TS * (j + 1) > T0) {  // (uniform) the tiles that meet the ends of the signal
+            const int s = U3T_TS * j + mphase - 2 + 4 * (16 * (wv >> 1) + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (unsigned)s < (unsigned)T0 ? o[r] : 0.f;
+          }
+          b3_store4(RU + U3T_CH + ring_at(ct), U3T_PS, 0, 0, 4 * quad, o);
+          ct += U3T_TS, cs += U3T_TS;
+          ct = ct >= U3T_RING ? ct - U3T_RING : ct;
+          cs = cs >= U3T_RING ? cs - U3T_RING : cs;
+          up += (U3T_TS / 4) * 8;
+        }
+      } else if (j > 0) {
+        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = bv;
+        int c = cc;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          uint4 b[3];
+          const bf16_t* rp = RU + quad * U3T_CH + ring_at(c);
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) b[pc] = *reinterpret_cast<const uint4*>(rp + pc * U3T_PS);
+          U3T_MFMA(sa, aw[st * 3 + 2], b[0]);
+          U3T_MFMA(sb, aw[st * 3 + 1], b[0]);
+          U3T_MFMA(sa, aw[st * 3 + 1], b[1]);
+          U3T_MFMA(sb, aw[st * 3 + 0], b[1]);
+          U3T_MFMA(sa, aw[st * 3 + 0], b[2]);
+          U3T_MFMA(sb, aw[st * 3 + 0], b[0]);
+          c += 2;
+          c = c >= U3T_RING ? c - U3T_RING : c;
+        }
+        // BN + ReLU -> Conv1d(8, 3, 1): this lane's four channels, the other four from the lane 16 further (the other channel quad)
+        float z[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          float zz = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) zz = fmaf(w1[k][r], fmaxf(sa[r] + sb[r], 0.f), zz);
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(zz), __float_as_uint(zz), false, false);
+          z[k] = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) + b1[k];  // rows (0, 1) and (2, 3): the pair's sum in both
+        }
+        const float mx = fmaxf(z[0], fmaxf(z[1], z[2]));
+        const float e0 = __expf(z[0] - mx), e1 = __expf(z[1] - mx), e2 = __expf(z[2] - mx);
+        const float inv = 1.f / (e0 + e1 + e2);
+        float y0 = e0 * inv, y1 = e1 * inv, y2 = e2 * inv;
+        if (poisoned) y0 = y1 = y2 = __builtin_nanf("");
+        const int t = U3T_TS * (j - 1) - 8 + 32 * wv + 2 * n + ph;
+        if (quad == 0 && (unsigned)t < (unsigned)T0) yrow[t] = y0, yrow[T0 + t] = y1, yrow[2 * T0 + t] = y2;
+        cc += U3T_TS;
+        cc = cc >= U3T_RING ? cc - U3T_RING : cc;
+      }
+      lds_barrier();
+#ifdef U3T_PROBE
+      WIN_STAMP(2 + j)
+#endif
+    }
+#undef U3T_MFMA
+    WIN_STAMP(28)
+  } else {
     float *G0 = lds + XU_G0, *G1 = lds + XU_G1, *U = lds + XU_U;
     WIN_STAMP(23)
     __syncthreads();
@@ -1928,6 +2103,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
   const bool u3b = u2b && net.cfg.plan_flags[5] != 6;   // plan_flags[5] = 6: up1.convT / up2.convT stay on the fp32 MFMA
   const bool d12b = u3b && net.cfg.plan_flags[5] != 7;  // plan_flags[5] = 7: down1.same / down2.same stay on the fp32 MFMA
   const bool d0t = d12b && net.cfg.plan_flags[5] != 8;  // plan_flags[5] = 8: inc / down0.same stay on the vector ALUs
+  const bool up3t = d0t && net.cfg.plan_flags[5] != 9;   // plan_flags[5] = 9: up3.convT on the fp32 MFMA, up3.same on the vector ALUs
   HostBlob *vw[5] = {}, *vb[5] = {};
   if (valu) {
     const float eps = net.cfg.bn_eps;
@@ -2126,7 +2302,8 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
       };
       double f32 = 0, bf16 = 0;
       for (int i = 2; i <= 16; ++i) {
-        if (b3 && i >= 7 && i <= 11) bf16 += 6.0 * padded(i);
+        if (up3t && i == 16) bf16 += (double)U3T_TILES * 8 * 6 * 16384.0;  // up3.convT: 8 (m-tile, n-tile) items per tile x one K-step
+        else if (b3 && i >= 7 && i <= 11) bf16 += 6.0 * padded(i);
         else if (u1b && i == 13) bf16 += 6.0 * 2.0 * 32 * 192 * 64 * 7;  // up1.same: 2 m-tiles x 12 n-tiles x 14 K-steps
         else if (u2b && i == 15) bf16 += 6.0 * 2.0 * 16 * 768 * 32 * 8;  // up2.same: 48 n-tiles x 2 halves x 4 K-steps
         else if (d12b && i == 3) bf16 += 48.0 * 2 * 6 * 16384.0;          // down1.same: 48 n-tiles x 2 K-steps
@@ -2136,7 +2313,9 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         else f32 += padded(i);
       }
       if (d0t) bf16 += (double)D0T_TILES * 16 * (1 + 2) * 6 * 16384.0;  // inc: 96 n-tiles x 1 K-step; down0.same: 96 x 2; six MFMAs each
-      st.set_issued(f32, bf16, (d0t ? 0.0 : flops(0, 1)) + flops(17, 17));
+      if (up3t) bf16 += (double)U3T_TILES * 8 * 4 * 6 * 16384.0;  // up3.same: 8 n-tiles per tile x four K-steps
+      // (the 1 x 1 head: 2 x 3 x 8 FLOP per sample on the vector ALUs in every form)
+      st.set_issued(f32, bf16, (d0t ? 0.0 : flops(0, 1)) + (up3t ? 2.0 * 3 * 8 * T0 : flops(17, 17)));
     }
     HostBlob* e0 = &net.convs[17]->e0;
     HostBlob* e1 = &net.convs[17]->e1;
@@ -2160,6 +2339,11 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     if (d0t) {
       p3inc = net.add_blob(b3_operand(*net.convs[0], true));
       p3d0s = net.add_blob(b3_operand(*net.convs[1], true));
+    }
+    HostBlob *p3u3t = nullptr, *p3u3s = nullptr;
+    if (up3t) {
+      p3u3t = net.add_blob(b3_operand(*net.convs[16], true));
+      p3u3s = net.add_blob(b3_operand(*net.convs[17], true));
     }
     HostBlob* p3uT[2] = {};
     if (u3b) {
@@ -2214,6 +2398,10 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
       a.af3_d0s = p3d0s ? reinterpret_cast<const uint4*>(p3d0s->d) : nullptr;
       a.bs_inc8 = n.convs[0]->bias.d;
       a.bs_d0s = n.convs[1]->bias.d;
+      a.af3_u3t = p3u3t ? reinterpret_cast<const uint4*>(p3u3t->d) : nullptr;
+      a.af3_u3s = p3u3s ? reinterpret_cast<const uint4*>(p3u3s->d) : nullptr;
+      a.bs_u3t = n.convs[16]->bias.d;
+      a.bs_u3s = n.convs[17]->bias.d;
       for (int i = 0; i < 6; ++i) {
         a.af3[i] = p3[i] ? reinterpret_cast<const uint4*>(p3[i]->d) : nullptr;
         a.af3_lines[i] = p3[i] ? (int)(p3[i]->h.size() * 4 / 128) : 0;
@@ -2249,7 +2437,9 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         a.pre = *n.pre;
         a.has_pre = 1;
       }
-      if (d0t) {
+      if (up3t) {
+        hipLaunchKernelGGL((pn_window_kernel<false, true, true, true, true, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
+      } else if (d0t) {
         hipLaunchKernelGGL((pn_window_kernel<false, true, true, true, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
       } else if (d12b) {
         hipLaunchKernelGGL((pn_window_kernel<false, true, true, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
@@ -2280,6 +2470,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
+    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true, true, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
   }
   net.steps = std::move(steps);
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_core_kernel<true>), CORE_LDS_FLOATS * sizeof(float)});
