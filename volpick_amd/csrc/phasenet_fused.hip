@@ -1047,7 +1047,9 @@ static_assert(D0T_TILES * D0T_TS >= W0_S - 4 + 8 && D0T_RING >= 2 * D0T_TS + 11 
 // softmax, store.  No fp32 level-0 row exists in the up path any more.  plan_flags[5] = 9 keeps the VALU / fp32-MFMA form.
 constexpr int U3T_TS = 256, U3T_TILES = 12, U3T_RING = 528, U3T_NCU = 768;
 using U3T_QU = B3Chunk<16, U3T_NCU>;                      // up2.same's output: sample t at column t + 1
-constexpr int U3T_PL = U3T_RING / 2 * 8, U3T_CH = 2 * U3T_PL, U3T_PS = 2 * U3T_CH;  // ring: bf16 per parity plane / chunk / piece
+constexpr int U3T_PLN = U3T_RING / 2, U3T_MIR = 4;  // entries of a parity plane; its first four entries are repeated behind it, so
+                                                    // that the four K-steps of a fragment (two columns apart) never wrap
+constexpr int U3T_PL = (U3T_PLN + U3T_MIR) * 8, U3T_CH = 2 * U3T_PL, U3T_PS = 2 * U3T_CH;  // ring: bf16 per parity plane / chunk / piece
 constexpr int U3T_RING_OFF = 3 * U3T_QU::PS;              // bf16 elements from the arena start: behind the U image
 static_assert(U3T_TILES * U3T_TS >= T0 + 8 && U3T_TILES * U3T_TS < 6 * U3T_RING && U3T_RING >= 2 * U3T_TS + 11 + 4 && U3T_NCU >= T1 + 2 &&
                   (U3T_RING_OFF + 3 * U3T_PS) * 2 <= CORE_LDS_FLOATS * 4 && U3T_RING_OFF % 8 == 0,
@@ -1773,11 +1775,45 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
   // registers (their LDS destination is still in use by this layer) and park them in LDS right after the barrier —
   // the read-back of the skip tensor costs the up phase nothing (it was 8 k cycles of exposed memory latency).
   constexpr int NSKQ = (8 * W0_Q + 511) / 512;
+  // U3T: the operands of the up path (the consumer waves' 48 registers of up3.same, the producer waves' 12 of up3.convT, the
+  // 1 x 1 head, the first skip quads) are requested under up2.same: by waves 8-15 at its start (they only convert and wait
+  // there), by waves 0-7 behind their last MFMA
+  [[maybe_unused]] uint4 u3_aw[B3Steps<16, 8>::STEPS * 3];
+  [[maybe_unused]] f32x4 u3_bv;
+  [[maybe_unused]] float u3_w1[3][4], u3_b1[3], u3_sk[4] = {0.f, 0.f, 0.f, 0.f};
+  [[maybe_unused]] const int u3_pl = tid - 512, u3_skq = u3_pl & 1, u3_sks = u3_pl >> 1;  // producer lane: skip channel quad, sample within the tile
+  [[maybe_unused]] const float* const u3_src = a.skip0 + (long)win * a.ws_s + HALO + (long)(4 * u3_skq) * a.ls_s;
+  [[maybe_unused]] auto u3_fetch_skip = [&](const int j, const bool edge) {  // samples 256 j - 2 + u3_sks of channels 4 u3_skq ..
+    const int ts = U3T_TS * j - 2 + u3_sks;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u3_sk[r] = (!edge || (unsigned)ts < (unsigned)T0) ? u3_src[(long)r * a.ls_s + ts] : 0.f;
+  };
+  [[maybe_unused]] auto u3_load_operands = [&]() {
+    const int q = (lane >> 4) & 1;
+    if (wave >= 8) {
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) u3_aw[pc] = a.af3_u3t[(long)(wave & 1) * (3 * 64) + pc * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) u3_bv[r] = a.bs_u3t[4 * q + r];
+      u3_fetch_skip(0, true);
+    } else {
+      b3_load_a<16, 8>(a.af3_u3s, 0, lane, u3_aw);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) u3_bv[r] = a.bs_u3s[4 * q + r];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        u3_b1[c] = a.b_out[c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u3_w1[c][r] = a.w_out[c * 8 + 4 * q + r];
+      }
+    }
+  };
   {
     RangeStoreS<S1_, IB> st{{lds + XU_U, T1}};
     if constexpr (!U2B) zero_halo<16, S1_, T1, IB>(lds + XU_U, tid, NTH);
     if (U3T && wave >= 8) {
-      if constexpr (U3T) {  // nothing to fetch here: the skip tensor comes back tile by tile in the up phase
+      if constexpr (U3T) {  // the skip tensor comes back tile by tile in the up phase; its first quads and the operands start now
+        u3_load_operands();
         __syncthreads();  // waves 0-7 are through with up2.convT's pieces
         b3c_from_f32<16, U2_NC, S1_, IB>(lds + A_SKIP1, P2, 3, tid, NTH);
         __syncthreads();  // skip 1 rests in the image: its fp32 rows give way to up2.same's output (pieces, U3T_QU)
@@ -1829,6 +1865,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
       b3c_from_f32<16, U2_NC, S1_, IB>(lds + A_SKIP1, P2, 3, tid, NTH);
       __syncthreads();
       b3c_mac_tiles_acc<16, U2_NC, 7, 6>(bp, aw, acc);
+      if constexpr (U3T) u3_load_operands();
       {
         const int co0 = 4 * (lane >> 4);
         float biasv[4];
@@ -1865,39 +1902,31 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
     bf16_t* const RU = l16 + U3T_RING_OFF;
     const int g = lane >> 4, n = lane & 15, ph = g >> 1, quad = g & 1;
     auto ring_at = [](const int c) { return (c & 1) * U3T_PL + (c >> 1) * 8; };
+    // a producer's store of four channels of one column, all three pieces (+ the mirror entry behind the plane for columns 0 .. 7)
+    auto ring_store = [&](bf16_t* const chunk, const int col, const int q, const float (&v)[4]) {
+      const unsigned h0 = pack_bf16x2(v[0], v[1]), h1 = pack_bf16x2(v[2], v[3]);
+      const float r0 = v[0] - bf16_lo(h0), r1 = v[1] - bf16_hi(h0), r2 = v[2] - bf16_lo(h1), r3 = v[3] - bf16_hi(h1);
+      const unsigned m0 = pack_bf16x2(r0, r1), m1 = pack_bf16x2(r2, r3);
+      const unsigned l0 = pack_bf16x2(r0 - bf16_lo(m0), r1 - bf16_hi(m0)), l1 = pack_bf16x2(r2 - bf16_lo(m1), r3 - bf16_hi(m1));
+      bf16_t* const p = chunk + ring_at(col) + 4 * q;
+      *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(p + U3T_PS) = make_uint2(m0, m1);
+      *reinterpret_cast<uint2*>(p + 2 * U3T_PS) = make_uint2(l0, l1);
+      if (col < 2 * U3T_MIR) {
+        *reinterpret_cast<uint2*>(p + U3T_PLN * 8) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(p + U3T_PLN * 8 + U3T_PS) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(p + U3T_PLN * 8 + 2 * U3T_PS) = make_uint2(l0, l1);
+      }
+    };
     WIN_STAMP(23)
     const bool producer = wave >= 8;  // (uniform)
     const int wv = wave & 7;
-    // operands: the consumer's 48 registers (four K-steps x three pieces), the producer's 12
-    uint4 aw[B3Steps<16, 8>::STEPS * 3];
-    f32x4 bv;
-    float w1[3][4], b1[3];  // consumer: its four channels' columns of the 1 x 1 conv
-    const int pl = tid - 512;                       // producer lane 0 .. 511
-    const int sk_q = pl & 1, sk_s = pl >> 1;        // skip tensor: channel quad, sample within the tile
-    const float* const sk_src = a.skip0 + (long)win * a.ws_s + HALO + (long)(4 * sk_q) * a.ls_s;
-    float sk[4] = {0.f, 0.f, 0.f, 0.f};
-    auto fetch_skip = [&](const int j) {  // samples 256 j - 2 + sk_s of channels 4 sk_q ..
-      const int ts = U3T_TS * j - 2 + sk_s;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sk[r] = (unsigned)ts < (unsigned)T0 ? sk_src[(long)r * a.ls_s + ts] : 0.f;
-    };
-    if (producer) {
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc) aw[pc] = a.af3_u3t[(long)(wv & 1) * (3 * 64) + pc * 64 + lane];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[r] = a.bs_u3t[4 * quad + r];
-      fetch_skip(0);
-    } else {
-      b3_load_a<16, 8>(a.af3_u3s, 0, lane, aw);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[r] = a.bs_u3s[4 * quad + r];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        b1[c] = a.b_out[c];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w1[c][r] = a.w_out[c * 8 + 4 * quad + r];
-      }
-    }
+    auto& aw = u3_aw;  // requested under up2.same (above)
+    const f32x4 bv = u3_bv;
+    auto& w1 = u3_w1;
+    auto& b1 = u3_b1;
+    auto& sk = u3_sk;
+    const int sk_q = u3_skq, sk_s = u3_sks;
     if (tid < 96) {  // ring columns 512 .. 527 <-> samples -16 .. -1 of both chunks: zeros
       const int cp = tid >> 4, c = U3T_RING - 16 + (tid & 15);  // cp = piece * 2 + chunk
       *reinterpret_cast<uint4*>(RU + (cp >> 1) * U3T_PS + (cp & 1) * U3T_CH + ring_at(c)) = make_uint4(0u, 0u, 0u, 0u);
@@ -1931,8 +1960,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
           U3T_MFMA(acc, aw[0], b[1]);
           U3T_MFMA(acc, aw[0], b[0]);
           // the skip quad fetched a phase ago -> pieces, chunk 0
-          b3_store4(RU + ring_at(cs), U3T_PS, 0, 0, 4 * sk_q, sk);
-          if (j + 1 < U3T_TILES) fetch_skip(j + 1);
+          ring_store(RU, cs, sk_q, sk);
+          if (j + 1 < U3T_TILES) u3_fetch_skip(j + 1, U3T_TS * (j + 2) > T0);
           float o[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = fmaxf(acc[r], 0.f);
@@ -1941,7 +1970,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = (unsigned)s < (unsigned)T0 ? o[r] : 0.f;
           }
-          b3_store4(RU + U3T_CH + ring_at(ct), U3T_PS, 0, 0, 4 * quad, o);
+          ring_store(RU + U3T_CH, ct, quad, o);
           ct += U3T_TS, cs += U3T_TS;
           ct = ct >= U3T_RING ? ct - U3T_RING : ct;
           cs = cs >= U3T_RING ? cs - U3T_RING : cs;
@@ -1949,11 +1978,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
         }
       } else if (j > 0) {
         f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = bv;
-        int c = cc;
+        const bf16_t* const rp0 = RU + quad * U3T_CH + ring_at(cc);  // K-step st: two columns = one plane entry further (mirrored: no wrap)
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
           uint4 b[3];
-          const bf16_t* rp = RU + quad * U3T_CH + ring_at(c);
+          const bf16_t* rp = rp0 + st * 8;
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc) b[pc] = *reinterpret_cast<const uint4*>(rp + pc * U3T_PS);
           U3T_MFMA(sa, aw[st * 3 + 2], b[0]);
@@ -1962,8 +1991,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
           U3T_MFMA(sb, aw[st * 3 + 0], b[1]);
           U3T_MFMA(sa, aw[st * 3 + 0], b[2]);
           U3T_MFMA(sb, aw[st * 3 + 0], b[0]);
-          c += 2;
-          c = c >= U3T_RING ? c - U3T_RING : c;
         }
         // BN + ReLU -> Conv1d(8, 3, 1): this lane's four channels, the other four from the lane 16 further (the other channel quad)
         float z[3];
