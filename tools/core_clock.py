@@ -49,14 +49,18 @@ print("workgroup starts after the first (us): median %.2f  p90 %.2f  max %.2f;  
       % (np.median(t_s), np.percentile(t_s, 90), t_s.max(), t_e.min(), np.median(t_e), t_e.max(), wall.min() * 1e6, wall.max() * 1e6))
 if n_steps == 1:  # whole-network kernel: slot 1 - slot 0 is the level-0 down phase; 18..22 and 23..28 detail the two level-0 phases
     dphase = np.diff(clk[:, 18:23].astype(np.int64), axis=1)
-    print("level-0 down phase median cycles: load x %d  inc %d  down0.same (two passes) %d  down0.down (MFMA) %d" % tuple(np.median(dphase, axis=0)))
+    print("level-0 down phase median cycles: load x %d  inc (tiled form: its first phase) %d  down0.same (tiled form: the other phases of inc + down0.same, skip stores) %d  down0.down (MFMA) %d" % tuple(np.median(dphase, axis=0)))
     sub = clk[:, [18, 29, 30, 31, 19]].astype(np.int64)
     if (sub[:, 1:4] > 0).all():
         print("load x in detail (wave 0's stamps): window read + partial reductions %d  barrier + 3-lane finish + barrier %d  "
               "normalise + store x image %d  closing barrier %d" % tuple(np.median(np.diff(sub, axis=1), axis=0)))
-    uphase = np.diff(clk[:, 23:29].astype(np.int64), axis=1)
-    print("level-0 up phase median cycles: load skip rows %d  up3.same(skip) %d  up3.convT (MFMA) %d  up3.same(convT) %d  1x1+softmax+store %d"
-          % tuple(np.median(uphase, axis=0)))
+    if (clk[:, 25] == 0).all():  # U3T form: stamps 23 (start), 24 (operands there, ring zeroed), 28 (last tile stored)
+        print("level-0 up phase (tiled, bf16 matrix cores) median cycles: prepare %d  thirteen phases of 256 samples %d"
+              % (np.median(clk[:, 24].astype(np.int64) - clk[:, 23].astype(np.int64)), np.median(clk[:, 28].astype(np.int64) - clk[:, 24].astype(np.int64))))
+    else:
+        uphase = np.diff(clk[:, 23:29].astype(np.int64), axis=1)
+        print("level-0 up phase median cycles: load skip rows %d  up3.same(skip) %d  up3.convT (MFMA) %d  up3.same(convT) %d  1x1+softmax+store %d"
+              % tuple(np.median(uphase, axis=0)))
     whole = (clk[:, 28] - clk[:, 0]).astype(np.float64)
     print("whole window median cycles %d (down %d, core %d, up %d)" % (np.median(whole), np.median(clk[:, 1] - clk[:, 0]),
           np.median(clk[:, 14] - clk[:, 1]), np.median(clk[:, 28] - clk[:, 14])))
