@@ -1776,8 +1776,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
   // the read-back of the skip tensor costs the up phase nothing (it was 8 k cycles of exposed memory latency).
   constexpr int NSKQ = (8 * W0_Q + 511) / 512;
   // U3T: the operands of the up path (the consumer waves' 48 registers of up3.same, the producer waves' 12 of up3.convT, the
-  // 1 x 1 head, the first skip quads) are requested under up2.same: by waves 8-15 at its start (they only convert and wait
-  // there), by waves 0-7 behind their last MFMA
+  // 1 x 1 head, the first skip quads) are requested under up2.same, behind every wave's last MFMA of it
   [[maybe_unused]] uint4 u3_aw[B3Steps<16, 8>::STEPS * 3];
   [[maybe_unused]] f32x4 u3_bv;
   [[maybe_unused]] float u3_w1[3][4], u3_b1[3], u3_sk[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1811,22 +1810,39 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
   {
     RangeStoreS<S1_, IB> st{{lds + XU_U, T1}};
     if constexpr (!U2B) zero_halo<16, S1_, T1, IB>(lds + XU_U, tid, NTH);
-    if (U3T && wave >= 8) {
-      if constexpr (U3T) {  // the skip tensor comes back tile by tile in the up phase; its first quads and the operands start now
-        u3_load_operands();
-        __syncthreads();  // waves 0-7 are through with up2.convT's pieces
-        b3c_from_f32<16, U2_NC, S1_, IB>(lds + A_SKIP1, P2, 3, tid, NTH);
-        __syncthreads();  // skip 1 rests in the image: its fp32 rows give way to up2.same's output (pieces, U3T_QU)
-        {  // the columns of that image no sample owns: column 0 (sample -1) and 752 .. 767
-          bf16_t* const UP = reinterpret_cast<bf16_t*>(lds);
-          const int i = tid - 512;
-          if (i < 3 * 2 * (U3T_NCU - T1)) {
-            const int cp = i / (U3T_NCU - T1), k = i - cp * (U3T_NCU - T1), col = k == 0 ? 0 : T1 + k;
-            *reinterpret_cast<uint4*>(UP + (cp >> 1) * U3T_QU::PS + (cp & 1) * U3T_QU::CHS + col * 8) = make_uint4(0u, 0u, 0u, 0u);
-          }
+    if constexpr (U3T) {
+      // U3T: nobody fetches skip rows here, so ALL sixteen waves share up2.same: wave w takes n-tiles 3 w .. 3 w + 2 (the matrix
+      // time per SIMD is the same; four waves per SIMD instead of two hide each other's fragment reads and epilogues)
+      bf16_t* const UP = reinterpret_cast<bf16_t*>(lds);
+      const bf16_t* bp = b3c_lane_ptr<16, U2_NC, 7>(P2, wave * 48, lane);
+      f32x4 acc[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      uint4 aw[B3Steps<16, 7>::STEPS * 3];
+      b3_load_a<16, 7>(a.af3_u2[1], 0, lane, aw);
+      b3c_mac_tiles_acc<16, U2_NC, 7, 3>(bp, aw, acc);
+      b3_load_a<16, 7>(a.af3_u2[0], 0, lane, aw);  // on its way under the refill
+      __syncthreads();
+      b3c_from_f32<16, U2_NC, S1_, IB>(lds + A_SKIP1, P2, 3, tid, NTH);
+      __syncthreads();  // skip 1 rests in the image: its fp32 rows give way to up2.same's output (pieces, U3T_QU)
+      if (tid < 3 * 2) *reinterpret_cast<uint4*>(UP + (tid >> 1) * U3T_QU::PS + (tid & 1) * U3T_QU::CHS) = make_uint4(0u, 0u, 0u, 0u);  // column 0 = sample -1
+      b3c_mac_tiles_acc<16, U2_NC, 7, 3>(bp, aw, acc);
+      u3_load_operands();
+      {
+        const int co0 = 4 * (lane >> 4);
+        float biasv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) biasv[r] = a.c.bs[12][co0 + r];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {  // pieces, sample t at column t + 1 (zeros behind the signal: columns 752 .. 767)
+          const int t = wave * 48 + j * 16 + (lane & 15);
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = t < T1 ? fmaxf(acc[j][r] + biasv[r], 0.f) : 0.f;
+          if (t + 1 < U3T_NCU) b3c_store4<16, U3T_NCU>(UP, t + 1, co0 >> 2, v);
         }
-        __syncthreads();
       }
+      __syncthreads();
     } else if (wave >= 8) {
       float4 skq[NSKQ];
       const float* src = a.skip0 + (long)win * a.ws_s;
@@ -1865,7 +1881,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
       b3c_from_f32<16, U2_NC, S1_, IB>(lds + A_SKIP1, P2, 3, tid, NTH);
       __syncthreads();
       b3c_mac_tiles_acc<16, U2_NC, 7, 6>(bp, aw, acc);
-      if constexpr (U3T) u3_load_operands();
       {
         const int co0 = 4 * (lane >> 4);
         float biasv[4];
@@ -1874,15 +1889,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
           const int t = wave * 96 + j * 16 + (lane & 15);
-          if constexpr (U3T) {  // pieces, sample t at column t + 1 (zeros behind the signal)
-            float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = t < T1 ? fmaxf(acc[j][r] + biasv[r], 0.f) : 0.f;
-            if (t + 1 < U3T_NCU) b3c_store4<16, U3T_NCU>(reinterpret_cast<bf16_t*>(lds), t + 1, co0 >> 2, v);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) st(co0 + r, t, C_u2same::RELU ? fmaxf(acc[j][r] + biasv[r], 0.f) : acc[j][r] + biasv[r]);
-          }
+          for (int r = 0; r < 4; ++r) st(co0 + r, t, C_u2same::RELU ? fmaxf(acc[j][r] + biasv[r], 0.f) : acc[j][r] + biasv[r]);
         }
       }
       __syncthreads();
