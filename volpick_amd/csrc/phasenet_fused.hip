@@ -2012,7 +2012,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
         }
         const float mx = fmaxf(z[0], fmaxf(z[1], z[2]));
         const float e0 = __expf(z[0] - mx), e1 = __expf(z[1] - mx), e2 = __expf(z[2] - mx);
-        const float inv = 1.f / (e0 + e1 + e2);
+        const float inv = __builtin_amdgcn_rcpf(e0 + e1 + e2);  // (1 ulp; the IEEE division is ten instructions on this issue-bound path)
         float y0 = e0 * inv, y1 = e1 * inv, y2 = e2 * inv;
         if (poisoned) y0 = y1 = y2 = __builtin_nanf("");
         const int t = U3T_TS * (j - 1) - 8 + 32 * wv + 2 * n + ph;
