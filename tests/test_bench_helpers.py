@@ -152,3 +152,17 @@ def test_emit_prints_exactly_one_stdout_line_and_writes_the_detail(tmp_path, cap
     assert cap.err.startswith("bench.py detail: {")
     det = json.loads((tmp_path / "d" / "bench_detail.json").read_text())
     assert det["forward"]["kernels"] and det["eqtransformer"]["forward"]["kernels"]
+
+
+def test_compact_line_sheds_optional_objects_rather_than_fail(monkeypatch):
+    """If an object ever outgrows the limit again, the line drops optional parts (they stay in the detail file) and keeps the
+    contract's keys, `roofline` and `cpu_baseline`."""
+    import json
+
+    full = json.loads((Path(__file__).resolve().parents[1] / "profiles" / "r04_b_bench.json").read_text())
+    monkeypatch.setattr(bench, "COMPACT_LIMIT", 2000)
+    d = json.loads(bench.compact_line(full, "bench_detail.json"))
+    assert len(json.dumps(d, separators=(",", ":"))) < 2000 and d["line_shrunk"] >= 1
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert "api" not in d and "mseed" not in d
