@@ -140,7 +140,7 @@ def compact_line(result, detail_path=None):
         out["eqtransformer"] = _compact_model(result["eqtransformer"])
     tr = result.get("train")
     if isinstance(tr, dict):
-        out["train"] = _pick(tr, "value", "unit", "ms_per_step", "batch", "dtype", "launches_per_step", "loss_after",
+        out["train"] = _pick(tr, "value", "unit", "ms_per_step", "batch", "dtype", "launches_per_step", "settle_steps", "loss_after",
                              "loss_torch_same_batch", "vs_torch_rocm", "error")
         if isinstance(tr.get("roofline"), dict):
             out["train"]["roofline"] = _pick(tr["roofline"], "bound", "achieved", "peak", "unit", "frac")
@@ -555,6 +555,14 @@ def bench_train(batch=512, steps=30, warmup=5, torch_steps=6, torch_baseline=Tru
     for _ in range(warmup):
         tr.step(xd, yd, 1e-4, want_loss=False)
     tr.synchronize()
+    # untimed steps until the clock has settled, as for the forward regions (this leg starts behind ~25 s of CPU baseline legs
+    # with the GPU idle: its first ~150 steps ran 15 % slower than tools/train_probe.py's steady 1.65-1.68 ms)
+    settle_steps, t_settle = 0, time.perf_counter()
+    while time.perf_counter() - t_settle < 0.4:
+        for _ in range(steps):
+            tr.step(xd, yd, 1e-4, want_loss=False)
+        tr.synchronize()
+        settle_steps += steps
     times = []
     for _ in range(5):
         t0 = time.perf_counter()
@@ -589,6 +597,7 @@ def bench_train(batch=512, steps=30, warmup=5, torch_steps=6, torch_baseline=Tru
     out = {
         "metric": "PhaseNet training windows/sec (fwd + loss + bwd + Adam)", "value": batch / dt, "unit": "windows/s",
         "ms_per_step": dt * 1e3, "ms_per_step_all": [t * 1e3 for t in times], "batch": batch, "steps": steps, "warmup": warmup,
+        "settle_steps": settle_steps,
         "dtype": "bf16 storage / f32 accumulate", "data": "synthetic (VCSEIS-shaped: 3 x 3001, Gaussian P/S labels sigma 20)",
         "launches_per_step": launches, "launches_without_update": launches_fwd_bwd, "loss_after": loss,
         "loss_torch_same_batch": loss_torch,
