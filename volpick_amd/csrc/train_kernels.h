@@ -519,31 +519,37 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const T* __restrict__ par
 }
 
 // All weight-gradient partials of a step folded in ONE launch: job j sums `rows` rows of `n` floats into `out`.
+// A block owns 4 * cq columns and walks the rows with 256 / cq row lanes: cq = 32 (128 columns, 8 row lanes) for the wide
+// jobs of the deep layers (57 k columns x 32 rows), cq = 4 (16 columns, 64 row lanes) for the level-0 layers, whose few
+// hundred columns x 512 rows left seven blocks walking 64 rows each behind one another (68 us for the launch; the
+// memory round trips of those seven blocks, not bytes).
 struct SumJob {
   const float* partial;
   float* out;
-  int rows, n, first_block;  // blocks [first_block, next job's first_block) own SUM_COLS columns each
+  int rows, n, first_block, cq;  // blocks [first_block, next job's first_block) own 4 * cq columns each
 };
 constexpr int MAX_SUM_JOBS = 24;
 struct SumJobs {
   SumJob job[MAX_SUM_JOBS];
   int count;
 };
-constexpr int SUM_COLS = 128;  // columns per block: 32 lanes x 16 bytes
+__host__ __device__ constexpr int sum_job_cq(int rows) { return rows > 100000 ? 4 : 32; }  // the 16-column form measured slower for every job of the step (bytes, not round trips, bound the launch)
 __global__ __launch_bounds__(256) void sum_rows_multi_kernel(const SumJobs jobs) {
-  __shared__ double sh[8][SUM_COLS + 4];
+  __shared__ double sh[1024 + 256];
   int j = 0;
   while (j + 1 < jobs.count && (int)blockIdx.x >= jobs.job[j + 1].first_block) ++j;
   const SumJob jb = jobs.job[j];
-  const int cl = 4 * (threadIdx.x & 31), col = ((int)blockIdx.x - jb.first_block) * SUM_COLS + cl, rl = threadIdx.x >> 5;
+  const int cq = jb.cq, W = 4 * cq, RL = 256 / cq;
+  const int ql = (int)threadIdx.x % cq, rl = (int)threadIdx.x / cq;
+  const int col = ((int)blockIdx.x - jb.first_block) * W + 4 * ql;
   double s[4] = {0.0, 0.0, 0.0, 0.0};
   if (col < jb.n) {  // n is a multiple of 4: a quad is inside or outside
     const float* p = jb.partial + col;
     int g = rl;
-    for (; g + 24 < jb.rows; g += 32) {  // four 16-byte loads in flight
+    for (; g + 3 * RL < jb.rows; g += 4 * RL) {  // four 16-byte loads in flight
       float4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(g + 8 * u) * jb.n);
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(g + RL * u) * jb.n);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         s[0] += (double)v[u].x;
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(256) void sum_rows_multi_kernel(const SumJobs jobs)
         s[3] += (double)v[u].w;
       }
     }
-    for (; g < jb.rows; g += 8) {
+    for (; g < jb.rows; g += RL) {
       const float4 v = *reinterpret_cast<const float4*>(p + (long)g * jb.n);
       s[0] += (double)v.x;
       s[1] += (double)v.y;
@@ -561,19 +567,24 @@ __global__ __launch_bounds__(256) void sum_rows_multi_kernel(const SumJobs jobs)
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) sh[rl][cl + i] = s[i];
+  for (int i = 0; i < 4; ++i) sh[rl * W + 4 * ql + i] = s[i];
   __syncthreads();
-  if (rl == 0 && col < jb.n) {
-    float4 o;
-    float* op = &o.x;
+  // fixed order: 256 / W groups of four row lanes, then the groups
+  const int c = (int)threadIdx.x % W, part = (int)threadIdx.x / W, P = 256 / W;  // RL / P = 4 row lanes per part
+  {
+    double t = 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int k = 0; k < 4; ++k) t += sh[(part * 4 + k) * W + c];
+    sh[1024 + part * W + c] = t;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < W) {
+    const int oc = ((int)blockIdx.x - jb.first_block) * W + c;
+    if (oc < jb.n) {
       double t = 0.0;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) t += sh[k][cl + i];
-      op[i] = (float)t;
+      for (int k = 0; k < P; ++k) t += sh[1024 + k * W + c];
+      jb.out[oc] = (float)t;
     }
-    *reinterpret_cast<float4*>(jb.out + col) = o;
   }
 }
 

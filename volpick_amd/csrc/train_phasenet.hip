@@ -10,6 +10,8 @@
 // inference packers); weight gradients on wgrad_kernel; everything else in train_kernels.h.
 // ConvTranspose outputs are kept at full length (4 L + 3): BatchNorm sees the samples the U-Net
 // crops away, and they receive gradient through the batch statistics.
+#include <hip/hip_ext.h>
+
 #include <memory>
 
 #include "conv_mfma.h"
@@ -527,7 +529,7 @@ int upload(Trainer& tr, const float* weights) {
   size_t wtot = 0;
   for (Layer& L : tr.layers) {
     L.wg.partial_off = wtot;
-    wtot += (size_t)(L.wg.out_n > 10000 ? 256 : 512) * (size_t)L.wg.out_n;
+    wtot += (size_t)512 * (size_t)L.wg.out_n;
   }
   tr.wg_partial_floats = wtot;
   TR_HIP(hipMalloc(&tr.wg_partial, wtot * sizeof(float)));
@@ -551,8 +553,11 @@ int upload(Trainer& tr, const float* weights) {
   TR_HIP(hipDeviceSynchronize());
   TR_HIP(hipStreamCreateWithFlags(&tr.stream, hipStreamNonBlocking));
   TR_HIP(hipStreamCreateWithFlags(&tr.stream_wg, hipStreamNonBlocking));
-  for (int i = 0; i < NLAYER; ++i) TR_HIP(hipEventCreateWithFlags(&tr.ev_gz[i], hipEventDisableTiming));
-  TR_HIP(hipEventCreateWithFlags(&tr.ev_wg, hipEventDisableTiming));
+  // consumed by another stream of this device only: a device-scope release at the event is enough (the default release
+  // to the system writes the L2 back: ~5 us in front of the stream's next launch, once per layer)
+  const unsigned ev_dev = hipEventDisableTiming | hipEventReleaseToDevice;
+  for (int i = 0; i < NLAYER; ++i) TR_HIP(hipEventCreateWithFlags(&tr.ev_gz[i], ev_dev));
+  TR_HIP(hipEventCreateWithFlags(&tr.ev_wg, ev_dev));
   TR_HIP(hipEventCreateWithFlags(&tr.ev_inputs, hipEventDisableTiming));
   return VP_OK;
 }
@@ -628,6 +633,20 @@ BnArgs bn_args(Trainer& tr, const BnOp& b, int B) {
       TRL((KERNEL<T, 2>), GRID, dim3(NTH), 0, s, a);                     \
     }                                                                                  \
   } while (0)
+// the same with an event bound to the launch's own completion (hipExtLaunchKernel's stop event): what another stream
+// waits for is this kernel's end, without the marker packet a hipEventRecord puts into the queue (6-8 us in front of the
+// next launch of this stream, eighteen times per step)
+#define BN_CROP_LAUNCH_EV(KERNEL, GRID, NTH, EV)                                                         \
+  do {                                                                                                   \
+    ++g_launches;                                                                                        \
+    if (a.crop == 0) {                                                                                   \
+      hipExtLaunchKernelGGL((KERNEL<T, 0>), GRID, dim3(NTH), 0, s, nullptr, EV, 0, a);                   \
+    } else if (a.crop == 1) {                                                                            \
+      hipExtLaunchKernelGGL((KERNEL<T, 1>), GRID, dim3(NTH), 0, s, nullptr, EV, 0, a);                   \
+    } else {                                                                                             \
+      hipExtLaunchKernelGGL((KERNEL<T, 2>), GRID, dim3(NTH), 0, s, nullptr, EV, 0, a);                   \
+    }                                                                                                    \
+  } while (0)
 template <class T>
 void bn_forward_v(const BnArgs& a, hipStream_t s) {
   const dim3 grid(a.C, a.GB);
@@ -635,12 +654,24 @@ void bn_forward_v(const BnArgs& a, hipStream_t s) {
   BN_CROP_LAUNCH(bnv_apply_kernel, grid, 256);
 }
 template <class T>
-void bn_backward_v(const BnArgs& a, hipStream_t s) {
+void bn_backward_v(const BnArgs& a, hipStream_t s, hipEvent_t gz_done) {
   const dim3 grid(a.C, a.GB);
   BN_CROP_LAUNCH(bnv_bwd_partial_kernel, grid, 256);
-  BN_CROP_LAUNCH(bnv_bwd_apply_kernel, grid, 256);
+  BN_CROP_LAUNCH_EV(bnv_bwd_apply_kernel, grid, 256, gz_done);
 }
 #undef BN_CROP_LAUNCH
+#undef BN_CROP_LAUNCH_EV
+
+// Partial results of a weight gradient: one row of out_n floats per workgroup, folded by sum_rows_multi_kernel.  With 256
+// rows for every tensor of > 10 k weights the rows were 267 MB per step -- written by the weight-gradient launches, read
+// again by the fold (68 us, on the step's critical path) -- for 1.1 MB of gradients: the rows are capped by their bytes.
+static int wg_rows_cap(int out_n) {
+  constexpr long budget = 1L << 22;  // same-box sweep: 1.64 ms per step unbounded, 1.60 at 8 M floats, 1.57 at 4-6 M, 1.60 at 2-3 M
+                                     // (below that the deep layers' launches have too few workgroups and end behind the main chain)
+  int cap = out_n > 10000 ? 256 : 512;
+  while (cap > 32 && (long)cap * out_n > budget) cap >>= 1;
+  return cap;
+}
 
 int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B, bool update, float lr) {
   hipStream_t s = tr.stream;
@@ -676,12 +707,13 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     int gx = (T0 + 255) / 256;
     if (tr.bf16) {
       gx = (T0 + 511) / 512;
-      TRL(head_fwd_bwd_pair_kernel<bf16_t>, dim3(gx, B), dim3(256), 0, s, h);
+      ++g_launches;
+      hipExtLaunchKernelGGL(head_fwd_bwd_pair_kernel<bf16_t>, dim3(gx, B), dim3(256), 0, s, nullptr, tr.ev_inputs, 0, h);
     } else {
-      TRL(head_fwd_bwd_kernel, dim3(gx, B), dim3(256), 0, s, h);
+      ++g_launches;
+      hipExtLaunchKernelGGL(head_fwd_bwd_kernel, dim3(gx, B), dim3(256), 0, s, nullptr, tr.ev_inputs, 0, h);
     }
-    // load_rows above read x, this launch read y: nothing behind this point touches the caller's buffers
-    (void)hipEventRecord(tr.ev_inputs, s);
+    // load_rows above read x, this launch read y: nothing behind its end (ev_inputs) touches the caller's buffers
     // two stages: 64 row groups, then the 64 group sums
     TRL((sum_rows_kernel<double, double>), dim3(1, 64), dim3(256), 0, s, tr.head_partial, gx * B, 28,
                        tr.head_stage);
@@ -692,14 +724,20 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
   }
   SumJobs jobs{};
   int sum_blocks = 0;
+  // Layers whose gz gets an event for the weight-gradient stream; the layers between hand their launch to the next event.
+  // An event costs the main chain ~5 us (the launch behind a kernel with a completion signal starts that much later):
+  // every other layer above level 0, every layer of the last four (their weight gradients are the step's tail).
+  constexpr unsigned ev_mask = 0x2aaaf;
+  struct { const WgradOp* w; WgradArgs g; int grid; } held[NLAYER];
+  int n_held = 0;
   static_assert(NLAYER <= MAX_SUM_JOBS, "one sum job per layer");
   for (int li = NLAYER - 1; li >= 0; --li) {
     Layer& L = tr.layers[li];
     const BnArgs a = bn_args(tr, L.bn, B);
     if (tr.bf16) {
-      bn_backward_v<bf16_t>(a, s);
+      bn_backward_v<bf16_t>(a, s, ((ev_mask >> li) & 1) ? tr.ev_gz[li] : nullptr);  // the event: gz of this layer is complete
     } else {
-      bn_backward_v<float>(a, s);
+      bn_backward_v<float>(a, s, ((ev_mask >> li) & 1) ? tr.ev_gz[li] : nullptr);
     }
     {
       const WgradOp& w = L.wg;
@@ -717,19 +755,25 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
       g.chunks = (w.Ln + w.TT - 1) / w.TT;
       g.partial = tr.wg_partial + w.partial_off;
       const int items = ((B + w.WB - 1) / w.WB) * g.chunks;
-      const int cap = w.out_n > 10000 ? 256 : 512;  // one partial result per workgroup: fewer, longer-lived workgroups for the big weight tensors
+      const int cap = wg_rows_cap(w.out_n);  // one partial result per workgroup: fewer, longer-lived workgroups for the big weight tensors
       const int grid = items < cap ? items : cap;
       ++g_launches;
-      (void)hipEventRecord(tr.ev_gz[li], s);  // gz of this layer is complete (bn_backward_v above)
-      (void)hipStreamWaitEvent(tr.stream_wg, tr.ev_gz[li], 0);
-      w.launch(g, grid, tr.stream_wg);
+      held[n_held].w = &w;
+      held[n_held].g = g;
+      held[n_held++].grid = grid;
+      if ((ev_mask >> li) & 1) {
+        (void)hipStreamWaitEvent(tr.stream_wg, tr.ev_gz[li], 0);
+        for (int k = 0; k < n_held; ++k) held[k].w->launch(held[k].g, held[k].grid, tr.stream_wg);
+        n_held = 0;
+      }
       SumJob& jb = jobs.job[jobs.count++];
       jb.partial = g.partial;
       jb.out = tr.grad + w.grad_off;
       jb.rows = grid;
       jb.n = w.out_n;
       jb.first_block = sum_blocks;
-      sum_blocks += (w.out_n + SUM_COLS - 1) / SUM_COLS;
+      jb.cq = sum_job_cq(grid);
+      sum_blocks += (w.out_n + 4 * jb.cq - 1) / (4 * jb.cq);
     }
     if (li == 0) {  // conv bias of `inc`: sum of gz per channel (zero up to rounding: BatchNorm removes the mean)
       const int GB = B < 64 ? B : 64;
