@@ -72,9 +72,11 @@ typedef struct {
                                       4 = one launch with up1.same and up2.same on the fp32 MFMA, 5 = with up2.same only,
                                       6 = with up1.convT and up2.convT on the fp32 MFMA, 7 = with down1.same and down2.same
                                       on the fp32 MFMA, 8 = with inc and down0.same as packed-FMA direct convolutions on
-                                      the vector ALUs (default: all of these on the bf16 matrix cores too -- up1.same /
+                                      the vector ALUs, 9 = with up3.convT on the fp32 MFMA and up3.same + head on the
+                                      vector ALUs (default: all of these on the bf16 matrix cores too -- up1.same /
                                       up2.same in two K halves over one piece image that is refilled in between, inc /
-                                      down0.same time-tiled, six tiles of 512 samples);
+                                      down0.same time-tiled in six tiles of 512 samples, up3.convT / up3.same / head in
+                                      twelve tiles of 256 with producer and consumer waves);
                                  [6]: PhaseNet: 1 = the one-launch plan reads the input tensor filled by gather_normalize
                                       instead of cutting and normalising its windows itself; EQTransformer: 2 = the fused
                                       encoder front cuts and normalises its windows itself (A/B: slower end to end);
