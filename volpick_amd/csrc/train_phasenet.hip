@@ -551,8 +551,16 @@ int upload(Trainer& tr, const float* weights) {
   // predecessor on the device -- 2.75 instead of 1.72 ms per 512-window step (tools/train_probe.py).  The uploads above ran
   // on the default stream: they are complete before the first step can be enqueued.
   TR_HIP(hipDeviceSynchronize());
-  TR_HIP(hipStreamCreateWithFlags(&tr.stream, hipStreamNonBlocking));
-  TR_HIP(hipStreamCreateWithFlags(&tr.stream_wg, hipStreamNonBlocking));
+  // The weight gradients' stream gets the LOWEST priority, the main chain the default one: streams of different priority
+  // never share a hardware queue (two default-priority streams created after other streams of the process had been
+  // destroyed did: the step ran 1.96 instead of 1.56 ms, its two chains serialised -- tools/train_after_forward_probe.py),
+  // and where both have workgroups waiting the chain the step's length hangs on goes first.
+  {
+    int pr_least = 0, pr_greatest = 0;
+    TR_HIP(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+    TR_HIP(hipStreamCreateWithFlags(&tr.stream, hipStreamNonBlocking));
+    TR_HIP(hipStreamCreateWithPriority(&tr.stream_wg, hipStreamNonBlocking, pr_least));  // (main chain at the highest: the same)
+  }
   // consumed by another stream of this device only: a device-scope release at the event is enough (the default release
   // to the system writes the L2 back: ~5 us in front of the stream's next launch, once per layer)
   const unsigned ev_dev = hipEventDisableTiming | hipEventReleaseToDevice;
