@@ -66,7 +66,11 @@ def test_end_to_end_against_autograd_with_the_same_rounding_points(step):
     loss32, *_ = torch_step(load_pretrained("phasenet"), x, y)
     assert abs(loss - want_loss) < 1e-3 * want_loss, (loss, want_loss)
     assert abs(loss - loss32) < 1e-2 * loss32, (loss, loss32)  # what the storage format itself costs: 2e-3 here
-    assert np.array_equal(t["inc.z"], z["inc"])  # the first conv sees identical inputs: identical bf16 values
+    # the first conv sees identical inputs: the same bf16 values, up to the few sums that land on a rounding boundary (the
+    # bf16-MFMA form adds its exact products in another order than torch's conv: one bf16 ulp there, nothing else)
+    diff = t["inc.z"] != z["inc"]
+    assert diff.mean() < 0.02, diff.mean()
+    assert np.all(np.abs(t["inc.z"] - z["inc"])[diff] <= 2.0 ** -7 * np.abs(z["inc"])[diff] + 1e-30)
     d = np.abs(pred - want_pred)
     assert np.median(d) < 1e-4 and np.percentile(d, 99) < 5e-3, (np.median(d), np.percentile(d, 99))
     for name in z:  # bulk agreement; single elements diverge (module docstring)

@@ -15,6 +15,7 @@
 #include <memory>
 
 #include "conv_mfma.h"
+#include "conv_train_b16.h"
 #include "train_kernels.h"
 
 namespace vp {
@@ -88,6 +89,9 @@ struct ConvOp {
   bool used = false;
   ConvGeom g{};
   int (*launch)(const ConvArgs&, int, hipStream_t) = nullptr;
+  // bf16 rows, filters of >= 7 taps: the bf16-MFMA form (conv_train_b16.h); its A operand is cut from the fp32 fragments
+  int (*launch_b16)(const ConvArgs&, const uint4*, int, hipStream_t) = nullptr;
+  size_t a3_n = 0, a3_off = 0;  // uint4 words of the operand / its place in Trainer::frag3
   const void* kernel = nullptr;
   size_t lds_bytes = 0;
   int src1 = -1, src2 = -1, dst = -1;
@@ -131,6 +135,10 @@ void set_conv(ConvOp* op, int src1, int src2, int dst, int cols, int l_out) {
   op->dst = dst;
   op->cols = cols;
   op->l_out = l_out;
+  if constexpr (Cfg::BF16 && Cfg::TAPS >= 7) {
+    op->launch_b16 = &launch_conv_b16<Cfg>;
+    op->a3_n = ConvB16<Cfg>::A_UINT4;
+  }
 }
 
 template <class Cfg, class T>
@@ -213,6 +221,9 @@ struct Trainer {
   float* stats = nullptr;
   double* bn_partial = nullptr;
   unsigned* bn_counter = nullptr;
+  uint4* frag3 = nullptr;  // three-piece A operands of the bf16-MFMA convs, cut from `frag` every step
+  ConvB16PackJobs b16_jobs{};
+  int b16_blocks = 0;
   float* wg_partial = nullptr;
   size_t wg_partial_floats = 0;
   double* head_partial = nullptr;
@@ -245,7 +256,7 @@ struct Trainer {
   }
   ~Trainer() {
     for (void* p : {(void*)arena, (void*)w, (void*)grad, (void*)adam_m, (void*)adam_v, (void*)mask, (void*)ema, (void*)frag_idx,
-                    (void*)frag, (void*)zeros, (void*)stats, (void*)bn_partial, (void*)bn_counter, (void*)wg_partial, (void*)head_partial,
+                    (void*)frag, (void*)zeros, (void*)stats, (void*)bn_partial, (void*)bn_counter, (void*)frag3, (void*)wg_partial, (void*)head_partial,
                     (void*)head_sums, (void*)head_stage, (void*)x_dev, (void*)y_dev, (void*)p_dev})
       if (p) (void)hipFree(p);
     if (stream) (void)hipStreamDestroy(stream);
@@ -517,6 +528,33 @@ int upload(Trainer& tr, const float* weights) {
   TR_HIP(hipMalloc(&tr.frag_idx, tr.frag_n * sizeof(int)));
   TR_HIP(hipMemcpy(tr.frag_idx, tr.frag_idx_host.data(), tr.frag_n * sizeof(int), hipMemcpyHostToDevice));
   TR_HIP(hipMalloc(&tr.frag, tr.frag_n * sizeof(float)));
+  {  // the bf16-MFMA convs' operands
+    size_t n3 = 0;
+    for (Layer& L : tr.layers)
+      for (ConvOp* op : {&L.fwd, &L.dgrad})
+        if (op->used && op->launch_b16) {
+          op->a3_off = n3;
+          n3 += op->a3_n;
+        }
+    if (n3) {
+      TR_HIP(hipMalloc(&tr.frag3, n3 * sizeof(uint4)));
+      for (Layer& L : tr.layers)
+        for (ConvOp* op : {&L.fwd, &L.dgrad})
+          if (op->used && op->launch_b16) {
+            if (tr.b16_jobs.count >= MAX_B16_JOBS) return VP_ERR_UNSUPPORTED;
+            ConvB16PackJob& jb = tr.b16_jobs.job[tr.b16_jobs.count++];
+            const int cb = op->g.cinp() / 4, tg = (op->g.taps + 7) / 8, mt = op->g.M() / 16;
+            jb.frag = tr.frag + op->frag_off;
+            jb.out = tr.frag3 + op->a3_off;
+            jb.MT = mt;
+            jb.CB = cb;
+            jb.TAPS = op->g.taps;
+            jb.TG = tg;
+            jb.first_block = tr.b16_blocks;
+            tr.b16_blocks += (mt * cb * tg + 3) / 4;
+          }
+    }
+  }
   TR_HIP(hipMalloc(&tr.zeros, 256 * sizeof(float)));
   TR_HIP(hipMemset(tr.zeros, 0, 256 * sizeof(float)));
   size_t ns = 0;
@@ -594,7 +632,12 @@ void run_conv(Trainer& tr, const ConvOp& op, int B) {
   a.n_windows = B;
   a.l_out = op.l_out;
   a.l_dst = op.l_out;
-  op.launch(a, op.cols, tr.stream);
+  static const bool b16 = [] { const char* e = getenv("VP_CONV_B16"); return !e || atoi(e) != 0; }();
+  if (op.launch_b16 && tr.frag3 && b16) {
+    op.launch_b16(a, tr.frag3 + op.a3_off, op.cols, tr.stream);
+  } else {
+    op.launch(a, op.cols, tr.stream);
+  }
 }
 
 BnArgs bn_args(Trainer& tr, const BnOp& b, int B) {
@@ -686,6 +729,7 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
   g_launches = 0;
   TRL(gather_pack_kernel, dim3((unsigned)((tr.frag_n + 255) / 256)), dim3(256), 0, s, tr.frag_idx, tr.w,
                      tr.frag, (long)tr.frag_n);
+  if (tr.b16_blocks) TRL(conv_b16_pack_kernel, dim3(tr.b16_blocks), dim3(256), 0, s, tr.b16_jobs);
   if (tr.bf16) {
     TRL(load_rows_bf16_kernel, dim3((T0 + 511) / 512, 3, B), dim3(256), 0, s, x_dev, tr.rows(tr.t_x), 3, T0);
   } else {
