@@ -383,6 +383,11 @@ int vp_train_synchronize(vp_trainer* t);
  * waits, on the device, for the point behind the step's last read of x / y -- so refilling or freeing them on `stream`
  * cannot overtake a queued step.  Host x / y are staged inside vp_train_step and need neither. */
 int vp_train_wait_inputs_consumed(vp_trainer* t, void* stream);
+/* The number (0 = this trainer's first vp_train_step) of the latest step whose reads of x / y are known to have completed,
+ * -1 if none: a caller that keeps device batches alive for queued steps may drop those of steps <= the result.  No host
+ * wait, nothing enters the trainer's stream (an event recorded there per step cost ~30 us of the step). */
+long long vp_train_inputs_consumed_upto(vp_trainer* t);
+long long vp_train_steps_enqueued(const vp_trainer* t);  /* the step a vp_train_step call just queued has the number (this - 1) */
 int vp_train_read(vp_trainer* t, int which, float* out, size_t n_floats);
 int vp_train_write_weights(vp_trainer* t, const float* weights, size_t n_floats);
 int vp_train_predictions(vp_trainer* t, float* out, int B);

@@ -184,6 +184,8 @@ SIGNATURES = {
     "vp_train_step": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(C.c_double)]),
     "vp_train_synchronize": (C.c_int, [_H]),
     "vp_train_wait_inputs_consumed": (C.c_int, [_H, C.c_void_p]),
+    "vp_train_inputs_consumed_upto": (C.c_longlong, [_H]),
+    "vp_train_steps_enqueued": (C.c_longlong, [_H]),
     "vp_train_read": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_size_t]),
     "vp_train_write_weights": (C.c_int, [_H, C.c_void_p, C.c_size_t]),
     "vp_train_predictions": (C.c_int, [_H, C.c_void_p, C.c_int]),

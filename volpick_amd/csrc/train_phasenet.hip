@@ -85,6 +85,14 @@ using W_u2s = WgradCfg<16, 16, 16, 7, 1, 8, 256>;
 using W_u3T = WgradCfg<16, 8, 0, 7, 4, 8, 256>;
 using W_u3s = WgradCfg<8, 8, 8, 7, 1, 8, 256>;
 
+// Where the bf16-MFMA form (conv_train_b16.h) loses to the fp32 one, same-box timeline of the step: the two up0.same-sized
+// layers whose 57 k weights stream per 48-column tile (six bytes per weight as pieces, four as fp32) and down2.same's input
+// gradient (15.5 vs 14.6 us).
+template <class Cfg> constexpr bool b16_loses = false;
+template <> constexpr bool b16_loses<F_u0s<1>> = true;  // 29.8 vs 28.7 us
+template <> constexpr bool b16_loses<G_u0s<1>> = true;  // 38.0 vs 31.3 us
+template <> constexpr bool b16_loses<G_d2s<1>> = true;
+
 struct ConvOp {
   bool used = false;
   ConvGeom g{};
@@ -135,7 +143,7 @@ void set_conv(ConvOp* op, int src1, int src2, int dst, int cols, int l_out) {
   op->dst = dst;
   op->cols = cols;
   op->l_out = l_out;
-  if constexpr (Cfg::BF16 && Cfg::TAPS >= 7) {
+  if constexpr (Cfg::BF16 && Cfg::TAPS >= 7 && !b16_loses<Cfg>) {
     op->launch_b16 = &launch_conv_b16<Cfg>;
     op->a3_n = ConvB16<Cfg>::A_UINT4;
   }
@@ -212,7 +220,12 @@ struct Trainer {
   float* adam_v = nullptr;
   float* mask = nullptr;
   float* ema = nullptr;     // EMA of the weights (allocated by vp_train_set_ema)
-  hipEvent_t ev_inputs = nullptr;  // behind the last reader of a step's x / y (the head kernel): vp_train_wait_inputs_consumed
+  // behind the last reader of a step's x / y (the head kernel), a ring over the steps in flight:
+  // vp_train_wait_inputs_consumed (the latest), vp_train_inputs_consumed_upto (which steps are past it)
+  static constexpr int EV_RING = 8;
+  hipEvent_t ev_inputs[EV_RING] = {};
+  long long ev_inputs_seq[EV_RING] = {-1, -1, -1, -1, -1, -1, -1, -1};
+  long long seq = 0;  // steps enqueued so far
   float ema_decay = 0.f;
   int* frag_idx = nullptr;
   float* frag = nullptr;
@@ -264,6 +277,8 @@ struct Trainer {
     for (hipEvent_t e : ev_gz)
       if (e) (void)hipEventDestroy(e);
     if (ev_wg) (void)hipEventDestroy(ev_wg);
+    for (hipEvent_t e : ev_inputs)
+      if (e) (void)hipEventDestroy(e);
   }
 };
 
@@ -604,7 +619,7 @@ int upload(Trainer& tr, const float* weights) {
   const unsigned ev_dev = hipEventDisableTiming | hipEventReleaseToDevice;
   for (int i = 0; i < NLAYER; ++i) TR_HIP(hipEventCreateWithFlags(&tr.ev_gz[i], ev_dev));
   TR_HIP(hipEventCreateWithFlags(&tr.ev_wg, ev_dev));
-  TR_HIP(hipEventCreateWithFlags(&tr.ev_inputs, hipEventDisableTiming));
+  for (hipEvent_t& e : tr.ev_inputs) TR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   return VP_OK;
 }
 
@@ -757,13 +772,16 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     h.T = T0;
     h.eps = tr.loss_eps;
     int gx = (T0 + 255) / 256;
+    const int slot = (int)(tr.seq % Trainer::EV_RING);
+    hipEvent_t ev_in = tr.ev_inputs[slot];
+    tr.ev_inputs_seq[slot] = tr.seq++;
     if (tr.bf16) {
       gx = (T0 + 511) / 512;
       ++g_launches;
-      hipExtLaunchKernelGGL(head_fwd_bwd_pair_kernel<bf16_t>, dim3(gx, B), dim3(256), 0, s, nullptr, tr.ev_inputs, 0, h);
+      hipExtLaunchKernelGGL(head_fwd_bwd_pair_kernel<bf16_t>, dim3(gx, B), dim3(256), 0, s, nullptr, ev_in, 0, h);
     } else {
       ++g_launches;
-      hipExtLaunchKernelGGL(head_fwd_bwd_kernel, dim3(gx, B), dim3(256), 0, s, nullptr, tr.ev_inputs, 0, h);
+      hipExtLaunchKernelGGL(head_fwd_bwd_kernel, dim3(gx, B), dim3(256), 0, s, nullptr, ev_in, 0, h);
     }
     // load_rows above read x, this launch read y: nothing behind its end (ev_inputs) touches the caller's buffers
     // two stages: 64 row groups, then the 64 group sums
@@ -774,8 +792,14 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     TRL(head_final_kernel, dim3(1), dim3(32), 0, s, tr.head_sums, tr.head_sums + 28,
                        tr.grad + tr.poff.at("out.bias"), tr.grad + tr.poff.at("out.weight"));
   }
-  SumJobs jobs{};
-  int sum_blocks = 0;
+  // The partial rows of the weight gradients are folded in two launches: those of layers 17 .. FOLD_EARLY on the
+  // weight-gradient stream as soon as they are written (beside the main chain's last layers), the level-0 layers' at the
+  // end of the step (a few MB: the fold in front of Adam is alone on the chip).
+  constexpr int FOLD_EARLY = NLAYER;  // (= no early fold.  Measured with 3: the fold, 54 us beside the main chain, sits in the
+                                      // weight-gradient queue in front of the level-0 layers' weight gradients, which are the
+                                      // step's tail: +30 us per step.  That queue has no slack left at its end.)
+  SumJobs jobs{}, jobs_early{};
+  int sum_blocks = 0, sum_blocks_early = 0;
   // Layers whose gz gets an event for the weight-gradient stream; the layers between hand their launch to the next event.
   // An event costs the main chain ~5 us (the launch behind a kernel with a completion signal starts that much later):
   // every other layer above level 0, every layer of the last four (their weight gradients are the step's tail).
@@ -818,14 +842,22 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
         for (int k = 0; k < n_held; ++k) held[k].w->launch(held[k].g, held[k].grid, tr.stream_wg);
         n_held = 0;
       }
-      SumJob& jb = jobs.job[jobs.count++];
+      static_assert(FOLD_EARLY >= NLAYER || ((ev_mask >> FOLD_EARLY) & 1), "the early fold follows launched weight gradients");
+      const bool early = li >= FOLD_EARLY;
+      SumJobs& jset = early ? jobs_early : jobs;
+      int& sum_blocks_set = early ? sum_blocks_early : sum_blocks;
+      SumJob& jb = jset.job[jset.count++];
       jb.partial = g.partial;
       jb.out = tr.grad + w.grad_off;
       jb.rows = grid;
       jb.n = w.out_n;
-      jb.first_block = sum_blocks;
+      jb.first_block = sum_blocks_set;
       jb.cq = sum_job_cq(grid);
-      sum_blocks += (w.out_n + 4 * jb.cq - 1) / (4 * jb.cq);
+      sum_blocks_set += (w.out_n + 4 * jb.cq - 1) / (4 * jb.cq);
+      if (li == FOLD_EARLY) {
+        ++g_launches;
+        hipLaunchKernelGGL(sum_rows_multi_kernel, dim3(sum_blocks_early), dim3(256), 0, tr.stream_wg, jobs_early);
+      }
     }
     if (li == 0) {  // conv bias of `inc`: sum of gz per channel (zero up to rounding: BatchNorm removes the mean)
       const int GB = B < 64 ? B : 64;
@@ -958,9 +990,26 @@ int vp_train_wait_inputs_consumed(vp_trainer* h, void* stream) {
   VP_REQUIRE(h, "vp_train_wait_inputs_consumed: null handle");
   Trainer& tr = *reinterpret_cast<Trainer*>(h);
   VP_HIP(hipSetDevice(tr.device));
-  VP_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), tr.ev_inputs, 0));
+  if (tr.seq > 0)
+    VP_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), tr.ev_inputs[(tr.seq - 1) % Trainer::EV_RING], 0));
   return VP_OK;
 }
+
+// The highest step number (0 = the first vp_train_step of this trainer) whose reads of x / y have completed, -1 if none is
+// known to have: a caller that keeps device batches alive for queued steps drops the ones up to it.  No host wait.
+long long vp_train_inputs_consumed_upto(vp_trainer* h) {
+  if (!h) return -1;
+  Trainer& tr = *reinterpret_cast<Trainer*>(h);
+  if (hipSetDevice(tr.device) != hipSuccess) return -1;
+  long long best = -1;
+  for (int i = 0; i < Trainer::EV_RING; ++i)
+    if (tr.ev_inputs_seq[i] > best && hipEventQuery(tr.ev_inputs[i]) == hipSuccess) best = tr.ev_inputs_seq[i];
+  (void)hipGetLastError();  // hipErrorNotReady of the pending ones is not an error
+  return best;
+}
+
+// Steps enqueued on this trainer so far: the step a vp_train_step call just queued has the number (this - 1).
+long long vp_train_steps_enqueued(const vp_trainer* h) { return h ? reinterpret_cast<const Trainer*>(h)->seq : 0; }
 
 int vp_train_synchronize(vp_trainer* h) {
   VP_REQUIRE(h, "vp_train_synchronize: null handle");

@@ -74,7 +74,7 @@ class PhaseNetTrainer:
                                                    self.max_batch, self.DTYPES[str(dtype)], C.byref(self._h)), "vp_train_create")
         _lib.check(self._lib.vp_train_set_hyper(self._h, betas[0], betas[1], eps, bn_momentum, loss_eps))
         self.global_step = 0
-        self._in_flight = collections.deque()  # (event behind a queued step, its x, its y): device inputs kept alive
+        self._in_flight = collections.deque()  # (number of a queued step, its x, its y): device inputs kept alive
 
     def close(self):
         if getattr(self, "_h", None):
@@ -102,41 +102,54 @@ class PhaseNetTrainer:
             raise ValueError(f"expected x and y of shape (B, 3, {self.in_samples}), got {tuple(x.shape)} / {tuple(y.shape)}")
         xk, xp, xm = self._arg(x)
         yk, yp, ym = self._arg(y)
-        while self._in_flight and self._in_flight[0][0].query():  # steps the trainer's stream has passed: their inputs may go
-            self._in_flight.popleft()
+        self._drop_consumed()
         if xm != ym:
             raise ValueError("x and y must both be host arrays or both be device tensors")
         if xm == _lib.VP_MEM_DEVICE:
             # the trainer runs on its own stream: x / y (or their fp32 copies made above) must be complete first.  An
             # event recorded on torch's stream that the trainer's stream waits for (hipStreamWaitEvent): the host does
             # not block, so a data loader filling the next batch on torch's stream keeps running
+            # Not needed -- and skipped: the wait is a marker in the trainer's queue in front of the step's first launch,
+            # ~25 us of the step -- when x and y are the very tensors of the previous step, unmodified since (torch counts
+            # in-place writes in Tensor._version): that step already waited for whatever produced them.
             torch = _torch()
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(xk.device))
-            if getattr(self, "_ext_stream", None) is None:
-                self._ext_stream = torch.cuda.ExternalStream(int(self._lib.vp_train_stream(self._h)), device=xk.device)
-            self._ext_stream.wait_event(ev)
+            producer = torch.cuda.current_stream(xk.device)
+            key = (xk.data_ptr(), xk._version, yk.data_ptr(), yk._version, producer.cuda_stream)
+            if key != getattr(self, "_last_inputs", None):
+                self._last_inputs = key
+                ev = torch.cuda.Event()
+                ev.record(producer)
+                if not ev.query():  # (already complete -- a batch prepared well ahead: nothing to wait for either)
+                    if getattr(self, "_ext_stream", None) is None:
+                        self._ext_stream = torch.cuda.ExternalStream(int(self._lib.vp_train_stream(self._h)), device=xk.device)
+                    self._ext_stream.wait_event(ev)
         loss = C.c_double(float("nan"))
         _lib.check(self._lib.vp_train_step(self._h, xp, yp, xm, int(x.shape[0]), float(lr), int(bool(update)),
                                            C.byref(loss) if want_loss else None), "vp_train_step")
         if xm == _lib.VP_MEM_DEVICE:
             # The step is (or may be) still queued on the trainer's non-blocking stream and reads x / y there:
-            #  * this object keeps x / y (or the fp32 copies `_arg` made) alive until an event recorded on the trainer's
-            #    stream behind the step has completed, so the caching allocator cannot hand their memory out while the step
+            #  * this object keeps x / y (or the fp32 copies `_arg` made) alive until the library reports the step's last
+            #    read of them complete (`_drop_consumed`), so the caching allocator cannot hand their memory out while the step
             #    reads it, whatever the caller does with its own references.  (Not Tensor.record_stream: the allocator would
             #    then record events on the trainer's stream when the tensors die -- possibly after vp_train_destroy has
             #    destroyed that stream.)
             #  * torch's current stream waits -- on the device, the host does not block -- for the event behind the step's
             #    last read of x / y, so `x.copy_(next_batch)` or any other refill enqueued there cannot overtake the step.
-            done = torch.cuda.Event()
-            done.record(self._ext_stream)
-            self._in_flight.append((done, xk, yk))
+            self._in_flight.append((int(self._lib.vp_train_steps_enqueued(self._h)) - 1, xk, yk))
             cur = torch.cuda.current_stream(xk.device)
             _lib.check(self._lib.vp_train_wait_inputs_consumed(self._h, C.c_void_p(cur.cuda_stream)), "vp_train_wait_inputs_consumed")
         self.forward_count = getattr(self, "forward_count", 0) + 1  # every step moves the BatchNorm running statistics
         if update:
             self.global_step += 1
         return loss.value if want_loss else None
+
+    def _drop_consumed(self):
+        """Device inputs of the steps the trainer's stream has read to the end may go (no event of ours enters that stream:
+        the library keeps one per step behind the last reader of x / y and answers which of them have completed)."""
+        if self._in_flight:
+            upto = int(self._lib.vp_train_inputs_consumed_upto(self._h))
+            while self._in_flight and self._in_flight[0][0] <= upto:
+                self._in_flight.popleft()
 
     def synchronize(self):
         _lib.check(self._lib.vp_train_synchronize(self._h))
