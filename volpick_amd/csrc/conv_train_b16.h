@@ -24,14 +24,19 @@ namespace vp {
 
 template <class C>
 struct ConvB16 {
-  static constexpr int TG = (C::TAPS + 7) / 8;    // tap groups of eight
-  static constexpr int STEPS = C::CB * TG;        // K-steps: (channel block, tap group)
+  // TPR = taps a lane takes from one channel row: 8 (filters of 3 .. 16 taps: K = four channels x eight taps) or 2 (the
+  // two-tap phases of the stride-4 transposed layers: K = sixteen channels x two taps, a lane reads one dword from each of
+  // four rows)
+  static constexpr int TPR = C::TAPS <= 2 ? 2 : 8;
+  static constexpr int TG = TPR == 8 ? (C::TAPS + 7) / 8 : 1;   // tap groups
+  static constexpr int STEPS = TPR == 8 ? C::CB * TG : C::CB / 4;  // K-steps: (channel block, tap group) / four channel blocks
   static constexpr bool TWO = (C::SN % 2) == 1;   // both parities occur among the lanes' starts
   static constexpr int SIG = C::SHIFT & 1;        // single image: shifted by one sample or not
-  static constexpr int WNEED = C::SN * (C::TN - 1) + 8 * TG + C::SHIFT;  // samples a row is read up to
-  static constexpr int WQ = (WNEED + 1 + 3) / 4;                          // staged quads per row (W4 of them from memory, zeros behind)
-  static constexpr int RS0 = 2 * WQ;                                      // dwords per row
-  static constexpr int RSD = (RS0 + 31) / 32 * 32 + (TWO ? 8 : 16);
+  static constexpr int WNEED = C::SN * (C::TN - 1) + TPR * TG + C::SHIFT;  // samples a row is read up to
+  static constexpr int WQ = (WNEED + 1 + 3) / 4;                            // staged quads per row (W4 of them from memory, zeros behind)
+  static constexpr int RS0 = 2 * WQ;                                        // dwords per row
+  static constexpr int RSD = (RS0 + 31) / 32 * 32 + (TPR == 2 ? 2 : TWO ? 8 : 16);  // (TPR 2: lane groups sit four rows apart)
+  static_assert(TPR == 8 || C::CB % 4 == 0, "two-tap layers: whole groups of sixteen channels");
   static constexpr int IMG = C::CINP * RSD + 16;  // second image: 16 banks off the first
   static constexpr int IN_DW = (TWO ? IMG : 0) + C::CINP * RSD + 4;
   static constexpr int OUT_DW = C::DIRECT ? 0 : C::LDS_OUT;
@@ -46,7 +51,7 @@ struct ConvB16 {
 struct ConvB16PackJob {
   const float* frag;
   uint4* out;
-  int MT, CB, TAPS, TG, first_block;  // blocks of 256 threads = four (m-tile, cb, tg) triples
+  int MT, CB, TAPS, TG, TPR, first_block;  // blocks of 256 threads = four (m-tile, K-step) pairs
 };
 constexpr int MAX_B16_JOBS = 40;
 struct ConvB16PackJobs {
@@ -58,14 +63,24 @@ __global__ __launch_bounds__(256) void conv_b16_pack_kernel(const ConvB16PackJob
   while (j + 1 < jobs.count && (int)blockIdx.x >= jobs.job[j + 1].first_block) ++j;
   const ConvB16PackJob jb = jobs.job[j];
   const int trip = ((int)blockIdx.x - jb.first_block) * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int steps = jb.CB * jb.TG;
+  const int steps = jb.TPR == 8 ? jb.CB * jb.TG : jb.CB / 4;
   if (trip >= jb.MT * steps) return;
-  const int mt = trip / steps, st = trip - mt * steps, cb = st / jb.TG, tg = st - cb * jb.TG;
+  const int mt = trip / steps, st = trip - mt * steps;
   float w[8];
+  if (jb.TPR == 8) {
+    const int cb = st / jb.TG, tg = st - cb * jb.TG;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int tap = 8 * tg + i;
-    w[i] = tap < jb.TAPS ? jb.frag[(((long)mt * jb.CB + cb) * jb.TAPS + tap) * 64 + lane] : 0.f;
+    for (int i = 0; i < 8; ++i) {
+      const int tap = 8 * tg + i;
+      w[i] = tap < jb.TAPS ? jb.frag[(((long)mt * jb.CB + cb) * jb.TAPS + tap) * 64 + lane] : 0.f;
+    }
+  } else {  // lane (row lane % 16, group lane / 16): channel block 4 st + group, its four channels x two taps
+    const int cb = 4 * st + (lane >> 4), m = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kk = i >> 1, tap = i & 1;
+      w[i] = tap < jb.TAPS ? jb.frag[(((long)mt * jb.CB + cb) * jb.TAPS + tap) * 64 + kk * 16 + m] : 0.f;
+    }
   }
   unsigned h[4], m[4], l[4];
 #pragma unroll
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(256) void conv_b16_kernel(const ConvArgs a, const u
   for (int j = 0; j < C::NW; ++j) {
     const int pos = C::SN * ((wn * C::NW + j) * 16 + n) + C::SHIFT;
     const int par = W::TWO ? (pos & 1) : W::SIG;
-    boff[j] = (W::TWO && par ? W::IMG : 0) + g * W::RSD + ((pos - par) >> 1);
+    boff[j] = (W::TWO && par ? W::IMG : 0) + (W::TPR == 8 ? g : 4 * g) * W::RSD + ((pos - par) >> 1);
   }
   const uint4* ap = a3 + (long)(wm * C::MW) * W::STEPS * 3 * 64 + lane;
   constexpr int PF = 2;
@@ -155,13 +170,18 @@ __global__ __launch_bounds__(256) void conv_b16_kernel(const ConvArgs a, const u
   for (int s = 0; s < PF && s < W::STEPS; ++s) load_a(s);
 #pragma unroll
   for (int s = 0; s < W::STEPS; ++s) {
-    const int cb = s / W::TG, tg = s - cb * W::TG;
     if (s + PF < W::STEPS) load_a(s + PF);
     uint4 b[C::NW];
 #pragma unroll
     for (int j = 0; j < C::NW; ++j) {
-      const unsigned* p = ldu + boff[j] + cb * 4 * W::RSD + 4 * tg;
-      b[j] = make_uint4(p[0], p[1], p[2], p[3]);
+      if constexpr (W::TPR == 8) {
+        const int cb = s / W::TG, tg = s - cb * W::TG;
+        const unsigned* p = ldu + boff[j] + cb * 4 * W::RSD + 4 * tg;
+        b[j] = make_uint4(p[0], p[1], p[2], p[3]);
+      } else {
+        const unsigned* p = ldu + boff[j] + s * 16 * W::RSD;
+        b[j] = make_uint4(p[0], p[W::RSD], p[2 * W::RSD], p[3 * W::RSD]);
+      }
     }
 #pragma unroll
     for (int pc = 2; pc >= 0; --pc)  // smallest products first

@@ -143,7 +143,7 @@ void set_conv(ConvOp* op, int src1, int src2, int dst, int cols, int l_out) {
   op->dst = dst;
   op->cols = cols;
   op->l_out = l_out;
-  if constexpr (Cfg::BF16 && Cfg::TAPS >= 7 && !b16_loses<Cfg>) {
+  if constexpr (Cfg::BF16 && (Cfg::TAPS >= 7 || (Cfg::TAPS == 2 && Cfg::CB % 4 == 0)) && !b16_loses<Cfg>) {
     op->launch_b16 = &launch_conv_b16<Cfg>;
     op->a3_n = ConvB16<Cfg>::A_UINT4;
   }
@@ -558,15 +558,16 @@ int upload(Trainer& tr, const float* weights) {
           if (op->used && op->launch_b16) {
             if (tr.b16_jobs.count >= MAX_B16_JOBS) return VP_ERR_UNSUPPORTED;
             ConvB16PackJob& jb = tr.b16_jobs.job[tr.b16_jobs.count++];
-            const int cb = op->g.cinp() / 4, tg = (op->g.taps + 7) / 8, mt = op->g.M() / 16;
+            const int cb = op->g.cinp() / 4, tpr = op->g.taps <= 2 ? 2 : 8, tg = tpr == 8 ? (op->g.taps + 7) / 8 : 1, mt = op->g.M() / 16;
             jb.frag = tr.frag + op->frag_off;
             jb.out = tr.frag3 + op->a3_off;
             jb.MT = mt;
             jb.CB = cb;
             jb.TAPS = op->g.taps;
             jb.TG = tg;
+            jb.TPR = tpr;
             jb.first_block = tr.b16_blocks;
-            tr.b16_blocks += (mt * cb * tg + 3) / 4;
+            tr.b16_blocks += (mt * (tpr == 8 ? cb * tg : cb / 4) + 3) / 4;
           }
     }
   }
@@ -792,19 +793,19 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     TRL(head_final_kernel, dim3(1), dim3(32), 0, s, tr.head_sums, tr.head_sums + 28,
                        tr.grad + tr.poff.at("out.bias"), tr.grad + tr.poff.at("out.weight"));
   }
-  // The partial rows of the weight gradients are folded in two launches: those of layers 17 .. FOLD_EARLY on the
-  // weight-gradient stream as soon as they are written (beside the main chain's last layers), the level-0 layers' at the
-  // end of the step (a few MB: the fold in front of Adam is alone on the chip).
-  constexpr int FOLD_EARLY = NLAYER;  // (= no early fold.  Measured with 3: the fold, 54 us beside the main chain, sits in the
-                                      // weight-gradient queue in front of the level-0 layers' weight gradients, which are the
-                                      // step's tail: +30 us per step.  That queue has no slack left at its end.)
-  SumJobs jobs{}, jobs_early{};
-  int sum_blocks = 0, sum_blocks_early = 0;
+  // The partial rows of the weight gradients are folded by sum_rows_multi_kernel: those of the layers >= FOLD_EARLY each
+  // right behind its weight gradient on that stream (where the stream still waits for the main chain between its
+  // launches), the rest in one launch at the end of the step, in front of Adam, alone on the chip.
+  // (same-box sweep of FOLD_EARLY: none 1.414 ms per step, 13: 1.389, 11: 1.405, 9: 1.411, 7: 1.418, 5: 1.436 -- the folds of
+  // the deep layers' 15 MB rows take more from the main chain beside them than they save at the end)
+  constexpr int FOLD_EARLY = 13;
+  SumJobs jobs{};
+  int sum_blocks = 0;
   // Layers whose gz gets an event for the weight-gradient stream; the layers between hand their launch to the next event.
   // An event costs the main chain ~5 us (the launch behind a kernel with a completion signal starts that much later):
   // every other layer above level 0, every layer of the last four (their weight gradients are the step's tail).
   constexpr unsigned ev_mask = 0x2aaaf;
-  struct { const WgradOp* w; WgradArgs g; int grid; } held[NLAYER];
+  struct { const WgradOp* w; WgradArgs g; int grid, li; } held[NLAYER];
   int n_held = 0;
   static_assert(NLAYER <= MAX_SUM_JOBS, "one sum job per layer");
   for (int li = NLAYER - 1; li >= 0; --li) {
@@ -836,27 +837,38 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
       ++g_launches;
       held[n_held].w = &w;
       held[n_held].g = g;
+      held[n_held].li = li;
       held[n_held++].grid = grid;
       if ((ev_mask >> li) & 1) {
         (void)hipStreamWaitEvent(tr.stream_wg, tr.ev_gz[li], 0);
-        for (int k = 0; k < n_held; ++k) held[k].w->launch(held[k].g, held[k].grid, tr.stream_wg);
+        for (int k = 0; k < n_held; ++k) {
+          const WgradOp& hw = *held[k].w;
+          hw.launch(held[k].g, held[k].grid, tr.stream_wg);
+          if (held[k].li >= FOLD_EARLY) {
+            SumJobs one{};
+            one.count = 1;
+            SumJob& ej = one.job[0];
+            ej.partial = held[k].g.partial;
+            ej.out = tr.grad + hw.grad_off;
+            ej.rows = held[k].grid;
+            ej.n = hw.out_n;
+            ej.first_block = 0;
+            ej.cq = sum_job_cq(held[k].grid);
+            ++g_launches;
+            hipLaunchKernelGGL(sum_rows_multi_kernel, dim3((hw.out_n + 4 * ej.cq - 1) / (4 * ej.cq)), dim3(256), 0, tr.stream_wg, one);
+          }
+        }
         n_held = 0;
       }
-      static_assert(FOLD_EARLY >= NLAYER || ((ev_mask >> FOLD_EARLY) & 1), "the early fold follows launched weight gradients");
-      const bool early = li >= FOLD_EARLY;
-      SumJobs& jset = early ? jobs_early : jobs;
-      int& sum_blocks_set = early ? sum_blocks_early : sum_blocks;
-      SumJob& jb = jset.job[jset.count++];
-      jb.partial = g.partial;
-      jb.out = tr.grad + w.grad_off;
-      jb.rows = grid;
-      jb.n = w.out_n;
-      jb.first_block = sum_blocks_set;
-      jb.cq = sum_job_cq(grid);
-      sum_blocks_set += (w.out_n + 4 * jb.cq - 1) / (4 * jb.cq);
-      if (li == FOLD_EARLY) {
-        ++g_launches;
-        hipLaunchKernelGGL(sum_rows_multi_kernel, dim3(sum_blocks_early), dim3(256), 0, tr.stream_wg, jobs_early);
+      if (li < FOLD_EARLY) {
+        SumJob& jb = jobs.job[jobs.count++];
+        jb.partial = g.partial;
+        jb.out = tr.grad + w.grad_off;
+        jb.rows = grid;
+        jb.n = w.out_n;
+        jb.first_block = sum_blocks;
+        jb.cq = sum_job_cq(grid);
+        sum_blocks += (w.out_n + 4 * jb.cq - 1) / (4 * jb.cq);
       }
     }
     if (li == 0) {  // conv bias of `inc`: sum of gz per channel (zero up to rounding: BatchNorm removes the mean)
