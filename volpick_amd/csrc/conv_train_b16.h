@@ -41,9 +41,10 @@ struct ConvB16 {
   static constexpr int IN_DW = (TWO ? IMG : 0) + C::CINP * RSD + 4;
   static constexpr int OUT_DW = C::DIRECT ? 0 : C::LDS_OUT;
   static constexpr int LDS_DW = IN_DW > OUT_DW ? IN_DW : OUT_DW;
+  static constexpr int STAT_DW = 2 * C::COUT * C::WAVES_N;  // BatchNorm sums of the tile: [COUT][WAVES_N][2], behind the images
   static constexpr size_t A_UINT4 = (size_t)C::MT * STEPS * 3 * 64;  // operand size [m-tile][step][piece][lane]
   static_assert(C::BF16 && C::EPI == EPI_STORE && !C::APRE && !C::AQ4, "the training step's plain bf16 layers");
-  static_assert(LDS_DW * 4 <= 64 * 1024, "LDS budget");
+  static_assert((LDS_DW + STAT_DW) * 4 <= 64 * 1024, "LDS budget");
 };
 
 // A operand of conv_b16_kernel from the fp32 fragments [m-tile][CB][TAPS][64]: lane (kk = lane / 16: channel of the block,
@@ -96,8 +97,12 @@ __global__ __launch_bounds__(256) void conv_b16_pack_kernel(const ConvB16PackJob
   o[128] = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
+// `stat` (may be null): the layer's BatchNorm statistics leave with the tile -- per workgroup and output channel the sum and
+// the sum of squares of the values AS STORED (rounded to bf16, inside [0, l_out)), [COUT][workgroups][2] floats, workgroup =
+// blockIdx.y * gridDim.x + blockIdx.x; bnv_apply_kernel folds them in a fixed order (BnArgs::fpart).  Saves the statistics
+// launch and its read of z.
 template <class C>
-__global__ __launch_bounds__(256) void conv_b16_kernel(const ConvArgs a, const uint4* __restrict__ a3) {
+__global__ __launch_bounds__(256) void conv_b16_kernel(const ConvArgs a, const uint4* __restrict__ a3, float* __restrict__ stat) {
   using W = ConvB16<C>;
   extern __shared__ float4 lds_raw[];
   unsigned* ldu = reinterpret_cast<unsigned*>(lds_raw);
@@ -192,8 +197,60 @@ __global__ __launch_bounds__(256) void conv_b16_kernel(const ConvArgs a, const u
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, q[s % (PF + 1)][i][pc]),
                                                             __builtin_bit_cast(bf16x8_b3, b[j]), acc[i][j], 0, 0, 0);
   }
-  // ---- epilogues: as conv_mfma_kernel's BF16 / EPI_STORE path -------------------------------------------------------------
   const float* bias = a.bias;
+  if (stat) {  // (uniform)
+    constexpr int RPC = C::P >= 4 ? 4 : C::P, NCH = 4 / RPC;  // rows of a lane's four that belong to one channel
+    static_assert(C::P == 1 || C::P == 2 || C::P == 4, "rows (channel, phase)");
+    float* lstat = lds + W::LDS_DW;
+    float ss[C::MW][NCH], sq[C::MW][NCH];
+#pragma unroll
+    for (int i = 0; i < C::MW; ++i)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) ss[i][c] = sq[i][c] = 0.f;
+#pragma unroll
+    for (int i = 0; i < C::MW; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = (wm * C::MW + i) * 16 + 4 * g + r;
+        const int co = m / C::P, p = m - co * C::P;
+        const float bs = bias[co];
+#pragma unroll
+        for (int j = 0; j < C::NW; ++j) {
+          const int t = C::P * (col0 + (wn * C::NW + j) * 16 + n) + p + C::OUT_OFF;
+          float x = acc[i][j][r] + bs;
+          if (C::RELU) x = fmaxf(x, 0.f);
+          x = bf16_lo(pack_bf16x2(x, 0.f));
+          if (t >= 0 && t < a.l_out) {
+            ss[i][r / RPC] += x;
+            sq[i][r / RPC] = fmaf(x, x, sq[i][r / RPC]);
+          }
+        }
+      }
+#pragma unroll
+    for (int i = 0; i < C::MW; ++i)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {  // the 16 columns of the lane row
+          ss[i][c] += __shfl_xor(ss[i][c], o, 64);
+          sq[i][c] += __shfl_xor(sq[i][c], o, 64);
+        }
+        if (n == 0) {
+          const int co = ((wm * C::MW + i) * 16 + 4 * g + c * RPC) / C::P;
+          lstat[(co * C::WAVES_N + wn) * 2] = ss[i][c];
+          lstat[(co * C::WAVES_N + wn) * 2 + 1] = sq[i][c];
+        }
+      }
+    __syncthreads();
+    if (tid < C::COUT) {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < C::WAVES_N; ++k) s0 += lstat[(tid * C::WAVES_N + k) * 2], s1 += lstat[(tid * C::WAVES_N + k) * 2 + 1];
+      const long nwg = (long)gridDim.x * gridDim.y, wg = (long)blockIdx.y * gridDim.x + blockIdx.x;
+      *reinterpret_cast<float2*>(stat + ((long)tid * nwg + wg) * 2) = make_float2(s0, s1);
+    }
+  }
+  // ---- epilogues: as conv_mfma_kernel's BF16 / EPI_STORE path -------------------------------------------------------------
   bf16_t* const dbase = reinterpret_cast<bf16_t*>(a.dst) + (long)win * a.wsd + a.dst_halo;
   if constexpr (C::DIRECT) {
 #pragma unroll
@@ -288,9 +345,9 @@ __global__ __launch_bounds__(256) void conv_b16_kernel(const ConvArgs a, const u
 }
 
 template <class C>
-int launch_conv_b16(const ConvArgs& a, const uint4* a3, int cols, hipStream_t stream) {
+int launch_conv_b16(const ConvArgs& a, const uint4* a3, float* stat, int cols, hipStream_t stream) {
   dim3 grid((cols + C::TN - 1) / C::TN, a.n_windows, 1);
-  hipLaunchKernelGGL(conv_b16_kernel<C>, grid, dim3(256), (size_t)ConvB16<C>::LDS_DW * 4, stream, a, a3);
+  hipLaunchKernelGGL(conv_b16_kernel<C>, grid, dim3(256), (size_t)(ConvB16<C>::LDS_DW + ConvB16<C>::STAT_DW) * 4, stream, a, a3, stat);
   return 0;
 }
 

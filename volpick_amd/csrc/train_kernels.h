@@ -39,6 +39,8 @@ struct BnArgs {
   float* stats;     // [4][C]: batch mean, rstd, S1 = sum(da'), S2 = sum(da' * xhat)
   double* partial;  // [C][GB][2]
   int GB;
+  const float* fpart;  // forward statistics from the conv's epilogue instead (conv_train_b16.h): [C][n_fpart][2] sums, or null
+  int n_fpart;
   int sl2;          // vector kernels: log2 of the lanes that share a row (VecWalk)
   float* g_gamma;   // gradient blob slots
   float* g_beta;
@@ -290,12 +292,30 @@ __global__ __launch_bounds__(256) void bnv_stats_partial_kernel(const BnArgs a) 
   }
 }
 
+// the same from the per-workgroup sums a conv launch left (BnArgs::fpart): all four waves, fixed order
+__device__ inline void channel_totals_fpart(const BnArgs& a, int c, double* sh /*[8]*/, double* s0, double* s1) {
+  const float2* p = reinterpret_cast<const float2*>(a.fpart) + (long)c * a.n_fpart;
+  double x = 0.0, y = 0.0;
+  for (int i = threadIdx.x; i < a.n_fpart; i += 256) {
+    const float2 v = p[i];
+    x += (double)v.x;
+    y += (double)v.y;
+  }
+  block_sum2_f64<4>(x, y, sh);
+  *s0 = x;
+  *s1 = y;
+}
+
 template <class T, int CROP>
 __global__ __launch_bounds__(256) void bnv_apply_kernel(const BnArgs a) {
-  __shared__ double sh[2];
+  __shared__ double sh[8];
   const int c = blockIdx.x, j = blockIdx.y, wave = threadIdx.x >> 6;
   double S, Q;
-  channel_totals_block(a, c, sh, &S, &Q);
+  if (a.fpart) {
+    channel_totals_fpart(a, c, sh, &S, &Q);
+  } else {
+    channel_totals_block(a, c, sh, &S, &Q);
+  }
   float mean, rstd;
   bn_finish_stats(a, c, S, Q, j == 0 && threadIdx.x == 0, &mean, &rstd);
   const float sc = a.gamma[c] * rstd, shv = a.beta[c] - mean * sc;

@@ -98,7 +98,8 @@ struct ConvOp {
   ConvGeom g{};
   int (*launch)(const ConvArgs&, int, hipStream_t) = nullptr;
   // bf16 rows, filters of >= 7 taps: the bf16-MFMA form (conv_train_b16.h); its A operand is cut from the fp32 fragments
-  int (*launch_b16)(const ConvArgs&, const uint4*, int, hipStream_t) = nullptr;
+  int (*launch_b16)(const ConvArgs&, const uint4*, float*, int, hipStream_t) = nullptr;
+  int tn = 0, cout = 0;  // columns per tile / output channels (the statistics a forward launch leaves: [cout][tiles x B][2])
   size_t a3_n = 0, a3_off = 0;  // uint4 words of the operand / its place in Trainer::frag3
   const void* kernel = nullptr;
   size_t lds_bytes = 0;
@@ -146,6 +147,8 @@ void set_conv(ConvOp* op, int src1, int src2, int dst, int cols, int l_out) {
   if constexpr (Cfg::BF16 && (Cfg::TAPS >= 7 || (Cfg::TAPS == 2 && Cfg::CB % 4 == 0)) && !b16_loses<Cfg>) {
     op->launch_b16 = &launch_conv_b16<Cfg>;
     op->a3_n = ConvB16<Cfg>::A_UINT4;
+    op->tn = Cfg::TN;
+    op->cout = Cfg::COUT;
   }
 }
 
@@ -234,6 +237,7 @@ struct Trainer {
   float* stats = nullptr;
   double* bn_partial = nullptr;
   unsigned* bn_counter = nullptr;
+  float* conv_stat = nullptr;  // BatchNorm sums a forward bf16-MFMA conv leaves per workgroup (one layer at a time)
   uint4* frag3 = nullptr;  // three-piece A operands of the bf16-MFMA convs, cut from `frag` every step
   ConvB16PackJobs b16_jobs{};
   int b16_blocks = 0;
@@ -269,7 +273,7 @@ struct Trainer {
   }
   ~Trainer() {
     for (void* p : {(void*)arena, (void*)w, (void*)grad, (void*)adam_m, (void*)adam_v, (void*)mask, (void*)ema, (void*)frag_idx,
-                    (void*)frag, (void*)zeros, (void*)stats, (void*)bn_partial, (void*)bn_counter, (void*)frag3, (void*)wg_partial, (void*)head_partial,
+                    (void*)frag, (void*)zeros, (void*)stats, (void*)bn_partial, (void*)bn_counter, (void*)frag3, (void*)conv_stat, (void*)wg_partial, (void*)head_partial,
                     (void*)head_sums, (void*)head_stage, (void*)x_dev, (void*)y_dev, (void*)p_dev})
       if (p) (void)hipFree(p);
     if (stream) (void)hipStreamDestroy(stream);
@@ -552,6 +556,13 @@ int upload(Trainer& tr, const float* weights) {
           n3 += op->a3_n;
         }
     if (n3) {
+      size_t ns2 = 0;
+      for (Layer& L : tr.layers)
+        if (L.fwd.launch_b16) {
+          const size_t need = (size_t)L.fwd.cout * ((L.fwd.cols + L.fwd.tn - 1) / L.fwd.tn) * tr.max_batch * 2;
+          if (need > ns2) ns2 = need;
+        }
+      if (ns2) TR_HIP(hipMalloc(&tr.conv_stat, ns2 * sizeof(float)));
       TR_HIP(hipMalloc(&tr.frag3, n3 * sizeof(uint4)));
       for (Layer& L : tr.layers)
         for (ConvOp* op : {&L.fwd, &L.dgrad})
@@ -624,7 +635,8 @@ int upload(Trainer& tr, const float* weights) {
   return VP_OK;
 }
 
-void run_conv(Trainer& tr, const ConvOp& op, int B) {
+// Returns the number of per-workgroup BatchNorm sums the launch left in tr.conv_stat (want_stat, bf16-MFMA form), else 0.
+int run_conv(Trainer& tr, const ConvOp& op, int B, bool want_stat = false) {
   ++g_launches;
   ConvArgs a{};
   const Tensor& s1 = tr.tensors[op.src1];
@@ -649,11 +661,14 @@ void run_conv(Trainer& tr, const ConvOp& op, int B) {
   a.l_out = op.l_out;
   a.l_dst = op.l_out;
   static const bool b16 = [] { const char* e = getenv("VP_CONV_B16"); return !e || atoi(e) != 0; }();
+  static const bool estat = [] { const char* e = getenv("VP_CONV_STAT"); return !e || atoi(e) != 0; }();
   if (op.launch_b16 && tr.frag3 && b16) {
-    op.launch_b16(a, tr.frag3 + op.a3_off, op.cols, tr.stream);
-  } else {
-    op.launch(a, op.cols, tr.stream);
+    const bool st = want_stat && estat && tr.conv_stat;
+    op.launch_b16(a, tr.frag3 + op.a3_off, st ? tr.conv_stat : nullptr, op.cols, tr.stream);
+    return st ? ((op.cols + op.tn - 1) / op.tn) * B : 0;
   }
+  op.launch(a, op.cols, tr.stream);
+  return 0;
 }
 
 BnArgs bn_args(Trainer& tr, const BnOp& b, int B) {
@@ -717,7 +732,7 @@ BnArgs bn_args(Trainer& tr, const BnOp& b, int B) {
 template <class T>
 void bn_forward_v(const BnArgs& a, hipStream_t s) {
   const dim3 grid(a.C, a.GB);
-  TRL(bnv_stats_partial_kernel<T>, grid, dim3(256), 0, s, a);
+  if (!a.fpart) TRL(bnv_stats_partial_kernel<T>, grid, dim3(256), 0, s, a);  // (else the conv launch left the sums)
   BN_CROP_LAUNCH(bnv_apply_kernel, grid, 256);
 }
 template <class T>
@@ -752,8 +767,10 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     TRL(load_rows_kernel, dim3((T0 + 255) / 256, 3, B), dim3(256), 0, s, x_dev, tr.rows(tr.t_x), 3, T0);
   }
   for (Layer& L : tr.layers) {
-    run_conv(tr, L.fwd, B);
-    const BnArgs a = bn_args(tr, L.bn, B);
+    const int n_stat = run_conv(tr, L.fwd, B, true);
+    BnArgs a = bn_args(tr, L.bn, B);
+    a.fpart = n_stat ? tr.conv_stat : nullptr;
+    a.n_fpart = n_stat;
     if (tr.bf16) {
       bn_forward_v<bf16_t>(a, s);
     } else {
