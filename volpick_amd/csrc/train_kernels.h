@@ -296,10 +296,15 @@ __global__ __launch_bounds__(256) void bnv_stats_partial_kernel(const BnArgs a) 
 __device__ inline void channel_totals_fpart(const BnArgs& a, int c, double* sh /*[8]*/, double* s0, double* s1) {
   const float2* p = reinterpret_cast<const float2*>(a.fpart) + (long)c * a.n_fpart;
   double x = 0.0, y = 0.0;
-  for (int i = threadIdx.x; i < a.n_fpart; i += 256) {
-    const float2 v = p[i];
-    x += (double)v.x;
-    y += (double)v.y;
+  for (int i0 = threadIdx.x; i0 < a.n_fpart; i0 += 256 * 8) {  // eight loads in flight (rolled: one L2 round trip per 256 entries)
+    float2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (i0 + 256 * k < a.n_fpart) ? p[i0 + 256 * k] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      x += (double)v[k].x;
+      y += (double)v[k].y;
+    }
   }
   block_sum2_f64<4>(x, y, sh);
   *s0 = x;
