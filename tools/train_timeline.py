@@ -16,7 +16,9 @@ short = lambda k: k.split("(")[0].split("::")[-1][:40]
 marks = [i for i, r in enumerate(rows) if "load_rows" in r[2] or "ConvCfg<3, 0, 8" in r[2]]
 starts = [m for j, m in enumerate(marks) if j == 0 or m - marks[j - 1] > per // 2]
 assert len(starts) >= 4, "no step marks found"
-a, b = starts[-3], starts[-2]
+# the shortest of the steady steps: under rocprofv3 the host may fall behind the device for a step (gaps that are the tool's)
+cands = [(rows[starts[i + 1]][0] - rows[starts[i]][0], starts[i], starts[i + 1]) for i in range(1, len(starts) - 1)]
+_, a, b = min(cands)
 step = rows[a:b]
 t0, t1 = step[0][0], rows[b][0]
 print(f"step: {len(step)} launches, {(t1 - t0) / 1e3:.1f} us from its first kernel's start to the next step's")

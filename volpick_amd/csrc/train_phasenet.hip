@@ -65,9 +65,12 @@ template <int BF> using G_u0T = ConvCfg<64, 0, 128, 1, 7, 4, 0, 0, 4, 1, 1, 0, E
 template <int BF> using G_u1T = ConvCfg<32, 0, 64, 1, 7, 4, 0, 0, 4, 1, 3, 0, EPI_STORE, 0, 0, BF>;
 template <int BF> using G_u2T = ConvCfg<16, 0, 32, 1, 7, 4, 0, 0, 2, 2, 3, 0, EPI_STORE, 0, 0, BF>;
 template <int BF> using G_u3T = ConvCfg<8, 0, 16, 1, 7, 4, 0, 0, 1, 4, 4, 0, EPI_STORE, 0, 0, BF>;
+#ifndef W0TT
+#define W0TT 512
+#endif
 //                     LO HI1 HI2 K S NWAVE TT [WB windows per item]
-using W_inc = WgradCfg<8, 3, 0, 7, 1, 8, 256>;
-using W_d0s = WgradCfg<8, 8, 0, 7, 1, 8, 256>;
+template <int BF> using W_inc = WgradCfg<8, 3, 0, 7, 1, 8, BF ? W0TT : 256>;
+template <int BF> using W_d0s = WgradCfg<8, 8, 0, 7, 1, 8, BF ? W0TT : 256>;
 using W_d0d = WgradCfg<8, 8, 0, 7, 4, 8, 256>;
 using W_d1s = WgradCfg<16, 8, 0, 7, 1, 8, 256>;
 using W_d1d = WgradCfg<16, 16, 0, 7, 4, 8, 96>;
@@ -83,7 +86,7 @@ using W_u1s = WgradCfg<32, 32, 32, 7, 1, 8, 96>;
 using W_u2T = WgradCfg<32, 16, 0, 7, 4, 8, 96>;
 using W_u2s = WgradCfg<16, 16, 16, 7, 1, 8, 256>;
 using W_u3T = WgradCfg<16, 8, 0, 7, 4, 8, 256>;
-using W_u3s = WgradCfg<8, 8, 8, 7, 1, 8, 256>;
+template <int BF> using W_u3s = WgradCfg<8, 8, 8, 7, 1, 8, BF ? W0TT : 256>;
 
 // Where the bf16-MFMA form (conv_train_b16.h) loses to the fp32 one, same-box timeline of the step: the two up0.same-sized
 // layers whose 57 k weights stream per 48-column tile (six bytes per weight as pieces, four as fp32) and down2.same's input
@@ -471,8 +474,8 @@ int build_plan(Trainer& tr) {
 #define WG(LI, CFG, WNAME, LO, HI1, HI2, LN, OFF)            \
   set_wgrad<CFG, ET>(&Ls[LI].wg, LO, HI1, HI2, LN, OFF);          \
   Ls[LI].wg.grad_off = P(WNAME);
-  WG(0, W_inc, "inc.weight", GZ(0), x, -1, T0, -3)
-  WG(1, W_d0s, "down_branch.0.0.weight", GZ(1), A(0), -1, T0, -3)
+  WG(0, W_inc<BF>, "inc.weight", GZ(0), x, -1, T0, -3)
+  WG(1, W_d0s<BF>, "down_branch.0.0.weight", GZ(1), A(0), -1, T0, -3)
   WG(2, W_d0d, "down_branch.0.2.weight", GZ(2), A(1), -1, T1, -padl[0])
   WG(3, W_d1s, "down_branch.1.0.weight", GZ(3), A(2), -1, T1, -3)
   WG(4, W_d1d, "down_branch.1.2.weight", GZ(4), A(3), -1, T2, -padl[1])
@@ -488,7 +491,7 @@ int build_plan(Trainer& tr) {
   WG(14, W_u2T, "up_branch.2.0.weight", A(13), GZ(14), -1, T2, 0)
   WG(15, W_u2s, "up_branch.2.2.weight", GZ(15), A(3), A(14), T1, -3)
   WG(16, W_u3T, "up_branch.3.0.weight", A(15), GZ(16), -1, T1, 0)
-  WG(17, W_u3s, "up_branch.3.2.weight", GZ(17), A(1), A(16), T0, -3)
+  WG(17, W_u3s<BF>, "up_branch.3.2.weight", GZ(17), A(1), A(16), T0, -3)
 #undef WG
 
   for (Layer& L : tr.layers)
