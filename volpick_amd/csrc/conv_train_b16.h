@@ -47,8 +47,9 @@ struct ConvB16 {
   static_assert((LDS_DW + STAT_DW) * 4 <= 64 * 1024, "LDS budget");
 };
 
-// A operand of conv_b16_kernel from the fp32 fragments [m-tile][CB][TAPS][64]: lane (kk = lane / 16: channel of the block,
-// row lane % 16) takes taps 8 tg .. 8 tg + 7 of its row and channel and cuts them into pieces.
+// A operand of conv_b16_kernel from the fp32 fragments [m-tile][CB][TAPS][64] (fragment lane = channel-of-block * 16 + row):
+// TPR 8: lane (row lane % 16, channel lane / 16 of block cb) takes taps 8 tg .. 8 tg + 7 of its row and channel; TPR 2: lane
+// (row, group lane / 16) takes the four channels x two taps of channel block 4 step + group.  Cut into the three pieces.
 struct ConvB16PackJob {
   const float* frag;
   uint4* out;
