@@ -156,11 +156,11 @@ void set_conv(ConvOp* op, int src1, int src2, int dst, int cols, int l_out) {
 
 template <class Cfg, class T>
 void set_wgrad(WgradOp* op, int lo, int hi1, int hi2, int Ln, int off) {
-  // bf16 rows: exact products on the bf16 matrix cores (wgrad_bf16_kernel), except for the four deepest layers (>= 4096
-  // channel pairs, <= 48 samples per row): their cost is the 115-230 KB partial result every workgroup writes, not the
-  // arithmetic, and the fp32-MFMA kernel with its smaller LDS images gets through that faster (21-37 us against 30-42)
-  constexpr bool deep = Cfg::LO * Cfg::HI >= 4096 && Cfg::TT <= 48;
-  if constexpr (sizeof(T) == 2 && !deep) {
+  // bf16 rows: exact products on the bf16 matrix cores (wgrad_bf16_kernel).  (Round 4 kept the four deepest layers -- >= 4096
+  // channel pairs, <= 48 samples per row -- on the fp32-MFMA kernel: with 256 partial rows per tensor their cost was the
+  // 115-230 KB every workgroup writes.  With the rows capped by bytes (wg_rows_cap: 64 workgroups for 57 k weights) the fp32
+  // form is bound by its matrix time on those few CUs: up0.same 99-118 us against 51 here; the step itself does not move.)
+  if constexpr (sizeof(T) == 2) {
     op->launch = &launch_wgrad_bf16<Cfg>;
   } else {
     op->launch = &launch_wgrad<Cfg, T>;
