@@ -211,7 +211,7 @@ struct Trainer {
   // gradient -> next layer's BatchNorm backward) is a string of short launches that leave most of the chip idle in the deep
   // layers.  Events order the two: ev_gz[L] (gz of L complete) -> wgrad of L; ev_wg (all weight gradients) -> fold + Adam.
   hipStream_t stream_wg = nullptr;
-  hipEvent_t ev_gz[32] = {}, ev_wg = nullptr;
+  hipEvent_t ev_gz[32] = {}, ev_wg = nullptr, ev_wg1 = nullptr;  // ev_wg1: every weight gradient but the first layer's
   std::vector<Tensor> tensors;
   std::vector<Layer> layers;
   std::map<std::string, long> poff;  // parameter name -> offset in the flat blob
@@ -283,6 +283,7 @@ struct Trainer {
     for (hipEvent_t e : ev_gz)
       if (e) (void)hipEventDestroy(e);
     if (ev_wg) (void)hipEventDestroy(ev_wg);
+    if (ev_wg1) (void)hipEventDestroy(ev_wg1);
     for (hipEvent_t e : ev_inputs)
       if (e) (void)hipEventDestroy(e);
   }
@@ -633,6 +634,7 @@ int upload(Trainer& tr, const float* weights) {
   const unsigned ev_dev = hipEventDisableTiming | hipEventReleaseToDevice;
   for (int i = 0; i < NLAYER; ++i) TR_HIP(hipEventCreateWithFlags(&tr.ev_gz[i], ev_dev));
   TR_HIP(hipEventCreateWithFlags(&tr.ev_wg, ev_dev));
+  TR_HIP(hipEventCreateWithFlags(&tr.ev_wg1, ev_dev));
   for (hipEvent_t& e : tr.ev_inputs) TR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   return VP_OK;
 }
@@ -818,8 +820,8 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
   // (same-box sweep of FOLD_EARLY: none 1.414 ms per step, 13: 1.389, 11: 1.405, 9: 1.411, 7: 1.418, 5: 1.436 -- the folds of
   // the deep layers' 15 MB rows take more from the main chain beside them than they save at the end)
   constexpr int FOLD_EARLY = 13;
-  SumJobs jobs{};
-  int sum_blocks = 0;
+  SumJobs jobs{}, jobs_last{};
+  int sum_blocks_main = 0, sum_blocks_last = 0;
   // Layers whose gz gets an event for the weight-gradient stream; the layers between hand their launch to the next event.
   // An event costs the main chain ~5 us (the launch behind a kernel with a completion signal starts that much later):
   // every other layer above level 0, every layer of the last four (their weight gradients are the step's tail).
@@ -879,8 +881,11 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
         }
         n_held = 0;
       }
+      if (li == 1) (void)hipEventRecord(tr.ev_wg1, tr.stream_wg);  // (layer 1 carries an event: its launch is out)
       if (li < FOLD_EARLY) {
-        SumJob& jb = jobs.job[jobs.count++];
+        SumJobs& jset = li == 0 ? jobs_last : jobs;
+        int& sum_blocks = li == 0 ? sum_blocks_last : sum_blocks_main;
+        SumJob& jb = jset.job[jset.count++];
         jb.partial = g.partial;
         jb.out = tr.grad + w.grad_off;
         jb.rows = grid;
@@ -904,9 +909,13 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     }
     if (L.dgrad.used) run_conv(tr, L.dgrad, B);
   }
+  // the fold of everything but the first layer's rows runs beside that layer's weight gradient, the step's last launch on
+  // the other stream; its own few rows behind it
+  (void)hipStreamWaitEvent(s, tr.ev_wg1, 0);
+  TRL(sum_rows_multi_kernel, dim3(sum_blocks_main), dim3(256), 0, s, jobs);
   (void)hipEventRecord(tr.ev_wg, tr.stream_wg);
   (void)hipStreamWaitEvent(s, tr.ev_wg, 0);  // every weight gradient's partial rows are written
-  TRL(sum_rows_multi_kernel, dim3(sum_blocks), dim3(256), 0, s, jobs);
+  TRL(sum_rows_multi_kernel, dim3(sum_blocks_last), dim3(256), 0, s, jobs_last);
   if (update) {
     tr.step += 1;
     const float bc1 = 1.f - powf(tr.beta1, (float)tr.step);
