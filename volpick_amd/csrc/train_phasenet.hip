@@ -798,9 +798,9 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
     hipEvent_t ev_in = tr.ev_inputs[slot];
     tr.ev_inputs_seq[slot] = tr.seq++;
     if (tr.bf16) {
-      gx = (T0 + 511) / 512;
+      gx = (T0 + 1023) / 1024;
       ++g_launches;
-      hipExtLaunchKernelGGL(head_fwd_bwd_pair_kernel<bf16_t>, dim3(gx, B), dim3(256), 0, s, nullptr, ev_in, 0, h);
+      hipExtLaunchKernelGGL((head_fwd_bwd_pair_kernel<bf16_t, 4>), dim3(gx, B), dim3(256), 0, s, nullptr, ev_in, 0, h);
     } else {
       ++g_launches;
       hipExtLaunchKernelGGL(head_fwd_bwd_kernel, dim3(gx, B), dim3(256), 0, s, nullptr, ev_in, 0, h);
