@@ -83,6 +83,7 @@ class PhaseNetTrainer:
                 self._in_flight.clear()
             self._lib.vp_train_destroy(self._h)
             self._h = None
+            self._last_inputs = None
 
     __del__ = close
 
@@ -114,9 +115,12 @@ class PhaseNetTrainer:
             # in-place writes in Tensor._version): that step already waited for whatever produced them.
             torch = _torch()
             producer = torch.cuda.current_stream(xk.device)
-            key = (xk.data_ptr(), xk._version, yk.data_ptr(), yk._version, producer.cuda_stream)
-            if key != getattr(self, "_last_inputs", None):
-                self._last_inputs = key
+            # (the very OBJECTS, held here so that their identity cannot be recycled: a fresh tensor that the allocator
+            # placed at the same address has the same data_ptr and may have the same version, and its producer may still run)
+            last = getattr(self, "_last_inputs", None)
+            same = (last is not None and last[0] is xk and last[1] is yk and last[2] == (xk._version, yk._version, producer.cuda_stream))
+            if not same:
+                self._last_inputs = (xk, yk, (xk._version, yk._version, producer.cuda_stream))
                 ev = torch.cuda.Event()
                 ev.record(producer)
                 if not ev.query():  # (already complete -- a batch prepared well ahead: nothing to wait for either)
