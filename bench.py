@@ -607,8 +607,9 @@ def bench_train(batch=512, steps=30, warmup=5, torch_steps=6, torch_baseline=Tru
         "roofline": {"bound": "mfma", "achieved": flop * batch / dt / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": flop * batch / dt / (PEAK_FP32_TFLOPS * 1e12),
                      "basis": "algorithmic 3 x forward FLOP of the whole step (all launches) / step time, against the dense fp32 "
-                              "rate the reference arithmetic is priced in; the convs run the fp32 MFMA on widened operands, the "
-                              "weight gradients the bf16 MFMA (exact on bf16-stored rows)"},
+                              "rate the reference arithmetic is priced in; since round 5 the convs run the bf16 MFMA with "
+                              "three-piece weights on the bf16-stored rows (two layers the fp32 MFMA), the weight gradients "
+                              "the bf16 MFMA (exact on bf16-stored rows)"},
     }
     tr.close()
     # the same step through stock PyTorch-ROCm (MIOpen / rocBLAS kernels, eager autograd) on this GPU.  On a fresh box MIOpen
