@@ -161,3 +161,40 @@ def test_device_inputs_may_be_refilled_right_after_an_asynchronous_step():
         assert np.abs(got_g[k] - want_g[k]).max() <= 1e-5 * np.abs(want_g[k]).max() + 1e-12, k  # (1e9 junk would be off by 1e9)
     assert np.isfinite(want) and len(spoil) == 4
     tr.close()
+
+
+def test_the_library_tells_which_queued_steps_have_read_their_inputs():
+    """Round 5: the trainer object no longer records an event of its own in the trainer's stream per step; the library keeps
+    a ring of events behind each step's last read of x / y (`vp_train_inputs_consumed_upto`, `vp_train_steps_enqueued`).
+    Steps are numbered from 0; nothing is reported before it has completed; after a host wait everything is; the Python
+    object drops the device batches it kept alive accordingly, and a fresh tensor that the allocator places where the previous
+    batch lay is not mistaken for it (the producer wait is skipped only for the very same, unmodified tensor objects)."""
+    B = 64
+    x, y = make_batch(B, 41)
+    tr = PhaseNetTrainer(PhaseNet.from_pretrained("volpick"), max_batch=B, dtype="bf16")
+    lib, h = tr._lib, tr._h
+    assert lib.vp_train_steps_enqueued(h) == 0 and lib.vp_train_inputs_consumed_upto(h) == -1
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    torch.cuda.synchronize()
+    n = 12  # more than the ring holds
+    for i in range(n):
+        tr.step(xd, yd, lr=0.0, update=False, want_loss=False)
+        assert lib.vp_train_steps_enqueued(h) == i + 1
+        assert -1 <= lib.vp_train_inputs_consumed_upto(h) <= i
+        assert all(seq <= i for seq, _, _ in tr._in_flight)
+    tr.synchronize()
+    assert lib.vp_train_inputs_consumed_upto(h) == n - 1 and not tr._in_flight
+    # host batches are staged by the library: they count as steps but keep nothing alive
+    tr.step(x, y, lr=0.0, update=False)
+    assert lib.vp_train_steps_enqueued(h) == n + 1 and not tr._in_flight
+    # a NEW pair of tensors (whatever their addresses) is waited for: results as from host arrays
+    want = tr.step(x, y, lr=0.0, update=False)
+    for seed in (42, 43):
+        x2, y2 = make_batch(B, seed)
+        ref = tr.step(x2, y2, lr=0.0, update=False)
+        del xd, yd
+        xd, yd = torch.from_numpy(x2).cuda(), torch.from_numpy(y2).cuda()  # may land on the freed blocks
+        got = tr.step(xd, yd, lr=0.0, update=False)
+        assert got == pytest.approx(ref, rel=1e-6)
+    assert np.isfinite(want)
+    tr.close()
