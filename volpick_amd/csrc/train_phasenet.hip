@@ -635,7 +635,7 @@ int upload(Trainer& tr, const float* weights) {
   for (int i = 0; i < NLAYER; ++i) TR_HIP(hipEventCreateWithFlags(&tr.ev_gz[i], ev_dev));
   TR_HIP(hipEventCreateWithFlags(&tr.ev_wg, ev_dev));
   TR_HIP(hipEventCreateWithFlags(&tr.ev_wg1, ev_dev));
-  for (hipEvent_t& e : tr.ev_inputs) TR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (hipEvent_t& e : tr.ev_inputs) TR_HIP(hipEventCreateWithFlags(&e, ev_dev));
   return VP_OK;
 }
 
