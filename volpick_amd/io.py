@@ -75,8 +75,10 @@ def _segments(recs):
     after that record's last sample, within half a period (libmseed trace-list tolerance)."""
     order = np.lexsort((recs["offset"], recs["start_us"], recs["channel"], recs["location"], recs["station"],
                         recs["network"]))
-    r = recs[order]
-    r = r[r["nsamples"] > 0]
+    keep = order if (recs["nsamples"] > 0).all() else order[recs["nsamples"][order] > 0]
+    # (rows of bytes: fancy indexing of a structured array copies field by field -- 1.9 of this function's 2.9 ms per station-day)
+    rows = np.ascontiguousarray(recs).view(np.uint8).reshape(len(recs), recs.dtype.itemsize)
+    r = rows[keep].view(recs.dtype).reshape(-1)
     if len(r) == 0:
         return r, np.zeros(0, np.int64)
     period = np.where(r["sample_rate"] > 0, 1e6 / np.where(r["sample_rate"] > 0, r["sample_rate"], 1.0), 0.0)
