@@ -87,13 +87,10 @@ using W_u2s = WgradCfg<16, 16, 16, 7, 1, 8, 256>;
 using W_u3T = WgradCfg<16, 8, 0, 7, 4, 8, 256>;
 template <int BF> using W_u3s = WgradCfg<8, 8, 8, 7, 1, 8, BF ? W0TT : 256>;
 
-// Where the bf16-MFMA form (conv_train_b16.h) loses to the fp32 one, same-box timeline of the step: the two up0.same-sized
-// layers whose 57 k weights stream per 48-column tile (six bytes per weight as pieces, four as fp32) and down2.same's input
-// gradient (15.5 vs 14.6 us).
+// (No layer keeps the fp32 form for its matrix time any more: with two K-steps of fragments in flight up0.same and its input
+// gradient -- 57 k weights per 48-column tile, six bytes each as pieces instead of four -- were 1-7 us slower on the bf16
+// pipe; with six in flight they are even.  The trait stays for the next such case.)
 template <class Cfg> constexpr bool b16_loses = false;
-template <> constexpr bool b16_loses<F_u0s<1>> = true;  // 29.8 vs 28.7 us
-template <> constexpr bool b16_loses<G_u0s<1>> = true;  // 38.0 vs 31.3 us
-template <> constexpr bool b16_loses<G_d2s<1>> = true;
 
 struct ConvOp {
   bool used = false;
