@@ -58,9 +58,11 @@ typedef struct {
                                       (selects the three-launch plan), bit1 = per-layer clock stamps;
                                  [2]: PhaseNet: 1 = hand-pipelined K loop in the MFMA layers (A/B); EQTransformer: 1 = the three
                                       BiLSTM blocks, two transformer blocks and the pick branches as six launches instead
-                                      of eqt_mid_kernel, 2 = eqt_mid_kernel with one window per 512-thread workgroup
-                                      (default: two windows per 1024-thread workgroup, so that a batch leaves half the
-                                      CUs to the kernels of the other device contexts);
+                                      of the one-launch middle kernel, 2 = eqt_mid_kernel with one window per 512-thread
+                                      workgroup, 3 = with two windows per 1024-thread workgroup (teams of eight waves: the
+                                      default of rounds 3-5); default: eqt_mid4_kernel, FOUR windows per 1024-thread
+                                      workgroup in teams of four waves, so that a batch of 256 holds 64 CUs and leaves the
+                                      rest to the kernels of the other device contexts (all three bit-identical);
                                  [3]: tiled level-0 kernel variants of the all-MFMA plan (A/B); 64 = PhaseNet's one-launch plan
                                       WITHOUT the first-come-first-served gate between the device contexts' forward
                                       launches (A/B: csrc/api.hip ForwardGate);

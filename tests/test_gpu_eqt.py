@@ -163,16 +163,23 @@ def test_forward_parity(model, oracle, B):
         assert (g > 0).all() and (g < 1).all()
 
 
-@pytest.mark.parametrize("B", [1, 2, 5, 256, 257])
-def test_middle_kernel_with_two_windows_per_workgroup_is_bitwise_the_one_window_form(model, B):
-    """Default: eqt_mid_kernel<2> -- 1024 threads, waves 0-7 one window, waves 8-15 the next (roles rotated by two waves), an
-    odd batch's last workgroup computing its last window twice; plan_flags[2] = 2: one window per 512-thread workgroup.
-    Same arithmetic per window: every output bit-identical."""
+@pytest.mark.parametrize("B", [1, 2, 3, 5, 256, 257, 258])
+def test_middle_kernel_with_several_windows_per_workgroup_is_bitwise_the_one_window_form(model, B):
+    """Default: eqt_mid4_kernel -- 1024 threads, FOUR windows per workgroup in teams of four waves (odd teams' roles rotated by
+    two waves), a batch's last workgroup computing its last window up to four times; plan_flags[2] = 3: eqt_mid_kernel<2>, two
+    windows in teams of eight waves (the default of rounds 3-5); plan_flags[2] = 2: one window per 512-thread workgroup.
+    Same arithmetic and the same order of every sum per window: every output bit-identical."""
     x = torch.from_numpy(synthetic_windows(B, 6000, seed=500 + B)).cuda()
     one = EQTransformer.from_pretrained("volpick")
     one._plan_flags = (0, 0, 2)
     one.cuda()
-    assert torch.equal(model._forward_raw(x, preprocess=True), one._forward_raw(x, preprocess=True))
+    two = EQTransformer.from_pretrained("volpick")
+    two._plan_flags = (0, 0, 3)
+    two.cuda()
+    want = one._forward_raw(x, preprocess=True)
+    assert torch.equal(model._forward_raw(x, preprocess=True), want)
+    assert torch.equal(two._forward_raw(x, preprocess=True), want)
+    one._release(), two._release()
 
 
 @pytest.mark.parametrize("B", [1, 2, 5, 256, 257])

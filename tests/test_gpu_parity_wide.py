@@ -245,7 +245,7 @@ PLAN_SELECTORS = {
     "phasenet": [(1,), (0, 1), (0, 0, 1), (0, 0, 0, 1), (0, 0, 0, 2), (0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 2),
                  (0, 0, 0, 0, 0, 3), (0, 0, 0, 0, 0, 4), (0, 0, 0, 0, 0, 5), (0, 0, 0, 0, 0, 6), (0, 0, 0, 0, 0, 7), (0, 0, 0, 0, 0, 8), (0, 0, 0, 0, 0, 9),
                  (0, 0, 0, 0, 0, 0, 1)],
-    "eqtransformer": [(1,), (0, 0, 1), (0, 0, 2), (0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 0, 2)] +
+    "eqtransformer": [(1,), (0, 0, 1), (0, 0, 2), (0, 0, 3), (0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 0, 2)] +
                      [(0, 0, 0, 0, 0, 0, 0, 1 << b) for b in range(13)] + [(0, 0, 0, 0, 0, 0, 0, 0x1F0), (0, 0, 0, 0, 0, 0, 0, 0xF)],
 }
 

@@ -28,8 +28,9 @@ def _scaled_attention(scale, flags=()):
 
 def test_a_windows_attention_form_does_not_depend_on_its_workgroup_partner():
     """Attention projections scaled until SOME windows of the batch leave the |q|, |k| <= 30 guard of the E_q E_k form and
-    others stay inside (checked on the oracle's activations): pairs (2i, 2i + 1) of eqt_mid_kernel<2> are then mixed.  Every
-    window must come out bit-identical to the one-window-per-workgroup plan (plan_flags[2] = 2), whatever it is paired with."""
+    others stay inside (checked on the oracle's activations): pairs (2i, 2i + 1) of eqt_mid_kernel<2> (plan_flags[2] = 3) and the
+    quadruples of eqt_mid4_kernel (the default) are then mixed.  Every window must come out bit-identical to the
+    one-window-per-workgroup plan (plan_flags[2] = 2), whatever it shares a workgroup with."""
     B = 64
     x = synthetic_windows(B, 6000, seed=4242)
     x[1::4] *= 0.02  # quiet windows between loud ones: a spread of activation sizes at the attention input
@@ -53,16 +54,21 @@ def test_a_windows_attention_form_does_not_depend_on_its_workgroup_partner():
     big, small = worst > 30.0 * 1.02, worst < 30.0 * 0.98
     mixed_pairs = int(sum((big[2 * i] and small[2 * i + 1]) or (small[2 * i] and big[2 * i + 1]) for i in range(B // 2)))
     assert mixed_pairs >= 4, (mixed_pairs, np.sort(worst))
-    two, _ = _scaled_attention(scale)
+    mixed_quads = int(sum(big[4 * i:4 * i + 4].any() and small[4 * i:4 * i + 4].any() for i in range(B // 4)))
+    assert mixed_quads >= 4, (mixed_quads, np.sort(worst))
     one, _ = _scaled_attention(scale, (0, 0, 2))
     xt = torch.from_numpy(x).cuda()
-    a, b = two._forward_raw(xt, preprocess=True), one._forward_raw(xt, preprocess=True)
-    assert torch.isfinite(a).all()
-    assert torch.equal(a, b)
-    # ... and whatever a window is paired with: the same windows shifted by one (every window gets another partner)
-    c = two._forward_raw(torch.roll(xt, 1, 0).contiguous(), preprocess=True)
-    assert torch.equal(torch.roll(c, -1, 0), a)
-    two._release(), one._release()
+    b = one._forward_raw(xt, preprocess=True)
+    for flags in ((), (0, 0, 3)):
+        many, _ = _scaled_attention(scale, flags)
+        a = many._forward_raw(xt, preprocess=True)
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b), flags
+        # ... and whatever a window is paired with: the same windows shifted by one (every window gets other partners)
+        c = many._forward_raw(torch.roll(xt, 1, 0).contiguous(), preprocess=True)
+        assert torch.equal(torch.roll(c, -1, 0), a), flags
+        many._release()
+    one._release()
 
 
 def _issued(model, index, rng=None):

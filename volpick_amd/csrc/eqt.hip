@@ -363,7 +363,8 @@ int plan_eqt(Net& net, const ParamView& pv) {
     mid_flops += st.flops_per_window;
     net.steps.push_back(std::move(st));
     // plan_flags[2] = 1 keeps the six separate launches (A/B timing); default: one launch for the whole latency-bound chain,
-    // two windows per workgroup; plan_flags[2] = 2: that launch with one window per workgroup (the form of rounds 1-2)
+    // four windows per workgroup in teams of four waves (eqt_mid4.hip); plan_flags[2] = 3: two windows per workgroup in teams
+    // of eight waves (the default of rounds 3-5); plan_flags[2] = 2: one window per workgroup (the form of rounds 1-2)
     if (net.cfg.plan_flags[2] != 1 && mid_first >= 0 && (int)net.steps.size() == mid_first + 6) {
       Step fused;
       fused.name = "fused.mid (3 BiLSTM + 2 transformer blocks + pick branches)";
@@ -381,7 +382,8 @@ int plan_eqt(Net& net, const ParamView& pv) {
         m.pick = mk_pick(n, B);
         m.clk = n.debug_clock ? reinterpret_cast<unsigned long long*>(n.debug_clock->d) : nullptr;  // slots [B][8] (tools/mid_clock.py)
         m.B = B;
-        return launch_eqt_mid(m, B, s_, n.cfg.plan_flags[2] == 2);
+        if (n.cfg.plan_flags[2] == 2 || n.cfg.plan_flags[2] == 3) return launch_eqt_mid(m, B, s_, n.cfg.plan_flags[2] == 2);
+        return launch_eqt_mid4(m, B, s_);
       };
       net.steps.erase(net.steps.begin() + mid_first, net.steps.end());
       net.steps.push_back(std::move(fused));

@@ -83,8 +83,12 @@ struct MidArgs {
   unsigned long long* clk;  // optional debug: 8 shader-clock stamps per window (start, after each of the six stages, end)
   int B;                    // windows (the two-window workgroups clamp their last window to it)
 };
-// default: two windows per 1024-thread workgroup (128 CUs for a batch of 256); one_window_per_workgroup: the 512-thread form
+// teams of eight waves: two windows per 1024-thread workgroup (128 CUs for a batch of 256; the default of rounds 3-5), or
+// one_window_per_workgroup: the 512-thread form
 int launch_eqt_mid(const MidArgs& a, int B, hipStream_t s, bool one_window_per_workgroup);
+// default since round 6: teams of four waves, FOUR windows per 1024-thread workgroup (64 CUs for a batch of 256), eqt_mid4.hip;
+// bit-identical to the forms above
+int launch_eqt_mid4(const MidArgs& a, int B, hipStream_t s);
 
 int launch_bilstm(const BiLstmArgs& a, int cin, int B, hipStream_t s);
 int launch_transformer(const TransformerArgs& a, int B, hipStream_t s);
