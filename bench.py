@@ -551,6 +551,11 @@ def bench_train(batch=512, steps=30, warmup=5, torch_steps=6, torch_baseline=Tru
     p = rng.integers(300, 1500, batch).astype(float)
     y = gaussian_labels(p, p + rng.integers(200, 1200, batch))
     xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    # the timed loop alternates TWO resident batches, so that every step meets a tensor pair other than the previous step's and
+    # pays what a loader's fresh batch pays (the producer event; no `inputs_unchanged` promise anywhere in the timed region)
+    xd2, yd2 = torch.roll(xd, 1, 0).contiguous(), torch.roll(yd, 1, 0).contiguous()
+    pairs = ((xd, yd), (xd2, yd2))
+    torch.cuda.synchronize()
     tr = PhaseNetTrainer(va.PhaseNet.from_pretrained("volpick"), max_batch=batch, dtype="bf16")
     for _ in range(warmup):
         tr.step(xd, yd, 1e-4, want_loss=False)
@@ -559,18 +564,24 @@ def bench_train(batch=512, steps=30, warmup=5, torch_steps=6, torch_baseline=Tru
     # with the GPU idle: its first ~150 steps ran 15 % slower than tools/train_probe.py's steady 1.65-1.68 ms)
     settle_steps, t_settle = 0, time.perf_counter()
     while time.perf_counter() - t_settle < 0.4:
-        for _ in range(steps):
-            tr.step(xd, yd, 1e-4, want_loss=False)
+        for i in range(steps):
+            tr.step(*pairs[i & 1], 1e-4, want_loss=False)
         tr.synchronize()
         settle_steps += steps
     times = []
     for _ in range(5):
         t0 = time.perf_counter()
-        for _ in range(steps):
-            tr.step(xd, yd, 1e-4, want_loss=False)
+        for i in range(steps):
+            tr.step(*pairs[i & 1], 1e-4, want_loss=False)
         tr.synchronize()
         times.append((time.perf_counter() - t0) / steps)
     dt = statistics.median(times)
+    # beside it: one batch re-run under the caller's promise that nothing wrote to it (no producer event per step)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(xd, yd, 1e-4, want_loss=False, inputs_unchanged=True)
+    tr.synchronize()
+    dt_same = (time.perf_counter() - t0) / steps
     # loss of the batch at the weights the timed steps arrived at (no update), and -- the comparator -- the same batch through
     # torch autograd's forward on the oracle module carrying THE SAME weights and the same bf16 storage points
     w_now = tr.weights()
@@ -597,6 +608,7 @@ def bench_train(batch=512, steps=30, warmup=5, torch_steps=6, torch_baseline=Tru
     out = {
         "metric": "PhaseNet training windows/sec (fwd + loss + bwd + Adam)", "value": batch / dt, "unit": "windows/s",
         "ms_per_step": dt * 1e3, "ms_per_step_all": [t * 1e3 for t in times], "batch": batch, "steps": steps, "warmup": warmup,
+        "inputs": "two resident batches alternating (a fresh tensor pair every step)", "ms_per_step_same_batch_promised": dt_same * 1e3,
         "settle_steps": settle_steps,
         "dtype": "bf16 storage / f32 accumulate", "data": "synthetic (VCSEIS-shaped: 3 x 3001, Gaussian P/S labels sigma 20)",
         "launches_per_step": launches, "launches_without_update": launches_fwd_bwd, "loss_after": loss,

@@ -344,6 +344,11 @@ int vp_mseed_decode(int device_id, const uint8_t* buf, int buf_mem, size_t nbyte
 int vp_mseed_decode_bench(int device_id, const uint8_t* buf_dev, size_t nbytes, const vp_mseed_record* recs,
                           const int64_t* out_index, int64_t n_recs, int out_kind, void* out_dev, int64_t out_len,
                           int iters, float* ms);
+/* vp_mseed_decode keeps its device scratch (file image, sample array of host destinations, record table: ~175 MB after one
+ * host-to-host station-day) per device, grow-only, for the life of the process, and serialises the calls on one device from
+ * their first use of it to their final stream synchronisation.  This frees it (waits for a call in flight; the next decode
+ * allocates again).  bytes_freed may be NULL.  No counterpart in the reference (obspy.read holds no device memory). */
+int vp_mseed_release_scratch(int device_id, size_t* bytes_freed);
 
 /* ---------------------------------------------------------------------------------------------
  * PhaseNet training step (BASELINE config 5): what one

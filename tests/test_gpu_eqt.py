@@ -300,7 +300,7 @@ def test_in_kernel_preprocessing_is_bitwise_gather_normalize(norm, per_comp):
 @pytest.mark.parametrize("blinding", [(500, 500), (1000, 1000), (250, 777), (0, 0), (496, 1), (17, 0), (2999, 2999)])
 def test_decoder_tail_skips_only_blinded_tiles(model, blinding):
     """annotate / classify blind the first and last samples of every window; eqt_tail3_kernel computes only the time tiles that
-    hold kept samples (four tiles of 1264 instead of five of 1200 for blinding (500, 500)).  The stacked rows are bit for bit
+    hold kept samples (four tiles of 1256 instead of five of 1200 for blinding (500, 500)).  The stacked rows are bit for bit
     those of the plan that computes every tile (plan_flags[7] bit 10), for avg and max stacking, with a tail window."""
     full = EQTransformer.from_pretrained("volpick")
     full._plan_flags = (0, 0, 0, 0, 0, 0, 0, 1024)

@@ -211,3 +211,16 @@ def test_read_then_classify_equals_classify_of_the_arrays():
     assert len(pg_d) == len(pg_h) > 0
     for p, q in zip(pg_d, pg_h):
         assert p.phase == q.phase and p.peak_time == q.peak_time and p.peak_value == q.peak_value
+
+
+def test_decode_scratch_can_be_released_and_is_rebuilt():
+    """vp_mseed_decode keeps its device scratch per device between calls; vp_mseed_release_scratch frees it and the
+    next read allocates again with the same result."""
+    rng = np.random.default_rng(77)
+    buf = file_bytes(three_component(9001, rng), reclen=512, encoding=11, byteorder=">")
+    first = va.read(buf)
+    assert vio.release_decode_scratch(0) > 0
+    assert vio.release_decode_scratch(0) == 0  # nothing left to free
+    again = va.read(buf)
+    for a, b in zip(first, again):
+        assert np.array_equal(a.data, b.data)

@@ -168,7 +168,7 @@ def test_the_library_tells_which_queued_steps_have_read_their_inputs():
     a ring of events behind each step's last read of x / y (`vp_train_inputs_consumed_upto`, `vp_train_steps_enqueued`).
     Steps are numbered from 0; nothing is reported before it has completed; after a host wait everything is; the Python
     object drops the device batches it kept alive accordingly, and a fresh tensor that the allocator places where the previous
-    batch lay is not mistaken for it (the producer wait is skipped only for the very same, unmodified tensor objects)."""
+    batch lay is not mistaken for it (the producer wait is skipped only on the caller's explicit promise `inputs_unchanged=True`, never inferred)."""
     B = 64
     x, y = make_batch(B, 41)
     tr = PhaseNetTrainer(PhaseNet.from_pretrained("volpick"), max_batch=B, dtype="bf16")
@@ -197,4 +197,13 @@ def test_the_library_tells_which_queued_steps_have_read_their_inputs():
         got = tr.step(xd, yd, lr=0.0, update=False)
         assert got == pytest.approx(ref, rel=1e-6)
     assert np.isfinite(want)
+    # a refill that torch's version counter does not see (x.data.copy_): without the caller's promise the step waits for it
+    x3, y3 = make_batch(B, 44)
+    ref = tr.step(x3, y3, lr=0.0, update=False)
+    v0 = (xd._version, yd._version)
+    xd.data.copy_(torch.from_numpy(x3), non_blocking=True), yd.data.copy_(torch.from_numpy(y3), non_blocking=True)
+    assert (xd._version, yd._version) == v0
+    assert tr.step(xd, yd, lr=0.0, update=False) == pytest.approx(ref, rel=1e-6)
+    # ... and with the promise kept (nothing written in between) the shortcut gives the same numbers
+    assert tr.step(xd, yd, lr=0.0, update=False, inputs_unchanged=True) == pytest.approx(ref, rel=1e-6)
     tr.close()

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Cycles per phase of the fused ResCNN kernel (eqt_res3_kernel): debug plan flag bit 1 = shader-clock stamps of workgroup 0."""
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch  # noqa: E402
+
+import volpick_amd as va  # noqa: E402
+from volpick_amd import _lib  # noqa: E402
+from volpick_amd.synthetic import synthetic_windows  # noqa: E402
+
+B = 256
+m = va.EQTransformer.from_pretrained("volpick")
+m._plan_flags = (0, 2)
+m.cuda()
+x = torch.from_numpy(synthetic_windows(B, 6000, seed=1)).cuda()
+for _ in range(5):
+    m._forward_raw(x, preprocess=True)
+clk = np.zeros(64 * 8, np.uint64)
+lib = _lib.load()
+lib.vp_debug_conv_clock(m._handle, clk.ctypes.data_as(C.c_void_p), 64)
+c = clk.astype(np.int64)[:20]
+names = ["L2 warm-up", "zero fill", "load x, act (split)"] + [f"block {i} conv{j}" for i in range(7) for j in (1, 2)] + ["store"]
+for n, v in zip(names, np.diff(c)):
+    print(f"{n:24s} {v:8d}")
+print("total", c[len(names)] - c[0])

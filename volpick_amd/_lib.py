@@ -170,6 +170,7 @@ SIGNATURES = {
         [C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(VpMseedRecord), _I64P, _I64P, C.c_int64, C.c_int,
          C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_int32)],
     ),
+    "vp_mseed_release_scratch": (C.c_int, [C.c_int, C.POINTER(C.c_size_t)]),
     "vp_mseed_decode_bench": (
         C.c_int,
         [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(VpMseedRecord), _I64P, C.c_int64, C.c_int, C.c_void_p, C.c_int64,

@@ -191,6 +191,7 @@ struct Res3Args {
   long af_bytes_k3, af_bytes_k2;  // size of one conv's operand (L2 warm-up)
   int warm;                       // 0: no pre-touch of the weights (plan flag plan_flags[4] = 1)
   int n_windows;                  // eqt_res3_kernel<2>: the last workgroup of an odd batch clamps its second window to it
+  unsigned long long* clk;        // debug (plan_flags[1] & 2): shader-clock stamps of workgroup 0 (tools/res3_clock.py)
 };
 
 __device__ __forceinline__ void split3(const float v, unsigned short& h, unsigned short& m, unsigned short& l) {
@@ -212,6 +213,11 @@ __device__ __forceinline__ void store3(bf16_t* img, const int col, const int ch,
   *reinterpret_cast<uint2*>(p + 2 * R3_PS) = make_uint2(l0, l1);
 }
 
+// R3_EXP (timing probes of tools/, never in the product build; results are WRONG with any of them):
+//   1 = every conv reuses block 0's operands (no weight stream after the first request), 2 = no MFMAs, 4 = no piece stores
+#ifndef R3_EXP
+#define R3_EXP 0
+#endif
 template <int TAPS>
 struct Res3A {
   uint4 q[TAPS * 2][3];
@@ -222,7 +228,10 @@ struct Res3A {
 #pragma unroll
     for (int st = 0; st < TAPS * 2; ++st)
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) q[st][pc] = p[(st * 3 + pc) * 64];
+      for (int pc = 0; pc < 3; ++pc) {
+        if (R3_EXP & 1) q[st][pc] = make_uint4(0x3c003c00u + lane, 0x3c003c00u + st, 0x3c003c00u + pc, 0x3c003c00u);  // no memory
+        else q[st][pc] = p[(st * 3 + pc) * 64];
+      }
     const int co = mt * 16 + 4 * (lane >> 4);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -265,6 +274,9 @@ __device__ __forceinline__ void res3_mac(const bf16_t* src, const Res3A<TAPS>& A
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           const uint4(&b)[3] = (s & 1) ? bB[j] : bA[j];
+          if (R3_EXP & 2) {
+            acc[j][0] += __uint_as_float(A.q[s][WP[t]].x ^ b[XP[t]].x);  // keeps the operands alive
+          } else
           acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_res, A.q[s][WP[t]]),
                                                           __builtin_bit_cast(bf16x8_res, b[XP[t]]), acc[j], 0, 0, 0);
         }
@@ -289,6 +301,11 @@ __global__ __launch_bounds__(256 * WPB) void eqt_res3_kernel(const Res3Args a) {
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int win = min((int)blockIdx.x * WPB + team, a.n_windows - 1);
   const int g = lane >> 4, n = lane & 15;
+  unsigned long long* clk = (a.clk && threadIdx.x == 0 && blockIdx.x == 0) ? a.clk : nullptr;
+  int stamp = 0;
+#define R3_STAMP() \
+  if (clk) clk[stamp++] = __builtin_readcyclecounter();
+  R3_STAMP()
   if (a.warm && team == 0) {
     // The weights (1 MB) have left L2 since the last launch (the other kernels of the step move 0.3 GB): every XCD's L2 is
     // warmed up front, one word per 128-byte line (see eqt_res_kernel) -- by ALL workgroups of the XCD, each a slice of the
@@ -307,11 +324,13 @@ __global__ __launch_bounds__(256 * WPB) void eqt_res3_kernel(const Res3Args a) {
     }
     if (sink == 0x12345678u && a.ls_x == -1) a.out[0] = __uint_as_float(sink);  // never true: keeps the loads alive
   }
+  R3_STAMP()
   for (int i = tid; i < 3 * R3_PS / 8; i += 256) {  // zero halo columns (and everything else once)
     reinterpret_cast<uint4*>(ACT)[i] = make_uint4(0u, 0u, 0u, 0u);
     reinterpret_cast<uint4*>(MID)[i] = make_uint4(0u, 0u, 0u, 0u);
   }
   __syncthreads();
+  R3_STAMP()
   {
     const float* x0 = a.x0 + (long)win * a.ws_x + HALO;
     const float* a0 = a.act0 + (long)win * a.ws_a + HALO;
@@ -328,6 +347,7 @@ __global__ __launch_bounds__(256 * WPB) void eqt_res3_kernel(const Res3Args a) {
     }
   }
   __syncthreads();
+  R3_STAMP()
   const int co = wave * 16 + 4 * g;  // this lane's four output channels
   f32x4 acc[3];
   // conv1: MID = relu(conv(ACT) + b) (BatchNorm folded); conv2: X += conv(MID) + b, ACT = relu(s X + b') for the next block
@@ -338,6 +358,9 @@ __global__ __launch_bounds__(256 * WPB) void eqt_res3_kernel(const Res3Args a) {
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = (t < RT) ? fmaxf(acc[j][r] + bv[r], 0.f) : 0.f;
+      if (R3_EXP & 4) {
+        if (v[0] + v[1] + v[2] + v[3] == 1234.5f) MID[t] = 1;
+      } else
       store3(MID, t + 1, co, v);
     }
   };
@@ -355,36 +378,42 @@ __global__ __launch_bounds__(256 * WPB) void eqt_res3_kernel(const Res3Args a) {
         }
         v[r] = (t < RT) ? fmaxf(fmaf(sv[r], o, ov[r]), 0.f) : 0.f;
       }
+      if (R3_EXP & 4) {
+        if (v[0] + v[1] + v[2] + v[3] == 1234.5f) ACT[t] = 1;
+      } else
       if (!last) store3(ACT, t + 1, co, v);
     }
   };
+#define R3_W(I, TAPS) ((R3_EXP & 1) ? ((TAPS) == 3 ? 0 : 4) : (I))
 #define R3_BLOCK(I, TAPS, NEXT_LOAD)                                                              \
   {                                                                                               \
     Res3A<TAPS> w2;                                                                               \
-    w2.load(a.af2[I], a.bs2[I], (I) == 6 ? nullptr : a.s_next[I], (I) == 6 ? nullptr : a.b_next[I], wave, lane); \
+    w2.load(a.af2[R3_W(I, TAPS)], a.bs2[I], (I) == 6 ? nullptr : a.s_next[I], (I) == 6 ? nullptr : a.b_next[I], wave, lane); \
     res3_mac<TAPS>(ACT, w1_##I, acc, lane);                                                       \
     conv1_epilogue(w1_##I.bias);                                                                  \
     __syncthreads();                                                                              \
+    R3_STAMP()                                                                                    \
     NEXT_LOAD                                                                                     \
     res3_mac<TAPS>(MID, w2, acc, lane);                                                           \
     conv2_epilogue(w2.bias, w2.sn, w2.bn, (I) == 6);                                              \
     __syncthreads();                                                                              \
+    R3_STAMP()                                                                                    \
   }
   // kernel sizes of the seven blocks: 3 3 3 3 2 3 2; the next block's conv1 operand is requested before this block's conv2
   Res3A<3> w1_0;
   w1_0.load(a.af1[0], a.bs1[0], nullptr, nullptr, wave, lane);
   Res3A<3> w1_1;
-  R3_BLOCK(0, 3, w1_1.load(a.af1[1], a.bs1[1], nullptr, nullptr, wave, lane);)
+  R3_BLOCK(0, 3, w1_1.load(a.af1[R3_W(1, 3)], a.bs1[1], nullptr, nullptr, wave, lane);)
   Res3A<3> w1_2;
-  R3_BLOCK(1, 3, w1_2.load(a.af1[2], a.bs1[2], nullptr, nullptr, wave, lane);)
+  R3_BLOCK(1, 3, w1_2.load(a.af1[R3_W(2, 3)], a.bs1[2], nullptr, nullptr, wave, lane);)
   Res3A<3> w1_3;
-  R3_BLOCK(2, 3, w1_3.load(a.af1[3], a.bs1[3], nullptr, nullptr, wave, lane);)
+  R3_BLOCK(2, 3, w1_3.load(a.af1[R3_W(3, 3)], a.bs1[3], nullptr, nullptr, wave, lane);)
   Res3A<2> w1_4;
-  R3_BLOCK(3, 3, w1_4.load(a.af1[4], a.bs1[4], nullptr, nullptr, wave, lane);)
+  R3_BLOCK(3, 3, w1_4.load(a.af1[R3_W(4, 2)], a.bs1[4], nullptr, nullptr, wave, lane);)
   Res3A<3> w1_5;
-  R3_BLOCK(4, 2, w1_5.load(a.af1[5], a.bs1[5], nullptr, nullptr, wave, lane);)
+  R3_BLOCK(4, 2, w1_5.load(a.af1[R3_W(5, 3)], a.bs1[5], nullptr, nullptr, wave, lane);)
   Res3A<2> w1_6;
-  R3_BLOCK(5, 3, w1_6.load(a.af1[6], a.bs1[6], nullptr, nullptr, wave, lane);)
+  R3_BLOCK(5, 3, w1_6.load(a.af1[R3_W(6, 2)], a.bs1[6], nullptr, nullptr, wave, lane);)
   R3_BLOCK(6, 2, )
 #undef R3_BLOCK
   float* out = a.out + (long)win * a.ws_out + HALO;
@@ -392,6 +421,8 @@ __global__ __launch_bounds__(256 * WPB) void eqt_res3_kernel(const Res3Args a) {
     const int c = i / RT, t = i - c * RT;
     out[(long)c * a.ls_out + t] = X[c * R3_XS + t];
   }
+  R3_STAMP()
+#undef R3_STAMP
 }
 
 // ---- the same with TWO waves per SIMD: K split over wave pairs -----------------------------------------------------------
@@ -705,6 +736,9 @@ int plan_eqt_fuse_res(Net& net) {
       a.af_bytes_k2 = 4L * 2 * 2 * 3 * 64 * 16;
       a.warm = n.cfg.plan_flags[4] != 1;
       a.n_windows = B;
+      a.clk = (n.debug_clock && n.debug_clock->d)  // the conv launches' region: unused under the fused plan
+                  ? reinterpret_cast<unsigned long long*>(n.debug_clock->d) + (size_t)n.max_batch * 32
+                  : nullptr;
       if (n.cfg.plan_flags[7] & 4096)  // bit 12: eight waves per window, K split over wave pairs (round 2's default: 31.5 us on 256 CUs)
         hipLaunchKernelGGL(eqt_res3k_kernel, dim3(B), dim3(R3K_NTH), R3K_LDS_BYTES, s, a);
       else if (n.cfg.plan_flags[7] & 512)  // bit 9: four waves per window, one window per workgroup

@@ -31,6 +31,10 @@ constexpr int M4_WPB = 4;      // windows per workgroup
 constexpr int M4_POOL = 9184;  // floats per window; the stages carve it up in turn
 static_assert((M4_POOL * 4) % 16 == 0 && M4_WPB * (M4_POOL + 16 * 48) * 4 <= 160 * 1024 - 256, "four windows fit a CU's LDS");
 
+// Debug clock stamps inside the stages (slots 8.. of the window's 32, the slots of eqt_mid_kernel: tools/mid_clock.py)
+#define M4_SUB(slot) \
+  if (sub && MID_TID == 0) sub[slot] = __builtin_readcyclecounter();
+
 __device__ __forceinline__ int m4_wave() { return __builtin_amdgcn_readfirstlane(MID_TID >> 6); }
 
 template <int CIN>
@@ -52,7 +56,7 @@ __device__ __forceinline__ void bi4_load(Bi4Frags<CIN>& g, const BiLstmArgs& a) 
 
 template <int CIN, class Prefetch>
 __device__ void mid4_bilstm(const BiLstmArgs& a, Bi4Frags<CIN>& g, const int b, float* P, float* cur, const bool from_memory,
-                            Prefetch&& prefetch) {
+                            Prefetch&& prefetch, unsigned long long* sub) {
   const int tid = MID_TID, lane = tid & 63, wave = m4_wave();
   float* gx = P;                // [2][T * GXS]
   float* hc = P + 2 * T * GXS;  // [32][48] recurrence outputs ...
@@ -77,9 +81,11 @@ __device__ void mid4_bilstm(const BiLstmArgs& a, Bi4Frags<CIN>& g, const int b, 
     lds_barrier();  // not __syncthreads(): the weight loads stay in flight
     x = xs;
   }
+  M4_SUB(8)
   lstm_project_mfma<CIN>(g.f[0], x, gx, wave);
   lstm_project_mfma<CIN>(g.f[1], x, gx + T * GXS, wave);
   __syncthreads();  // xs is dead from here
+  M4_SUB(9)
   if (wave < 2) {   // W_hh has arrived long ago; say so before the new requests queue up behind it (loads complete in order)
 #pragma unroll
     for (int j = 0; j < EQT_H / 2; ++j) asm volatile("" ::"v"(g.whh[j]));
@@ -94,6 +100,7 @@ __device__ void mid4_bilstm(const BiLstmArgs& a, Bi4Frags<CIN>& g, const int b, 
     lstm_recur<GXS, true>(gx + wave * T * GXS, g.whh, wave == 1, hc + wave * 16 * 48, 48);
   }
   __syncthreads();
+  M4_SUB(10)
   if (wave >= 1) {  // Conv1d(32,16,1) + BatchNorm, folded
     float* dst = a.dst + (long)b * a.ws_dst;
     const int n0 = 16 * (wave - 1), t = n0 + (lane & 15);
@@ -116,7 +123,7 @@ __device__ void mid4_bilstm(const BiLstmArgs& a, Bi4Frags<CIN>& g, const int b, 
 //   q, k: [T][KP],  e: [48][AES];  `finish(acc, n0)`: what waves 0-2 do with their tile of a.x
 template <class Prefetch, class Finish>
 __device__ void mid4_attention(const AttnFrag& f, const float wa_lane, const float* x, float (*q)[KP], float (*k)[KP], float* e,
-                               const float eps, const int width, Prefetch&& prefetch, Finish&& finish) {
+                               const float eps, const int width, Prefetch&& prefetch, Finish&& finish, unsigned long long* sub) {
   const int tid = MID_TID, lane = tid & 63, wave = m4_wave();
   {
     const int mt = wave;  // q rows 0-15, 16-31, k rows 0-15, 16-31
@@ -140,6 +147,7 @@ __device__ void mid4_attention(const AttnFrag& f, const float wa_lane, const flo
       }
     }
     __syncthreads();
+    M4_SUB(1)
     // Loads complete in order: whatever the wave still needs from EARLIER requests is taken out of its registers before the
     // new requests go out, or its first use would wait for them as well.
     float wa[32];
@@ -147,11 +155,14 @@ __device__ void mid4_attention(const AttnFrag& f, const float wa_lane, const flo
     __builtin_amdgcn_sched_barrier(0);
     prefetch();
     __builtin_amdgcn_sched_barrier(0);
+    M4_SUB(0)
     attn_scores<AES, 8>(q, k, e, wa, plain);
   }
   __syncthreads();
+  M4_SUB(2)
   attn_softmax<AES, true>(e, eps, width);
   __syncthreads();
+  M4_SUB(3)
   if (wave < 3) {  // vT[c][i] = sum_j x[c][j] a[i][j]: A = x rows out of LDS, B(k = j, n = i) = a[i][j]
     const int n0 = 16 * wave;
     const float* ap = x + (lane & 15) * 48 + (lane >> 4) * 12;          // K index of (lane group g, step ks) = 12 g + ks
@@ -162,6 +173,7 @@ __device__ void mid4_attention(const AttnFrag& f, const float wa_lane, const flo
     finish(acc, n0);
   }
   __syncthreads();
+  M4_SUB(4)
 }
 
 struct Tr4Frags {
@@ -191,7 +203,8 @@ __device__ __forceinline__ void tr4_load_late(Tr4Frags& g, const TransformerArgs
 }
 
 template <class Prefetch>
-__device__ void mid4_transformer(const TransformerArgs& a, Tr4Frags& g, const int b, float* P, float* cur, Prefetch&& prefetch) {
+__device__ void mid4_transformer(const TransformerArgs& a, Tr4Frags& g, const int b, float* P, float* cur, Prefetch&& prefetch,
+                                 unsigned long long* sub) {
   const int tid = MID_TID, lane = tid & 63, wave = m4_wave();
   float(*q)[KP] = reinterpret_cast<float(*)[KP]>(P);
   float(*k)[KP] = q + T;
@@ -200,6 +213,7 @@ __device__ void mid4_transformer(const TransformerArgs& a, Tr4Frags& g, const in
   float* y1T = P + 128 * 48;  // [16][48] LN1 output
   float* rT = y1T + 16 * 48;  // [16][48] the second K half of the second linear layer
   static_assert(2 * T * KP + 48 * AES <= 128 * 48 && 128 * 48 + 2 * 16 * 48 <= M4_POOL, "transformer stage fits the pool");
+  M4_SUB(11)
   // y1 = LN1(x + attention(x)) right in the epilogue of the a.x product (three waves, four channels per lane)
   mid4_attention(
       g.af, g.wa_lane, cur, q, k, e, a.attn_eps, 0,
@@ -215,8 +229,10 @@ __device__ void mid4_transformer(const TransformerArgs& a, Tr4Frags& g, const in
         layer_norm_mfma<0>(z, g.ln_par, a.ln_eps);
 #pragma unroll
         for (int r = 0; r < 4; ++r) y1T[(c0 + r) * 48 + col] = z[r];  // all 48 columns: column 47 is padding
-      });
+      },
+      sub ? sub + 20 : nullptr);
   const float ln_par = g.ln_par;
+  M4_SUB(13)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {  // FF: Linear(16,128) + ReLU
 #pragma unroll
@@ -229,6 +245,7 @@ __device__ void mid4_transformer(const TransformerArgs& a, Tr4Frags& g, const in
     }
   }
   __syncthreads();
+  M4_SUB(14)
   // Linear(128,16) in two K halves, as the eight-wave team sums them: bias + first half (waves 0, 1), plus the second half
   // (waves 2, 3, handed over through LDS)
   const int half = wave >> 1, nt0 = (wave & 1) ? 2 : 0, ntn = (wave & 1) ? 1 : 2;
@@ -245,6 +262,7 @@ __device__ void mid4_transformer(const TransformerArgs& a, Tr4Frags& g, const in
     }
   }
   __syncthreads();
+  M4_SUB(15)
   if (!half) {  // LN2(y1 + FF(y1)) and the stage's outputs, from the accumulators of the first K half
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -267,6 +285,7 @@ __device__ void mid4_transformer(const TransformerArgs& a, Tr4Frags& g, const in
       }
     }
   }
+  M4_SUB(16)
   __syncthreads();
 }
 
@@ -284,7 +303,7 @@ __device__ __forceinline__ void pick4_load(Pick4Frags& g, const PickBranchArgs& 
                // score loop this runs under has no registers to spare
 }
 
-__device__ void mid4_pick(const PickBranchArgs& a, Pick4Frags& g, const int b, float* P, const float* cur) {
+__device__ void mid4_pick(const PickBranchArgs& a, Pick4Frags& g, const int b, float* P, const float* cur, unsigned long long* sub) {
   const int tid = MID_TID, wave = m4_wave();
   float* gx = P;                 // [2][T * GXS] input projections of the P and the S branch ...
   float(*q)[KP] = reinterpret_cast<float(*)[KP]>(P);  // ... and, once the recurrences have read them, q / k / e
@@ -293,11 +312,13 @@ __device__ void mid4_pick(const PickBranchArgs& a, Pick4Frags& g, const int b, f
   float* hl = P + 2 * T * GXS;   // [2][16][48] LSTM outputs of the P and the S branch
   float* vT = hl + 2 * 16 * 48;  // [16][48]
   static_assert(2 * T * KP + 48 * AES <= 2 * T * GXS && 2 * T * GXS + 3 * 16 * 48 <= M4_POOL, "pick stage fits the pool");
+  M4_SUB(17)
   if (tid < 32) hl[tid * 48 + 47] = 0.f;  // K padding of the a.x products
   lstm_load_whh(g.whh, (wave & 1) ? a.lstm[1] : a.lstm[0]);  // every wave: no branch, see bi_load
   lstm_project_mfma<EQT_H>(g.f[0], cur, gx, wave);
   lstm_project_mfma<EQT_H>(g.f[1], cur, gx + T * GXS, wave);
   __syncthreads();
+  M4_SUB(18)
   if (wave < 2) {
 #pragma unroll
     for (int j = 0; j < EQT_H / 2; ++j) asm volatile("" ::"v"(g.whh[j]));  // see mid4_bilstm
@@ -316,6 +337,7 @@ __device__ void mid4_pick(const PickBranchArgs& a, Pick4Frags& g, const int b, f
     lstm_recur<GXS, true>(gx + wave * T * GXS, g.whh, false, hl + wave * 16 * 48, 48);
   }
   __syncthreads();  // gx is dead from here
+  M4_SUB(19)
 #pragma unroll
   for (int br = 0; br < 2; ++br) {
     mid4_attention(g.af[br], g.wa_lane[br], hl + br * 16 * 48, q, k, e, a.attn_eps, a.width, NoPrefetch(),
@@ -325,7 +347,8 @@ __device__ void mid4_pick(const PickBranchArgs& a, Pick4Frags& g, const int b, f
 #pragma unroll
                        for (int r = 0; r < 4; ++r) vT[(4 * ((tid & 63) >> 4) + r) * 48 + i] = acc[r];
                      }
-                   });
+                   },
+                   sub && br ? sub + 26 : nullptr);
     float* up = a.up + (long)((1 + br) * a.B + b) * a.ws_up + HALO;
     for (int idx = tid; idx < EQT_H * 48; idx += M4_NTH) {
       const int c = idx / 48, t = idx - c * 48;
@@ -345,6 +368,7 @@ __global__ __launch_bounds__(M4_WPB* M4_NTH) void eqt_mid4_kernel(const MidArgs 
   float* cur = cur_all + team * 16 * 48;
   const int b = min((int)blockIdx.x * M4_WPB + team, a.B - 1);
   int stamp = 0;
+  unsigned long long* sub = a.clk ? a.clk + (long)b * 32 : nullptr;
   if (MID_TID < 16) cur[MID_TID * 48 + 47] = 0.f;  // K padding of the a.x products; no stage writes column 47
   {  // every cache line of the argument block requested at once (see eqt_mid_kernel)
     typedef const unsigned __attribute__((address_space(4))) * uptr_t;
@@ -363,17 +387,17 @@ __global__ __launch_bounds__(M4_WPB* M4_NTH) void eqt_mid4_kernel(const MidArgs 
   Bi4Frags<EQT_H> g1, g2;
   Tr4Frags t0, t1;
   Pick4Frags pf;
-  mid4_bilstm<64>(a.lstm[0], g0, b, P, cur, true, [&] { bi4_load<EQT_H>(g1, a.lstm[1]); });
+  mid4_bilstm<64>(a.lstm[0], g0, b, P, cur, true, [&] { bi4_load<EQT_H>(g1, a.lstm[1]); }, sub);
   M4_STAMP()
-  mid4_bilstm<EQT_H>(a.lstm[1], g1, b, P, cur, false, [&] { bi4_load<EQT_H>(g2, a.lstm[2]); });
+  mid4_bilstm<EQT_H>(a.lstm[1], g1, b, P, cur, false, [&] { bi4_load<EQT_H>(g2, a.lstm[2]); }, nullptr);
   M4_STAMP()
-  mid4_bilstm<EQT_H>(a.lstm[2], g2, b, P, cur, false, [&] { tr4_load_early(t0, a.tr[0]); });
+  mid4_bilstm<EQT_H>(a.lstm[2], g2, b, P, cur, false, [&] { tr4_load_early(t0, a.tr[0]); }, nullptr);
   M4_STAMP()
-  mid4_transformer(a.tr[0], t0, b, P, cur, [&] { tr4_load_early(t1, a.tr[1]); });
+  mid4_transformer(a.tr[0], t0, b, P, cur, [&] { tr4_load_early(t1, a.tr[1]); }, nullptr);
   M4_STAMP()
-  mid4_transformer(a.tr[1], t1, b, P, cur, [&] { pick4_load(pf, a.pick); });
+  mid4_transformer(a.tr[1], t1, b, P, cur, [&] { pick4_load(pf, a.pick); }, sub);
   M4_STAMP()
-  mid4_pick(a.pick, pf, b, P, cur);
+  mid4_pick(a.pick, pf, b, P, cur, sub);
   M4_STAMP()
 #undef M4_STAMP
 }

@@ -112,8 +112,10 @@ __device__ void lstm_recur(const float* gx, const f32x2 (&whh)[EQT_H / 2], const
     for (int j = 0; j < EQT_H / 2; j += 2) {  // h of unit u lives in the quad 4u .. 4u + 3
       const f32x2 ha = {lane_bcast(h, 8 * j), lane_bcast(h, 8 * j + 4)};
       const f32x2 hb = {lane_bcast(h, 8 * j + 8), lane_bcast(h, 8 * j + 12)};
-      ga = __builtin_elementwise_fma(whh[j], ha, ga);
-      gb = __builtin_elementwise_fma(whh[j + 1], hb, gb);
+      // four scalar FMAs, not two v_pk_fma_f32: on gfx950 the packed form is no faster (the fp32 rate needs no packing) and its
+      // operand pairs cost moves; measured 27.7 k -> 26.2 k cycles per 47 steps with two recurrence waves per SIMD (LOG.md, round 6)
+      ga.x = fmaf(whh[j].x, ha.x, ga.x), ga.y = fmaf(whh[j].y, ha.y, ga.y);
+      gb.x = fmaf(whh[j + 1].x, hb.x, gb.x), gb.y = fmaf(whh[j + 1].y, hb.y, gb.y);
     }
     const float g0 = ga.x, g1 = ga.y, g2 = gb.x, g3 = gb.y;
     const float g = (g0 + g1) + (g2 + g3);

@@ -50,12 +50,15 @@ constexpr int T_OUT = 6000;
 constexpr int T3_NTH = 512, T3_WAVES = 8;
 constexpr int HSB = 81, OUT_QS = 16 * HSB, OUT_PS = 2 * OUT_QS;  // heads' staging: 8-byte units per row / quad plane / piece
 constexpr int HT_N = 43;                                         // head table entries: k = -15 .. 27
-// Two tilings of a row.  TW = 1200: five tiles cover the 6000 samples (the form of round 2).  TW = 1264: FOUR tiles cover the
-// 5008 samples [496, 5504) that are left when the caller blinds 500 samples at either end of every window (README.md:58,
+// Two tilings of a row.  TW = 1200: five tiles cover the 6000 samples (the form of round 2).  TW = 1256: FOUR tiles cover the
+// 5004 samples [496, 5500) that are left when the caller blinds 500 samples at either end of every window (README.md:58,
 // BASELINE configs[2]) -- the blinded samples are never stacked, so their tiles are not computed: the launch walks the
 // output range [t_lo, t_hi) it is given, in whichever tiling needs fewer tiles (plan_eqt_fuse_tail_b3).  The wider tile
-// fits the same 157 KB: stage 6 still computes 640 columns (needs 638), stages 4 and 5 one n-tile more per wave (192 / 384
-// columns for 164 / 322 needed), whose surplus outputs beyond the stage-6 image are not stored.
+// fits the same 157 KB: stage 6 still computes 640 columns (needs 634), stage 5 still 320 (needs exactly 320: rounds 3-5 used
+// TW = 1264, which needs 322 -- one n-tile more for every wave of stage 5, 17 % of that stage, for eight samples nobody keeps),
+// stage 4 one n-tile more for the younger waves (192 columns for 163 needed).  TW is a multiple of 8, not of 16: the heads' last
+// 16-sample block of a tile is half used.  The zero-weight padded taps of stage 6 reach two columns past what stage 5 writes:
+// those columns are zeroed per tile (0 x stale NaN would be NaN).
 template <int TW_>
 struct T3 {
   static constexpr int TW = TW_;
@@ -63,16 +66,19 @@ struct T3 {
   // issue first; with equal shares the younger wave was still a quarter of a stage behind when the older one was through
   // (tools/tail_clock.py).  TW = 1200: stage 4 needs 10 n-tiles per phase: 3 to the older, 2 to the younger wave; stages 5 and 6
   // measured no faster with 6 + 4 than with 5 + 5
-  static constexpr int NB4O = 3, NB4Y = TW_ > 1200 ? 3 : 2, NB5 = TW_ > 1200 ? 6 : 5, NB6 = 5;
+  static constexpr int NB4O = 3, NB4Y = TW_ > 1200 ? 3 : 2, NB5 = 5, NB6 = 5;
   static constexpr int C4 = 2 * (NB4O + NB4Y) * 16, C5 = 4 * NB5 * 16, C6 = T3_WAVES * NB6 * 16;  // columns computed per stage
   // stage-3 samples a tile parks: what its kept outputs need + the one more that reaches them through the zero-weight padded
   // taps of stages 5 / 6 and the heads (0 x stale non-finite = NaN)
   static constexpr int PARK_COLS = TW_ > 1200 ? 176 : 168;
-  static constexpr int NC4 = 208, NC5 = C5 + 16, NC6 = C6 + 16;  // image columns (a place for every column a stage reads)
+  static constexpr int NC4 = 208, NC5 = (2 * C4 > C5 + 16 ? 2 * C4 : C5 + 16), NC6 = C6 + 16;  // image columns (a place for every column a stage reads or writes)
+  static constexpr int BLOCKS = (TW_ + 15) / 16;  // the heads' 16-sample blocks of a tile (the last one half used where TW % 16 = 8)
   using Q4 = B3Chunk<32, NC4>;                                    // chunk-plane images (conv_b3.h)
   using Q5 = B3Chunk<16, NC5>;
   using Q6 = B3Chunk<16, NC6>;
   static constexpr bool GUARD5 = 2 * C5 > NC6;  // stage 5 computes columns beyond the stage-6 image: those stores are skipped
+  // columns of the stage-6 input image behind what stage 5 writes that a kept output reaches through zero-weight taps: zeroed per tile
+  static constexpr bool ZERO6 = (TW_ + 12) / 2 + 7 >= 2 * C5;
   static constexpr int R0_BYTES = 3 * Q6::PS * 2, R1_BYTES = 3 * OUT_PS * 8;
   static constexpr int A5_N = 2 * B3Steps<16, 5>::STEPS * 3 * 64, A6_N = B3Steps<16, 7>::STEPS * 3 * 64;  // uint4: operands of stages 5 and 6
   static constexpr int OFF_R1 = R0_BYTES, OFF_HT = OFF_R1 + R1_BYTES, OFF_A5 = OFF_HT + 3 * HT_N * 16 + 48, OFF_A6 = OFF_A5 + A5_N * 16;
@@ -82,9 +88,10 @@ struct T3 {
                 "LDS budget");
   static_assert(NC4 >= PARK_COLS && NC5 >= C5 + 6 && NC6 >= C6 + 8 && NC5 >= 2 * C4 && (GUARD5 || NC6 >= 2 * C5) && HSB % 2 == 1,
                 "every column a stage reads or writes has a place");
-  static_assert(TW % 16 == 0 && TW % 8 == 0, "tile grid");
+  static_assert(TW % 8 == 0, "tile grid: 16-byte stores of the heads, whole stage-3 samples");
   // what a tile needs (file comment) is computed, and what is computed has a place
-  static_assert(TW + 11 <= 2 * C6 && C6 / 8 <= HSB - 1 && (TW / 16 + 15) / 16 <= T3_WAVES, "stage 6 / heads");
+  static_assert(TW + 11 <= 2 * C6 && C6 / 8 <= HSB - 1 && (BLOCKS + 15) / 16 <= T3_WAVES, "stage 6 / heads");
+  static_assert((TW + 12) / 2 + 7 < NC6 && (!ZERO6 || 2 * C5 % 2 == 0), "the padded taps of stage 6 stay inside its input image");
   static_assert(TW / 2 + 6 + 6 <= 2 * C5 && TW / 2 + 6 + 6 <= NC6 && TW / 4 + 6 + 5 <= 2 * C4 && TW / 8 + 6 + 4 <= PARK_COLS, "halo chain");
   // ... and everything a kept output touches, zero-weight taps included, is this tile's data: heads staged t <= TW + 12 -> stage-6
   // column <= (TW + 12) / 2 -> stage-5 sample + 7 -> stage-5 column -> stage-4 sample + 1 + 5 -> stage-4 column -> image column + 4
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
   using Q5 = typename K::Q5;
   using Q6 = typename K::Q6;
   constexpr int TW = K::TW, NB4O = K::NB4O, NB4Y = K::NB4Y, NB5 = K::NB5, NB6 = K::NB6, PARK_COLS = K::PARK_COLS, NC4 = K::NC4,
-                NC5 = K::NC5, NC6 = K::NC6, OFF_R1 = K::OFF_R1, OFF_HT = K::OFF_HT, OFF_A5 = K::OFF_A5, OFF_A6 = K::OFF_A6,
+                NC5 = K::NC5, NC6 = K::NC6, C5 = K::C5, BLOCKS = K::BLOCKS, OFF_R1 = K::OFF_R1, OFF_HT = K::OFF_HT, OFF_A5 = K::OFF_A5, OFF_A6 = K::OFF_A6,
                 A5_N = K::A5_N, A6_N = K::A6_N, T3_LDS_BYTES = K::LDS_BYTES;
   (void)sizeof(Q5), (void)sizeof(Q6);
   extern __shared__ uint4 t3_lds[];
@@ -234,8 +241,15 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
         const int t = 2 * (colb + j * 16 + n) + ph;
         float v[4];
         t3_finish(acc, bias5, (unsigned)(t - lo) < 3000u, v);
-        if (!K::GUARD5 || t < NC6) b3c_store4<16, NC6>(IN6, t, g, v);  // (TW = 1264: columns beyond the stage-6 image are nobody's input)
+        if (!K::GUARD5 || t < NC6) b3c_store4<16, NC6>(IN6, t, g, v);  // (tilings whose stage 5 computes columns beyond the stage-6 image: nobody's input)
       };
+      if (K::ZERO6) {  // columns [2 C5, NC6) of the stage-6 input image: 16-byte units (column, 8 channels) of every chunk plane
+        constexpr int ZC = NC6 - 2 * C5, UNITS = 3 * 2 * ZC;
+        for (int i = tid; i < UNITS; i += T3_NTH) {
+          const int plane = i / ZC, col = 2 * C5 + (i - plane * ZC);  // plane = piece * 2 + chunk
+          *reinterpret_cast<uint4*>(IN6 + (plane >> 1) * Q6::PS + (plane & 1) * Q6::CHS + col * 8) = make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
       b3c_mac_tiles<16, NC5, 5, NB5>(b3c_lane_ptr<16, NC5, 5>(IN5, colb + 1, lane), a5, finish);
     }
     __syncthreads();
@@ -266,7 +280,7 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
     }
     __syncthreads();
     T3_STAMP(4)
-    if (w < (TW / 16 + 15) / 16) {
+    if (w < (BLOCKS + 15) / 16) {
       // heads: wave w owns the 16-sample blocks 16 w .. 16 w + 15 of the tile: y[t0 + 16 blk + m] = b + sum_tap sum_ci
       // w[ci][tap - m] x_ci[staged 16 blk + tap + 1]; K-step s = taps 4 s .. 4 s + 3, lane group g the tap 4 s + g
       f32x4 acc = {bh, bh, bh, bh};
@@ -295,7 +309,7 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       const int blk = 16 * w + n;
-      if (blk < TW / 16 && t0 + 16 * blk < T_OUT) {  // (the last tile of a row may reach past it)
+      if (16 * blk + 4 * g < TW && t0 + 16 * blk + 4 * g < T_OUT) {  // (a tile's last block may be half used; the last tile of a row may reach past it)
         const int b = id.win - id.d * a.B;
         float4 r;
         // sigmoid as v_exp + v_rcp (3e-7 absolute; the library expf and the IEEE division are ~18 instructions per value on a
@@ -336,12 +350,12 @@ struct Tail3Tiling {
 Tail3Tiling tail3_tiling(const vp_config& cfg, int out_lo, int out_hi) {
   const bool whole = (cfg.plan_flags[7] & 1024) || out_hi <= 0;
   const int t_lo = whole ? 0 : (out_lo / 16) * 16, t_hi = whole ? T_OUT : out_hi;
-  const int tiles_a = (t_hi - t_lo + 1199) / 1200, tiles_b = (t_hi - t_lo + 1263) / 1264;
+  const int tiles_a = (t_hi - t_lo + 1199) / 1200, tiles_b = (t_hi - t_lo + 1255) / 1256;
   Tail3Tiling t;
   t.wide = tiles_b < tiles_a;
   t.t_lo = t_lo;
   t.tiles_per_row = t.wide ? tiles_b : tiles_a;
-  t.issued_bf16 = 3.0 * t.tiles_per_row * (t.wide ? T3<1264>::GROUPS : T3<1200>::GROUPS) * 6 * 16384.0;
+  t.issued_bf16 = 3.0 * t.tiles_per_row * (t.wide ? T3<1256>::GROUPS : T3<1200>::GROUPS) * 6 * 16384.0;
   return t;
 }
 
@@ -368,7 +382,7 @@ int plan_eqt_fuse_tail_b3(Net& net) {
     return VP_ERR_INVALID;
   }
   const int x3 = c4->src1;
-  net.need(x3, HALO - 5 + T_OUT / 8 + T3<1264>::PARK_COLS);  // the last tile of a row may read past it: zero margin
+  net.need(x3, HALO - 5 + T_OUT / 8 + T3<1256>::PARK_COLS);  // the last tile of a row may read past it: zero margin
   net.tensor_sets[c4->dst] = 0;  // stages 4 and 5 are never materialised by this plan
   net.tensor_sets[c5->dst] = 0;
   HostBlob* p4 = net.add_blob(b3_operand(*c4, true));
@@ -438,13 +452,13 @@ int plan_eqt_fuse_tail_b3(Net& net) {
                 : nullptr;
     const int grid = a.n_tiles < 256 ? a.n_tiles : 256;
     if (wide)
-      hipLaunchKernelGGL(eqt_tail3_kernel<1264>, dim3(grid), dim3(T3_NTH), T3<1264>::LDS_BYTES, s, a);
+      hipLaunchKernelGGL(eqt_tail3_kernel<1256>, dim3(grid), dim3(T3_NTH), T3<1256>::LDS_BYTES, s, a);
     else
       hipLaunchKernelGGL(eqt_tail3_kernel<1200>, dim3(grid), dim3(T3_NTH), T3<1200>::LDS_BYTES, s, a);
     return 0;
   };
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_tail3_kernel<1200>), (size_t)T3<1200>::LDS_BYTES});
-  net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_tail3_kernel<1264>), (size_t)T3<1264>::LDS_BYTES});
+  net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_tail3_kernel<1256>), (size_t)T3<1256>::LDS_BYTES});
   st.issued_for_range = [](const Net& n, int lo, int hi, double* w) {
     w[0] = 0.0, w[1] = tail3_tiling(n.cfg, lo, hi).issued_bf16, w[2] = 0.0;
   };

@@ -392,6 +392,8 @@ struct MseedScratch {
       cap[slot] = 0;
       const size_t want = bytes + bytes / 4 + 4096;
       if (hipMalloc(&p[slot], want) != hipSuccess) {
+        (void)hipGetLastError();  // the failure is reported here: do not leave HIP's sticky last error for an unrelated later check
+        p[slot] = nullptr;
         set_error("vp_mseed_decode: cannot allocate %zu bytes of device scratch", want);
         return VP_ERR_HIP;
       }
@@ -399,6 +401,16 @@ struct MseedScratch {
     }
     *out = p[slot];
     return VP_OK;
+  }
+  size_t release() {  // caller holds mu
+    size_t freed = 0;
+    for (int i = 0; i < 4; ++i) {
+      if (p[i]) (void)hipFree(p[i]);
+      freed += cap[i];
+      p[i] = nullptr;
+      cap[i] = 0;
+    }
+    return freed;
   }
 };
 MseedScratch& mseed_scratch(int device) {
@@ -410,6 +422,16 @@ MseedScratch& mseed_scratch(int device) {
 }  // namespace vp
 
 using namespace vp;
+
+extern "C" int vp_mseed_release_scratch(int device_id, size_t* bytes_freed) {
+  VP_REQUIRE(device_id >= 0, "vp_mseed_release_scratch: device index");
+  MseedScratch& sc = mseed_scratch(device_id);
+  std::lock_guard<std::mutex> lock(sc.mu);  // behind any decode call in flight on this device
+  VP_HIP(hipSetDevice(device_id));
+  const size_t freed = sc.release();
+  if (bytes_freed) *bytes_freed = freed;
+  return VP_OK;
+}
 
 extern "C" int vp_mseed_scan(const uint8_t* buf, size_t nbytes, vp_mseed_record* recs, int64_t cap,
                              int64_t* n_found) {

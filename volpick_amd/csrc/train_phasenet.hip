@@ -23,6 +23,7 @@ namespace {
 
 constexpr int T0 = 3001, T1 = 751, T2 = 188, T3 = 47, T4 = 12;
 constexpr int NLAYER = 18;
+static int wg_rows_cap(int out_n);  // rows of partial weight-gradient results a launch may write (defined below)
 
 //                    CIN1 CIN2 COUT P TAPS SN IN_OFF OUT_OFF WM WN NW RELU EPI
 // (BF = 1: rows stored as bf16, conv_mfma.h)
@@ -594,7 +595,7 @@ int upload(Trainer& tr, const float* weights) {
   size_t wtot = 0;
   for (Layer& L : tr.layers) {
     L.wg.partial_off = wtot;
-    wtot += (size_t)512 * (size_t)L.wg.out_n;
+    wtot += (size_t)wg_rows_cap(L.wg.out_n) * (size_t)L.wg.out_n;  // what the launches can reach (512 rows each was 550 MB)
   }
   tr.wg_partial_floats = wtot;
   TR_HIP(hipMalloc(&tr.wg_partial, wtot * sizeof(float)));
@@ -823,6 +824,9 @@ int forward_backward(Trainer& tr, const float* x_dev, const float* y_dev, int B,
   // An event costs the main chain ~5 us (the launch behind a kernel with a completion signal starts that much later):
   // every other layer above level 0, every layer of the last four (their weight gradients are the step's tail).
   constexpr unsigned ev_mask = 0x2aaaf;
+  // ev_wg1 is recorded at li == 1 on the premise that layer 1's launch has just been flushed, li == 0 flushes the rest, and the
+  // first layer handled (NLAYER - 1) opens the chain: a retuned mask must keep those three bits
+  static_assert((ev_mask & 3u) == 3u && ((ev_mask >> (NLAYER - 1)) & 1u), "ev_mask: layers 0, 1 and NLAYER - 1 carry an event");
   struct { const WgradOp* w; WgradArgs g; int grid, li; } held[NLAYER];
   int n_held = 0;
   static_assert(NLAYER <= MAX_SUM_JOBS, "one sum job per layer");

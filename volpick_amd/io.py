@@ -169,6 +169,13 @@ def read_mseed(source, device=0, dtype=None, device_resident=False):
     return st
 
 
+def release_decode_scratch(device=0):
+    """Free the device scratch `read_mseed` keeps per device between calls (vp_mseed_release_scratch); returns the bytes freed."""
+    freed = C.c_size_t(0)
+    _lib.check(_lib.load().vp_mseed_release_scratch(int(device), C.byref(freed)), "vp_mseed_release_scratch")
+    return int(freed.value)
+
+
 def read_sac(source):
     """SAC binary (either byte order) -> Stream with one Trace.  Host only: the body is raw float32."""
     buf = _as_bytes(source)

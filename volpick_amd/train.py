@@ -97,8 +97,14 @@ class PhaseNetTrainer:
         a = np.ascontiguousarray(a, dtype=np.float32)
         return a, a.ctypes.data_as(C.c_void_p), _lib.VP_MEM_HOST
 
-    def step(self, x, y, lr, update=True, want_loss=True):
-        """Forward + loss + backward (+ Adam when ``update``).  x, y: (B, 3, 3001)."""
+    def step(self, x, y, lr, update=True, want_loss=True, inputs_unchanged=False):
+        """Forward + loss + backward (+ Adam when ``update``).  x, y: (B, 3, 3001).
+
+        ``inputs_unchanged=True`` is the caller's PROMISE that x and y are the very tensors of the previous step and that
+        nothing has written to them since, by any route (a benchmark re-running one batch): the trainer's stream then does not
+        wait for the producer stream again.  It is never inferred: torch's ``Tensor._version`` does not see writes through
+        ``x.data``, raw-pointer kernels (this library's own device writers, DLPack consumers) or collective outputs, and a
+        loader that refills a persistent buffer that way would be read half-filled."""
         if tuple(x.shape) != tuple(y.shape) or x.ndim != 3 or x.shape[1] != 3 or x.shape[2] != self.in_samples:
             raise ValueError(f"expected x and y of shape (B, 3, {self.in_samples}), got {tuple(x.shape)} / {tuple(y.shape)}")
         xk, xp, xm = self._arg(x)
@@ -110,17 +116,15 @@ class PhaseNetTrainer:
             # the trainer runs on its own stream: x / y (or their fp32 copies made above) must be complete first.  An
             # event recorded on torch's stream that the trainer's stream waits for (hipStreamWaitEvent): the host does
             # not block, so a data loader filling the next batch on torch's stream keeps running
-            # Not needed -- and skipped: the wait is a marker in the trainer's queue in front of the step's first launch,
-            # ~25 us of the step -- when x and y are the very tensors of the previous step, unmodified since (torch counts
-            # in-place writes in Tensor._version): that step already waited for whatever produced them.
+            # (The wait is a marker in the trainer's queue in front of the step's first launch, ~25 us of the step; skipped only
+            # on the caller's explicit promise -- and then only for the very OBJECTS of the previous step, held here so that
+            # their identity cannot be recycled -- or when the producer has already finished.)
             torch = _torch()
             producer = torch.cuda.current_stream(xk.device)
-            # (the very OBJECTS, held here so that their identity cannot be recycled: a fresh tensor that the allocator
-            # placed at the same address has the same data_ptr and may have the same version, and its producer may still run)
             last = getattr(self, "_last_inputs", None)
-            same = (last is not None and last[0] is xk and last[1] is yk and last[2] == (xk._version, yk._version, producer.cuda_stream))
+            same = bool(inputs_unchanged) and last is not None and last[0] is xk and last[1] is yk and last[2] == producer.cuda_stream
+            self._last_inputs = (xk, yk, producer.cuda_stream)
             if not same:
-                self._last_inputs = (xk, yk, (xk._version, yk._version, producer.cuda_stream))
                 ev = torch.cuda.Event()
                 ev.record(producer)
                 if not ev.query():  # (already complete -- a batch prepared well ahead: nothing to wait for either)
