@@ -60,6 +60,8 @@ def pipe_time_s(issued, batch):
     return batch * (issued["mfma_f32"] / (PEAK_FP32_TFLOPS * 1e12) + issued["mfma_bf16"] / (PEAK_BF16_TFLOPS * 1e12) +
                     issued["valu"] / (PEAK_FP32_TFLOPS * 1e12))
 
+# the arithmetic type of the path, said in full: fp32 results from exact bf16-piece products
+DTYPE_LABEL = "f32 (exact 3xbf16 split products, fp32 accumulate)"
 COMPACT_LIMIT = 8000  # bytes: the driver keeps the last 8 KB of stdout and parses the last line (round 4's 20 KB line was cut)
 
 
@@ -96,7 +98,7 @@ def _compact_model(m):
         out["sustained"] = _pick(m["sustained"], "value", "ms_per_step", "seconds", "shader_clock_ghz")
     r = m.get("roofline")
     if r:
-        rr = _pick(r, "bound", "kernel", "achieved", "peak", "unit", "frac", "kernel_ms", "pipe_time_ms", "traffic")
+        rr = _pick(r, "bound", "kernel", "achieved", "peak", "unit", "frac", "useful_frac", "kernel_ms", "pipe_time_ms", "traffic")
         if isinstance(rr.get("kernel"), str):
             rr["kernel"] = rr["kernel"][:72]
         if r.get("step_bound"):
@@ -117,7 +119,7 @@ def _compact_model(m):
         if isinstance(a.get("cpu_oracle_10min"), dict):
             out["api"]["picks_identical_10min"] = a["cpu_oracle_10min"].get("picks_identical")
     if m.get("ranks"):
-        out["ranks"] = [_pick(x, "rank", "device", "ms_per_step_own_median", "weight_broadcast_path", "rccl_comm_ranks", "windows_per_step", "segment", "keeps")
+        out["ranks"] = [_pick(x, "rank", "device", "ms_per_step_own_median", "gpu_ms", "fixed_ms", "weight_broadcast_path", "rccl_comm_ranks", "windows_per_step", "segment", "keeps")
                         for x in m["ranks"]]
     return out
 
@@ -131,7 +133,7 @@ def compact_line(result, detail_path=None):
     for k in ("value", "unit", "ms_per_step"):
         body.pop(k, None)
     out.update(body)
-    for k in ("weight_broadcast_path", "weight_broadcast_s", "picks", "detections", "picks_digest"):
+    for k in ("weight_broadcast_path", "weight_broadcast_s", "picks", "detections", "picks_digest", "call_split_ms"):
         if k in result:
             out[k] = result[k]
     if result.get("ranks"):
@@ -964,9 +966,9 @@ def bench_model(model_name, env, cpu_budget_s):
         k["pipe_time_ms"] = pipe_time_s(k["issued_flop_per_window"], args.batch) * 1e3
         k["frac_of_pipe_peaks"] = k["pipe_time_ms"] / k["ms"] if k["ms"] > 0 else None
         if k["name"].startswith("fused.mid"):
-            k["note"] = ("two windows per 1024-thread workgroup: a 256-window launch holds 128 of the 256 CUs (the other contexts' "
-                         "kernels run on the rest); one window per workgroup took 66 us on all 256; frac_of_pipe_peaks is against "
-                         "the whole chip")
+            k["note"] = ("four windows per 1024-thread workgroup (teams of four waves): a 256-window launch holds 64 of the 256 CUs "
+                         "(the other contexts' kernels run on the rest); two windows per workgroup took 91 us on 128 CUs, one 66 us "
+                         "on all 256; frac_of_pipe_peaks is against the whole chip")
         kernels.append(k)
     fwd_ms = sum(k["ms"] for k in kernels)
     # Roofline candidates are the launches that hold >= 5 % of the forward FLOPs (the MFMA / packed-FMA bound ones).
@@ -986,7 +988,12 @@ def bench_model(model_name, env, cpu_budget_s):
     dom_ms = C.c_float()
     _lib.check(lib.vp_profile_step_in_pipeline(h, args.batch, 200, kernels.index(dom), C.byref(dom_ms)),
                "vp_profile_step_in_pipeline")
-    per_s = args.batch / (dom_ms.value * 1e-3) / 1e12 if dom_ms.value > 0 else 0.0
+    # The duration the fractions are taken on is one the timed loop pays: a one-launch plan's kernel cannot take longer than a
+    # whole step of that loop, so where the HIP-event figure (one queue, a gap between two launches of it) exceeds the step,
+    # the step is the duration (never a kernel_ms above ms_per_step).
+    step_ms = dt / args.steps * 1e3
+    dom_dur_ms = min(dom_ms.value, step_ms) if (len(kernels) == 1 and world == 1) else dom_ms.value
+    per_s = args.batch / (dom_dur_ms * 1e-3) / 1e12 if dom_dur_ms > 0 else 0.0
     dom_algorithmic = dom["flop_per_window"] * per_s
     dom_issued_flop = sum(dom["issued_flop_per_window"].values())
     dom_pipe_s = pipe_time_s(dom["issued_flop_per_window"], args.batch)
@@ -1017,7 +1024,7 @@ def bench_model(model_name, env, cpu_budget_s):
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": DTYPE_LABEL,
         "data": "synthetic",
         "sustained": sustained,
         "timing": {
@@ -1035,7 +1042,7 @@ def bench_model(model_name, env, cpu_budget_s):
                         f"blinding={list(blinding)}, stacking=avg, full path A2-A8 per step",
             "batch": args.batch,
             "in_samples": T,
-            "parallelism": f"stream-sharded x{world}, weights broadcast once (RCCL)",
+            "parallelism": f"stream-sharded x{world}, weights broadcast once (RCCL)" if world > 1 else "one rank (nothing broadcast)",
             "device_contexts": NCTX,
             "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
             "inflight_steps_per_context": DEPTH,
@@ -1060,8 +1067,12 @@ def bench_model(model_name, env, cpu_budget_s):
                           "(pn_window_kernel, round 2 -> 3: pipe time 56 -> 46 us per 256 windows with up1.same / up2.same on the "
                           "bf16 pipes, duration 102 -> 94-98 us at the same clock); read it beside kernel_ms"),
             "issued_flop_per_window": dom["issued_flop_per_window"],
+            "useful_frac": dom["flop_per_window"] * args.batch * 6 / (PEAK_BF16_TFLOPS * 1e12) / (dom_dur_ms * 1e-3) if dom_dur_ms > 0 else None,
+            "useful_frac_basis": "ALGORITHMIC FLOP (SURVEY 8d) x 6 piece products at the dense bf16 MFMA peak / the same duration: what "
+                                 "frac would be without padded tiles, recomputed halos and the fp32-MFMA / VALU layers",
             "pipe_time_ms": dom_pipe_s * 1e3,
-            "kernel_ms": dom_ms.value,
+            "kernel_ms": dom_dur_ms,
+            "kernel_ms_hip_events": dom_ms.value,
             "kernel_ms_back_to_back": dom["ms"],
             "kernel_ms_note": "HIP events around the launch, 200 passes on ONE stream: every pass pays the event records and the "
                               "drain / refill of the chip between two launches of one queue (what rocprofv3's AverageNs of the same "
@@ -1149,10 +1160,12 @@ def bench_strong(env):
     mine = torch.from_numpy(np.ascontiguousarray(data[:, sg["lo"]:sg["hi"]])).to(dev) if sg else None
     del data
     t_start = UTCDateTime("2021-01-01T00:00:00")
-    res = [None]
+    res, tms = [None], []
 
     def one_day():
-        res[0] = classify_stream_sharded(model, (n, lambda lo, hi: mine), t_start, "XX.DAY.", **kw)
+        tm = {}
+        res[0] = classify_stream_sharded(model, (n, lambda lo, hi: mine), t_start, "XX.DAY.", timing=tm, **kw)
+        tms.append(tm)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -1163,9 +1176,13 @@ def bench_strong(env):
     steps, warm = max(1, min(args.steps, 20)), max(1, min(args.warmup, 3))
     for _ in range(warm):
         one_day()
+    tms.clear()
     times = timed_repeats(lambda: [one_day() for _ in range(steps)], sync_all, min(args.repeats, 5), use_dist, dev)
     dt = statistics.median(times)
     n_windows = 17_269
+    # this rank's split of a call (medians over the timed calls): gpu_ms = annotate of its segment, synchronised; fixed_ms = the
+    # rest (segment plan, trigger scan + result copy, header / column exchange, stitching and record columns on rank 0)
+    split = {k: statistics.median(t[k] for t in tms) for k in ("total_ms", "gpu_ms", "scan_ms", "wait_ms", "exchange_ms", "stitch_ms", "fixed_ms")}
     out = {
         "metric": "waveform-windows/sec",
         "value": n_windows * steps / dt,
@@ -1176,11 +1193,12 @@ def bench_strong(env):
         "ms_per_step": dt / steps * 1e3,
         "higher_is_better": True,
         "scaling": "strong",
-        "scaling_note": "LATENCY of one station-day, not the throughput target: about 8 ms of a call is host work (stream cut, "
-                        "stitching, pick gather) that does not shrink with N, so one day over 8 GPUs tops out near 3x; the "
-                        ">= 7x target of BASELINE.json is the weak-scaling (many streams) default mode of this script",
+        "scaling_note": "LATENCY of one station-day: per rank and call, gpu_ms (annotate of its segment) shrinks with N, "
+                        "fixed_ms (trigger scan, two small collectives of integer columns, stitching on rank 0) does not; "
+                        "the >= 7x target of BASELINE.json is the weak-scaling (many streams) default mode of this script",
+        "call_split_ms": {k: round(v, 3) for k, v in split.items()},
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": DTYPE_LABEL,
         "data": "synthetic",
         "timing": {"repeats": len(times), "windows_per_s_min": n_windows * steps / max(times),
                    "windows_per_s_max": n_windows * steps / min(times)},
@@ -1189,8 +1207,9 @@ def bench_strong(env):
                         "blinding=[500, 500], 17,269 windows, split by window range over the ranks; a step = the whole "
                         "day through annotate + trigger scan + stitching of the pick lists on rank 0",
             "batch": args.batch,
-            "parallelism": f"window-range sharding x{world} (segment + halo per rank), weights broadcast once (RCCL), "
-                           "pick lists gathered through the host",
+            "parallelism": (f"window-range sharding x{world} (segment + halo per rank), weights broadcast once, trigger columns "
+                            "gathered as fixed-width integer tensors (no pickling)") if world > 1 else
+                           "one rank: the whole day on one GPU (no broadcast, no exchange)",
             "segment_samples_this_rank": (sg["hi"] - sg["lo"]) if sg else 0,
         },
         "weight_broadcast_s": t_bcast,
@@ -1200,6 +1219,7 @@ def bench_strong(env):
         info = {"rank": rank, "device": torch.cuda.current_device(), "segment": [sg["lo"], sg["hi"]] if sg else None,
                 "keeps": [sg["keep_lo"], sg["keep_hi"]] if sg else None,
                 "ms_per_step_own_median": statistics.median(OWN_TIMES) / steps * 1e3 if OWN_TIMES else None,
+                "gpu_ms": round(split["gpu_ms"], 3), "fixed_ms": round(split["fixed_ms"], 3), "call_split_ms": {k: round(v, 3) for k, v in split.items()},
                 "weight_broadcast_s": t_bcast, "weight_broadcast_path": _bcast_path(), "rccl_comm_ranks": _rccl_ranks(),
                 "librccl": _rccl_libraries()}
         gathered = [None] * world

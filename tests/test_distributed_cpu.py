@@ -8,7 +8,7 @@ import pytest
 import torch.multiprocessing as mp
 
 from oracle import pipeline as OP
-from volpick_amd.distributed import _head_run_end, shard_range, stitch_triggers
+from volpick_amd.distributed import _head_run_end, _trigger_columns, shard_range, stitch_trigger_columns, stitch_triggers
 
 
 def test_shard_range_partitions():
@@ -58,6 +58,22 @@ def test_stitch_triggers_equals_unsplit_scan():
         got = stitch_triggers(parts, len(specs))
         want = sorted(pick_fn(rows, specs), key=lambda t: (t[0], t[1]))
         assert got == want, (trial, cuts)
+        # the column form classify_stream_sharded uses: ONE scan per part -- the specs plus a (thr_off, thr_off) row per spec whose
+        # trigger at the part's first sample is the head run -- and only the triggers that touch a cut go through the joining logic
+        cparts = []
+        for k in range(parts_n):
+            a, b = cuts[k], cuts[k + 1]
+            head_specs = [(row, label, t_off, t_off) for row, label, _, t_off in specs] if k else []
+            sp, on, off, pk, v = _trigger_columns(pick_fn(rows[:, a:b], specs + head_specs))
+            head = [-1] * len(specs)
+            for i in np.flatnonzero((sp >= len(specs)) & (on == 0)):
+                head[int(sp[i]) - len(specs)] = int(off[i]) + a
+            assert head == parts[k]["head_end"], (trial, k)
+            own = sp < len(specs)
+            cparts.append((a, b, head, (sp[own], on[own] + a, off[own] + a, pk[own] + a, v[own])))
+        csp, con, coff, cpk, cv = stitch_trigger_columns(cparts, len(specs))
+        assert list(zip(csp.tolist(), con.tolist(), coff.tolist(), cpk.tolist(), cv.tolist())) == \
+            [(si, on, off, pk, float(np.float32(v))) for si, on, off, pk, v in want], (trial, cuts)
 
 
 def _worker(rank, world, port, q):
@@ -160,6 +176,15 @@ def _stream_worker(rank, world, port, q):
         got = classify_stream_sharded(model, (n, load), t0, "XX.ONE.", annotate_fn=oracle_annotate, pick_fn=oracle_pick,
                                       **kw)
         assert len(touched) == 1 and (touched[0][0] > 0 if rank else touched[0][1] < n)
+        # the same call with room for EVERY trigger row beside the header: one collective instead of two
+        import volpick_amd.distributed as D
+
+        cap0, D._EXCHANGE_CAP, tm = D._EXCHANGE_CAP, 4096, {}
+        again = classify_stream_sharded(model, (n, load), t0, "XX.ONE.", annotate_fn=oracle_annotate, pick_fn=oracle_pick, timing=tm, **kw)
+        D._EXCHANGE_CAP = cap0
+        assert (again is None) == (got is None) and tm["fixed_ms"] <= tm["total_ms"] and tm["wait_ms"] >= 0.0
+        if got is not None:
+            assert len(got.picks) >= 2 and [str(p) for p in again.picks] == [str(p) for p in got.picks]
         if rank == 0:
             want_rows = torch.from_numpy(np.ascontiguousarray(oracle_annotate(data)))
             want = oracle_pick(want_rows, model._trigger_specs(model._argdict(kw)))

@@ -218,6 +218,9 @@ __device__ __forceinline__ void store3(bf16_t* img, const int col, const int ch,
 #ifndef R3_EXP
 #define R3_EXP 0
 #endif
+#ifndef R3_CLOCK
+#define R3_CLOCK 0
+#endif
 template <int TAPS>
 struct Res3A {
   uint4 q[TAPS * 2][3];
@@ -301,11 +304,41 @@ __global__ __launch_bounds__(256 * WPB) void eqt_res3_kernel(const Res3Args a) {
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int win = min((int)blockIdx.x * WPB + team, a.n_windows - 1);
   const int g = lane >> 4, n = lane & 15;
+  // Debug stamps (tools/res3_clock.py) exist in -DR3_CLOCK=1 builds only: the kernel stands at 256 registers and the three
+  // values a run-time switch keeps alive spilled 21 of them.
+#if R3_CLOCK
   unsigned long long* clk = (a.clk && threadIdx.x == 0 && blockIdx.x == 0) ? a.clk : nullptr;
   int stamp = 0;
 #define R3_STAMP() \
   if (clk) clk[stamp++] = __builtin_readcyclecounter();
+#else
+#define R3_STAMP()
+#endif
   R3_STAMP()
+  // Prologue: EVERYTHING is requested before the first wait, the window's own rows first (loads return in order), then block
+  // 0's first operand, then this workgroup's share of the L2 warm-up.  (Rounds 2-5 had three loops of load -> use, i.e. one
+  // exposed memory latency per trip: 12 k cycles for the warm-up's seven trips, 12 k for the fifteen of x / act, of a 118 k-
+  // cycle kernel -- tools/res3_clock.py.)
+  constexpr int NXR = (64 * RT + 255) / 256, NAR = (16 * RT + 255) / 256;
+  float xr[NXR], ar[NAR][4];
+  {
+    const float* x0 = a.x0 + (long)win * a.ws_x + HALO;
+    const float* a0 = a.act0 + (long)win * a.ws_a + HALO;
+#pragma unroll
+    for (int k = 0; k < NXR; ++k) {
+      const int i = tid + 256 * k, c = i / RT, t = i - c * RT;
+      xr[k] = i < 64 * RT ? x0[(long)c * a.ls_x + t] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NAR; ++k) {  // four channels of one column per item
+      const int i = tid + 256 * k, cq = i / RT, t = i - cq * RT;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ar[k][r] = i < 16 * RT ? a0[(long)(4 * cq + r) * a.ls_a + t] : 0.f;
+    }
+  }
+  Res3A<3> w1_0;
+  w1_0.load(a.af1[0], a.bs1[0], nullptr, nullptr, wave, lane);
+  unsigned wv[14] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // looked at behind the prologue's LDS stores, not here
   if (a.warm && team == 0) {
     // The weights (1 MB) have left L2 since the last launch (the other kernels of the step move 0.3 GB): every XCD's L2 is
     // warmed up front, one word per 128-byte line (see eqt_res_kernel) -- by ALL workgroups of the XCD, each a slice of the
@@ -313,17 +346,26 @@ __global__ __launch_bounds__(256 * WPB) void eqt_res3_kernel(const Res3Args a) {
     // through one CU made those eight workgroups, hence the launch, 4 us longer.
     const int nx = gridDim.x >= 8 ? gridDim.x >> 3 : 1, xw = (int)blockIdx.x >> 3;  // workgroups per XCD that take part; this one's index
     constexpr int kers_pf[7] = {3, 3, 3, 3, 2, 3, 2};
-    unsigned sink = 0u;
     if (xw < nx) {
+      if ((long)nx * 256 * 128 >= a.af_bytes_k3) {  // one line per conv and thread at most: fourteen independent loads, no trip waits
 #pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        const int lines = (int)((kers_pf[i] == 3 ? a.af_bytes_k3 : a.af_bytes_k2) / 128);
-        for (int l = xw * 256 + tid; l < lines; l += nx * 256)
-          sink ^= reinterpret_cast<const unsigned*>(a.af1[i])[l * 32] ^ reinterpret_cast<const unsigned*>(a.af2[i])[l * 32];
+        for (int i = 0; i < 7; ++i) {
+          const int lines = (int)((kers_pf[i] == 3 ? a.af_bytes_k3 : a.af_bytes_k2) / 128);
+          const int l = min(xw * 256 + tid, lines - 1);  // (beyond the conv's lines: its last line again, one request per wave)
+          wv[2 * i] = reinterpret_cast<const unsigned*>(a.af1[i])[l * 32];
+          wv[2 * i + 1] = reinterpret_cast<const unsigned*>(a.af2[i])[l * 32];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          const int lines = (int)((kers_pf[i] == 3 ? a.af_bytes_k3 : a.af_bytes_k2) / 128);
+          for (int l = xw * 256 + tid; l < lines; l += nx * 256)
+            wv[0] ^= reinterpret_cast<const unsigned*>(a.af1[i])[l * 32] ^ reinterpret_cast<const unsigned*>(a.af2[i])[l * 32];
+        }
       }
     }
-    if (sink == 0x12345678u && a.ls_x == -1) a.out[0] = __uint_as_float(sink);  // never true: keeps the loads alive
   }
+  __builtin_amdgcn_sched_barrier(0);
   R3_STAMP()
   for (int i = tid; i < 3 * R3_PS / 8; i += 256) {  // zero halo columns (and everything else once)
     reinterpret_cast<uint4*>(ACT)[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -331,20 +373,21 @@ __global__ __launch_bounds__(256 * WPB) void eqt_res3_kernel(const Res3Args a) {
   }
   __syncthreads();
   R3_STAMP()
-  {
-    const float* x0 = a.x0 + (long)win * a.ws_x + HALO;
-    const float* a0 = a.act0 + (long)win * a.ws_a + HALO;
-    for (int i = tid; i < 64 * RT; i += 256) {
-      const int c = i / RT, t = i - c * RT;
-      X[c * R3_XS + t] = x0[(long)c * a.ls_x + t];
-    }
-    for (int i = tid; i < 16 * RT; i += 256) {  // four channels of one column per trip
-      const int cq = i / RT, t = i - cq * RT;
-      float v[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = a0[(long)(4 * cq + k) * a.ls_a + t];
-      store3(ACT, t + 1, 4 * cq, v);
-    }
+  for (int k = 0; k < NXR; ++k) {
+    const int i = tid + 256 * k, c = i / RT, t = i - c * RT;
+    if (i < 64 * RT) X[c * R3_XS + t] = xr[k];
+  }
+#pragma unroll
+  for (int k = 0; k < NAR; ++k) {
+    const int i = tid + 256 * k, cq = i / RT, t = i - cq * RT;
+    if (i < 16 * RT) store3(ACT, t + 1, 4 * cq, ar[k]);
+  }
+  {
+    unsigned sink = 0u;
+#pragma unroll
+    for (int i = 0; i < 14; ++i) sink ^= wv[i];
+    if (sink == 0x12345678u && a.ls_x == -1) a.out[0] = __uint_as_float(sink);  // never true: keeps the warm-up loads alive
   }
   __syncthreads();
   R3_STAMP()
@@ -400,8 +443,6 @@ __global__ __launch_bounds__(256 * WPB) void eqt_res3_kernel(const Res3Args a) {
     R3_STAMP()                                                                                    \
   }
   // kernel sizes of the seven blocks: 3 3 3 3 2 3 2; the next block's conv1 operand is requested before this block's conv2
-  Res3A<3> w1_0;
-  w1_0.load(a.af1[0], a.bs1[0], nullptr, nullptr, wave, lane);
   Res3A<3> w1_1;
   R3_BLOCK(0, 3, w1_1.load(a.af1[R3_W(1, 3)], a.bs1[1], nullptr, nullptr, wave, lane);)
   Res3A<3> w1_2;

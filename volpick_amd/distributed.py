@@ -322,26 +322,75 @@ def _head_run_end(pick_fn, rows, spec, lo, hi):
         n *= 4
 
 
-def classify_stream_sharded(model, data, starttime, trace_id, group=None, annotate_fn=None, pick_fn=None, **kwargs):
+_EXCHANGE_CAP = 16  # trigger rows per rank that travel WITH the header (classify_stream_sharded): enough for a quiet segment
+
+
+def _trigger_columns(found):
+    """[(spec, on, off, peak, value)] or the five arrays -> the five arrays (int32, int64 x 3, float32)."""
+    if isinstance(found, tuple):
+        return found
+    if not found:
+        return (np.empty(0, np.int32), np.empty(0, np.int64), np.empty(0, np.int64), np.empty(0, np.int64), np.empty(0, np.float32))
+    z = list(zip(*found))
+    return (np.asarray(z[0], np.int32), np.asarray(z[1], np.int64), np.asarray(z[2], np.int64), np.asarray(z[3], np.int64),
+            np.asarray(z[4], np.float32))
+
+
+def stitch_trigger_columns(parts, n_specs):
+    """``stitch_triggers`` on columns.  ``parts`` (in segment order): (keep_lo, keep_hi, head_end[n_specs], columns) with the
+    columns in stream sample indices.  Only the triggers that touch a cut -- the one that ends on a part's last owned sample
+    and the one that ends where the part's head run ends: two per spec and cut at most -- go through the run-joining logic of
+    ``stitch_triggers``; everything else stays arrays.  Returns the five columns sorted by (spec, onset)."""
+    plain, edge_parts = [], []
+    for k, (keep_lo, keep_hi, head_end, cols) in enumerate(parts):
+        sp, on, off, pk, v = cols
+        touch = np.zeros(len(sp), bool)
+        if k + 1 < len(parts):
+            touch |= off == keep_hi - 1
+        if k > 0:
+            he = np.asarray(head_end, np.int64)[sp] if len(sp) else np.empty(0, np.int64)
+            touch |= (he >= 0) & (off == he)
+        plain.append(tuple(c[~touch] for c in cols))
+        idx = np.flatnonzero(touch)
+        edge_parts.append(dict(keep_lo=keep_lo, keep_hi=keep_hi, head_end=list(head_end),
+                               triggers=[(int(sp[i]), int(on[i]), int(off[i]), int(pk[i]), float(v[i])) for i in idx]))
+    joined = _trigger_columns(stitch_triggers(edge_parts, n_specs))
+    sp, on, off, pk, v = (np.concatenate([c[i] for c in plain] + [joined[i]]) for i in range(5))
+    order = np.lexsort((on, sp))
+    return sp[order], on[order], off[order], pk[order], v[order]
+
+
+def classify_stream_sharded(model, data, starttime, trace_id, group=None, annotate_fn=None, pick_fn=None, timing=None, **kwargs):
     """ONE long (3, N) block spread over the ranks (BASELINE config 4: a 24 h stream on 8 GPUs) ->
     ``ClassifyOutput`` on rank 0, ``None`` elsewhere.
 
     Rank r takes segment r of ``segments.plan_segments`` -- only its samples [lo, hi) (owned range + halo) are read
-    from ``data`` and uploaded -- annotates it, and scans the output range it owns.  What travels is the trigger list
-    of each rank plus, per trigger spec, where the run that starts at the rank's first owned sample ends
-    (``stitch_triggers`` joins runs that cross a cut): a few hundred bytes through the host, no probability rows and no
-    data-path collective.  ``data``: a (3, N) array / tensor, or ``(N, load)`` with
-    ``load(lo, hi) -> (3, hi - lo)`` for callers that never hold the whole stream.
-    ``annotate_fn(block) -> (n_out, len)`` and ``pick_fn(rows, specs) -> [(spec, on, off, peak, value)]`` replace the
-    GPU path in the CPU tests (the oracle stands there)."""
+    from ``data`` and uploaded -- annotates it, and scans the output range it owns: ONE trigger scan per rank, the trigger
+    specs plus, per spec, a (thr_off, thr_off) row whose trigger at the first owned sample (if any) is the run that reaches
+    in from the segment before (``head_end``).  What travels is fixed-width integer columns -- a header (count, owned range,
+    head ends, the first few trigger rows) all-gathered, and, unless every list was that short, the trigger columns padded to
+    the largest count and gathered on rank 0 -- a few KB, no probability rows, no data-path collective, no pickling (SURVEY.md
+    section 8e).  Rank 0 joins the runs that cross a cut
+    (``stitch_trigger_columns``) and returns record lists that are built on first access, as ``classify()`` does.
+    ``data``: a (3, N) array / tensor, or ``(N, load)`` with ``load(lo, hi) -> (3, hi - lo)`` for callers that never hold the
+    whole stream.  ``annotate_fn(block) -> (n_out, len)`` and ``pick_fn(rows, specs) -> [(spec, on, off, peak, value)]`` (or
+    the five columns) replace the GPU path in the CPU tests (the oracle stands there).  ``timing``: a dict that receives
+    this rank's ``total_ms``, ``gpu_ms`` (annotate, synchronised), ``scan_ms``, ``wait_ms`` (a barrier in front of the exchange:
+    the wait for the slowest rank, measured only when ``timing`` is given), ``exchange_ms``, ``stitch_ms`` and ``fixed_ms`` =
+    total - gpu - wait: the part of a call that does not shrink with the number of ranks."""
+    import time
+
     import torch
     import torch.distributed as dist
 
-    from .picks import ClassifyOutput, Detection, DetectionList, Pick, PickList
+    from .models import _records_from_columns
+    from .picks import ClassifyOutput
     from .segments import plan_segments
 
+    t_begin = time.perf_counter()
     args = model._argdict(kwargs)
     specs = model._trigger_specs(args)
+    n_specs = len(specs)
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
     if isinstance(data, tuple):
         n, load = int(data[0]), data[1]
@@ -352,33 +401,89 @@ def classify_stream_sharded(model, data, starttime, trace_id, group=None, annota
         def annotate_fn(block):
             fn = model._annotate_segments if model._is_long(block.shape[1], args) else model._annotate_block
             return fn(block, args)[0]
-    pick_fn = pick_fn or model._pick_rows
-    mine = None
+    if pick_fn is None:
+        def pick_fn(rows, sp):
+            return model._pick_rows(rows, sp, columns=True)
+    cols = _trigger_columns([])
+    head, keep = [-1] * n_specs, (-1, -1)
+    t_gpu = t_scan = 0.0
     if rank < len(segs):  # a short stream has fewer segments than ranks: the surplus ranks own nothing
         sg = segs[rank]
+        t0 = time.perf_counter()
         rows = annotate_fn(load(sg["lo"], sg["hi"]))
         rows = rows if torch.is_tensor(rows) else torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32))
+        t_gpu = time.perf_counter() - t0
+        t0 = time.perf_counter()
         a, b = sg["keep_lo"] - sg["lo"], sg["keep_hi"] - sg["lo"]
-        found = pick_fn(rows[:, a:b], specs)
-        head = [(-1 if rank == 0 else _head_run_end(pick_fn, rows, sp, a, b)) for sp in specs]
-        mine = dict(keep_lo=sg["keep_lo"], keep_hi=sg["keep_hi"],
-                    triggers=[(si, on + sg["keep_lo"], off + sg["keep_lo"], pk + sg["keep_lo"], v)
-                              for si, on, off, pk, v in found],
-                    head_end=[(-1 if h < 0 else h + sg["lo"]) for h in head])
+        # the run of samples > thr_off that starts at the first owned sample = the first trigger of a (thr_off, thr_off) row
+        head_specs = [(row, label, thr_off, thr_off) for row, label, _, thr_off in specs] if rank > 0 else []
+        sp, on, off, pk, v = _trigger_columns(pick_fn(rows[:, a:b], list(specs) + head_specs))
+        if head_specs:
+            is_head = sp >= n_specs
+            for i in np.flatnonzero(is_head & (on == 0)):
+                head[int(sp[i]) - n_specs] = int(off[i]) + sg["keep_lo"]
+            sp, on, off, pk, v = sp[~is_head], on[~is_head], off[~is_head], pk[~is_head], v[~is_head]
+        cols = (sp, on + sg["keep_lo"], off + sg["keep_lo"], pk + sg["keep_lo"], v)
+        keep = (sg["keep_lo"], sg["keep_hi"])
+        t_scan = time.perf_counter() - t0
+    t_wait = 0.0
+    if timing is not None and world > 1:  # (diagnostic only) the wait for the slowest rank, kept apart from the exchange proper
+        t0 = time.perf_counter()
+        dist.barrier(group=group)
+        t_wait = time.perf_counter() - t0
+    t0 = time.perf_counter()
     if world == 1:
-        parts = [mine]
+        parts = [(keep[0], keep[1], head, cols)]
     else:
-        parts = [None] * world if rank == 0 else None
-        dist.gather_object(mine, parts, dst=0, group=group)
-    if rank != 0:
-        return None
-    triggers = stitch_triggers([p for p in parts if p is not None], len(specs))
-    sr = model.sampling_rate
-    picks, detections = PickList(), DetectionList()
-    for si, on, off, pk, v in triggers:
-        label = specs[si][1]
-        if label == "Detection":
-            detections.append(Detection(trace_id, starttime + on / sr, starttime + off / sr, v))
-        else:
-            picks.append(Pick(trace_id, starttime + on / sr, starttime + off / sr, starttime + pk / sr, v, label))
-    return ClassifyOutput(model.name, picks=PickList(sorted(picks)), detections=DetectionList(sorted(detections)))
+        # Two small collectives of integer tensors: the headers (count, owned range, head ends) all-gathered, so that every rank
+        # knows the largest count; the trigger columns, padded to it, gathered on rank 0.  (One all-gather of header + a fixed
+        # 1024 rows per rank was measured too: 1.1 ms against 0.5 ms for these two over a four-rank gloo group -- 41 KB per rank
+        # through the host's loopback; the inline rows are kept for short lists only.)
+        CAP = int(_EXCHANGE_CAP)
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        m = len(cols[0])
+
+        def pack(width):
+            q = np.zeros((width, 5), np.int64)
+            k = min(m, width)
+            q[:k, 0], q[:k, 1], q[:k, 2], q[:k, 3] = cols[0][:k], cols[1][:k], cols[2][:k], cols[3][:k]
+            q[:k, 4] = cols[4][:k].astype(np.float32).view(np.int32)  # the value's bits: nothing is rounded on the way
+            return q
+
+        block = np.concatenate([np.asarray([m, keep[0], keep[1]] + head, np.int64), pack(CAP).ravel()])
+        mine = torch.from_numpy(block).to(dev)
+        blocks = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(blocks, mine, group=group)
+        blocks = torch.stack(blocks).cpu().numpy()
+        headers, rows_of = blocks[:, :3 + n_specs], [blocks[r, 3 + n_specs:].reshape(CAP, 5) for r in range(world)]
+        width = int(headers[:, 0].max())
+        if width > CAP:  # (decided by every rank alike, from the same headers)
+            mine = torch.from_numpy(pack(width)).to(dev)
+            pieces = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+            dist.gather(mine, pieces, dst=_global_rank(group, 0), group=group)
+            if rank == 0:
+                rows_of = [p_.cpu().numpy() for p_ in pieces]
+        if rank == 0:
+            parts = []
+            for r in range(world):
+                cnt = int(headers[r, 0])
+                if headers[r, 1] < 0:  # a surplus rank
+                    continue
+                q = rows_of[r][:cnt]
+                parts.append((int(headers[r, 1]), int(headers[r, 2]), headers[r, 3:].tolist(),
+                              (q[:, 0].astype(np.int32), q[:, 1].copy(), q[:, 2].copy(), q[:, 3].copy(),
+                               q[:, 4].astype(np.int32).view(np.float32))))
+    t_exchange = time.perf_counter() - t0
+    result, t_stitch = None, 0.0
+    if rank == 0:
+        t0 = time.perf_counter()
+        sp, on, off, pk, v = parts[0][3] if len(parts) == 1 else stitch_trigger_columns(parts, n_specs)
+        picks, detections = _records_from_columns([(0, sp, on, off, pk, v)] if len(sp) else [], [trace_id], [starttime._us],
+                                                  [s_[1] for s_ in specs], model.sampling_rate)
+        result = ClassifyOutput(model.name, picks=picks, detections=detections)
+        t_stitch = time.perf_counter() - t0
+    if timing is not None:
+        total = time.perf_counter() - t_begin
+        timing.update(total_ms=total * 1e3, gpu_ms=t_gpu * 1e3, scan_ms=t_scan * 1e3, wait_ms=t_wait * 1e3, exchange_ms=t_exchange * 1e3,
+                      stitch_ms=t_stitch * 1e3, fixed_ms=(total - t_gpu - t_wait) * 1e3)
+    return result
