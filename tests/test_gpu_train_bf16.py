@@ -38,6 +38,66 @@ def close_bf16(got, want, what, abs_frac=2e-5, knife_edge=0.0):
     bad = np.abs(got - want) > tol
     allowed = int(max(1, knife_edge * bad.size)) if knife_edge > 0 else 0
     assert int(bad.sum()) <= allowed, (what, int(bad.sum()), float((np.abs(got - want) / tol).max()))
+    return bad  # the elements let through under `knife_edge`: the caller proves that each of them IS one (assert_knife_edges)
+
+
+def assert_knife_edges(bad, name, bn, z_stored, ga, gz_got, crop, abs_frac):
+    """Every element of gz that close_bf16 let through under `knife_edge` must be a knife edge and nothing else:
+    (1) its BatchNorm output u = fma(z, sc, sh) is zero to within two bf16 ulps of |z sc| + |sh| (sc, sh: the channel's scale and
+        shift from the batch statistics of the stored z), i.e. the ReLU gate hangs on the last bits of the statistics;
+    (2) its gz is torch's value for the OTHER gate state (the backward recomputed with exactly these elements' gates flipped),
+        to the same tolerance every other element meets.
+    An indexing bug that corrupts one element per tensor passes neither."""
+    idx = np.argwhere(bad)
+    z_in = torch.from_numpy(np.ascontiguousarray(z_stored)).clone().requires_grad_(True)
+    u = bn(z_in)  # training mode: batch statistics of the stored z
+    with torch.no_grad():
+        mean = z_in.mean(dim=(0, 2))
+        var = z_in.var(dim=(0, 2), unbiased=False)
+        sc = bn.weight / torch.sqrt(var + bn.eps)
+        sh = bn.bias - mean * sc
+    for b, c, tpos in idx:
+        zz, ss, hh = float(z_in[b, c, tpos].detach()), float(sc[c]), float(sh[c])
+        assert abs(float(u[b, c, tpos].detach())) <= 2 * ULP * (abs(zz * ss) + abs(hh)) + 1e-30, \
+            (name, "let through, but not a knife edge", (int(b), int(c), int(tpos)), float(u[b, c, tpos].detach()), zz * ss, hh)
+    mask = (u.detach() > 0).to(torch.float32)
+    for b, c, tpos in idx:
+        mask[b, c, tpos] = 1.0 - mask[b, c, tpos]
+    a_alt = u * mask
+    if crop is not None:
+        lo, La = crop
+        a_alt = a_alt[:, :, lo: lo + La]
+    (gz_alt,) = torch.autograd.grad(a_alt, z_in, ga)  # (not .backward(): the module's parameter gradients stay as the caller left them)
+    want = gz_alt.numpy().astype(np.float64)
+    got = np.asarray(gz_got, np.float64)
+    tol = ULP * np.abs(want) + abs_frac * np.abs(want).max() + 1e-30
+    for b, c, tpos in idx:
+        assert abs(got[b, c, tpos] - want[b, c, tpos]) <= tol[b, c, tpos], \
+            (name, "not the other gate's value either", (int(b), int(c), int(tpos)), got[b, c, tpos], want[b, c, tpos])
+
+
+def assert_differences_sit_on_rounding_boundaries(conv, x_in, diff, got, what):
+    """Where the kernel's stored bf16 conv output differs from torch's rounded one, it must still be THE nearest-even bf16 rounding
+    of a value that two fp32 summation orders of the same exact products can produce: |got - z32| <= half a bf16 spacing at that
+    magnitude + 2^-23 (sum |w||x| + |b|), z32 = torch's unrounded fp32 sum.  For a sum of ordinary size that means the unrounded
+    value sits on a rounding boundary (the two sides land one ulp apart); for a sum that nearly cancels the slack of the summation
+    order is all there is.  A wrong tap, a shifted sample or a corrupted element is neither."""
+    with torch.no_grad():
+        z32 = conv(x_in).numpy().astype(np.float64)
+        absconv = torch.nn.functional.conv1d(x_in.abs(), conv.weight.abs(), None if conv.bias is None else conv.bias.abs(),
+                                             padding=conv.padding).numpy().astype(np.float64)
+    v, gv = z32[diff], np.asarray(got, np.float64)[diff]
+    big = np.maximum(np.abs(v), np.abs(gv)).astype(np.float32)
+    lo = (big.view(np.uint32) & np.uint32(0xFFFF0000))
+    spacing = ((lo + np.uint32(0x10000)).view(np.float32).astype(np.float64) - lo.view(np.float32).astype(np.float64))
+    slack = 2.0 ** -23 * absconv[diff] + 1e-30
+    off = np.abs(gv - v)
+    assert np.all(off <= spacing / 2 + slack), (what, int((off > spacing / 2 + slack).sum()), float((off / (spacing / 2 + slack)).max()))
+    # ... and most of them ARE boundary cases: the unrounded value within the slack of the midpoint of two bf16 neighbours
+    f = v.astype(np.float32)
+    flo = (f.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32).astype(np.float64)
+    mid = flo + np.sign(v) * spacing / 2
+    assert np.mean(np.abs(v - mid) <= slack + spacing * 2.0 ** -10) > 0.9 or len(v) < 20, what
 
 
 def is_bf16(a):
@@ -74,6 +134,7 @@ def test_end_to_end_against_autograd_with_the_same_rounding_points(step):
     diff = t["inc.z"] != z["inc"]
     assert diff.mean() < 0.02, diff.mean()
     assert np.all(np.abs(t["inc.z"] - z["inc"])[diff] <= 2.0 ** -7 * np.abs(z["inc"])[diff] + 1e-30)
+    assert_differences_sit_on_rounding_boundaries(load_pretrained("phasenet").inc, round_bf16(torch.from_numpy(x)), diff, t["inc.z"], "inc.z")
     d = np.abs(pred - want_pred)
     assert np.median(d) < 1e-4 and np.percentile(d, 99) < 5e-3, (np.median(d), np.percentile(d, 99))
     for name in z:  # bulk agreement; single elements diverge (module docstring)
@@ -136,16 +197,20 @@ def check_every_kernel(B, x, y, tr, loss, t, g, pred, net=None):
         # ---- BatchNorm (batch statistics) + ReLU on the stored z --------------------------------------------------
         z_in = T[name + ".z"].clone().requires_grad_(True)
         a_ref = torch.relu(bn(z_in))
+        crop = None
         if kind == "convT":
             a_ref = a_ref[:, :, OC.PN_UP_CROP[0]: a_ref.shape[-1] - OC.PN_UP_CROP[1]]
             La = t[name + ".a"].shape[-1]
             off = (a_ref.shape[-1] - La) // 2
             a_ref = a_ref[:, :, off: off + La]
+            crop = (OC.PN_UP_CROP[0] + off, La)
         close_bf16(t[name + ".a"], a_ref.detach().numpy(), name + ".a", abs_frac=1e-4)
         # ---- BatchNorm backward from the stored ga: gz, d gamma, d beta -------------------------------------------
         # (gates from the STORED a, as the kernel takes them: rounding never turns a positive value into zero)
         a_ref.backward(ga[name])
-        close_bf16(t[name + ".gz"], z_in.grad.numpy(), name + ".gz", abs_frac=2e-4, knife_edge=2e-6)
+        let_through = close_bf16(t[name + ".gz"], z_in.grad.numpy(), name + ".gz", abs_frac=2e-4, knife_edge=2e-6)
+        if let_through.any():  # (the same bn module: its running statistics move, nothing the checks below read)
+            assert_knife_edges(let_through, name, bn, t[name + ".z"], ga[name], t[name + ".gz"], crop, abs_frac=2e-4)
         for p in bn.parameters():
             want = p.grad.numpy()
             assert np.abs(g[pname[id(p)]] - want).max() < 2e-4 * np.abs(want).max() + 1e-7, (name, pname[id(p)])
