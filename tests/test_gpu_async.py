@@ -262,3 +262,42 @@ def test_stream_sharded_entry_point_on_one_rank_equals_classify():
     assert len(got.picks) == len(want.picks) > 0 and len(got.detections) == len(want.detections)
     for p, q in zip(got.picks, want.picks):
         assert (p.trace_id, p.phase, p.peak_time, p.peak_value) == (q.trace_id, q.phase, q.peak_time, q.peak_value)
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_many_long_stations_equal_per_station_calls(pinned):
+    """classify() on a host Stream of several LONG station blocks (each spread over the device contexts segment by segment), from
+    pageable rows or from rows in page-locked memory (volpick_amd.pinned_array: asynchronous DMA); short blocks and int32 counts
+    mixed in.  Every station's pick list equals the one-station call's."""
+    from volpick_amd import Stream, Trace, UTCDateTime, pinned_array
+    from volpick_amd.synthetic import synthetic_stream_array
+
+    m = va.PhaseNet.from_pretrained("volpick")
+    m._max_batch = 8
+    m.cuda()
+    T, overlap = m.in_samples, 1500
+    n_long = T + (T - overlap) * 90 + 5
+    assert m._is_long(n_long, m._argdict(dict(overlap=overlap)))
+    t0 = UTCDateTime("2023-03-03T03:03:03")
+    stations, full = [], Stream()
+    for k, n in enumerate([n_long, n_long + 777, 20_000, n_long, 3 * T]):
+        data, _, _ = synthetic_stream_array(n, seed=700 + k, n_events=max(2, n // 50_000))
+        rows = []
+        for i in range(3):
+            src = (data[i] * 1000).astype(np.int32) if k == 1 else data[i]  # one station as counts: cast on the device
+            if pinned:
+                row = pinned_array(n, src.dtype)
+                row[:] = src
+                src = row
+            rows.append(src)
+        st = Stream([Trace(rows[i], dict(network="XX", station=f"M{k}", location="", channel="HH" + c, starttime=t0 + 10 * k,
+                                         sampling_rate=100.0)) for i, c in enumerate("ZNE")])
+        stations.append(st)
+        full += st
+    kw = dict(overlap=overlap, P_threshold=0.25, S_threshold=0.25)
+    together = m.classify(full, **kw)
+    apart = sorted(p for st in stations for p in m.classify(st, **kw).picks)
+    assert len(together.picks) == len(apart) > 10
+    for a, b in zip(together.picks, apart):
+        assert (a.trace_id, a.phase, a.start_time, a.end_time, a.peak_time, a.peak_value) == (
+            b.trace_id, b.phase, b.start_time, b.end_time, b.peak_time, b.peak_value)

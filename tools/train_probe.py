@@ -24,7 +24,19 @@ def bare():
     _lib.check(lib.vp_train_step(tr._h, C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), _lib.VP_MEM_DEVICE, B, 1e-4, 1, None))
 
 
-for name, fn in (("tr.step", lambda: tr.step(xd, yd, 1e-4, want_loss=False)), ("bare vp_train_step", bare), ("tr.step", lambda: tr.step(xd, yd, 1e-4, want_loss=False))):
+xd2, yd2 = torch.roll(xd, 1, 0).contiguous(), torch.roll(yd, 1, 0).contiguous()
+torch.cuda.synchronize()
+flip = [0]
+
+
+def alternating():  # a fresh tensor pair every step: what a loader hands over (bench.py's train leg)
+    flip[0] ^= 1
+    tr.step(*((xd, yd), (xd2, yd2))[flip[0]], 1e-4, want_loss=False)
+
+
+for name, fn in (("tr.step", lambda: tr.step(xd, yd, 1e-4, want_loss=False)), ("bare vp_train_step", bare),
+                 ("tr.step promised", lambda: tr.step(xd, yd, 1e-4, want_loss=False, inputs_unchanged=True)),
+                 ("tr.step alternating", alternating), ("tr.step", lambda: tr.step(xd, yd, 1e-4, want_loss=False))):
     for _ in range(5):
         fn()
     tr.synchronize()

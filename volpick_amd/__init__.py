@@ -19,7 +19,7 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 from .models import EQTransformer, PhaseNet, WaveformModel  # noqa: F401
 from .picks import ClassifyOutput, Detection, DetectionList, Pick, PickList  # noqa: F401
-from .stream import Stream, Trace, UTCDateTime  # noqa: F401
+from .stream import Stream, Trace, UTCDateTime, pinned_array  # noqa: F401
 from ._lib import VolpickHipError  # noqa: F401
 from .io import read  # noqa: F401
 

@@ -410,7 +410,7 @@ class WaveformModel:
         if torch.is_tensor(data):  # assembled on the device by _group_stream
             x = data.to(dev, torch.float32).contiguous()
         elif isinstance(data, _Rows):
-            x = data.upload(torch, dev)
+            x = data.upload(torch, dev)[0]
         else:
             x = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(dev)
         out = torch.empty((3, n), dtype=torch.float32, device=dev)
@@ -456,7 +456,7 @@ class WaveformModel:
             if torch.is_tensor(data):
                 x = data[:, lo:hi].to(dev, torch.float32).contiguous()
             elif isinstance(data, _Rows):
-                x = _Rows([p[lo:hi] for p in data.parts]).upload(torch, dev)
+                x = _Rows([p[lo:hi] for p in data.parts]).upload(torch, dev)[0]
             else:
                 x = torch.from_numpy(np.ascontiguousarray(data[:, lo:hi], dtype=np.float32)).to(dev)
             y = torch.empty((3, hi - lo), dtype=torch.float32, device=dev)
@@ -556,7 +556,7 @@ class WaveformModel:
         if torch.is_tensor(data):  # assembled on the device by _group_stream
             x = data.to(dev, torch.float32).contiguous()
         elif isinstance(data, _Rows):
-            x = data.upload(torch, dev)
+            x = data.upload(torch, dev)[0]
         else:
             x = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(dev)
         torch.cuda.current_stream(dev).synchronize()
@@ -803,14 +803,27 @@ class _Rows:
     def __getitem__(self, idx):
         return np.asarray(self)[idx]
 
-    def upload(self, torch, dev):
-        x = torch.empty(self.shape, dtype=torch.float32, device=dev)
-        for c, p in enumerate(self.parts):
-            h = torch.from_numpy(np.ascontiguousarray(p))
-            # int32 counts (what a miniSEED file decodes to) and float64 rows travel as they are and are cast on the device:
-            # the host-side cast of a day-long row costs 20 ms, 30 x its upload
-            x[c].copy_(h if h.dtype == torch.float32 else h.to(dev))
-        return x
+    def upload(self, torch, dev, out=None, copy_stream=None):
+        """-> (device array, temporaries to keep alive until the copies are done).  ``copy_stream``: the copies run under this
+        stream while every allocation is made under the caller's current one (torch's caching allocator ties a block to the
+        stream it was allocated under and touches that stream again when the block is reused or released)."""
+        import contextlib
+
+        x = out if out is not None else torch.empty(self.shape, dtype=torch.float32, device=dev)
+        hosts = [torch.from_numpy(np.ascontiguousarray(p)) for p in self.parts]
+        # int32 counts (what a miniSEED file decodes to) and float64 rows travel as they are and are cast on the device: the
+        # host-side cast of a day-long row costs 20 ms, 30 x its upload.  Rows in page-locked memory
+        # (volpick_amd.pinned_array) go by DMA without the runtime's staging copy.
+        temps = [None if h.dtype == torch.float32 else torch.empty(h.shape, dtype=h.dtype, device=dev) for h in hosts]
+        with (torch.cuda.stream(copy_stream) if copy_stream is not None else contextlib.nullcontext()):
+            for c, (h, t) in enumerate(zip(hosts, temps)):
+                pinned = h.is_pinned()
+                if t is None:
+                    x[c].copy_(h, non_blocking=pinned)
+                else:
+                    t.copy_(h, non_blocking=pinned)
+                    x[c].copy_(t)
+        return x, [t for t in temps if t is not None]
 
 
 # --------------------------------------------------------------------------- stream handling
