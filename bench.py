@@ -84,8 +84,9 @@ def _pick(d, *keys):
     return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
 
 
-def _compact_model(m):
-    """The short form of one model's result (the top-level PhaseNet line or the `eqtransformer` object)."""
+def _compact_model(m, brief=False):
+    """The short form of one model's result (the top-level PhaseNet line or, `brief`, the `eqtransformer` object: what the two
+    share -- the host's CPU model, the quota -- is said once)."""
     out = _pick(m, "value", "unit", "ms_per_step")
     if isinstance(m.get("config"), dict):
         out["config"] = _pick(m["config"], "workload", "batch", "parallelism")
@@ -108,9 +109,10 @@ def _compact_model(m):
         out["roofline"] = rr
     c = m.get("cpu_baseline")
     if c:
-        out["cpu_baseline"] = _pick(c, "value", "unit", "cores", "kind", "cpu_model", "physical_cores", "cgroup_cpu_quota")
+        out["cpu_baseline"] = _pick(c, "value", "unit", "cores", "kind") if brief else \
+            _pick(c, "value", "unit", "cores", "kind", "cpu_model", "physical_cores", "cgroup_cpu_quota")
         if isinstance(c.get("sample"), str):
-            out["cpu_baseline"]["sample"] = c["sample"][:110]
+            out["cpu_baseline"]["sample"] = c["sample"][:48 if brief else 110]
     if m.get("pick_parity"):
         out["pick_parity"] = _pick(m["pick_parity"], "picks_hip", "picks_oracle", "max_abs_dt_samples", "max_abs_dvalue")
     a = m.get("api")
@@ -146,7 +148,7 @@ def compact_line(result, detail_path=None):
     if result.get("ranks"):
         out["rccl_comm_ranks"] = result["ranks"][0].get("rccl_comm_ranks")
     if isinstance(result.get("eqtransformer"), dict):
-        out["eqtransformer"] = _compact_model(result["eqtransformer"])
+        out["eqtransformer"] = _compact_model(result["eqtransformer"], brief=True)
     tr = result.get("train")
     if isinstance(tr, dict):
         out["train"] = _pick(tr, "value", "unit", "ms_per_step", "batch", "dtype", "launches_per_step", "settle_steps", "loss_after",

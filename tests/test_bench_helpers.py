@@ -166,3 +166,20 @@ def test_compact_line_sheds_optional_objects_rather_than_fail(monkeypatch):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert "api" not in d and "mseed" not in d
+
+
+def test_compact_line_from_round_6_detail_stays_under_four_kilobytes():
+    """The line with everything round 6 added (api.many_stations for both models, roofline.useful_frac, the long dtype label, the
+    train / mseed objects from their child processes): still < 4 KB, strict JSON, the new keys present."""
+    import json
+
+    full = json.loads((Path(__file__).resolve().parents[1] / "profiles" / "r06_b_bench_detail.json").read_text())
+    line = bench.compact_line(full, "bench_detail.json")
+    assert "\n" not in line and len(line) < 4096
+    d = json.loads(line, parse_constant=lambda c: (_ for _ in ()).throw(AssertionError(f"non-strict JSON constant {c}")))
+    for k in ("roofline.useful_frac", "roofline.frac", "roofline.kernel_ms", "api.many_stations.value", "api.many_stations.picks_equal",
+              "eqtransformer.api.many_stations.value", "eqtransformer.roofline.useful_frac", "train.ms_per_step", "mseed.value",
+              "cpu_baseline.cpu_model", "eqtransformer.cpu_baseline.value", "config.parallelism"):
+        _required(d, k)
+    assert d["dtype"].startswith("f32 (exact 3xbf16") and d["roofline"]["kernel_ms"] <= d["ms_per_step"] * 1.0001
+    assert "RCCL" not in d["config"]["parallelism"]  # one rank: nothing was broadcast
