@@ -56,26 +56,28 @@ typedef struct {
                                  [0]: 1 = PhaseNet layer-by-layer plan instead of the fused kernels (debug / A-B);
                                  [1]: bit0 = fused kernels also dump their LDS intermediates to the debug tensors
                                       (selects the three-launch plan), bit1 = per-layer clock stamps;
-                                 [2]: PhaseNet: 1 = hand-pipelined K loop in the MFMA layers (A/B); EQTransformer: 1 = the three
+                                 [2]: PhaseNet: (1 = hand-pipelined K loop in the MFMA layers: removed in round 6, rejected);
+                                      EQTransformer: 1 = the three
                                       BiLSTM blocks, two transformer blocks and the pick branches as six launches instead
                                       of the one-launch middle kernel, 2 = eqt_mid_kernel with one window per 512-thread
                                       workgroup, 3 = with two windows per 1024-thread workgroup (teams of eight waves: the
                                       default of rounds 3-5); default: eqt_mid4_kernel, FOUR windows per 1024-thread
                                       workgroup in teams of four waves, so that a batch of 256 holds 64 CUs and leaves the
                                       rest to the kernels of the other device contexts (all three bit-identical);
-                                 [3]: tiled level-0 kernel variants of the all-MFMA plan (A/B); 64 = PhaseNet's one-launch plan
+                                 [3]: 1 = the tiled level-0 up kernel of the three-launch plans with one workgroup per tile
+                                      (A/B; 2, the persistent down kernel, was removed in round 6); 64 = PhaseNet's one-launch plan
                                       WITHOUT the first-come-first-served gate between the device contexts' forward
                                       launches (A/B: csrc/api.hip ForwardGate);
                                  [4]: 1 = no L2 warm-up of the weight streams;
                                  [5]: PhaseNet plan: 0 = the whole network in one launch, its five deepest layers on the
                                       bf16 matrix cores with exact three-piece operands (default), 1 = three launches,
                                       all MFMA (bit-identical to the layer plan), 2 = three launches, level-0
-                                      stride-1 convs on the VALU, 3 = one launch, every core layer on the fp32 MFMA,
-                                      4 = one launch with up1.same and up2.same on the fp32 MFMA, 5 = with up2.same only,
-                                      6 = with up1.convT and up2.convT on the fp32 MFMA, 7 = with down1.same and down2.same
-                                      on the fp32 MFMA, 8 = with inc and down0.same as packed-FMA direct convolutions on
-                                      the vector ALUs, 9 = with up3.convT on the fp32 MFMA and up3.same + head on the
-                                      vector ALUs (default: all of these on the bf16 matrix cores too -- up1.same /
+                                      stride-1 convs on the VALU, 3 = one launch, every core layer on the fp32 MFMA
+                                      (the reference of the bf16-piece layers), 8 = one launch with inc and down0.same
+                                      as packed-FMA direct convolutions on the vector ALUs and up3.convT / up3.same /
+                                      head in round 4's forms (the rounding reference of the tiled level-0 layers);
+                                      4, 5, 6, 7, 9 -- intermediate forms of rounds 2-5 -- were removed in round 6 and
+                                      are rejected (default: all of these on the bf16 matrix cores too -- up1.same /
                                       up2.same in two K halves over one piece image that is refilled in between, inc /
                                       down0.same time-tiled in six tiles of 512 samples, up3.convT / up3.same / head in
                                       twelve tiles of 256 with producer and consumer waves);
@@ -96,8 +98,9 @@ typedef struct {
                                       blind the output (default: only the tiles that hold kept samples),
                                       bit11 = stage 3 of the fused decoder 0-3 kernel shares its n-tiles evenly between
                                       the two waves of a SIMD (default: 14 + 10),
-                                      bit12 = the bf16-piece ResCNN kernel with eight waves per window (K split over wave
-                                      pairs; default: four waves per window and TWO windows per workgroup, bit9: one) */
+                                      (bit12, the bf16-piece ResCNN kernel with eight waves per window and K split over
+                                      wave pairs, was removed in round 6 and is rejected; default: four waves per window
+                                      and TWO windows per workgroup, bit9: one) */
   int32_t reserved[4];        /* must be 0 */
 } vp_config;
 

@@ -242,12 +242,30 @@ def test_regression_bar_full_batch(default_pair):
 
 # ---- (e) every documented plan selector (include/volpick_hip.h: vp_config.plan_flags) still produces oracle-grade outputs --------
 PLAN_SELECTORS = {
-    "phasenet": [(1,), (0, 1), (0, 0, 1), (0, 0, 0, 1), (0, 0, 0, 2), (0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 2),
-                 (0, 0, 0, 0, 0, 3), (0, 0, 0, 0, 0, 4), (0, 0, 0, 0, 0, 5), (0, 0, 0, 0, 0, 6), (0, 0, 0, 0, 0, 7), (0, 0, 0, 0, 0, 8), (0, 0, 0, 0, 0, 9),
-                 (0, 0, 0, 0, 0, 0, 1)],
+    "phasenet": [(1,), (0, 1), (0, 0, 0, 1), (0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 2),
+                 (0, 0, 0, 0, 0, 3), (0, 0, 0, 0, 0, 8), (0, 0, 0, 0, 0, 0, 1)],
     "eqtransformer": [(1,), (0, 0, 1), (0, 0, 2), (0, 0, 3), (0, 0, 0, 0, 1), (0, 0, 0, 0, 0, 0, 2)] +
-                     [(0, 0, 0, 0, 0, 0, 0, 1 << b) for b in range(13)] + [(0, 0, 0, 0, 0, 0, 0, 0x1F0), (0, 0, 0, 0, 0, 0, 0, 0xF)],
+                     [(0, 0, 0, 0, 0, 0, 0, 1 << b) for b in range(12)] + [(0, 0, 0, 0, 0, 0, 0, 0x1F0), (0, 0, 0, 0, 0, 0, 0, 0xF)],
 }
+
+
+# A/B forms that round 6 removed: the library says so instead of running something else
+REMOVED_SELECTORS = {
+    "phasenet": [(0, 0, 1), (0, 0, 0, 2), (0, 0, 0, 0, 0, 4), (0, 0, 0, 0, 0, 5), (0, 0, 0, 0, 0, 6), (0, 0, 0, 0, 0, 7), (0, 0, 0, 0, 0, 9)],
+    "eqtransformer": [(0, 0, 0, 0, 0, 0, 0, 4096)],
+}
+
+
+@pytest.mark.parametrize("name,flags", [(n, f) for n, fl in REMOVED_SELECTORS.items() for f in fl],
+                         ids=[f"{n}-{'.'.join(map(str, f))}" for n, fl in REMOVED_SELECTORS.items() for f in fl])
+def test_removed_plan_selectors_are_rejected(name, flags):
+    from volpick_amd._lib import VolpickHipError
+
+    m = MODELS[name].from_pretrained("volpick")
+    m._plan_flags = flags
+    with pytest.raises(VolpickHipError, match="removed in round 6"):
+        m.cuda()
+        m(torch.zeros((1, 3, m.in_samples)).cuda())
 
 
 @pytest.mark.parametrize("name,flags", [(n, f) for n, fl in PLAN_SELECTORS.items() for f in fl],

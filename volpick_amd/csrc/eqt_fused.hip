@@ -466,202 +466,8 @@ __global__ __launch_bounds__(256 * WPB) void eqt_res3_kernel(const Res3Args a) {
 #undef R3_STAMP
 }
 
-// ---- the same with TWO waves per SIMD: K split over wave pairs -----------------------------------------------------------
-// One wave per SIMD issues a chained v_mfma_f32_16x16x32_bf16 every 20-26 cycles, two waves together every 11-18
-// (tools/micro/micro_b3_mfma.hip), and a window has work for four m-tiles only.  So a window takes eight waves: wave
-// (m-tile mt = w % 4, channel half kh = w / 4) runs the K-steps of input channels 32 kh .. 32 kh + 31 for all three
-// n-tiles, the two waves of an m-tile exchange partial sums through LDS (the wave of half 0 ends up with n-tiles 0 and 1,
-// the other with n-tile 2) and each does the epilogue of what it owns.  Half the operand registers per wave (36 / 24).
-constexpr int R3K_NTH = 512;
-constexpr int R3K_OFF_ACT = 64 * R3_XS * 4, R3K_OFF_MID = R3K_OFF_ACT + 3 * R3_PS * 2, R3K_OFF_RED = R3K_OFF_MID + 3 * R3_PS * 2;
-constexpr int R3K_LDS_BYTES = R3K_OFF_RED + 4 * 3 * 64 * 16;  // + partial sums [m-tile][n-tile][lane] float4
-static_assert(R3K_OFF_ACT % 16 == 0 && R3K_LDS_BYTES <= 160 * 1024, "LDS budget");
-
-template <int TAPS>
-struct Res3KA {
-  uint4 q[TAPS][3];  // this wave's channel half of every tap
-  float bias[4], sn[4], bn[4];
-  __device__ __forceinline__ void load(const uint4* af, const float* b, const float* s, const float* sh, const int mt, const int kh,
-                                       const int lane) {
-    const uint4* p = af + (long)mt * (TAPS * 2 * 3 * 64) + lane;
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap)
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc) q[tap][pc] = p[((tap * 2 + kh) * 3 + pc) * 64];
-    const int co = mt * 16 + 4 * (lane >> 4);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      bias[r] = b[co + r];
-      sn[r] = s ? s[co + r] : 0.f;
-      bn[r] = sh ? sh[co + r] : 0.f;
-    }
-  }
-};
-
-template <int TAPS>
-__device__ __forceinline__ void res3k_mac(const bf16_t* src, const Res3KA<TAPS>& A, f32x4 (&acc)[3], const int lane, const int kh) {
-  constexpr int IN_OFF = (TAPS == 3) ? -1 : 0;
-  const int g = lane >> 4, n = lane & 15;
-#pragma unroll
-  for (int j = 0; j < 3; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bf16_t* bp = src + (kh * 4 + g) * R3_CHS + (n + IN_OFF + 1) * 8;
-  uint4 bA[3][3], bB[3][3];
-  auto load_b = [&](uint4 (&b)[3][3], const int tap) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc) b[j][pc] = *reinterpret_cast<const uint4*>(bp + pc * R3_PS + (j * 16 + tap) * 8);
-  };
-  load_b(bA, 0);
-#pragma unroll
-  for (int s = 0; s < TAPS; ++s) {
-    if (s + 1 < TAPS) {
-      if (s & 1) load_b(bA, s + 1); else load_b(bB, s + 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    constexpr int WP[6] = {2, 1, 0, 1, 0, 0}, XP[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        const uint4(&b)[3] = (s & 1) ? bB[j] : bA[j];
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_res, A.q[s][WP[t]]),
-                                                        __builtin_bit_cast(bf16x8_res, b[XP[t]]), acc[j], 0, 0, 0);
-      }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-__global__ __launch_bounds__(R3K_NTH) void eqt_res3k_kernel(const Res3Args a) {
-  extern __shared__ uint4 r3k_lds[];
-  char* base = reinterpret_cast<char*>(r3k_lds);
-  float* X = reinterpret_cast<float*>(base);
-  bf16_t* ACT = reinterpret_cast<bf16_t*>(base + R3K_OFF_ACT);
-  bf16_t* MID = reinterpret_cast<bf16_t*>(base + R3K_OFF_MID);
-  f32x4* RED = reinterpret_cast<f32x4*>(base + R3K_OFF_RED);
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), win = blockIdx.x;
-  const int mt = wave & 3, kh = wave >> 2;
-  const int g = lane >> 4, n = lane & 15;
-  if (a.warm) {  // see eqt_res3_kernel
-    const int nx = gridDim.x >= 8 ? gridDim.x >> 3 : 1, xw = win >> 3;
-    constexpr int kers_pf[7] = {3, 3, 3, 3, 2, 3, 2};
-    unsigned sink = 0u;
-    if (xw < nx) {
-#pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        const int lines = (int)((kers_pf[i] == 3 ? a.af_bytes_k3 : a.af_bytes_k2) / 128);
-        for (int l = xw * R3K_NTH + tid; l < lines; l += nx * R3K_NTH)
-          sink ^= reinterpret_cast<const unsigned*>(a.af1[i])[l * 32] ^ reinterpret_cast<const unsigned*>(a.af2[i])[l * 32];
-      }
-    }
-    if (sink == 0x12345678u && a.ls_x == -1) a.out[0] = __uint_as_float(sink);
-  }
-  for (int i = tid; i < 2 * 3 * R3_PS / 8; i += R3K_NTH)  // ACT and MID lie side by side: zero halo columns (and everything else once)
-    reinterpret_cast<uint4*>(ACT)[i] = make_uint4(0u, 0u, 0u, 0u);
-  __syncthreads();
-  {
-    const float* x0 = a.x0 + (long)win * a.ws_x + HALO;
-    const float* a0 = a.act0 + (long)win * a.ws_a + HALO;
-    for (int i = tid; i < 64 * RT; i += R3K_NTH) {
-      const int c = i / RT, t = i - c * RT;
-      X[c * R3_XS + t] = x0[(long)c * a.ls_x + t];
-    }
-    for (int i = tid; i < 16 * RT; i += R3K_NTH) {  // four channels of one column per trip
-      const int cq = i / RT, t = i - cq * RT;
-      float v[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = a0[(long)(4 * cq + k) * a.ls_a + t];
-      store3(ACT, t + 1, 4 * cq, v);
-    }
-  }
-  __syncthreads();
-  const int co = mt * 16 + 4 * g;  // this lane's four output channels
-  f32x4 acc[3];
-  f32x4* red = RED + (mt * 3) * 64 + lane;
-  // the wave of half 0 keeps n-tiles 0 and 1, the other n-tile 2: what a wave does not keep goes to its partner
-  auto exchange = [&]() {  // whole-vector moves and adds only: element-wise updates sent the accumulators through scratch
-    if (kh == 0) {
-      red[2 * 64] = acc[2];
-    } else {
-      red[0] = acc[0];
-      red[64] = acc[1];
-    }
-    __syncthreads();
-    const f32x4 pa = red[kh == 0 ? 0 : 2 * 64], pb = red[64];
-    if (kh == 0) {
-      acc[0] = acc[0] + pa;
-      acc[1] = acc[1] + pb;
-    } else {
-      acc[2] = acc[2] + pa;
-    }
-  };
-  auto conv1_tile = [&](const int j, const float (&bv)[4]) {
-    const int t = j * 16 + n;
-    float v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = (t < RT) ? fmaxf(acc[j][r] + bv[r], 0.f) : 0.f;
-    store3(MID, t + 1, co, v);
-  };
-  auto conv2_tile = [&](const int j, const float (&bv)[4], const float (&sv)[4], const float (&ov)[4], const bool last) {
-    const int t = j * 16 + n;
-    float v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float o = 0.f;
-      if (t < RT) {
-        o = acc[j][r] + bv[r] + X[(co + r) * R3_XS + t];
-        X[(co + r) * R3_XS + t] = o;
-      }
-      v[r] = (t < RT) ? fmaxf(fmaf(sv[r], o, ov[r]), 0.f) : 0.f;
-    }
-    if (!last) store3(ACT, t + 1, co, v);
-  };
-#define R3K_BLOCK(I, TAPS, NEXT_LOAD)                                                             \
-  {                                                                                               \
-    Res3KA<TAPS> w2;                                                                              \
-    w2.load(a.af2[I], a.bs2[I], (I) == 6 ? nullptr : a.s_next[I], (I) == 6 ? nullptr : a.b_next[I], mt, kh, lane); \
-    res3k_mac<TAPS>(ACT, w1_##I, acc, lane, kh);                                                  \
-    exchange();                                                                                   \
-    if (kh == 0) {                                                                                \
-      conv1_tile(0, w1_##I.bias);                                                                 \
-      conv1_tile(1, w1_##I.bias);                                                                 \
-    } else {                                                                                      \
-      conv1_tile(2, w1_##I.bias);                                                                 \
-    }                                                                                             \
-    __syncthreads();                                                                              \
-    NEXT_LOAD                                                                                     \
-    res3k_mac<TAPS>(MID, w2, acc, lane, kh);                                                      \
-    exchange();                                                                                   \
-    if (kh == 0) {                                                                                \
-      conv2_tile(0, w2.bias, w2.sn, w2.bn, (I) == 6);                                             \
-      conv2_tile(1, w2.bias, w2.sn, w2.bn, (I) == 6);                                             \
-    } else {                                                                                      \
-      conv2_tile(2, w2.bias, w2.sn, w2.bn, (I) == 6);                                             \
-    }                                                                                             \
-    __syncthreads();                                                                              \
-  }
-  Res3KA<3> w1_0;
-  w1_0.load(a.af1[0], a.bs1[0], nullptr, nullptr, mt, kh, lane);
-  Res3KA<3> w1_1;
-  R3K_BLOCK(0, 3, w1_1.load(a.af1[1], a.bs1[1], nullptr, nullptr, mt, kh, lane);)
-  Res3KA<3> w1_2;
-  R3K_BLOCK(1, 3, w1_2.load(a.af1[2], a.bs1[2], nullptr, nullptr, mt, kh, lane);)
-  Res3KA<3> w1_3;
-  R3K_BLOCK(2, 3, w1_3.load(a.af1[3], a.bs1[3], nullptr, nullptr, mt, kh, lane);)
-  Res3KA<2> w1_4;
-  R3K_BLOCK(3, 3, w1_4.load(a.af1[4], a.bs1[4], nullptr, nullptr, mt, kh, lane);)
-  Res3KA<3> w1_5;
-  R3K_BLOCK(4, 2, w1_5.load(a.af1[5], a.bs1[5], nullptr, nullptr, mt, kh, lane);)
-  Res3KA<2> w1_6;
-  R3K_BLOCK(5, 3, w1_6.load(a.af1[6], a.bs1[6], nullptr, nullptr, mt, kh, lane);)
-  R3K_BLOCK(6, 2, )
-#undef R3K_BLOCK
-  float* out = a.out + (long)win * a.ws_out + HALO;
-  for (int i = tid; i < 64 * RT; i += R3K_NTH) {
-    const int c = i / RT, t = i - c * RT;
-    out[(long)c * a.ls_out + t] = X[c * R3_XS + t];
-  }
-}
+// (eqt_res3k_kernel -- eight waves per window, K split over wave pairs with a partial-sum exchange through LDS; round 2's default,
+// 31.5 us on 256 CUs against 44.5 us on 128 -- was removed in round 6: plan_flags[7] bit 12 is rejected.)
 
 // fp32 MFMA-order fragments [mt][cb][tap][64] (pack_afrag) -> three-piece bf16 operand [mt][tap * 2 + half][piece][64][8]
 std::vector<float> res3_operand(const ConvLayer& L, int taps) {
@@ -705,6 +511,10 @@ std::vector<float> res3_operand(const ConvLayer& L, int taps) {
 
 // Replaces the steps "res0.conv1" .. "res6.conv2" of the layer plan by one fused step.
 int plan_eqt_fuse_res(Net& net) {
+  if (net.cfg.plan_flags[7] & 4096) {
+    set_error("EQTransformer plan_flags[7] bit 12 (ResCNN kernel with K split over wave pairs): removed in round 6");
+    return VP_ERR_UNSUPPORTED;
+  }
   int first = -1;
   for (size_t i = 0; i < net.steps.size(); ++i)
     if (net.steps[i].name == "res0.conv1") first = (int)i;
@@ -739,7 +549,6 @@ int plan_eqt_fuse_res(Net& net) {
       b1[i] = net.add_blob(res3_operand(*c1[i], c1[i]->g.taps));
       b2[i] = net.add_blob(res3_operand(*c2[i], c2[i]->g.taps));
     }
-  if (bf3) net.extra_kernels.push_back({reinterpret_cast<const void*>(&eqt_res3k_kernel), (size_t)R3K_LDS_BYTES});
   Step st;
   st.name = "fused.rescnn (7 residual blocks)";
   st.flops_per_window = 0;
@@ -780,9 +589,7 @@ int plan_eqt_fuse_res(Net& net) {
       a.clk = (n.debug_clock && n.debug_clock->d)  // the conv launches' region: unused under the fused plan
                   ? reinterpret_cast<unsigned long long*>(n.debug_clock->d) + (size_t)n.max_batch * 32
                   : nullptr;
-      if (n.cfg.plan_flags[7] & 4096)  // bit 12: eight waves per window, K split over wave pairs (round 2's default: 31.5 us on 256 CUs)
-        hipLaunchKernelGGL(eqt_res3k_kernel, dim3(B), dim3(R3K_NTH), R3K_LDS_BYTES, s, a);
-      else if (n.cfg.plan_flags[7] & 512)  // bit 9: four waves per window, one window per workgroup
+      if (n.cfg.plan_flags[7] & 512)  // bit 9: four waves per window, one window per workgroup
         hipLaunchKernelGGL(eqt_res3_kernel<1>, dim3(B), dim3(256), 0, s, a);
       else  // four waves per window, two windows per workgroup: 44.5 us on 128 CUs
         hipLaunchKernelGGL(eqt_res3_kernel<2>, dim3((B + 1) / 2), dim3(512), 0, s, a);

@@ -439,84 +439,10 @@ __global__ __launch_bounds__(256) void pn_up3_kernel(const Up3Args a) {
 // tile's input rows are fetched into registers while the current tile computes.
 // ---------------------------------------------------------------------------------------------
 constexpr int N_TILES = (T0 + TT - 1) / TT;     // 6
-constexpr int NSPLIT_D = 3, TPS_D = (N_TILES + NSPLIT_D - 1) / NSPLIT_D;  // down0: 45 KB LDS -> 3 workgroups / CU
 constexpr int NSPLIT_U = 2, TPS_U = (N_TILES + NSPLIT_U - 1) / NSPLIT_U;  // up3:   66 KB LDS -> 2 workgroups / CU
 
-__global__ __launch_bounds__(256) void pn_down0p_kernel(const Down0Args a) {
-  extern __shared__ float4 lds_raw[];
-  float* lds = reinterpret_cast<float*>(lds_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int win = blockIdx.y;
-  const int tile_lo = blockIdx.x * TPS_D, tile_hi = (tile_lo + TPS_D < N_TILES) ? tile_lo + TPS_D : N_TILES;
-  constexpr int NTH = 256;
-  constexpr int NQ = (TT + 28) / 4;  // float4 per x row
-  float aI[D_inc::CB * D_inc::TAPS], aS[D_same::CB * D_same::TAPS], aD[D_down::CB * D_down::TAPS];
-  float bI[4], bS[4], bD[4];
-  load_areg<D_inc>(a.af_inc, 0, lane, aI);
-  load_areg<D_same>(a.af_same, 0, lane, aS);
-  load_areg<D_down>(a.af_down, 0, lane, aD);
-  load_biasreg<D_inc>(a.bs_inc, 0, lane, bI);
-  load_biasreg<D_same>(a.bs_same, 0, lane, bS);
-  load_biasreg<D_down>(a.bs_down, 0, lane, bD);
-  for (int i = tid; i < D0_S / 4; i += NTH)  // 4th (padding) input channel: true zeros, written once
-    *reinterpret_cast<float4*>(lds + D0_X + 3 * D0_S + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  const float* xsrc = a.x + (long)win * a.ws_x;
-  float4 px[2];  // 3 rows x NQ float4 = 405 <= 2 * 256
-  auto fetch = [&](int tile) __attribute__((always_inline)) {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int i = tid + k * NTH;
-      px[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < 3 * NQ) {
-        const int c = i / NQ, q = i - c * NQ;
-        const int p = tile * TT - 8 + 4 * q;  // physical index of local -4 + 4q
-        if (p >= 0 && p + 3 < a.ls_x) px[k] = *reinterpret_cast<const float4*>(xsrc + (long)c * a.ls_x + p);
-      }
-    }
-  };
-  fetch(tile_lo);
-  for (int tile = tile_lo; tile < tile_hi; ++tile) {
-    const int t0 = tile * TT, o = t0 - 12;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int i = tid + k * NTH;
-      if (i < 3 * NQ) {
-        const int c = i / NQ, q = i - c * NQ;
-        *reinterpret_cast<float4*>(lds + D0_X + c * D0_S + 4 * q) = px[k];
-      }
-    }
-    __syncthreads();
-    if (tile + 1 < tile_hi) fetch(tile + 1);
-    const int sig_lo = -o, sig_hi = T0 - o;
-    {
-      ImageStore<D0_S, IB> st{lds + D0_H, 0, TT + 16, sig_lo, sig_hi};
-      conv_lds_areg<D_inc, D0_S, IB, D0_S, IB>(lds + D0_X, lds + D0_X, aI, bI, 0, (TT + 16) / 2, st, wave, 4, lane);
-    }
-    __syncthreads();
-    {
-      ImageStore<D0_S, IB> st{lds + D0_K, 0, TT + 16, sig_lo, sig_hi};
-      conv_lds_areg<D_same, D0_S, IB, D0_S, IB>(lds + D0_H, lds + D0_H, aS, bS, 0, (TT + 16) / 2, st, wave, 4, lane);
-    }
-    __syncthreads();
-    {  // skip tensor rows [t0, t0 + TT) -> memory, 16-byte coalesced (local 12 <-> column 16)
-      float* d = a.skip0 + (long)win * a.ws_s + HALO + t0;
-      for (int i = tid; i < 8 * (TT / 4); i += NTH) {
-        const int c = i / (TT / 4), q = i - c * (TT / 4);
-        if (t0 + 4 * q < T0)
-          *reinterpret_cast<float4*>(d + (long)c * a.ls_s + 4 * q) =
-              *reinterpret_cast<const float4*>(lds + D0_K + c * D0_S + IB + 12 + 4 * q);  // zeros beyond the signal
-      }
-    }
-    {
-      GlobalRowStore st{a.d0 + (long)win * a.ws_d + HALO, a.ls_d, T1, tile * (TT / 4)};
-      conv_lds_areg<D_down, D0_S, IB, D0_S, IB>(lds + D0_K, lds + D0_K, aD, bD, 0, TT / 8, st, wave, 4, lane);
-    }
-    // no barrier needed here: the next iteration's first barrier orders these reads before any rewrite
-    // of the skip image (written after two more barriers); X is rewritten now, but its last reader (inc)
-    // finished two barriers ago.
-  }
-}
+// (pn_down0p_kernel, the persistent form of the level-0 down kernel -- plan_flags[3] = 2, measured 4-15 % slower than one workgroup
+// per tile -- was removed in round 6.)
 
 __global__ __launch_bounds__(256) void pn_up3p_kernel(const Up3Args a) {
   extern __shared__ float4 lds_raw[];
@@ -2122,11 +2048,22 @@ std::vector<float> pack_valu(const float* W, int cin, bool transposed, const std
 
 int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
   const bool debug_dumps = (debug_flags & 1) != 0, debug_clock = (debug_flags & 2) != 0;
-  // plan_flags[2] = 1 selects the hand-pipelined K loop (sched_barrier) for A/B timing; the compiler's own
-  // schedule measured 0-5 % faster on every layer (tools/micro/micro_layers.hip), so it is the default.
-  const bool pipe = net.cfg.plan_flags[2] == 1;
+  // Pruned in round 6 (kept in source as `if constexpr` branches of the templates, no longer instantiated): the hand-pipelined K
+  // loop (plan_flags[2] = 1; the compiler's own schedule measured 0-5 % faster on every layer, tools/micro/micro_layers.hip) and
+  // the intermediate forms of pn_window_kernel between its references (plan_flags[5] = 4, 5, 6, 7, 9).
+  {
+    const int f5 = net.cfg.plan_flags[5];
+    if (net.cfg.plan_flags[2] == 1 || f5 == 4 || f5 == 5 || f5 == 6 || f5 == 7 || f5 == 9) {
+      set_error("PhaseNet plan_flags[2] = %d / plan_flags[5] = %d: this A/B form was removed in round 6 (kept: plan_flags[5] = 0, 1, 2, 3, 8)",
+                net.cfg.plan_flags[2], f5);
+      return VP_ERR_UNSUPPORTED;
+    }
+  }
   const bool persistent = net.cfg.plan_flags[3] != 1;  // plan_flags[3] = 1: one workgroup per tile for up3 too (A/B timing)
-  const bool down0_persistent = net.cfg.plan_flags[3] == 2;
+  if (net.cfg.plan_flags[3] == 2) {
+    set_error("PhaseNet plan_flags[3] = 2 (persistent level-0 down kernel): removed in round 6");
+    return VP_ERR_UNSUPPORTED;
+  }
   // plan_flags[5] = 1 keeps the MFMA forms of the two level-0 kernels (A/B timing; bit-identical to the layer plan),
   // 2 the three-launch plan with the VALU level-0 kernels; default: the whole network in one launch (pn_window_kernel).
   // The debug dumps of the intermediates exist in the three-launch plans only.
@@ -2223,10 +2160,6 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         v.b_down = reinterpret_cast<const f32x2*>(vb[2]->d);
         v.n_windows = B;
         hipLaunchKernelGGL(pn_down0v_kernel, dim3(VD_TILES * B), dim3(256), VD_LDS_FLOATS * sizeof(float), s, v);
-      } else if (down0_persistent && !debug_dumps) {
-        hipLaunchKernelGGL(pn_down0p_kernel, dim3(NSPLIT_D, B), dim3(256), D0_LDS_FLOATS * sizeof(float), s, a);
-      } else if (pipe) {
-        hipLaunchKernelGGL(pn_down0_kernel<true>, dim3(n_tiles, B), dim3(256), D0_LDS_FLOATS * sizeof(float), s, a);
       } else {
         hipLaunchKernelGGL(pn_down0_kernel<false>, dim3(n_tiles, B), dim3(256), D0_LDS_FLOATS * sizeof(float), s, a);
       }
@@ -2267,11 +2200,7 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
       }
       a.clk = clk ? reinterpret_cast<unsigned long long*>(clk->d) : nullptr;
       a.warm = n.cfg.plan_flags[4] != 1;
-      if (pipe) {
-        hipLaunchKernelGGL(pn_core_kernel<true>, dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
-      } else {
-        hipLaunchKernelGGL(pn_core_kernel<false>, dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
-      }
+      hipLaunchKernelGGL(pn_core_kernel<false>, dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
       return 0;
     };
     steps.push_back(std::move(st));
@@ -2315,8 +2244,6 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         hipLaunchKernelGGL(pn_up3v_kernel, dim3(VU_TILES * B), dim3(256), VU_LDS_FLOATS * sizeof(float), s, v);
       } else if (persistent && !debug_dumps) {
         hipLaunchKernelGGL(pn_up3p_kernel, dim3(NSPLIT_U, B), dim3(256), UP3_LDS_FLOATS * sizeof(float), s, a);
-      } else if (pipe) {
-        hipLaunchKernelGGL(pn_up3_kernel<true>, dim3(n_tiles, B), dim3(256), UP3_LDS_FLOATS * sizeof(float), s, a);
       } else {
         hipLaunchKernelGGL(pn_up3_kernel<false>, dim3(n_tiles, B), dim3(256), UP3_LDS_FLOATS * sizeof(float), s, a);
       }
@@ -2472,22 +2399,14 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
         a.pre = *n.pre;
         a.has_pre = 1;
       }
+      // Three forms are kept (round 6 pruned the rest: the intermediate forms of rounds 2-5 -- plan_flags[5] = 4, 5, 6, 7, 9 and the
+      // hand-pipelined K loop plan_flags[2] = 1 -- were A/B stations on the way, no test's reference any more): the default, the
+      // round-4 form with level 0 on the vector ALUs (plan_flags[5] = 8: the rounding reference of the tiled level-0 layers), and
+      // every core layer on the fp32 MFMA (plan_flags[5] = 3: the reference of the bf16-piece layers).
       if (up3t) {
         hipLaunchKernelGGL((pn_window_kernel<false, true, true, true, true, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
-      } else if (d0t) {
-        hipLaunchKernelGGL((pn_window_kernel<false, true, true, true, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
       } else if (d12b) {
         hipLaunchKernelGGL((pn_window_kernel<false, true, true, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
-      } else if (u3b) {
-        hipLaunchKernelGGL((pn_window_kernel<false, true, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
-      } else if (u2b) {
-        hipLaunchKernelGGL((pn_window_kernel<false, true, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
-      } else if (u1b) {
-        hipLaunchKernelGGL((pn_window_kernel<false, true, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
-      } else if (b3) {
-        hipLaunchKernelGGL((pn_window_kernel<false, true>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
-      } else if (pipe) {
-        hipLaunchKernelGGL((pn_window_kernel<true, false>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
       } else {
         hipLaunchKernelGGL((pn_window_kernel<false, false>), dim3(B), dim3(1024), CORE_LDS_FLOATS * sizeof(float), s, a);
       }
@@ -2497,24 +2416,14 @@ int plan_phasenet_fused(Net& net, const ParamView& pv, int debug_flags) {
     steps.push_back(std::move(st));
     net.fused_pre = net.cfg.plan_flags[6] != 1;  // plan_flags[6] = 1: gather_normalize_kernel fills the input tensor as in the other plans
     net.fused_pre_poisons = true;                // ... and then writes the NaN predictions of a non-finite window itself
-    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<true, false>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, false>), CORE_LDS_FLOATS * sizeof(float)});
-    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true>), CORE_LDS_FLOATS * sizeof(float)});
-    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true>), CORE_LDS_FLOATS * sizeof(float)});
-    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
-    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
-    net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
     net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_window_kernel<false, true, true, true, true, true, true, true>), CORE_LDS_FLOATS * sizeof(float)});
   }
   net.steps = std::move(steps);
-  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_core_kernel<true>), CORE_LDS_FLOATS * sizeof(float)});
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_core_kernel<false>), CORE_LDS_FLOATS * sizeof(float)});
-  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_down0_kernel<true>), D0_LDS_FLOATS * sizeof(float)});
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_down0_kernel<false>), D0_LDS_FLOATS * sizeof(float)});
-  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_up3_kernel<true>), UP3_LDS_FLOATS * sizeof(float)});
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_up3_kernel<false>), UP3_LDS_FLOATS * sizeof(float)});
-  net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_down0p_kernel), D0_LDS_FLOATS * sizeof(float)});
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_up3p_kernel), UP3_LDS_FLOATS * sizeof(float)});
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_down0v_kernel), VD_LDS_FLOATS * sizeof(float)});
   net.extra_kernels.push_back({reinterpret_cast<const void*>(&pn_up3v_kernel), VU_LDS_FLOATS * sizeof(float)});
