@@ -185,6 +185,20 @@ def _stream_worker(rank, world, port, q):
         assert (again is None) == (got is None) and tm["fixed_ms"] <= tm["total_ms"] and tm["wait_ms"] >= 0.0
         if got is not None:
             assert len(got.picks) >= 2 and [str(p) for p in again.picks] == [str(p) for p in got.picks]
+        # a stream too short for two segments (plan_segments gives one): rank 1 owns nothing, reads nothing, still takes part in the
+        # exchange; rank 0's answer is the unsplit one
+        from volpick_amd.segments import plan_segments
+
+        n_short = 3 * T + 100
+        assert len(plan_segments(n_short, T, overlap, blinding, world)) == 1
+        touched.clear()
+        short = classify_stream_sharded(model, (n_short, lambda lo, hi: load(lo, hi)), t0, "XX.ONE.", annotate_fn=oracle_annotate,
+                                        pick_fn=oracle_pick, **kw)
+        assert (short is None) == (rank != 0) and len(touched) == (1 if rank == 0 else 0)
+        if rank == 0:
+            rows_s = torch.from_numpy(np.ascontiguousarray(oracle_annotate(data[:, :n_short])))
+            want_s = oracle_pick(rows_s, model._trigger_specs(model._argdict(kw)))
+            assert sorted((p.phase, round((p.peak_time - t0) * 100)) for p in short.picks) == sorted((("P", "S")[si], pk) for si, on, off, pk, v in want_s)
         if rank == 0:
             want_rows = torch.from_numpy(np.ascontiguousarray(oracle_annotate(data)))
             want = oracle_pick(want_rows, model._trigger_specs(model._argdict(kw)))
