@@ -435,6 +435,13 @@ class WaveformModel:
         """Like ``_annotate_block`` for a long (3,N) block: ``segments.plan_segments`` cuts it into one segment
         per device context; segment r+1 is uploaded while segment r computes, the stacked outputs are cut and
         joined on the device -- sample for sample the unsplit result (volpick_amd/segments.py)."""
+        job = self._segments_submit(data, args, 0)
+        return job if isinstance(job, tuple) else self._segments_collect(job)
+
+    def _segments_submit(self, data, args, slot_base):
+        """First half of ``_annotate_segments``: upload and enqueue every segment (submit slots ``slot_base`` .. on each
+        context) -> a job for ``_segments_collect``; a block too short for more than one segment comes back finished, as
+        ``_annotate_block``'s tuple.  ``classify()`` uploads the NEXT station's segments between the two halves."""
         from .segments import plan_segments
 
         torch = _torch()
@@ -464,39 +471,47 @@ class WaveformModel:
             return x, y
 
         def submit(r, sg, x, y):
-            _lib.check(lib.vp_classify_submit(self._context(r % nc), r // nc, C.c_void_p(x.data_ptr()), _lib.VP_MEM_DEVICE,
+            _lib.check(lib.vp_classify_submit(self._context(r % nc), slot_base + r // nc, C.c_void_p(x.data_ptr()), _lib.VP_MEM_DEVICE,
                                               sg["hi"] - sg["lo"], args["overlap"], args["blinding"][0], args["blinding"][1],
                                               stacking, batch, None, 0, C.c_void_p(y.data_ptr()), _lib.VP_MEM_DEVICE, 0),
                        "vp_classify_submit")
 
         jobs = []
+        t0 = time.perf_counter()
         if tm is None:  # segment r + 1 is uploaded while segment r computes
             for r, sg in enumerate(segs):
                 x, y = upload(sg)
                 submit(r, sg, x, y)
                 jobs.append((x, y))
         else:  # profiled: all uploads, then all compute (the two phases separated; their sum exceeds the pipelined wall time)
-            t0 = time.perf_counter()
             jobs = [upload(sg) for sg in segs]
             tm["h2d_ms"] = tm.get("h2d_ms", 0.0) + (time.perf_counter() - t0) * 1e3
             t0 = time.perf_counter()
             for r, (sg, (x, y)) in enumerate(zip(segs, jobs)):
                 submit(r, sg, x, y)
+        return dict(segs=segs, jobs=jobs, slot_base=slot_base, n=n, t0=t0, overlap=args["overlap"])
+
+    def _segments_collect(self, job):
+        """Second half: wait for the segments, cut and join their stacked outputs on the device."""
+        torch = _torch()
+        lib = _lib.load()
+        dev = torch.device("cuda", self._device_index)
+        nc, n, segs, tm = self.n_contexts, job["n"], job["segs"], self._timing
         out = torch.empty((3, n), dtype=torch.float32, device=dev)
         fv = lv = -1
         found = C.c_int()
-        for r, (sg, (x, y)) in enumerate(zip(segs, jobs)):
+        for r, (sg, (x, y)) in enumerate(zip(segs, job["jobs"])):
             f, l, w = C.c_int64(), C.c_int64(), C.c_int64()
-            _lib.check(lib.vp_classify_collect(self._context(r % nc), r // nc, C.byref(f), C.byref(l), C.byref(w), None, None, None,
+            _lib.check(lib.vp_classify_collect(self._context(r % nc), job["slot_base"] + r // nc, C.byref(f), C.byref(l), C.byref(w), None, None, None,
                                                None, None, 0, C.byref(found)), "vp_classify_collect")
             out[:, sg["keep_lo"]:sg["keep_hi"]] = y[:, sg["keep_lo"] - sg["lo"]:sg["keep_hi"] - sg["lo"]]
             if r == 0:
                 fv = f.value
             lv = l.value + sg["lo"]
-        n_windows = int(lib.vp_window_starts(n, self.in_samples, args["overlap"], None, 0))
+        n_windows = int(lib.vp_window_starts(n, self.in_samples, job["overlap"], None, 0))
         torch.cuda.current_stream(dev).synchronize()
         if tm is not None:
-            tm["gpu_ms"] = tm.get("gpu_ms", 0.0) + (time.perf_counter() - t0) * 1e3
+            tm["gpu_ms"] = tm.get("gpu_ms", 0.0) + (time.perf_counter() - job["t0"]) * 1e3
             tm["windows"] = tm.get("windows", 0) + n_windows
         return out, fv, lv, n_windows
 
@@ -689,24 +704,44 @@ class WaveformModel:
 
         tm = self._timing
         t_mark = time.perf_counter()
+        long_pending, n_long = [], [0]
+
+        def finish_long():
+            while long_pending:
+                g0, job = long_pending.pop(0)
+                dev_out = job[0] if isinstance(job, tuple) else self._segments_collect(job)[0]
+                t2 = time.perf_counter()
+                found = self._pick_rows(dev_out, specs, columns=True)
+                if tm is not None:
+                    tm["pick_scan_d2h_ms"] = tm.get("pick_scan_d2h_ms", 0.0) + (time.perf_counter() - t2) * 1e3
+                    t2 = time.perf_counter()
+                emit(g0, found)
+                if tm is not None:
+                    tm["emit_records_ms"] = tm.get("emit_records_ms", 0.0) + (time.perf_counter() - t2) * 1e3
+
         for grp in _group_stream(stream, self.component_order, sr, copy, self.in_samples):
             if self._is_long(grp["data"].shape[1], args):  # a day-long block: its segments occupy all contexts
                 for g0, job in pending:
                     emit(g0, self._collect_block(job, args, specs, True)[0])
                 pending = []
-                if tm is not None:
+                if tm is not None:  # profiled: the phases apart, one block at a time
+                    finish_long()
                     tm["host_assembly_ms"] = tm.get("host_assembly_ms", 0.0) + (time.perf_counter() - t_mark) * 1e3
-                dev_out, fv, lv, nw = self._annotate_segments(grp["data"], args)
-                t_mark = time.perf_counter()
-                found = self._pick_rows(dev_out, specs, columns=True)
+                # Many stations: block k + 1 is uploaded and enqueued (on the other pair of submit slots) BEFORE block k is
+                # collected, scanned and emitted -- the host's upload, the longest part of a PhaseNet station-day, then runs
+                # beside block k's last segments instead of behind them.
+                two_sets = 2 * self._seg_per_context <= _lib.VP_MAX_INFLIGHT  # a second set of submit slots for the block behind
+                if not two_sets:
+                    finish_long()
+                job = self._segments_submit(grp["data"], args, self._seg_per_context * (n_long[0] & 1) if two_sets else 0)
+                n_long[0] += 1
+                finish_long()
+                long_pending.append((grp, job))
                 if tm is not None:
-                    tm["pick_scan_d2h_ms"] = tm.get("pick_scan_d2h_ms", 0.0) + (time.perf_counter() - t_mark) * 1e3
+                    finish_long()
                     t_mark = time.perf_counter()
-                emit(grp, found)
-                if tm is not None:
-                    tm["emit_records_ms"] = tm.get("emit_records_ms", 0.0) + (time.perf_counter() - t_mark) * 1e3
-                t_mark = time.perf_counter()
                 continue
+            finish_long()  # (the short-block paths below use slot 0 of the same contexts)
             if self.batch_across_blocks and torch.is_tensor(grp["data"]):
                 nw = (grp["data"].shape[1] - self.in_samples) // step + 2
                 if chunk and n_win + nw > self._max_windows_per_call:
@@ -720,6 +755,7 @@ class WaveformModel:
                 emit(g0, self._collect_block(job, args, specs, True)[0])
             pending.append((grp, self._submit_block(n_host % max(1, self.n_contexts), grp["data"], args, specs, 8192)))
             n_host += 1  # host blocks only: device-resident blocks take the chunk path and must not advance the context
+        finish_long()
         for g0, job in pending:
             emit(g0, self._collect_block(job, args, specs, True)[0])
         flush_chunk()
