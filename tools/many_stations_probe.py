@@ -27,6 +27,8 @@ for r, s in zip(pinned, data):
 for rows_name, rows in (("pageable", list(data)), ("pinned", pinned)):
     for _ in (0,):
         m = (va.PhaseNet if name == "phasenet" else va.EQTransformer).from_pretrained("volpick").cuda()
+        if len(sys.argv) > 3:
+            m._seg_per_context = int(sys.argv[3])  # segments of a long block per device context (default 2)
         st = va.Stream([va.Trace(rows[i], dict(network="XX", station=f"S{k:03d}", location="", channel=f"HH{c}", starttime=t0,
                                                sampling_rate=100.0)) for k in range(n_st) for i, c in enumerate("ZNE")])
         m.classify(st, batch_size=256, **kw)
