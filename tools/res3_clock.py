@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Cycles per phase of the fused ResCNN kernel (eqt_res3_kernel): debug plan flag bit 1 = shader-clock stamps of workgroup 0."""
+"""Cycles per phase of the fused ResCNN kernel (eqt_res3_kernel): debug plan flag bit 1 = shader-clock stamps of workgroup 0
+(a -DR3_CLOCK=1 build of the library, VOLPICK_HIP_LIB).  `res3_clock.py waves` reads a -DR3_CLOCK=2 build: wave 0 of EACH team of
+workgroup 0, with stamps inside the phases (MFMAs issued / epilogue done / barrier passed)."""
 import ctypes as C
 import sys
 from pathlib import Path
@@ -23,6 +25,20 @@ for _ in range(5):
 clk = np.zeros(64 * 8, np.uint64)
 lib = _lib.load()
 lib.vp_debug_conv_clock(m._handle, clk.ctypes.data_as(C.c_void_p), 64)
+if len(sys.argv) > 1 and sys.argv[1] == "waves":
+    c = clk.astype(np.int64)
+    t0 = c[0]
+    print("per conv and team: cycles to [MFMAs issued, epilogue done, barrier passed], measured from the barrier before the conv")
+    for team in (0, 1):
+        w = c[team * 128: team * 128 + 4 + 42 + 1]
+        print(f"team {team}: prologue stamps at", list(w[:4] - t0))
+        for i in range(7):
+            for j in (0, 1):
+                k = 4 + 6 * i + 3 * j
+                base = w[k - 1]
+                print(f"  block {i} conv{j + 1}: start {base - t0:7d}   mac {w[k] - base:6d}  epilogue {w[k + 1] - w[k]:6d}  barrier {w[k + 2] - w[k + 1]:6d}   = {w[k + 2] - base:6d}")
+        print(f"  store {w[46] - w[45]:6d}   total {w[46] - w[0]}")
+    sys.exit(0)
 c = clk.astype(np.int64)[:20]
 names = ["L2 warm-up", "zero fill", "load x, act (split)"] + [f"block {i} conv{j}" for i in range(7) for j in (1, 2)] + ["store"]
 for n, v in zip(names, np.diff(c)):
