@@ -182,25 +182,26 @@ def test_middle_kernel_with_several_windows_per_workgroup_is_bitwise_the_one_win
     one._release(), two._release()
 
 
-@pytest.mark.parametrize("B", [1, 2, 3, 5, 256, 257])
-def test_rescnn_kernel_with_one_operand_stream_per_workgroup_is_bitwise_the_one_window_form(model, B):
-    """Default: eqt_res3s_kernel -- four waves per TWO windows, a wave taking its 16 output channels for both (one operand stream
-    per workgroup, requested in parts inside the K loops; the six n-tiles in pairs; the residual rows in registers; an odd batch's
-    last workgroup computing its last window twice); plan_flags[7] bit 13: eqt_res3_kernel<2> (waves 0-3 one window, waves 4-7
-    the next, own LDS images, shared barriers: the default of rounds 5-6); bit 9: one window per 256-thread workgroup.  Same
-    products in the same order into every accumulator, same epilogue arithmetic: bit-identical.  (Bit 12, eight waves per
-    window with K split over wave pairs, was removed in round 6.)"""
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 7, 256, 257, 258])
+def test_rescnn_kernels_with_several_windows_per_workgroup_are_bitwise_the_one_window_form(model, B):
+    """Default: eqt_res3t_kernel -- eight waves per THREE windows, wave = (16 output channels, half of the nine n-tiles: 5 + 4),
+    the operand requested in parts inside the K loops, the residual rows in registers, a batch's last workgroup computing its last
+    window up to three times; plan_flags[7] bit 14: eqt_res3s_kernel (four waves per two windows, n-tiles in pairs); bit 13:
+    eqt_res3_kernel<2> (waves 0-3 one window, waves 4-7 the next: the default of rounds 5-6); bit 9: one window per 256-thread
+    workgroup.  Same products in the same order into every accumulator, same epilogue arithmetic: bit-identical.  (Bit 12, eight
+    waves per window with K split over wave pairs, was removed in round 6.)"""
     x = torch.from_numpy(synthetic_windows(B, 6000, seed=600 + B)).cuda()
-    one = EQTransformer.from_pretrained("volpick")
-    one._plan_flags = (0, 0, 0, 0, 0, 0, 0, 512)
-    one.cuda()
-    two = EQTransformer.from_pretrained("volpick")
-    two._plan_flags = (0, 0, 0, 0, 0, 0, 0, 8192)
-    two.cuda()
-    want = one._forward_raw(x, preprocess=True)
+    want = None
+    for bit in (512, 8192, 16384):
+        m = EQTransformer.from_pretrained("volpick")
+        m._plan_flags = (0, 0, 0, 0, 0, 0, 0, bit)
+        m.cuda()
+        got = m._forward_raw(x, preprocess=True)
+        m._release()
+        if want is None:
+            want = got
+        assert torch.equal(got, want), bit
     assert torch.equal(model._forward_raw(x, preprocess=True), want)
-    assert torch.equal(two._forward_raw(x, preprocess=True), want)
-    one._release(), two._release()
 
 
 def test_six_launch_plan_matches_fused_middle_kernel(model, oracle):

@@ -39,6 +39,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "waves":
                 print(f"  block {i} conv{j + 1}: start {base - t0:7d}   mac {w[k] - base:6d}  epilogue {w[k + 1] - w[k]:6d}  barrier {w[k + 2] - w[k + 1]:6d}   = {w[k + 2] - base:6d}")
         print(f"  store {w[46] - w[45]:6d}   total {w[46] - w[0]}")
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "waves1":  # eqt_res3s_kernel, -DR3_CLOCK=2: wave 0 of workgroup 0
+    c = clk.astype(np.int64)
+    print("per conv: cycles to [MFMAs issued, last pair's epilogue done, barrier passed]")
+    for i in range(7):
+        for j in (0, 1):
+            k = 4 + 6 * i + 3 * j
+            base = c[k - 1]
+            print(f"  block {i} conv{j + 1}: mac {c[k] - base:6d}  epilogue {c[k + 1] - c[k]:6d}  barrier {c[k + 2] - c[k + 1]:6d}   = {c[k + 2] - base:6d}")
+    print(f"  prologue {c[3] - c[0]}  store {c[46] - c[45]}  total {c[46] - c[0]}")
+    sys.exit(0)
 c = clk.astype(np.int64)[:20]
 names = ["L2 warm-up", "zero fill", "load x, act (split)"] + [f"block {i} conv{j}" for i in range(7) for j in (1, 2)] + ["store"]
 for n, v in zip(names, np.diff(c)):
