@@ -93,14 +93,17 @@ typedef struct {
                                       kernel, bit6 = the fused decoder tail (stages 4-6 + heads), bit7 = the fused encoder 3-6 kernel, bit8 = stages 1 and 2 of the fused encoder 0-2 kernel on the fp32 MFMA
                                       instead of the bf16 matrix cores with exact three-piece operands (the two
                                       forms agree to fp32 rounding, not bitwise), bit9 = the bf16-piece ResCNN kernel with
-                                      four waves per window (one per SIMD) instead of eight (K split over wave pairs),
+                                      four waves per window and ONE window per 256-thread workgroup,
                                       bit10 = the decoder tail computes every tile of a row even where annotate / classify
                                       blind the output (default: only the tiles that hold kept samples),
                                       bit11 = stage 3 of the fused decoder 0-3 kernel shares its n-tiles evenly between
                                       the two waves of a SIMD (default: 14 + 10),
+                                      bit13 = the bf16-piece ResCNN kernel with four waves per window and TWO windows per
+                                      512-thread workgroup (the default of rounds 5-6; default now: eqt_res3t_kernel, eight
+                                      waves per THREE windows, a wave taking 16 output channels of five or four of the nine
+                                      n-tiles; the three forms are bit-identical),
                                       (bit12, the bf16-piece ResCNN kernel with eight waves per window and K split over
-                                      wave pairs, was removed in round 6 and is rejected; default: four waves per window
-                                      and TWO windows per workgroup, bit9: one) */
+                                      wave pairs, was removed in round 6 and is rejected) */
   int32_t reserved[4];        /* must be 0 */
 } vp_config;
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counter passes over the forward kernels of BOTH models (counters only: --kernel-trace + --pmc, program directly after --;
-# one small counter group per pass).   usage, on the GPU box:  bash tools/pmc_sq_all.sh TAG [iterations]
+# one small counter group per pass).   usage, on the GPU box:  bash tools/pmc_sq_all.sh TAG [iterations] ["models"]
 # -> gpurun_out/sq_TAG/{phasenet,eqtransformer}_gN/ (raw CSVs) and gpurun_out/sq_TAG/summary.txt: per kernel the mean of
 #    every counter over the launches after the first, and what follows from them:
 #      mfma_busy      = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES: share of the kernel's busy time in which a matrix
@@ -16,7 +16,7 @@ GROUPS_=(
  "SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"
  "SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_THREAD_CYCLES_VALU SQ_LDS_IDX_ACTIVE"
 )
-for model in phasenet eqtransformer; do
+for model in ${3:-phasenet eqtransformer}; do
   i=0
   for grp in "${GROUPS_[@]}"; do
     i=$((i+1))

@@ -31,7 +31,7 @@ NAMES = {
     "phasenet": [("pn_window_kernel", "fused.window (whole PhaseNet, one workgroup per window)")],
     "eqtransformer": [("eqt_front_kernel", "fused.front (encoder.0-2, time-tiled)"),
                       ("eqt_enc36_b3_kernel", "fused.enc36 (encoder.3-6, one window per workgroup)"), ("eqt_enc36_kernel", "fused.enc36 (encoder.3-6, one window per workgroup)"),
-                      ("eqt_res3k_kernel", "fused.rescnn (7 residual blocks)"), ("eqt_res3_kernel", "fused.rescnn (7 residual blocks)"), ("eqt_res_kernel", "fused.rescnn (7 residual blocks)"),
+                      ("eqt_res3t_kernel", "fused.rescnn (7 residual blocks)"), ("eqt_res3k_kernel", "fused.rescnn (7 residual blocks)"), ("eqt_res3_kernel", "fused.rescnn (7 residual blocks)"), ("eqt_res_kernel", "fused.rescnn (7 residual blocks)"),
                       ("eqt_mid4_kernel", "fused.mid (3 BiLSTM + 2 transformer blocks + pick branches)"),
                       ("eqt_mid_kernel", "fused.mid (3 BiLSTM + 2 transformer blocks + pick branches)"),
                       ("eqt_dec03_kernel", "fused.dec03 (decoder.0-3, one row per workgroup)"),

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Cycles per phase of the fused ResCNN kernel (eqt_res3_kernel): debug plan flag bit 1 = shader-clock stamps of workgroup 0
-(a -DR3_CLOCK=1 build of the library, VOLPICK_HIP_LIB).  `res3_clock.py waves` reads a -DR3_CLOCK=2 build: wave 0 of EACH team of
-workgroup 0, with stamps inside the phases (MFMAs issued / epilogue done / barrier passed)."""
+"""Cycles per phase of the fused ResCNN kernel (eqt_res3t_kernel; eqt_res3_kernel with VOLPICK_PLAN_FLAGS=0,0,0,0,0,0,0,8192):
+debug plan flag bit 1 = shader-clock stamps of workgroup 0 (a -DR3_CLOCK=1 build of the library, VOLPICK_HIP_LIB).
+`res3_clock.py waves` reads a -DR3_CLOCK=2 build: wave 0 of EACH half (team) of workgroup 0, with stamps inside the phases (MFMAs
+issued / last epilogue done / barrier passed).  Builds: make BUILD=build_x TARGET=../../exp/lib_x.so EXTRA=-DR3_CLOCK=2"""
 import ctypes as C
 import sys
 from pathlib import Path
@@ -39,18 +40,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "waves":
                 print(f"  block {i} conv{j + 1}: start {base - t0:7d}   mac {w[k] - base:6d}  epilogue {w[k + 1] - w[k]:6d}  barrier {w[k + 2] - w[k + 1]:6d}   = {w[k + 2] - base:6d}")
         print(f"  store {w[46] - w[45]:6d}   total {w[46] - w[0]}")
     sys.exit(0)
-if len(sys.argv) > 1 and sys.argv[1] == "waves1":  # eqt_res3s_kernel, -DR3_CLOCK=2: wave 0 of workgroup 0
-    c = clk.astype(np.int64)
-    print("per conv: cycles to [MFMAs issued, last pair's epilogue done, barrier passed]")
-    for i in range(7):
-        for j in (0, 1):
-            k = 4 + 6 * i + 3 * j
-            base = c[k - 1]
-            print(f"  block {i} conv{j + 1}: mac {c[k] - base:6d}  epilogue {c[k + 1] - c[k]:6d}  barrier {c[k + 2] - c[k + 1]:6d}   = {c[k + 2] - base:6d}")
-    print(f"  prologue {c[3] - c[0]}  store {c[46] - c[45]}  total {c[46] - c[0]}")
-    sys.exit(0)
 c = clk.astype(np.int64)[:20]
-names = ["L2 warm-up", "zero fill", "load x, act (split)"] + [f"block {i} conv{j}" for i in range(7) for j in (1, 2)] + ["store"]
+names = ["requests issued (+ L2 warm-up)", "zero fill", "load x, act (split)"] + [f"block {i} conv{j}" for i in range(7) for j in (1, 2)] + ["store"]
 for n, v in zip(names, np.diff(c)):
     print(f"{n:24s} {v:8d}")
 print("total", c[len(names)] - c[0])

@@ -244,8 +244,8 @@ struct Res3A {
       bn[r] = sh ? sh[co + r] : 0.f;
     }
   }
-  // the same request in PARTS fragments k = 0 .. TAPS * 6 - 1 (the per-channel vectors ride with part 0): eqt_res3s_kernel
-  // spreads them over the K loop of the conv before
+  // the same request in PARTS fragments k = 0 .. TAPS * 6 - 1 (the per-channel vectors ride with part 0), spread over
+  // the K loop of the conv before
   static constexpr int PARTS = TAPS * 2 * 3;
   __device__ __forceinline__ void load_part(const uint4* af, const float* b, const float* s, const float* sh, const int mt, const int lane,
                                             const int k) {
@@ -287,7 +287,7 @@ __device__ __forceinline__ void res3_mac(const bf16_t* src, const Res3A<TAPS>& A
     if (s + 1 < TAPS * 2 && !(R3_EXP & 8)) {
       if (s & 1) load_b(bA, s + 1); else load_b(bB, s + 1);
     }
-    if constexpr (NL > 0) {  // -DR3_SPREAD=1 (experiment): the next operand in parts, between the K-steps
+    if constexpr (NL > 0) {  // the next operand in parts, between the K-steps
 #pragma unroll
       for (int k = s * NL / (TAPS * 2); k < (s + 1) * NL / (TAPS * 2); ++k) next_part(k);
     }
@@ -459,10 +459,6 @@ __global__ __launch_bounds__(256 * WPB) void eqt_res3_kernel(const Res3Args a) {
     }
   };
 #define R3_W(I, TAPS) ((R3_EXP & 1) ? ((TAPS) == 3 ? 0 : 4) : (I))
-#ifndef R3_SPREAD
-#define R3_SPREAD 0
-#endif
-#if R3_SPREAD
 #define R3_BLOCK(I, TAPS, TN, W1NEXT)                                                             \
   {                                                                                               \
     Res3A<TAPS> w2;                                                                               \
@@ -494,40 +490,6 @@ __global__ __launch_bounds__(256 * WPB) void eqt_res3_kernel(const Res3Args a) {
   Res3A<2> w1_6;
   R3_BLOCK(5, 3, 2, w1_6.load_part(a.af1[6], a.bs1[6], nullptr, nullptr, wave, lane, k);)
   R3_BLOCK(6, 2, 0, (void)k;)
-#else
-#define R3_BLOCK(I, TAPS, NEXT_LOAD)                                                              \
-  {                                                                                               \
-    Res3A<TAPS> w2;                                                                               \
-    w2.load(a.af2[R3_W(I, TAPS)], a.bs2[I], (I) == 6 ? nullptr : a.s_next[I], (I) == 6 ? nullptr : a.b_next[I], wave, lane); \
-    res3_mac<TAPS>(ACT, w1_##I, acc, lane);                                                       \
-    R3_WSTAMP()                                                                                   \
-    conv1_epilogue(w1_##I.bias);                                                                  \
-    R3_WSTAMP()                                                                                   \
-    __syncthreads();                                                                              \
-    R3_STAMP()                                                                                    \
-    NEXT_LOAD                                                                                     \
-    res3_mac<TAPS>(MID, w2, acc, lane);                                                           \
-    R3_WSTAMP()                                                                                   \
-    conv2_epilogue(w2.bias, w2.sn, w2.bn, (I) == 6);                                              \
-    R3_WSTAMP()                                                                                   \
-    __syncthreads();                                                                              \
-    R3_STAMP()                                                                                    \
-  }
-  // kernel sizes of the seven blocks: 3 3 3 3 2 3 2; the next block's conv1 operand is requested before this block's conv2
-  Res3A<3> w1_1;
-  R3_BLOCK(0, 3, w1_1.load(a.af1[R3_W(1, 3)], a.bs1[1], nullptr, nullptr, wave, lane);)
-  Res3A<3> w1_2;
-  R3_BLOCK(1, 3, w1_2.load(a.af1[R3_W(2, 3)], a.bs1[2], nullptr, nullptr, wave, lane);)
-  Res3A<3> w1_3;
-  R3_BLOCK(2, 3, w1_3.load(a.af1[R3_W(3, 3)], a.bs1[3], nullptr, nullptr, wave, lane);)
-  Res3A<2> w1_4;
-  R3_BLOCK(3, 3, w1_4.load(a.af1[R3_W(4, 2)], a.bs1[4], nullptr, nullptr, wave, lane);)
-  Res3A<3> w1_5;
-  R3_BLOCK(4, 2, w1_5.load(a.af1[R3_W(5, 3)], a.bs1[5], nullptr, nullptr, wave, lane);)
-  Res3A<2> w1_6;
-  R3_BLOCK(5, 3, w1_6.load(a.af1[R3_W(6, 2)], a.bs1[6], nullptr, nullptr, wave, lane);)
-  R3_BLOCK(6, 2, )
-#endif
 #undef R3_BLOCK
   float* out = a.out + (long)win * a.ws_out + HALO;
   for (int i = tid; i < 64 * RT; i += 256) {
@@ -539,238 +501,29 @@ __global__ __launch_bounds__(256 * WPB) void eqt_res3_kernel(const Res3Args a) {
 #undef R3_WSTAMP
 }
 
-// ---- ONE operand stream per workgroup (round 6) ---------------------------------------------------------------------------------
-// eqt_res3_kernel<2> read where its conv phases go (tools/res3_clock.py waves, profiles/r06_g_*): 6.8 k cycles per k = 3 conv for
-// 3.5 k of matrix time per SIMD -- and the same 6 k with the MFMAs taken out, the same with the fragment reads taken out, 4.3 k
-// with the WEIGHT STREAM taken out.  Wave w of either team requests the same 18 KB operand of m-tile w, 144 KB per conv and CU
-// out of L2 at the 27-40 B/clk a CU gets of lines that sixteen CUs of its XCD want at the same moment, and the requests stand in
-// program order in front of the conv's MFMAs.  Here a wave takes its m-tile for BOTH windows of the workgroup: four waves (one per
-// SIMD), half the weight traffic, its parts requested between the K-steps of the conv before; the six n-tiles go in PAIRS whose
-// MFMAs alternate (consecutive instructions never share an accumulator), the epilogue of a pair issued among the MFMAs of the
-// next one; the residual rows never leave the registers (a lane owns the same four channels x six columns through all 14 convs).
-// Same products, same order into every accumulator, same epilogue arithmetic: bit-identical to eqt_res3_kernel.
-template <int TAPS, int TN, bool CONV2, bool LAST, class NextPart, class Stamp>
-__device__ __forceinline__ void res3s_conv(const bf16_t* src_all, bf16_t* dst_all, const Res3A<TAPS>& A, float (&X)[2][3][4],
-                                           NextPart next_part, const int lane, const int co, Stamp stamp) {
-  constexpr int IN_OFF = (TAPS == 3) ? -1 : 0, STEPS = TAPS * 2, SLOTS = 3 * STEPS, AHEAD = 2, NBUF = AHEAD + 1;
-  constexpr int NL = TN * 2 * 3;  // fragments of the next conv's operand
-  const int g = lane >> 4, n = lane & 15;
-  const bf16_t* bp = src_all + g * R3_CHS + (n + IN_OFF + 1) * 8;
-  uint4 b[NBUF][2][3];  // [slot % NBUF][tile of the pair][piece]
-  auto load_b = [&](const int i) {
-    const int p = i / STEPS, s = i - p * STEPS, tap = s >> 1, ks = s & 1;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int q = 2 * p + u, h = q / 3, j = q - 3 * h;
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc)
-        b[i % NBUF][u][pc] = *reinterpret_cast<const uint4*>(bp + h * 3 * R3_PS + pc * R3_PS + (j * 16 + tap) * 8 + ks * 4 * R3_CHS);
-    }
-  };
-  // a tile's epilogue in two slices, issued among the MFMAs of two different K-steps of the next pair (one n-tile's epilogue is
-  // ~40 vector instructions; twelve MFMAs leave room for ~24): values(): bias, residual, next block's BatchNorm + ReLU;
-  // pieces(): split into the three bf16 pieces + stores
-  auto values = [&](const int q, const f32x4 acc, float (&v)[4]) {
-    const int h = q / 3, j = q - 3 * h, t = j * 16 + n;
-    if (!CONV2) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = (t < RT) ? fmaxf(acc[r] + A.bias[r], 0.f) : 0.f;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float o = 0.f;
-        if (t < RT) {
-          o = acc[r] + A.bias[r] + X[h][j][r];
-          X[h][j][r] = o;
-        }
-        v[r] = (t < RT) ? fmaxf(fmaf(A.sn[r], o, A.bn[r]), 0.f) : 0.f;
-      }
-    }
-  };
-  auto pieces = [&](const int q, const float (&v)[4]) {
-    const int h = q / 3, j = q - 3 * h, t = j * 16 + n;
-    if (!(CONV2 && LAST)) store3(dst_all + h * 3 * R3_PS, t + 1, co, v);
-  };
-#pragma unroll
-  for (int i = 0; i < AHEAD; ++i) load_b(i);
-  f32x4 prev0 = {0.f, 0.f, 0.f, 0.f}, prev1 = prev0;
-  float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f};
-  static_assert(STEPS >= 4, "four K-steps carry the epilogue slices of the pair before");
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-      const int i = p * STEPS + s;
-      __builtin_amdgcn_sched_barrier(0);
-      if (i + AHEAD < SLOTS) load_b(i + AHEAD);
-      if (NL > 0) {
-#pragma unroll
-        for (int k = i * NL / SLOTS; k < (i + 1) * NL / SLOTS; ++k) next_part(k);
-      }
-      if (p > 0 && s == 0) values(2 * p - 2, prev0, va);  // the pair before: its epilogue among this pair's MFMAs
-      if (p > 0 && s == 1) pieces(2 * p - 2, va);
-      if (p > 0 && s == 2) values(2 * p - 1, prev1, vb);
-      if (p > 0 && s == 3) pieces(2 * p - 1, vb);
-      constexpr int WP[6] = {2, 1, 0, 1, 0, 0}, XP[6] = {0, 1, 2, 0, 1, 0};  // (w piece, x piece), smallest products first
-#pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_res, A.q[s][WP[t]]),
-                                                      __builtin_bit_cast(bf16x8_res, b[i % NBUF][0][XP[t]]), acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_res, A.q[s][WP[t]]),
-                                                      __builtin_bit_cast(bf16x8_res, b[i % NBUF][1][XP[t]]), acc1, 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    prev0 = acc0;
-    prev1 = acc1;
-  }
-  stamp();
-  values(4, prev0, va);
-  values(5, prev1, vb);
-  pieces(4, va);
-  pieces(5, vb);
-  stamp();
-}
-
-__global__ __launch_bounds__(256) void eqt_res3s_kernel(const Res3Args a) {
-  __shared__ __attribute__((aligned(16))) bf16_t ACT[2 * 3 * R3_PS];  // [window of the workgroup][piece][chunk][column][8]
-  __shared__ __attribute__((aligned(16))) bf16_t MID[2 * 3 * R3_PS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, n = lane & 15, co = wave * 16 + 4 * g;  // this lane's four output channels, in every conv
-  const int win[2] = {min((int)blockIdx.x * 2, a.n_windows - 1), min((int)blockIdx.x * 2 + 1, a.n_windows - 1)};  // (odd batch: the last window twice)
-#if R3_CLOCK
-  unsigned long long* clk = (a.clk && tid == 0 && blockIdx.x == 0) ? a.clk : nullptr;
-  int stamp = 0;
-#define R3S_STAMP() \
-  if (clk) clk[stamp++] = __builtin_readcyclecounter();
-#else
-#define R3S_STAMP()
-#endif
-  auto wstamp = [&]() {  // -DR3_CLOCK=2: inside the convs too (MFMAs issued / last pair's epilogue done)
-#if R3_CLOCK == 2
-    R3S_STAMP()
-#endif
-  };
-  R3S_STAMP()
-  // Prologue: everything requested before the first wait (as in eqt_res3_kernel): the residual rows straight into the accumulator
-  // layout, the activation rows as (four channels x one column) items, block 0's operand, this workgroup's share of the L2 warm-up.
-  float X[2][3][4];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const float* x0 = a.x0 + (long)win[h] * a.ws_x + HALO;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) X[h][j][r] = (j * 16 + n < RT) ? x0[(long)(co + r) * a.ls_x + j * 16 + n] : 0.f;
-  }
-  constexpr int NAR = (2 * 16 * RT + 255) / 256;
-  float ar[NAR][4];
-#pragma unroll
-  for (int k = 0; k < NAR; ++k) {
-    const int i = tid + 256 * k, h = i / (16 * RT), rem = i - h * (16 * RT), cq = rem / RT, t = rem - cq * RT;
-    const float* a0 = a.act0 + (long)win[h & 1] * a.ws_a + HALO;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ar[k][r] = i < 2 * 16 * RT ? a0[(long)(4 * cq + r) * a.ls_a + t] : 0.f;
-  }
-  Res3A<3> w1_0;
-  w1_0.load(a.af1[0], a.bs1[0], nullptr, nullptr, wave, lane);
-  unsigned wv[14] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-  if (a.warm) {  // every XCD's L2, one word per 128-byte line, a slice per workgroup (see eqt_res3_kernel)
-    const int nx = gridDim.x >= 8 ? gridDim.x >> 3 : 1, xw = (int)blockIdx.x >> 3;
-    constexpr int kers_pf[7] = {3, 3, 3, 3, 2, 3, 2};
-    if (xw < nx) {
-      if ((long)nx * 256 * 128 >= a.af_bytes_k3) {
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-          const int lines = (int)((kers_pf[i] == 3 ? a.af_bytes_k3 : a.af_bytes_k2) / 128);
-          const int l = min(xw * 256 + tid, lines - 1);
-          wv[2 * i] = reinterpret_cast<const unsigned*>(a.af1[i])[l * 32];
-          wv[2 * i + 1] = reinterpret_cast<const unsigned*>(a.af2[i])[l * 32];
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-          const int lines = (int)((kers_pf[i] == 3 ? a.af_bytes_k3 : a.af_bytes_k2) / 128);
-          for (int l = xw * 256 + tid; l < lines; l += nx * 256)
-            wv[0] ^= reinterpret_cast<const unsigned*>(a.af1[i])[l * 32] ^ reinterpret_cast<const unsigned*>(a.af2[i])[l * 32];
-        }
-      }
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  R3S_STAMP()
-  for (int i = tid; i < 2 * 3 * R3_PS / 8; i += 256) {  // zero halo columns (and everything else once)
-    reinterpret_cast<uint4*>(ACT)[i] = make_uint4(0u, 0u, 0u, 0u);
-    reinterpret_cast<uint4*>(MID)[i] = make_uint4(0u, 0u, 0u, 0u);
-  }
-  __syncthreads();
-  R3S_STAMP()
-#pragma unroll
-  for (int k = 0; k < NAR; ++k) {
-    const int i = tid + 256 * k, h = i / (16 * RT), rem = i - h * (16 * RT), cq = rem / RT, t = rem - cq * RT;
-    if (i < 2 * 16 * RT) store3(ACT + h * 3 * R3_PS, t + 1, 4 * cq, ar[k]);
-  }
-  {
-    unsigned sink = 0u;
-#pragma unroll
-    for (int i = 0; i < 14; ++i) sink ^= wv[i];
-    if (sink == 0x12345678u && a.ls_x == -1) a.out[0] = __uint_as_float(sink);  // never true: keeps the warm-up loads alive
-  }
-  __syncthreads();
-  R3S_STAMP()
-  // conv1: MID = relu(conv(ACT) + b) (BatchNorm folded); conv2: X += conv(MID) + b, ACT = relu(s X + b') for the next block.
-  // The operand of the conv after next is requested in parts between the K-steps of each conv.
-#define R3S_BLOCK(I, TAPS, TN1, W1NEXT)                                                                                       \
-  {                                                                                                                           \
-    Res3A<TAPS> w2;                                                                                                           \
-    res3s_conv<TAPS, TAPS, false, false>(ACT, MID, w1_##I, X, [&](const int k) {                                               \
-      w2.load_part(a.af2[I], a.bs2[I], (I) == 6 ? nullptr : a.s_next[I], (I) == 6 ? nullptr : a.b_next[I], wave, lane, k);    \
-    }, lane, co, wstamp);                                                                                                     \
-    __syncthreads();                                                                                                          \
-    R3S_STAMP()                                                                                                               \
-    res3s_conv<TAPS, TN1, true, (I) == 6>(MID, ACT, w2, X, [&](const int k) { W1NEXT }, lane, co, wstamp);                     \
-    __syncthreads();                                                                                                          \
-    R3S_STAMP()                                                                                                               \
-  }
-  Res3A<3> w1_1;
-  R3S_BLOCK(0, 3, 3, w1_1.load_part(a.af1[1], a.bs1[1], nullptr, nullptr, wave, lane, k);)
-  Res3A<3> w1_2;
-  R3S_BLOCK(1, 3, 3, w1_2.load_part(a.af1[2], a.bs1[2], nullptr, nullptr, wave, lane, k);)
-  Res3A<3> w1_3;
-  R3S_BLOCK(2, 3, 3, w1_3.load_part(a.af1[3], a.bs1[3], nullptr, nullptr, wave, lane, k);)
-  Res3A<2> w1_4;
-  R3S_BLOCK(3, 3, 2, w1_4.load_part(a.af1[4], a.bs1[4], nullptr, nullptr, wave, lane, k);)
-  Res3A<3> w1_5;
-  R3S_BLOCK(4, 2, 3, w1_5.load_part(a.af1[5], a.bs1[5], nullptr, nullptr, wave, lane, k);)
-  Res3A<2> w1_6;
-  R3S_BLOCK(5, 3, 2, w1_6.load_part(a.af1[6], a.bs1[6], nullptr, nullptr, wave, lane, k);)
-  R3S_BLOCK(6, 2, 0, (void)k;)
-#undef R3S_BLOCK
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    float* out = a.out + (long)win[h] * a.ws_out + HALO;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (j * 16 + n < RT) out[(long)(co + r) * a.ls_out + j * 16 + n] = X[h][j][r];
-  }
-  R3S_STAMP()
-#undef R3S_STAMP
-}
-
 // ---- THREE windows per workgroup, eight waves (round 6) ----------------------------------------------------------------------------
-// eqt_res3s_kernel halves the weight traffic but leaves ONE wave per SIMD: everything that is not an MFMA (fragment reads at ~7
-// cycles each, the epilogue slices, waits) lengthens its K-steps (tools/micro/mfma_slot_probe.hip: 253 cycles per twelve MFMAs with
-// six reads and twelve vector instructions beside them, 183 with a second wave on the SIMD).  Here: two waves per SIMD AND a shared
-// stream -- wave = (m-tile, half), the nine n-tiles of three windows split 5 + 4 over the two halves (the waves of an m-tile sit
-// on one SIMD, which therefore has nine n-tiles whichever wave issues them), two requests of each operand per three windows
-// (2 / 3 of eqt_res3_kernel's traffic per window, on 86 CUs instead of 128).  147 KB of LDS (no residual rows there).  Tiles one
-// after the other, one accumulator each; a tile's epilogue among the next tile's MFMAs.  Bit-identical to the other forms.
-template <int TAPS, int TN, bool CONV2, bool LAST, int NT, int Q0, class NextPart>
+// Where eqt_res3_kernel<2> spent its conv phases (tools/res3_clock.py waves, profiles/r06_g_*): 6.8 k cycles per k = 3 conv for
+// 3.5 k of matrix time per SIMD -- the same 6 k with the MFMAs taken out, the same with the fragment reads taken out, 4.3 k with
+// the WEIGHT STREAM taken out.  Wave w of either team requests the same 18 KB operand of m-tile w (144 KB per conv and CU, 21
+// 1-KB requests per wave), and those requests stood in program order in front of the conv's MFMAs: a wave issues in order, the
+// texture path takes ~25 cycles per request.  Three steps from there, each measured:
+//   (1) the requests in PARTS between the K-steps of the conv before (Res3A::load_part; now the form of eqt_res3_kernel too):
+//       107 k -> 94 k cycles per launch;
+//   (2) a wave taking its m-tile for BOTH windows of a workgroup (four waves, half the traffic, the residual rows in registers, a
+//       tile's epilogue among the next tile's MFMAs): 90 k -- but ONE wave per SIMD: everything that is not an MFMA lengthens its
+//       K-steps (tools/micro/mfma_slot_probe.hip: 253 cycles per twelve MFMAs with six fragment reads and twelve vector
+//       instructions beside them, 183 with a second wave on the SIMD).  Built, measured (+1.2 % windows/s), replaced by
+//   (3) this kernel: two waves per SIMD AND a shared stream -- wave = (m-tile, half), the nine n-tiles of THREE windows split 5 + 4
+//       over the halves (the two waves of an m-tile sit on one SIMD, which has nine n-tiles whichever wave issues them), two
+//       requests of each operand per three windows, on 86 CUs instead of 128.  147 KB of LDS (no residual rows there).  Tiles one
+//       after the other, one accumulator each (a chain into one accumulator issues as fast as alternating ones: tools/micro/
+//       mfma_chain_probe.hip); a tile's epilogue in two slices among the MFMAs of the next tile's first two K-steps.
+//       101 k cycles per THREE windows (33.8 k per window against 53.4 k), matrix pipes 63 % busy (profiles/r06_g_sq_*).
+// The L2 warm-up of rounds 2-5 is gone (8 k cycles of prologue; the parts are requested a whole conv ahead of their use).
+// Same products in the same order into every accumulator, same epilogue arithmetic: bit-identical to eqt_res3_kernel.
+template <int TAPS, int TN, bool CONV2, bool LAST, int NT, int Q0, class NextPart, class Stamp>
 __device__ __forceinline__ void res3t_conv(const bf16_t* src_all, bf16_t* dst_all, const Res3A<TAPS>& A, float (&X)[NT][4],
-                                           NextPart next_part, const int lane, const int co) {
+                                           NextPart next_part, const int lane, const int co, Stamp stamp) {
   constexpr int IN_OFF = (TAPS == 3) ? -1 : 0, STEPS = TAPS * 2, SLOTS = NT * STEPS, AHEAD = 2, NBUF = AHEAD + 1;
   constexpr int NL = TN * 2 * 3;  // fragments of the next conv's operand
   const int g = lane >> 4, n = lane & 15;
@@ -830,14 +583,30 @@ __device__ __forceinline__ void res3t_conv(const bf16_t* src_all, bf16_t* dst_al
     __builtin_amdgcn_sched_barrier(0);
     prev = acc;
   }
+  stamp();
   values(NT - 1, prev, v);
   pieces(NT - 1, v);
+  stamp();
 }
 
 template <int NT, int Q0>
 __device__ __forceinline__ void res3t_body(const Res3Args& a, bf16_t* ACT, bf16_t* MID, const int (&win)[3], const int mt) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int g = lane >> 4, n = lane & 15, co = mt * 16 + 4 * g;  // this lane's four output channels, in every conv
+#if R3_CLOCK
+  unsigned long long* clk = (a.clk && (tid & 255) == 0 && blockIdx.x == 0) ? a.clk + (tid >> 8) * 128 : nullptr;  // wave 0 of either half
+  int stamp = 0;
+#define R3T_STAMP() \
+  if (clk) clk[stamp++] = __builtin_readcyclecounter();
+#else
+#define R3T_STAMP()
+#endif
+  auto wstamp = [&]() {
+#if R3_CLOCK == 2
+    R3T_STAMP()
+#endif
+  };
+  R3T_STAMP()
   // Prologue: everything requested before the first wait (as in eqt_res3_kernel): the residual rows of this wave's tiles straight
   // into the accumulator layout, the activation rows as (four channels x one column) items, block 0's operand.
   float X[NT][4];
@@ -860,17 +629,20 @@ __device__ __forceinline__ void res3t_body(const Res3Args& a, bf16_t* ACT, bf16_
   Res3A<3> w1_0;
   w1_0.load(a.af1[0], a.bs1[0], nullptr, nullptr, mt, lane);
   __builtin_amdgcn_sched_barrier(0);
+  R3T_STAMP()
   for (int i = tid; i < 3 * 3 * R3_PS / 8; i += 512) {  // zero halo columns (and everything else once)
     reinterpret_cast<uint4*>(ACT)[i] = make_uint4(0u, 0u, 0u, 0u);
     reinterpret_cast<uint4*>(MID)[i] = make_uint4(0u, 0u, 0u, 0u);
   }
   __syncthreads();
+  R3T_STAMP()
 #pragma unroll
   for (int k = 0; k < NAR; ++k) {
     const int i = tid + 512 * k, h = i / (16 * RT), rem = i - h * (16 * RT), cq = rem / RT, t = rem - cq * RT;
     if (i < 3 * 16 * RT) store3(ACT + h * 3 * R3_PS, t + 1, 4 * cq, ar[k]);
   }
   __syncthreads();
+  R3T_STAMP()
   // conv1: MID = relu(conv(ACT) + b) (BatchNorm folded); conv2: X += conv(MID) + b, ACT = relu(s X + b') for the next block.
   // The operand of the conv after next is requested in parts between the K-steps of each conv.
 #define R3T_BLOCK(I, TAPS, TN1, W1NEXT)                                                                                       \
@@ -878,10 +650,12 @@ __device__ __forceinline__ void res3t_body(const Res3Args& a, bf16_t* ACT, bf16_
     Res3A<TAPS> w2;                                                                                                           \
     res3t_conv<TAPS, TAPS, false, false, NT, Q0>(ACT, MID, w1_##I, X, [&](const int k) {                                       \
       w2.load_part(a.af2[I], a.bs2[I], (I) == 6 ? nullptr : a.s_next[I], (I) == 6 ? nullptr : a.b_next[I], mt, lane, k);      \
-    }, lane, co);                                                                                                             \
+    }, lane, co, wstamp);                                                                                                     \
     __syncthreads();                                                                                                          \
-    res3t_conv<TAPS, TN1, true, (I) == 6, NT, Q0>(MID, ACT, w2, X, [&](const int k) { W1NEXT }, lane, co);                     \
+    R3T_STAMP()                                                                                                               \
+    res3t_conv<TAPS, TN1, true, (I) == 6, NT, Q0>(MID, ACT, w2, X, [&](const int k) { W1NEXT }, lane, co, wstamp);             \
     __syncthreads();                                                                                                          \
+    R3T_STAMP()                                                                                                               \
   }
   Res3A<3> w1_1;
   R3T_BLOCK(0, 3, 3, w1_1.load_part(a.af1[1], a.bs1[1], nullptr, nullptr, mt, lane, k);)
@@ -905,6 +679,8 @@ __device__ __forceinline__ void res3t_body(const Res3Args& a, bf16_t* ACT, bf16_
     for (int r = 0; r < 4; ++r)
       if (j * 16 + n < RT) out[(long)(co + r) * a.ls_out + j * 16 + n] = X[u][r];
   }
+  R3T_STAMP()
+#undef R3T_STAMP
 }
 
 __global__ __launch_bounds__(512) void eqt_res3t_kernel(const Res3Args a) {
@@ -913,7 +689,7 @@ __global__ __launch_bounds__(512) void eqt_res3t_kernel(const Res3Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int last = a.n_windows - 1;  // (a batch that is no multiple of three: the last window up to three times, identical stores)
   const int win[3] = {min((int)blockIdx.x * 3, last), min((int)blockIdx.x * 3 + 1, last), min((int)blockIdx.x * 3 + 2, last)};
-  if (wave < 4) res3t_body<5, 0>(a, ACT, MID, win, wave);
+  if (wave < 4) res3t_body<5, 0>(a, ACT, MID, win, wave);  // (6 + 3 measured the same)
   else res3t_body<4, 5>(a, ACT, MID, win, wave - 4);
 }
 
@@ -1044,8 +820,6 @@ int plan_eqt_fuse_res(Net& net) {
         hipLaunchKernelGGL(eqt_res3_kernel<1>, dim3(B), dim3(256), 0, s, a);
       else if (n.cfg.plan_flags[7] & 8192)  // bit 13: four waves per window, two windows per workgroup (rounds 5-6: 45 us on 128 CUs)
         hipLaunchKernelGGL(eqt_res3_kernel<2>, dim3((B + 1) / 2), dim3(512), 0, s, a);
-      else if (n.cfg.plan_flags[7] & 16384)  // bit 14: four waves per TWO windows, one operand stream per workgroup
-        hipLaunchKernelGGL(eqt_res3s_kernel, dim3((B + 1) / 2), dim3(256), 0, s, a);
       else  // eight waves per THREE windows
         hipLaunchKernelGGL(eqt_res3t_kernel, dim3((B + 2) / 3), dim3(512), 0, s, a);
       return 0;
