@@ -44,6 +44,12 @@ __device__ __forceinline__ void b3_store4(bf16_t* img, const int ps, const int c
   const unsigned m0 = pack_bf16x2(r0, r1), m1 = pack_bf16x2(r2, r3);
   const unsigned l0 = pack_bf16x2(r0 - bf16_lo(m0), r1 - bf16_hi(m0)), l1 = pack_bf16x2(r2 - bf16_lo(m1), r3 - bf16_hi(m1));
   bf16_t* p = img + col * cs + ch;
+#ifdef B3_EXP
+  if (B3_EXP & 4) {  // timing probe (see b3c_store4): the pieces are computed, nothing is stored
+    asm volatile("" ::"v"(h0), "v"(h1), "v"(m0), "v"(m1), "v"(l0), "v"(l1), "v"(p));
+    return;
+  }
+#endif
   *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
   *reinterpret_cast<uint2*>(p + ps) = make_uint2(m0, m1);
   *reinterpret_cast<uint2*>(p + 2 * ps) = make_uint2(l0, l1);
@@ -322,14 +328,28 @@ struct B3Chunk {
   static constexpr int CHS = NC * 8, PS = (C / 8) * CHS;  // bf16 per chunk plane / per piece
 };
 // four consecutive channels 4 quad .. 4 quad + 3 of column col, split into the three pieces (pairs at a time: v_cvt_pk_bf16_f32)
+// B3_EXP (timing probes of tools/, never in the product build; results are WRONG with any of them): 4 = b3c_store4 computes the
+// pieces and stores nothing, 16 = it does not compute them either, 32 = it stores them where sixteen lanes fill 128 contiguous bytes
+#ifndef B3_EXP
+#define B3_EXP 0
+#endif
 template <int C, int NC>
 __device__ __forceinline__ void b3c_store4(bf16_t* img, const int col, const int quad, const float (&v)[4]) {
   using Q = B3Chunk<C, NC>;
+  if (B3_EXP & 16) {
+    asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+    return;
+  }
   const unsigned h0 = pack_bf16x2(v[0], v[1]), h1 = pack_bf16x2(v[2], v[3]);
   const float r0 = v[0] - bf16_lo(h0), r1 = v[1] - bf16_hi(h0), r2 = v[2] - bf16_lo(h1), r3 = v[3] - bf16_hi(h1);
   const unsigned m0 = pack_bf16x2(r0, r1), m1 = pack_bf16x2(r2, r3);
   const unsigned l0 = pack_bf16x2(r0 - bf16_lo(m0), r1 - bf16_hi(m0)), l1 = pack_bf16x2(r2 - bf16_lo(m1), r3 - bf16_hi(m1));
   bf16_t* p = img + (quad >> 1) * Q::CHS + col * 8 + (quad & 1) * 4;
+  if (B3_EXP & 32) p = img + (quad >> 1) * Q::CHS + ((col >> 5) * 16 + (threadIdx.x & 15)) * 4;  // 16 lanes -> 128 contiguous bytes: no bank conflict
+  if (B3_EXP & 4) {
+    asm volatile("" ::"v"(h0), "v"(h1), "v"(m0), "v"(m1), "v"(l0), "v"(l1), "v"(p));
+    return;
+  }
   *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
   *reinterpret_cast<uint2*>(p + Q::PS) = make_uint2(m0, m1);
   *reinterpret_cast<uint2*>(p + 2 * Q::PS) = make_uint2(l0, l1);
@@ -344,8 +364,13 @@ __device__ __forceinline__ const bf16_t* b3c_lane_ptr(const bf16_t* img, const i
 // One m-tile (operand `a` in registers) x NB n-tiles, n-tile after n-tile: the accumulator of n-tile j goes to
 // finish(j, acc) -- branch-free code: bias, activation, split, stores -- while the fragments of n-tile j + 1 are on their
 // way.  Fragments are read two (K-step, n-tile) pairs ahead of their MFMAs.
-template <int C, int NC, int TAPS, int NB, class Finish>
-__device__ __forceinline__ void b3c_mac_tiles(const bf16_t* p, const uint4 (&a)[B3Steps<C, TAPS>::STEPS * 3], Finish finish) {
+// (slot(i), i = 0 .. STEPS * NB - 1: code issued between the K-steps, e.g. the parts of a request that would otherwise stand as
+// one burst in front of the stage's MFMAs -- a wave issues in order)
+struct B3NoSlot {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+template <int C, int NC, int TAPS, int NB, class Finish, class Slot = B3NoSlot>
+__device__ __forceinline__ void b3c_mac_tiles(const bf16_t* p, const uint4 (&a)[B3Steps<C, TAPS>::STEPS * 3], Finish finish, Slot slot = Slot()) {
   using G = B3Steps<C, TAPS>;
   using Q = B3Chunk<C, NC>;
   constexpr int STEPS = G::STEPS;
@@ -370,6 +395,7 @@ __device__ __forceinline__ void b3c_mac_tiles(const bf16_t* p, const uint4 (&a)[
     for (int s = 0; s < STEPS; ++s) {
       const int i = j * STEPS + s;
       if (i + AHEAD < PAIRS) load_b(i + AHEAD);
+      slot(i);
       constexpr int WP[6] = {2, 1, 0, 1, 0, 0}, XP[6] = {0, 1, 2, 0, 1, 0};  // (w piece, x piece), smallest products first
 #pragma unroll
       for (int t = 0; t < 6; ++t)

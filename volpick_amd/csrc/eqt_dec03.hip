@@ -74,6 +74,7 @@ struct Dec03Args {
   const float* edge_b;  // [3][32]
   int B, n_rows;
   int even_split;  // plan_flags[7] bit 11: stage 3's n-tiles 12 + 12 over the two waves of a SIMD instead of 14 + 10
+  unsigned long long* clk;  // -DD3_CLOCK=1 builds (tools/dec03_clock.py): shader-clock stamps of waves 0 and 4 of workgroup 0
 };
 
 // Stage output t = 2 * column + phase at img[co * S + t]; [0, len) is the row, beyond it the next stage's zero padding.
@@ -196,12 +197,29 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
     load_stage0(d);
     __syncthreads();
     const int mt23 = wave_u & 3, blk23 = wave_u >> 2;
+    // (The operands of stages 1-3 are requested as bursts of 18 / 18 / 15 1-KB loads per wave at the stage boundaries.  Spreading
+    // them over the K-steps of the stage before, as eqt_res3t_kernel does, was built and measured in round 6: stage 0 4.1 k cycles
+    // instead of 5.2 k, stage 3 14.8 k instead of 13.7 k (29 registers spilled), the row 42.6 k either way, 0.8 % SLOWER in the
+    // pipeline.  The stages' K loops run at 65-84 % of their matrix time whatever the requests do: tools/dec03_clock.py.)
+#ifndef D3_CLOCK
+#define D3_CLOCK 0
+#endif
+#if D3_CLOCK
+    unsigned long long* clk = (a.clk && (tid & 255) == 0 && blockIdx.x == 0) ? a.clk + (tid >> 8) * 128 : nullptr;
+    int stamp = 0;
+#define D3_STAMP() \
+  if (clk && stamp < 120) clk[stamp++] = __builtin_readcyclecounter();
+#else
+#define D3_STAMP()
+#endif
     while (true) {
       const int next = row + gridDim.x;
       const bool more = next < a.n_rows;
       const int nd = more ? next / a.B : d;
+      D3_STAMP()  // 0: row start
       park();
       __syncthreads();
+      D3_STAMP()  // 1: input parked
       uint4 a1[B3Steps<64, 3>::STEPS * 3];  // stage 1's operand: on its way under stage 0
       b3_load_a<64, 3>(a.af3[0] + d * a.af3_stride[0], wave_u, lane, a1);
       {  // stage 0: 16 x 47 -> 64 x 94, three pieces
@@ -216,7 +234,9 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
         float bias1[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias1[r] = a.bs[1][d * 64 + co0 + r];
+        D3_STAMP()  // 2: stage 0 done (this wave)
         __syncthreads();
+        D3_STAMP()  // 3: barrier
         b3c_mac_tile_pairs<64, B3_X1_NC, 3, 6>(b3c_lane_ptr<64, B3_X1_NC, 3>(X1, 0, lane), a1, [&](const int j, const f32x4 acc) {
           const int t = 2 * (j * 16 + n) + ph;
           float v[4];
@@ -225,9 +245,11 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
           b3c_store4<64, B3_X2_NC>(X2, t + 1, co0 >> 2, v);
         });
       }
+      D3_STAMP()  // 4: stage 1 done (this wave)
       uint4 a2[B3Steps<64, 3>::STEPS * 3];  // stage 2's operand: requested before the barrier, stage 1's registers are free
       b3_load_a<64, 3>(a.af3[1] + d * a.af3_stride[1], wave_u & 3, lane, a2);
       __syncthreads();
+      D3_STAMP()  // 5: barrier
       float eb;
       {  // stage 2: 64 x 188 -> 32 x 375 (three-piece image in the place of the dead stage-0 / stage-1 inputs: its padding
          // columns are cleared here, every row) + the two samples at the cropped edge from the definition
@@ -263,6 +285,7 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
             st.quad(co0, 2 * (colb + j * 16 + n) + ph, v);
           });
         }
+        D3_STAMP()  // 6: stage 2's MFMAs issued (this wave)
         float pacc = 0.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -275,6 +298,7 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
         }
         EDGE[wave_u * 64 + lane] = pacc;
       }
+      D3_STAMP()  // 7: stage 2 done (this wave)
       // stage 3's operand (m-tile mt23 = channels 8 mt23 .. + 7, both phases): 60 registers, so only now that stage 2's are free
       uint4 a3[B3Steps<32, 5>::STEPS * 3];
       float bias3[4];
@@ -286,6 +310,7 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
       request(more ? next : row);
       load_stage0(nd);
       __syncthreads();
+      D3_STAMP()  // 8: barrier
       if (blk23 == 1) {  // the four waves whose last n-tiles read the edge samples finish them, each for itself (same values)
         float acc = eb;
 #pragma unroll
@@ -326,11 +351,13 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
           stage3(304, std::integral_constant<int, 5>{});
         }
       }
+      D3_STAMP()  // 9: stage 3 done (this wave)
       if (!more) break;
       row = next;
       d = nd;
       __syncthreads();  // the next row's input and stage-0 output land where stage 3 has just read
     }
+#undef D3_STAMP
     return;
   }
   // image offsets through an opaque register (eqt_tail.hip: keeps the B fragments' addresses inside the DS immediates)
@@ -493,6 +520,7 @@ int plan_eqt_fuse_dec03(Net& net, bool b3) {
     a.B = B;
     a.n_rows = 3 * B;
     a.even_split = (n.cfg.plan_flags[7] >> 11) & 1;
+    a.clk = (n.debug_clock && n.debug_clock->d) ? reinterpret_cast<unsigned long long*>(n.debug_clock->d) + (size_t)n.max_batch * 32 : nullptr;
     const int grid = a.n_rows < 256 ? a.n_rows : 256;
     if (b3) {
       for (int i = 0; i < 3; ++i) {

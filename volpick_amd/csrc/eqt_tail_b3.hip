@@ -180,6 +180,14 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
       for (int k = 0; k < 3; ++k) pre[k][r] = (k < 2 || tid + 2 * T3_NTH < 8 * PARK_COLS) ? row[pre_off[k]] : 0.f;
     }
   };
+  // the same request in twelve parts, one between the K-steps of stage 6 each: as one burst in front of the stage its twelve loads
+  // per wave held the stage up by ~0.9 k cycles (a wave issues in order; the same 0.9 k wherever the burst stands: tools/
+  // tail_clock.py, profiles/r06_g_eqt_tail_probes.txt), spread they cost 0.6 k
+  auto request_part = [&](const Tile3& t, const int q) {
+    const int r = q / 3, k = q - 3 * r;
+    const float* row = a.x3 + (long)t.win * a.ws3 + (HALO - 5 + t.t0 / 8) + (long)r * a.ls3;
+    pre[k][r] = (k < 2 || tid + 2 * T3_NTH < 8 * PARK_COLS) ? row[pre_off[k]] : 0.f;
+  };
   auto park = [&]() {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -254,7 +262,6 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
     }
     __syncthreads();
     T3_STAMP(3)
-    if (more) request(nid);  // travels under stage 6 and the heads
     {  // stage 6: column c reads the image columns c + tap; one m-tile: lane group g holds phase g / 2, channels 4 (g % 2) ..;
        // output t = 2 c + p = sample t0 - 6 + t of the row -> 8-byte unit (t % 16) * HSB + t / 16 of its quad's staging plane
       const int colb = w * (NB6 * 16), ph = g >> 1;
@@ -268,15 +275,26 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
         const int t = 2 * (colb + j * 16 + n) + ph;
         float v[4];
         t3_finish(acc, bias6, (unsigned)(t - lo) < (unsigned)T_OUT, v);
+        if (B3_EXP & 16) {
+          asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+          return;
+        }
         const unsigned h0 = pack_bf16x2(v[0], v[1]), h1 = pack_bf16x2(v[2], v[3]);
         const float r0 = v[0] - bf16_lo(h0), r1 = v[1] - bf16_hi(h0), r2 = v[2] - bf16_lo(h1), r3 = v[3] - bf16_hi(h1);
         const unsigned m0 = pack_bf16x2(r0, r1), m1 = pack_bf16x2(r2, r3);
         const unsigned l0 = pack_bf16x2(r0 - bf16_lo(m0), r1 - bf16_hi(m0)), l1 = pack_bf16x2(r2 - bf16_lo(m1), r3 - bf16_hi(m1));
+        if (B3_EXP & 4) {
+          asm volatile("" ::"v"(h0), "v"(h1), "v"(m0), "v"(m1), "v"(l0), "v"(l1), "v"(q));
+          return;
+        }
         q[2 * j] = make_uint2(h0, h1);
         q[2 * j + OUT_PS] = make_uint2(m0, m1);
         q[2 * j + 2 * OUT_PS] = make_uint2(l0, l1);
       };
-      b3c_mac_tiles<16, NC6, 7, NB6>(b3c_lane_ptr<16, NC6, 7>(IN6, colb, lane), a6, finish);
+      // (the next tile's stage-3 rows travel under stage 6 and the heads; the last tile asks for its own again)
+      b3c_mac_tiles<16, NC6, 7, NB6>(b3c_lane_ptr<16, NC6, 7>(IN6, colb, lane), a6, finish, [&](const int i) {
+        if (i < 12) request_part(nid, i);
+      });
     }
     __syncthreads();
     T3_STAMP(4)
