@@ -251,14 +251,16 @@ struct Res3A {
                                             const int k) {
     if (R3_EXP & 1) q[k / 3][k % 3] = make_uint4(0x3c003c00u + lane, 0x3c003c00u + k, 0x3c003c00u, 0x3c003c00u);  // no memory
     else q[k / 3][k % 3] = af[(long)mt * (TAPS * 2 * 3 * 64) + lane + k * 64];
-    if (k == 0) {
+    if (k == 0) {  // one 16-byte load per vector (the arrays are hipMalloc'ed, co is a multiple of four); s / sh are null for conv1 and
+                   // for the last block: uniform branches around the two loads
       const int co = mt * 16 + 4 * (lane >> 4);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        bias[r] = b[co + r];
-        sn[r] = s ? s[co + r] : 0.f;
-        bn[r] = sh ? sh[co + r] : 0.f;
-      }
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 vb = *reinterpret_cast<const float4*>(b + co);
+      const float4 vs = s ? *reinterpret_cast<const float4*>(s + co) : z;
+      const float4 vh = sh ? *reinterpret_cast<const float4*>(sh + co) : z;
+      bias[0] = vb.x, bias[1] = vb.y, bias[2] = vb.z, bias[3] = vb.w;
+      sn[0] = vs.x, sn[1] = vs.y, sn[2] = vs.z, sn[3] = vs.w;
+      bn[0] = vh.x, bn[1] = vh.y, bn[2] = vh.z, bn[3] = vh.w;
     }
   }
 };
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(256 * WPB) void eqt_res3_kernel(const Res3Args a) {
 template <int TAPS, int TN, bool CONV2, bool LAST, int NT, int Q0, class NextPart, class Stamp>
 __device__ __forceinline__ void res3t_conv(const bf16_t* src_all, bf16_t* dst_all, const Res3A<TAPS>& A, float (&X)[NT][4],
                                            NextPart next_part, const int lane, const int co, Stamp stamp) {
-  constexpr int IN_OFF = (TAPS == 3) ? -1 : 0, STEPS = TAPS * 2, SLOTS = NT * STEPS, AHEAD = 2, NBUF = AHEAD + 1;
+    constexpr int IN_OFF = (TAPS == 3) ? -1 : 0, STEPS = TAPS * 2, SLOTS = NT * STEPS, AHEAD = 2, NBUF = AHEAD + 1;  // (read-ahead 3 / 4: 104 / 108 k cycles against 101 k)
   constexpr int NL = TN * 2 * 3;  // fragments of the next conv's operand
   const int g = lane >> 4, n = lane & 15;
   const bf16_t* bp = src_all + g * R3_CHS + (n + IN_OFF + 1) * 8;
