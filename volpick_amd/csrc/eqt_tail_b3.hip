@@ -220,6 +220,8 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
     const bool more = next < a.n_tiles;
     const Tile3 nid = more ? tile3_id<TW>(next, a) : id;
     const int t0 = id.t0;
+    // the window's non-finite flag, read HERE: behind the heads' MFMAs its trip to L2 stood between the last MFMA and the stores
+    const float win_flag = a.flags ? a.flags[id.win - id.d * a.B] : 0.f;
     T3_STAMP(0)
     park();
     __syncthreads();
@@ -304,7 +306,8 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
       f32x4 acc = {bh, bh, bh, bh};
       const uint2* bp = OUT6 + (16 * w + n);
       const uint4* ap = HT + (g - n + 15);
-      uint4 av[2][3], bv[2][3];
+      constexpr int HD = 1, HB = HD + 1;  // K-steps of operands in flight ahead of the MFMAs (2 / 3 measured the same: 2.09 / 2.14 k cycles)
+      uint4 av[HB][3], bv[HB][3];
       auto load_ab = [&](const int s, uint4 (&aa)[3], uint4 (&bb)[3]) {
         const int e = 4 * s + g + 1, chunk = (e & 15) * HSB + (e >> 4);
 #pragma unroll
@@ -314,16 +317,17 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
           bb[pc] = make_uint4(c0.x, c0.y, c1.x, c1.y);
         }
       };
-      load_ab(0, av[0], bv[0]);
+#pragma unroll
+      for (int s = 0; s < HD && s < 7; ++s) load_ab(s, av[s % HB], bv[s % HB]);
 #pragma unroll
       for (int s = 0; s < 7; ++s) {
-        if (s + 1 < 7) load_ab(s + 1, av[(s + 1) & 1], bv[(s + 1) & 1]);
+        if (s + HD < 7) load_ab(s + HD, av[(s + HD) % HB], bv[(s + HD) % HB]);
         __builtin_amdgcn_sched_barrier(0);
         constexpr int WP[6] = {2, 1, 0, 1, 0, 0}, XP[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
         for (int t = 0; t < 6; ++t)
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, av[s & 1][WP[t]]),
-                                                       __builtin_bit_cast(bf16x8_b3, bv[s & 1][XP[t]]), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_b3, av[s % HB][WP[t]]),
+                                                       __builtin_bit_cast(bf16x8_b3, bv[s % HB][XP[t]]), acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       const int blk = 16 * w + n;
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(T3_NTH) void eqt_tail3_kernel(const Tail3Args a) {
         r.y = __builtin_amdgcn_rcpf(1.f + __expf(-acc[1]));
         r.z = __builtin_amdgcn_rcpf(1.f + __expf(-acc[2]));
         r.w = __builtin_amdgcn_rcpf(1.f + __expf(-acc[3]));
-        if (a.flags && a.flags[b] != 0.f) r.x = r.y = r.z = r.w = __builtin_nanf("");  // what launch_poison writes (prepost.h)
+        if (win_flag != 0.f) r.x = r.y = r.z = r.w = __builtin_nanf("");  // what launch_poison writes (prepost.h)
         *reinterpret_cast<float4*>(a.y + ((long)b * 3 + id.d) * T_OUT + t0 + 16 * blk + 4 * g) = r;
       }
     }
