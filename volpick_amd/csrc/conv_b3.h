@@ -410,8 +410,8 @@ __device__ __forceinline__ void b3c_mac_tiles(const bf16_t* p, const uint4 (&a)[
 
 // The same with the n-tiles taken in PAIRS whose MFMAs alternate: consecutive instructions never share an accumulator, so one
 // wave issues them back to back (a chain into one accumulator issues every 20-26 cycles from one wave, LOG.md).  NB even.
-template <int C, int NC, int TAPS, int NB, class Finish>
-__device__ __forceinline__ void b3c_mac_tile_pairs(const bf16_t* p, const uint4 (&a)[B3Steps<C, TAPS>::STEPS * 3], Finish finish) {
+template <int C, int NC, int TAPS, int NB, class Finish, class Slot = B3NoSlot>
+__device__ __forceinline__ void b3c_mac_tile_pairs(const bf16_t* p, const uint4 (&a)[B3Steps<C, TAPS>::STEPS * 3], Finish finish, Slot slot = Slot()) {
   using G = B3Steps<C, TAPS>;
   using Q = B3Chunk<C, NC>;
   static_assert(NB % 2 == 0, "pairs of n-tiles");
@@ -440,6 +440,7 @@ __device__ __forceinline__ void b3c_mac_tile_pairs(const bf16_t* p, const uint4 
     for (int s = 0; s < STEPS; ++s) {
       const int i = jp * STEPS + s;
       if (i + 1 < PAIRS) load_b(i + 1);
+      slot(i);
       constexpr int WP[6] = {2, 1, 0, 1, 0, 0}, XP[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
       for (int t = 0; t < 6; ++t) {

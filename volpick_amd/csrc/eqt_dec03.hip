@@ -263,15 +263,15 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
         // 3 pre-summed taps.  Every wave takes eight input channels -- weights requested here, used behind the conv -- and leaves
         // its partial sum in LDS (one wave doing all 64 kept the other seven at the barrier for 10 k cycles per row).
         constexpr int n0 = (L3 - 2 - 2) >> 1;
-        float ew[8][3];
+        // (Round 6: the 24 weights of a lane as eight 12-byte loads between the K-steps of the conv below -- as 24 4-byte loads in
+        // front of it they held its MFMAs up, 192 requests per workgroup; and the edge sum reads its nine fragments as 16-byte
+        // LDS words, not 72 2-byte ones.  Same products, same order of the sum: bit-identical.)
+        struct F3 {
+          float x, y, z;
+        };
+        F3 ew[8];
         eb = a.edge_b[d * 32 + (lane >> 1)];  // used behind the next barrier: requested here, or its wait there covers the operand loads too
-        {
-          const float* e = a.edge_w + ((long)d * 64 * 64 + lane) * 3 + (long)(8 * wave_u) * 64 * 3;
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) ew[u][k] = e[u * 64 * 3 + k];
-        }
+        const F3* e = reinterpret_cast<const F3*>(a.edge_w + ((long)d * 64 * 64 + lane) * 3 + (long)(8 * wave_u) * 64 * 3);
         const ClipQuad st{X3, L3 - 2};
         {  // wave = (m-tile w % 4: phase mt / 2, channels 16 (mt % 2) ..; block w / 4 of six n-tiles), operand in registers
           const int mt2 = wave_u & 3, ph = mt2 >> 1, co0 = (mt2 & 1) * 16 + 4 * g, colb = (wave_u >> 2) * 96;
@@ -283,17 +283,35 @@ __global__ __launch_bounds__(D03_NTH) void eqt_dec03_kernel(const Dec03Args a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[r] + bias2[r], 0.f);
             st.quad(co0, 2 * (colb + j * 16 + n) + ph, v);
+          }, [&](const int i) {  // 18 slots: a weight triple every other one
+            if (i % 2 == 0 && i / 2 < 8) ew[i / 2] = e[(i / 2) * 64];
           });
         }
         D3_STAMP()  // 6: stage 2's MFMAs issued (this wave)
         float pacc = 0.f;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const bf16_t* xs = X2 + wave_u * QX2::CHS + (n0 + 1) * 8 + u;  // channel 8 w + u = chunk w
+        {
+          // x[k][u] = channel 8 w + u (chunk w) at column n0 + 1 + k: the sum of its three pieces, exact; a 16-byte word = the eight
+          // channels of one piece at one column, channel 2 i in the low half of dword i
+          float xk[3][8];
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
-            const float x = (from_bf16(xs[k * 8]) + from_bf16(xs[k * 8 + QX2::PS])) + from_bf16(xs[k * 8 + 2 * QX2::PS]);  // exact
-            pacc = fmaf(ew[u][k], x, pacc);
+            uint4 q[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) q[pc] = *reinterpret_cast<const uint4*>(X2 + pc * QX2::PS + wave_u * QX2::CHS + (n0 + 1 + k) * 8);
+            const unsigned* qh = reinterpret_cast<const unsigned*>(&q[0]);
+            const unsigned* qm = reinterpret_cast<const unsigned*>(&q[1]);
+            const unsigned* ql = reinterpret_cast<const unsigned*>(&q[2]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              xk[k][2 * i] = (bf16_lo(qh[i]) + bf16_lo(qm[i])) + bf16_lo(ql[i]);
+              xk[k][2 * i + 1] = (bf16_hi(qh[i]) + bf16_hi(qm[i])) + bf16_hi(ql[i]);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            pacc = fmaf(ew[u].x, xk[0][u], pacc);
+            pacc = fmaf(ew[u].y, xk[1][u], pacc);
+            pacc = fmaf(ew[u].z, xk[2][u], pacc);
           }
         }
         EDGE[wave_u * 64 + lane] = pacc;
