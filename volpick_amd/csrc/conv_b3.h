@@ -115,10 +115,12 @@ struct B3BlockStore : B3Store<C> {
 
 // The conv.  L = LdsLayer (conv_lds.h) with CIN1, CIN2 multiples of 32; MPERM: GEMM rows ordered (phase, channel).
 // Items = (m-tile, block of NB n-tiles); wave w takes items w, w + nwaves, ...
-template <class L, bool MPERM, int C1, int C2, class Store, int PF_ = 3>
-__device__ __forceinline__ void conv_b3(const B3Image<C1> i1, const B3Image<C2> i2, const uint4* __restrict__ af3,
-                                        const float* __restrict__ bias, const int cols, const Store store, const int wave,
-                                        const int nwaves, const int lane) {
+// PRE: the first PF K-steps of the wave's FIRST item are already on their way into q (conv_b3_request, called in front of the
+// barrier that precedes this layer: a layer's first fragments otherwise make their trip to L2 with all sixteen waves waiting).
+template <class L, bool MPERM, int C1, int C2, class Store, int PF_, bool PRE>
+__device__ __forceinline__ void conv_b3_impl(const B3Image<C1> i1, const B3Image<C2> i2, const uint4* __restrict__ af3,
+                                             const float* __restrict__ bias, const int cols, const Store store, const int wave,
+                                             const int nwaves, const int lane, uint4 (&q)[PF_ + 1][3]) {
   static_assert(L::CIN1 % 32 == 0 && L::CIN2 % 32 == 0 && L::CIN1 == C1 && (L::CIN2 == 0 || L::CIN2 == C2), "32-channel K-steps");
   static_assert(MPERM || L::P == 1, "multi-phase layers order their rows (phase, channel)");
   constexpr int KS1 = L::CIN1 / 32, KS = (L::CIN1 + L::CIN2) / 32, STEPS = L::TAPS * KS, NB = L::NB;
@@ -137,13 +139,14 @@ __device__ __forceinline__ void conv_b3(const B3Image<C1> i1, const B3Image<C2> 
 #pragma unroll
     for (int r = 0; r < 4; ++r) biasv[r] = bias[co0 + r];
     const uint4* ap = af3 + (long)mt * (STEPS * 3 * 64) + lane;
-    uint4 q[PF + 1][3];  // A pieces of K-steps s .. s + PF
-    auto load_a = [&](const int s) {
+    auto load_a = [&](const int s) {  // q: A pieces of K-steps s .. s + PF
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc) q[s % (PF + 1)][pc] = ap[(s * 3 + pc) * 64];
     };
+    if (!(PRE && item == wave)) {  // (uniform)
 #pragma unroll
-    for (int s = 0; s < PF && s < STEPS; ++s) load_a(s);
+      for (int s = 0; s < PF && s < STEPS; ++s) load_a(s);
+    }
     // B: the (K-step, n-tile) pairs as one sequence, the fragment of pair i + 1 read before the MFMAs of pair i
     uint4 b[2][3];
     auto load_b = [&](uint4 (&bv)[3], const int s, const int j) {
@@ -191,24 +194,54 @@ __device__ __forceinline__ void conv_b3(const B3Image<C1> i1, const B3Image<C2> 
   }
 }
 
+template <class L, bool MPERM, int C1, int C2, class Store, int PF_ = 3>
+__device__ __forceinline__ void conv_b3(const B3Image<C1> i1, const B3Image<C2> i2, const uint4* __restrict__ af3,
+                                        const float* __restrict__ bias, const int cols, const Store store, const int wave,
+                                        const int nwaves, const int lane) {
+  uint4 q[PF_ + 1][3];
+  conv_b3_impl<L, MPERM, C1, C2, Store, PF_, false>(i1, i2, af3, bias, cols, store, wave, nwaves, lane, q);
+}
+// the first PF K-steps of the wave's first item of layer L, requested ahead (same item order as conv_b3: item = wave)
+template <class L, int PF_ = 3>
+__device__ __forceinline__ void conv_b3_request(const uint4* __restrict__ af3, const int cols, const int wave, const int lane,
+                                                uint4 (&q)[PF_ + 1][3]) {
+  constexpr int KS = (L::CIN1 + L::CIN2) / 32, STEPS = L::TAPS * KS, MT = L::M / 16;
+  const int NT = (cols + 15) >> 4, NBLK = (NT + L::NB - 1) / L::NB, items = MT * NBLK;
+  if (wave < items) {
+    const uint4* ap = af3 + (long)(wave % MT) * (STEPS * 3 * 64) + lane;
+#pragma unroll
+    for (int s = 0; s < PF_ && s < STEPS; ++s)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) q[s % (PF_ + 1)][pc] = ap[(s * 3 + pc) * 64];
+  }
+}
+template <class L, bool MPERM, int C1, int C2, class Store, int PF_ = 3>
+__device__ __forceinline__ void conv_b3_requested(const B3Image<C1> i1, const B3Image<C2> i2, const uint4* __restrict__ af3,
+                                                  const float* __restrict__ bias, const int cols, const Store store, const int wave,
+                                                  const int nwaves, const int lane, uint4 (&q)[PF_ + 1][3]) {
+  conv_b3_impl<L, MPERM, C1, C2, Store, PF_, true>(i1, i2, af3, bias, cols, store, wave, nwaves, lane, q);
+}
+
 // ---- a concat layer whose two inputs cannot rest in LDS as piece images at the same time (PhaseNet up1.same) ------------------
 // One item (m-tile mt, NB n-tiles from column colb) per wave, its accumulators carried across calls: the K-steps of ONE
 // 32-channel step `KSTEP` of the concatenated input (all taps) from the image `im` that holds those channels.
-template <class L, int KSTEP, int NB>
-__device__ __forceinline__ void conv_b3_part(const B3Image<32> im, const uint4* __restrict__ af3, const int mt, const int colb,
-                                             const int lane, f32x4 (&acc)[NB]) {
+// (PRE: the first three taps' fragments were requested ahead into q by conv_b3_part_request, in front of a barrier)
+template <class L, int KSTEP, int NB, bool PRE>
+__device__ __forceinline__ void conv_b3_part_impl(const B3Image<32> im, const uint4* __restrict__ af3, const int mt, const int colb,
+                                                  const int lane, f32x4 (&acc)[NB], uint4 (&q)[4][3]) {
   static_assert(L::P == 1 && L::SN == 1 && (L::CIN1 + L::CIN2) % 32 == 0, "plain unit-stride conv, 32-channel K-steps");
   constexpr int KS = (L::CIN1 + L::CIN2) / 32, STEPS = L::TAPS * KS, PF = 3;
   static_assert(KSTEP < KS, "channel step of the concat");
   const int g = lane >> 4, n = lane & 15;
   const uint4* ap = af3 + (long)mt * (STEPS * 3 * 64) + lane;
-  uint4 q[PF + 1][3];
   auto load_a = [&](const int tap) {
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) q[tap % (PF + 1)][pc] = ap[((tap * KS + KSTEP) * 3 + pc) * 64];
   };
+  if (!PRE) {
 #pragma unroll
-  for (int tap = 0; tap < PF && tap < L::TAPS; ++tap) load_a(tap);
+    for (int tap = 0; tap < PF && tap < L::TAPS; ++tap) load_a(tap);
+  }
   uint4 b[2][3];
   auto load_b = [&](uint4 (&bv)[3], const int tap, const int j) {
     const bf16_t* p = im.img + (colb + j * 16 + n + tap + L::IN_OFF + im.c0) * 40 + 8 * g;
@@ -232,6 +265,27 @@ __device__ __forceinline__ void conv_b3_part(const B3Image<32> im, const uint4* 
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+}
+
+template <class L, int KSTEP, int NB>
+__device__ __forceinline__ void conv_b3_part(const B3Image<32> im, const uint4* __restrict__ af3, const int mt, const int colb,
+                                             const int lane, f32x4 (&acc)[NB]) {
+  uint4 q[4][3];
+  conv_b3_part_impl<L, KSTEP, NB, false>(im, af3, mt, colb, lane, acc, q);
+}
+template <class L, int KSTEP>
+__device__ __forceinline__ void conv_b3_part_request(const uint4* __restrict__ af3, const int mt, const int lane, uint4 (&q)[4][3]) {
+  constexpr int KS = (L::CIN1 + L::CIN2) / 32, STEPS = L::TAPS * KS, PF = 3;
+  const uint4* ap = af3 + (long)mt * (STEPS * 3 * 64) + lane;
+#pragma unroll
+  for (int tap = 0; tap < PF && tap < L::TAPS; ++tap)
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) q[tap % (PF + 1)][pc] = ap[((tap * KS + KSTEP) * 3 + pc) * 64];
+}
+template <class L, int KSTEP, int NB>
+__device__ __forceinline__ void conv_b3_part_requested(const B3Image<32> im, const uint4* __restrict__ af3, const int mt, const int colb,
+                                                       const int lane, f32x4 (&acc)[NB], uint4 (&q)[4][3]) {
+  conv_b3_part_impl<L, KSTEP, NB, true>(im, af3, mt, colb, lane, acc, q);
 }
 
 // 4 x 4 transpose between a lane's four registers and the four 16-lane rows of the wavefront: afterwards v[k] of row g holds what
