@@ -1048,10 +1048,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
   const bool vstore = tid < W0_Q;            // lanes whose float4 lies inside an image row (751..755 store the zero margin)
   const bool own = tid < W_LANES;            // lanes holding signal samples
 
-#ifndef PN_HOIST
-#define PN_HOIST 0
-#endif
-  // PN_HOIST: every layer's first fragments are requested in front of the barrier BEFORE the layer (a layer's operand request
+  // Round 6: every layer's first fragments are requested in front of the barrier BEFORE the layer (a layer's operand request
   // otherwise makes its trip to L2 with all sixteen waves waiting for it: 1.1 k cycles in front of down2.same, 2.9 k in front of
   // up0.convT -- tools/core_clock.py, profiles/r06_j_*)
   [[maybe_unused]] uint4 aw1[B3Steps<8, 7>::STEPS * 3];  // down1.same's operand
@@ -1450,7 +1447,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
     }
     }
     if constexpr (D12B) {
-      if (PN_HOIST) b3_load_a<8, 7>(a.af3_d12[0], 0, lane, aw1);
+      b3_load_a<8, 7>(a.af3_d12[0], 0, lane, aw1);
     }
     lds_barrier();  // not __syncthreads(): the skip rows drain to memory under the first core layers
     WIN_STAMP(22)
@@ -1493,7 +1490,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
     {  // down1.same: one m-tile, 47 n-tiles: three per wave
       zero_halo<16, S1_, T1, IB>(lds + A_SKIP1, tid, NTH);
       auto& aw = aw1;
-      if (!PN_HOIST) b3_load_a<8, 7>(a.af3_d12[0], 0, lane, aw);
       float biasv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) biasv[r] = a.c.bs[0][4 * g + r];
@@ -1509,7 +1505,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
       CORE_WIN_STAMP(stamp)
       ++stamp;
     }
-    [[maybe_unused]] uint4 aw2[B3Steps<16, 7>::STEPS * 3];  // down2.same's operand (PN_HOIST: requested a layer ahead, under down1.down)
+    [[maybe_unused]] uint4 aw2[B3Steps<16, 7>::STEPS * 3];  // down2.same's operand (requested a layer ahead, behind down1.down's MFMAs)
     {  // down1.down (fp32 MFMA, strided) -> piece image
       const B3BlockStoreC<16, B3_D1_NC> st{iD1, 3, T2};
       b3c_zero_rest<16, B3_D1_NC>(iD1, 3, 3 + 192, tid, NTH);
@@ -1518,9 +1514,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
       } else {
         conv_lds<C_d1down, S1_, IB, S1_, IB, PIPE, (C_d1down::NB < BDB_MAX_NB), ADEEP_LAYER(C_d1down)>(lds + A_SKIP1, lds + A_SKIP1, a.c.af[1], a.c.bs[1], T2, st, wave, NWV, lane);
       }
-      if (PN_HOIST && wave < 8) b3_load_a<16, 7>(a.af3_d12[1], wave & 1, lane, aw2);  // travels under the barrier wait
-      if (PN_HOIST) lds_barrier();  // not __syncthreads(): it would wait for the request just made
-      else __syncthreads();
+      if (wave < 8) b3_load_a<16, 7>(a.af3_d12[1], wave & 1, lane, aw2);  // travels under the barrier wait
+      lds_barrier();  // not __syncthreads(): it would wait for the request just made
       CORE_WIN_STAMP(stamp)
       ++stamp;
     }
@@ -1529,7 +1524,6 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
       if (wave < 8) {
         const int mt = wave & 1, colb = (wave >> 1) * 48;
         auto& aw = aw2;
-        if (!PN_HOIST) b3_load_a<16, 7>(a.af3_d12[1], mt, lane, aw);
         float biasv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) biasv[r] = a.c.bs[2][mt * 16 + 4 * g + r];
@@ -1550,7 +1544,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
   CORE_LAYER(1, C_d1down, A_SKIP1, S1_, A_SKIP1, S1_, IB, A_D1, S2_, IB, RangeStoreS, 16, T2, T2)
   CORE_LAYER(2, C_d2same, A_D1, S2_, A_D1, S2_, IB, A_SKIP2, S2_, IB, RangeStoreS, 32, T2, T2)
   }
-  [[maybe_unused]] uint4 q_u1t[4][3];  // up1.convT's first fragments (PN_HOIST: requested under up0.same's closing barrier)
+  [[maybe_unused]] uint4 q_u1t[4][3];  // up1.convT's first fragments (requested under up0.same's closing barrier)
   [[maybe_unused]] uint4 q_u1s[4][3];  // up1.same's, either K half
   [[maybe_unused]] uint4 aT2[B3Steps<32, 2>::STEPS * 3];  // up2.convT's operand
   [[maybe_unused]] uint4 aw_u2[B3Steps<16, 7>::STEPS * 3];  // up2.same's first operand (the K half of up2.convT's channels)
@@ -1561,64 +1555,57 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
     const B3Image<64> iSK3{l16 + B3_SK3_OFF, B3_SK3_PS, 3}, iD3{l16 + A_R * 2, B3_D3_PS, 3}, iU0T{l16 + A_R * 2 + (U3B ? B3_U0T_SHIFT : 0), B3_U0T_PS, 3};
     const B3Image<128> iBOT{l16 + A_Q * 2, B3_BOT_PS, 1};
 #define B3_END          \
-  if (PN_HOIST) lds_barrier(); /* not __syncthreads(): the next layer's first fragments are in flight */ \
-  else __syncthreads(); \
+  lds_barrier(); /* not __syncthreads(): the next layer's first fragments are in flight */ \
   CORE_WIN_STAMP(stamp)      \
   ++stamp;
-    // PN_HOIST: the first K-steps of every layer's first item are requested in front of the barrier BEFORE the layer
+    // the first K-steps of every layer's first item are requested in front of the barrier BEFORE the layer
     // (conv_b3_request): a layer's first fragments otherwise make their trip to L2 with all sixteen waves waiting
     [[maybe_unused]] uint4 q_d3s[4][3], q_d3d[4][3], q_d4s[4][3], q_u0t[4][3], q_u0s[3][3];
     {  // down2.down (fp32 MFMA, strided) -> three-piece image
       B3BlockStore<32> st{{iD2.img, iD2.ps, iD2.c0, T3, B3_D2_NC}};
       st.zero_rest(3, 3 + 48, tid, NTH);
       conv_lds_q4<C_d2down, S2_, IB, S2_, IB>(lds + A_SKIP2, lds + A_SKIP2, a.af4[3], a.c.bs[3], T3, st, wave, NWV, lane);
-      if (PN_HOIST) conv_b3_request<C_d3same>(a.af3[0], T3, wave, lane, q_d3s);
+      conv_b3_request<C_d3same>(a.af3[0], T3, wave, lane, q_d3s);
       B3_END
     }
     {  // down3.same
       B3Store<64> st{iSK3.img, iSK3.ps, iSK3.c0, T3, B3_SK3_NC};
       st.zero_rest(3, 3 + 48, tid, NTH);
-      if (PN_HOIST) conv_b3_requested<C_d3same, false, 32, 32>(iD2, iD2, a.af3[0], a.c.bs[4], T3, st, wave, NWV, lane, q_d3s);
-      else conv_b3<C_d3same, false, 32, 32>(iD2, iD2, a.af3[0], a.c.bs[4], T3, st, wave, NWV, lane);
-      if (PN_HOIST) conv_b3_request<C_d3down>(a.af3[1], T4, wave, lane, q_d3d);
+      conv_b3_requested<C_d3same, false, 32, 32>(iD2, iD2, a.af3[0], a.c.bs[4], T3, st, wave, NWV, lane, q_d3s);
+      conv_b3_request<C_d3down>(a.af3[1], T4, wave, lane, q_d3d);
       B3_END
     }
     {  // down3.down
       B3Store<64> st{iD3.img, iD3.ps, iD3.c0, T4, B3_D3_NC};
       st.zero_rest(3, 3 + 16, tid, NTH);
-      if (PN_HOIST) conv_b3_requested<C_d3down, false, 64, 64>(iSK3, iSK3, a.af3[1], a.c.bs[5], T4, st, wave, NWV, lane, q_d3d);
-      else conv_b3<C_d3down, false, 64, 64>(iSK3, iSK3, a.af3[1], a.c.bs[5], T4, st, wave, NWV, lane);
-      if (PN_HOIST) conv_b3_request<C_d4same>(a.af3[2], T4, wave, lane, q_d4s);
+      conv_b3_requested<C_d3down, false, 64, 64>(iSK3, iSK3, a.af3[1], a.c.bs[5], T4, st, wave, NWV, lane, q_d3d);
+      conv_b3_request<C_d4same>(a.af3[2], T4, wave, lane, q_d4s);
       B3_END
     }
     {  // down4.same
       B3Store<128> st{iBOT.img, iBOT.ps, iBOT.c0, T4, B3_BOT_NC};
       st.zero_rest(1, 1 + 16, tid, NTH);
-      if (PN_HOIST) conv_b3_requested<C_d4same, false, 64, 64>(iD3, iD3, a.af3[2], a.c.bs[6], T4, st, wave, NWV, lane, q_d4s);
-      else conv_b3<C_d4same, false, 64, 64>(iD3, iD3, a.af3[2], a.c.bs[6], T4, st, wave, NWV, lane);
-      if (PN_HOIST) conv_b3_request<C_u0T>(a.af3[3], T4 + 1, wave, lane, q_u0t);
+      conv_b3_requested<C_d4same, false, 64, 64>(iD3, iD3, a.af3[2], a.c.bs[6], T4, st, wave, NWV, lane, q_d4s);
+      conv_b3_request<C_u0T>(a.af3[3], T4 + 1, wave, lane, q_u0t);
       B3_END
     }
     {  // up0.convT: rows ordered (phase, channel); samples 4 c + phase - 1, columns c in [0, 16)
       B3Store<64> st{iU0T.img, iU0T.ps, iU0T.c0, T3, B3_U0T_NC};
       st.zero_rest(2, B3_U0T_NC, tid, NTH);
-      if (PN_HOIST) conv_b3_requested<C_u0T, true, 128, 128>(iBOT, iBOT, a.af3[3], a.c.bs[7], T4 + 1, st, wave, NWV, lane, q_u0t);
-      else conv_b3<C_u0T, true, 128, 128>(iBOT, iBOT, a.af3[3], a.c.bs[7], T4 + 1, st, wave, NWV, lane);
-      if (PN_HOIST) conv_b3_request<C_u0same, 2>(a.af3[4], T3, wave, lane, q_u0s);
+      conv_b3_requested<C_u0T, true, 128, 128>(iBOT, iBOT, a.af3[3], a.c.bs[7], T4 + 1, st, wave, NWV, lane, q_u0t);
+      conv_b3_request<C_u0same, 2>(a.af3[4], T3, wave, lane, q_u0s);
       B3_END
     }
     if constexpr (U3B) {  // up0.same: cat(skip 3, up0.convT) -> three-piece image for up1.convT
       B3Store<64> st{l16 + A_Q * 2, B3_U0S_PS, 1, T3, B3_U0S_NC};
       st.zero_rest(1, 1 + 48, tid, NTH);
-      if (PN_HOIST) conv_b3_requested<C_u0same, false, 64, 64, decltype(st), 2>(iSK3, iU0T, a.af3[4], a.c.bs[8], T3, st, wave, NWV, lane, q_u0s);
-      else conv_b3<C_u0same, false, 64, 64, decltype(st), 2>(iSK3, iU0T, a.af3[4], a.c.bs[8], T3, st, wave, NWV, lane);
-      if (PN_HOIST && U1B) conv_b3_request<C_u1T>(a.af3_uT[0], T3 + 1, wave, lane, q_u1t);
+      conv_b3_requested<C_u0same, false, 64, 64, decltype(st), 2>(iSK3, iU0T, a.af3[4], a.c.bs[8], T3, st, wave, NWV, lane, q_u0s);
+      if (U1B) conv_b3_request<C_u1T>(a.af3_uT[0], T3 + 1, wave, lane, q_u1t);
       B3_END
     } else {  // up0.same: cat(skip 3, up0.convT) -> fp32 image for up1.convT
       F32QuadStore<S3_, IB> st{lds + X_U0S, T3};
       zero_halo<64, S3_, T3, IB>(lds + X_U0S, tid, NTH);
-      if (PN_HOIST) conv_b3_requested<C_u0same, false, 64, 64, decltype(st), 2>(iSK3, iU0T, a.af3[4], a.c.bs[8], T3, st, wave, NWV, lane, q_u0s);
-      else conv_b3<C_u0same, false, 64, 64, decltype(st), 2>(iSK3, iU0T, a.af3[4], a.c.bs[8], T3, st, wave, NWV, lane);
+      conv_b3_requested<C_u0same, false, 64, 64, decltype(st), 2>(iSK3, iU0T, a.af3[4], a.c.bs[8], T3, st, wave, NWV, lane, q_u0s);
       B3_END
     }
 #undef B3_END
@@ -1636,11 +1623,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
       const B3Image<64> iU0S{reinterpret_cast<bf16_t*>(lds) + A_Q * 2, B3_U0S_PS, 1};
       B3Store<32> st{iP.img, iP.ps, iP.c0, T2, B3_U1_NC};
       st.zero_rest(2, 2 + 192, tid, NTH);
-      if (PN_HOIST) conv_b3_requested<C_u1T, true, 64, 64>(iU0S, iU0S, a.af3_uT[0], a.c.bs[9], T3 + 1, st, wave, NWV, lane, q_u1t);
-      else conv_b3<C_u1T, true, 64, 64>(iU0S, iU0S, a.af3_uT[0], a.c.bs[9], T3 + 1, st, wave, NWV, lane);
-      if (PN_HOIST && wave < 8) conv_b3_part_request<C_u1same, 1>(a.af3[5], wave & 1, lane, q_u1s);
-      if (PN_HOIST) lds_barrier();
-      else __syncthreads();
+      conv_b3_requested<C_u1T, true, 64, 64>(iU0S, iU0S, a.af3_uT[0], a.c.bs[9], T3 + 1, st, wave, NWV, lane, q_u1t);
+      if (wave < 8) conv_b3_part_request<C_u1same, 1>(a.af3[5], wave & 1, lane, q_u1s);
+      lds_barrier();
       CORE_WIN_STAMP(stamp)
       ++stamp;
     } else {  // up1.convT (fp32 MFMA, 8 m-tiles x 1 block) -> three-piece image
@@ -1663,21 +1648,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
       const int mt = wave & 1, colb = (wave >> 1) * 48;
       f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
       if (wave < 8) {
-        if (PN_HOIST && U3B) conv_b3_part_requested<C_u1same, 1, 3>(iP, a.af3[5], mt, colb, lane, acc, q_u1s);
+        if (U3B) conv_b3_part_requested<C_u1same, 1, 3>(iP, a.af3[5], mt, colb, lane, acc, q_u1s);
         else conv_b3_part<C_u1same, 1, 3>(iP, a.af3[5], mt, colb, lane, acc);
-        if (PN_HOIST) conv_b3_part_request<C_u1same, 0>(a.af3[5], mt, lane, q_u1s);  // the second half's first taps: under the refill
+        conv_b3_part_request<C_u1same, 0>(a.af3[5], mt, lane, q_u1s);  // the second half's first taps: under the refill
       }
-      if (PN_HOIST) lds_barrier();
-      else __syncthreads();  // every wave is through with up1.convT's pieces
+      lds_barrier();
       b3_from_f32<S2_, IB>(lds + A_SKIP2, iP, -3, B3_U1_NC - 3, tid, NTH);
-      if (PN_HOIST) lds_barrier();
-      else __syncthreads();
+      lds_barrier();
       if constexpr (U3B) {
         if (wave >= 8) b3c_zero_rest<32, B3_U1S_NC>(iU1S, 1, 193, tid - 512, NTH - 512);
       }
       if (wave < 8) {
-        if (PN_HOIST) conv_b3_part_requested<C_u1same, 0, 3>(iP, a.af3[5], mt, colb, lane, acc, q_u1s);
-        else conv_b3_part<C_u1same, 0, 3>(iP, a.af3[5], mt, colb, lane, acc);
+        conv_b3_part_requested<C_u1same, 0, 3>(iP, a.af3[5], mt, colb, lane, acc, q_u1s);
         const int co0 = mt * 16 + 4 * (lane >> 4);
         float biasv[4];
 #pragma unroll
@@ -1697,9 +1679,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
         }
       }
       if constexpr (U3B) {
-        if (PN_HOIST) b3_load_a<32, 2>(a.af3_uT[1], wave & 3, lane, aT2);
+        b3_load_a<32, 2>(a.af3_uT[1], wave & 3, lane, aT2);
       }
-      if (PN_HOIST && U3B) lds_barrier();
+      if (U3B) lds_barrier();
       else __syncthreads();
       CORE_WIN_STAMP(stamp)
       ++stamp;
@@ -1714,7 +1696,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
     b3c_zero_rest<16, U2_NC>(P2, 3, 3 + T1, tid, NTH);
     const int mt = wave & 3, colb = (wave >> 2) * 48, g = lane >> 4, n = lane & 15;
     auto& aT = aT2;
-    if (!(PN_HOIST && B3 && U1B)) b3_load_a<32, 2>(a.af3_uT[1], mt, lane, aT);
+    if (!(B3 && U1B)) b3_load_a<32, 2>(a.af3_uT[1], mt, lane, aT);
     float biasv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) biasv[r] = a.c.bs[11][4 * g + r];
@@ -1726,9 +1708,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
       if ((unsigned)t < (unsigned)T1) b3c_store4<16, U2_NC>(P2, t + 3, g, v);
     });
     if constexpr (U3T) {
-      if (PN_HOIST) b3_load_a<16, 7>(a.af3_u2[1], 0, lane, aw_u2);
+      b3_load_a<16, 7>(a.af3_u2[1], 0, lane, aw_u2);
     }
-    if (PN_HOIST && U3T) lds_barrier();
+    if (U3T) lds_barrier();
     else __syncthreads();
     CORE_WIN_STAMP(stamp)
     ++stamp;
@@ -1796,7 +1778,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(60))) void pn_
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       auto& aw = aw_u2;
-      if (!(PN_HOIST && U3B)) b3_load_a<16, 7>(a.af3_u2[1], 0, lane, aw);
+      if (!U3B) b3_load_a<16, 7>(a.af3_u2[1], 0, lane, aw);
       b3c_mac_tiles_acc<16, U2_NC, 7, 3>(bp, aw, acc);
       b3_load_a<16, 7>(a.af3_u2[0], 0, lane, aw);  // on its way under the refill
       __syncthreads();
