@@ -302,10 +302,12 @@ __device__ __forceinline__ void conv_lds(const float* in1, const float* in2, con
 // s = cb * TAPS + tap grouped in fours: [MT][CB * TAPS / 4][64 lanes][4].  A "superblock" is four channel blocks
 // (4 * TAPS K-steps = TAPS loads per lane); the loads of superblock sb + 1 are issued before the MFMAs of sb, and the B
 // fragments run one K-step ahead in two register sets under pinned order (as the deep path of conv_lds).
-template <class L, int S1, int B1, int S2, int B2, class Store>
-__device__ __forceinline__ void conv_lds_q4(const float* in1, const float* in2, const float* __restrict__ afrag4,
-                                            const float* __restrict__ bias, const int cols, Store store, const int wave,
-                                            const int nwaves, const int lane) {
+// PRE: superblock 0 of the wave's FIRST item is already on its way into qa (conv_lds_q4_request, called in front of the barrier
+// that precedes this layer: the layer's first fragments otherwise make their trip to L2 with every wave of the workgroup waiting).
+template <class L, int S1, int B1, int S2, int B2, class Store, bool PRE>
+__device__ __forceinline__ void conv_lds_q4_impl(const float* in1, const float* in2, const float* __restrict__ afrag4,
+                                                 const float* __restrict__ bias, const int cols, Store store, const int wave,
+                                                 const int nwaves, const int lane, f32x4 (&qa)[L::TAPS]) {
   static_assert(L::CB % 4 == 0 && L::CB1 % 4 == 0, "superblocks of four channel blocks");
   constexpr int NQ = L::TAPS, SB_STEPS = 4 * L::TAPS, NSB = L::CB / 4;
   const int NT = (cols + 15) >> 4;
@@ -358,8 +360,8 @@ __device__ __forceinline__ void conv_lds_q4(const float* in1, const float* in2, 
     };
     static_assert(L::CIN2 == 0 || S1 == S2, "both images share the row stride");
     static_assert(SB_STEPS % 2 == 0, "the B sets alternate per K-step");
-    f32x4 qa[NQ], qb[NQ];
-    load_q(qa, 0);
+    f32x4 qb[NQ];
+    if (!(PRE && item == wave)) load_q(qa, 0);  // (uniform)
     load_b(bA, bptr(0), 0);
 #pragma unroll 1
     for (int sb = 0; sb < NSB; sb += 2) {
@@ -372,6 +374,30 @@ __device__ __forceinline__ void conv_lds_q4(const float* in1, const float* in2, 
     }
     lds_epilogue<L>(acc, biasv, mt, colb, g, n, store);
   }
+}
+template <class L, int S1, int B1, int S2, int B2, class Store>
+__device__ __forceinline__ void conv_lds_q4(const float* in1, const float* in2, const float* __restrict__ afrag4,
+                                            const float* __restrict__ bias, const int cols, Store store, const int wave,
+                                            const int nwaves, const int lane) {
+  f32x4 qa[L::TAPS];
+  conv_lds_q4_impl<L, S1, B1, S2, B2, Store, false>(in1, in2, afrag4, bias, cols, store, wave, nwaves, lane, qa);
+}
+// superblock 0 of the wave's first item of layer L, requested ahead (same item order as conv_lds_q4: item = wave)
+template <class L>
+__device__ __forceinline__ void conv_lds_q4_request(const float* __restrict__ afrag4, const int cols, const int wave, const int lane,
+                                                    f32x4 (&qa)[L::TAPS]) {
+  const int NT = (cols + 15) >> 4, NBLK = (NT + L::NB - 1) / L::NB, items = L::MT * NBLK;
+  if (wave < items) {
+    const f32x4* ap = reinterpret_cast<const f32x4*>(afrag4) + (long)(wave % L::MT) * (L::CB * L::TAPS / 4) * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < L::TAPS; ++k) qa[k] = ap[k * 64];
+  }
+}
+template <class L, int S1, int B1, int S2, int B2, class Store>
+__device__ __forceinline__ void conv_lds_q4_requested(const float* in1, const float* in2, const float* __restrict__ afrag4,
+                                                      const float* __restrict__ bias, const int cols, Store store, const int wave,
+                                                      const int nwaves, const int lane, f32x4 (&qa)[L::TAPS]) {
+  conv_lds_q4_impl<L, S1, B1, S2, B2, Store, true>(in1, in2, afrag4, bias, cols, store, wave, nwaves, lane, qa);
 }
 
 // Store functor: LDS image with a valid range [lo, hi) in the caller's local coordinates and a
