@@ -173,7 +173,7 @@ def test_compact_line_from_round_6_detail_stays_under_four_kilobytes():
     train / mseed objects from their child processes): still < 4 KB, strict JSON, the new keys present."""
     import json
 
-    full = json.loads((Path(__file__).resolve().parents[1] / "profiles" / "r06_i_bench_detail.json").read_text())
+    full = json.loads((Path(__file__).resolve().parents[1] / "profiles" / "r06_k_bench_detail.json").read_text())
     line = bench.compact_line(full, "bench_detail.json")
     assert "\n" not in line and len(line) < 4096
     d = json.loads(line, parse_constant=lambda c: (_ for _ in ()).throw(AssertionError(f"non-strict JSON constant {c}")))
